@@ -1,0 +1,109 @@
+/*
+ * mesh_raster.h -- C ABI of the MI355X (gfx950) differentiable mesh rasterizer.
+ *
+ * Drop-in boundary for the reference's one native module, the pybind11
+ * extension `rasterize_triangles_cpp`
+ *   (src/mesh_renderer/kernels/rasterize_triangles.cpp:421-424), whose only
+ * caller is BarycentricRasterizer (src/mesh_renderer/rasterize_triangles_ext.py
+ * :39-40 forward, :56-61 backward).  The interpolation / shading entry points
+ * replace the eager-torch bodies of rasterize_clip_space
+ * (src/mesh_renderer/rasterize.py:112-150) and phong_shader
+ * (src/mesh_renderer/render.py:287-386).
+ *
+ * Conventions for every entry point
+ *   - all data pointers are DEVICE pointers (HBM resident), contiguous, C order;
+ *   - the caller owns every buffer, outputs included; nothing is allocated or
+ *     freed here, so a call sequence can be captured into a hipGraph;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the
+ *     legacy default stream) and the call returns without synchronising;
+ *   - `workspace` is scratch the call may overwrite; its minimum size comes
+ *     from the matching *_workspace_bytes() query, 256-byte aligned;
+ *   - return value: MR_OK or a negative MR_E* code; no exceptions cross the ABI;
+ *   - batched: B independent images share one `triangles` array; the
+ *     reference's per-image call is B = 1.
+ *
+ * Numerical contract: mr_rasterize_forward reproduces the reference's ids, z
+ * and barycentrics BIT FOR BIT (un-fused binary32 arithmetic in the
+ * reference's evaluation order, binary64 pixel centres / bbox projection;
+ * SURVEY.md Appendix A).  Gradients agree within 1e-4 abs (summation order
+ * differs: LDS/atomic accumulation instead of a serial row-major loop).
+ */
+#ifndef MESH_RASTER_H_
+#define MESH_RASTER_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MR_OK 0
+#define MR_EINVAL (-1)     /* null pointer, negative count, W/H out of [1, 65535] */
+#define MR_EWORKSPACE (-2) /* workspace missing, too small or misaligned */
+#define MR_ELAUNCH (-3)    /* a HIP launch / memset failed (see mr_last_hip_error) */
+
+/* Library / ABI version: major*10000 + minor*100 + patch. */
+int mr_version(void);
+/* hipError_t of the most recent failed launch in this process, 0 if none. */
+int mr_last_hip_error(void);
+
+/* ---- rasterize_triangles_cpp.forward -------------------------------------
+ * Replaces rasterize_triangles_forward (rasterize_triangles.cpp:302-419).
+ *   clip      [B,V,4] f32  clip-space XYZW
+ *   triangles [T,3]   i32  vertex ids (a triangle with an id outside [0,V) is
+ *                          skipped; the reference would read out of bounds)
+ *   ids       [B,H,W]   i32 out  winning triangle id, 0 where nothing was drawn
+ *   bary      [B,H,W,3] f32 out  perspective-correct barycentrics, 0 where empty
+ *   z         [B,H,W]   f32 out  NDC depth of the winner, 1.0 where empty
+ * Row 0 is the BOTTOM scanline (NDC y = -1), as in the reference. */
+size_t mr_rasterize_forward_workspace_bytes(int B, int V, int T, int W, int H);
+int mr_rasterize_forward(const float *clip, const int32_t *triangles,
+                         int B, int V, int T, int W, int H,
+                         int32_t *ids, float *bary, float *z,
+                         void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- rasterize_triangles_cpp.backward ------------------------------------
+ * Replaces rasterize_triangles_backward (rasterize_triangles.cpp:131-273).
+ *   dbary [B,H,W,3] f32   dL/d(bary)
+ *   ids, bary             the forward's outputs
+ *   dclip [B,V,4] f32 out dL/d(clip); zeroed here; column 2 (z) stays 0 */
+size_t mr_rasterize_backward_workspace_bytes(int B, int V, int T, int W, int H);
+int mr_rasterize_backward(const float *dbary, const float *clip,
+                          const int32_t *triangles, const int32_t *ids,
+                          const float *bary, int B, int V, int T, int W, int H,
+                          float *dclip, void *workspace, size_t workspace_bytes,
+                          void *stream);
+
+/* ---- deferred attribute interpolation -------------------------------------
+ * Replaces the gather / multiply / sum / alpha / background-blend block of
+ * rasterize_clip_space (src/mesh_renderer/rasterize.py:118-150).
+ *   attrs      [B,V,A] f32
+ *   background [A]     f32
+ *   out        [B,H,W,A] f32 out (not flipped) */
+int mr_interpolate_forward(const int32_t *ids, const float *bary,
+                           const float *attrs, const int32_t *triangles,
+                           const float *background, int B, int V, int T,
+                           int W, int H, int A, float *out, void *stream);
+
+/* Its autograd backward (index_put_(accumulate) + d/d bary).
+ *   dout   [B,H,W,A] f32
+ *   dattrs [B,V,A]   f32 out, zeroed here
+ *   dbary  [B,H,W,3] f32 out */
+size_t mr_interpolate_backward_workspace_bytes(int B, int V, int T, int W, int H, int A);
+int mr_interpolate_backward(const float *dout, const int32_t *ids,
+                            const float *bary, const float *attrs,
+                            const int32_t *triangles, const float *background,
+                            int B, int V, int T, int W, int H, int A,
+                            float *dattrs, float *dbary, void *workspace,
+                            size_t workspace_bytes, void *stream);
+
+/* ---- tuning hooks (no reference counterpart; results never change) ----------
+ * Pixel tile walked by one wavefront in the forward raster kernel:
+ * 0 = 8x8 (default), 1 = 16x4, 2 = 32x2. */
+int mr_set_raster_tile_shape(int shape);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MESH_RASTER_H_ */

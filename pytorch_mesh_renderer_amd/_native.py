@@ -1,0 +1,188 @@
+"""ctypes binding of the C-ABI HIP library (include/mesh_raster.h).
+
+This is the ONLY compute back end of the package: there is no CPU or eager
+fallback.  If libmesh_raster_hip.so is missing or a tensor is not on a HIP
+device, the call raises.  PyTorch supplies device memory and the stream; the
+kernels are ours.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB_PATH = os.path.join(_CSRC, "libmesh_raster_hip.so")
+
+MR_OK, MR_EINVAL, MR_EWORKSPACE, MR_ELAUNCH = 0, -1, -2, -3
+_ERR = {MR_EINVAL: "invalid argument", MR_EWORKSPACE: "workspace too small or misaligned",
+        MR_ELAUNCH: "HIP launch failed"}
+
+_lib = None
+_workspaces = {}
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """Compile libmesh_raster_hip.so in-tree for gfx950 (hipcc cross-compiles on CPU)."""
+    out = subprocess.run(["make", "-C", _CSRC, "all"], capture_output=True, text=True)
+    if verbose:
+        print(out.stdout)
+    if out.returncode != 0:
+        raise NativeLibraryError("hipcc build failed:\n" + out.stdout + out.stderr)
+    return LIB_PATH
+
+
+def lib():
+    """Load the shared library (never builds implicitly, never falls back)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeLibraryError(
+                "%s not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or make -C pytorch_mesh_renderer_amd/csrc). There is no fallback path." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        vp, ci, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+        L.mr_version.restype = ci
+        L.mr_last_hip_error.restype = ci
+        L.mr_set_raster_tile_shape.argtypes = [ci]
+        L.mr_set_raster_tile_shape.restype = ci
+        L.mr_rasterize_forward_workspace_bytes.argtypes = [ci] * 5
+        L.mr_rasterize_forward_workspace_bytes.restype = sz
+        L.mr_rasterize_forward.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, sz, vp]
+        L.mr_rasterize_forward.restype = ci
+        L.mr_rasterize_backward_workspace_bytes.argtypes = [ci] * 5
+        L.mr_rasterize_backward_workspace_bytes.restype = sz
+        L.mr_rasterize_backward.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, sz, vp]
+        L.mr_rasterize_backward.restype = ci
+        L.mr_interpolate_forward.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp]
+        L.mr_interpolate_forward.restype = ci
+        L.mr_interpolate_backward_workspace_bytes.argtypes = [ci] * 6
+        L.mr_interpolate_backward_workspace_bytes.restype = sz
+        L.mr_interpolate_backward.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci,
+                                              vp, vp, vp, sz, vp]
+        L.mr_interpolate_backward.restype = ci
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc != MR_OK:
+        extra = ""
+        if rc == MR_ELAUNCH:
+            extra = " (hipError %d)" % lib().mr_last_hip_error()
+        raise RuntimeError("%s failed: %s%s" % (what, _ERR.get(rc, "error %d" % rc), extra))
+
+
+def _require_device(*tensors):
+    dev = tensors[0].device
+    if dev.type != "cuda":
+        raise RuntimeError(
+            "pytorch_mesh_renderer_amd runs on MI355X only: got a %s tensor. Move inputs to "
+            "a HIP device ('cuda'); there is no CPU fallback." % dev.type)
+    for t in tensors:
+        if t.device != dev:
+            raise RuntimeError("all tensors must be on the same device")
+    return dev
+
+
+def _workspace(dev, nbytes):
+    """Per-(device, stream) scratch tensor, grown on demand.  Reuse is safe because
+    every consumer is enqueued on the same stream."""
+    if nbytes == 0:
+        return None, 0
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
+        _workspaces[key] = ws
+    return ws, ws.numel()
+
+
+def _stream(dev):
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def rasterize_forward(clip, triangles, width, height):
+    """clip [B,V,4] f32, triangles [T,3] i32 (device) -> ids [B,H,W] i32, bary [B,H,W,3], z [B,H,W]."""
+    dev = _require_device(clip, triangles)
+    L = lib()
+    clip = clip.contiguous()
+    triangles = triangles.contiguous()
+    B, V, _ = clip.shape
+    T = triangles.shape[0]
+    ids = torch.empty(B, height, width, dtype=torch.int32, device=dev)
+    bary = torch.empty(B, height, width, 3, dtype=torch.float32, device=dev)
+    z = torch.empty(B, height, width, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        need = L.mr_rasterize_forward_workspace_bytes(B, V, T, width, height)
+        ws, have = _workspace(dev, need)
+        rc = L.mr_rasterize_forward(_ptr(clip), _ptr(triangles), B, V, T, width, height,
+                                    _ptr(ids), _ptr(bary), _ptr(z), _ptr(ws), have, _stream(dev))
+    _check(rc, "mr_rasterize_forward")
+    return ids, bary, z
+
+
+def rasterize_backward(dbary, clip, triangles, ids, bary):
+    """-> dclip [B,V,4] f32."""
+    dev = _require_device(dbary, clip, triangles, ids, bary)
+    L = lib()
+    dbary, clip, triangles = dbary.contiguous(), clip.contiguous(), triangles.contiguous()
+    ids, bary = ids.contiguous(), bary.contiguous()
+    B, V, _ = clip.shape
+    T = triangles.shape[0]
+    _, H, W = ids.shape
+    dclip = torch.empty(B, V, 4, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        need = L.mr_rasterize_backward_workspace_bytes(B, V, T, W, H)
+        ws, have = _workspace(dev, need)
+        rc = L.mr_rasterize_backward(_ptr(dbary), _ptr(clip), _ptr(triangles), _ptr(ids),
+                                     _ptr(bary), B, V, T, W, H, _ptr(dclip), _ptr(ws), have,
+                                     _stream(dev))
+    _check(rc, "mr_rasterize_backward")
+    return dclip
+
+
+def interpolate_forward(ids, bary, attrs, triangles, background):
+    """attrs [B,V,A], background [A] -> [B,H,W,A]."""
+    dev = _require_device(ids, bary, attrs, triangles, background)
+    L = lib()
+    ids, bary, attrs = ids.contiguous(), bary.contiguous(), attrs.contiguous()
+    triangles, background = triangles.contiguous(), background.contiguous()
+    B, H, W = ids.shape
+    V, A = attrs.shape[1], attrs.shape[2]
+    T = triangles.shape[0]
+    out = torch.empty(B, H, W, A, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.mr_interpolate_forward(_ptr(ids), _ptr(bary), _ptr(attrs), _ptr(triangles),
+                                      _ptr(background), B, V, T, W, H, A, _ptr(out), _stream(dev))
+    _check(rc, "mr_interpolate_forward")
+    return out
+
+
+def interpolate_backward(dout, ids, bary, attrs, triangles, background):
+    """-> (dattrs [B,V,A], dbary [B,H,W,3])."""
+    dev = _require_device(dout, ids, bary, attrs, triangles, background)
+    L = lib()
+    dout, ids, bary = dout.contiguous(), ids.contiguous(), bary.contiguous()
+    attrs, triangles, background = attrs.contiguous(), triangles.contiguous(), background.contiguous()
+    B, H, W = ids.shape
+    V, A = attrs.shape[1], attrs.shape[2]
+    T = triangles.shape[0]
+    dattrs = torch.empty(B, V, A, dtype=torch.float32, device=dev)
+    dbary = torch.empty(B, H, W, 3, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        need = L.mr_interpolate_backward_workspace_bytes(B, V, T, W, H, A)
+        ws, have = _workspace(dev, need)
+        rc = L.mr_interpolate_backward(_ptr(dout), _ptr(ids), _ptr(bary), _ptr(attrs),
+                                       _ptr(triangles), _ptr(background), B, V, T, W, H, A,
+                                       _ptr(dattrs), _ptr(dbary), _ptr(ws), have, _stream(dev))
+    _check(rc, "mr_interpolate_backward")
+    return dattrs, dbary

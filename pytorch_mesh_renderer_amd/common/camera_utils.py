@@ -1,0 +1,93 @@
+"""Camera math for the render path: batched 4x4 matrices, device-aware.
+
+Counterpart of src/common/camera_utils.py (euler_matrices :10-42, look_at
+:45-96, perspective :99-139, transform_homogeneous :142-170).  Same names,
+argument meaning, output layout and error behaviour; unlike the reference every
+function allocates on the device of its inputs, so the whole path can live in
+HBM.  All functions are plain differentiable torch ops (the examples optimise
+camera position and Euler angles through them).
+"""
+import math
+
+import torch
+
+_DEGENERACY_CUTOFF = 1e-6
+
+
+def euler_matrices(angles):
+    """XYZ Tait-Bryan rotation as [batch, 4, 4] matrices; angles [batch, 3] in radians."""
+    s, c = torch.sin(angles), torch.cos(angles)
+    s0, s1, s2 = s.unbind(dim=1)
+    c0, c1, c2 = c.unbind(dim=1)
+    zero, one = torch.zeros_like(s0), torch.ones_like(s0)
+    rows = [
+        c2 * c1, c2 * s1 * s0 - c0 * s2, s2 * s0 + c2 * c0 * s1, zero,
+        c1 * s2, c2 * c0 + s2 * s1 * s0, c0 * s2 * s1 - c2 * s0, zero,
+        -s1, c1 * s0, c1 * c0, zero,
+        zero, zero, zero, one,
+    ]
+    return torch.stack(rows, dim=1).reshape(-1, 4, 4)
+
+
+def _assert_all_greater(values, cutoff, message):
+    # Same failure mode as the reference's np.testing.assert_array_less
+    # (camera_utils.py:68-69, 74-76): AssertionError carrying the message.
+    if not bool((values.detach() > cutoff).all()):
+        raise AssertionError(message)
+
+
+def look_at(eye, center, world_up):
+    """gluLookAt: world -> eye space, [batch, 4, 4], right-handed."""
+    forward = center - eye
+    forward_norm = torch.linalg.norm(forward, dim=1, keepdim=True)
+    _assert_all_greater(forward_norm, _DEGENERACY_CUTOFF,
+                        "Camera matrix is degenerate because eye and center are close.")
+    forward = forward / forward_norm
+
+    to_side = torch.cross(forward, world_up, dim=-1)
+    to_side_norm = torch.linalg.norm(to_side, dim=1, keepdim=True)
+    _assert_all_greater(to_side_norm, _DEGENERACY_CUTOFF,
+                        "Camera matrix is degenerate because up and gaze are too close "
+                        "or because up is degenerate.")
+    to_side = to_side / to_side_norm
+    cam_up = torch.cross(to_side, forward, dim=-1)
+
+    batch = center.shape[0]
+    rotation = torch.zeros(batch, 4, 4, dtype=eye.dtype, device=eye.device)
+    rotation[:, 0, :3] = to_side
+    rotation[:, 1, :3] = cam_up
+    rotation[:, 2, :3] = -forward
+    rotation[:, 3, 3] = 1.0
+    translation = torch.eye(4, dtype=eye.dtype, device=eye.device).repeat(batch, 1, 1)
+    translation[:, :3, 3] = -eye
+    return torch.matmul(rotation, translation)
+
+
+def perspective(aspect_ratio, fov_y, near_clip, far_clip):
+    """gluPerspective: eye -> left-handed clip space, [batch, 4, 4]; fov_y in degrees."""
+    # fov * pi/360 converts to radians and halves the angle in one go
+    focal_y = 1.0 / torch.tan(fov_y * (math.pi / 360.0))
+    depth_range = far_clip - near_clip
+    p_22 = -(far_clip + near_clip) / depth_range
+    p_23 = -2.0 * (far_clip * near_clip / depth_range)
+    zero = torch.zeros_like(p_23)
+    rows = [
+        focal_y / aspect_ratio, zero, zero, zero,
+        zero, focal_y, zero, zero,
+        zero, zero, p_22, p_23,
+        zero, zero, -torch.ones_like(p_23), zero,
+    ]
+    return torch.stack(rows, dim=1).reshape(-1, 4, 4)
+
+
+def transform_homogeneous(matrices, vertices):
+    """(M V^T)^T with w=1 appended: [batch,4,4] x [batch,N,3] -> [batch,N,4]."""
+    if len(matrices.shape) != 3:
+        raise ValueError(
+            "matrices must have 3 dimensions (missing batch dimension?)")
+    if len(vertices.shape) != 3:
+        raise ValueError(
+            "vertices must have 3 dimensions (missing batch dimension?)")
+    ones = torch.ones(vertices.shape[0], vertices.shape[1], 1,
+                      dtype=vertices.dtype, device=vertices.device)
+    return torch.matmul(torch.cat([vertices, ones], 2), matrices.transpose(1, 2))

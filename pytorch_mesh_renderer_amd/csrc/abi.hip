@@ -1,0 +1,106 @@
+// extern "C" surface of libmesh_raster_hip.so (see include/mesh_raster.h).
+// Argument validation lives here; kernels and launch geometry live in the
+// per-stage .hip files.  No allocation, no synchronisation, no exceptions.
+#include "mr_internal.h"
+
+namespace {
+
+inline bool bad_dims(int B, int V, int T, int W, int H) {
+  return B < 0 || V < 0 || T < 0 || W < 1 || H < 1 || W > 65535 || H > 65535;
+}
+
+inline int check_ws(const void *ws, size_t have, size_t need) {
+  if (need == 0) return MR_OK;
+  if (ws == nullptr || have < need) return MR_EWORKSPACE;
+  if (((uintptr_t)ws & 255u) != 0) return MR_EWORKSPACE;
+  return MR_OK;
+}
+
+}  // namespace
+
+namespace mr {
+extern int g_raster_tile_shape;
+}
+
+extern "C" {
+
+int mr_version(void) { return 100; /* 0.1.0 */ }
+
+int mr_last_hip_error(void) { return mr::g_last_hip_error; }
+
+// Tuning hook (not part of the reference surface): 0 = 8x8, 1 = 16x4, 2 = 32x2
+// pixel tile per wavefront in the forward raster kernel.  Results are identical.
+int mr_set_raster_tile_shape(int shape) {
+  if (shape < 0 || shape > 2) return MR_EINVAL;
+  mr::g_raster_tile_shape = shape;
+  return MR_OK;
+}
+
+size_t mr_rasterize_forward_workspace_bytes(int B, int V, int T, int W, int H) {
+  if (bad_dims(B, V, T, W, H)) return 0;
+  return mr::raster_forward_ws(B, V, T, W, H);
+}
+
+int mr_rasterize_forward(const float *clip, const int32_t *triangles, int B, int V, int T, int W,
+                         int H, int32_t *ids, float *bary, float *z, void *workspace,
+                         size_t workspace_bytes, void *stream) {
+  if (bad_dims(B, V, T, W, H)) return MR_EINVAL;
+  if (B == 0) return MR_OK;
+  if (!ids || !bary || !z) return MR_EINVAL;
+  if ((V > 0 && !clip) || (T > 0 && !triangles)) return MR_EINVAL;
+  const int rc = check_ws(workspace, workspace_bytes, mr::raster_forward_ws(B, V, T, W, H));
+  if (rc != MR_OK) return rc;
+  return mr::launch_raster_forward(clip, triangles, B, V, T, W, H, ids, bary, z, workspace,
+                                   (hipStream_t)stream);
+}
+
+size_t mr_rasterize_backward_workspace_bytes(int B, int V, int T, int W, int H) {
+  if (bad_dims(B, V, T, W, H)) return 0;
+  return mr::raster_backward_ws(B, V, T, W, H);
+}
+
+int mr_rasterize_backward(const float *dbary, const float *clip, const int32_t *triangles,
+                          const int32_t *ids, const float *bary, int B, int V, int T, int W,
+                          int H, float *dclip, void *workspace, size_t workspace_bytes,
+                          void *stream) {
+  if (bad_dims(B, V, T, W, H)) return MR_EINVAL;
+  if (B == 0 || V == 0) return MR_OK;
+  if (!dbary || !clip || !ids || !bary || !dclip || (T > 0 && !triangles)) return MR_EINVAL;
+  const int rc = check_ws(workspace, workspace_bytes, mr::raster_backward_ws(B, V, T, W, H));
+  if (rc != MR_OK) return rc;
+  return mr::launch_raster_backward(dbary, clip, triangles, ids, bary, B, V, T, W, H, dclip,
+                                    workspace, (hipStream_t)stream);
+}
+
+int mr_interpolate_forward(const int32_t *ids, const float *bary, const float *attrs,
+                           const int32_t *triangles, const float *background, int B, int V,
+                           int T, int W, int H, int A, float *out, void *stream) {
+  // the reference gathers triangle 0's corners for empty pixels, so T = 0 is an error there too
+  if (bad_dims(B, V, T, W, H) || A < 0 || T < 1 || V < 1) return MR_EINVAL;
+  if (B == 0 || A == 0) return MR_OK;
+  if (!ids || !bary || !attrs || !triangles || !background || !out) return MR_EINVAL;
+  return mr::launch_interp_forward(ids, bary, attrs, triangles, background, B, V, T, W, H, A, out,
+                                   (hipStream_t)stream);
+}
+
+size_t mr_interpolate_backward_workspace_bytes(int B, int V, int T, int W, int H, int A) {
+  if (bad_dims(B, V, T, W, H) || A < 0) return 0;
+  return mr::interp_backward_ws(B, V, T, W, H, A);
+}
+
+int mr_interpolate_backward(const float *dout, const int32_t *ids, const float *bary,
+                            const float *attrs, const int32_t *triangles,
+                            const float *background, int B, int V, int T, int W, int H, int A,
+                            float *dattrs, float *dbary, void *workspace,
+                            size_t workspace_bytes, void *stream) {
+  if (bad_dims(B, V, T, W, H) || A < 0 || T < 1 || V < 1) return MR_EINVAL;
+  if (B == 0) return MR_OK;
+  if (!dout || !ids || !bary || !attrs || !triangles || !background || !dattrs || !dbary)
+    return MR_EINVAL;
+  const int rc = check_ws(workspace, workspace_bytes, mr::interp_backward_ws(B, V, T, W, H, A));
+  if (rc != MR_OK) return rc;
+  return mr::launch_interp_backward(dout, ids, bary, attrs, triangles, background, B, V, T, W, H,
+                                    A, dattrs, dbary, workspace, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,78 @@
+// Shared device helpers and launch plumbing for the gfx950 rasterizer kernels.
+// Everything here is CDNA4-only: wave64, __builtin_amdgcn_* intrinsics.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <limits.h>
+#include <stdint.h>
+
+#include "mesh_raster.h"
+
+namespace mr {
+
+constexpr int kWave = 64;       // gfx950 wavefront
+constexpr int kXcds = 8;        // MI355X: 8 XCDs, each with a private L2
+
+// Per-(image, triangle) setup record produced by k_setup and consumed by the
+// raster kernel through wave-uniform (scalar) loads.  64 bytes, 64-B aligned.
+//   a = (m0 m1 m2 m3)  b = (m4 m5 m6 m7)  c = (m8 z0 z1 z2)  d = (w0 w1 w2 -)
+// m[] is the sign-corrected adjugate of [[x],[y],[w]] (rows = edge functions).
+struct alignas(64) TriRec {
+  float4 a, b, c, d;
+};
+
+// Pixel bbox [l, r) x [bot, top) packed as 4 x u16; an empty / culled triangle
+// is stored as all zeros so that no region ever selects it.
+__device__ __forceinline__ uint2 pack_bbox(int l, int r, int bot, int top) {
+  return make_uint2((unsigned)l | ((unsigned)r << 16), (unsigned)bot | ((unsigned)top << 16));
+}
+
+__device__ __forceinline__ int lane_id() {
+  return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
+// Remap the hardware block id so that each XCD (blocks b, b+8, b+16, ... land
+// on the same XCD under round-robin dispatch) owns one CONTIGUOUS range of the
+// logical work list.  Placement only affects speed (which L2 holds which
+// image's triangle records), never correctness.  Returns -1 for padding blocks.
+__device__ __forceinline__ int xcd_contiguous_block(int hw_block, int n_logical, int per_xcd) {
+  const int logical = (hw_block % kXcds) * per_xcd + hw_block / kXcds;
+  return logical < n_logical ? logical : -1;
+}
+
+// ---- host side -------------------------------------------------------------
+extern thread_local int g_last_hip_error;
+
+inline int check_launch() {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    g_last_hip_error = (int)e;
+    return MR_ELAUNCH;
+  }
+  return MR_OK;
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Host launchers (one per .hip file)
+int launch_raster_forward(const float *clip, const int32_t *tris, int B, int V, int T, int W,
+                          int H, int32_t *ids, float *bary, float *z, void *ws, hipStream_t s);
+size_t raster_forward_ws(int B, int V, int T, int W, int H);
+int launch_raster_backward(const float *dbary, const float *clip, const int32_t *tris,
+                           const int32_t *ids, const float *bary, int B, int V, int T, int W,
+                           int H, float *dclip, void *ws, hipStream_t s);
+size_t raster_backward_ws(int B, int V, int T, int W, int H);
+int launch_interp_forward(const int32_t *ids, const float *bary, const float *attrs,
+                          const int32_t *tris, const float *bg, int B, int V, int T, int W,
+                          int H, int A, float *out, hipStream_t s);
+int launch_interp_backward(const float *dout, const int32_t *ids, const float *bary,
+                           const float *attrs, const int32_t *tris, const float *bg, int B,
+                           int V, int T, int W, int H, int A, float *dattrs, float *dbary,
+                           void *ws, hipStream_t s);
+size_t interp_backward_ws(int B, int V, int T, int W, int H, int A);
+
+}  // namespace mr
