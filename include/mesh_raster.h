@@ -103,6 +103,13 @@ int mr_interpolate_backward(const float *dout, const int32_t *ids,
  * 0 = 8x8 (default), 1 = 16x4, 2 = 32x2. */
 int mr_set_raster_tile_shape(int shape);
 
+/* ---- measurement hook -------------------------------------------------------
+ * When both are non-NULL, every mr_rasterize_forward() records hipEvent `start`
+ * immediately before and `stop` immediately after its G-buffer kernel (k_raster)
+ * on the call's stream, so a caller can time that kernel alone inside a larger
+ * step (bench.py's roofline leg).  Pass NULLs to switch it off (the default). */
+int mr_set_raster_profile_events(void *start_event, void *stop_event);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,6 +50,8 @@ def lib():
         L.mr_last_hip_error.restype = ci
         L.mr_set_raster_tile_shape.argtypes = [ci]
         L.mr_set_raster_tile_shape.restype = ci
+        L.mr_set_raster_profile_events.argtypes = [vp, vp]
+        L.mr_set_raster_profile_events.restype = ci
         L.mr_rasterize_forward_workspace_bytes.argtypes = [ci] * 5
         L.mr_rasterize_forward_workspace_bytes.restype = sz
         L.mr_rasterize_forward.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, sz, vp]

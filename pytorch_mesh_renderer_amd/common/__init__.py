@@ -1,0 +1,3 @@
+from . import camera_utils, shapes, synthetic
+
+__all__ = ["camera_utils", "shapes", "synthetic"]

@@ -20,6 +20,7 @@ inline int check_ws(const void *ws, size_t have, size_t need) {
 
 namespace mr {
 extern int g_raster_tile_shape;
+extern hipEvent_t g_raster_ev_start, g_raster_ev_stop;
 }
 
 extern "C" {
@@ -33,6 +34,13 @@ int mr_last_hip_error(void) { return mr::g_last_hip_error; }
 int mr_set_raster_tile_shape(int shape) {
   if (shape < 0 || shape > 2) return MR_EINVAL;
   mr::g_raster_tile_shape = shape;
+  return MR_OK;
+}
+
+int mr_set_raster_profile_events(void *start_event, void *stop_event) {
+  if ((start_event == nullptr) != (stop_event == nullptr)) return MR_EINVAL;
+  mr::g_raster_ev_start = (hipEvent_t)start_event;
+  mr::g_raster_ev_stop = (hipEvent_t)stop_event;
   return MR_OK;
 }
 

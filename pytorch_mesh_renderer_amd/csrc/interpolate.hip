@@ -20,7 +20,8 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kChunk = 4;  // attributes per accumulation pass (x3 corners = kAcc)
-static_assert(kChunk * 3 == kAcc, "chunk must fill the accumulator");
+constexpr int kAcc = kChunk * 3;
+static_assert(kAcc <= kAccStride, "chunk must fit the accumulator row");
 
 // alpha = clamp(sum(2*bary), 0, 1)  (rasterize.py:145-147)
 __device__ __forceinline__ float coverage_alpha(const F3 b, float &pre_clamp) {
@@ -91,27 +92,40 @@ __global__ __launch_bounds__(kThreads) void k_interp_dbary(
 // Per-pixel values for the attribute scatter-add: alpha * dout[a] * b_k for the 4
 // attributes of one chunk and the 3 corners.
 struct AttrGradFn {
+  static constexpr int kN = kChunk * 3;
   const float *__restrict__ dout;
   const int32_t *__restrict__ ids;
   const F3 *__restrict__ bary;
   int A, a_begin;
-  __device__ __forceinline__ bool operator()(size_t pix, int T, int &tri, float (&v)[kAcc]) const {
-    const F3 b = bary[pix];
+
+  struct Pixel {
+    F3 b;
+    float gv[kChunk];
+  };
+  struct Triangle {};
+
+  __device__ __forceinline__ bool load_pixel(size_t pix, int T, int &tri, Pixel &p) const {
+    p.b = bary[pix];
     float pre;
-    const float alpha = coverage_alpha(b, pre);
+    const float alpha = coverage_alpha(p.b, pre);
     if (!(alpha > 0.0f)) return false;  // background: every term is alpha * ... = 0
     const int t = ids[pix];
     if ((unsigned)t >= (unsigned)T) return false;
     const float *g = dout + pix * A + a_begin;
 #pragma unroll
-    for (int c = 0; c < kChunk; ++c) {
-      const float gv = (a_begin + c < A) ? alpha * g[c] : 0.0f;
-      v[c * 3 + 0] = gv * b.x;
-      v[c * 3 + 1] = gv * b.y;
-      v[c * 3 + 2] = gv * b.z;
-    }
+    for (int c = 0; c < kChunk; ++c) p.gv[c] = (a_begin + c < A) ? alpha * g[c] : 0.0f;
     tri = t;
     return true;
+  }
+  __device__ __forceinline__ void load_triangle(int, int, Triangle &) const {}
+  __device__ __forceinline__ void accumulate(const Pixel &p, const Triangle &,
+                                             float (&acc)[kN]) const {
+#pragma unroll
+    for (int c = 0; c < kChunk; ++c) {
+      acc[c * 3 + 0] += p.gv[c] * p.b.x;
+      acc[c * 3 + 1] += p.gv[c] * p.b.y;
+      acc[c * 3 + 2] += p.gv[c] * p.b.z;
+    }
   }
 };
 
@@ -124,7 +138,7 @@ __global__ __launch_bounds__(kThreads) void k_attr_finalize(
   bool any = false;
 #pragma unroll
   for (int k = 0; k < kAcc; ++k) {
-    s[k] = acc[gid * kAcc + k];
+    s[k] = acc[gid * kAccStride + k];
     any |= (s[k] != 0.0f);
   }
   if (!any) return;
@@ -163,7 +177,7 @@ int launch_interp_forward(const int32_t *ids, const float *bary, const float *at
 
 size_t interp_backward_ws(int B, int V, int T, int W, int H, int A) {
   (void)V; (void)W; (void)H; (void)A;
-  return align_up((size_t)B * T * kAcc * sizeof(float), 256);
+  return align_up((size_t)B * T * kAccStride * sizeof(float), 256);
 }
 
 int launch_interp_backward(const float *dout, const int32_t *ids, const float *bary,
@@ -183,7 +197,7 @@ int launch_interp_backward(const float *dout, const int32_t *ids, const float *b
   float *acc = (float *)ws;
   const long nbt = (long)B * T;
   for (int a_begin = 0; a_begin < A; a_begin += kChunk) {
-    if (hipMemsetAsync(acc, 0, (size_t)nbt * kAcc * sizeof(float), s) != hipSuccess)
+    if (hipMemsetAsync(acc, 0, (size_t)nbt * kAccStride * sizeof(float), s) != hipSuccess)
       return check_launch();
     AttrGradFn fn{dout, ids, (const F3 *)bary, A, a_begin};
     rc = launch_accumulate_runs(fn, B, T, W, H, acc, s);

@@ -2,28 +2,29 @@
 //
 // Replaces rasterize_triangles_backward
 // (reference: src/mesh_renderer/kernels/rasterize_triangles.cpp:131-273), a serial
-// loop that recomputes a 3x3 adjugate per pixel and does nine '+=' into
-// df_dvertices.  Here the per-pixel work is reduced to what actually depends on
-// the pixel.  With U the sign-corrected adjugate, S_k its column sums and
-// b / g the pixel's barycentrics / upstream gradient:
+// row-major loop that rebuilds a 3x3 adjugate per pixel and does nine '+=' into
+// df_dvertices[V,4].
 //
-//   dL/dM[k][j] = sum_px sum_i g_i * ( -U[i][k] b_j + S_k b_i b_j ) / |det|
-//               = ( S_k * C_j  -  sum_i U[i][k] * A_ij ) / |det|
-//   A_ij = sum_px g_i b_j   (9 numbers per triangle)
-//   C_j  = sum_px (g . b) b_j   (3 numbers per triangle)
+//   k_bwd_setup        one thread per (image, triangle): sign-corrected adjugate U,
+//                      its column sums and 1/|det| as a 64-byte record (cpp:180-198).
+//   k_accumulate_runs  (run_accum.h) streams the G-buffer once -- 28 B/px: dbary 12
+//                      + id 4 + bary 12.  Each lane walks down a pixel column, fetches
+//                      the triangle record only when the id changes, evaluates the
+//                      nine partials of cpp:202-269 per pixel and keeps them in
+//                      registers for the run; runs land in an LDS hash table and
+//                      leave as contiguous float atomics into acc[B][T][9(+3)].
+//   k_bwd_scatter      one thread per touched (image, triangle): nine atomics into
+//                      dclip[B,V,4].
 //
-// k_accumulate_runs (run_accum.h) streams the G-buffer once (28 B/px: dbary 12 + id 4 + bary 12).
-//               Each lane walks DOWN one pixel column, so every wave load is 64
-//               consecutive pixels (coalesced), and keeps the 12 sums in registers
-//               while the triangle id does not change (runs of tens of pixels).
-//               A finished run is added into a workgroup-local LDS hash table keyed
-//               by triangle id (ds_add_f32); the table is drained with 48-byte
-//               contiguous global float atomics into acc[B][T][12].
-// k_finalize    one thread per (image, triangle) with a non-zero accumulator:
-//               rebuilds U once and scatters the 9 vertex partials into dclip.
-//
-// The sums are associated differently from the reference's row-major serial loop
-// (fp32, order-dependent there too), so parity is to 1e-4 abs, not bitwise.
+// Numerics.  d b_i / d M = (-U_ic b_j + S_c b_i b_j)/|det| is a small difference
+// of large terms for small or sliver triangles, so the cancellation has to happen
+// PER PIXEL, before any summation (summing g*b first and combining with U
+// afterwards is ~sqrt(#pixels) less accurate -- measured 1.5e-4 vs the
+// reference).  This file is therefore compiled with -ffp-contract=off and keeps
+// the reference's association inside each per-pixel partial; only the order in
+// which pixels are summed differs (fp32, order-dependent in the reference too),
+// and the division by |det| is a multiplication by its fp32 reciprocal (<= 1.5 ulp
+// per partial).  Parity bar: 1e-4 abs.
 #include "run_accum.h"
 
 namespace mr {
@@ -32,97 +33,147 @@ namespace {
 constexpr int kThreads = 256;
 constexpr float kDegenerateCutoff = 0.9f;  // cpp:13
 
-// Per-pixel values for the rasterizer backward: A_ij = g_i b_j, C_j = (g.b) b_j.
+// u[9] row-major (row i = edge i, column c = clip component x/y/w), colsum[3],
+// inv_abs_det.  64 bytes.
+struct alignas(64) BwdRec {
+  float4 a, b, c, d;  // a=(u0..u3) b=(u4..u7) c=(u8,S0,S1,S2) d=(1/|det|,-,-,-)
+};
+
+__global__ __launch_bounds__(kThreads) void k_bwd_setup(
+    const float4 *__restrict__ clip, const int32_t *__restrict__ tris, int B, int V, int T,
+    BwdRec *__restrict__ recs) {
+  const long gid = (long)blockIdx.x * kThreads + threadIdx.x;
+  if (gid >= (long)B * T) return;
+  const int b = (int)(gid / T);
+  const int t = (int)(gid - (long)b * T);
+  const int i0 = tris[3 * t], i1 = tris[3 * t + 1], i2 = tris[3 * t + 2];
+  BwdRec r;
+  r.a = r.b = r.c = r.d = make_float4(0.f, 0.f, 0.f, 0.f);
+  if ((unsigned)i0 < (unsigned)V && (unsigned)i1 < (unsigned)V && (unsigned)i2 < (unsigned)V) {
+    const float4 p0 = clip[(long)b * V + i0], p1 = clip[(long)b * V + i1], p2 = clip[(long)b * V + i2];
+    const float a11 = p0.x, a12 = p1.x, a13 = p2.x;
+    const float a21 = p0.y, a22 = p1.y, a23 = p2.y;
+    const float a31 = p0.w, a32 = p1.w, a33 = p2.w;
+    float u0 = a22 * a33 - a32 * a23, u1 = a13 * a32 - a33 * a12, u2 = a12 * a23 - a22 * a13;
+    float u3 = a23 * a31 - a33 * a21, u4 = a11 * a33 - a31 * a13, u5 = a13 * a21 - a23 * a11;
+    float u6 = a21 * a32 - a31 * a22, u7 = a12 * a31 - a32 * a11, u8 = a11 * a22 - a21 * a12;
+    const float det = a11 * u0 + a12 * u3 + a13 * u6;
+    if (det < 0.0f) {
+      u0 = -u0; u1 = -u1; u2 = -u2; u3 = -u3; u4 = -u4; u5 = -u5; u6 = -u6; u7 = -u7; u8 = -u8;
+    }
+    r.a = make_float4(u0, u1, u2, u3);
+    r.b = make_float4(u4, u5, u6, u7);
+    r.c = make_float4(u8, (u0 + u3) + u6, (u1 + u4) + u7, (u2 + u5) + u8);  // cpp:187-198
+    r.d = make_float4(1.0f / fabsf(det), 0.f, 0.f, 0.f);
+  }
+  recs[gid] = r;
+}
+
 struct RasterGradFn {
+  static constexpr int kN = 9;  // [corner j][component c] partials
   const F3 *__restrict__ dbary;
   const int32_t *__restrict__ ids;
   const F3 *__restrict__ bary;
-  __device__ __forceinline__ bool operator()(size_t pix, int T, int &tri, float (&v)[kAcc]) const {
+  const BwdRec *__restrict__ recs;
+  int T_;
+
+  struct Pixel {
+    F3 b, g;
+  };
+  struct Triangle {
+    float u[9], s[3], inv;
+  };
+
+  __device__ __forceinline__ bool load_pixel(size_t pix, int T, int &tri, Pixel &p) const {
     const int t = ids[pix];
-    const F3 b = bary[pix];
-    if ((unsigned)t >= (unsigned)T) return false;                           // foreign id
-    if (t == 0 && (b.x + b.y) + b.z < kDegenerateCutoff) return false;      // cpp:162
-    const F3 g = dbary[pix];
-    const float gb = g.x * b.x + g.y * b.y + g.z * b.z;
-    v[0] = g.x * b.x; v[1] = g.x * b.y; v[2] = g.x * b.z;
-    v[3] = g.y * b.x; v[4] = g.y * b.y; v[5] = g.y * b.z;
-    v[6] = g.z * b.x; v[7] = g.z * b.y; v[8] = g.z * b.z;
-    v[9] = gb * b.x; v[10] = gb * b.y; v[11] = gb * b.z;
+    p.b = bary[pix];
+    if ((unsigned)t >= (unsigned)T) return false;                               // foreign id
+    if (t == 0 && (p.b.x + p.b.y) + p.b.z < kDegenerateCutoff) return false;    // cpp:162
+    p.g = dbary[pix];
     tri = t;
     return true;
   }
-};
-
-__global__ __launch_bounds__(kThreads) void k_finalize(
-    const float *__restrict__ acc, const float4 *__restrict__ clip,
-    const int32_t *__restrict__ tris, int B, int V, int T, float *__restrict__ dclip) {
-  const long gid = (long)blockIdx.x * kThreads + threadIdx.x;
-  if (gid >= (long)B * T) return;
-  float a[kAcc];
-  bool any = false;
-#pragma unroll
-  for (int k = 0; k < kAcc; ++k) {
-    a[k] = acc[gid * kAcc + k];
-    any |= (a[k] != 0.0f);  // NaN counts as touched
+  __device__ __forceinline__ void load_triangle(int img, int tri, Triangle &t) const {
+    const BwdRec *r = recs + (size_t)img * T_ + tri;
+    const float4 a = r->a, b = r->b, c = r->c, d = r->d;
+    t.u[0] = a.x; t.u[1] = a.y; t.u[2] = a.z; t.u[3] = a.w;
+    t.u[4] = b.x; t.u[5] = b.y; t.u[6] = b.z; t.u[7] = b.w;
+    t.u[8] = c.x; t.s[0] = c.y; t.s[1] = c.z; t.s[2] = c.w;
+    t.inv = d.x;
   }
-  if (!any) return;  // no pixel of this triangle survived (or its gradient is 0)
-  const int b = (int)(gid / T);
-  const int t = (int)(gid - (long)b * T);
-  const int vi[3] = {tris[3 * t], tris[3 * t + 1], tris[3 * t + 2]};
-  float xs[3], ys[3], ws[3];
+  __device__ __forceinline__ void accumulate(const Pixel &p, const Triangle &t,
+                                             float (&acc)[kN]) const {
+    const float b[3] = {p.b.x, p.b.y, p.b.z};
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    if ((unsigned)vi[k] >= (unsigned)V) return;
-    const float4 p = clip[(long)b * V + vi[k]];
-    xs[k] = p.x; ys[k] = p.y; ws[k] = p.w;
-  }
-  const float a11 = xs[0], a12 = xs[1], a13 = xs[2];
-  const float a21 = ys[0], a22 = ys[1], a23 = ys[2];
-  const float a31 = ws[0], a32 = ws[1], a33 = ws[2];
-  float u[9];
-  u[0] = a22 * a33 - a32 * a23; u[1] = a13 * a32 - a33 * a12; u[2] = a12 * a23 - a22 * a13;
-  u[3] = a23 * a31 - a33 * a21; u[4] = a11 * a33 - a31 * a13; u[5] = a13 * a21 - a23 * a11;
-  u[6] = a21 * a32 - a31 * a22; u[7] = a12 * a31 - a32 * a11; u[8] = a11 * a22 - a21 * a12;
-  const float det = a11 * u[0] + a12 * u[3] + a13 * u[6];
-  if (det < 0.0f) {
+    for (int c = 0; c < 3; ++c) {
+      // S_c * b_i, shared by the three corners (cpp:202-230 computes it inline)
+      const float sb0 = t.s[c] * b[0], sb1 = t.s[c] * b[1], sb2 = t.s[c] * b[2];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) u[k] = -u[k];
-  }
-  const float inv_abs_det = 1.0f / fabsf(det);
-  const int out_col[3] = {0, 1, 3};  // x, y, w; the z column never receives gradient
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    const float colsum = u[c] + u[3 + c] + u[6 + c];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const float v = (colsum * a[9 + j] - (u[c] * a[j] + u[3 + c] * a[3 + j] + u[6 + c] * a[6 + j])) *
-                      inv_abs_det;
-      atomicAdd(&dclip[((long)b * V + vi[j]) * 4 + out_col[c]], v);
+      for (int j = 0; j < 3; ++j) {
+        const float d0 = (-t.u[0 + c]) * b[j] + sb0 * b[j];
+        const float d1 = (-t.u[3 + c]) * b[j] + sb1 * b[j];
+        const float d2 = (-t.u[6 + c]) * b[j] + sb2 * b[j];
+        const float v = (p.g.x * d0 + p.g.y * d1) + p.g.z * d2;  // cpp:232-269 numerator
+        acc[j * 3 + c] += v * t.inv;
+      }
     }
   }
+};
+
+__global__ __launch_bounds__(kThreads) void k_bwd_scatter(
+    const float *__restrict__ acc, const int32_t *__restrict__ tris, int B, int V, int T,
+    float *__restrict__ dclip) {
+  const long gid = (long)blockIdx.x * kThreads + threadIdx.x;
+  if (gid >= (long)B * T) return;
+  float a[9];
+  bool any = false;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    a[k] = acc[gid * kAccStride + k];
+    any |= (a[k] != 0.0f);  // NaN counts as touched
+  }
+  if (!any) return;
+  const int b = (int)(gid / T);
+  const int t = (int)(gid - (long)b * T);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int vi = tris[3 * t + j];
+    if ((unsigned)vi >= (unsigned)V) continue;
+    float *dst = dclip + ((long)b * V + vi) * 4;
+    atomicAdd(&dst[0], a[j * 3 + 0]);  // x
+    atomicAdd(&dst[1], a[j * 3 + 1]);  // y
+    atomicAdd(&dst[3], a[j * 3 + 2]);  // w; the z column never receives gradient
+  }
 }
+
+inline size_t acc_bytes(int B, int T) { return align_up((size_t)B * T * kAccStride * sizeof(float), 256); }
 
 }  // namespace
 
 size_t raster_backward_ws(int B, int V, int T, int W, int H) {
   (void)V; (void)W; (void)H;
-  return align_up((size_t)B * T * kAcc * sizeof(float), 256);
+  return acc_bytes(B, T) + align_up((size_t)B * T * sizeof(BwdRec), 256);
 }
 
 int launch_raster_backward(const float *dbary, const float *clip, const int32_t *tris,
                            const int32_t *ids, const float *bary, int B, int V, int T, int W,
                            int H, float *dclip, void *ws, hipStream_t s) {
-  float *acc = (float *)ws;
   if (B == 0 || V == 0) return MR_OK;
   if (hipMemsetAsync(dclip, 0, (size_t)B * V * 4 * sizeof(float), s) != hipSuccess) return check_launch();
   if (T == 0) return MR_OK;
-  if (hipMemsetAsync(acc, 0, (size_t)B * T * kAcc * sizeof(float), s) != hipSuccess) return check_launch();
-  RasterGradFn fn{(const F3 *)dbary, ids, (const F3 *)bary};
-  int rc = launch_accumulate_runs(fn, B, T, W, H, acc, s);
-  if (rc != MR_OK) return rc;
+  float *acc = (float *)ws;
+  BwdRec *recs = (BwdRec *)((char *)ws + acc_bytes(B, T));
+  if (hipMemsetAsync(acc, 0, (size_t)B * T * kAccStride * sizeof(float), s) != hipSuccess) return check_launch();
   const long nbt = (long)B * T;
-  hipLaunchKernelGGL(k_finalize, dim3((unsigned)((nbt + kThreads - 1) / kThreads)), dim3(kThreads),
-                     0, s, acc, (const float4 *)clip, tris, B, V, T, dclip);
+  const unsigned tri_blocks = (unsigned)((nbt + kThreads - 1) / kThreads);
+  hipLaunchKernelGGL(k_bwd_setup, dim3(tri_blocks), dim3(kThreads), 0, s, (const float4 *)clip,
+                     tris, B, V, T, recs);
+  int rc = check_launch();
+  if (rc != MR_OK) return rc;
+  RasterGradFn fn{(const F3 *)dbary, ids, (const F3 *)bary, recs, T};
+  rc = launch_accumulate_runs(fn, B, T, W, H, acc, s);
+  if (rc != MR_OK) return rc;
+  hipLaunchKernelGGL(k_bwd_scatter, dim3(tri_blocks), dim3(kThreads), 0, s, acc, tris, B, V, T, dclip);
   return check_launch();
 }
 

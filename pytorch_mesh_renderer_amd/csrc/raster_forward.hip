@@ -299,7 +299,8 @@ size_t raster_forward_ws(int B, int V, int T, int W, int H) {
          align_up((size_t)W * sizeof(float), 256) + align_up((size_t)H * sizeof(float), 256);
 }
 
-int g_raster_tile_shape = 0;  // 0: 8x8, 1: 16x4, 2: 32x2 (tuning hook, see mr_set_tuning)
+int g_raster_tile_shape = 0;  // 0: 8x8, 1: 16x4, 2: 32x2 (mr_set_raster_tile_shape)
+hipEvent_t g_raster_ev_start = nullptr, g_raster_ev_stop = nullptr;  // mr_set_raster_profile_events
 
 int launch_raster_forward(const float *clip, const int32_t *tris, int B, int V, int T, int W,
                           int H, int32_t *ids, float *bary, float *z, void *ws, hipStream_t s) {
@@ -330,12 +331,14 @@ int launch_raster_forward(const float *clip, const int32_t *tris, int B, int V, 
 #define MR_LAUNCH_RASTER(TW, TH)                                                              \
   hipLaunchKernelGGL((k_raster<TW, TH>), grid, block, 0, s, recs, bbs, pxtab, pytab, T, W, H, \
                      regions_x, per_image, n_regions, per_xcd, ids, bary, z)
+  if (g_raster_ev_start) (void)hipEventRecord(g_raster_ev_start, s);
   switch (g_raster_tile_shape) {
     case 1: MR_LAUNCH_RASTER(16, 4); break;
     case 2: MR_LAUNCH_RASTER(32, 2); break;
     default: MR_LAUNCH_RASTER(8, 8); break;
   }
 #undef MR_LAUNCH_RASTER
+  if (g_raster_ev_stop) (void)hipEventRecord(g_raster_ev_stop, s);
   return check_launch();
 }
 

@@ -15,9 +15,15 @@
 //   3. the table is drained once per workgroup with contiguous 48-byte global
 //      float atomics into acc[image][triangle][kAcc].
 //
-// PixelFn supplies the per-pixel values:
-//   struct Fn { __device__ bool operator()(size_t pix, int T, int &tri, float (&v)[12]) const; };
-// returning false for pixels that contribute nothing.
+// The functor supplies the per-pixel values:
+//   struct Fn {
+//     static constexpr int kN = ...;          // sums per triangle (<= 12)
+//     struct Pixel {...}; struct Triangle {...};
+//     __device__ bool load_pixel(size_t pix, int T, int &tri, Pixel &p) const;  // false: skip
+//     __device__ void load_triangle(int img, int tri, Triangle &t) const;       // on run change
+//     __device__ void accumulate(const Pixel &p, const Triangle &t, float (&a)[kN]) const;
+//   };
+// Per-triangle data (e.g. the adjugate) is fetched once per run, not per pixel.
 #pragma once
 
 #include "mr_internal.h"
@@ -29,7 +35,7 @@ constexpr int kRunRowsPerWave = 32;                                  // pixels e
 constexpr int kRunRegionH = kRunRowsPerWave * (kRunThreads / kWave);  // 128 rows / workgroup
 constexpr int kRunSlots = 512;                                       // LDS hash slots
 constexpr int kRunSlotsLog2 = 9;
-constexpr int kAcc = 12;
+constexpr int kAccStride = 12;  // floats per (image, triangle) row of acc[]: 48 B
 constexpr int kRunMaxProbe = 16;
 
 __device__ __forceinline__ int run_find_slot(int *keys, int tri) {
@@ -42,27 +48,30 @@ __device__ __forceinline__ int run_find_slot(int *keys, int tri) {
   return -1;
 }
 
+template <int N>
 __device__ __forceinline__ void run_flush(int *keys, float *vals, float *acc_img, int tri,
-                                          float (&a)[kAcc]) {
+                                          float (&a)[N]) {
   if (tri < 0) return;
   const int slot = run_find_slot(keys, tri);
   if (slot >= 0) {
 #pragma unroll
-    for (int k = 0; k < kAcc; ++k) atomicAdd(&vals[slot * kAcc + k], a[k]);
+    for (int k = 0; k < N; ++k) atomicAdd(&vals[slot * N + k], a[k]);
   } else {  // table saturated (very dense mesh): straight to HBM
 #pragma unroll
-    for (int k = 0; k < kAcc; ++k) atomicAdd(&acc_img[(size_t)tri * kAcc + k], a[k]);
+    for (int k = 0; k < N; ++k) atomicAdd(&acc_img[(size_t)tri * kAccStride + k], a[k]);
   }
 #pragma unroll
-  for (int k = 0; k < kAcc; ++k) a[k] = 0.0f;
+  for (int k = 0; k < N; ++k) a[k] = 0.0f;
 }
 
-template <class PixelFn>
+template <class Fn>
 __global__ __launch_bounds__(kRunThreads) void k_accumulate_runs(
-    PixelFn fn, int T, int W, int H, int regions_x, int regions_per_image, int n_regions,
+    Fn fn, int T, int W, int H, int regions_x, int regions_per_image, int n_regions,
     int regions_per_xcd, float *__restrict__ acc) {
+  constexpr int N = Fn::kN;
+  static_assert(N <= kAccStride, "accumulator row too small");
   __shared__ int s_keys[kRunSlots];
-  __shared__ float s_vals[kRunSlots * kAcc];
+  __shared__ float s_vals[kRunSlots * N];
 
   const int region = xcd_contiguous_block((int)blockIdx.x, n_regions, regions_per_xcd);
   if (region < 0) return;
@@ -73,7 +82,7 @@ __global__ __launch_bounds__(kRunThreads) void k_accumulate_runs(
 
   const int tid = (int)threadIdx.x;
   for (int i = tid; i < kRunSlots; i += kRunThreads) s_keys[i] = -1;
-  for (int i = tid; i < kRunSlots * kAcc; i += kRunThreads) s_vals[i] = 0.0f;
+  for (int i = tid; i < kRunSlots * N; i += kRunThreads) s_vals[i] = 0.0f;
   __syncthreads();
 
   const int lane = tid & (kWave - 1);
@@ -81,34 +90,35 @@ __global__ __launch_bounds__(kRunThreads) void k_accumulate_runs(
   const int x = rx * kWave + lane;
   const int y_begin = ry * kRunRegionH + wave * kRunRowsPerWave;
   const int y_end = min(y_begin + kRunRowsPerWave, H);
-  float *acc_img = acc + (size_t)img * T * kAcc;
+  float *acc_img = acc + (size_t)img * T * kAccStride;
 
   if (x < W) {
-    float a[kAcc];
+    float a[N];
 #pragma unroll
-    for (int k = 0; k < kAcc; ++k) a[k] = 0.0f;
+    for (int k = 0; k < N; ++k) a[k] = 0.0f;
     int run_tri = -1;
+    typename Fn::Triangle tri_data;
     size_t pix = ((size_t)img * H + y_begin) * W + x;
     for (int y = y_begin; y < y_end; ++y, pix += W) {
       int tri;
-      float v[kAcc];
-      if (!fn(pix, T, tri, v)) continue;
+      typename Fn::Pixel p;
+      if (!fn.load_pixel(pix, T, tri, p)) continue;
       if (tri != run_tri) {
-        run_flush(s_keys, s_vals, acc_img, run_tri, a);
+        run_flush<N>(s_keys, s_vals, acc_img, run_tri, a);
         run_tri = tri;
+        fn.load_triangle(img, tri, tri_data);
       }
-#pragma unroll
-      for (int k = 0; k < kAcc; ++k) a[k] += v[k];
+      fn.accumulate(p, tri_data, a);
     }
-    run_flush(s_keys, s_vals, acc_img, run_tri, a);
+    run_flush<N>(s_keys, s_vals, acc_img, run_tri, a);
   }
   __syncthreads();
 
-  // Drain: 16 lanes per slot (12 active) -> 48 contiguous bytes per triangle.
+  // Drain: 16 lanes per slot (N active) -> one contiguous <=48-byte row per triangle.
   for (int i = tid; i < kRunSlots * 16; i += kRunThreads) {
     const int slot = i >> 4, k = i & 15;
     const int tri = s_keys[slot];
-    if (tri >= 0 && k < kAcc) atomicAdd(&acc_img[(size_t)tri * kAcc + k], s_vals[slot * kAcc + k]);
+    if (tri >= 0 && k < N) atomicAdd(&acc_img[(size_t)tri * kAccStride + k], s_vals[slot * N + k]);
   }
 }
 

@@ -1,0 +1,157 @@
+"""Multi-GPU execution of render jobs: one process per GPU, batch-sharded.
+
+The reference is single-process and loops over the batch serially
+(src/mesh_renderer/rasterize.py:112-121); every image is an independent (camera,
+mesh) job, so the batch shards across ranks with NO data-path collective.  The only
+exchange is the hand-over of the finished images: one all-gather (or gather to a
+root) of [B_local, H, W, 4] float32 over RCCL / xGMI, which is independent of the
+backward pass and therefore issued on a side stream so that it overlaps it.  When
+all ranks optimise one shared mesh, its [V,3] gradient is summed with a (latency
+bound, 30 KB - 300 KB) all-reduce.
+
+torch.distributed's "nccl" backend is RCCL on ROCm; "gloo" is used by the CPU tests.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise the default process group from torchrun's environment.
+
+    Returns (rank, world_size, local_rank).  A single-process run (no WORLD_SIZE or
+    WORLD_SIZE=1) does not create a group."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        kwargs = {}
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            kwargs["device_id"] = torch.device("cuda", local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
+    return rank, world, local_rank
+
+
+def shard_bounds(n_items, rank, world_size):
+    """Contiguous, balanced [begin, end) of `n_items` independent jobs for `rank`:
+    the first n_items % world_size ranks get one extra job."""
+    base, extra = divmod(n_items, world_size)
+    begin = rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
+
+
+def shard_batch(tensors, rank, world_size):
+    """Slice every [B, ...] tensor of a dict to this rank's jobs (non-tensors pass through)."""
+    out = {}
+    for key, value in tensors.items():
+        if torch.is_tensor(value) and value.dim() > 0 and key != "triangles":
+            begin, end = shard_bounds(value.shape[0], rank, world_size)
+            out[key] = value[begin:end]
+        else:
+            out[key] = value
+    return out
+
+
+class ImageGather:
+    """All-gather of per-rank image shards, overlappable with the backward pass.
+
+    start(local) enqueues the collective on a side stream (GPU) and returns at once;
+    wait() makes the current stream wait for it and returns the [B_total, H, W, C]
+    tensor.  Shards may be uneven (they are padded to the largest one)."""
+
+    def __init__(self, n_total, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.n_total = n_total
+        self.counts = [shard_bounds(n_total, r, self.world)[1] - shard_bounds(n_total, r, self.world)[0]
+                       for r in range(self.world)]
+        self._side = None
+        self._out = None
+        self._work = None
+
+    def start(self, local):
+        if self.world == 1:
+            self._out = local
+            return
+        max_count = max(self.counts)
+        if local.shape[0] != self.counts[self.rank]:
+            raise ValueError("rank %d holds %d images, expected %d"
+                             % (self.rank, local.shape[0], self.counts[self.rank]))
+        on_gpu = local.is_cuda
+        if on_gpu:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=local.device)
+            self._side.wait_stream(torch.cuda.current_stream(local.device))
+        ctx = torch.cuda.stream(self._side) if on_gpu else _NullContext()
+        with ctx:
+            send = local.detach()
+            if send.shape[0] != max_count:
+                pad = torch.zeros((max_count - send.shape[0],) + tuple(send.shape[1:]),
+                                  dtype=send.dtype, device=send.device)
+                send = torch.cat([send, pad], 0)
+            send = send.contiguous()
+            if on_gpu:
+                send.record_stream(self._side)
+            gathered = torch.empty((self.world * max_count,) + tuple(send.shape[1:]),
+                                   dtype=send.dtype, device=send.device)
+            if dist.get_backend(self.group) == "gloo":
+                chunks = list(gathered.chunk(self.world, 0))
+                dist.all_gather(chunks, send, group=self.group)
+            else:
+                dist.all_gather_into_tensor(gathered, send, group=self.group)
+            self._out = gathered
+            self._max_count = max_count
+
+    def wait(self):
+        if self.world == 1:
+            return self._out
+        if self._side is not None:
+            torch.cuda.current_stream(self._out.device).wait_stream(self._side)
+        if all(c == self._max_count for c in self.counts):
+            return self._out
+        pieces = [self._out[r * self._max_count: r * self._max_count + c]
+                  for r, c in enumerate(self.counts)]
+        return torch.cat(pieces, 0)
+
+
+class _NullContext:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+def gather_images(local, n_total, group=None):
+    """Blocking convenience wrapper around ImageGather."""
+    g = ImageGather(n_total, group)
+    g.start(local)
+    return g.wait()
+
+
+def allreduce_shared_mesh_grad(grad, group=None):
+    """Sum the gradient of a mesh shared by all ranks (e.g. several views of one vertex
+    set): one small all-reduce, in place."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=group)
+    return grad
+
+
+def render_sharded(render_fn, batch, n_total, group=None):
+    """Render this rank's shard of `batch` (a dict of full-batch tensors, see
+    common.synthetic.sphere_job) with `render_fn(shard) -> [B_local,H,W,4]` and return
+    (local_images, gather_handle).  Call gather_handle.wait() after the backward."""
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    shard = shard_batch(batch, rank, world)
+    local = render_fn(shard)
+    handle = ImageGather(n_total, group)
+    handle.start(local)
+    return local, handle

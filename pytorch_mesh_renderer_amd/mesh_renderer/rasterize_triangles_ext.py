@@ -1,0 +1,74 @@
+"""Autograd boundary of the HIP rasterizer.
+
+Drop-in for src/mesh_renderer/rasterize_triangles_ext.py:6-63: same class name,
+same forward / backward signatures and return tuples.  The reference's class
+rasterizes ONE image per call; this one also accepts a batch ([B,V,4]) so that
+rasterize_clip_space does not need a Python loop over images
+(src/mesh_renderer/rasterize.py:112-121) -- on MI355X the batch is the grid.
+"""
+import torch
+
+from .. import _native
+
+
+class BarycentricRasterizer(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, clip_space_vertices, triangles, image_width, image_height):
+        """clip_space_vertices [V,4] or [B,V,4] f32, triangles [T,3] i32 ->
+        (px_triangle_ids [.., H, W] i32, px_barycentric_coords [.., H, W, 3] f32,
+         z_buffer [.., H, W] f32); ids are 0, barycentrics 0 and z 1.0 where no
+        triangle was drawn; row 0 is the bottom scanline."""
+        unbatched = clip_space_vertices.dim() == 2
+        clip = clip_space_vertices.detach()
+        if unbatched:
+            clip = clip.unsqueeze(0)
+        if clip.dtype != torch.float32:
+            raise RuntimeError("clip_space_vertices must be float32")
+        if triangles.dtype != torch.int32:
+            raise RuntimeError("triangles must be int32")
+        ids, bary, z = _native.rasterize_forward(clip, triangles, int(image_width), int(image_height))
+        ctx.save_for_backward(clip, triangles, ids, bary)
+        ctx.unbatched = unbatched
+        ctx.mark_non_differentiable(ids)
+        if unbatched:
+            return ids[0], bary[0], z[0]
+        return ids, bary, z
+
+    @staticmethod
+    def backward(ctx, _, df_dbarycentric_coords, __):
+        """Gradient w.r.t. clip-space vertices only; triangles get zeros, sizes None
+        and the gradient of z is ignored, as in the reference (:46-63)."""
+        clip, triangles, ids, bary = ctx.saved_tensors
+        dbary = df_dbarycentric_coords
+        if ctx.unbatched:
+            dbary = dbary.unsqueeze(0)
+        dclip = _native.rasterize_backward(dbary.contiguous(), clip, triangles, ids, bary)
+        if ctx.unbatched:
+            dclip = dclip[0]
+        return dclip, torch.zeros_like(triangles), None, None
+
+
+class AttributeInterpolator(torch.autograd.Function):
+    """Deferred attribute interpolation + alpha / background blend as one HIP op.
+
+    Fuses the gather / multiply / sum / clamp / blend block of
+    src/mesh_renderer/rasterize.py:118-150 and its autograd backward."""
+
+    @staticmethod
+    def forward(ctx, ids, bary, attributes, triangles, background):
+        out = _native.interpolate_forward(ids, bary.detach(), attributes.detach(), triangles,
+                                          background.detach())
+        ctx.save_for_backward(ids, bary.detach(), attributes.detach(), triangles, background.detach())
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        ids, bary, attributes, triangles, background = ctx.saved_tensors
+        dattrs, dbary = _native.interpolate_backward(dout.contiguous(), ids, bary, attributes,
+                                                     triangles, background)
+        dbackground = None
+        if ctx.needs_input_grad[4]:
+            # d/d background = sum over pixels of (1 - alpha) * dout  (rasterize.py:149-150)
+            alpha = torch.clamp(2.0 * bary.sum(-1, keepdim=True), 0.0, 1.0)
+            dbackground = ((1.0 - alpha) * dout).sum(dim=(0, 1, 2))
+        return None, dbary, dattrs, None, dbackground

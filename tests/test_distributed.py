@@ -1,0 +1,74 @@
+"""CPU suite, part 3: the N>1 path (batch sharding + image gather) over gloo, world_size 2.
+
+The HIP kernels need a GPU, so the per-rank "renderer" here is the CPU oracle: what is
+under test is the host logic of pytorch_mesh_renderer_amd.distributed -- shard bounds,
+uneven shards, the all-gather hand-over and the shared-mesh gradient all-reduce.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle
+from pytorch_mesh_renderer_amd import distributed
+from pytorch_mesh_renderer_amd.common import synthetic
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _oracle_render(shard, width, height):
+    ids, bary, z = oracle.forward(shard["clip"].numpy(), shard["triangles"].numpy(), width, height)
+    return torch.from_numpy(np.concatenate([bary, z[..., None]], -1))  # [B_local,H,W,4]
+
+
+def _worker(rank, world, port, n_total, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    r, w, _ = distributed.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    job = synthetic.sphere_job(n_total, 48, 40, 6)
+    local, handle = distributed.render_sharded(lambda s: _oracle_render(s, 48, 40), job, n_total)
+    begin, end = distributed.shard_bounds(n_total, rank, world)
+    assert local.shape[0] == end - begin
+    full = handle.wait()
+    grad = torch.full((job["vertices"].shape[1], 3), float(rank + 1))
+    distributed.allreduce_shared_mesh_grad(grad)
+    torch.save({"full": full, "grad": grad}, os.path.join(out_dir, "rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [4, 5])   # even and uneven shards
+def test_sharded_render_and_gather_world2(tmp_path, n_total):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), n_total, str(tmp_path)), nprocs=world, join=True)
+    job = synthetic.sphere_job(n_total, 48, 40, 6)
+    want = _oracle_render(job, 48, 40)
+    for rank in range(world):
+        got = torch.load(os.path.join(str(tmp_path), "rank%d.pt" % rank))
+        assert got["full"].shape == want.shape
+        assert torch.equal(got["full"], want), "gathered images differ from the single-process render"
+        assert torch.all(got["grad"] == 3.0)   # 1 + 2: summed over ranks
+
+
+def test_shard_bounds_cover_and_balance():
+    for n in (0, 1, 7, 32, 33, 64):
+        for world in (1, 2, 3, 8):
+            spans = [distributed.shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [e - b for b, e in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_single_process_gather_is_identity():
+    x = torch.arange(24.0).reshape(2, 3, 4, 1)
+    assert torch.equal(distributed.gather_images(x, 2), x)

@@ -1,0 +1,170 @@
+"""CPU suite, part 2: host logic and the C-ABI library (no GPU compute here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, golden_json, golden_npz, sha
+from pytorch_mesh_renderer_amd import _native, mesh_renderer
+from pytorch_mesh_renderer_amd.common import camera_utils, shapes, synthetic
+from pytorch_mesh_renderer_amd.mesh_renderer import rasterize as rasterize_module  # the function
+import sys
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "mesh_raster.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mr_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(_native.LIB_PATH):
+        _native.build()
+    lib = ctypes.CDLL(_native.LIB_PATH)
+    names = _declared_symbols()
+    assert len(names) >= 9
+    for name in names:
+        assert hasattr(lib, name), "include/mesh_raster.h declares %s but the .so lacks it" % name
+    assert _native.lib().mr_version() >= 100
+
+
+def test_abi_argument_validation_without_gpu():
+    L = _native.lib()
+    # bad sizes are rejected before anything touches a device
+    assert L.mr_rasterize_forward_workspace_bytes(1, 8, 12, 0, 64) == 0
+    assert L.mr_rasterize_forward_workspace_bytes(1, 8, 12, 70000, 64) == 0
+    need = L.mr_rasterize_forward_workspace_bytes(32, 2502, 5000, 1024, 1024)
+    assert need >= 32 * 5000 * 72
+    null = ctypes.c_void_p(0)
+    assert L.mr_rasterize_forward(null, null, 1, 8, 12, 64, 64, null, null, null, null, 0, null) == _native.MR_EINVAL
+    assert L.mr_rasterize_forward(null, null, -1, 8, 12, 64, 64, null, null, null, null, 0, null) == _native.MR_EINVAL
+    assert L.mr_set_raster_tile_shape(7) == _native.MR_EINVAL
+
+
+def test_no_cpu_fallback():
+    clip = torch.zeros(3, 4)
+    tris = torch.zeros(1, 3, dtype=torch.int32)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        from pytorch_mesh_renderer_amd.mesh_renderer.rasterize import rasterize_barycentric
+        rasterize_barycentric(clip, tris, 8, 8)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "pytorch_mesh_renderer_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                assert "mr_oracle" not in src and "libmr_oracle" not in src, f
+
+
+def test_shapes_match_reference_hashes():
+    h = golden_json("shapes_hashes.json")
+    for k in (50, 158):
+        v, t, n = shapes.sphere(1.0, k)
+        e = h["sphere_%d" % k]
+        assert (v.shape[0], t.shape[0]) == (e["V"], e["T"])
+        assert sha(v.numpy()) == e["vertices"] and sha(t.numpy()) == e["triangles"]
+        assert sha(n.numpy()) == e["normals"]
+    v, t, n = shapes.cube(2.0)
+    assert sha(v.numpy()) == h["cube_2"]["vertices"] and sha(t.numpy()) == h["cube_2"]["triangles"]
+    assert shapes.sphere(1.0, 50)[1].shape == (5000, 3)
+
+
+def test_camera_utils_match_reference():
+    g = golden_npz("camera_utils.npz")
+    eyes = torch.from_numpy(g["eyes"])
+    look = camera_utils.look_at(eyes, torch.zeros(5, 3), torch.tensor(5 * [[0.0, 1.0, 0.0]]))
+    np.testing.assert_allclose(look.numpy(), g["look_at"], atol=1e-7, rtol=0)
+    persp = camera_utils.perspective(1.25, torch.tensor([40.0, 13.3]), torch.tensor([0.01, 0.1]),
+                                     torch.tensor([10.0, 25.0]))
+    np.testing.assert_allclose(persp.numpy(), g["perspective"], atol=0, rtol=0)
+    euler = camera_utils.euler_matrices(torch.from_numpy(g["euler_in"]))
+    np.testing.assert_allclose(euler.numpy(), g["euler"], atol=1e-7, rtol=0)
+    tone = mesh_renderer.tone_mapper(torch.from_numpy(g["tone_in"]), 0.7)
+    np.testing.assert_allclose(tone.numpy(), g["tone_out"], atol=1e-6, rtol=0)
+
+
+def test_camera_utils_errors():
+    with pytest.raises(AssertionError, match="eye and center are close"):
+        camera_utils.look_at(torch.zeros(1, 3), torch.zeros(1, 3), torch.tensor([[0.0, 1.0, 0.0]]))
+    with pytest.raises(AssertionError, match="up and gaze are too close"):
+        camera_utils.look_at(torch.zeros(1, 3), torch.tensor([[0.0, 1.0, 0.0]]),
+                             torch.tensor([[0.0, 1.0, 0.0]]))
+    with pytest.raises(ValueError, match="matrices must have 3 dimensions"):
+        camera_utils.transform_homogeneous(torch.eye(4), torch.zeros(1, 3, 3))
+    with pytest.raises(ValueError, match="vertices must have 3 dimensions"):
+        camera_utils.transform_homogeneous(torch.eye(4).unsqueeze(0), torch.zeros(3, 3))
+
+
+def test_camera_utils_are_differentiable():
+    eye = torch.tensor([[0.0, 0.0, 6.0]], requires_grad=True)  # the reference cannot do this
+    m = camera_utils.look_at(eye, torch.zeros(1, 3), torch.tensor([[0.0, 1.0, 0.0]]))
+    m.sum().backward()
+    assert eye.grad is not None and torch.isfinite(eye.grad).all()
+
+
+def _scene(batch=2):
+    v, t, n = shapes.cube(2.0)
+    rep = lambda x: x.unsqueeze(0).repeat(batch, 1, 1)
+    return dict(vertices=rep(v), triangles=t, normals=rep(n), diffuse_colors=torch.ones(batch, 8, 3),
+                camera_position=torch.tensor([0.0, 0.0, 6.0]), camera_lookat=torch.zeros(3),
+                camera_up=torch.tensor([0.0, 1.0, 0.0]),
+                light_positions=torch.zeros(batch, 1, 3), light_intensities=torch.ones(batch, 1, 3),
+                image_width=8, image_height=8)
+
+
+@pytest.mark.parametrize("patch,message", [
+    (dict(vertices=torch.zeros(8, 3)), "Vertices must have shape"),
+    (dict(normals=torch.zeros(2, 8, 2)), "Normals must have shape"),
+    (dict(light_positions=torch.zeros(2, 3)), "light_positions must have shape"),
+    (dict(light_intensities=torch.zeros(2, 1, 4)), "light_intensities must have shape"),
+    (dict(diffuse_colors=torch.zeros(2, 8)), "diffuse_colors must have shape"),
+    (dict(ambient_color=torch.zeros(3)), "ambient_color must have shape"),
+    (dict(camera_position=torch.zeros(5, 3)), "camera_position must have shape"),
+    (dict(camera_lookat=torch.zeros(2)), "camera_lookat must have shape"),
+    (dict(camera_up=torch.zeros(4, 3)), "camera_up must have shape"),
+    (dict(fov_y=torch.zeros(3)), "fov_y must be a float"),
+    (dict(near_clip=torch.zeros(3)), "near_clip must be a float"),
+    (dict(far_clip=torch.zeros(3)), "far_clip must be a float"),
+    (dict(specular_colors=torch.zeros(2, 8, 3)), "without shininess"),
+    (dict(shininess_coefficients=6.0), "without specular"),
+    (dict(specular_colors=torch.zeros(2, 8, 3), shininess_coefficients=torch.zeros(2, 8, 1)),
+     "at most"),
+])
+def test_render_value_errors(patch, message):
+    args = _scene()
+    args.update(patch)
+    with pytest.raises(ValueError, match=message):
+        mesh_renderer.render(**args)
+
+
+def test_rasterize_value_errors():
+    from pytorch_mesh_renderer_amd.mesh_renderer.rasterize import rasterize_clip_space
+    clip, attrs = torch.zeros(1, 3, 4), torch.zeros(1, 3, 2)
+    tris, bg = torch.zeros(1, 3, dtype=torch.int32), torch.zeros(2)
+    with pytest.raises(ValueError, match="Image width"):
+        rasterize_clip_space(clip, attrs, tris, 0, 4, bg)
+    with pytest.raises(ValueError, match="Image height"):
+        rasterize_clip_space(clip, attrs, tris, 4, 0, bg)
+    with pytest.raises(ValueError, match="must be 3D"):
+        rasterize_clip_space(clip[0], attrs, tris, 4, 4, bg)
+
+
+def test_export_surface_matches_reference_package():
+    assert callable(mesh_renderer.render) and callable(mesh_renderer.tone_mapper)
+    assert callable(mesh_renderer.rasterize) and callable(rasterize_module)
+    # (as in the reference, the functions shadow their submodules on the package object)
+    assert callable(sys.modules['pytorch_mesh_renderer_amd.mesh_renderer.render'].phong_shader)
+    import pytorch_mesh_renderer_amd.mesh_renderer.rasterize_triangles_ext as ext
+    assert issubclass(ext.BarycentricRasterizer, torch.autograd.Function)
+
+
+def test_synthetic_job_is_deterministic():
+    a, b = synthetic.sphere_job(3, 64, 48, 6), synthetic.sphere_job(3, 64, 48, 6)
+    assert torch.equal(a["clip"], b["clip"]) and a["clip"].shape == (3, 38, 4)
+    assert torch.allclose(a["eyes"].norm(dim=1), torch.full((3,), 3.0), atol=1e-5)

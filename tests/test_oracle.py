@@ -1,0 +1,171 @@
+"""CPU suite, part 1: the oracle is pinned against the reference.
+
+oracle/mr_oracle.c must reproduce, bit for bit, every golden vector that
+tools/make_goldens.py captured from the reference's own kernel, and -- when the
+compiled reference (oracle/_ref) is present -- the reference itself on fresh
+random inputs.  oracle/shading.py must reproduce the reference's rasterize() /
+render() outputs and gradients.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import shading
+from conftest import (TRIANGLE_CASES, bits_equal, golden_json, golden_npz, seeded_dbary, sha)
+from pytorch_mesh_renderer_amd.common import synthetic
+
+
+def test_cube64_bitwise():
+    g = golden_npz("raster_cube64.npz")
+    ids, bary, z = oracle.forward(g["clip"], g["triangles"], 64, 64)
+    assert bits_equal(ids, g["ids"]) and bits_equal(bary, g["bary"]) and bits_equal(z, g["z"])
+    dclip = oracle.backward(g["dbary"], g["clip"], g["triangles"], ids, bary)
+    assert bits_equal(dclip, g["dclip"])
+    assert np.all(dclip[:, 2] == 0.0)  # the z column never receives gradient
+
+
+@pytest.mark.parametrize("case", TRIANGLE_CASES)
+def test_triangle_cases_bitwise(case):
+    g = golden_npz("raster_triangles_160x120.npz")
+    clip, tris = g[case + ".clip"], g[case + ".triangles"]
+    ids, bary, z = oracle.forward(clip, tris, 160, 120)
+    assert bits_equal(ids, g[case + ".ids"])
+    assert bits_equal(bary, g[case + ".bary"])
+    assert bits_equal(z, g[case + ".z"])
+    dbary = seeded_dbary((120, 160, 3), seed=1).numpy()
+    assert bits_equal(oracle.backward(dbary, clip, tris, ids, bary), g[case + ".dclip"])
+
+
+def test_reference_semantics_in_goldens():
+    """Behaviours the survey probed on the reference (no culling, ties, clipping)."""
+    g = golden_npz("raster_triangles_160x120.npz")
+    covered = lambda c: int((g[c + ".bary"].sum(-1) > 0.5).sum())
+    assert covered("w_111") == covered("reversed_winding") > 0        # both windings draw
+    assert covered("all_w_negative") == 0 and covered("collinear") == 0
+    assert covered("beyond_far_plane") == 0                            # z > 1 rejected
+    tie = g["coincident_tie.ids"][g["coincident_tie.bary"].sum(-1) > 0.5]
+    assert np.all(tie == 1)                                            # ties -> later id
+    assert covered("one_w_negative") > covered("w_111")                # full-screen bbox path
+
+
+def test_native_resolution_triangles_hashes():
+    g = golden_npz("raster_triangles_160x120.npz")
+    h = golden_json("raster_triangles_640x480.json")
+    for case in ("w_111", "w_perspective"):
+        ids, bary, z = oracle.forward(g[case + ".clip"], g[case + ".triangles"], 640, 480)
+        assert sha(ids) == h[case]["ids"] and sha(bary) == h[case]["bary"] and sha(z) == h[case]["z"]
+        d = oracle.backward(seeded_dbary((480, 640, 3), seed=1).numpy(), g[case + ".clip"],
+                            g[case + ".triangles"], ids, bary)
+        assert bits_equal(d, np.array(h[case]["dclip"], np.float32))
+
+
+def test_jacobian_28x21_bitwise():
+    g = golden_npz("raster_jacobian_28x21.npz")
+    ids, bary, z = oracle.forward(g["clip"], g["triangles"], 28, 21)
+    assert bits_equal(ids, g["ids"]) and bits_equal(bary, g["bary"])
+    n = 21 * 28 * 3
+    for i in range(0, n, 7):  # every 7th column of the Jacobian
+        e = np.zeros(n, np.float32)
+        e[i] = 1.0
+        d = oracle.backward(e.reshape(21, 28, 3), g["clip"], g["triangles"], ids, bary)
+        assert bits_equal(d.reshape(-1), g["jacobian"][:, i])
+
+
+def test_sphere_256_all_cameras():
+    h = golden_json("raster_sphere_hashes.json")["c2_256x256_b8"]
+    job = synthetic.sphere_job(8, 256, 256, 50)
+    assert sha(job["clip"].numpy()) == h["clip"]  # same input bits as when the goldens were made
+    ids, bary, z = oracle.forward(job["clip"].numpy(), job["triangles"].numpy(), 256, 256, threads=8)
+    for b in range(8):
+        assert sha(ids[b]) == h["cameras"][b]["ids"]
+        assert sha(bary[b]) == h["cameras"][b]["bary"]
+        assert sha(z[b]) == h["cameras"][b]["z"]
+        d = oracle.backward(seeded_dbary((256, 256, 3), seed=b).numpy(), job["clip"][b].numpy(),
+                            job["triangles"].numpy(), ids[b], bary[b])
+        assert sha(d) == h["cameras"][b]["dclip"]
+    cam0 = golden_npz("raster_sphere256_cam0.npz")
+    assert bits_equal(ids[0], cam0["ids"]) and bits_equal(z[0], cam0["z"])
+
+
+def test_sphere_1024_picked_cameras():
+    h = golden_json("raster_sphere_hashes.json")["c3_1024x1024_b32"]
+    dgold = golden_npz("raster_sphere1024_dclip.npz")
+    job = synthetic.sphere_job(32, 1024, 1024, 50)
+    assert sha(job["clip"].numpy()) == h["clip"]
+    for b in (0, 16):
+        clip = job["clip"][b].numpy()
+        ids, bary, z = oracle.forward(clip, job["triangles"].numpy(), 1024, 1024)
+        hb = h["cameras"][str(b)]
+        assert sha(ids) == hb["ids"] and sha(bary) == hb["bary"] and sha(z) == hb["z"]
+        d = oracle.backward(seeded_dbary((1024, 1024, 3), seed=b).numpy(), clip,
+                            job["triangles"].numpy(), ids, bary)
+        assert bits_equal(d, dgold["dclip_%d" % b])
+
+
+@pytest.mark.skipif(not oracle.have_reference_kernel(), reason="oracle/_ref not built")
+def test_against_compiled_reference_random():
+    """Differential fuzz: random soups, odd sizes, vertices behind the eye."""
+    rng = np.random.default_rng(1234)
+    for trial in range(12):
+        V, T = int(rng.integers(3, 40)), int(rng.integers(1, 60))
+        W, H = int(rng.integers(1, 90)), int(rng.integers(1, 70))
+        clip = rng.normal(size=(V, 4)).astype(np.float32)
+        clip[:, 3] = np.abs(clip[:, 3]) + 0.2 if trial % 3 else clip[:, 3]  # some w <= 0
+        tris = rng.integers(0, V, size=(T, 3)).astype(np.int32)
+        ids, bary, z = oracle.forward(clip, tris, W, H)
+        r_ids, r_bary, r_z = oracle.reference_forward(clip, tris, W, H)
+        assert bits_equal(ids, r_ids) and bits_equal(bary, r_bary) and bits_equal(z, r_z)
+        g = rng.normal(size=(H, W, 3)).astype(np.float32)
+        assert bits_equal(oracle.backward(g, clip, tris, ids, bary),
+                          oracle.reference_backward(g, clip, tris, r_ids, r_bary))
+
+
+def test_threaded_equals_serial():
+    job = synthetic.sphere_job(4, 96, 64, 10)
+    a = oracle.forward(job["clip"].numpy(), job["triangles"].numpy(), 96, 64, threads=1)
+    b = oracle.forward(job["clip"].numpy(), job["triangles"].numpy(), 96, 64, threads=4)
+    assert all(bits_equal(x, y) for x, y in zip(a, b))
+
+
+# ---- shading oracle (torch CPU restatement of rasterize() / render()) ---------------------------
+
+def _t(a, grad=False):
+    t = torch.from_numpy(np.array(a))
+    return t.requires_grad_(True) if grad else t
+
+
+def test_shading_oracle_rasterize_unlit_cube():
+    g = golden_npz("rasterize_unlit_cube_64x48.npz")
+    v, a = _t(g["vertices"], True), _t(g["attributes"], True)
+    out = shading.rasterize(v, a, _t(g["triangles"]), _t(g["projection"]), 64, 48, _t(g["background"]))
+    np.testing.assert_allclose(out.detach().numpy(), g["out"], atol=1e-6, rtol=0)
+    torch.mean(torch.abs(out - _t(g["target"]))).backward()
+    np.testing.assert_allclose(v.grad.numpy(), g["dvertices"], atol=1e-6, rtol=0)
+    np.testing.assert_allclose(a.grad.numpy(), g["dattributes"], atol=1e-7, rtol=0)
+
+
+@pytest.mark.parametrize("name", ["render_gray_cube_64x48.npz", "render_lit_cube_64x48.npz",
+                                  "render_specular_cube_64x48.npz",
+                                  "render_specular_scalar_cube_64x48.npz",
+                                  "render_sphere5k_128.npz"])
+def test_shading_oracle_render(name):
+    g = golden_npz(name)
+    h, w = g["image"].shape[1:3]
+    leaves = {k: _t(g[k], True) for k in ("vertices", "normals", "diffuse", "light_positions",
+                                         "light_intensities")}
+    spec = _t(g["specular"], True) if "specular" in g.files else None
+    amb = _t(g["ambient"], True) if "ambient" in g.files else None
+    shine = _t(g["shininess"]) if "shininess" in g.files else None
+    img = shading.render(leaves["vertices"], _t(g["triangles"]), leaves["normals"], leaves["diffuse"],
+                         _t(g["eye"]), _t(g["center"]), _t(g["up"]), leaves["light_positions"],
+                         leaves["light_intensities"], w, h, specular_colors=spec,
+                         shininess_coefficients=shine, ambient_color=amb)
+    np.testing.assert_allclose(img.detach().numpy(), g["image"], atol=2e-6, rtol=0)
+    torch.mean(torch.abs(img - _t(g["target"]))).backward()
+    for k, t in leaves.items():
+        np.testing.assert_allclose(t.grad.numpy(), g["d_" + k], atol=2e-6, rtol=0, err_msg=k)
+    if spec is not None:
+        np.testing.assert_allclose(spec.grad.numpy(), g["d_specular"], atol=2e-6, rtol=0)
+    if amb is not None:
+        np.testing.assert_allclose(amb.grad.numpy(), g["d_ambient"], atol=2e-6, rtol=0)

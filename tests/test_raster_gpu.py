@@ -1,0 +1,263 @@
+"""GPU parity, kernel level: HIP rasterizer (through the C ABI) vs oracle and goldens.
+
+Bar (BASELINE.json north_star): triangle ids, z-buffer and barycentrics BIT-EXACT;
+gradients within 1e-4 abs under the normalised upstream gradient randn/(H*W).
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import (TRIANGLE_CASES, bits_equal, golden_json, golden_npz, seeded_dbary, sha)
+from pytorch_mesh_renderer_amd import _native
+from pytorch_mesh_renderer_amd.common import synthetic
+from pytorch_mesh_renderer_amd.mesh_renderer.rasterize import rasterize_barycentric
+
+pytestmark = pytest.mark.gpu
+GRAD_ATOL = 1e-4  # north_star tolerance for gradients
+
+
+def hip_forward(clip, tris, w, h, device):
+    c = torch.as_tensor(clip).to(device)
+    t = torch.as_tensor(tris).to(device)
+    if c.dim() == 2:
+        ids, bary, z = _native.rasterize_forward(c.unsqueeze(0), t, w, h)
+        return ids[0].cpu().numpy(), bary[0].cpu().numpy(), z[0].cpu().numpy()
+    ids, bary, z = _native.rasterize_forward(c, t, w, h)
+    return ids.cpu().numpy(), bary.cpu().numpy(), z.cpu().numpy()
+
+
+def hip_backward(dbary, clip, tris, ids, bary, device):
+    args = [torch.as_tensor(np.ascontiguousarray(a)).to(device) for a in (dbary, clip, tris, ids, bary)]
+    if args[1].dim() == 2:
+        args = [a.unsqueeze(0) if i != 2 else a for i, a in enumerate(args)]
+        return _native.rasterize_backward(*args)[0].cpu().numpy()
+    return _native.rasterize_backward(*args).cpu().numpy()
+
+
+def assert_forward_bitwise(got, want):
+    for name, a, b in zip(("ids", "bary", "z"), got, want):
+        assert bits_equal(a, b), "%s differs in %d elements" % (name, int((a != b).sum()))
+
+
+def test_cube64_golden(device):
+    g = golden_npz("raster_cube64.npz")
+    got = hip_forward(g["clip"], g["triangles"], 64, 64, device)
+    assert_forward_bitwise(got, (g["ids"], g["bary"], g["z"]))
+    d = hip_backward(g["dbary"], g["clip"], g["triangles"], g["ids"], g["bary"], device)
+    np.testing.assert_allclose(d, g["dclip"], atol=GRAD_ATOL, rtol=0)
+    assert np.all(d[:, 2] == 0.0)
+
+
+@pytest.mark.parametrize("case", TRIANGLE_CASES)
+def test_triangle_cases_golden(device, case):
+    g = golden_npz("raster_triangles_160x120.npz")
+    clip, tris = g[case + ".clip"], g[case + ".triangles"]
+    got = hip_forward(clip, tris, 160, 120, device)
+    assert_forward_bitwise(got, (g[case + ".ids"], g[case + ".bary"], g[case + ".z"]))
+    d = hip_backward(seeded_dbary((120, 160, 3), seed=1).numpy(), clip, tris, got[0], got[1], device)
+    np.testing.assert_allclose(d, g[case + ".dclip"], atol=GRAD_ATOL, rtol=0)
+
+
+def test_reference_test_triangles_640x480(device):
+    g = golden_npz("raster_triangles_160x120.npz")
+    h = golden_json("raster_triangles_640x480.json")
+    for case in ("w_111", "w_perspective"):
+        ids, bary, z = hip_forward(g[case + ".clip"], g[case + ".triangles"], 640, 480, device)
+        assert sha(ids) == h[case]["ids"] and sha(bary) == h[case]["bary"] and sha(z) == h[case]["z"]
+
+
+def test_jacobian_28x21(device):
+    """Counterpart of testInternalRenderGradientComputation: the analytic Jacobian itself."""
+    g = golden_npz("raster_jacobian_28x21.npz")
+    got = hip_forward(g["clip"], g["triangles"], 28, 21, device)
+    assert_forward_bitwise(got, (g["ids"], g["bary"], g["z"]))
+    n = 21 * 28 * 3
+    cols = list(range(0, n, 5))
+    # one batched launch: image k carries the k-th unit upstream gradient
+    e = np.zeros((len(cols), n), np.float32)
+    e[np.arange(len(cols)), cols] = 1.0
+    rep = lambda a: np.repeat(a[None], len(cols), 0)
+    d = hip_backward(e.reshape(len(cols), 21, 28, 3), rep(g["clip"]), g["triangles"],
+                     rep(g["ids"]), rep(g["bary"]), device)
+    want = g["jacobian"][:, cols].T.reshape(len(cols), 8, 4)
+    np.testing.assert_allclose(d, want, atol=1e-4, rtol=1e-5)
+
+
+def test_sphere_256_b8_config2(device):
+    """BASELINE config 2: 5k-tri sphere, 256x256, batch 8, forward G-buffer."""
+    h = golden_json("raster_sphere_hashes.json")["c2_256x256_b8"]
+    job = synthetic.sphere_job(8, 256, 256, 50)
+    assert sha(job["clip"].numpy()) == h["clip"]
+    ids, bary, z = hip_forward(job["clip"].numpy(), job["triangles"].numpy(), 256, 256, device)
+    for b in range(8):
+        assert sha(ids[b]) == h["cameras"][b]["ids"], b
+        assert sha(bary[b]) == h["cameras"][b]["bary"], b
+        assert sha(z[b]) == h["cameras"][b]["z"], b
+    dbary = np.stack([seeded_dbary((256, 256, 3), seed=b).numpy() for b in range(8)])
+    d = hip_backward(dbary, job["clip"].numpy(), job["triangles"].numpy(), ids, bary, device)
+    cam0 = golden_npz("raster_sphere256_cam0.npz")
+    np.testing.assert_allclose(d[0], cam0["dclip"], atol=GRAD_ATOL, rtol=0)
+    want = oracle.backward(dbary, job["clip"].numpy(), job["triangles"].numpy(), ids, bary, threads=8)
+    np.testing.assert_allclose(d, want, atol=GRAD_ATOL, rtol=0)
+
+
+def test_sphere_1024_b32_config3_full_size(device):
+    """BASELINE config 3 at full size: hashes of the reference's own output for 4 of
+    the 32 cameras, size-independent properties for all of them."""
+    h = golden_json("raster_sphere_hashes.json")["c3_1024x1024_b32"]
+    dgold = golden_npz("raster_sphere1024_dclip.npz")
+    job = synthetic.sphere_job(32, 1024, 1024, 50)
+    assert sha(job["clip"].numpy()) == h["clip"]
+    clip_d, tris_d = job["clip"].to(device), job["triangles"].to(device)
+    ids, bary, z = _native.rasterize_forward(clip_d, tris_d, 1024, 1024)
+    for b in (0, 7, 16, 29):
+        hb = h["cameras"][str(b)]
+        assert sha(ids[b].cpu().numpy()) == hb["ids"], b
+        assert sha(bary[b].cpu().numpy()) == hb["bary"], b
+        assert sha(z[b].cpu().numpy()) == hb["z"], b
+    # properties for every image: barycentrics sum to 1 on covered pixels, are exactly 0 with
+    # z == 1 and id == 0 elsewhere; z in [-1, 1]; ids in range
+    s = bary.sum(-1)
+    covered = s > 0.5
+    assert torch.all((s[covered] - 1.0).abs() < 1e-5)
+    assert torch.all(bary[~covered] == 0) and torch.all(z[~covered] == 1.0) and torch.all(ids[~covered] == 0)
+    assert torch.all(z[covered] >= -1.0) and torch.all(z[covered] <= 1.0)
+    assert int(ids.min()) >= 0 and int(ids.max()) < 5000
+    frac = covered.float().mean().item()
+    assert 0.70 < frac < 0.78  # the sphere fills ~74 % of the frame
+    # idempotence: a second launch gives the same bits
+    ids2, bary2, z2 = _native.rasterize_forward(clip_d, tris_d, 1024, 1024)
+    assert torch.equal(ids, ids2) and torch.equal(bary, bary2) and torch.equal(z, z2)
+    # backward vs the reference's own df_dvertices
+    dbary = torch.stack([seeded_dbary((1024, 1024, 3), seed=b) for b in range(32)]).to(device)
+    d = _native.rasterize_backward(dbary, clip_d, tris_d, ids, bary).cpu().numpy()
+    for b in (0, 7, 16, 29):
+        np.testing.assert_allclose(d[b], dgold["dclip_%d" % b], atol=GRAD_ATOL, rtol=0)
+    assert np.all(d[:, :, 2] == 0)
+    # linearity of the backward in the upstream gradient
+    d2 = _native.rasterize_backward(2.0 * dbary, clip_d, tris_d, ids, bary).cpu().numpy()
+    np.testing.assert_allclose(d2, 2.0 * d, atol=1e-6, rtol=1e-4)
+    # g == const  =>  gradient ~ 0 (barycentrics sum to one)
+    ones = torch.full_like(dbary, 1.0 / (1024 * 1024))
+    d1 = _native.rasterize_backward(ones, clip_d, tris_d, ids, bary).cpu().numpy()
+    assert np.abs(d1).max() < 1e-4
+
+
+@pytest.mark.parametrize("shape", [0, 1, 2])
+def test_tile_shapes_agree(device, shape):
+    job = synthetic.sphere_job(2, 200, 136, 20)
+    want = oracle.forward(job["clip"].numpy(), job["triangles"].numpy(), 200, 136)
+    _native.lib().mr_set_raster_tile_shape(shape)
+    try:
+        got = hip_forward(job["clip"].numpy(), job["triangles"].numpy(), 200, 136, device)
+    finally:
+        _native.lib().mr_set_raster_tile_shape(0)
+    assert_forward_bitwise(got, want)
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (7, 3), (63, 65), (64, 64), (65, 129), (300, 200), (1000, 37)])
+def test_ragged_image_sizes(device, w, h):
+    job = synthetic.sphere_job(3, w, h, 12)
+    want = oracle.forward(job["clip"].numpy(), job["triangles"].numpy(), w, h)
+    got = hip_forward(job["clip"].numpy(), job["triangles"].numpy(), w, h, device)
+    assert_forward_bitwise(got, want)
+    dbary = np.stack([seeded_dbary((h, w, 3), seed=b).numpy() for b in range(3)])
+    d = hip_backward(dbary, job["clip"].numpy(), job["triangles"].numpy(), got[0], got[1], device)
+    np.testing.assert_allclose(
+        d, oracle.backward(dbary, job["clip"].numpy(), job["triangles"].numpy(), want[0], want[1]),
+        atol=GRAD_ATOL, rtol=0)
+
+
+def test_random_soups_vs_oracle(device):
+    """Random triangle soups: vertices behind the eye, degenerate and repeated triangles."""
+    rng = np.random.default_rng(99)
+    for trial in range(10):
+        V, T = int(rng.integers(3, 60)), int(rng.integers(1, 300))
+        W, H = int(rng.integers(1, 200)), int(rng.integers(1, 150))
+        B = int(rng.integers(1, 4))
+        clip = rng.normal(size=(B, V, 4)).astype(np.float32)
+        if trial % 2:
+            clip[..., 3] = np.abs(clip[..., 3]) + 0.1
+        tris = rng.integers(0, V, size=(T, 3)).astype(np.int32)
+        tris[T // 2] = tris[0]            # duplicate triangle -> exact z tie
+        want = oracle.forward(clip, tris, W, H)
+        got = hip_forward(clip, tris, W, H, device)
+        assert_forward_bitwise(got, want)
+
+
+def test_bin_overflow_many_triangles_one_region(device):
+    """More triangles over one 64x64 region than the LDS bin holds (multi-pass path)."""
+    rng = np.random.default_rng(5)
+    T = 3000
+    centers = rng.uniform(-0.9, 0.9, size=(T, 1, 2)).astype(np.float32)
+    offs = rng.uniform(-0.3, 0.3, size=(T, 3, 2)).astype(np.float32)
+    xy = (centers + offs).reshape(-1, 2)
+    zz = rng.uniform(-0.9, 0.9, size=(T * 3, 1)).astype(np.float32)
+    clip = np.concatenate([xy, zz, np.ones((T * 3, 1), np.float32)], 1)
+    tris = np.arange(T * 3, dtype=np.int32).reshape(T, 3)
+    want = oracle.forward(clip, tris, 64, 48)
+    got = hip_forward(clip, tris, 64, 48, device)
+    assert_forward_bitwise(got, want)
+    assert (want[1].sum(-1) > 0.5).mean() > 0.9
+
+
+def test_empty_inputs(device):
+    clip = torch.zeros(2, 5, 4, device=device)
+    tris = torch.zeros(0, 3, dtype=torch.int32, device=device)
+    ids, bary, z = _native.rasterize_forward(clip, tris, 33, 17)
+    assert torch.all(ids == 0) and torch.all(bary == 0) and torch.all(z == 1.0)
+    d = _native.rasterize_backward(torch.ones(2, 17, 33, 3, device=device), clip, tris, ids, bary)
+    assert d.shape == (2, 5, 4) and torch.all(d == 0)
+
+
+def test_out_of_range_vertex_ids_are_skipped(device):
+    g = golden_npz("raster_triangles_160x120.npz")
+    clip = g["w_111.clip"]
+    tris = np.array([[0, 1, 2], [0, 1, 99], [-1, 1, 2]], np.int32)
+    got = hip_forward(clip, tris, 160, 120, device)
+    assert_forward_bitwise(got, (g["w_111.ids"], g["w_111.bary"], g["w_111.z"]))
+
+
+def test_non_finite_vertices_do_not_fault(device):
+    clip = np.array([[np.nan, 0, 0, 1], [np.inf, 1, 0, 1], [1, 1, 0.5, 1], [-1, -1, 0.5, 1],
+                     [1e30, -1e30, 0, 1e-30]], np.float32)
+    tris = np.array([[0, 1, 2], [2, 3, 4], [1, 2, 3]], np.int32)
+    want = oracle.forward(clip, tris, 40, 30)
+    got = hip_forward(clip, tris, 40, 30, device)
+    assert bits_equal(got[0], want[0])
+    np.testing.assert_array_equal(got[1], want[1])  # NaN-aware equality
+    np.testing.assert_array_equal(got[2], want[2])
+
+
+def test_autograd_function_matches_reference_contract(device):
+    """BarycentricRasterizer: return tuple, dtypes, init values, backward tuple (ext.py:6-63)."""
+    g = golden_npz("raster_cube64.npz")
+    clip = torch.tensor(g["clip"], device=device, requires_grad=True)
+    tris = torch.tensor(g["triangles"], device=device)
+    ids, bary, z = rasterize_barycentric(clip, tris, 64, 64)
+    assert ids.dtype == torch.int32 and ids.shape == (64, 64)
+    assert bary.dtype == torch.float32 and bary.shape == (64, 64, 3)
+    assert z.dtype == torch.float32 and z.shape == (64, 64)
+    assert bits_equal(bary.detach().cpu().numpy(), g["bary"])
+    (bary * torch.tensor(g["dbary"], device=device)).sum().backward()
+    np.testing.assert_allclose(clip.grad.cpu().numpy(), g["dclip"], atol=GRAD_ATOL, rtol=0)
+    # batched form used internally
+    idsb, baryb, zb = rasterize_barycentric(clip.detach().unsqueeze(0).repeat(3, 1, 1), tris, 64, 64)
+    assert idsb.shape == (3, 64, 64) and torch.equal(idsb[2], ids)
+    with pytest.raises(RuntimeError):
+        rasterize_barycentric(clip, tris.long(), 64, 64)
+
+
+def test_gradcheck_single_pixel(device):
+    """Counterpart of testSimpleTriangleGradientComputation (eps 4e-2, atol 0.1, rtol 0.01)."""
+    tris = torch.tensor([[0, 1, 2]], dtype=torch.int32, device=device)
+
+    def pixel(clip):
+        _, bary, _ = rasterize_barycentric(clip, tris, 640, 480)
+        return bary[245:246, 325:326, :]
+
+    clip = torch.tensor([[-0.5, -0.5, 0.8, 1.0], [0.0, 0.5, 0.3, 1.0], [0.5, -0.5, 0.3, 1.0]],
+                        dtype=torch.float32, device=device, requires_grad=True)
+    assert torch.autograd.gradcheck(pixel, clip, eps=4e-2, atol=0.1, rtol=0.01,
+                                    nondet_tol=1e-5)

@@ -1,0 +1,256 @@
+"""GPU parity, API level: rasterize() / render() vs the reference's own outputs.
+
+Counterparts of the reference's rasterize_triangles_test.py and mesh_renderer_test.py
+(golden-image, Jacobian and optimisation tests) plus float goldens captured from the
+reference (tools/make_goldens.py).  Bar: RGBA and gradients within 1e-4 abs.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from conftest import GOLDEN, golden_npz
+from oracle import shading
+from pytorch_mesh_renderer_amd import mesh_renderer
+from pytorch_mesh_renderer_amd.common import camera_utils, synthetic
+from pytorch_mesh_renderer_amd.mesh_renderer.rasterize import rasterize_barycentric
+
+pytestmark = pytest.mark.gpu
+ATOL = 1e-4
+
+CUBE_V = torch.tensor([[-1, -1, 1], [-1, -1, -1], [-1, 1, -1], [-1, 1, 1], [1, -1, 1],
+                       [1, -1, -1], [1, 1, -1], [1, 1, 1]], dtype=torch.float32)
+CUBE_T = torch.tensor([[0, 1, 2], [2, 3, 0], [3, 2, 6], [6, 7, 3], [7, 6, 5], [5, 4, 7],
+                       [4, 5, 1], [1, 0, 4], [5, 6, 2], [2, 1, 5], [7, 4, 0], [0, 3, 7]],
+                      dtype=torch.int32)
+
+
+def expect_image_file_and_render_are_near(name, image, max_outlier_fraction=0.001,
+                                          pixel_error_threshold=0.01):
+    """Same soft comparison as the reference's test_utils.py:105-160."""
+    baseline = np.asarray(Image.open(os.path.join(GOLDEN, "ref_png", name))).astype(float) / 255.0
+    result = np.clip(image.detach().cpu().numpy(), 0.0, 1.0)
+    assert baseline.shape == result.shape
+    outliers = np.any(np.abs(baseline - result) > pixel_error_threshold, axis=2)
+    fraction = np.count_nonzero(outliers) / np.prod(baseline.shape[:2])
+    assert fraction <= max_outlier_fraction, "%s: %.5f of pixels are outliers" % (name, fraction)
+
+
+def _leaf(g, key, device):
+    return torch.tensor(g[key], device=device, requires_grad=True)
+
+
+def test_rasterize_unlit_cube_golden(device):
+    g = golden_npz("rasterize_unlit_cube_64x48.npz")
+    v, a = _leaf(g, "vertices", device), _leaf(g, "attributes", device)
+    out = mesh_renderer.rasterize(v, a, torch.tensor(g["triangles"], device=device),
+                                  torch.tensor(g["projection"], device=device), 64, 48,
+                                  torch.tensor(g["background"], device=device))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g["out"], atol=ATOL, rtol=0)
+    torch.mean(torch.abs(out - torch.tensor(g["target"], device=device))).backward()
+    np.testing.assert_allclose(v.grad.cpu().numpy(), g["dvertices"], atol=ATOL, rtol=0)
+    np.testing.assert_allclose(a.grad.cpu().numpy(), g["dattributes"], atol=ATOL, rtol=0)
+
+
+def _render_golden(name, device):
+    g = golden_npz(name)
+    h, w = g["image"].shape[1:3]
+    leaves = {k: _leaf(g, k, device) for k in ("vertices", "normals", "diffuse", "light_positions",
+                                               "light_intensities")}
+    spec = _leaf(g, "specular", device) if "specular" in g.files else None
+    amb = _leaf(g, "ambient", device) if "ambient" in g.files else None
+    shine = torch.tensor(g["shininess"], device=device) if "shininess" in g.files else None
+    dev = lambda k: torch.tensor(g[k], device=device)
+    img = mesh_renderer.render(leaves["vertices"], dev("triangles"), leaves["normals"],
+                               leaves["diffuse"], dev("eye"), dev("center"), dev("up"),
+                               leaves["light_positions"], leaves["light_intensities"], w, h,
+                               specular_colors=spec, shininess_coefficients=shine, ambient_color=amb)
+    assert img.shape == g["image"].shape and img.dtype == torch.float32
+    np.testing.assert_allclose(img.detach().cpu().numpy(), g["image"], atol=ATOL, rtol=0)
+    alpha = img[..., 3].detach().cpu().numpy()
+    assert set(np.unique(alpha)) <= {0.0, 1.0} and np.array_equal(alpha, g["image"][..., 3])
+    torch.mean(torch.abs(img - dev("target"))).backward()
+    for k, t in leaves.items():
+        np.testing.assert_allclose(t.grad.cpu().numpy(), g["d_" + k], atol=ATOL, rtol=0, err_msg=k)
+    if spec is not None:
+        np.testing.assert_allclose(spec.grad.cpu().numpy(), g["d_specular"], atol=ATOL, rtol=0)
+    if amb is not None:
+        np.testing.assert_allclose(amb.grad.cpu().numpy(), g["d_ambient"], atol=ATOL, rtol=0)
+
+
+@pytest.mark.parametrize("name", ["render_gray_cube_64x48.npz", "render_lit_cube_64x48.npz",
+                                  "render_sphere5k_128.npz"])
+def test_render_diffuse_goldens(device, name):
+    _render_golden(name, device)
+
+
+@pytest.mark.parametrize("name", ["render_specular_cube_64x48.npz",
+                                  "render_specular_scalar_cube_64x48.npz"])
+def test_render_specular_goldens(device, name):
+    _render_golden(name, device)
+
+
+def test_renders_simple_and_perspective_triangle_png(device):
+    """rasterize_triangles_test.py:72-77."""
+    tris = torch.tensor([[0, 1, 2]], dtype=torch.int32, device=device)
+    base = np.array([[-0.5, -0.5, 0.8, 1.0], [0.0, 0.5, 0.3, 1.0], [0.5, -0.5, 0.3, 1.0]], np.float32)
+    for w_vec, png in (((1.0, 1.0, 1.0), "Simple_Triangle.png"),
+                       ((0.2, 0.5, 2.0), "Perspective_Corrected_Triangle.png")):
+        clip = torch.tensor(base * np.reshape(np.array(w_vec, np.float32), [3, 1]), device=device)
+        _, bary, _ = rasterize_barycentric(clip, tris, 640, 480)
+        image = torch.cat([bary, torch.ones(480, 640, 1, device=device)], dim=2)
+        expect_image_file_and_render_are_near(png, image)
+
+
+def test_renders_two_cubes_in_batch_png(device):
+    """rasterize_triangles_test.py:79-117."""
+    cube = CUBE_V.to(device)
+    rgba = torch.cat([cube * 0.5 + 0.5, torch.ones(8, 1, device=device)], dim=1)
+    persp = camera_utils.perspective(640 / 480, torch.tensor([40.0], device=device),
+                                     torch.tensor([0.01], device=device),
+                                     torch.tensor([10.0], device=device))
+    center = torch.zeros(1, 3, device=device)
+    up = torch.tensor([[0.0, 1.0, 0.0]], device=device)
+    looks = [camera_utils.look_at(torch.tensor([eye], device=device), center, up)
+             for eye in ([2.0, 3.0, 6.0], [-3.0, 1.0, 6.0])]
+    projection = torch.cat([torch.matmul(persp, l) for l in looks], dim=0)
+    rendered = mesh_renderer.rasterize(torch.stack([cube, cube]), torch.stack([rgba, rgba]),
+                                       CUBE_T.to(device), projection, 640, 480,
+                                       torch.tensor([0.0, 0.0, 0.0, 0.0]))
+    for i in (0, 1):
+        expect_image_file_and_render_are_near("Unlit_Cube_%d.png" % i, rendered[i])
+
+
+def _gray_cube_scene(device, vertices=None):
+    cube = CUBE_V.to(device) if vertices is None else vertices
+    normals = torch.nn.functional.normalize(CUBE_V, dim=1, p=2).to(device)
+    rot = camera_utils.euler_matrices(
+        torch.tensor([[-20.0, 0.0, 60.0], [45.0, 60.0, 0.0]], device=device))[:, :3, :3]
+    vw = torch.matmul(torch.stack([cube, cube]), rot.transpose(1, 2))
+    nw = torch.matmul(torch.stack([normals, normals]), rot.transpose(1, 2))
+    return vw, nw
+
+
+def test_renders_simple_cube_png(device):
+    """mesh_renderer_test.py:30-70."""
+    vw, nw = _gray_cube_scene(device)
+    eye = torch.tensor(2 * [[0.0, 0.0, 6.0]], device=device)
+    images = mesh_renderer.render(vw, CUBE_T.to(device), nw, torch.ones_like(vw), eye,
+                                  torch.zeros(2, 3, device=device),
+                                  torch.tensor(2 * [[0.0, 1.0, 0.0]], device=device),
+                                  eye.unsqueeze(1), torch.ones(2, 1, 3, device=device), 640, 480)
+    for i in range(2):
+        expect_image_file_and_render_are_near("Gray_Cube_%d.png" % i, images[i])
+
+
+def test_complex_shading_runs_and_broadcasts(device):
+    """mesh_renderer_test.py:72-149 (the reference asserts nothing; we also check that
+    per-vertex and scalar shininess agree, and compare with the CPU oracle)."""
+    vw, nw = _gray_cube_scene(device)
+    g = torch.Generator().manual_seed(2)
+    kd, ks = torch.rand(2, 8, 3, generator=g), torch.rand(2, 8, 3, generator=g)
+    eye = torch.tensor([[0.0, 0.0, 6.0], [0.0, 0.2, 18.0]])
+    center = torch.tensor([[0.0, 0.0, 0.0], [0.1, -0.1, 0.1]])
+    up = torch.tensor([[0.0, 1.0, 0.0], [0.1, 1.0, 0.15]])
+    lpos = torch.tensor([[[0.0, 0.0, 6.0], [1.0, 2.0, 6.0]], [[0.0, -2.0, 4.0], [1.0, 3.0, 4.0]]])
+    lint = torch.tensor([[[1.0, 1.0, 1.0], [1.0, 1.0, 1.0]], [[2.0, 0.0, 1.0], [0.0, 2.0, 1.0]]])
+    amb = torch.tensor([[0.0, 0.0, 0.0], [0.1, 0.1, 0.2]])
+    d = lambda t: t.to(device)
+    kw = dict(ambient_color=d(amb), fov_y=d(torch.tensor([40.0, 13.3])),
+              near_clip=d(torch.tensor(0.1)), far_clip=d(torch.tensor(25.0)))
+    a = mesh_renderer.render(vw, CUBE_T.to(device), nw, d(kd), d(eye), d(center), d(up), d(lpos),
+                             d(lint), 160, 120, d(ks), 6.0 * torch.ones(2, 8, device=device), **kw)
+    b = mesh_renderer.render(vw, CUBE_T.to(device), nw, d(kd), d(eye), d(center), d(up), d(lpos),
+                             d(lint), 160, 120, d(ks), 6.0, **kw)
+    np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=1e-5, rtol=0)
+    tm = mesh_renderer.tone_mapper(a[..., 0:3], 0.7)
+    assert float(tm.max()) <= 1.0 and float(tm.min()) >= 0.0
+
+
+def test_full_render_jacobian_vs_oracle(device):
+    """Counterpart of testFullRenderGradientComputation (28x21): instead of finite
+    differences, rows of the Jacobian are compared with the CPU oracle's autograd."""
+    def scene(vertices, dev):
+        normals = torch.nn.functional.normalize(CUBE_V, dim=1, p=2).to(dev)
+        rot = camera_utils.euler_matrices(
+            torch.tensor([[-20.0, 0.0, 60.0], [45.0, 60.0, 0.0]]))[:, :3, :3].to(dev)
+        vw = torch.matmul(torch.stack([vertices, vertices]), rot.transpose(1, 2))
+        nw = torch.matmul(torch.stack([normals, normals]), rot.transpose(1, 2))
+        eye = torch.tensor(2 * [[0.0, 0.0, 6.0]], device=dev)
+        return vw, nw, eye
+
+    vg = CUBE_V.clone().to(device).requires_grad_(True)
+    vw, nw, eye = scene(vg, device)
+    img = mesh_renderer.render(vw, CUBE_T.to(device), nw, torch.ones_like(vw), eye,
+                               torch.zeros(2, 3, device=device),
+                               torch.tensor(2 * [[0.0, 1.0, 0.0]], device=device), eye.unsqueeze(1),
+                               torch.ones(2, 1, 3, device=device), 28, 21)
+    vc = CUBE_V.clone().requires_grad_(True)
+    vw_c, nw_c, eye_c = scene(vc, torch.device("cpu"))
+    ref = shading.render(vw_c, CUBE_T, nw_c, torch.ones_like(vw_c), eye_c, torch.zeros(2, 3),
+                         torch.tensor(2 * [[0.0, 1.0, 0.0]]), eye_c.unsqueeze(1), torch.ones(2, 1, 3),
+                         28, 21)
+    np.testing.assert_allclose(img.detach().cpu().numpy(), ref.detach().numpy(), atol=ATOL, rtol=0)
+    rng = np.random.default_rng(0)
+    for _ in range(6):  # random projections of the Jacobian
+        w = torch.tensor(rng.normal(size=tuple(ref.shape)).astype(np.float32)) / ref.numel()
+        (gd,) = torch.autograd.grad(img, vg, w.to(device), retain_graph=True)
+        (gc,) = torch.autograd.grad(ref, vc, w, retain_graph=True)
+        np.testing.assert_allclose(gd.cpu().numpy(), gc.numpy(), atol=ATOL, rtol=0)
+
+
+def test_that_cube_rotates(device):
+    """mesh_renderer_test.py:204-271: the gradients are useful for optimisation."""
+    cube = CUBE_V.to(device)
+    normals = torch.nn.functional.normalize(cube, dim=1, p=2)
+    eye = torch.tensor([[0.0, 0.0, 6.0]], device=device)
+
+    def render_with_rotation(angles):
+        rot = camera_utils.euler_matrices(angles)[0, :3, :3]
+        vw = torch.matmul(cube, rot.T).reshape(1, 8, 3)
+        nw = torch.matmul(normals, rot.T).reshape(1, 8, 3)
+        out = mesh_renderer.render(vw, CUBE_T.to(device), nw, torch.ones_like(vw), eye,
+                                   torch.zeros(1, 3, device=device),
+                                   torch.tensor([[0.0, 1.0, 0.0]], device=device),
+                                   eye.reshape(1, 1, 3), torch.ones(1, 1, 3, device=device), 640, 480)
+        return out.reshape(480, 640, 4)
+
+    angles = torch.zeros(1, 3, device=device, requires_grad=True)
+    desired = render_with_rotation(torch.tensor([[-20.0, 0.0, 60.0]], device=device))
+    optimizer = torch.optim.SGD([angles], 0.7, 0.1)
+
+    def step():
+        optimizer.zero_grad()
+        loss = torch.mean(torch.abs(render_with_rotation(angles) - desired))
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_([angles], 1.0)
+        return loss
+
+    for _ in range(35):
+        optimizer.step(step)
+    expect_image_file_and_render_are_near("Gray_Cube_0.png", desired)
+    expect_image_file_and_render_are_near("Gray_Cube_0.png", render_with_rotation(angles).detach(),
+                                          max_outlier_fraction=0.01, pixel_error_threshold=0.04)
+
+
+def test_render_sphere_matches_oracle_at_256(device):
+    """The bench workload (smaller): full render fwd + grads vs the CPU oracle."""
+    job = synthetic.sphere_job(2, 256, 256, 50)
+    cpu = {k: job[k].clone().requires_grad_(True) for k in ("vertices", "normals", "diffuse")}
+    gpu = {k: job[k].clone().to(device).requires_grad_(True) for k in ("vertices", "normals", "diffuse")}
+    up = torch.tensor(2 * [[0.0, 1.0, 0.0]])
+    ref = shading.render(cpu["vertices"], job["triangles"], cpu["normals"], cpu["diffuse"], job["eyes"],
+                         torch.zeros(2, 3), up, job["light_positions"], job["light_intensities"], 256, 256)
+    img = mesh_renderer.render(gpu["vertices"], job["triangles"].to(device), gpu["normals"],
+                               gpu["diffuse"], job["eyes"].to(device), torch.zeros(2, 3, device=device),
+                               up.to(device), job["light_positions"].to(device),
+                               job["light_intensities"].to(device), 256, 256)
+    np.testing.assert_allclose(img.detach().cpu().numpy(), ref.detach().numpy(), atol=ATOL, rtol=0)
+    target = torch.rand(ref.shape, generator=torch.Generator().manual_seed(1))
+    torch.mean(torch.abs(ref - target)).backward()
+    torch.mean(torch.abs(img - target.to(device))).backward()
+    for k in cpu:
+        np.testing.assert_allclose(gpu[k].grad.cpu().numpy(), cpu[k].grad.numpy(), atol=ATOL, rtol=0,
+                                   err_msg=k)
