@@ -12,7 +12,7 @@ import torch
 
 import oracle
 from oracle import shading
-from conftest import (TRIANGLE_CASES, bits_equal, golden_json, golden_npz, seeded_dbary, sha)
+from conftest import (golden_sphere_job, TRIANGLE_CASES, bits_equal, golden_json, golden_npz, seeded_dbary, sha)
 from pytorch_mesh_renderer_amd.common import synthetic
 
 
@@ -74,7 +74,7 @@ def test_jacobian_28x21_bitwise():
 
 def test_sphere_256_all_cameras():
     h = golden_json("raster_sphere_hashes.json")["c2_256x256_b8"]
-    job = synthetic.sphere_job(8, 256, 256, 50)
+    job = golden_sphere_job("sphere_clip_256_b8.npy")
     assert sha(job["clip"].numpy()) == h["clip"]  # same input bits as when the goldens were made
     ids, bary, z = oracle.forward(job["clip"].numpy(), job["triangles"].numpy(), 256, 256, threads=8)
     for b in range(8):
@@ -91,7 +91,7 @@ def test_sphere_256_all_cameras():
 def test_sphere_1024_picked_cameras():
     h = golden_json("raster_sphere_hashes.json")["c3_1024x1024_b32"]
     dgold = golden_npz("raster_sphere1024_dclip.npz")
-    job = synthetic.sphere_job(32, 1024, 1024, 50)
+    job = golden_sphere_job("sphere_clip_1024_b32.npy")
     assert sha(job["clip"].numpy()) == h["clip"]
     for b in (0, 16):
         clip = job["clip"][b].numpy()

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 import oracle
-from conftest import (TRIANGLE_CASES, bits_equal, golden_json, golden_npz, seeded_dbary, sha)
+from conftest import (golden_sphere_job, TRIANGLE_CASES, bits_equal, golden_json, golden_npz, seeded_dbary, sha)
 from pytorch_mesh_renderer_amd import _native
 from pytorch_mesh_renderer_amd.common import synthetic
 from pytorch_mesh_renderer_amd.mesh_renderer.rasterize import rasterize_barycentric
@@ -87,7 +87,7 @@ def test_jacobian_28x21(device):
 def test_sphere_256_b8_config2(device):
     """BASELINE config 2: 5k-tri sphere, 256x256, batch 8, forward G-buffer."""
     h = golden_json("raster_sphere_hashes.json")["c2_256x256_b8"]
-    job = synthetic.sphere_job(8, 256, 256, 50)
+    job = golden_sphere_job("sphere_clip_256_b8.npy")
     assert sha(job["clip"].numpy()) == h["clip"]
     ids, bary, z = hip_forward(job["clip"].numpy(), job["triangles"].numpy(), 256, 256, device)
     for b in range(8):
@@ -107,7 +107,7 @@ def test_sphere_1024_b32_config3_full_size(device):
     the 32 cameras, size-independent properties for all of them."""
     h = golden_json("raster_sphere_hashes.json")["c3_1024x1024_b32"]
     dgold = golden_npz("raster_sphere1024_dclip.npz")
-    job = synthetic.sphere_job(32, 1024, 1024, 50)
+    job = golden_sphere_job("sphere_clip_1024_b32.npy")
     assert sha(job["clip"].numpy()) == h["clip"]
     clip_d, tris_d = job["clip"].to(device), job["triangles"].to(device)
     ids, bary, z = _native.rasterize_forward(clip_d, tris_d, 1024, 1024)

@@ -54,6 +54,13 @@ def test_rasterize_unlit_cube_golden(device):
     np.testing.assert_allclose(a.grad.cpu().numpy(), g["dattributes"], atol=ATOL, rtol=0)
 
 
+def _assert_close_where_reference_is_finite(got, want, what):
+    """With per-vertex shininess the reference's own gradients are NaN (pow(0, s) *
+    log(0) in torch-CPU autograd); those entries pin nothing and are skipped."""
+    ok = np.isfinite(want)
+    np.testing.assert_allclose(got[ok], want[ok], atol=ATOL, rtol=0, err_msg=what)
+
+
 def _render_golden(name, device):
     g = golden_npz(name)
     h, w = g["image"].shape[1:3]
@@ -73,11 +80,11 @@ def _render_golden(name, device):
     assert set(np.unique(alpha)) <= {0.0, 1.0} and np.array_equal(alpha, g["image"][..., 3])
     torch.mean(torch.abs(img - dev("target"))).backward()
     for k, t in leaves.items():
-        np.testing.assert_allclose(t.grad.cpu().numpy(), g["d_" + k], atol=ATOL, rtol=0, err_msg=k)
+        _assert_close_where_reference_is_finite(t.grad.cpu().numpy(), g["d_" + k], k)
     if spec is not None:
-        np.testing.assert_allclose(spec.grad.cpu().numpy(), g["d_specular"], atol=ATOL, rtol=0)
+        _assert_close_where_reference_is_finite(spec.grad.cpu().numpy(), g["d_specular"], "specular")
     if amb is not None:
-        np.testing.assert_allclose(amb.grad.cpu().numpy(), g["d_ambient"], atol=ATOL, rtol=0)
+        _assert_close_where_reference_is_finite(amb.grad.cpu().numpy(), g["d_ambient"], "ambient")
 
 
 @pytest.mark.parametrize("name", ["render_gray_cube_64x48.npz", "render_lit_cube_64x48.npz",

@@ -151,6 +151,8 @@ def main():
             np.savez_compressed(os.path.join(GOLDEN, "raster_sphere256_cam0.npz"), ids=ids, bary=bary,
                                 z=z, dclip=dclip)
     sphere["c2_256x256_b8"] = {"clip": sha(job["clip"].numpy()), "cameras": per_cam}
+    # clip-space inputs are stored, not regenerated: sin/cos/matmul differ across host CPUs
+    np.save(os.path.join(GOLDEN, "sphere_clip_256_b8.npy"), job["clip"].numpy())
     job = synthetic.sphere_job(32, 1024, 1024, 50)
     picked = {}
     dclips = {}
@@ -161,6 +163,7 @@ def main():
                           "ids_sample": ids[::97, ::89].tolist()}
         dclips["dclip_%d" % b] = dclip
     sphere["c3_1024x1024_b32"] = {"clip": sha(job["clip"].numpy()), "cameras": picked}
+    np.save(os.path.join(GOLDEN, "sphere_clip_1024_b32.npy"), job["clip"].numpy())
     np.savez_compressed(os.path.join(GOLDEN, "raster_sphere1024_dclip.npz"), **dclips)
     json.dump(sphere, open(os.path.join(GOLDEN, "raster_sphere_hashes.json"), "w"), indent=1)
 
