@@ -98,6 +98,44 @@ int mr_interpolate_backward(const float *dout, const int32_t *ids,
                             float *dattrs, float *dbary, void *workspace,
                             size_t workspace_bytes, void *stream);
 
+/* ---- fused deferred shading (diffuse + ambient Phong) ---------------------------
+ * Replaces, for render() without specular terms, attribute interpolation
+ * (src/mesh_renderer/rasterize.py:118-150), the unpack / normalise / mask block of
+ * render() (src/mesh_renderer/render.py:199-215) and phong_shader's ambient +
+ * diffuse terms, alpha mask and vertical flip (render.py:287-323, 373-386).
+ *   ids, bary                 the G-buffer of mr_rasterize_forward
+ *   normals, positions, diffuse  [B,V,3] f32 per-vertex attributes (positions =
+ *                             world-space vertices)
+ *   light_positions, light_intensities [B,L,3] f32, 1 <= L <= mr_shade_max_lights()
+ *   ambient                   [B,3] f32 or NULL
+ *   rgba                      [B,H,W,4] f32 out; row 0 is the TOP scanline; alpha is
+ *                             1 on covered pixels with a non-negative diffuse colour */
+int mr_shade_max_lights(void);
+int mr_shade_forward(const int32_t *ids, const float *bary, const float *normals,
+                     const float *positions, const float *diffuse,
+                     const int32_t *triangles, const float *light_positions,
+                     const float *light_intensities, const float *ambient,
+                     int B, int V, int T, int W, int H, int L, float *rgba,
+                     void *stream);
+
+/* Backward of mr_shade_forward AND of the rasterizer underneath it, in one pass
+ * over the G-buffer (reads 32 B/px).  All outputs are zeroed here.
+ *   drgba        [B,H,W,4] f32  dL/d(rgba); the alpha channel's gradient is ignored
+ *   clip         [B,V,4]   f32  the clip-space vertices the G-buffer was made from
+ *   dclip        [B,V,4]   f32 out  through the barycentrics (column z stays 0)
+ *   dnormals, dpositions, ddiffuse [B,V,3] f32 out  through the interpolated attributes
+ *   light_grads  [B, 6L+3] f32 out  per image: d light_positions (L x 3),
+ *                               d light_intensities (L x 3), d ambient (3; 0 if NULL) */
+size_t mr_shade_backward_workspace_bytes(int B, int V, int T, int W, int H);
+int mr_shade_backward(const float *drgba, const int32_t *ids, const float *bary,
+                      const float *clip, const float *normals, const float *positions,
+                      const float *diffuse, const int32_t *triangles,
+                      const float *light_positions, const float *light_intensities,
+                      const float *ambient, int B, int V, int T, int W, int H, int L,
+                      float *dclip, float *dnormals, float *dpositions,
+                      float *ddiffuse, float *light_grads, void *workspace,
+                      size_t workspace_bytes, void *stream);
+
 /* ---- tuning hooks (no reference counterpart; results never change) ----------
  * Pixel tile walked by one wavefront in the forward raster kernel:
  * 0 = 8x8 (default), 1 = 16x4, 2 = 32x2. */

@@ -67,6 +67,13 @@ def lib():
         L.mr_interpolate_backward.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci,
                                               vp, vp, vp, sz, vp]
         L.mr_interpolate_backward.restype = ci
+        L.mr_shade_max_lights.restype = ci
+        L.mr_shade_forward.argtypes = [vp] * 9 + [ci] * 6 + [vp, vp]
+        L.mr_shade_forward.restype = ci
+        L.mr_shade_backward_workspace_bytes.argtypes = [ci] * 5
+        L.mr_shade_backward_workspace_bytes.restype = sz
+        L.mr_shade_backward.argtypes = [vp] * 11 + [ci] * 6 + [vp] * 6 + [sz, vp]
+        L.mr_shade_backward.restype = ci
         _lib = L
     return _lib
 
@@ -188,3 +195,60 @@ def interpolate_backward(dout, ids, bary, attrs, triangles, background):
                                        _ptr(dattrs), _ptr(dbary), _ptr(ws), have, _stream(dev))
     _check(rc, "mr_interpolate_backward")
     return dattrs, dbary
+
+
+def shade_max_lights():
+    return int(lib().mr_shade_max_lights())
+
+
+def shade_forward(ids, bary, normals, positions, diffuse, triangles, light_positions,
+                  light_intensities, ambient):
+    """Fused interpolation + diffuse/ambient Phong: -> rgba [B,H,W,4] (row 0 = top)."""
+    tensors = [ids, bary, normals, positions, diffuse, triangles, light_positions, light_intensities]
+    dev = _require_device(*(tensors + ([ambient] if ambient is not None else [])))
+    L = lib()
+    ids, bary, normals, positions, diffuse, triangles, light_positions, light_intensities = [
+        t.contiguous() for t in tensors]
+    ambient = ambient.contiguous() if ambient is not None else None
+    B, H, W = ids.shape
+    V, T, nl = normals.shape[1], triangles.shape[0], light_positions.shape[1]
+    rgba = torch.empty(B, H, W, 4, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.mr_shade_forward(_ptr(ids), _ptr(bary), _ptr(normals), _ptr(positions), _ptr(diffuse),
+                                _ptr(triangles), _ptr(light_positions), _ptr(light_intensities),
+                                _ptr(ambient), B, V, T, W, H, nl, _ptr(rgba), _stream(dev))
+    _check(rc, "mr_shade_forward")
+    return rgba
+
+
+def shade_backward(drgba, ids, bary, clip, normals, positions, diffuse, triangles, light_positions,
+                   light_intensities, ambient):
+    """-> (dclip [B,V,4], dnormals, dpositions, ddiffuse [B,V,3], dlight_positions,
+    dlight_intensities [B,L,3], dambient [B,3] or None)."""
+    tensors = [drgba, ids, bary, clip, normals, positions, diffuse, triangles, light_positions,
+               light_intensities]
+    dev = _require_device(*(tensors + ([ambient] if ambient is not None else [])))
+    L = lib()
+    (drgba, ids, bary, clip, normals, positions, diffuse, triangles, light_positions,
+     light_intensities) = [t.contiguous() for t in tensors]
+    ambient = ambient.contiguous() if ambient is not None else None
+    B, H, W = ids.shape
+    V, T, nl = normals.shape[1], triangles.shape[0], light_positions.shape[1]
+    dclip = torch.empty(B, V, 4, dtype=torch.float32, device=dev)
+    dn = torch.empty(B, V, 3, dtype=torch.float32, device=dev)
+    dp = torch.empty(B, V, 3, dtype=torch.float32, device=dev)
+    dd = torch.empty(B, V, 3, dtype=torch.float32, device=dev)
+    lg = torch.empty(B, 6 * nl + 3, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        need = L.mr_shade_backward_workspace_bytes(B, V, T, W, H)
+        ws, have = _workspace(dev, need)
+        rc = L.mr_shade_backward(_ptr(drgba), _ptr(ids), _ptr(bary), _ptr(clip), _ptr(normals),
+                                 _ptr(positions), _ptr(diffuse), _ptr(triangles),
+                                 _ptr(light_positions), _ptr(light_intensities), _ptr(ambient),
+                                 B, V, T, W, H, nl, _ptr(dclip), _ptr(dn), _ptr(dp), _ptr(dd),
+                                 _ptr(lg), _ptr(ws), have, _stream(dev))
+    _check(rc, "mr_shade_backward")
+    dlpos = lg[:, :3 * nl].reshape(B, nl, 3)
+    dlint = lg[:, 3 * nl:6 * nl].reshape(B, nl, 3)
+    damb = lg[:, 6 * nl:] if ambient is not None else None
+    return dclip, dn, dp, dd, dlpos, dlint, damb

@@ -21,7 +21,7 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kChunk = 4;  // attributes per accumulation pass (x3 corners = kAcc)
 constexpr int kAcc = kChunk * 3;
-static_assert(kAcc <= kAccStride, "chunk must fit the accumulator row");
+constexpr int kAccStride = 12;  // floats per acc row
 
 // alpha = clamp(sum(2*bary), 0, 1)  (rasterize.py:145-147)
 __device__ __forceinline__ float coverage_alpha(const F3 b, float &pre_clamp) {
@@ -93,6 +93,8 @@ __global__ __launch_bounds__(kThreads) void k_interp_dbary(
 // attributes of one chunk and the 3 corners.
 struct AttrGradFn {
   static constexpr int kN = kChunk * 3;
+  static constexpr int kStride = kAccStride;
+  static constexpr int kSlots = 512;
   const float *__restrict__ dout;
   const int32_t *__restrict__ ids;
   const F3 *__restrict__ bary;
@@ -103,8 +105,12 @@ struct AttrGradFn {
     float gv[kChunk];
   };
   struct Triangle {};
+  using Image = NoImageSums;
 
-  __device__ __forceinline__ bool load_pixel(size_t pix, int T, int &tri, Pixel &p) const {
+  __device__ __forceinline__ void begin_image(int, Image &) const {}
+  __device__ __forceinline__ void end_image(int, Image &) const {}
+  __device__ __forceinline__ bool load_pixel(int, int, int, size_t pix, int T, int &tri,
+                                             Pixel &p) const {
     p.b = bary[pix];
     float pre;
     const float alpha = coverage_alpha(p.b, pre);
@@ -119,7 +125,7 @@ struct AttrGradFn {
   }
   __device__ __forceinline__ void load_triangle(int, int, Triangle &) const {}
   __device__ __forceinline__ void accumulate(const Pixel &p, const Triangle &,
-                                             float (&acc)[kN]) const {
+                                             float (&acc)[kN], Image &) const {
 #pragma unroll
     for (int c = 0; c < kChunk; ++c) {
       acc[c * 3 + 0] += p.gv[c] * p.b.x;

@@ -74,5 +74,17 @@ int launch_interp_backward(const float *dout, const int32_t *ids, const float *b
                            int V, int T, int W, int H, int A, float *dattrs, float *dbary,
                            void *ws, hipStream_t s);
 size_t interp_backward_ws(int B, int V, int T, int W, int H, int A);
+int shade_max_lights();
+int launch_shade_forward(const int32_t *ids, const float *bary, const float *normals,
+                         const float *positions, const float *diffuse, const int32_t *tris,
+                         const float *light_pos, const float *light_col, const float *ambient,
+                         int B, int V, int T, int W, int H, int L, float *rgba, hipStream_t s);
+size_t shade_backward_ws(int B, int V, int T, int W, int H);
+int launch_shade_backward(const float *drgba, const int32_t *ids, const float *bary,
+                          const float *clip, const float *normals, const float *positions,
+                          const float *diffuse, const int32_t *tris, const float *light_pos,
+                          const float *light_col, const float *ambient, int B, int V, int T, int W,
+                          int H, int L, float *dclip, float *dnormals, float *dpositions,
+                          float *ddiffuse, float *light_grads, void *ws, hipStream_t s);
 
 }  // namespace mr

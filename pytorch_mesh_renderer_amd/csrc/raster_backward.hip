@@ -28,21 +28,11 @@
 #include "run_accum.h"
 
 namespace mr {
-namespace {
 
-constexpr int kThreads = 256;
-constexpr float kDegenerateCutoff = 0.9f;  // cpp:13
-
-// u[9] row-major (row i = edge i, column c = clip component x/y/w), colsum[3],
-// inv_abs_det.  64 bytes.
-struct alignas(64) BwdRec {
-  float4 a, b, c, d;  // a=(u0..u3) b=(u4..u7) c=(u8,S0,S1,S2) d=(1/|det|,-,-,-)
-};
-
-__global__ __launch_bounds__(kThreads) void k_bwd_setup(
+__global__ __launch_bounds__(256) void k_bwd_setup(
     const float4 *__restrict__ clip, const int32_t *__restrict__ tris, int B, int V, int T,
     BwdRec *__restrict__ recs) {
-  const long gid = (long)blockIdx.x * kThreads + threadIdx.x;
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
   if (gid >= (long)B * T) return;
   const int b = (int)(gid / T);
   const int t = (int)(gid - (long)b * T);
@@ -69,8 +59,25 @@ __global__ __launch_bounds__(kThreads) void k_bwd_setup(
   recs[gid] = r;
 }
 
+int launch_bwd_setup(const float *clip, const int32_t *tris, int B, int V, int T, BwdRec *recs,
+                     hipStream_t s) {
+  const long nbt = (long)B * T;
+  if (nbt == 0) return MR_OK;
+  hipLaunchKernelGGL(k_bwd_setup, dim3((unsigned)((nbt + 255) / 256)), dim3(256), 0, s,
+                     (const float4 *)clip, tris, B, V, T, recs);
+  return check_launch();
+}
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr float kDegenerateCutoff = 0.9f;  // cpp:13
+constexpr int kStride = 12;                // floats per acc row (9 used): 48 B
+
 struct RasterGradFn {
   static constexpr int kN = 9;  // [corner j][component c] partials
+  static constexpr int kStride = mr::kStride;
+  static constexpr int kSlots = 512;
   const F3 *__restrict__ dbary;
   const int32_t *__restrict__ ids;
   const F3 *__restrict__ bary;
@@ -80,11 +87,13 @@ struct RasterGradFn {
   struct Pixel {
     F3 b, g;
   };
-  struct Triangle {
-    float u[9], s[3], inv;
-  };
+  using Triangle = BwdTriangle;
+  using Image = NoImageSums;
 
-  __device__ __forceinline__ bool load_pixel(size_t pix, int T, int &tri, Pixel &p) const {
+  __device__ __forceinline__ void begin_image(int, Image &) const {}
+  __device__ __forceinline__ void end_image(int, Image &) const {}
+  __device__ __forceinline__ bool load_pixel(int, int, int, size_t pix, int T, int &tri,
+                                             Pixel &p) const {
     const int t = ids[pix];
     p.b = bary[pix];
     if ((unsigned)t >= (unsigned)T) return false;                               // foreign id
@@ -94,29 +103,11 @@ struct RasterGradFn {
     return true;
   }
   __device__ __forceinline__ void load_triangle(int img, int tri, Triangle &t) const {
-    const BwdRec *r = recs + (size_t)img * T_ + tri;
-    const float4 a = r->a, b = r->b, c = r->c, d = r->d;
-    t.u[0] = a.x; t.u[1] = a.y; t.u[2] = a.z; t.u[3] = a.w;
-    t.u[4] = b.x; t.u[5] = b.y; t.u[6] = b.z; t.u[7] = b.w;
-    t.u[8] = c.x; t.s[0] = c.y; t.s[1] = c.z; t.s[2] = c.w;
-    t.inv = d.x;
+    load_bwd_triangle(recs + (size_t)img * T_ + tri, t);
   }
-  __device__ __forceinline__ void accumulate(const Pixel &p, const Triangle &t,
-                                             float (&acc)[kN]) const {
-    const float b[3] = {p.b.x, p.b.y, p.b.z};
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      // S_c * b_i, shared by the three corners (cpp:202-230 computes it inline)
-      const float sb0 = t.s[c] * b[0], sb1 = t.s[c] * b[1], sb2 = t.s[c] * b[2];
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const float d0 = (-t.u[0 + c]) * b[j] + sb0 * b[j];
-        const float d1 = (-t.u[3 + c]) * b[j] + sb1 * b[j];
-        const float d2 = (-t.u[6 + c]) * b[j] + sb2 * b[j];
-        const float v = (p.g.x * d0 + p.g.y * d1) + p.g.z * d2;  // cpp:232-269 numerator
-        acc[j * 3 + c] += v * t.inv;
-      }
-    }
+  __device__ __forceinline__ void accumulate(const Pixel &p, const Triangle &t, float (&acc)[kN],
+                                             Image &) const {
+    raster_pixel_partials(p.b, p.g, t, acc);
   }
 };
 
@@ -129,7 +120,7 @@ __global__ __launch_bounds__(kThreads) void k_bwd_scatter(
   bool any = false;
 #pragma unroll
   for (int k = 0; k < 9; ++k) {
-    a[k] = acc[gid * kAccStride + k];
+    a[k] = acc[gid * kStride + k];
     any |= (a[k] != 0.0f);  // NaN counts as touched
   }
   if (!any) return;
@@ -146,7 +137,7 @@ __global__ __launch_bounds__(kThreads) void k_bwd_scatter(
   }
 }
 
-inline size_t acc_bytes(int B, int T) { return align_up((size_t)B * T * kAccStride * sizeof(float), 256); }
+inline size_t acc_bytes(int B, int T) { return align_up((size_t)B * T * kStride * sizeof(float), 256); }
 
 }  // namespace
 
@@ -163,17 +154,15 @@ int launch_raster_backward(const float *dbary, const float *clip, const int32_t 
   if (T == 0) return MR_OK;
   float *acc = (float *)ws;
   BwdRec *recs = (BwdRec *)((char *)ws + acc_bytes(B, T));
-  if (hipMemsetAsync(acc, 0, (size_t)B * T * kAccStride * sizeof(float), s) != hipSuccess) return check_launch();
-  const long nbt = (long)B * T;
-  const unsigned tri_blocks = (unsigned)((nbt + kThreads - 1) / kThreads);
-  hipLaunchKernelGGL(k_bwd_setup, dim3(tri_blocks), dim3(kThreads), 0, s, (const float4 *)clip,
-                     tris, B, V, T, recs);
-  int rc = check_launch();
+  if (hipMemsetAsync(acc, 0, (size_t)B * T * kStride * sizeof(float), s) != hipSuccess) return check_launch();
+  int rc = launch_bwd_setup(clip, tris, B, V, T, recs, s);
   if (rc != MR_OK) return rc;
   RasterGradFn fn{(const F3 *)dbary, ids, (const F3 *)bary, recs, T};
   rc = launch_accumulate_runs(fn, B, T, W, H, acc, s);
   if (rc != MR_OK) return rc;
-  hipLaunchKernelGGL(k_bwd_scatter, dim3(tri_blocks), dim3(kThreads), 0, s, acc, tris, B, V, T, dclip);
+  const long nbt = (long)B * T;
+  hipLaunchKernelGGL(k_bwd_scatter, dim3((unsigned)((nbt + kThreads - 1) / kThreads)), dim3(kThreads),
+                     0, s, acc, tris, B, V, T, dclip);
   return check_launch();
 }
 

@@ -1,27 +1,31 @@
 // Per-triangle scatter-add of per-pixel quantities, the gfx950 way.
 //
-// Both backward passes of the path end in "for every covered pixel, add K numbers
-// to the triangle that owns the pixel" (reference: the nine '+=' of
+// Every backward pass of the path ends in "for each covered pixel, add K numbers to
+// the triangle that owns the pixel" (reference: the nine '+=' of
 // rasterize_triangles.cpp:232-269, and the index_put_(accumulate=True) that
 // autograd derives from the gather in src/mesh_renderer/rasterize.py:130-132).
 // Doing that with one global atomic per number per pixel is ~20 G atomics/s on
 // MI355X -- tens of milliseconds at 1024^2 x 32.  Instead:
 //
 //   1. each lane walks DOWN one pixel column (wave loads stay 64 consecutive
-//      pixels = coalesced) and keeps kAcc running sums in registers for as long
-//      as the triangle id does not change (runs are tens of pixels long);
+//      pixels = coalesced) and keeps the K running sums in registers for as long as
+//      the triangle id does not change (runs are tens of pixels long);
 //   2. a finished run goes into a workgroup-local LDS hash table keyed by triangle
 //      id with ds_add_f32;
-//   3. the table is drained once per workgroup with contiguous 48-byte global
-//      float atomics into acc[image][triangle][kAcc].
+//   3. the table is drained once per workgroup with contiguous global float atomics
+//      into acc[image][triangle][kStride].
 //
-// The functor supplies the per-pixel values:
+// The functor supplies the per-pixel work:
 //   struct Fn {
-//     static constexpr int kN = ...;          // sums per triangle (<= 12)
-//     struct Pixel {...}; struct Triangle {...};
-//     __device__ bool load_pixel(size_t pix, int T, int &tri, Pixel &p) const;  // false: skip
-//     __device__ void load_triangle(int img, int tri, Triangle &t) const;       // on run change
-//     __device__ void accumulate(const Pixel &p, const Triangle &t, float (&a)[kN]) const;
+//     static constexpr int kN      = ...;   // sums per triangle
+//     static constexpr int kStride = ...;   // floats per acc row (>= kN)
+//     static constexpr int kSlots  = ...;   // LDS hash slots, power of two
+//     struct Pixel {...}; struct Triangle {...}; struct Image {...};
+//     __device__ void begin_image(int img, Image &) const;
+//     __device__ bool load_pixel(int img, int x, int y, size_t pix, int T, int &tri, Pixel &) const;
+//     __device__ void load_triangle(int img, int tri, Triangle &) const;   // on run change
+//     __device__ void accumulate(const Pixel &, const Triangle &, float (&a)[kN], Image &) const;
+//     __device__ void end_image(int img, Image &) const;   // per-lane image-wide sums
 //   };
 // Per-triangle data (e.g. the adjugate) is fetched once per run, not per pixel.
 #pragma once
@@ -33,32 +37,31 @@ namespace mr {
 constexpr int kRunThreads = 256;
 constexpr int kRunRowsPerWave = 32;                                  // pixels each lane walks
 constexpr int kRunRegionH = kRunRowsPerWave * (kRunThreads / kWave);  // 128 rows / workgroup
-constexpr int kRunSlots = 512;                                       // LDS hash slots
-constexpr int kRunSlotsLog2 = 9;
-constexpr int kAccStride = 12;  // floats per (image, triangle) row of acc[]: 48 B
 constexpr int kRunMaxProbe = 16;
 
+template <int SLOTS>
 __device__ __forceinline__ int run_find_slot(int *keys, int tri) {
-  unsigned h = ((unsigned)tri * 2654435761u) >> (32 - kRunSlotsLog2);
+  static_assert((SLOTS & (SLOTS - 1)) == 0, "power of two");
+  unsigned h = (((unsigned)tri * 2654435761u) >> 12) & (SLOTS - 1);
   for (int probe = 0; probe < kRunMaxProbe; ++probe) {
     const int old = atomicCAS(&keys[h], -1, tri);
     if (old == -1 || old == tri) return (int)h;
-    h = (h + 1) & (kRunSlots - 1);
+    h = (h + 1) & (SLOTS - 1);
   }
   return -1;
 }
 
-template <int N>
+template <int N, int STRIDE, int SLOTS>
 __device__ __forceinline__ void run_flush(int *keys, float *vals, float *acc_img, int tri,
                                           float (&a)[N]) {
   if (tri < 0) return;
-  const int slot = run_find_slot(keys, tri);
+  const int slot = run_find_slot<SLOTS>(keys, tri);
   if (slot >= 0) {
 #pragma unroll
     for (int k = 0; k < N; ++k) atomicAdd(&vals[slot * N + k], a[k]);
   } else {  // table saturated (very dense mesh): straight to HBM
 #pragma unroll
-    for (int k = 0; k < N; ++k) atomicAdd(&acc_img[(size_t)tri * kAccStride + k], a[k]);
+    for (int k = 0; k < N; ++k) atomicAdd(&acc_img[(size_t)tri * STRIDE + k], a[k]);
   }
 #pragma unroll
   for (int k = 0; k < N; ++k) a[k] = 0.0f;
@@ -68,10 +71,10 @@ template <class Fn>
 __global__ __launch_bounds__(kRunThreads) void k_accumulate_runs(
     Fn fn, int T, int W, int H, int regions_x, int regions_per_image, int n_regions,
     int regions_per_xcd, float *__restrict__ acc) {
-  constexpr int N = Fn::kN;
-  static_assert(N <= kAccStride, "accumulator row too small");
-  __shared__ int s_keys[kRunSlots];
-  __shared__ float s_vals[kRunSlots * N];
+  constexpr int N = Fn::kN, STRIDE = Fn::kStride, SLOTS = Fn::kSlots;
+  static_assert(N <= STRIDE, "accumulator row too small");
+  __shared__ int s_keys[SLOTS];
+  __shared__ float s_vals[SLOTS * N];
 
   const int region = xcd_contiguous_block((int)blockIdx.x, n_regions, regions_per_xcd);
   if (region < 0) return;
@@ -81,8 +84,8 @@ __global__ __launch_bounds__(kRunThreads) void k_accumulate_runs(
   const int rx = rr - ry * regions_x;
 
   const int tid = (int)threadIdx.x;
-  for (int i = tid; i < kRunSlots; i += kRunThreads) s_keys[i] = -1;
-  for (int i = tid; i < kRunSlots * N; i += kRunThreads) s_vals[i] = 0.0f;
+  for (int i = tid; i < SLOTS; i += kRunThreads) s_keys[i] = -1;
+  for (int i = tid; i < SLOTS * N; i += kRunThreads) s_vals[i] = 0.0f;
   __syncthreads();
 
   const int lane = tid & (kWave - 1);
@@ -90,8 +93,10 @@ __global__ __launch_bounds__(kRunThreads) void k_accumulate_runs(
   const int x = rx * kWave + lane;
   const int y_begin = ry * kRunRegionH + wave * kRunRowsPerWave;
   const int y_end = min(y_begin + kRunRowsPerWave, H);
-  float *acc_img = acc + (size_t)img * T * kAccStride;
+  float *acc_img = acc + (size_t)img * T * STRIDE;
 
+  typename Fn::Image image_sums;
+  fn.begin_image(img, image_sums);
   if (x < W) {
     float a[N];
 #pragma unroll
@@ -102,35 +107,38 @@ __global__ __launch_bounds__(kRunThreads) void k_accumulate_runs(
     for (int y = y_begin; y < y_end; ++y, pix += W) {
       int tri;
       typename Fn::Pixel p;
-      if (!fn.load_pixel(pix, T, tri, p)) continue;
+      if (!fn.load_pixel(img, x, y, pix, T, tri, p)) continue;
       if (tri != run_tri) {
-        run_flush<N>(s_keys, s_vals, acc_img, run_tri, a);
+        run_flush<N, STRIDE, SLOTS>(s_keys, s_vals, acc_img, run_tri, a);
         run_tri = tri;
         fn.load_triangle(img, tri, tri_data);
       }
-      fn.accumulate(p, tri_data, a);
+      fn.accumulate(p, tri_data, a, image_sums);
     }
-    run_flush<N>(s_keys, s_vals, acc_img, run_tri, a);
+    run_flush<N, STRIDE, SLOTS>(s_keys, s_vals, acc_img, run_tri, a);
   }
+  fn.end_image(img, image_sums);  // every lane takes part (wave-level reduction inside)
   __syncthreads();
 
-  // Drain: 16 lanes per slot (N active) -> one contiguous <=48-byte row per triangle.
-  for (int i = tid; i < kRunSlots * 16; i += kRunThreads) {
-    const int slot = i >> 4, k = i & 15;
+  // Drain: consecutive lanes take consecutive floats of a slot -> one contiguous
+  // <= 4*kN-byte row of global float atomics per triangle.
+  constexpr int kLanesPerSlot = N <= 16 ? 16 : (N <= 32 ? 32 : 64);
+  for (int i = tid; i < SLOTS * kLanesPerSlot; i += kRunThreads) {
+    const int slot = i / kLanesPerSlot, k = i % kLanesPerSlot;
     const int tri = s_keys[slot];
-    if (tri >= 0 && k < N) atomicAdd(&acc_img[(size_t)tri * kAccStride + k], s_vals[slot * N + k]);
+    if (tri >= 0 && k < N) atomicAdd(&acc_img[(size_t)tri * STRIDE + k], s_vals[slot * N + k]);
   }
 }
 
-template <class PixelFn>
-inline int launch_accumulate_runs(const PixelFn &fn, int B, int T, int W, int H, float *acc,
+template <class Fn>
+inline int launch_accumulate_runs(const Fn &fn, int B, int T, int W, int H, float *acc,
                                   hipStream_t s) {
   const int regions_x = (W + kWave - 1) / kWave;
   const int regions_y = (H + kRunRegionH - 1) / kRunRegionH;
   const int per_image = regions_x * regions_y;
   const int n_regions = per_image * B;
   const int per_xcd = (n_regions + kXcds - 1) / kXcds;
-  hipLaunchKernelGGL((k_accumulate_runs<PixelFn>), dim3((unsigned)(per_xcd * kXcds)),
+  hipLaunchKernelGGL((k_accumulate_runs<Fn>), dim3((unsigned)(per_xcd * kXcds)),
                      dim3(kRunThreads), 0, s, fn, T, W, H, regions_x, per_image, n_regions,
                      per_xcd, acc);
   return check_launch();
@@ -139,5 +147,55 @@ inline int launch_accumulate_runs(const PixelFn &fn, int B, int T, int W, int H,
 struct F3 {
   float x, y, z;
 };
+
+struct NoImageSums {};
+
+// ---- the rasterizer's own backward, shared by raster_backward.hip and shade.hip ----
+// Record per (image, triangle): sign-corrected adjugate u[9] (row i = edge i, column
+// c = clip component x/y/w), its column sums and 1/|det| (rasterize_triangles.cpp
+// :180-198).  64 bytes.
+struct alignas(64) BwdRec {
+  float4 a, b, c, d;  // a=(u0..u3) b=(u4..u7) c=(u8,S0,S1,S2) d=(1/|det|,-,-,-)
+};
+
+struct BwdTriangle {
+  float u[9], s[3], inv;
+};
+
+__device__ __forceinline__ void load_bwd_triangle(const BwdRec *r, BwdTriangle &t) {
+  const float4 a = r->a, b = r->b, c = r->c, d = r->d;
+  t.u[0] = a.x; t.u[1] = a.y; t.u[2] = a.z; t.u[3] = a.w;
+  t.u[4] = b.x; t.u[5] = b.y; t.u[6] = b.z; t.u[7] = b.w;
+  t.u[8] = c.x; t.s[0] = c.y; t.s[1] = c.z; t.s[2] = c.w;
+  t.inv = d.x;
+}
+
+// The nine partials of rasterize_triangles.cpp:202-269 for one pixel, added into
+// acc[j*3 + c] (corner j, clip component c = x, y, w).  FMA contraction is switched
+// off inside: (-U b_j + S b_i b_j) is a small difference of large terms for small /
+// sliver triangles and must round as in the reference.
+__device__ __forceinline__ void raster_pixel_partials(const F3 bary, const F3 g, const BwdTriangle &t,
+                                                      float *acc) {
+#pragma clang fp contract(off)
+  const float b[3] = {bary.x, bary.y, bary.z};
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float sb0 = t.s[c] * b[0], sb1 = t.s[c] * b[1], sb2 = t.s[c] * b[2];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float d0 = (-t.u[0 + c]) * b[j] + sb0 * b[j];
+      const float d1 = (-t.u[3 + c]) * b[j] + sb1 * b[j];
+      const float d2 = (-t.u[6 + c]) * b[j] + sb2 * b[j];
+      const float v = (g.x * d0 + g.y * d1) + g.z * d2;
+      acc[j * 3 + c] += v * t.inv;
+    }
+  }
+}
+
+// One thread per (image, triangle): fills BwdRec from clip-space vertices.
+__global__ void k_bwd_setup(const float4 *__restrict__ clip, const int32_t *__restrict__ tris, int B,
+                            int V, int T, BwdRec *__restrict__ recs);
+int launch_bwd_setup(const float *clip, const int32_t *tris, int B, int V, int T, BwdRec *recs,
+                     hipStream_t s);
 
 }  // namespace mr

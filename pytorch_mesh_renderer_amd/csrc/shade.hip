@@ -1,0 +1,405 @@
+// Fused deferred shading for gfx950 (MI355X): attribute interpolation + Phong,
+// forward and backward, straight from the G-buffer.
+//
+// Replaces, for the diffuse + ambient path of mesh_renderer.render():
+//   * the corner gather / multiply / sum / alpha / background blend of
+//     rasterize_clip_space  (reference: src/mesh_renderer/rasterize.py:118-150),
+//   * the attribute unpacking, normalisation and mask of render()
+//     (src/mesh_renderer/render.py:199-215),
+//   * phong_shader's ambient and diffuse terms, the alpha mask and the vertical flip
+//     (src/mesh_renderer/render.py:287-323, 373-386),
+// and the whole autograd graph the reference builds behind them.  In the reference
+// these are ~40 eager ops over [B, L, H*W, 3] tensors (3.6 GB of gathered corners at
+// 1024^2 x 32); here the forward reads 16 B/px (id + barycentrics) and writes 16 B/px
+// (RGBA), and the backward reads 32 B/px (dRGBA + id + barycentrics).
+//
+//   k_shade_forward    one thread per pixel; vertex attributes are gathered from the
+//                      L2-resident [B,V,3] arrays (no concatenated attribute tensor).
+//   ShadeGradFn        per-pixel backward evaluated inside k_accumulate_runs
+//                      (run_accum.h): recomputes the pixel's shading, back-propagates
+//                      to the interpolated normal / position / diffuse colour, to the
+//                      barycentrics and -- through rasterize_triangles.cpp:202-269 -- to
+//                      the clip-space corners; 36 sums per triangle (27 attribute + 9
+//                      clip) ride the column runs, light / ambient gradients are
+//                      per-lane sums reduced once per wave.
+//   k_shade_scatter    one thread per touched (image, triangle): atomics into
+//                      dnormals / dpositions / ddiffuse [B,V,3] and dclip [B,V,4].
+#include "run_accum.h"
+
+namespace mr {
+namespace {
+
+constexpr int kThreads = 256;
+constexpr float kNormEps = 1e-12f;         // torch.nn.functional.normalize default eps
+constexpr float kDegenerateCutoff = 0.9f;  // rasterize_triangles.cpp:13
+constexpr int kMaxLights = 4;              // fused path; more lights use the composed path
+
+struct Lights {
+  const float *__restrict__ pos;  // [B,L,3]
+  const float *__restrict__ col;  // [B,L,3]
+  const float *__restrict__ amb;  // [B,3] or nullptr
+  int L;
+};
+
+struct Corners {  // the three corners' (normal, position, diffuse): 27 floats
+  float c[3][9];
+};
+
+__device__ __forceinline__ void load_corners(const F3 *__restrict__ normals,
+                                             const F3 *__restrict__ positions,
+                                             const F3 *__restrict__ diffuse,
+                                             const int32_t *__restrict__ tris, size_t vbase, int V,
+                                             int tri, Corners &o) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    int vi = tris[3 * tri + k];
+    if ((unsigned)vi >= (unsigned)V) vi = 0;
+    const F3 n = normals[vbase + vi], p = positions[vbase + vi], d = diffuse[vbase + vi];
+    o.c[k][0] = n.x; o.c[k][1] = n.y; o.c[k][2] = n.z;
+    o.c[k][3] = p.x; o.c[k][4] = p.y; o.c[k][5] = p.z;
+    o.c[k][6] = d.x; o.c[k][7] = d.y; o.c[k][8] = d.z;
+  }
+}
+
+// alpha = clamp(sum(2*bary), 0, 1); attr = alpha * interp + (1 - alpha) * (-1)
+// (rasterize.py:137-150 with render.py:197's background of -1).
+__device__ __forceinline__ void interpolate9(const Corners &cr, const F3 b, float &pre, float &alpha,
+                                             float (&interp)[9], float (&attr)[9]) {
+  pre = (2.0f * b.x + 2.0f * b.y) + 2.0f * b.z;
+  alpha = fminf(fmaxf(pre, 0.0f), 1.0f);
+  const float one_m = 1.0f - alpha;
+#pragma unroll
+  for (int a = 0; a < 9; ++a) {
+    interp[a] = (cr.c[0][a] * b.x + cr.c[1][a] * b.y) + cr.c[2][a] * b.z;
+    attr[a] = alpha * interp[a] + one_m * -1.0f;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void k_shade_forward(
+    const int32_t *__restrict__ ids, const F3 *__restrict__ bary, const F3 *__restrict__ normals,
+    const F3 *__restrict__ positions, const F3 *__restrict__ diffuse,
+    const int32_t *__restrict__ tris, Lights lights, int B, int V, int T, int W, int H,
+    float4 *__restrict__ out) {
+  const size_t px_per_image = (size_t)W * H;
+  const size_t n_px = px_per_image * B;
+  for (size_t pix = (size_t)blockIdx.x * kThreads + threadIdx.x; pix < n_px;
+       pix += (size_t)gridDim.x * kThreads) {
+    const int img = (int)(pix / px_per_image);
+    const size_t rem = pix - (size_t)img * px_per_image;
+    const int y = (int)(rem / W), x = (int)(rem - (size_t)y * W);
+    const F3 b = bary[pix];
+    float4 rgba = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float pre_probe = (2.0f * b.x + 2.0f * b.y) + 2.0f * b.z;
+    if (pre_probe > 0.0f) {  // alpha == 0: every attribute is the -1 background, mask = 0
+      int t = ids[pix];
+      if ((unsigned)t >= (unsigned)T) t = 0;
+      Corners cr;
+      load_corners(normals, positions, diffuse, tris, (size_t)img * V, V, t, cr);
+      float pre, alpha, interp[9], at[9];
+      interpolate9(cr, b, pre, alpha, interp, at);
+      const bool mask = (at[6] >= 0.0f) || (at[7] >= 0.0f) || (at[8] >= 0.0f);  // render.py:215
+      if (mask) {
+        const float nn = sqrtf(at[0] * at[0] + at[1] * at[1] + at[2] * at[2]);
+        const float inv_nn = 1.0f / fmaxf(nn, kNormEps);
+        const float nx = at[0] * inv_nn, ny = at[1] * inv_nn, nz = at[2] * inv_nn;
+        float r = 0.f, g = 0.f, bl = 0.f;
+        if (lights.amb) {  // render.py:298-301
+          const float *am = lights.amb + (size_t)img * 3;
+          r = am[0] * at[6]; g = am[1] * at[7]; bl = am[2] * at[8];
+        }
+        for (int l = 0; l < lights.L; ++l) {  // render.py:304-323
+          const float *lp = lights.pos + ((size_t)img * lights.L + l) * 3;
+          const float *li = lights.col + ((size_t)img * lights.L + l) * 3;
+          const float vx = lp[0] - at[3], vy = lp[1] - at[4], vz = lp[2] - at[5];
+          const float inv_vn = 1.0f / fmaxf(sqrtf(vx * vx + vy * vy + vz * vz), kNormEps);
+          const float ndl = fminf(fmaxf(nx * (vx * inv_vn) + ny * (vy * inv_vn) + nz * (vz * inv_vn), 0.0f), 1.0f);
+          r += at[6] * ndl * li[0];
+          g += at[7] * ndl * li[1];
+          bl += at[8] * ndl * li[2];
+        }
+        rgba = make_float4(r, g, bl, 1.0f);
+      }
+    }
+    // render.py:384-386: the image is flipped vertically (G-buffer row 0 is the bottom)
+    out[((size_t)img * H + (H - 1 - y)) * W + x] = rgba;
+  }
+}
+
+template <int L>
+struct ShadeGradFn {
+  static constexpr int kN = 36;       // 27 attribute partials [corner][attr] + 9 clip partials
+  static constexpr int kStride = 36;
+  static constexpr int kSlots = 256;
+  const float4 *__restrict__ drgba;   // [B,H,W,4], image rows (flipped w.r.t. the G-buffer)
+  const int32_t *__restrict__ ids;
+  const F3 *__restrict__ bary;
+  const F3 *__restrict__ normals;
+  const F3 *__restrict__ positions;
+  const F3 *__restrict__ diffuse;
+  const int32_t *__restrict__ tris;
+  const BwdRec *__restrict__ recs;
+  Lights lights;
+  float *__restrict__ light_grads;    // [B][L*6 + 3]: dpos (L x 3), dcol (L x 3), dambient (3)
+  int V, T_, W, H;
+
+  struct Pixel {
+    F3 b, g;
+    int tri;
+  };
+  struct Triangle {
+    Corners cr;
+    BwdTriangle bt;
+  };
+  struct Image {
+    float lp[L][3], li[L][3], amb[3];      // this image's lights (loaded once per lane)
+    float dpos[L][3], dcol[L][3], damb[3];  // per-lane partial sums
+  };
+
+  __device__ __forceinline__ void begin_image(int img, Image &im) const {
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        im.lp[l][c] = lights.pos[((size_t)img * L + l) * 3 + c];
+        im.li[l][c] = lights.col[((size_t)img * L + l) * 3 + c];
+        im.dpos[l][c] = 0.f;
+        im.dcol[l][c] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      im.amb[c] = lights.amb ? lights.amb[(size_t)img * 3 + c] : 0.f;
+      im.damb[c] = 0.f;
+    }
+  }
+
+  __device__ __forceinline__ bool load_pixel(int img, int x, int y, size_t pix, int T, int &tri,
+                                             Pixel &p) const {
+    p.b = bary[pix];
+    const float pre = (2.0f * p.b.x + 2.0f * p.b.y) + 2.0f * p.b.z;
+    if (!(pre > 0.0f)) return false;  // background: mask = 0, no gradient anywhere
+    const int t = ids[pix];
+    if ((unsigned)t >= (unsigned)T) return false;
+    const float4 g = drgba[((size_t)img * H + (H - 1 - y)) * W + x];  // un-flip
+    p.g.x = g.x; p.g.y = g.y; p.g.z = g.z;  // d/d alpha is dropped: the mask is not differentiable
+    p.tri = t;
+    tri = t;
+    return true;
+  }
+
+  __device__ __forceinline__ void load_triangle(int img, int tri, Triangle &t) const {
+    load_corners(normals, positions, diffuse, tris, (size_t)img * V, V, tri, t.cr);
+    load_bwd_triangle(recs + (size_t)img * T_ + tri, t.bt);
+  }
+
+  __device__ __forceinline__ void accumulate(const Pixel &p, const Triangle &t, float (&acc)[kN],
+                                             Image &im) const {
+    float pre, alpha, interp[9], at[9];
+    interpolate9(t.cr, p.b, pre, alpha, interp, at);
+    if (!((at[6] >= 0.0f) || (at[7] >= 0.0f) || (at[8] >= 0.0f))) return;  // masked: where() -> 0
+    const float g[3] = {p.g.x, p.g.y, p.g.z};
+    const float nn = sqrtf(at[0] * at[0] + at[1] * at[1] + at[2] * at[2]);
+    const float inv_nn = 1.0f / fmaxf(nn, kNormEps);
+    const float N[3] = {at[0] * inv_nn, at[1] * inv_nn, at[2] * inv_nn};
+    float dN[3] = {0.f, 0.f, 0.f}, dP[3] = {0.f, 0.f, 0.f};
+    float dKd[3] = {g[0] * im.amb[0], g[1] * im.amb[1], g[2] * im.amb[2]};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) im.damb[c] += g[c] * at[6 + c];
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      const float v[3] = {im.lp[l][0] - at[3], im.lp[l][1] - at[4], im.lp[l][2] - at[5]};
+      const float vn = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+      const float inv_vn = 1.0f / fmaxf(vn, kNormEps);
+      const float D[3] = {v[0] * inv_vn, v[1] * inv_vn, v[2] * inv_vn};
+      const float pre_l = N[0] * D[0] + N[1] * D[1] + N[2] * D[2];
+      const float ndl = fminf(fmaxf(pre_l, 0.0f), 1.0f);
+      float t_l = 0.f;  // d/d ndl
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        dKd[c] += g[c] * ndl * im.li[l][c];
+        im.dcol[l][c] += g[c] * at[6 + c] * ndl;
+        t_l += g[c] * at[6 + c] * im.li[l][c];
+      }
+      if (pre_l >= 0.0f && pre_l <= 1.0f) {  // torch.clamp passes the gradient inclusively
+        float dD[3], dd = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          dN[c] += t_l * D[c];
+          dD[c] = t_l * N[c];
+          dd += D[c] * dD[c];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          // backward of v / max(|v|, eps)
+          const float dv = (vn > kNormEps ? (dD[c] - D[c] * dd) : dD[c]) * inv_vn;
+          im.dpos[l][c] += dv;
+          dP[c] -= dv;
+        }
+      }
+    }
+    float dat[9];
+    {
+      const float nd = N[0] * dN[0] + N[1] * dN[1] + N[2] * dN[2];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        dat[c] = (nn > kNormEps ? (dN[c] - N[c] * nd) : dN[c]) * inv_nn;
+        dat[3 + c] = dP[c];
+        dat[6 + c] = dKd[c];
+      }
+    }
+    // interpolation backward (rasterize.py:137-150)
+    float dalpha = 0.f, db[3] = {0.f, 0.f, 0.f};
+    const float bw[3] = {p.b.x, p.b.y, p.b.z};
+#pragma unroll
+    for (int a = 0; a < 9; ++a) {
+      const float di = alpha * dat[a];
+      dalpha += dat[a] * (interp[a] + 1.0f);  // background is -1
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        db[k] += di * t.cr.c[k][a];
+        acc[k * 9 + a] += di * bw[k];
+      }
+    }
+    const float dpre = (pre >= 0.0f && pre <= 1.0f) ? 2.0f * dalpha : 0.0f;
+    F3 dbary;
+    dbary.x = db[0] + dpre; dbary.y = db[1] + dpre; dbary.z = db[2] + dpre;
+    // rasterizer backward (cpp:162 skip rule, then cpp:202-269)
+    if (!(p.tri == 0 && (p.b.x + p.b.y) + p.b.z < kDegenerateCutoff))
+      raster_pixel_partials(p.b, dbary, t.bt, acc + 27);
+  }
+
+  __device__ __forceinline__ void end_image(int img, Image &im) const {
+    float *dst = light_grads + (size_t)img * (L * 6 + 3);
+    const int lane = lane_id();
+    auto reduce_add = [&](float v, int slot) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+      if (lane == 0 && v != 0.0f) atomicAdd(&dst[slot], v);
+    };
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        reduce_add(im.dpos[l][c], l * 3 + c);
+        reduce_add(im.dcol[l][c], L * 3 + l * 3 + c);
+      }
+    }
+    if (lights.amb) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) reduce_add(im.damb[c], L * 6 + c);
+    }
+  }
+};
+
+__global__ __launch_bounds__(kThreads) void k_shade_scatter(
+    const float *__restrict__ acc, const int32_t *__restrict__ tris, int B, int V, int T,
+    float *__restrict__ dnormals, float *__restrict__ dpositions, float *__restrict__ ddiffuse,
+    float *__restrict__ dclip) {
+  const long gid = (long)blockIdx.x * kThreads + threadIdx.x;
+  if (gid >= (long)B * T) return;
+  const float4 *row = (const float4 *)(acc + gid * 36);  // 144-byte rows, 16-byte aligned
+  float a[36];
+  bool any = false;
+#pragma unroll
+  for (int q = 0; q < 9; ++q) {
+    const float4 v = row[q];
+    a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+    any |= (v.x != 0.f) | (v.y != 0.f) | (v.z != 0.f) | (v.w != 0.f);
+  }
+  if (!any) return;
+  const int b = (int)(gid / T);
+  const int t = (int)(gid - (long)b * T);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int vi = tris[3 * t + k];
+    if ((unsigned)vi >= (unsigned)V) continue;
+    const size_t v3 = ((size_t)b * V + vi) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      atomicAdd(&dnormals[v3 + c], a[k * 9 + c]);
+      atomicAdd(&dpositions[v3 + c], a[k * 9 + 3 + c]);
+      atomicAdd(&ddiffuse[v3 + c], a[k * 9 + 6 + c]);
+    }
+    float *dc = dclip + ((size_t)b * V + vi) * 4;
+    atomicAdd(&dc[0], a[27 + k * 3 + 0]);
+    atomicAdd(&dc[1], a[27 + k * 3 + 1]);
+    atomicAdd(&dc[3], a[27 + k * 3 + 2]);
+  }
+}
+
+inline unsigned capped_blocks(size_t n) {
+  const size_t want = (n + kThreads - 1) / kThreads;
+  const size_t cap = 256u * 32u;
+  return (unsigned)(want < cap ? (want ? want : 1) : cap);
+}
+
+inline size_t shade_acc_bytes(int B, int T) { return align_up((size_t)B * T * 36 * sizeof(float), 256); }
+
+}  // namespace
+
+int shade_max_lights() { return kMaxLights; }
+
+int launch_shade_forward(const int32_t *ids, const float *bary, const float *normals,
+                         const float *positions, const float *diffuse, const int32_t *tris,
+                         const float *light_pos, const float *light_col, const float *ambient,
+                         int B, int V, int T, int W, int H, int L, float *rgba, hipStream_t s) {
+  const size_t n_px = (size_t)B * W * H;
+  if (n_px == 0) return MR_OK;
+  Lights lights{light_pos, light_col, ambient, L};
+  hipLaunchKernelGGL(k_shade_forward, dim3(capped_blocks(n_px)), dim3(kThreads), 0, s, ids,
+                     (const F3 *)bary, (const F3 *)normals, (const F3 *)positions,
+                     (const F3 *)diffuse, tris, lights, B, V, T, W, H, (float4 *)rgba);
+  return check_launch();
+}
+
+size_t shade_backward_ws(int B, int V, int T, int W, int H) {
+  (void)V; (void)W; (void)H;
+  return shade_acc_bytes(B, T) + align_up((size_t)B * T * sizeof(BwdRec), 256);
+}
+
+int launch_shade_backward(const float *drgba, const int32_t *ids, const float *bary,
+                          const float *clip, const float *normals, const float *positions,
+                          const float *diffuse, const int32_t *tris, const float *light_pos,
+                          const float *light_col, const float *ambient, int B, int V, int T, int W,
+                          int H, int L, float *dclip, float *dnormals, float *dpositions,
+                          float *ddiffuse, float *light_grads, void *ws, hipStream_t s) {
+  if (B == 0) return MR_OK;
+  const size_t v3 = (size_t)B * V * 3 * sizeof(float);
+  if (V > 0) {
+    if (hipMemsetAsync(dclip, 0, (size_t)B * V * 4 * sizeof(float), s) != hipSuccess) return check_launch();
+    if (hipMemsetAsync(dnormals, 0, v3, s) != hipSuccess) return check_launch();
+    if (hipMemsetAsync(dpositions, 0, v3, s) != hipSuccess) return check_launch();
+    if (hipMemsetAsync(ddiffuse, 0, v3, s) != hipSuccess) return check_launch();
+  }
+  if (hipMemsetAsync(light_grads, 0, (size_t)B * (L * 6 + 3) * sizeof(float), s) != hipSuccess)
+    return check_launch();
+  if (T == 0 || V == 0) return MR_OK;
+  float *acc = (float *)ws;
+  BwdRec *recs = (BwdRec *)((char *)ws + shade_acc_bytes(B, T));
+  if (hipMemsetAsync(acc, 0, (size_t)B * T * 36 * sizeof(float), s) != hipSuccess) return check_launch();
+  int rc = launch_bwd_setup(clip, tris, B, V, T, recs, s);
+  if (rc != MR_OK) return rc;
+  Lights lights{light_pos, light_col, ambient, L};
+#define MR_SHADE_BWD(NL)                                                                        \
+  {                                                                                             \
+    ShadeGradFn<NL> fn{(const float4 *)drgba, ids, (const F3 *)bary, (const F3 *)normals,       \
+                       (const F3 *)positions, (const F3 *)diffuse, tris, recs, lights,          \
+                       light_grads, V, T, W, H};                                                \
+    rc = launch_accumulate_runs(fn, B, T, W, H, acc, s);                                        \
+  }
+  switch (L) {
+    case 1: MR_SHADE_BWD(1); break;
+    case 2: MR_SHADE_BWD(2); break;
+    case 3: MR_SHADE_BWD(3); break;
+    case 4: MR_SHADE_BWD(4); break;
+    default: return MR_EINVAL;
+  }
+#undef MR_SHADE_BWD
+  if (rc != MR_OK) return rc;
+  const long nbt = (long)B * T;
+  hipLaunchKernelGGL(k_shade_scatter, dim3((unsigned)((nbt + kThreads - 1) / kThreads)),
+                     dim3(kThreads), 0, s, acc, tris, B, V, T, dnormals, dpositions, ddiffuse, dclip);
+  return check_launch();
+}
+
+}  // namespace mr

@@ -72,3 +72,36 @@ class AttributeInterpolator(torch.autograd.Function):
             alpha = torch.clamp(2.0 * bary.sum(-1, keepdim=True), 0.0, 1.0)
             dbackground = ((1.0 - alpha) * dout).sum(dim=(0, 1, 2))
         return None, dbary, dattrs, None, dbackground
+
+
+class FusedPhongRenderer(torch.autograd.Function):
+    """G-buffer rasterization + attribute interpolation + diffuse/ambient Phong as ONE
+    differentiable op: 2 kernels forward (k_raster, k_shade_forward), 1 pass over the
+    G-buffer backward.  Used by render() when no specular term is requested; covers
+    src/mesh_renderer/rasterize.py:66-152 and src/mesh_renderer/render.py:199-228,
+    287-323, 373-386 and their autograd graph."""
+
+    @staticmethod
+    def forward(ctx, clip, positions, normals, diffuse, triangles, light_positions,
+                light_intensities, ambient, image_width, image_height):
+        clip_d = clip.detach().contiguous()
+        ids, bary, _ = _native.rasterize_forward(clip_d, triangles, int(image_width), int(image_height))
+        args = [t.detach().contiguous() for t in (normals, positions, diffuse)]
+        lp, li = light_positions.detach().contiguous(), light_intensities.detach().contiguous()
+        amb = ambient.detach().contiguous() if ambient is not None else None
+        rgba = _native.shade_forward(ids, bary, args[0], args[1], args[2], triangles, lp, li, amb)
+        saved = [clip_d, ids, bary, args[0], args[1], args[2], triangles, lp, li]
+        if amb is not None:
+            saved.append(amb)
+        ctx.save_for_backward(*saved)
+        ctx.has_ambient = amb is not None
+        return rgba
+
+    @staticmethod
+    def backward(ctx, drgba):
+        saved = ctx.saved_tensors
+        clip, ids, bary, normals, positions, diffuse, triangles, lp, li = saved[:9]
+        amb = saved[9] if ctx.has_ambient else None
+        dclip, dn, dp, dd, dlp, dli, damb = _native.shade_backward(
+            drgba.contiguous(), ids, bary, clip, normals, positions, diffuse, triangles, lp, li, amb)
+        return dclip, dp, dn, dd, None, dlp, dli, damb, None, None

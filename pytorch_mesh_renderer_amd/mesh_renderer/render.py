@@ -76,6 +76,12 @@ def render(vertices, triangles, normals, diffuse_colors, camera_position, camera
     if shininess_coefficients is not None and specular_colors is None:
         raise ValueError("Shininess coefficients were supplied without specular colors.")
 
+    if specular_colors is None and _fused_path_applies(vertices, normals, diffuse_colors,
+                                                       light_positions):
+        return _render_fused(vertices, triangles, normals, diffuse_colors, camera_position,
+                             camera_lookat, camera_up, light_positions, light_intensities,
+                             image_width, image_height, ambient_color, fov_y, near_clip, far_clip)
+
     pieces = [normals, vertices, diffuse_colors]  # attribute layout, render.py:171-181
     per_vertex_shininess = False
     if specular_colors is not None:
@@ -125,6 +131,33 @@ def render(vertices, triangles, normals, diffuse_colors, camera_position, camera
         camera_position=camera_position.to(device) if pixel_specular is not None else None,
         specular_colors=pixel_specular, shininess_coefficients=shininess_coefficients,
         ambient_color=ambient_color.to(device) if ambient_color is not None else None)
+
+
+def _fused_path_applies(vertices, normals, diffuse_colors, light_positions):
+    """The fused HIP shading kernels cover diffuse + ambient Phong with 1..4 lights on
+    float32 inputs of matching [B,V,3] shape; everything else takes the composed path."""
+    from .. import _native
+    return (vertices.dtype == torch.float32 and normals.shape == vertices.shape and
+            diffuse_colors.shape == vertices.shape and
+            1 <= light_positions.shape[1] <= _native.shade_max_lights())
+
+
+def _render_fused(vertices, triangles, normals, diffuse_colors, camera_position, camera_lookat,
+                  camera_up, light_positions, light_intensities, image_width, image_height,
+                  ambient_color, fov_y, near_clip, far_clip):
+    from .rasterize_triangles_ext import FusedPhongRenderer
+    device = vertices.device
+    camera_matrices = camera_utils.look_at(camera_position.to(device), camera_lookat.to(device),
+                                           camera_up.to(device))
+    perspective_transforms = camera_utils.perspective(image_width / image_height, fov_y,
+                                                      near_clip, far_clip)
+    clip_space_transforms = torch.matmul(perspective_transforms, camera_matrices)
+    clip = camera_utils.transform_homogeneous(clip_space_transforms, vertices)
+    return FusedPhongRenderer.apply(
+        clip, vertices, normals, diffuse_colors, triangles, light_positions.to(device),
+        light_intensities.to(device).to(torch.float32),
+        ambient_color.to(device) if ambient_color is not None else None,
+        image_width, image_height)
 
 
 def phong_shader(normals, alphas, pixel_positions, light_positions, light_intensities,
