@@ -32,7 +32,7 @@ int mr_last_hip_error(void) { return mr::g_last_hip_error; }
 // Tuning hook (not part of the reference surface): 0 = 8x8, 1 = 16x4, 2 = 32x2
 // pixel tile per wavefront in the forward raster kernel.  Results are identical.
 int mr_set_raster_tile_shape(int shape) {
-  if (shape < 0 || shape > 2) return MR_EINVAL;
+  if (shape < 0 || shape > 18) return MR_EINVAL;
   mr::g_raster_tile_shape = shape;
   return MR_OK;
 }

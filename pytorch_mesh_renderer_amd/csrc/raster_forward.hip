@@ -7,17 +7,30 @@
 //   k_setup   one thread per (image, triangle): sign-corrected adjugate, clip z/w,
 //             pixel bbox (binary64 projection as in cpp:361-366), packed into a
 //             64-byte record; plus the binary64 pixel-centre tables (cpp:376-377).
-//   k_raster  one 256-thread workgroup per 64x64-pixel region.  The workgroup
-//             compacts, IN TRIANGLE-ID ORDER, the triangles whose bbox touches the
-//             region into an LDS bin; each of its 4 wavefronts then walks 8x8 (or
-//             16x4 / 32x2) pixel tiles, one pixel per lane: the tile's candidates
-//             are picked from the LDS bin by a 64-wide bbox test + ballot, their
-//             records arrive through wave-uniform scalar loads (SGPR operands), and
-//             every lane runs the reference's exact edge / barycentric / z test.
-//             Walking candidates in ascending id reproduces the reference's
-//             sequential z-buffer semantics (ties -> later id, NaN handling)
-//             without any ordering trick.  Each pixel is written exactly once:
-//             (id, z, b0, b1, b2), 20 B/px, whole 128-B lines per workgroup.
+//   k_raster  one 256-thread workgroup per 64x64-pixel region, two stages:
+//     bin    each wavefront scans a quarter of the image's triangle list (no barrier
+//            in the loop): bbox-vs-region test, then an EXACT trivial reject -- the
+//            reference's own edge function evaluated at the region's most favourable
+//            pixel centre; fp32 multiply/add are monotone, so a negative value there
+//            proves every pixel of the region fails that edge.  Survivors are copied,
+//            in triangle-id order, as 80-byte entries (adjugate, z, w, id, bbox) into
+//            an LDS bin; 80 B = 20 banks keeps per-lane ds_read_b128 conflict-free.
+//     tiles  each wavefront walks 8x8 pixel tiles, one pixel per lane.  Per tile:
+//            (0) once per region, one thread per bin entry walks the tiles under the
+//                entry's bbox, applies the same exact trivial reject per tile and sets
+//                its bit in that tile's 256-bit LDS mask;
+//            (1) coverage: for every surviving entry, read wave-uniformly from LDS,
+//                all lanes evaluate the three edge functions and record "inside" as
+//                one bit of a per-lane mask -- no divisions, no divergence;
+//            (2) depth: each lane walks ITS OWN set bits in ascending id, re-reads that
+//                entry from LDS and runs the reference's barycentric / z arithmetic.
+//                The loop runs max-over-lanes(depth complexity) times, not once per
+//                candidate, and every active lane does useful work.
+//            Ascending id per pixel reproduces the reference's sequential z-buffer
+//            (ties -> later id, NaN handling) with no ordering trick.  Each pixel is
+//            written exactly once: (id, z, b0, b1, b2), 20 B/px, whole 128-B lines
+//            per workgroup.  A bin that fills up is flushed and the walk resumes from
+//            the stored state (rare: > 64 survivors in one quarter of the list).
 //
 // Exactness: this file is compiled with -ffp-contract=off; every float expression
 // below is written in the reference's association order.
@@ -158,9 +171,11 @@ __device__ __forceinline__ void shade_candidate(
   }
 }
 
+// First-generation kernel (kept for A/B runs through mr_set_raster_variant): candidates are
+// walked wave-uniformly with scalar record loads and a divergent accept branch.
 // TW x TH = 64: pixel tile walked by one wavefront, one pixel per lane.
 template <int TW, int TH>
-__global__ __launch_bounds__(kThreads) void k_raster(
+__global__ __launch_bounds__(kThreads) void k_raster_v1(
     const TriRec *__restrict__ recs, const uint2 *__restrict__ bbs,
     const float *__restrict__ pxtab, const float *__restrict__ pytab, int T, int W, int H,
     int regions_x, int regions_per_image, int n_regions, int regions_per_xcd,
@@ -290,6 +305,354 @@ __global__ __launch_bounds__(kThreads) void k_raster(
   raster_pass(n_bin, first_pass);
 }
 
+// ---------------------------------------------------------------------------------------
+// Second-generation kernel: LDS bin of full records, coverage / depth split.
+// ---------------------------------------------------------------------------------------
+constexpr int kEntryDw = 20;   // LDS entry: 20 dwords = 80 B (see file header)
+constexpr int kSubCap = 64;    // entries one wavefront may add per round
+constexpr int kWaves = kThreads / kWave;
+constexpr int kBin2Cap = kSubCap * kWaves;
+
+// Entry layout (dwords): 0-8 m[9] | 9-11 z0 z1 z2 | 12-14 w0 w1 w2 | 15 id | 16 bbx | 17 bby
+struct Entry {
+  float4 q0, q1, q2, q3;
+  uint2 bb;
+};
+
+__device__ __forceinline__ Entry read_entry(const float *s_ent, int e) {
+  const float *p = s_ent + e * kEntryDw;
+  Entry r;
+  r.q0 = *(const float4 *)(p);
+  r.q1 = *(const float4 *)(p + 4);
+  r.q2 = *(const float4 *)(p + 8);
+  r.q3 = *(const float4 *)(p + 12);
+  r.bb = *(const uint2 *)(p + 16);
+  return r;
+}
+
+// Exact trivial reject of one triangle against a rectangle of pixel centres
+// [pxlo, pxhi] x [pylo, pyhi]: edge i is evaluated with the reference's own un-fused
+// expression (cpp:46) at the centre that maximises it.  fl(a*px), fl(.+.) are monotone,
+// so every pixel centre of the rectangle gets a value <= this one; a negative value
+// means edge i rejects the whole rectangle.  NaNs compare false and never reject.
+__device__ __forceinline__ bool rect_outside_edge(float a, float b, float c, float pxlo, float pxhi,
+                                                  float pylo, float pyhi) {
+  const float fx = (a >= 0.0f) ? pxhi : pxlo;
+  const float fy = (b >= 0.0f) ? pyhi : pylo;
+  const float e = (a * fx + b * fy) + c;
+  return e < 0.0f;
+}
+
+__device__ __forceinline__ bool rect_outside_triangle(const float4 q0, const float4 q1, const float m8,
+                                                      float pxlo, float pxhi, float pylo, float pyhi) {
+  // bitwise |: all three edges are evaluated straight-line (no dependent branches)
+  return (int)rect_outside_edge(q0.x, q0.y, q0.z, pxlo, pxhi, pylo, pyhi) |
+         (int)rect_outside_edge(q0.w, q1.x, q1.y, pxlo, pxhi, pylo, pyhi) |
+         (int)rect_outside_edge(q1.z, q1.w, m8, pxlo, pxhi, pylo, pyhi);
+}
+
+__global__ __launch_bounds__(kThreads, 7) void k_raster(
+    const TriRec *__restrict__ recs, const uint2 *__restrict__ bbs,
+    const float *__restrict__ pxtab, const float *__restrict__ pytab, int T, int W, int H,
+    int regions_x, int regions_per_image, int n_regions, int regions_per_xcd,
+    int32_t *__restrict__ ids, float *__restrict__ bary, float *__restrict__ zbuf, int debug_skip) {
+  constexpr int kTiles = (kRegionW / 8) * (kRegionH / 8);  // 64 tiles of 8x8 pixels
+  constexpr int kMaskWords = kBin2Cap / 32;
+  __shared__ __attribute__((aligned(16))) float s_ent[kBin2Cap * kEntryDw];
+  __shared__ unsigned s_tmask[kTiles][kMaskWords];  // per tile: which bin entries touch it
+  __shared__ float s_ext[4][8];                     // tile column / row pixel-centre extents
+  __shared__ float s_pxy[2][kRegionW];              // pixel centres of the region's columns / rows
+  __shared__ int s_count[kWaves], s_stop[kWaves], s_wave_total[kWaves];
+  constexpr int kRoundChunks = kThreads;  // chunks of 64 triangles scanned per round
+  __shared__ int s_chunk_count[kRoundChunks];
+
+  const int region = xcd_contiguous_block((int)blockIdx.x, n_regions, regions_per_xcd);
+  if (region < 0) return;  // padding block (whole workgroup)
+  const int img = region / regions_per_image;
+  const int rr = region - img * regions_per_image;
+  const int ry = rr / regions_x;
+  const int rx = rr - ry * regions_x;
+  const int X0 = rx * kRegionW, Y0 = ry * kRegionH;
+  const int X1 = min(X0 + kRegionW, W), Y1 = min(Y0 + kRegionH, H);
+
+  const int tid = (int)threadIdx.x;
+  const int lane = tid & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const TriRec *img_recs = recs + (size_t)img * T;
+  const uint2 *img_bbs = bbs + (size_t)img * T;
+  const size_t img_px = (size_t)img * H * W;
+
+  // pixel-centre extents of the region (tables are monotone in the pixel index)
+  const float rpxlo = pxtab[X0], rpxhi = pxtab[X1 - 1], rpylo = pytab[Y0], rpyhi = pytab[Y1 - 1];
+  // The region's pixel centres live in LDS: the tile loop must not issue global LOADS,
+  // because vmcnt is in-order on gfx950 and a load's wait would also drain the previous
+  // tile's G-buffer stores (measured: +0.1 ms at 1024^2 x 32).
+  static_assert(kRegionW == kRegionH && kRegionW == kWave, "one table slot per lane");
+  if (tid < kWave) s_pxy[0][tid] = pxtab[min(X0 + tid, W - 1)];
+  else if (tid < 2 * kWave) s_pxy[1][tid - kWave] = pytab[min(Y0 + tid - kWave, H - 1)];
+
+  // ---- stage 2a: which bin entries touch which 8x8 tile -------------------------------
+  // One thread per bin entry walks the tiles under the entry's bbox and applies the exact
+  // trivial reject against each; survivors set their bit in the tile's 256-bit mask.  This
+  // costs ~(entries x tiles-per-entry) lane-tests per region instead of (tiles x entries).
+  auto build_tile_masks = [&](const int n) {
+    for (int i = tid; i < kTiles * kMaskWords; i += kThreads) (&s_tmask[0][0])[i] = 0u;
+    if (tid < 8) {  // pixel-centre extents of the 8 tile columns / rows of this region
+      const int cx0 = tid * 8, cx1 = min(tid * 8 + 7, X1 - 1 - X0);
+      const int cy0 = tid * 8, cy1 = min(tid * 8 + 7, Y1 - 1 - Y0);
+      s_ext[0][tid] = s_pxy[0][cx0];
+      s_ext[1][tid] = s_pxy[0][max(cx1, cx0)];
+      s_ext[2][tid] = s_pxy[1][cy0];
+      s_ext[3][tid] = s_pxy[1][max(cy1, cy0)];
+    }
+    __syncthreads();
+    if (tid < n) {
+      const float *p = s_ent + tid * kEntryDw;
+      const uint2 bb = *(const uint2 *)(p + 16);
+      const float4 q0 = *(const float4 *)(p), q1 = *(const float4 *)(p + 4);
+      const float m8 = p[8];
+      const int l = (int)(bb.x & 0xffffu), r = (int)(bb.x >> 16);
+      const int bt = (int)(bb.y & 0xffffu), tp = (int)(bb.y >> 16);
+      // tile range under the bbox, clipped to the region (the bin stage guarantees overlap)
+      const int tx0 = (max(l, X0) - X0) >> 3, tx1 = (min(r, X1) - 1 - X0) >> 3;
+      const int ty0 = (max(bt, Y0) - Y0) >> 3, ty1 = (min(tp, Y1) - 1 - Y0) >> 3;
+      const unsigned bit = 1u << (tid & 31);
+      const int word = tid >> 5;
+      for (int ty = ty0; ty <= ty1; ++ty) {
+        const float ylo = s_ext[2][ty], yhi = s_ext[3][ty];
+        for (int tx = tx0; tx <= tx1; ++tx) {
+          if (!rect_outside_triangle(q0, q1, m8, s_ext[0][tx], s_ext[1][tx], ylo, yhi))
+            atomicOr(&s_tmask[ty * 8 + tx][word], bit);
+        }
+      }
+    }
+    __syncthreads();
+  };
+
+  // ---- stage 2b: the tile walk --------------------------------------------------------
+  auto raster_pass = [&](const int n, const bool fresh) {
+    const int n_words = (n + 31) >> 5;
+    for (int tile = wave; tile < kTiles; tile += kWaves) {
+      const int ty = tile >> 3, tx = tile & 7;
+      const int x0 = X0 + tx * 8, y0 = Y0 + ty * 8;
+      if (x0 >= X1 || y0 >= Y1) continue;  // wave-uniform
+      const int ix = x0 + (lane & 7), iy = y0 + (lane >> 3);
+      const bool in_image = ix < W && iy < H;
+      const size_t pix = img_px + (size_t)iy * W + ix;
+      const float px = s_pxy[0][tx * 8 + (lane & 7)];
+      const float py = s_pxy[1][ty * 8 + (lane >> 3)];
+      PixelState st;
+      if (fresh) {
+        st.z = 1.0f; st.b0 = 0.0f; st.b1 = 0.0f; st.b2 = 0.0f; st.id = 0;  // cpp:313-321
+      } else if (in_image) {
+        st.z = zbuf[pix]; st.id = ids[pix];
+        st.b0 = bary[3 * pix]; st.b1 = bary[3 * pix + 1]; st.b2 = bary[3 * pix + 2];
+      }
+      for (int w = 0; w < n_words; ++w) {
+        unsigned todo = (unsigned)__builtin_amdgcn_readfirstlane((int)s_tmask[tile][w]);
+        if (todo == 0u || (debug_skip & 16)) continue;
+        const int ebase = w * 32;
+        // (1) coverage: wave-uniform entry, all lanes; one mask bit per candidate.  The next
+        //     candidate's entry is requested from LDS before the current one is evaluated.
+        unsigned mine = 0u;
+        {
+          int j = __builtin_ctz(todo);
+          todo &= todo - 1;
+          const float *p = s_ent + (ebase + j) * kEntryDw;  // wave-uniform address
+          float4 q0 = *(const float4 *)(p), q1 = *(const float4 *)(p + 4);
+          float m8 = p[8];
+          uint2 bb = *(const uint2 *)(p + 16);
+          for (;;) {
+            int jn = -1;
+            float4 n0 = q0, n1 = q1;
+            float nm8 = m8;
+            uint2 nbb = bb;
+            if (todo) {
+              jn = __builtin_ctz(todo);
+              todo &= todo - 1;
+              const float *pn = s_ent + (ebase + jn) * kEntryDw;
+              n0 = *(const float4 *)(pn);
+              n1 = *(const float4 *)(pn + 4);
+              nm8 = pn[8];
+              nbb = *(const uint2 *)(pn + 16);
+            }
+            const unsigned bbx = (unsigned)__builtin_amdgcn_readfirstlane((int)bb.x);
+            const unsigned bby = (unsigned)__builtin_amdgcn_readfirstlane((int)bb.y);
+            const int l = (int)(bbx & 0xffffu), wdt = (int)(bbx >> 16) - l;
+            const int bt = (int)(bby & 0xffffu), hgt = (int)(bby >> 16) - bt;
+            const float e0 = (q0.x * px + q0.y * py) + q0.z;  // cpp:46
+            const float e1 = (q0.w * px + q1.x * py) + q1.y;
+            const float e2 = (q1.z * px + q1.w * py) + m8;
+            const float s = (e0 + e1) + e2;
+            // cpp:96-97 (all >= 0 and some > 0  <=>  all >= 0 and s > 0), inside the bbox
+            const bool inside = (int)((unsigned)(ix - l) < (unsigned)wdt) &
+                                (int)((unsigned)(iy - bt) < (unsigned)hgt) & (int)(e0 >= 0.0f) &
+                                (int)(e1 >= 0.0f) & (int)(e2 >= 0.0f) & (int)(s > 0.0f);
+            mine |= inside ? (1u << j) : 0u;  // j is wave-uniform
+            if (jn < 0) break;
+            j = jn; q0 = n0; q1 = n1; m8 = nm8; bb = nbb;
+          }
+        }
+        // (2) depth: every lane walks its own candidates in ascending id
+        if (debug_skip & 8) { st.id += (int)mine; continue; }  // timing probe: coverage only
+        while (__ballot(mine != 0u)) {
+          if (mine != 0u) {
+            const int e = ebase + (__ffs((int)mine) - 1);
+            mine &= mine - 1u;
+            const Entry t = read_entry(s_ent, e);  // per-lane LDS address
+            const float e0 = (t.q0.x * px + t.q0.y * py) + t.q0.z;  // same bits as in (1)
+            const float e1 = (t.q0.w * px + t.q1.x * py) + t.q1.y;
+            const float e2 = (t.q1.z * px + t.q1.w * py) + t.q2.x;
+            const float s = (e0 + e1) + e2;                              // cpp:384
+            const float b0 = e0 / s, b1 = e1 / s, b2 = e2 / s;           // cpp:385-387
+            const float cz = (b0 * t.q2.y + b1 * t.q2.z) + b2 * t.q2.w;  // cpp:395
+            const float cw = (b0 * t.q3.x + b1 * t.q3.y) + b2 * t.q3.z;  // cpp:396
+            const float zz = cz / cw;                                    // cpp:397
+            if (!(zz < -1.0f || zz > 1.0f || zz > st.z)) {               // cpp:401
+              st.z = zz;
+              st.id = __builtin_bit_cast(int, t.q3.w);
+              st.b0 = b0; st.b1 = b1; st.b2 = b2;
+            }
+          }
+        }
+      }
+      if (in_image) {
+        ids[pix] = st.id;
+        zbuf[pix] = st.z;
+        bary[3 * pix + 0] = st.b0;
+        bary[3 * pix + 1] = st.b1;
+        bary[3 * pix + 2] = st.b2;
+      }
+    }
+  };
+
+  // ---- stage 1: rounds of (scan a slice of the list -> bin -> walk the tiles) -----------
+  // A round covers up to kRoundChunks 64-triangle chunks.  Wavefront w takes chunks
+  // w, w+4, w+8, ... so that survivors -- which cluster in id space for any mesh with
+  // spatially coherent numbering -- spread evenly over the four 64-entry sub-bins; the
+  // id order is restored at compaction from per-chunk survivor counts.
+  bool first_pass = true;
+  int round_base = 0;  // first triangle of the round, workgroup-uniform, multiple of 64
+  do {
+    const int chunks_left = (T - round_base + kWave - 1) / kWave;
+    const int round_chunks = min(chunks_left, kRoundChunks);
+    s_chunk_count[tid] = 0;  // kRoundChunks == kThreads
+    __syncthreads();
+    int count = 0, stop = round_chunks;  // stop: first chunk this wavefront could not take
+    constexpr int kUnroll = 2;  // chunks per trip: their loads are issued together
+    for (int c0 = wave; c0 < round_chunks && stop == round_chunks; c0 += kUnroll * kWaves) {
+      uint2 bb[kUnroll];
+      bool near[kUnroll];
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        const int c = c0 + u * kWaves;
+        const int t = round_base + c * kWave + lane;
+        bb[u] = (c < round_chunks && t < T) ? img_bbs[t] : make_uint2(0u, 0u);
+      }
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        const int l = (int)(bb[u].x & 0xffffu), r = (int)(bb[u].x >> 16);
+        const int bt = (int)(bb[u].y & 0xffffu), tp = (int)(bb[u].y >> 16);
+        near[u] = (l < X1) && (r > X0) && (bt < Y1) && (tp > Y0);  // empty bbox = all zeros
+      }
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        const int c = c0 + u * kWaves;
+        if (c >= round_chunks || stop != round_chunks) continue;  // wave-uniform
+        const int t = round_base + c * kWave + lane;
+        bool pass = false;
+        if (near[u]) {
+          const TriRec *rp = img_recs + t;
+          pass = !rect_outside_triangle(rp->a, rp->b, rp->c.x, rpxlo, rpxhi, rpylo, rpyhi);
+        }
+        const unsigned long long m = __ballot(pass);
+        const int cnt = __builtin_popcountll(m);
+        if (count + cnt > kSubCap) {  // this wavefront's sub-bin is full
+          stop = c;
+          continue;
+        }
+        if (pass) {
+          const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
+                                                          __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+          float *p = s_ent + (wave * kSubCap + count + rank) * kEntryDw;
+          const TriRec *rp = img_recs + t;  // L1/L2-hot: just read by the reject test
+          const float4 q3 = rp->d;
+          *(float4 *)(p) = rp->a;
+          *(float4 *)(p + 4) = rp->b;
+          *(float4 *)(p + 8) = rp->c;
+          *(float4 *)(p + 12) = make_float4(q3.x, q3.y, q3.z, __builtin_bit_cast(float, t));
+          *(uint4 *)(p + 16) = make_uint4(bb[u].x, bb[u].y, (unsigned)c, (unsigned)rank);
+        }
+        if (lane == 0) s_chunk_count[c] = cnt;
+        count += cnt;
+      }
+    }
+    if (lane == 0) {
+      s_count[wave] = count;
+      s_stop[wave] = stop;
+    }
+    __syncthreads();
+    // chunks before the first one any wavefront had to refuse are complete
+    int keep_chunks = round_chunks;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) keep_chunks = min(keep_chunks, s_stop[w]);
+    // exclusive prefix sum of the kept chunks' survivor counts (thread t <-> chunk t)
+    int n;
+    {
+      const int v = (tid < keep_chunks) ? s_chunk_count[tid] : 0;
+      int incl = v;
+#pragma unroll
+      for (int off = 1; off < kWave; off <<= 1) {
+        const int up = __shfl_up(incl, off);
+        if (lane >= off) incl += up;
+      }
+      if (lane == kWave - 1) s_wave_total[wave] = incl;
+      __syncthreads();
+      int wave_off = 0;
+      n = 0;
+#pragma unroll
+      for (int w = 0; w < kWaves; ++w) {
+        const int tot = s_wave_total[w];
+        if (w < wave) wave_off += tot;
+        n += tot;
+      }
+      s_chunk_count[tid] = wave_off + incl - v;  // now: offset of chunk tid in the sorted bin
+    }
+    // move every kept entry to its id-ordered slot (in place, via registers)
+    Entry mine;
+    unsigned my_chunk = 0u, my_rank = 0u;
+    const bool have = (tid & (kWave - 1)) < s_count[tid >> 6];
+    if (have) {
+      mine = read_entry(s_ent, tid);
+      const uint2 tag = *(const uint2 *)(s_ent + tid * kEntryDw + 18);
+      my_chunk = tag.x;
+      my_rank = tag.y;
+    }
+    __syncthreads();
+    if (have && (int)my_chunk < keep_chunks) {
+      float *p = s_ent + (s_chunk_count[my_chunk] + (int)my_rank) * kEntryDw;
+      *(float4 *)(p) = mine.q0;
+      *(float4 *)(p + 4) = mine.q1;
+      *(float4 *)(p + 8) = mine.q2;
+      *(float4 *)(p + 12) = mine.q3;
+      *(uint2 *)(p + 16) = mine.bb;
+    }
+    const int next_base = round_base + keep_chunks * kWave;
+    __syncthreads();
+    if (debug_skip == 0 || debug_skip >= 8) {
+      build_tile_masks(n);
+      raster_pass(n, first_pass);
+    } else if (debug_skip == 2) {
+      raster_pass(0, first_pass);  // timing probe: tile walk over an empty bin
+    } else if (debug_skip == 3) {
+      build_tile_masks(n);         // timing probe: bin + tile masks, no walk
+    }
+    first_pass = false;
+    round_base = next_base;
+    if (round_base < T) __syncthreads();  // tiles done with the bin; orders the state stores
+  } while (round_base < T);
+}
+
 }  // namespace
 
 size_t raster_forward_ws(int B, int V, int T, int W, int H) {
@@ -299,7 +662,7 @@ size_t raster_forward_ws(int B, int V, int T, int W, int H) {
          align_up((size_t)W * sizeof(float), 256) + align_up((size_t)H * sizeof(float), 256);
 }
 
-int g_raster_tile_shape = 0;  // 0: 8x8, 1: 16x4, 2: 32x2 (mr_set_raster_tile_shape)
+int g_raster_tile_shape = 0;  // 0: two-phase kernel; 1, 2: first-generation kernel, 8x8 / 16x4 tiles
 hipEvent_t g_raster_ev_start = nullptr, g_raster_ev_stop = nullptr;  // mr_set_raster_profile_events
 
 int launch_raster_forward(const float *clip, const int32_t *tris, int B, int V, int T, int W,
@@ -328,14 +691,21 @@ int launch_raster_forward(const float *clip, const int32_t *tris, int B, int V, 
   const int n_regions = per_image * B;
   const int per_xcd = (n_regions + kXcds - 1) / kXcds;
   const dim3 grid((unsigned)(per_xcd * kXcds)), block(kThreads);
-#define MR_LAUNCH_RASTER(TW, TH)                                                              \
-  hipLaunchKernelGGL((k_raster<TW, TH>), grid, block, 0, s, recs, bbs, pxtab, pytab, T, W, H, \
-                     regions_x, per_image, n_regions, per_xcd, ids, bary, z)
+#define MR_LAUNCH_RASTER(KERNEL)                                                         \
+  hipLaunchKernelGGL(KERNEL, grid, block, 0, s, recs, bbs, pxtab, pytab, T, W, H, regions_x, \
+                     per_image, n_regions, per_xcd, ids, bary, z)
   if (g_raster_ev_start) (void)hipEventRecord(g_raster_ev_start, s);
   switch (g_raster_tile_shape) {
-    case 1: MR_LAUNCH_RASTER(16, 4); break;
-    case 2: MR_LAUNCH_RASTER(32, 2); break;
-    default: MR_LAUNCH_RASTER(8, 8); break;
+    case 1: MR_LAUNCH_RASTER((k_raster_v1<8, 8>)); break;
+    case 2: MR_LAUNCH_RASTER((k_raster_v1<16, 4>)); break;
+    case 3: case 4: case 5: case 10: case 18:  // timing probes (results are NOT valid)
+      hipLaunchKernelGGL(k_raster, grid, block, 0, s, recs, bbs, pxtab, pytab, T, W, H, regions_x,
+                         per_image, n_regions, per_xcd, ids, bary, z, g_raster_tile_shape - 2);
+      break;
+    default:
+      hipLaunchKernelGGL(k_raster, grid, block, 0, s, recs, bbs, pxtab, pytab, T, W, H, regions_x,
+                         per_image, n_regions, per_xcd, ids, bary, z, 0);
+      break;
   }
 #undef MR_LAUNCH_RASTER
   if (g_raster_ev_stop) (void)hipEventRecord(g_raster_ev_stop, s);
