@@ -98,7 +98,7 @@ def make_step(job, device, gather):
         image = forward()
         if gather is not None:
             gather.start(image)          # side stream: overlaps loss + backward
-        loss = torch.mean(torch.abs(image - target))
+        loss = torch.nn.functional.l1_loss(image, target)   # mean |image - target|
         loss.backward()
         if gather is not None:
             gather.wait()

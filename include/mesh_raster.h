@@ -111,12 +111,13 @@ int mr_interpolate_backward(const float *dout, const int32_t *ids,
  *   rgba                      [B,H,W,4] f32 out; row 0 is the TOP scanline; alpha is
  *                             1 on covered pixels with a non-negative diffuse colour */
 int mr_shade_max_lights(void);
+size_t mr_shade_forward_workspace_bytes(int B, int V, int T, int W, int H);
 int mr_shade_forward(const int32_t *ids, const float *bary, const float *normals,
                      const float *positions, const float *diffuse,
                      const int32_t *triangles, const float *light_positions,
                      const float *light_intensities, const float *ambient,
                      int B, int V, int T, int W, int H, int L, float *rgba,
-                     void *stream);
+                     void *workspace, size_t workspace_bytes, void *stream);
 
 /* Backward of mr_shade_forward AND of the rasterizer underneath it, in one pass
  * over the G-buffer (reads 32 B/px).  All outputs are zeroed here.

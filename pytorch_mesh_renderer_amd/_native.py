@@ -68,7 +68,9 @@ def lib():
                                               vp, vp, vp, sz, vp]
         L.mr_interpolate_backward.restype = ci
         L.mr_shade_max_lights.restype = ci
-        L.mr_shade_forward.argtypes = [vp] * 9 + [ci] * 6 + [vp, vp]
+        L.mr_shade_forward_workspace_bytes.argtypes = [ci] * 5
+        L.mr_shade_forward_workspace_bytes.restype = sz
+        L.mr_shade_forward.argtypes = [vp] * 9 + [ci] * 6 + [vp, vp, sz, vp]
         L.mr_shade_forward.restype = ci
         L.mr_shade_backward_workspace_bytes.argtypes = [ci] * 5
         L.mr_shade_backward_workspace_bytes.restype = sz
@@ -214,9 +216,12 @@ def shade_forward(ids, bary, normals, positions, diffuse, triangles, light_posit
     V, T, nl = normals.shape[1], triangles.shape[0], light_positions.shape[1]
     rgba = torch.empty(B, H, W, 4, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
+        need = L.mr_shade_forward_workspace_bytes(B, V, T, W, H)
+        ws, have = _workspace(dev, need)
         rc = L.mr_shade_forward(_ptr(ids), _ptr(bary), _ptr(normals), _ptr(positions), _ptr(diffuse),
                                 _ptr(triangles), _ptr(light_positions), _ptr(light_intensities),
-                                _ptr(ambient), B, V, T, W, H, nl, _ptr(rgba), _stream(dev))
+                                _ptr(ambient), B, V, T, W, H, nl, _ptr(rgba), _ptr(ws), have,
+                                _stream(dev))
     _check(rc, "mr_shade_forward")
     return rgba
 

@@ -117,16 +117,23 @@ int mr_shade_forward(const int32_t *ids, const float *bary, const float *normals
                      const float *positions, const float *diffuse, const int32_t *triangles,
                      const float *light_positions, const float *light_intensities,
                      const float *ambient, int B, int V, int T, int W, int H, int L, float *rgba,
-                     void *stream) {
+                     void *workspace, size_t workspace_bytes, void *stream) {
   if (bad_dims(B, V, T, W, H) || T < 1 || V < 1 || L < 1 || L > mr::shade_max_lights())
     return MR_EINVAL;
   if (B == 0) return MR_OK;
   if (!ids || !bary || !normals || !positions || !diffuse || !triangles || !light_positions ||
       !light_intensities || !rgba)
     return MR_EINVAL;
+  const int rc = check_ws(workspace, workspace_bytes, mr::shade_forward_ws(B, V, T, W, H));
+  if (rc != MR_OK) return rc;
   return mr::launch_shade_forward(ids, bary, normals, positions, diffuse, triangles, light_positions,
-                                  light_intensities, ambient, B, V, T, W, H, L, rgba,
+                                  light_intensities, ambient, B, V, T, W, H, L, rgba, workspace,
                                   (hipStream_t)stream);
+}
+
+size_t mr_shade_forward_workspace_bytes(int B, int V, int T, int W, int H) {
+  if (bad_dims(B, V, T, W, H)) return 0;
+  return mr::shade_forward_ws(B, V, T, W, H);
 }
 
 size_t mr_shade_backward_workspace_bytes(int B, int V, int T, int W, int H) {

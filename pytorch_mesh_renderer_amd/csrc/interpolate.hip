@@ -95,6 +95,7 @@ struct AttrGradFn {
   static constexpr int kN = kChunk * 3;
   static constexpr int kStride = kAccStride;
   static constexpr int kSlots = 512;
+  static constexpr int kMinWavesPerSimd = 6;
   const float *__restrict__ dout;
   const int32_t *__restrict__ ids;
   const F3 *__restrict__ bary;
@@ -105,22 +106,31 @@ struct AttrGradFn {
     float gv[kChunk];
   };
   struct Triangle {};
+  struct Raw {
+    F3 b;
+    int t;
+    float g[kChunk];
+  };
   using Image = NoImageSums;
 
   __device__ __forceinline__ void begin_image(int, Image &) const {}
   __device__ __forceinline__ void end_image(int, Image &) const {}
-  __device__ __forceinline__ bool load_pixel(int, int, int, size_t pix, int T, int &tri,
-                                             Pixel &p) const {
-    p.b = bary[pix];
-    float pre;
-    const float alpha = coverage_alpha(p.b, pre);
-    if (!(alpha > 0.0f)) return false;  // background: every term is alpha * ... = 0
-    const int t = ids[pix];
-    if ((unsigned)t >= (unsigned)T) return false;
+  __device__ __forceinline__ void fetch(int, int, int, size_t pix, Raw &r) const {
+    r.b = bary[pix];
+    r.t = ids[pix];
     const float *g = dout + pix * A + a_begin;
 #pragma unroll
-    for (int c = 0; c < kChunk; ++c) p.gv[c] = (a_begin + c < A) ? alpha * g[c] : 0.0f;
-    tri = t;
+    for (int c = 0; c < kChunk; ++c) r.g[c] = (a_begin + c < A) ? g[c] : 0.0f;  // uniform test
+  }
+  __device__ __forceinline__ bool prepare(const Raw &r, int T, int &tri, Pixel &p) const {
+    float pre;
+    const float alpha = coverage_alpha(r.b, pre);
+    if (!(alpha > 0.0f)) return false;  // background: every term is alpha * ... = 0
+    if ((unsigned)r.t >= (unsigned)T) return false;
+    p.b = r.b;
+#pragma unroll
+    for (int c = 0; c < kChunk; ++c) p.gv[c] = alpha * r.g[c];
+    tri = r.t;
     return true;
   }
   __device__ __forceinline__ void load_triangle(int, int, Triangle &) const {}

@@ -78,7 +78,9 @@ int shade_max_lights();
 int launch_shade_forward(const int32_t *ids, const float *bary, const float *normals,
                          const float *positions, const float *diffuse, const int32_t *tris,
                          const float *light_pos, const float *light_col, const float *ambient,
-                         int B, int V, int T, int W, int H, int L, float *rgba, hipStream_t s);
+                         int B, int V, int T, int W, int H, int L, float *rgba, void *ws,
+                         hipStream_t s);
+size_t shade_forward_ws(int B, int V, int T, int W, int H);
 size_t shade_backward_ws(int B, int V, int T, int W, int H);
 int launch_shade_backward(const float *drgba, const int32_t *ids, const float *bary,
                           const float *clip, const float *normals, const float *positions,

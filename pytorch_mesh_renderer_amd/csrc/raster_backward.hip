@@ -78,6 +78,7 @@ struct RasterGradFn {
   static constexpr int kN = 9;  // [corner j][component c] partials
   static constexpr int kStride = mr::kStride;
   static constexpr int kSlots = 512;
+  static constexpr int kMinWavesPerSimd = 6;
   const F3 *__restrict__ dbary;
   const int32_t *__restrict__ ids;
   const F3 *__restrict__ bary;
@@ -87,19 +88,26 @@ struct RasterGradFn {
   struct Pixel {
     F3 b, g;
   };
+  struct Raw {
+    F3 b, g;
+    int t;
+  };
   using Triangle = BwdTriangle;
   using Image = NoImageSums;
 
   __device__ __forceinline__ void begin_image(int, Image &) const {}
   __device__ __forceinline__ void end_image(int, Image &) const {}
-  __device__ __forceinline__ bool load_pixel(int, int, int, size_t pix, int T, int &tri,
-                                             Pixel &p) const {
-    const int t = ids[pix];
-    p.b = bary[pix];
-    if ((unsigned)t >= (unsigned)T) return false;                               // foreign id
-    if (t == 0 && (p.b.x + p.b.y) + p.b.z < kDegenerateCutoff) return false;    // cpp:162
-    p.g = dbary[pix];
-    tri = t;
+  __device__ __forceinline__ void fetch(int, int, int, size_t pix, Raw &r) const {
+    r.t = ids[pix];
+    r.b = bary[pix];
+    r.g = dbary[pix];
+  }
+  __device__ __forceinline__ bool prepare(const Raw &r, int T, int &tri, Pixel &p) const {
+    if ((unsigned)r.t >= (unsigned)T) return false;                             // foreign id
+    if (r.t == 0 && (r.b.x + r.b.y) + r.b.z < kDegenerateCutoff) return false;  // cpp:162
+    p.b = r.b;
+    p.g = r.g;
+    tri = r.t;
     return true;
   }
   __device__ __forceinline__ void load_triangle(int img, int tri, Triangle &t) const {

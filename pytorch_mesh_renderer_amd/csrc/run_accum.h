@@ -20,13 +20,17 @@
 //     static constexpr int kN      = ...;   // sums per triangle
 //     static constexpr int kStride = ...;   // floats per acc row (>= kN)
 //     static constexpr int kSlots  = ...;   // LDS hash slots, power of two
-//     struct Pixel {...}; struct Triangle {...}; struct Image {...};
+//     static constexpr int kMinWavesPerSimd = ...;  // occupancy the register allocator must allow
+//     struct Raw {...}; struct Pixel {...}; struct Triangle {...}; struct Image {...};
 //     __device__ void begin_image(int img, Image &) const;
-//     __device__ bool load_pixel(int img, int x, int y, size_t pix, int T, int &tri, Pixel &) const;
+//     __device__ void fetch(int img, int x, int y, size_t pix, Raw &) const;   // loads only
+//     __device__ bool prepare(const Raw &, int T, int &tri, Pixel &) const;    // false: skip
 //     __device__ void load_triangle(int img, int tri, Triangle &) const;   // on run change
 //     __device__ void accumulate(const Pixel &, const Triangle &, float (&a)[kN], Image &) const;
 //     __device__ void end_image(int img, Image &) const;   // per-lane image-wide sums
 //   };
+// fetch() must not branch on loaded data: the kernel issues the NEXT pixel's fetch before
+// it evaluates the current one, so two pixels' loads are in flight per lane.
 // Per-triangle data (e.g. the adjugate) is fetched once per run, not per pixel.
 #pragma once
 
@@ -68,7 +72,7 @@ __device__ __forceinline__ void run_flush(int *keys, float *vals, float *acc_img
 }
 
 template <class Fn>
-__global__ __launch_bounds__(kRunThreads) void k_accumulate_runs(
+__global__ __launch_bounds__(kRunThreads, Fn::kMinWavesPerSimd) void k_accumulate_runs(
     Fn fn, int T, int W, int H, int regions_x, int regions_per_image, int n_regions,
     int regions_per_xcd, float *__restrict__ acc) {
   constexpr int N = Fn::kN, STRIDE = Fn::kStride, SLOTS = Fn::kSlots;
@@ -104,10 +108,14 @@ __global__ __launch_bounds__(kRunThreads) void k_accumulate_runs(
     int run_tri = -1;
     typename Fn::Triangle tri_data;
     size_t pix = ((size_t)img * H + y_begin) * W + x;
+    typename Fn::Raw raw_next;
+    if (y_begin < y_end) fn.fetch(img, x, y_begin, pix, raw_next);
     for (int y = y_begin; y < y_end; ++y, pix += W) {
+      const typename Fn::Raw raw = raw_next;
+      if (y + 1 < y_end) fn.fetch(img, x, y + 1, pix + W, raw_next);  // software prefetch
       int tri;
       typename Fn::Pixel p;
-      if (!fn.load_pixel(img, x, y, pix, T, tri, p)) continue;
+      if (!fn.prepare(raw, T, tri, p)) continue;
       if (tri != run_tri) {
         run_flush<N, STRIDE, SLOTS>(s_keys, s_vals, acc_img, run_tri, a);
         run_tri = tri;

@@ -45,20 +45,48 @@ struct Corners {  // the three corners' (normal, position, diffuse): 27 floats
   float c[3][9];
 };
 
-__device__ __forceinline__ void load_corners(const F3 *__restrict__ normals,
-                                             const F3 *__restrict__ positions,
-                                             const F3 *__restrict__ diffuse,
-                                             const int32_t *__restrict__ tris, size_t vbase, int V,
-                                             int tri, Corners &o) {
+// Corners of one (image, triangle), gathered once by k_corner_setup so that the per-pixel
+// kernels follow ONE pointer (id -> 128-byte record) instead of two (id -> vertex ids ->
+// nine scattered 12-byte reads).  128 bytes, 128-byte aligned = one cache line.
+struct alignas(128) CornerRec {
+  float4 q[8];  // 27 floats used, row-major [corner][attribute]
+};
+
+__global__ __launch_bounds__(kThreads) void k_corner_setup(
+    const F3 *__restrict__ normals, const F3 *__restrict__ positions, const F3 *__restrict__ diffuse,
+    const int32_t *__restrict__ tris, int B, int V, int T, CornerRec *__restrict__ out) {
+  const long gid = (long)blockIdx.x * kThreads + threadIdx.x;
+  if (gid >= (long)B * T) return;
+  const int b = (int)(gid / T);
+  const int t = (int)(gid - (long)b * T);
+  float v[32];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    int vi = tris[3 * tri + k];
+    int vi = tris[3 * t + k];
     if ((unsigned)vi >= (unsigned)V) vi = 0;
-    const F3 n = normals[vbase + vi], p = positions[vbase + vi], d = diffuse[vbase + vi];
-    o.c[k][0] = n.x; o.c[k][1] = n.y; o.c[k][2] = n.z;
-    o.c[k][3] = p.x; o.c[k][4] = p.y; o.c[k][5] = p.z;
-    o.c[k][6] = d.x; o.c[k][7] = d.y; o.c[k][8] = d.z;
+    const size_t at = (size_t)b * V + vi;
+    const F3 n = normals[at], p = positions[at], d = diffuse[at];
+    v[k * 9 + 0] = n.x; v[k * 9 + 1] = n.y; v[k * 9 + 2] = n.z;
+    v[k * 9 + 3] = p.x; v[k * 9 + 4] = p.y; v[k * 9 + 5] = p.z;
+    v[k * 9 + 6] = d.x; v[k * 9 + 7] = d.y; v[k * 9 + 8] = d.z;
   }
+#pragma unroll
+  for (int i = 27; i < 32; ++i) v[i] = 0.f;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) out[gid].q[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+}
+
+__device__ __forceinline__ void load_corners(const CornerRec *__restrict__ rec, Corners &o) {
+  float v[28];
+#pragma unroll
+  for (int q = 0; q < 7; ++q) {
+    const float4 f = rec->q[q];
+    v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int a = 0; a < 9; ++a) o.c[k][a] = v[k * 9 + a];
 }
 
 // alpha = clamp(sum(2*bary), 0, 1); attr = alpha * interp + (1 - alpha) * (-1)
@@ -75,51 +103,73 @@ __device__ __forceinline__ void interpolate9(const Corners &cr, const F3 b, floa
   }
 }
 
+// Shading of one covered pixel from its interpolated attributes (render.py:201-215, 298-323).
+__device__ __forceinline__ float4 shade_pixel(const Corners &cr, const F3 b, const Lights &lights, int img) {
+  float pre, alpha, interp[9], at[9];
+  interpolate9(cr, b, pre, alpha, interp, at);
+  const bool mask = (at[6] >= 0.0f) || (at[7] >= 0.0f) || (at[8] >= 0.0f);  // render.py:215
+  if (!mask) return make_float4(0.f, 0.f, 0.f, 0.f);
+  const float nn = sqrtf(at[0] * at[0] + at[1] * at[1] + at[2] * at[2]);
+  const float inv_nn = 1.0f / fmaxf(nn, kNormEps);
+  const float nx = at[0] * inv_nn, ny = at[1] * inv_nn, nz = at[2] * inv_nn;
+  float r = 0.f, g = 0.f, bl = 0.f;
+  if (lights.amb) {  // render.py:298-301
+    const float *am = lights.amb + (size_t)img * 3;
+    r = am[0] * at[6]; g = am[1] * at[7]; bl = am[2] * at[8];
+  }
+  for (int l = 0; l < lights.L; ++l) {  // render.py:304-323
+    const float *lp = lights.pos + ((size_t)img * lights.L + l) * 3;
+    const float *li = lights.col + ((size_t)img * lights.L + l) * 3;
+    const float vx = lp[0] - at[3], vy = lp[1] - at[4], vz = lp[2] - at[5];
+    const float inv_vn = 1.0f / fmaxf(sqrtf(vx * vx + vy * vy + vz * vz), kNormEps);
+    const float ndl = fminf(fmaxf(nx * (vx * inv_vn) + ny * (vy * inv_vn) + nz * (vz * inv_vn), 0.0f), 1.0f);
+    r += at[6] * ndl * li[0];
+    g += at[7] * ndl * li[1];
+    bl += at[8] * ndl * li[2];
+  }
+  return make_float4(r, g, bl, 1.0f);
+}
+
+// One workgroup = 256 consecutive pixels of a row segment x kRows consecutive rows; each
+// thread shades kRows pixels of one column.  All G-buffer loads of the kRows pixels are
+// issued first, then all corner-record loads, then the arithmetic: the kernel is bound
+// by load latency (two dependent levels: id -> corner record), not by bandwidth or VALU.
+constexpr int kShadeRows = 4;
+
 __global__ __launch_bounds__(kThreads) void k_shade_forward(
-    const int32_t *__restrict__ ids, const F3 *__restrict__ bary, const F3 *__restrict__ normals,
-    const F3 *__restrict__ positions, const F3 *__restrict__ diffuse,
-    const int32_t *__restrict__ tris, Lights lights, int B, int V, int T, int W, int H,
-    float4 *__restrict__ out) {
-  const size_t px_per_image = (size_t)W * H;
-  const size_t n_px = px_per_image * B;
-  for (size_t pix = (size_t)blockIdx.x * kThreads + threadIdx.x; pix < n_px;
-       pix += (size_t)gridDim.x * kThreads) {
-    const int img = (int)(pix / px_per_image);
-    const size_t rem = pix - (size_t)img * px_per_image;
-    const int y = (int)(rem / W), x = (int)(rem - (size_t)y * W);
-    const F3 b = bary[pix];
-    float4 rgba = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float pre_probe = (2.0f * b.x + 2.0f * b.y) + 2.0f * b.z;
-    if (pre_probe > 0.0f) {  // alpha == 0: every attribute is the -1 background, mask = 0
-      int t = ids[pix];
-      if ((unsigned)t >= (unsigned)T) t = 0;
-      Corners cr;
-      load_corners(normals, positions, diffuse, tris, (size_t)img * V, V, t, cr);
-      float pre, alpha, interp[9], at[9];
-      interpolate9(cr, b, pre, alpha, interp, at);
-      const bool mask = (at[6] >= 0.0f) || (at[7] >= 0.0f) || (at[8] >= 0.0f);  // render.py:215
-      if (mask) {
-        const float nn = sqrtf(at[0] * at[0] + at[1] * at[1] + at[2] * at[2]);
-        const float inv_nn = 1.0f / fmaxf(nn, kNormEps);
-        const float nx = at[0] * inv_nn, ny = at[1] * inv_nn, nz = at[2] * inv_nn;
-        float r = 0.f, g = 0.f, bl = 0.f;
-        if (lights.amb) {  // render.py:298-301
-          const float *am = lights.amb + (size_t)img * 3;
-          r = am[0] * at[6]; g = am[1] * at[7]; bl = am[2] * at[8];
-        }
-        for (int l = 0; l < lights.L; ++l) {  // render.py:304-323
-          const float *lp = lights.pos + ((size_t)img * lights.L + l) * 3;
-          const float *li = lights.col + ((size_t)img * lights.L + l) * 3;
-          const float vx = lp[0] - at[3], vy = lp[1] - at[4], vz = lp[2] - at[5];
-          const float inv_vn = 1.0f / fmaxf(sqrtf(vx * vx + vy * vy + vz * vz), kNormEps);
-          const float ndl = fminf(fmaxf(nx * (vx * inv_vn) + ny * (vy * inv_vn) + nz * (vz * inv_vn), 0.0f), 1.0f);
-          r += at[6] * ndl * li[0];
-          g += at[7] * ndl * li[1];
-          bl += at[8] * ndl * li[2];
-        }
-        rgba = make_float4(r, g, bl, 1.0f);
-      }
-    }
+    const int32_t *__restrict__ ids, const F3 *__restrict__ bary,
+    const CornerRec *__restrict__ corners, Lights lights, int B, int T, int W, int H,
+    int x_blocks, int y_blocks, float4 *__restrict__ out) {
+  const int blk = (int)blockIdx.x;
+  const int img = blk / (x_blocks * y_blocks);
+  const int rem = blk - img * (x_blocks * y_blocks);
+  const int yb = rem / x_blocks, xb = rem - yb * x_blocks;
+  const int x = xb * kThreads + (int)threadIdx.x;
+  if (x >= W) return;
+  const int y0 = yb * kShadeRows;
+  F3 b[kShadeRows];
+  int t[kShadeRows];
+  bool live[kShadeRows];
+#pragma unroll
+  for (int r = 0; r < kShadeRows; ++r) {
+    const int y = min(y0 + r, H - 1);
+    const size_t pix = ((size_t)img * H + y) * W + x;
+    b[r] = bary[pix];
+    t[r] = ids[pix];
+  }
+  Corners cr[kShadeRows];
+#pragma unroll
+  for (int r = 0; r < kShadeRows; ++r) {
+    // alpha == 0: every attribute is the -1 background, mask = 0 -> transparent black
+    live[r] = ((2.0f * b[r].x + 2.0f * b[r].y) + 2.0f * b[r].z) > 0.0f;
+    if ((unsigned)t[r] >= (unsigned)T) t[r] = 0;
+    if (live[r]) load_corners(corners + (size_t)img * T + t[r], cr[r]);
+  }
+#pragma unroll
+  for (int r = 0; r < kShadeRows; ++r) {
+    const int y = y0 + r;
+    if (y >= H) break;
+    const float4 rgba = live[r] ? shade_pixel(cr[r], b[r], lights, img) : make_float4(0.f, 0.f, 0.f, 0.f);
     // render.py:384-386: the image is flipped vertically (G-buffer row 0 is the bottom)
     out[((size_t)img * H + (H - 1 - y)) * W + x] = rgba;
   }
@@ -130,21 +180,24 @@ struct ShadeGradFn {
   static constexpr int kN = 36;       // 27 attribute partials [corner][attr] + 9 clip partials
   static constexpr int kStride = 36;
   static constexpr int kSlots = 256;
+  static constexpr int kMinWavesPerSimd = 3;  // <= 168 VGPRs
   const float4 *__restrict__ drgba;   // [B,H,W,4], image rows (flipped w.r.t. the G-buffer)
   const int32_t *__restrict__ ids;
   const F3 *__restrict__ bary;
-  const F3 *__restrict__ normals;
-  const F3 *__restrict__ positions;
-  const F3 *__restrict__ diffuse;
-  const int32_t *__restrict__ tris;
+  const CornerRec *__restrict__ corners;
   const BwdRec *__restrict__ recs;
   Lights lights;
   float *__restrict__ light_grads;    // [B][L*6 + 3]: dpos (L x 3), dcol (L x 3), dambient (3)
-  int V, T_, W, H;
+  int T_, W, H;
 
   struct Pixel {
     F3 b, g;
     int tri;
+  };
+  struct Raw {
+    F3 b;
+    int t;
+    float4 g;
   };
   struct Triangle {
     Corners cr;
@@ -173,22 +226,24 @@ struct ShadeGradFn {
     }
   }
 
-  __device__ __forceinline__ bool load_pixel(int img, int x, int y, size_t pix, int T, int &tri,
-                                             Pixel &p) const {
-    p.b = bary[pix];
-    const float pre = (2.0f * p.b.x + 2.0f * p.b.y) + 2.0f * p.b.z;
+  __device__ __forceinline__ void fetch(int img, int x, int y, size_t pix, Raw &r) const {
+    r.b = bary[pix];
+    r.t = ids[pix];
+    r.g = drgba[((size_t)img * H + (H - 1 - y)) * W + x];  // un-flip
+  }
+  __device__ __forceinline__ bool prepare(const Raw &r, int T, int &tri, Pixel &p) const {
+    const float pre = (2.0f * r.b.x + 2.0f * r.b.y) + 2.0f * r.b.z;
     if (!(pre > 0.0f)) return false;  // background: mask = 0, no gradient anywhere
-    const int t = ids[pix];
-    if ((unsigned)t >= (unsigned)T) return false;
-    const float4 g = drgba[((size_t)img * H + (H - 1 - y)) * W + x];  // un-flip
-    p.g.x = g.x; p.g.y = g.y; p.g.z = g.z;  // d/d alpha is dropped: the mask is not differentiable
-    p.tri = t;
-    tri = t;
+    if ((unsigned)r.t >= (unsigned)T) return false;
+    p.b = r.b;
+    p.g.x = r.g.x; p.g.y = r.g.y; p.g.z = r.g.z;  // d/d alpha is dropped: the mask is not differentiable
+    p.tri = r.t;
+    tri = r.t;
     return true;
   }
 
   __device__ __forceinline__ void load_triangle(int img, int tri, Triangle &t) const {
-    load_corners(normals, positions, diffuse, tris, (size_t)img * V, V, tri, t.cr);
+    load_corners(corners + (size_t)img * T_ + tri, t.cr);
     load_bwd_triangle(recs + (size_t)img * T_ + tri, t.bt);
   }
 
@@ -335,26 +390,46 @@ inline unsigned capped_blocks(size_t n) {
 
 inline size_t shade_acc_bytes(int B, int T) { return align_up((size_t)B * T * 36 * sizeof(float), 256); }
 
+inline size_t corner_bytes(int B, int T) { return align_up((size_t)B * T * sizeof(CornerRec), 256); }
+
 }  // namespace
 
 int shade_max_lights() { return kMaxLights; }
 
+size_t shade_forward_ws(int B, int V, int T, int W, int H) {
+  (void)V; (void)W; (void)H;
+  return corner_bytes(B, T);
+}
+
+static int launch_corner_setup(const float *normals, const float *positions, const float *diffuse,
+                               const int32_t *tris, int B, int V, int T, CornerRec *out, hipStream_t s) {
+  const long nbt = (long)B * T;
+  hipLaunchKernelGGL(k_corner_setup, dim3((unsigned)((nbt + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+                     s, (const F3 *)normals, (const F3 *)positions, (const F3 *)diffuse, tris, B, V, T, out);
+  return check_launch();
+}
+
 int launch_shade_forward(const int32_t *ids, const float *bary, const float *normals,
                          const float *positions, const float *diffuse, const int32_t *tris,
                          const float *light_pos, const float *light_col, const float *ambient,
-                         int B, int V, int T, int W, int H, int L, float *rgba, hipStream_t s) {
+                         int B, int V, int T, int W, int H, int L, float *rgba, void *ws,
+                         hipStream_t s) {
   const size_t n_px = (size_t)B * W * H;
   if (n_px == 0) return MR_OK;
+  CornerRec *corners = (CornerRec *)ws;
+  int rc = launch_corner_setup(normals, positions, diffuse, tris, B, V, T, corners, s);
+  if (rc != MR_OK) return rc;
   Lights lights{light_pos, light_col, ambient, L};
-  hipLaunchKernelGGL(k_shade_forward, dim3(capped_blocks(n_px)), dim3(kThreads), 0, s, ids,
-                     (const F3 *)bary, (const F3 *)normals, (const F3 *)positions,
-                     (const F3 *)diffuse, tris, lights, B, V, T, W, H, (float4 *)rgba);
+  const int x_blocks = (W + kThreads - 1) / kThreads, y_blocks = (H + kShadeRows - 1) / kShadeRows;
+  hipLaunchKernelGGL(k_shade_forward, dim3((unsigned)(x_blocks * y_blocks * B)), dim3(kThreads), 0, s,
+                     ids, (const F3 *)bary, corners, lights, B, T, W, H, x_blocks, y_blocks,
+                     (float4 *)rgba);
   return check_launch();
 }
 
 size_t shade_backward_ws(int B, int V, int T, int W, int H) {
   (void)V; (void)W; (void)H;
-  return shade_acc_bytes(B, T) + align_up((size_t)B * T * sizeof(BwdRec), 256);
+  return shade_acc_bytes(B, T) + align_up((size_t)B * T * sizeof(BwdRec), 256) + corner_bytes(B, T);
 }
 
 int launch_shade_backward(const float *drgba, const int32_t *ids, const float *bary,
@@ -376,15 +451,17 @@ int launch_shade_backward(const float *drgba, const int32_t *ids, const float *b
   if (T == 0 || V == 0) return MR_OK;
   float *acc = (float *)ws;
   BwdRec *recs = (BwdRec *)((char *)ws + shade_acc_bytes(B, T));
+  CornerRec *corners = (CornerRec *)((char *)recs + align_up((size_t)B * T * sizeof(BwdRec), 256));
   if (hipMemsetAsync(acc, 0, (size_t)B * T * 36 * sizeof(float), s) != hipSuccess) return check_launch();
   int rc = launch_bwd_setup(clip, tris, B, V, T, recs, s);
+  if (rc != MR_OK) return rc;
+  rc = launch_corner_setup(normals, positions, diffuse, tris, B, V, T, corners, s);
   if (rc != MR_OK) return rc;
   Lights lights{light_pos, light_col, ambient, L};
 #define MR_SHADE_BWD(NL)                                                                        \
   {                                                                                             \
-    ShadeGradFn<NL> fn{(const float4 *)drgba, ids, (const F3 *)bary, (const F3 *)normals,       \
-                       (const F3 *)positions, (const F3 *)diffuse, tris, recs, lights,          \
-                       light_grads, V, T, W, H};                                                \
+    ShadeGradFn<NL> fn{(const float4 *)drgba, ids, (const F3 *)bary, corners, recs, lights,     \
+                       light_grads, T, W, H};                                                   \
     rc = launch_accumulate_runs(fn, B, T, W, H, acc, s);                                        \
   }
   switch (L) {

@@ -41,7 +41,7 @@ def test_abi_argument_validation_without_gpu():
     null = ctypes.c_void_p(0)
     assert L.mr_rasterize_forward(null, null, 1, 8, 12, 64, 64, null, null, null, null, 0, null) == _native.MR_EINVAL
     assert L.mr_rasterize_forward(null, null, -1, 8, 12, 64, 64, null, null, null, null, 0, null) == _native.MR_EINVAL
-    assert L.mr_set_raster_tile_shape(7) == _native.MR_EINVAL
+    assert L.mr_set_raster_tile_shape(99) == _native.MR_EINVAL
 
 
 def test_no_cpu_fallback():
