@@ -95,7 +95,7 @@ struct AttrGradFn {
   static constexpr int kN = kChunk * 3;
   static constexpr int kStride = kAccStride;
   static constexpr int kSlots = 512;
-  static constexpr int kMinWavesPerSimd = 6;
+  static constexpr int kMinWavesPerSimd = 5;
   const float *__restrict__ dout;
   const int32_t *__restrict__ ids;
   const F3 *__restrict__ bary;
