@@ -136,6 +136,63 @@ __global__ __launch_bounds__(kThreads) void k_setup(
   bbs[gid] = bb;
 }
 
+// ---------------------------------------------------------------------------------------
+// Coarse binning: one 1024-thread workgroup per (image, 256x256-pixel cell) compacts, in
+// triangle-id order, the ids whose bbox touches the cell.  The raster kernel's regions
+// (4x4 per cell) then scan ~T * ((256 + d) / W)^2 ids instead of all T (d = triangle size).
+// ---------------------------------------------------------------------------------------
+constexpr int kCellRegions = 4;                       // regions per cell edge
+constexpr int kCellW = kCellRegions * kRegionW;       // 256
+constexpr int kCellH = kCellRegions * kRegionH;
+constexpr int kCoarseThreads = 1024;
+
+__global__ __launch_bounds__(kCoarseThreads) void k_coarse(
+    const uint2 *__restrict__ bbs, int T, int W, int H, int cells_x, int cells_per_image,
+    int32_t *__restrict__ cell_ids, int32_t *__restrict__ cell_count) {
+  __shared__ int s_wave_count[kCoarseThreads / kWave];
+  const int img = (int)blockIdx.x / cells_per_image;
+  const int cell = (int)blockIdx.x - img * cells_per_image;
+  const int cy = cell / cells_x, cx = cell - cy * cells_x;
+  const int X0 = cx * kCellW, Y0 = cy * kCellH;
+  const int X1 = min(X0 + kCellW, W), Y1 = min(Y0 + kCellH, H);
+  const int tid = (int)threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+  const uint2 *img_bbs = bbs + (size_t)img * T;
+  int32_t *out = cell_ids + ((size_t)img * cells_per_image + cell) * T;
+  int n = 0;  // workgroup-uniform
+  constexpr int kUnroll = 4;
+  for (int base = 0; base < T; base += kUnroll * kCoarseThreads) {
+    uint2 bb[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int t = base + u * kCoarseThreads + tid;
+      bb[u] = (t < T) ? img_bbs[t] : make_uint2(0u, 0u);
+    }
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int t = base + u * kCoarseThreads + tid;
+      const int l = (int)(bb[u].x & 0xffffu), r = (int)(bb[u].x >> 16);
+      const int bt = (int)(bb[u].y & 0xffffu), tp = (int)(bb[u].y >> 16);
+      const bool hit = (l < X1) && (r > X0) && (bt < Y1) && (tp > Y0);  // empty bbox = all zeros
+      const unsigned long long m = __ballot(hit);
+      if (lane == 0) s_wave_count[wave] = __builtin_popcountll(m);
+      __syncthreads();
+      int offset = n, total = 0;
+#pragma unroll
+      for (int w = 0; w < kCoarseThreads / kWave; ++w) {
+        const int c = s_wave_count[w];
+        if (w < wave) offset += c;
+        total += c;
+      }
+      if (hit)
+        out[offset + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
+                                                    __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = t;
+      n += total;
+      __syncthreads();
+    }
+  }
+  if (tid == 0) cell_count[(size_t)img * cells_per_image + cell] = n;
+}
+
 // Per-pixel running z-buffer state (registers).
 struct PixelState {
   float z, b0, b1, b2;
@@ -355,7 +412,9 @@ __global__ __launch_bounds__(kThreads, 5) void k_raster(
     const TriRec *__restrict__ recs, const uint2 *__restrict__ bbs,
     const float *__restrict__ pxtab, const float *__restrict__ pytab, int T, int W, int H,
     int regions_x, int regions_per_image, int n_regions, int regions_per_xcd,
-    int32_t *__restrict__ ids, float *__restrict__ bary, float *__restrict__ zbuf, int debug_skip) {
+    const int32_t *__restrict__ cell_ids, const int32_t *__restrict__ cell_count, int cells_x,
+    int cells_per_image, int32_t *__restrict__ ids, float *__restrict__ bary,
+    float *__restrict__ zbuf, int debug_skip) {
   constexpr int kTiles = (kRegionW / 8) * (kRegionH / 8);  // 64 tiles of 8x8 pixels
   constexpr int kMaskWords = kBin2Cap / 32;
   __shared__ __attribute__((aligned(16))) float s_ent[kBin2Cap * kEntryDw];
@@ -381,6 +440,10 @@ __global__ __launch_bounds__(kThreads, 5) void k_raster(
   const TriRec *img_recs = recs + (size_t)img * T;
   const uint2 *img_bbs = bbs + (size_t)img * T;
   const size_t img_px = (size_t)img * H * W;
+  // this region's coarse cell: the id-ordered list of triangles whose bbox touches it
+  const int cell = (ry / kCellRegions) * cells_x + (rx / kCellRegions);
+  const int32_t *cand = cell_ids + ((size_t)img * cells_per_image + cell) * T;
+  const int n_cand = cell_count[(size_t)img * cells_per_image + cell];
 
   // pixel-centre extents of the region (tables are monotone in the pixel index)
   const float rpxlo = pxtab[X0], rpxhi = pxtab[X1 - 1], rpylo = pytab[Y0], rpyhi = pytab[Y1 - 1];
@@ -532,9 +595,9 @@ __global__ __launch_bounds__(kThreads, 5) void k_raster(
   // spatially coherent numbering -- spread evenly over the four 64-entry sub-bins; the
   // id order is restored at compaction from per-chunk survivor counts.
   bool first_pass = true;
-  int round_base = 0;  // first triangle of the round, workgroup-uniform, multiple of 64
+  int round_base = 0;  // first list position of the round, workgroup-uniform, multiple of 64
   do {
-    const int chunks_left = (T - round_base + kWave - 1) / kWave;
+    const int chunks_left = (n_cand - round_base + kWave - 1) / kWave;
     const int round_chunks = min(chunks_left, kRoundChunks);
     s_chunk_count[tid] = 0;  // kRoundChunks == kThreads
     __syncthreads();
@@ -542,12 +605,17 @@ __global__ __launch_bounds__(kThreads, 5) void k_raster(
     constexpr int kUnroll = 2;  // chunks per trip: their loads are issued together
     for (int c0 = wave; c0 < round_chunks && stop == round_chunks; c0 += kUnroll * kWaves) {
       uint2 bb[kUnroll];
+      int tri[kUnroll];
       bool near[kUnroll];
 #pragma unroll
       for (int u = 0; u < kUnroll; ++u) {
         const int c = c0 + u * kWaves;
-        const int t = round_base + c * kWave + lane;
-        bb[u] = (c < round_chunks && t < T) ? img_bbs[t] : make_uint2(0u, 0u);
+        const int k = round_base + c * kWave + lane;
+        tri[u] = (c < round_chunks && k < n_cand) ? cand[k] : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        bb[u] = (tri[u] >= 0) ? img_bbs[tri[u]] : make_uint2(0u, 0u);
       }
 #pragma unroll
       for (int u = 0; u < kUnroll; ++u) {
@@ -559,7 +627,7 @@ __global__ __launch_bounds__(kThreads, 5) void k_raster(
       for (int u = 0; u < kUnroll; ++u) {
         const int c = c0 + u * kWaves;
         if (c >= round_chunks || stop != round_chunks) continue;  // wave-uniform
-        const int t = round_base + c * kWave + lane;
+        const int t = tri[u];
         bool pass = false;
         if (near[u]) {
           const TriRec *rp = img_recs + t;
@@ -649,8 +717,8 @@ __global__ __launch_bounds__(kThreads, 5) void k_raster(
     }
     first_pass = false;
     round_base = next_base;
-    if (round_base < T) __syncthreads();  // tiles done with the bin; orders the state stores
-  } while (round_base < T);
+    if (round_base < n_cand) __syncthreads();  // tiles done with the bin; orders the state stores
+  } while (round_base < n_cand);
 }
 
 }  // namespace
@@ -658,8 +726,10 @@ __global__ __launch_bounds__(kThreads, 5) void k_raster(
 size_t raster_forward_ws(int B, int V, int T, int W, int H) {
   (void)V;
   const size_t nbt = (size_t)B * T;
+  const size_t cells = (size_t)((W + kCellW - 1) / kCellW) * ((H + kCellH - 1) / kCellH) * B;
   return align_up(nbt * sizeof(TriRec), 256) + align_up(nbt * sizeof(uint2), 256) +
-         align_up((size_t)W * sizeof(float), 256) + align_up((size_t)H * sizeof(float), 256);
+         align_up((size_t)W * sizeof(float), 256) + align_up((size_t)H * sizeof(float), 256) +
+         align_up(cells * T * sizeof(int32_t), 256) + align_up(cells * sizeof(int32_t), 256);
 }
 
 int g_raster_tile_shape = 0;  // 0: two-phase kernel; 1, 2: first-generation kernel, 8x8 / 16x4 tiles
@@ -676,6 +746,12 @@ int launch_raster_forward(const float *clip, const int32_t *tris, int B, int V, 
   float *pxtab = (float *)p;
   p += align_up((size_t)W * sizeof(float), 256);
   float *pytab = (float *)p;
+  p += align_up((size_t)H * sizeof(float), 256);
+  const int cells_x = (W + kCellW - 1) / kCellW, cells_y = (H + kCellH - 1) / kCellH;
+  const int cells_per_image = cells_x * cells_y;
+  int32_t *cell_ids = (int32_t *)p;
+  p += align_up((size_t)cells_per_image * B * T * sizeof(int32_t), 256);
+  int32_t *cell_count = (int32_t *)p;
 
   const long setup_threads = (long)nbt + W + H;
   const unsigned setup_blocks = (unsigned)((setup_threads + kThreads - 1) / kThreads);
@@ -684,6 +760,10 @@ int launch_raster_forward(const float *clip, const int32_t *tris, int B, int V, 
   int rc = check_launch();
   if (rc != MR_OK) return rc;
   if (B == 0) return MR_OK;
+  hipLaunchKernelGGL(k_coarse, dim3((unsigned)(cells_per_image * B)), dim3(kCoarseThreads), 0, s, bbs, T,
+                     W, H, cells_x, cells_per_image, cell_ids, cell_count);
+  rc = check_launch();
+  if (rc != MR_OK) return rc;
 
   const int regions_x = (W + kRegionW - 1) / kRegionW;
   const int regions_y = (H + kRegionH - 1) / kRegionH;
@@ -700,11 +780,13 @@ int launch_raster_forward(const float *clip, const int32_t *tris, int B, int V, 
     case 2: MR_LAUNCH_RASTER((k_raster_v1<16, 4>)); break;
     case 3: case 4: case 5: case 10: case 18:  // timing probes (results are NOT valid)
       hipLaunchKernelGGL(k_raster, grid, block, 0, s, recs, bbs, pxtab, pytab, T, W, H, regions_x,
-                         per_image, n_regions, per_xcd, ids, bary, z, g_raster_tile_shape - 2);
+                         per_image, n_regions, per_xcd, cell_ids, cell_count, cells_x, cells_per_image,
+                         ids, bary, z, g_raster_tile_shape - 2);
       break;
     default:
       hipLaunchKernelGGL(k_raster, grid, block, 0, s, recs, bbs, pxtab, pytab, T, W, H, regions_x,
-                         per_image, n_regions, per_xcd, ids, bary, z, 0);
+                         per_image, n_regions, per_xcd, cell_ids, cell_count, cells_x, cells_per_image,
+                         ids, bary, z, 0);
       break;
   }
 #undef MR_LAUNCH_RASTER
