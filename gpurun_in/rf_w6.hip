@@ -409,7 +409,7 @@ __device__ __forceinline__ bool rect_outside_triangle(const float4 q0, const flo
          (int)rect_outside_edge(q1.z, q1.w, m8, pxlo, pxhi, pylo, pyhi);
 }
 
-__global__ __launch_bounds__(kThreads, 7) void k_raster(
+__global__ __launch_bounds__(kThreads, 6) void k_raster(
     const TriRec *__restrict__ recs, const uint2 *__restrict__ bbs,
     const float *__restrict__ pxtab, const float *__restrict__ pytab, int T, int W, int H,
     int regions_x, int regions_per_image, int n_regions, int regions_per_xcd,

@@ -138,6 +138,119 @@ __global__ __launch_bounds__(kRunThreads, Fn::kMinWavesPerSimd) void k_accumulat
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Row-transposed variant for functors with many sums per triangle (N = 36).
+//
+// With 36 register accumulators per lane the run-based kernel above sits at 2-3 waves per
+// SIMD, and every row on which ANY lane finishes a run costs 36 ds_add_f32 wave-instructions
+// (~26 LDS cycles each on gfx950, whatever the number of active lanes): 0.8 ms of 1.17 ms at
+// 1024^2 x 32.  Here no sum lives in a pixel lane's registers:
+//   1. each lane evaluates its pixel's N values and parks them in an LDS row (N/4
+//      ds_write_b128, all lanes active, conflict-free at a 36-float stride);
+//   2. lanes 0..N-1 then walk the 64 parked pixels left to right -- uniform control flow,
+//      the pixel's triangle id comes from v_readlane -- summing element `lane`; where the
+//      id changes the N-lane partial leaves as ONE contiguous global float atomic
+//      (144 B for N = 36) into acc[image][triangle][kStride].
+// Triangle data is still fetched once per vertical run and kept in registers.
+template <class Fn>
+__global__ __launch_bounds__(kRunThreads, Fn::kMinWavesPerSimd) void k_accumulate_rows(
+    Fn fn, int T, int W, int H, int regions_x, int regions_per_image, int n_regions,
+    int regions_per_xcd, float *__restrict__ acc) {
+  constexpr int N = Fn::kN, STRIDE = Fn::kStride;
+  static_assert(N % 4 == 0 && N <= kWave && N <= STRIDE, "row-transposed flush needs N % 4 == 0");
+  __shared__ __attribute__((aligned(16))) float s_stage[kRunThreads / kWave][kWave * N];
+
+  const int region = xcd_contiguous_block((int)blockIdx.x, n_regions, regions_per_xcd);
+  if (region < 0) return;
+  const int img = region / regions_per_image;
+  const int rr = region - img * regions_per_image;
+  const int ry = rr / regions_x;
+  const int rx = rr - ry * regions_x;
+
+  const int tid = (int)threadIdx.x;
+  const int lane = tid & (kWave - 1);
+  const int wave = tid >> 6;
+  const int x = rx * kWave + lane;
+  const bool in_range = x < W;
+  const int xc = in_range ? x : W - 1;
+  const int y_begin = ry * kRunRegionH + wave * kRunRowsPerWave;
+  const int y_end = min(y_begin + kRunRowsPerWave, H);
+  float *acc_img = acc + (size_t)img * T * STRIDE;
+  float *stage = s_stage[wave];
+
+  typename Fn::Image image_sums;
+  fn.begin_image(img, image_sums);
+  int run_tri = -1;
+  typename Fn::Triangle tri_data;
+  size_t pix = ((size_t)img * H + y_begin) * W + xc;
+  typename Fn::Raw raw_next;
+  if (y_begin < y_end) fn.fetch(img, xc, y_begin, pix, raw_next);
+  for (int y = y_begin; y < y_end; ++y, pix += W) {  // wave-uniform trip count
+    const typename Fn::Raw raw = raw_next;
+    if (y + 1 < y_end) fn.fetch(img, xc, y + 1, pix + W, raw_next);  // software prefetch
+    int tri = -1;
+    typename Fn::Pixel p;
+    const bool valid = fn.prepare(raw, T, tri, p) && in_range;
+    if (!__ballot(valid)) continue;  // nothing in this row segment (background)
+    if (valid && tri != run_tri) {
+      run_tri = tri;
+      fn.load_triangle(img, tri, tri_data);
+    }
+    float v[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = 0.0f;
+    if (valid) fn.accumulate(p, tri_data, v, image_sums);
+    float4 *row = (float4 *)(stage + lane * N);
+#pragma unroll
+    for (int q = 0; q < N / 4; ++q) row[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    const int my_tri = valid ? tri : -1;
+    // segment heads along x: a valid pixel whose left neighbour holds another id (or none)
+    const int left_tri = __shfl_up(my_tri, 1);
+    const bool head = valid && (lane == 0 || left_tri != my_tri);
+    unsigned long long heads = __ballot(head);
+    const unsigned long long valids = __ballot(valid);
+    __builtin_amdgcn_wave_barrier();  // LDS executes one wavefront's operations in order
+    // transposed reduction: lane k < N sums element k over each segment of equal ids
+    const float *col = stage + min(lane, N - 1);
+    while (heads) {  // wave-uniform: ~3-4 segments per 64 pixels
+      const int p0 = __builtin_ctzll(heads);
+      heads &= heads - 1;
+      // the segment ends at the next head or at the first invalid pixel after p0
+      const unsigned long long after = ~0ull << p0;
+      const unsigned long long stop = (heads | ~valids) & after;
+      const int p1 = stop ? __builtin_ctzll(stop) : kWave;
+      const int t = __builtin_amdgcn_readlane(my_tri, p0);
+      float sum = 0.0f;
+      int p = p0;
+      for (; p + 8 <= p1; p += 8) {  // 8 independent LDS reads in flight
+        float r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = col[(p + j) * N];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum += r[j];
+      }
+      for (; p < p1; ++p) sum += col[p * N];
+      if (lane < N) atomicAdd(&acc_img[(size_t)t * STRIDE + lane], sum);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  fn.end_image(img, image_sums);
+}
+
+template <class Fn>
+inline int launch_accumulate_rows(const Fn &fn, int B, int T, int W, int H, float *acc,
+                                  hipStream_t s) {
+  const int regions_x = (W + kWave - 1) / kWave;
+  const int regions_y = (H + kRunRegionH - 1) / kRunRegionH;
+  const int per_image = regions_x * regions_y;
+  const int n_regions = per_image * B;
+  const int per_xcd = (n_regions + kXcds - 1) / kXcds;
+  hipLaunchKernelGGL((k_accumulate_rows<Fn>), dim3((unsigned)(per_xcd * kXcds)),
+                     dim3(kRunThreads), 0, s, fn, T, W, H, regions_x, per_image, n_regions,
+                     per_xcd, acc);
+  return check_launch();
+}
+
 template <class Fn>
 inline int launch_accumulate_runs(const Fn &fn, int B, int T, int W, int H, float *acc,
                                   hipStream_t s) {

@@ -180,7 +180,7 @@ struct ShadeGradFn {
   static constexpr int kN = 36;       // 27 attribute partials [corner][attr] + 9 clip partials
   static constexpr int kStride = 36;
   static constexpr int kSlots = 256;
-  static constexpr int kMinWavesPerSimd = 3;  // <= 168 VGPRs
+  static constexpr int kMinWavesPerSimd = 3;
   const float4 *__restrict__ drgba;   // [B,H,W,4], image rows (flipped w.r.t. the G-buffer)
   const int32_t *__restrict__ ids;
   const F3 *__restrict__ bary;
@@ -462,7 +462,7 @@ int launch_shade_backward(const float *drgba, const int32_t *ids, const float *b
   {                                                                                             \
     ShadeGradFn<NL> fn{(const float4 *)drgba, ids, (const F3 *)bary, corners, recs, lights,     \
                        light_grads, T, W, H};                                                   \
-    rc = launch_accumulate_runs(fn, B, T, W, H, acc, s);                                        \
+    rc = launch_accumulate_rows(fn, B, T, W, H, acc, s);                                        \
   }
   switch (L) {
     case 1: MR_SHADE_BWD(1); break;
