@@ -137,6 +137,36 @@ int mr_shade_backward(const float *drgba, const int32_t *ids, const float *bary,
                       float *ddiffuse, float *light_grads, void *workspace,
                       size_t workspace_bytes, void *stream);
 
+/* ---- SoftRas renderer ---------------------------------------------------------------
+ * Replaces rasterize_batch / rasterize of the reference's second renderer
+ * (src/soft_mesh_renderer/rasterize.py:14-110, 212-424) and the autograd graph behind it.
+ *   clip               [B,V,4] f32   clip-space vertices
+ *   positions, normals, diffuse [B,V,3] f32 (positions = world-space vertices)
+ *   triangles          [T,3] i32     counter-clockwise = front-facing (back faces are culled)
+ *   light_positions    [B,L,3] f32, light_intensities [B,L] f32 (scalar), 1 <= L <= mr_soft_max_lights()
+ *   sigma, gamma, blur the reference's sigma_val, gamma_val, blur_radius (NDC units)
+ *   rgba               [B,H,W,4] f32 out; row 0 is the TOP scanline; alpha = silhouette
+ *   aux                [B,H,W,4] f32 out; per-pixel softmax state kept for the backward */
+int mr_soft_max_lights(void);
+size_t mr_soft_workspace_bytes(int B, int V, int T, int W, int H);
+int mr_soft_forward(const float *clip, const float *positions, const float *normals,
+                    const float *diffuse, const int32_t *triangles,
+                    const float *light_positions, const float *light_intensities,
+                    int B, int V, int T, int W, int H, int L,
+                    float sigma, float gamma, float blur, float *rgba, float *aux,
+                    void *workspace, size_t workspace_bytes, void *stream);
+/* All gradient outputs are zeroed here.  drgba [B,H,W,4]; dclip [B,V,4];
+ * dpositions / dnormals / ddiffuse [B,V,3]; dlight_positions [B,L,3]; dlight_intensities [B,L]. */
+int mr_soft_backward(const float *drgba, const float *rgba, const float *aux,
+                     const float *clip, const float *positions, const float *normals,
+                     const float *diffuse, const int32_t *triangles,
+                     const float *light_positions, const float *light_intensities,
+                     int B, int V, int T, int W, int H, int L,
+                     float sigma, float gamma, float blur,
+                     float *dclip, float *dpositions, float *dnormals, float *ddiffuse,
+                     float *dlight_positions, float *dlight_intensities,
+                     void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- tuning hooks (no reference counterpart; results never change) ----------
  * Pixel tile walked by one wavefront in the forward raster kernel:
  * 0 = 8x8 (default), 1 = 16x4, 2 = 32x2. */

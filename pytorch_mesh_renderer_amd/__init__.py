@@ -9,7 +9,7 @@ All per-pixel work (coverage, z-buffer, barycentrics, attribute interpolation an
 their gradients) runs in hand-written HIP kernels for gfx950 behind the C ABI of
 include/mesh_raster.h; there is no CPU or eager fallback.
 """
-from . import common, mesh_renderer
+from . import common, mesh_renderer, soft_mesh_renderer
 from .mesh_renderer import render, tone_mapper, rasterize
 
-__all__ = ["common", "mesh_renderer", "render", "tone_mapper", "rasterize"]
+__all__ = ["common", "mesh_renderer", "soft_mesh_renderer", "render", "tone_mapper", "rasterize"]

@@ -76,6 +76,14 @@ def lib():
         L.mr_shade_backward_workspace_bytes.restype = sz
         L.mr_shade_backward.argtypes = [vp] * 11 + [ci] * 6 + [vp] * 6 + [sz, vp]
         L.mr_shade_backward.restype = ci
+        L.mr_soft_max_lights.restype = ci
+        L.mr_soft_workspace_bytes.argtypes = [ci] * 5
+        L.mr_soft_workspace_bytes.restype = sz
+        cf = ctypes.c_float
+        L.mr_soft_forward.argtypes = [vp] * 7 + [ci] * 6 + [cf] * 3 + [vp, vp, vp, sz, vp]
+        L.mr_soft_forward.restype = ci
+        L.mr_soft_backward.argtypes = [vp] * 10 + [ci] * 6 + [cf] * 3 + [vp] * 6 + [vp, sz, vp]
+        L.mr_soft_backward.restype = ci
         _lib = L
     return _lib
 
@@ -257,3 +265,61 @@ def shade_backward(drgba, ids, bary, clip, normals, positions, diffuse, triangle
     dlint = lg[:, 3 * nl:6 * nl].reshape(B, nl, 3)
     damb = lg[:, 6 * nl:] if ambient is not None else None
     return dclip, dn, dp, dd, dlpos, dlint, damb
+
+
+def soft_max_lights():
+    return int(lib().mr_soft_max_lights())
+
+
+def soft_forward(clip, positions, normals, diffuse, triangles, light_positions, light_intensities,
+                 width, height, sigma, gamma, blur):
+    """SoftRas forward: -> (rgba [B,H,W,4] with row 0 = top, aux [B,H,W,4] for the backward)."""
+    tensors = [clip, positions, normals, diffuse, triangles, light_positions, light_intensities]
+    dev = _require_device(*tensors)
+    L = lib()
+    clip, positions, normals, diffuse, triangles, light_positions, light_intensities = [
+        t.contiguous() for t in tensors]
+    B, V, _ = clip.shape
+    T, nl = triangles.shape[0], light_positions.shape[1]
+    rgba = torch.empty(B, height, width, 4, dtype=torch.float32, device=dev)
+    aux = torch.empty(B, height, width, 4, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        need = L.mr_soft_workspace_bytes(B, V, T, width, height)
+        ws, have = _workspace(dev, need)
+        rc = L.mr_soft_forward(_ptr(clip), _ptr(positions), _ptr(normals), _ptr(diffuse), _ptr(triangles),
+                               _ptr(light_positions), _ptr(light_intensities), B, V, T, width, height, nl,
+                               float(sigma), float(gamma), float(blur), _ptr(rgba), _ptr(aux), _ptr(ws),
+                               have, _stream(dev))
+    _check(rc, "mr_soft_forward")
+    return rgba, aux
+
+
+def soft_backward(drgba, rgba, aux, clip, positions, normals, diffuse, triangles, light_positions,
+                  light_intensities, sigma, gamma, blur):
+    """-> (dclip [B,V,4], dpositions, dnormals, ddiffuse [B,V,3], dlight_positions [B,L,3],
+    dlight_intensities [B,L])."""
+    tensors = [drgba, rgba, aux, clip, positions, normals, diffuse, triangles, light_positions,
+               light_intensities]
+    dev = _require_device(*tensors)
+    L = lib()
+    (drgba, rgba, aux, clip, positions, normals, diffuse, triangles, light_positions,
+     light_intensities) = [t.contiguous() for t in tensors]
+    B, V, _ = clip.shape
+    T, nl = triangles.shape[0], light_positions.shape[1]
+    _, H, W, _ = rgba.shape
+    dclip = torch.empty(B, V, 4, dtype=torch.float32, device=dev)
+    dp = torch.empty(B, V, 3, dtype=torch.float32, device=dev)
+    dn = torch.empty(B, V, 3, dtype=torch.float32, device=dev)
+    dd = torch.empty(B, V, 3, dtype=torch.float32, device=dev)
+    dlp = torch.empty(B, nl, 3, dtype=torch.float32, device=dev)
+    dli = torch.empty(B, nl, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        need = L.mr_soft_workspace_bytes(B, V, T, W, H)
+        ws, have = _workspace(dev, need)
+        rc = L.mr_soft_backward(_ptr(drgba), _ptr(rgba), _ptr(aux), _ptr(clip), _ptr(positions),
+                                _ptr(normals), _ptr(diffuse), _ptr(triangles), _ptr(light_positions),
+                                _ptr(light_intensities), B, V, T, W, H, nl, float(sigma), float(gamma),
+                                float(blur), _ptr(dclip), _ptr(dp), _ptr(dn), _ptr(dd), _ptr(dlp),
+                                _ptr(dli), _ptr(ws), have, _stream(dev))
+    _check(rc, "mr_soft_backward")
+    return dclip, dp, dn, dd, dlp, dli

@@ -1,3 +1,3 @@
-from . import camera_utils, shapes, synthetic
+from . import camera_utils, meshes, shapes, synthetic
 
-__all__ = ["camera_utils", "shapes", "synthetic"]
+__all__ = ["camera_utils", "meshes", "shapes", "synthetic"]

@@ -163,4 +163,52 @@ int mr_shade_backward(const float *drgba, const int32_t *ids, const float *bary,
                                    (hipStream_t)stream);
 }
 
+int mr_soft_max_lights(void) { return mr::soft_max_lights(); }
+
+size_t mr_soft_workspace_bytes(int B, int V, int T, int W, int H) {
+  if (bad_dims(B, V, T, W, H)) return 0;
+  return mr::soft_ws(B, V, T, W, H);
+}
+
+int mr_soft_forward(const float *clip, const float *positions, const float *normals,
+                    const float *diffuse, const int32_t *triangles, const float *light_positions,
+                    const float *light_intensities, int B, int V, int T, int W, int H, int L,
+                    float sigma, float gamma, float blur, float *rgba, float *aux, void *workspace,
+                    size_t workspace_bytes, void *stream) {
+  if (bad_dims(B, V, T, W, H) || L < 1 || L > mr::soft_max_lights() || !(sigma > 0.f) || !(gamma > 0.f))
+    return MR_EINVAL;
+  if (B == 0) return MR_OK;
+  if (!rgba || !aux || !light_positions || !light_intensities) return MR_EINVAL;
+  if (T > 0 && (!clip || !positions || !normals || !diffuse || !triangles)) return MR_EINVAL;
+  const int rc = check_ws(workspace, workspace_bytes, mr::soft_ws(B, V, T, W, H));
+  if (rc != MR_OK) return rc;
+  return mr::launch_soft_forward(clip, positions, normals, diffuse, triangles, light_positions,
+                                 light_intensities, B, V, T, W, H, L, sigma, gamma, blur, rgba, aux,
+                                 workspace, (hipStream_t)stream);
+}
+
+int mr_soft_backward(const float *drgba, const float *rgba, const float *aux, const float *clip,
+                     const float *positions, const float *normals, const float *diffuse,
+                     const int32_t *triangles, const float *light_positions,
+                     const float *light_intensities, int B, int V, int T, int W, int H, int L,
+                     float sigma, float gamma, float blur, float *dclip, float *dpositions,
+                     float *dnormals, float *ddiffuse, float *dlight_positions,
+                     float *dlight_intensities, void *workspace, size_t workspace_bytes, void *stream) {
+  if (bad_dims(B, V, T, W, H) || L < 1 || L > mr::soft_max_lights() || !(sigma > 0.f) || !(gamma > 0.f))
+    return MR_EINVAL;
+  if (B == 0) return MR_OK;
+  if (!drgba || !rgba || !aux || !light_positions || !light_intensities || !dlight_positions ||
+      !dlight_intensities)
+    return MR_EINVAL;
+  if (V > 0 && (!clip || !positions || !normals || !diffuse || !dclip || !dpositions || !dnormals || !ddiffuse))
+    return MR_EINVAL;
+  if (T > 0 && !triangles) return MR_EINVAL;
+  const int rc = check_ws(workspace, workspace_bytes, mr::soft_ws(B, V, T, W, H));
+  if (rc != MR_OK) return rc;
+  return mr::launch_soft_backward(drgba, rgba, aux, clip, positions, normals, diffuse, triangles,
+                                  light_positions, light_intensities, B, V, T, W, H, L, sigma, gamma,
+                                  blur, dclip, dpositions, dnormals, ddiffuse, dlight_positions,
+                                  dlight_intensities, workspace, (hipStream_t)stream);
+}
+
 }  // extern "C"

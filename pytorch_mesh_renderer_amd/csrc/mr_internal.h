@@ -89,4 +89,17 @@ int launch_shade_backward(const float *drgba, const int32_t *ids, const float *b
                           int H, int L, float *dclip, float *dnormals, float *dpositions,
                           float *ddiffuse, float *light_grads, void *ws, hipStream_t s);
 
+int soft_max_lights();
+size_t soft_ws(int B, int V, int T, int W, int H);
+int launch_soft_forward(const float *clip, const float *positions, const float *normals,
+                        const float *diffuse, const int32_t *tris, const float *lpos,
+                        const float *lint, int B, int V, int T, int W, int H, int L, float sigma,
+                        float gamma, float blur, float *rgba, float *aux, void *ws, hipStream_t s);
+int launch_soft_backward(const float *drgba, const float *rgba, const float *aux, const float *clip,
+                         const float *positions, const float *normals, const float *diffuse,
+                         const int32_t *tris, const float *lpos, const float *lint, int B, int V, int T,
+                         int W, int H, int L, float sigma, float gamma, float blur, float *dclip,
+                         float *dpositions, float *dnormals, float *ddiffuse, float *dlpos, float *dlint,
+                         void *ws, hipStream_t s);
+
 }  // namespace mr

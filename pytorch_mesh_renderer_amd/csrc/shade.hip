@@ -24,7 +24,7 @@
 //                      per-lane sums reduced once per wave.
 //   k_shade_scatter    one thread per touched (image, triangle): atomics into
 //                      dnormals / dpositions / ddiffuse [B,V,3] and dclip [B,V,4].
-#include "run_accum.h"
+#include "corner_rec.h"
 
 namespace mr {
 namespace {
@@ -39,17 +39,6 @@ struct Lights {
   const float *__restrict__ col;  // [B,L,3]
   const float *__restrict__ amb;  // [B,3] or nullptr
   int L;
-};
-
-struct Corners {  // the three corners' (normal, position, diffuse): 27 floats
-  float c[3][9];
-};
-
-// Corners of one (image, triangle), gathered once by k_corner_setup so that the per-pixel
-// kernels follow ONE pointer (id -> 128-byte record) instead of two (id -> vertex ids ->
-// nine scattered 12-byte reads).  128 bytes, 128-byte aligned = one cache line.
-struct alignas(128) CornerRec {
-  float4 q[8];  // 27 floats used, row-major [corner][attribute]
 };
 
 __global__ __launch_bounds__(kThreads) void k_corner_setup(
@@ -74,19 +63,6 @@ __global__ __launch_bounds__(kThreads) void k_corner_setup(
   for (int i = 27; i < 32; ++i) v[i] = 0.f;
 #pragma unroll
   for (int q = 0; q < 8; ++q) out[gid].q[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-}
-
-__device__ __forceinline__ void load_corners(const CornerRec *__restrict__ rec, Corners &o) {
-  float v[28];
-#pragma unroll
-  for (int q = 0; q < 7; ++q) {
-    const float4 f = rec->q[q];
-    v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w;
-  }
-#pragma unroll
-  for (int k = 0; k < 3; ++k)
-#pragma unroll
-    for (int a = 0; a < 9; ++a) o.c[k][a] = v[k * 9 + a];
 }
 
 // alpha = clamp(sum(2*bary), 0, 1); attr = alpha * interp + (1 - alpha) * (-1)
@@ -401,7 +377,7 @@ size_t shade_forward_ws(int B, int V, int T, int W, int H) {
   return corner_bytes(B, T);
 }
 
-static int launch_corner_setup(const float *normals, const float *positions, const float *diffuse,
+int launch_corner_setup(const float *normals, const float *positions, const float *diffuse,
                                const int32_t *tris, int B, int V, int T, CornerRec *out, hipStream_t s) {
   const long nbt = (long)B * T;
   hipLaunchKernelGGL(k_corner_setup, dim3((unsigned)((nbt + kThreads - 1) / kThreads)), dim3(kThreads), 0,

@@ -250,6 +250,50 @@ def main():
                 torch.tensor(2 * [[0.0, 1.0, 0.0]]), job["light_positions"], job["light_intensities"],
                 128, 128)
 
+    # ---- G8: SoftRas renderer -------------------------------------------------
+    from src import soft_mesh_renderer as soft
+    soft_rb = sys.modules["src.soft_mesh_renderer.rasterize"].rasterize_batch
+    # the single-triangle scene of the reference's test_single_triangle_forward, both blur settings
+    st = dict(
+        clip=torch.tensor([[1.0, -1.0, 0.25, 1.0], [1.0, 1.0, 0.25, 1.0], [-1.0, -1.0, 0.25, 1.0]]),
+        triangles=torch.tensor([[0, 1, 2]], dtype=torch.int32),
+        world=torch.tensor([[1.0, -1.0, 0.0], [1.0, 1.0, 0.0], [-1.0, -1.0, 0.0]]),
+        normals=torch.tensor([[0.0, 0.0, 1.0]] * 3), diffuse=torch.tensor([[1.0, 0.0, 0.0]] * 3),
+        light_positions=torch.tensor([[0.0, 0.0, 100000.0]]), light_intensities=torch.tensor([1.0]))
+    blur2 = 0.1 * np.sqrt(2.0) + 1e-6
+    sigma2 = float(-blur2 ** 2 / torch.special.logit(torch.tensor(1e-3)))
+    soft_out = {k: v.numpy() for k, v in st.items()}
+    for tag, (sig, gam, blur) in {"a": (1e-5, 1e-4, 0.01), "b": (sigma2, 1e-4, blur2)}.items():
+        img = soft_rb(st["clip"], st["triangles"], st["world"], st["normals"], st["diffuse"],
+                      st["light_positions"], st["light_intensities"], 10, 10, sig, gam, blur)
+        soft_out["image_" + tag] = img.numpy()
+        soft_out["params_" + tag] = np.array([sig, gam, blur], np.float64)
+    np.savez_compressed(os.path.join(GOLDEN, "soft_single_triangle_10x10.npz"), **soft_out)
+
+    def soft_case(path, k, size, sigma, gamma, batch=1):
+        job = synthetic.sphere_job(batch, size, size, k)
+        tris_ccw = job["triangles"]                       # shapes.sphere winds CCW seen from outside
+        leaves = {"vertices": job["vertices"], "diffuse": torch.rand(batch, job["vertices"].shape[1], 3,
+                                                                      generator=torch.Generator().manual_seed(k)),
+                  "light_positions": job["light_positions"]}
+        leaves = {n: v.clone().requires_grad_(True) for n, v in leaves.items()}
+        lint = torch.full((batch, 1), 1.3)
+        img = soft.render(leaves["vertices"], tris_ccw, leaves["diffuse"], job["eyes"], torch.zeros(batch, 3),
+                          torch.tensor(batch * [[0.0, 1.0, 0.0]]), leaves["light_positions"], lint, size, size,
+                          sigma_val=sigma, gamma_val=gamma)
+        target = torch.rand(img.shape, generator=torch.Generator().manual_seed(9))
+        torch.mean(torch.abs(img - target)).backward()
+        data = {"triangles": tris_ccw.numpy(), "eye": job["eyes"].numpy(), "light_intensities": lint.numpy(),
+                "image": img.detach().numpy(), "target": target.numpy(),
+                "params": np.array([sigma, gamma], np.float64)}
+        for n, v in leaves.items():
+            data[n] = v.detach().numpy()
+            data["d_" + n] = v.grad.numpy()
+        np.savez_compressed(path, **data)
+
+    soft_case(os.path.join(GOLDEN, "soft_sphere_k6_32.npz"), 6, 32, 1e-5, 1e-4)       # reference defaults
+    soft_case(os.path.join(GOLDEN, "soft_sphere_k10_32.npz"), 10, 32, 1e-4, 1e-2)     # softer blend
+
     # ---- camera utilities ---------------------------------------------------------------------
     eyes = synthetic.orbit_eyes(5)
     np.savez_compressed(
