@@ -65,8 +65,11 @@ class ImageGather:
     wait() makes the current stream wait for it and returns the [B_total, H, W, C]
     tensor.  Shards may be uneven (they are padded to the largest one)."""
 
-    def __init__(self, n_total, group=None):
+    def __init__(self, n_total, group=None, force_collective=False):
+        """force_collective: run the collective even in a 1-rank group (smoke tests of the
+        RCCL / side-stream path on a single GPU)."""
         self.group = group
+        self.force = bool(force_collective) and dist.is_initialized()
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.n_total = n_total
@@ -77,7 +80,7 @@ class ImageGather:
         self._work = None
 
     def start(self, local):
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             self._out = local
             return
         max_count = max(self.counts)
@@ -110,7 +113,7 @@ class ImageGather:
             self._max_count = max_count
 
     def wait(self):
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return self._out
         if self._side is not None:
             torch.cuda.current_stream(self._out.device).wait_stream(self._side)

@@ -261,3 +261,35 @@ def test_gradcheck_single_pixel(device):
                         dtype=torch.float32, device=device, requires_grad=True)
     assert torch.autograd.gradcheck(pixel, clip, eps=4e-2, atol=0.1, rtol=0.01,
                                     nondet_tol=1e-5)
+
+
+def test_config4_scale_single_image(device):
+    """BASELINE config 4's per-image shape: 50k-tri sphere (K=158), 2048x2048 -- exercises 64
+    coarse cells and ~900-entry cell lists; bit-exact vs the CPU oracle."""
+    job = synthetic.sphere_job(1, 2048, 2048, 158)
+    assert job["triangles"].shape[0] == 49928
+    want = oracle.forward(job["clip"].numpy(), job["triangles"].numpy(), 2048, 2048)
+    got = hip_forward(job["clip"].numpy(), job["triangles"].numpy(), 2048, 2048, device)
+    assert_forward_bitwise(got, want)
+
+
+def test_rccl_image_gather_single_rank(device):
+    """The RCCL + side-stream hand-over path on one GPU (1-rank nccl group)."""
+    import os
+    import torch.distributed as dist
+    from pytorch_mesh_renderer_amd import distributed
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    if not dist.is_initialized():
+        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=device)
+    try:
+        x = torch.rand(3, 17, 9, 4, device=device)
+        g = distributed.ImageGather(3, force_collective=True)
+        g.start(x)
+        y = (x * 2).sum()            # work on the main stream while the gather runs
+        out = g.wait()
+        assert torch.equal(out, x) and float(y) > 0
+        grad = torch.ones(5, 3, device=device)
+        assert torch.equal(distributed.allreduce_shared_mesh_grad(grad.clone()), grad)
+    finally:
+        dist.destroy_process_group()
