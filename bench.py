@@ -76,9 +76,9 @@ def make_step(job, device, gather):
     tri = job["triangles"].to(device)
     vertices = job["vertices"].to(device).requires_grad_(True)
     normals, diffuse = job["normals"].to(device), job["diffuse"].to(device)
-    eyes = job["eyes"].to(device)
+    eyes = job["eyes"]                      # cameras stay host tensors, as in the reference's usage
     center = torch.zeros_like(eyes)
-    up = torch.tensor([0.0, 1.0, 0.0], device=device)
+    up = torch.tensor([0.0, 1.0, 0.0])
     lpos, lint = job["light_positions"].to(device), job["light_intensities"].to(device)
 
     def forward():

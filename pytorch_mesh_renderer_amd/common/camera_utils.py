@@ -91,3 +91,19 @@ def transform_homogeneous(matrices, vertices):
     ones = torch.ones(vertices.shape[0], vertices.shape[1], 1,
                       dtype=vertices.dtype, device=vertices.device)
     return torch.matmul(torch.cat([vertices, ones], 2), matrices.transpose(1, 2))
+
+
+def clip_space_transforms(camera_position, camera_lookat, camera_up, fov_y, near_clip, far_clip,
+                          aspect_ratio, device):
+    """perspective(...) @ look_at(...) as [batch, 4, 4] on `device`.
+
+    The 4x4 math runs where the camera tensors live.  Cameras given as host tensors (the
+    reference's usual case) are therefore handled on the CPU and uploaded once: no tiny GPU
+    kernels, and look_at's degeneracy assertions -- which need the values -- do not force a
+    device synchronisation in the middle of a render.  Cameras that live on the GPU (e.g. when
+    they are being optimised there) stay on the GPU and remain differentiable either way."""
+    cam_device = camera_position.device
+    to_cam = lambda t: t.to(cam_device)
+    view = look_at(camera_position, to_cam(camera_lookat), to_cam(camera_up))
+    proj = perspective(aspect_ratio, to_cam(fov_y), to_cam(near_clip), to_cam(far_clip))
+    return torch.matmul(proj, view).to(device, non_blocking=True)

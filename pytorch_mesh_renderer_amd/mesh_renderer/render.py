@@ -68,9 +68,9 @@ def render(vertices, triangles, normals, diffuse_colors, camera_position, camera
         camera_up = camera_up.unsqueeze(0).repeat(batch_size, 1)
     elif list(camera_up.shape) != [batch_size, 3]:
         raise ValueError("camera_up must have shape [batch_size, 3] or [3].")
-    fov_y = _per_batch(fov_y, batch_size, device, "fov_y")
-    near_clip = _per_batch(near_clip, batch_size, device, "near_clip")
-    far_clip = _per_batch(far_clip, batch_size, device, "far_clip")
+    fov_y = _per_batch(fov_y, batch_size, camera_position.device, "fov_y")
+    near_clip = _per_batch(near_clip, batch_size, camera_position.device, "near_clip")
+    far_clip = _per_batch(far_clip, batch_size, camera_position.device, "far_clip")
     if specular_colors is not None and shininess_coefficients is None:
         raise ValueError("Specular colors were supplied without shininess coefficients.")
     if shininess_coefficients is not None and specular_colors is None:
@@ -100,11 +100,9 @@ def render(vertices, triangles, normals, diffuse_colors, camera_position, camera
             pieces.append(shininess_coefficients.unsqueeze(2))
     vertex_attributes = torch.cat(pieces, 2)
 
-    camera_matrices = camera_utils.look_at(camera_position.to(device), camera_lookat.to(device),
-                                           camera_up.to(device))
-    perspective_transforms = camera_utils.perspective(image_width / image_height, fov_y,
-                                                      near_clip, far_clip)
-    clip_space_transforms = torch.matmul(perspective_transforms, camera_matrices)
+    clip_space_transforms = camera_utils.clip_space_transforms(
+        camera_position, camera_lookat, camera_up, fov_y, near_clip, far_clip,
+        image_width / image_height, device)
 
     # background -1 marks uncovered pixels: a real diffuse colour is never negative
     background = torch.full((vertex_attributes.shape[2],), -1.0, device=device)
@@ -147,11 +145,9 @@ def _render_fused(vertices, triangles, normals, diffuse_colors, camera_position,
                   ambient_color, fov_y, near_clip, far_clip):
     from .rasterize_triangles_ext import FusedPhongRenderer
     device = vertices.device
-    camera_matrices = camera_utils.look_at(camera_position.to(device), camera_lookat.to(device),
-                                           camera_up.to(device))
-    perspective_transforms = camera_utils.perspective(image_width / image_height, fov_y,
-                                                      near_clip, far_clip)
-    clip_space_transforms = torch.matmul(perspective_transforms, camera_matrices)
+    clip_space_transforms = camera_utils.clip_space_transforms(
+        camera_position, camera_lookat, camera_up, fov_y, near_clip, far_clip,
+        image_width / image_height, device)
     clip = camera_utils.transform_homogeneous(clip_space_transforms, vertices)
     return FusedPhongRenderer.apply(
         clip, vertices, normals, diffuse_colors, triangles, light_positions.to(device),

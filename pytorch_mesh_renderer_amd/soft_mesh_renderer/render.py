@@ -49,15 +49,13 @@ def render(vertices, triangles, diffuse_colors, camera_position, camera_lookat, 
         camera_up = camera_up.unsqueeze(0).repeat(batch_size, 1)
     elif list(camera_up.shape) != [batch_size, 3]:
         raise ValueError("camera_up must have shape [batch_size, 3] or [3].")
-    fov_y = _per_batch(fov_y, batch_size, device, "fov_y")
-    near_clip = _per_batch(near_clip, batch_size, device, "near_clip")
-    far_clip = _per_batch(far_clip, batch_size, device, "far_clip")
+    fov_y = _per_batch(fov_y, batch_size, camera_position.device, "fov_y")
+    near_clip = _per_batch(near_clip, batch_size, camera_position.device, "near_clip")
+    far_clip = _per_batch(far_clip, batch_size, camera_position.device, "far_clip")
 
-    camera_matrices = camera_utils.look_at(camera_position.to(device), camera_lookat.to(device),
-                                           camera_up.to(device))
-    perspective_transforms = camera_utils.perspective(image_width / image_height, fov_y,
-                                                      near_clip, far_clip)
-    clip_space_transforms = torch.matmul(perspective_transforms, camera_matrices)
+    clip_space_transforms = camera_utils.clip_space_transforms(
+        camera_position, camera_lookat, camera_up, fov_y, near_clip, far_clip,
+        image_width / image_height, device)
     normals = meshes.compute_vertex_normals(vertices, triangles)
     # NB: like the reference (render.py:150-165), blur_radius is accepted but not forwarded.
     return rasterize(vertices, triangles, normals, diffuse_colors, light_positions.to(device),
