@@ -167,6 +167,15 @@ int mr_soft_backward(const float *drgba, const float *rgba, const float *aux,
                      float *dlight_positions, float *dlight_intensities,
                      void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- mean-absolute-error image loss --------------------------------------------------
+ * The loss the reference's optimisation tests and examples use,
+ * torch.mean(torch.abs(render - target)) (src/mesh_renderer/mesh_renderer_test.py:250),
+ * as one streaming pass each way.  a, b: n floats (16-byte aligned); loss: 1 float out;
+ * upstream: 1 float (dL/dloss, read on the device); da: n floats out = upstream*sign(a-b)/n. */
+int mr_l1_loss_forward(const float *a, const float *b, size_t n, float *loss, void *stream);
+int mr_l1_loss_backward(const float *a, const float *b, size_t n, const float *upstream,
+                        float *da, void *stream);
+
 /* ---- tuning hooks (no reference counterpart; results never change) ----------
  * Pixel tile walked by one wavefront in the forward raster kernel:
  * 0 = 8x8 (default), 1 = 16x4, 2 = 32x2. */

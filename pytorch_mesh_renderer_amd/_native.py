@@ -84,6 +84,10 @@ def lib():
         L.mr_soft_forward.restype = ci
         L.mr_soft_backward.argtypes = [vp] * 10 + [ci] * 6 + [cf] * 3 + [vp] * 6 + [vp, sz, vp]
         L.mr_soft_backward.restype = ci
+        L.mr_l1_loss_forward.argtypes = [vp, vp, sz, vp, vp]
+        L.mr_l1_loss_forward.restype = ci
+        L.mr_l1_loss_backward.argtypes = [vp, vp, sz, vp, vp, vp]
+        L.mr_l1_loss_backward.restype = ci
         _lib = L
     return _lib
 
@@ -323,3 +327,25 @@ def soft_backward(drgba, rgba, aux, clip, positions, normals, diffuse, triangles
                                 _ptr(dli), _ptr(ws), have, _stream(dev))
     _check(rc, "mr_soft_backward")
     return dclip, dp, dn, dd, dlp, dli
+
+
+def l1_loss_forward(a, b):
+    """mean |a - b| over all elements -> 0-D tensor (device)."""
+    dev = _require_device(a, b)
+    a, b = a.contiguous(), b.contiguous()
+    out = torch.empty((), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib().mr_l1_loss_forward(_ptr(a), _ptr(b), a.numel(), _ptr(out), _stream(dev))
+    _check(rc, "mr_l1_loss_forward")
+    return out
+
+
+def l1_loss_backward(a, b, upstream):
+    dev = _require_device(a, b, upstream)
+    a, b = a.contiguous(), b.contiguous()
+    da = torch.empty_like(a)
+    with torch.cuda.device(dev):
+        rc = lib().mr_l1_loss_backward(_ptr(a), _ptr(b), a.numel(), _ptr(upstream.contiguous()), _ptr(da),
+                                       _stream(dev))
+    _check(rc, "mr_l1_loss_backward")
+    return da

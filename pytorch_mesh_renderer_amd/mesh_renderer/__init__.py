@@ -1,6 +1,7 @@
 """Same export surface as the reference's src/mesh_renderer/__init__.py:1-5."""
 from .render import render, tone_mapper
 from .rasterize import rasterize
+from . import losses
 
 __version__ = '0.0.1'
 name = 'mesh_renderer'

@@ -1,0 +1,35 @@
+"""Image losses used with the renderer.
+
+The reference has no loss module; its tests and examples spell the loss out as
+`torch.mean(torch.abs(render - target))` (src/mesh_renderer/mesh_renderer_test.py:250,
+src/examples/example5.py:70-92).  In eager torch that is five passes over the image; this is
+the same quantity as one HIP pass forward and one backward.
+"""
+import torch
+
+from .. import _native
+
+
+class _MeanAbsError(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, image, target):
+        a, b = image.detach(), target.detach()
+        ctx.save_for_backward(a, b)
+        return _native.l1_loss_forward(a, b)
+
+    @staticmethod
+    def backward(ctx, grad):
+        a, b = ctx.saved_tensors
+        da = _native.l1_loss_backward(a, b, grad.to(torch.float32).reshape(1))
+        db = -da if ctx.needs_input_grad[1] else None
+        return da, db
+
+
+def l1_loss(image, target):
+    """mean(|image - target|) over every element; same value and gradients as
+    torch.mean(torch.abs(image - target)) (sign(0) = 0)."""
+    if image.shape != target.shape:
+        raise ValueError("image and target must have the same shape")
+    if image.dtype != torch.float32 or target.dtype != torch.float32:
+        raise ValueError("l1_loss expects float32 tensors")
+    return _MeanAbsError.apply(image, target)
