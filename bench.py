@@ -9,8 +9,8 @@ transform, G-buffer rasterization, attribute interpolation, Phong shading), the 
 image loss mean|image - target| against a fixed target, and backward to the world-space vertex
 positions.  All inputs are resident in HBM before the timed region starts.  With N
 ranks every rank renders its own 32 jobs (weak scaling; no data-path collective) and
-the finished images are exchanged with one RCCL all-gather that overlaps the
-backward.  Rank 0 prints ONE JSON line.
+the finished images are handed over to rank 0 with one RCCL gather per step that
+overlaps the loss, the backward and the next forward.  Rank 0 prints ONE JSON line.
 
 Extra objects in the line:
   roofline      the forward G-buffer kernel (k_raster): algorithmic bytes per launch
@@ -97,11 +97,11 @@ def make_step(job, device, gather):
         vertices.grad = None
         image = forward()
         if gather is not None:
-            gather.start(image)          # side stream: overlaps loss + backward
+            gather.wait()                # the previous step's hand-over (no-op the first time) ...
+            gather.start(image)          # ... then this one, on the side stream: it overlaps the loss,
+                                         # the backward and the next step's forward
         loss = mesh_renderer.losses.l1_loss(image, target)   # mean |image - target|, one HIP pass each way
         loss.backward()
-        if gather is not None:
-            gather.wait()
         return loss
 
     return step, vertices
@@ -155,7 +155,9 @@ def main():
         shift = (rank * 7) % BATCH
         job = {k: (torch.roll(v, shift, 0) if torch.is_tensor(v) and k != "triangles" else v)
                for k, v in job.items()}
-    gather = distributed.ImageGather(BATCH * world) if world > 1 else None
+    # images are handed over to rank 0 (RCCL gather): the root receives its N-1 shards over N-1
+    # xGMI links at once; an all-gather would move N times the bytes for nothing
+    gather = distributed.ImageGather(BATCH * world, mode="root") if world > 1 else None
     # ImageGather shards n_total evenly: each rank contributes exactly BATCH images
     step, vertices = make_step(job, device, gather)
 
@@ -172,6 +174,8 @@ def main():
     for i in range(args.steps):
         events.arm(i)
         step()
+    if gather is not None:
+        gather.wait()                    # the last step's hand-over belongs to the timed region
     barrier()
     elapsed = time.perf_counter() - t0
     events.disarm()
@@ -200,7 +204,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[2]: 5k-tri UV sphere (V=%d, T=%d), %dx%d, batch=%d per GPU, "
                                    "mesh_renderer.render forward + L1 loss + backward to vertex positions; "
-                                   "image all-gather over RCCL when n_gpus>1" % (V, T, WIDTH, HEIGHT, BATCH),
+                                   "image gather to rank 0 over RCCL when n_gpus>1" % (V, T, WIDTH, HEIGHT, BATCH),
                        "global_batch": BATCH * world, "image": [HEIGHT, WIDTH], "triangles": T},
             "roofline": {"bound": "hbm", "kernel": "k_raster (forward G-buffer write)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -59,15 +59,24 @@ def shard_batch(tensors, rank, world_size):
 
 
 class ImageGather:
-    """All-gather of per-rank image shards, overlappable with the backward pass.
+    """Hand-over of per-rank image shards, overlappable with the backward pass.
 
     start(local) enqueues the collective on a side stream (GPU) and returns at once;
     wait() makes the current stream wait for it and returns the [B_total, H, W, C]
-    tensor.  Shards may be uneven (they are padded to the largest one)."""
+    tensor (mode "all": on every rank; mode "root": on rank `dst`, None elsewhere).
+    Shards may be uneven (they are padded to the largest one).
 
-    def __init__(self, n_total, group=None, force_collective=False):
+    mode "all"  = all_gather: every rank ends up with every image.
+    mode "root" = gather to one rank (RCCL point-to-point under the hood): on a fully
+                  connected xGMI node the root receives its N-1 shards over N-1 different
+                  links at once, the other ranks only send -- 1/N of the all-gather's traffic."""
+
+    def __init__(self, n_total, group=None, force_collective=False, mode="all", dst=0):
         """force_collective: run the collective even in a 1-rank group (smoke tests of the
         RCCL / side-stream path on a single GPU)."""
+        if mode not in ("all", "root"):
+            raise ValueError("mode must be 'all' or 'root'")
+        self.mode, self.dst = mode, dst
         self.group = group
         self.force = bool(force_collective) and dist.is_initialized()
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -102,6 +111,17 @@ class ImageGather:
             send = send.contiguous()
             if on_gpu:
                 send.record_stream(self._side)
+            self._max_count = max_count
+            if self.mode == "root":
+                gathered = None
+                if self.rank == self.dst:
+                    gathered = torch.empty((self.world * max_count,) + tuple(send.shape[1:]),
+                                           dtype=send.dtype, device=send.device)
+                dist.gather(send, list(gathered.chunk(self.world, 0)) if gathered is not None else None,
+                            dst=self.dst, group=self.group)
+                self._keep = send          # the send buffer must outlive the collective
+                self._out = gathered
+                return
             gathered = torch.empty((self.world * max_count,) + tuple(send.shape[1:]),
                                    dtype=send.dtype, device=send.device)
             if dist.get_backend(self.group) == "gloo":
@@ -110,13 +130,14 @@ class ImageGather:
             else:
                 dist.all_gather_into_tensor(gathered, send, group=self.group)
             self._out = gathered
-            self._max_count = max_count
 
     def wait(self):
         if self.world == 1 and not self.force:
             return self._out
         if self._side is not None:
-            torch.cuda.current_stream(self._out.device).wait_stream(self._side)
+            torch.cuda.current_stream().wait_stream(self._side)
+        if self._out is None:              # mode "root" on a non-root rank
+            return None
         if all(c == self._max_count for c in self.counts):
             return self._out
         pieces = [self._out[r * self._max_count: r * self._max_count + c]

@@ -29,6 +29,30 @@ def _oracle_render(shard, width, height):
     return torch.from_numpy(np.concatenate([bary, z[..., None]], -1))  # [B_local,H,W,4]
 
 
+def _root_worker(rank, world, port, n_total, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    distributed.init_from_env(backend="gloo")
+    job = synthetic.sphere_job(n_total, 24, 20, 6)
+    shard = distributed.shard_batch(job, rank, world)
+    handle = distributed.ImageGather(n_total, mode="root", dst=0)
+    for _ in range(2):                       # two steps, waiting one step late like bench.py
+        handle.wait() if handle._out is not None or handle._side is not None else None
+        handle.start(_oracle_render(shard, 24, 20))
+    full = handle.wait()
+    assert (full is not None) == (rank == 0)
+    if rank == 0:
+        torch.save(full, os.path.join(out_dir, "root.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_to_root_world2(tmp_path):
+    mp.spawn(_root_worker, args=(2, _free_port(), 5, str(tmp_path)), nprocs=2, join=True)
+    job = synthetic.sphere_job(5, 24, 20, 6)
+    assert torch.equal(torch.load(os.path.join(str(tmp_path), "root.pt")), _oracle_render(job, 24, 20))
+
+
 def _worker(rank, world, port, n_total, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
                       WORLD_SIZE=str(world), LOCAL_RANK=str(rank))

@@ -289,6 +289,12 @@ def test_rccl_image_gather_single_rank(device):
         y = (x * 2).sum()            # work on the main stream while the gather runs
         out = g.wait()
         assert torch.equal(out, x) and float(y) > 0
+        r = distributed.ImageGather(3, force_collective=True, mode="root")   # what bench.py uses
+        r.wait()                      # nothing pending yet: must be a no-op
+        r.start(x)
+        r.wait()
+        r.start(x + 1.0)              # back-to-back hand-overs, waited one step late
+        assert torch.equal(r.wait(), x + 1.0)
         grad = torch.ones(5, 3, device=device)
         assert torch.equal(distributed.allreduce_shared_mesh_grad(grad.clone()), grad)
     finally:
