@@ -176,9 +176,12 @@ int mr_l1_loss_forward(const float *a, const float *b, size_t n, float *loss, vo
 int mr_l1_loss_backward(const float *a, const float *b, size_t n, const float *upstream,
                         float *da, void *stream);
 
-/* ---- tuning hooks (no reference counterpart; results never change) ----------
- * Pixel tile walked by one wavefront in the forward raster kernel:
- * 0 = 8x8 (default), 1 = 16x4, 2 = 32x2. */
+/* ---- stage-timing probe (no reference counterpart) -----------------------------
+ * 0 = normal operation (default).  3, 4, 5, 10, 18, 34, 42 switch stages of the forward
+ * raster kernel off so that tools/raster_bench.py can time the rest: 3 = bin only,
+ * 4 = empty tile walk + stores, 5 = bin + tile masks, 10 = no depth loop, 18 = no
+ * coverage loop, 34 = no stores, 42 = no depth loop and no stores.  The G-buffer is
+ * UNDEFINED while a probe is selected; any other value returns MR_EINVAL. */
 int mr_set_raster_tile_shape(int shape);
 
 /* ---- measurement hook -------------------------------------------------------

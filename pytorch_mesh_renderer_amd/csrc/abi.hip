@@ -29,10 +29,13 @@ int mr_version(void) { return 100; /* 0.1.0 */ }
 
 int mr_last_hip_error(void) { return mr::g_last_hip_error; }
 
-// Tuning hook (not part of the reference surface): 0 = 8x8, 1 = 16x4, 2 = 32x2
-// pixel tile per wavefront in the forward raster kernel.  Results are identical.
+// Measurement hook (not part of the reference surface): 0 = normal operation; the other
+// accepted values switch stages of k_raster off for timing and leave the outputs undefined.
 int mr_set_raster_tile_shape(int shape) {
-  if (shape < 0 || shape > 18) return MR_EINVAL;
+  static const int kProbes[] = {0, 3, 4, 5, 10, 18, 34, 42};
+  bool ok = false;
+  for (int v : kProbes) ok |= (v == shape);
+  if (!ok) return MR_EINVAL;
   mr::g_raster_tile_shape = shape;
   return MR_OK;
 }

@@ -45,7 +45,6 @@ namespace {
 
 constexpr int kRegionW = 64;   // pixels per workgroup region
 constexpr int kRegionH = 64;
-constexpr int kBinCap = 1024;  // LDS bin capacity (triangles per pass)
 constexpr int kThreads = 256;
 
 // x86 cvttss2si semantics for the reference's static_cast<int> (cpp:21,29):
@@ -125,8 +124,9 @@ __global__ __launch_bounds__(kThreads) void k_setup(
       if (r > l && top > bot) {
         bb = pack_bbox(l, r, bot, top);
         TriRec rec;
-        rec.a = make_float4(m0, m1, m2, m3);
-        rec.b = make_float4(m4, m5, m6, m7);
+        // edge i = (m[3i], m[3i+1], m[3i+2]); edges 0 and 1 interleaved for packed fp32 math
+        rec.a = make_float4(m0, m3, m1, m4);
+        rec.b = make_float4(m2, m5, m6, m7);
         rec.c = make_float4(m8, p0.z, p1.z, p2.z);
         rec.d = make_float4(w0, w1, w2, 0.0f);
         recs[gid] = rec;
@@ -199,171 +199,8 @@ struct PixelState {
   int id;
 };
 
-// One candidate triangle against one pixel: exactly the body of cpp:376-409.
-// m*, z*, w* are wave-uniform (SGPR) values; px, py, st are per lane.
-__device__ __forceinline__ void shade_candidate(
-    const float m0, const float m1, const float m2, const float m3, const float m4,
-    const float m5, const float m6, const float m7, const float m8, const float z0,
-    const float z1, const float z2, const float w0, const float w1, const float w2,
-    const int tri, const bool in_bbox, const float px, const float py, PixelState &st) {
-  const float e0 = (m0 * px + m1 * py) + m2;  // cpp:46
-  const float e1 = (m3 * px + m4 * py) + m5;
-  const float e2 = (m6 * px + m7 * py) + m8;
-  const float s = (e0 + e1) + e2;  // cpp:384
-  // cpp:96-97.  With all three >= 0 (hence no NaN), "some edge > 0" is the same
-  // predicate as s > 0: a sum of non-negative floats is zero only if all are.
-  const bool inside = in_bbox && (e0 >= 0.0f) && (e1 >= 0.0f) && (e2 >= 0.0f) && (s > 0.0f);
-  if (inside) {
-    const float b0 = e0 / s, b1 = e1 / s, b2 = e2 / s;  // cpp:385-387
-    const float cz = (b0 * z0 + b1 * z1) + b2 * z2;     // cpp:395
-    const float cw = (b0 * w0 + b1 * w1) + b2 * w2;     // cpp:396
-    const float zz = cz / cw;                           // cpp:397
-    if (!(zz < -1.0f || zz > 1.0f || zz > st.z)) {      // cpp:401
-      st.z = zz;
-      st.id = tri;
-      st.b0 = b0;
-      st.b1 = b1;
-      st.b2 = b2;
-    }
-  }
-}
-
-// First-generation kernel (kept for A/B runs through mr_set_raster_variant): candidates are
-// walked wave-uniformly with scalar record loads and a divergent accept branch.
-// TW x TH = 64: pixel tile walked by one wavefront, one pixel per lane.
-template <int TW, int TH>
-__global__ __launch_bounds__(kThreads) void k_raster_v1(
-    const TriRec *__restrict__ recs, const uint2 *__restrict__ bbs,
-    const float *__restrict__ pxtab, const float *__restrict__ pytab, int T, int W, int H,
-    int regions_x, int regions_per_image, int n_regions, int regions_per_xcd,
-    int32_t *__restrict__ ids, float *__restrict__ bary, float *__restrict__ zbuf) {
-  static_assert(TW * TH == kWave, "one pixel per lane");
-  static_assert(kRegionW % TW == 0 && kRegionH % TH == 0, "tiles must pave the region");
-  __shared__ int s_tri[kBinCap];
-  __shared__ uint2 s_bb[kBinCap];
-  __shared__ int s_wave_count[kThreads / kWave];
-
-  const int region = xcd_contiguous_block((int)blockIdx.x, n_regions, regions_per_xcd);
-  if (region < 0) return;  // padding block (whole workgroup)
-  const int img = region / regions_per_image;
-  const int rr = region - img * regions_per_image;
-  const int ry = rr / regions_x;
-  const int rx = rr - ry * regions_x;
-  const int X0 = rx * kRegionW, Y0 = ry * kRegionH;
-  const int X1 = min(X0 + kRegionW, W), Y1 = min(Y0 + kRegionH, H);
-
-  const int tid = (int)threadIdx.x;
-  const int lane = tid & (kWave - 1);
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const TriRec *img_recs = recs + (size_t)img * T;
-  const uint2 *img_bbs = bbs + (size_t)img * T;
-  const size_t img_px = (size_t)img * H * W;
-
-  int n_bin = 0;        // workgroup-uniform
-  bool first_pass = true;
-
-  // Rasterize every tile of the region against the current LDS bin.
-  auto raster_pass = [&](const int n, const bool fresh) {
-    constexpr int kTilesX = kRegionW / TW, kTilesY = kRegionH / TH;
-    for (int tile = wave; tile < kTilesX * kTilesY; tile += kThreads / kWave) {
-      const int ty = tile / kTilesX, tx = tile - ty * kTilesX;
-      const int x0 = X0 + tx * TW, y0 = Y0 + ty * TH;
-      if (x0 >= X1 || y0 >= Y1) continue;  // wave-uniform
-      const int x1 = min(x0 + TW, X1), y1 = min(y0 + TH, Y1);
-      const int ix = x0 + (lane % TW), iy = y0 + (lane / TW);
-      const bool in_image = ix < W && iy < H;
-      const size_t pix = img_px + (size_t)iy * W + ix;
-      const float px = pxtab[min(ix, W - 1)];
-      const float py = pytab[min(iy, H - 1)];
-      PixelState st;
-      if (fresh) {
-        st.z = 1.0f; st.b0 = 0.0f; st.b1 = 0.0f; st.b2 = 0.0f; st.id = 0;  // cpp:313-321
-      } else if (in_image) {
-        // bin overflowed earlier: resume from what this very lane stored
-        st.z = zbuf[pix]; st.id = ids[pix];
-        st.b0 = bary[3 * pix]; st.b1 = bary[3 * pix + 1]; st.b2 = bary[3 * pix + 2];
-      }
-      for (int base = 0; base < n; base += kWave) {
-        const int k = base + lane;
-        bool hit = false;
-        int my_tri = 0;
-        uint2 my_bb = make_uint2(0u, 0u);
-        if (k < n) {
-          my_tri = s_tri[k];
-          my_bb = s_bb[k];
-          const int l = (int)(my_bb.x & 0xffffu), r = (int)(my_bb.x >> 16);
-          const int bt = (int)(my_bb.y & 0xffffu), tp = (int)(my_bb.y >> 16);
-          hit = (l < x1) && (r > x0) && (bt < y1) && (tp > y0);
-        }
-        unsigned long long todo = __ballot(hit);
-        while (todo) {  // ascending lane == ascending triangle id
-          const int j = __builtin_ctzll(todo);
-          todo &= todo - 1;
-          const int tri = __builtin_amdgcn_readlane(my_tri, j);
-          const unsigned bbx = (unsigned)__builtin_amdgcn_readlane((int)my_bb.x, j);
-          const unsigned bby = (unsigned)__builtin_amdgcn_readlane((int)my_bb.y, j);
-          const int l = (int)(bbx & 0xffffu), wdt = (int)(bbx >> 16) - l;
-          const int bt = (int)(bby & 0xffffu), hgt = (int)(bby >> 16) - bt;
-          const bool in_bbox =
-              ((unsigned)(ix - l) < (unsigned)wdt) && ((unsigned)(iy - bt) < (unsigned)hgt);
-          const TriRec *rp = img_recs + tri;  // wave-uniform address -> scalar loads
-          const float4 ra = rp->a, rb = rp->b, rc = rp->c, rd = rp->d;
-          shade_candidate(ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w, rc.x, rc.y, rc.z,
-                          rc.w, rd.x, rd.y, rd.z, tri, in_bbox, px, py, st);
-        }
-      }
-      if (in_image) {
-        ids[pix] = st.id;
-        zbuf[pix] = st.z;
-        bary[3 * pix + 0] = st.b0;
-        bary[3 * pix + 1] = st.b1;
-        bary[3 * pix + 2] = st.b2;
-      }
-    }
-  };
-
-  // Bin the image's triangles against this region, 256 at a time, keeping id order.
-  for (int base = 0; base < T; base += kThreads) {
-    const int t = base + tid;
-    bool hit = false;
-    uint2 bb = make_uint2(0u, 0u);
-    if (t < T) {
-      bb = img_bbs[t];
-      const int l = (int)(bb.x & 0xffffu), r = (int)(bb.x >> 16);
-      const int bt = (int)(bb.y & 0xffffu), tp = (int)(bb.y >> 16);
-      hit = (l < X1) && (r > X0) && (bt < Y1) && (tp > Y0);  // empty bbox = all zeros
-    }
-    const unsigned long long m = __ballot(hit);
-    if (lane == 0) s_wave_count[wave] = __builtin_popcountll(m);
-    __syncthreads();
-    int offset = n_bin, total = 0;
-#pragma unroll
-    for (int w = 0; w < kThreads / kWave; ++w) {
-      const int c = s_wave_count[w];
-      if (w < wave) offset += c;
-      total += c;
-    }
-    if (hit) {
-      const int pos = offset + (int)__builtin_amdgcn_mbcnt_hi(
-                                   (unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-      s_tri[pos] = t;
-      s_bb[pos] = bb;
-    }
-    n_bin += total;
-    __syncthreads();
-    if (n_bin + kThreads > kBinCap && base + kThreads < T) {
-      // bin (nearly) full with triangles still to come: flush it
-      raster_pass(n_bin, first_pass);
-      first_pass = false;
-      n_bin = 0;
-      __syncthreads();  // tiles done reading the bin; also orders the state stores
-    }
-  }
-  raster_pass(n_bin, first_pass);
-}
-
 // ---------------------------------------------------------------------------------------
-// Second-generation kernel: LDS bin of full records, coverage / depth split.
+// The raster kernel: LDS bin of full records, coverage / depth split.
 // ---------------------------------------------------------------------------------------
 constexpr int kEntryDw = 20;   // LDS entry: 20 dwords = 80 B (see file header)
 constexpr int kSubCap = 64;    // entries one wavefront may add per round
@@ -371,14 +208,28 @@ constexpr int kWaves = kThreads / kWave;
 constexpr int kBin2Cap = kSubCap * kWaves;
 static_assert(kSubCap >= kWave, "a 64-triangle chunk must always fit an empty sub-bin (progress)");
 
-// Entry layout (dwords): 0-8 m[9] | 9-11 z0 z1 z2 | 12-14 w0 w1 w2 | 15 id | 16 bbx | 17 bby
+// Entry layout (dwords): 0-3 a0 a1 b0 b1 | 4-7 c0 c1 a2 b2 | 8 c2 | 9-11 z0 z1 z2 | 12-14 w0 w1 w2 |
+// 15 id | 16 bbox clipped to the region, region-relative: l | bottom << 16 | 17 (w-1) | (h-1) << 16 |
+// 18-19 scratch
+// where edge_i(px, py) = (a_i * px + b_i * py) + c_i  (cpp:46).
 struct Entry {
   float4 q0, q1, q2, q3;
   uint2 bb;
 };
 
+typedef float v2f __attribute__((ext_vector_type(2)));  // packed fp32 (v_pk_mul_f32 / v_pk_add_f32)
+typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pk_sub_u16(unsigned a, unsigned b) {  // per-half a - b, wrapping
+  return __builtin_bit_cast(unsigned, __builtin_bit_cast(v2u16, a) - __builtin_bit_cast(v2u16, b));
+}
+__device__ __forceinline__ unsigned pk_min_u16(unsigned a, unsigned b) {
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(v2u16, a),
+                                                                __builtin_bit_cast(v2u16, b)));
+}
+
 __device__ __forceinline__ Entry read_entry(const float *s_ent, int e) {
-  const float *p = s_ent + e * kEntryDw;
+  const float *p = s_ent + __mul24(e, kEntryDw);
   Entry r;
   r.q0 = *(const float4 *)(p);
   r.q1 = *(const float4 *)(p + 4);
@@ -404,12 +255,15 @@ __device__ __forceinline__ bool rect_outside_edge(float a, float b, float c, flo
 __device__ __forceinline__ bool rect_outside_triangle(const float4 q0, const float4 q1, const float m8,
                                                       float pxlo, float pxhi, float pylo, float pyhi) {
   // bitwise |: all three edges are evaluated straight-line (no dependent branches)
-  return (int)rect_outside_edge(q0.x, q0.y, q0.z, pxlo, pxhi, pylo, pyhi) |
-         (int)rect_outside_edge(q0.w, q1.x, q1.y, pxlo, pxhi, pylo, pyhi) |
+  return (int)rect_outside_edge(q0.x, q0.z, q1.x, pxlo, pxhi, pylo, pyhi) |
+         (int)rect_outside_edge(q0.y, q0.w, q1.y, pxlo, pxhi, pylo, pyhi) |
          (int)rect_outside_edge(q1.z, q1.w, m8, pxlo, pxhi, pylo, pyhi);
 }
 
-__global__ __launch_bounds__(kThreads, 7) void k_raster(
+#ifndef MR_RASTER_WAVES
+#define MR_RASTER_WAVES 6  // register-allocation hint; 6 yields <= 72 VGPRs = 7 waves per SIMD
+#endif
+__global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
     const TriRec *__restrict__ recs, const uint2 *__restrict__ bbs,
     const float *__restrict__ pxtab, const float *__restrict__ pytab, int T, int W, int H,
     int regions_x, int regions_per_image, int n_regions, int regions_per_xcd,
@@ -419,12 +273,16 @@ __global__ __launch_bounds__(kThreads, 7) void k_raster(
   constexpr int kTiles = (kRegionW / 8) * (kRegionH / 8);  // 64 tiles of 8x8 pixels
   constexpr int kMaskWords = kBin2Cap / 32;
   __shared__ __attribute__((aligned(16))) float s_ent[kBin2Cap * kEntryDw];
-  __shared__ unsigned s_tmask[kTiles][kMaskWords];  // per tile: which bin entries touch it
-  __shared__ float s_ext[4][8];                     // tile column / row pixel-centre extents
-  __shared__ float s_pxy[2][kRegionW];              // pixel centres of the region's columns / rows
-  __shared__ int s_count[kWaves], s_stop[kWaves], s_wave_total[kWaves];
+  // LDS budget: 20480 (entries) + 2048 (masks / bin bookkeeping) + 512 (pixel centres) = 23040 B
+  // = 18 allocation granules of 1280 B, so that SEVEN workgroups fit the 160 KB of a CU.  The
+  // bin-stage bookkeeping is dead by the time the tile masks are built and shares their storage.
+  __shared__ unsigned s_shared[kTiles * kMaskWords];
+  unsigned (*s_tmask)[kMaskWords] = (unsigned (*)[kMaskWords])s_shared;  // per tile: entries touching it
   constexpr int kRoundChunks = kThreads;  // chunks of 64 triangles scanned per round
-  __shared__ int s_chunk_count[kRoundChunks];
+  int *s_chunk_count = (int *)s_shared;   // [kRoundChunks]
+  int *s_count = s_chunk_count + kRoundChunks, *s_stop = s_count + kWaves, *s_wave_total = s_stop + kWaves;
+  static_assert(kRoundChunks + 3 * kWaves <= kTiles * kMaskWords, "bookkeeping must fit the mask storage");
+  __shared__ float s_pxy[2][kRegionW];  // pixel centres of the region's columns / rows
 
   const int region = xcd_contiguous_block((int)blockIdx.x, n_regions, regions_per_xcd);
   if (region < 0) return;  // padding block (whole workgroup)
@@ -460,32 +318,25 @@ __global__ __launch_bounds__(kThreads, 7) void k_raster(
   // trivial reject against each; survivors set their bit in the tile's 256-bit mask.  This
   // costs ~(entries x tiles-per-entry) lane-tests per region instead of (tiles x entries).
   auto build_tile_masks = [&](const int n) {
-    for (int i = tid; i < kTiles * kMaskWords; i += kThreads) (&s_tmask[0][0])[i] = 0u;
-    if (tid < 8) {  // pixel-centre extents of the 8 tile columns / rows of this region
-      const int cx0 = tid * 8, cx1 = min(tid * 8 + 7, X1 - 1 - X0);
-      const int cy0 = tid * 8, cy1 = min(tid * 8 + 7, Y1 - 1 - Y0);
-      s_ext[0][tid] = s_pxy[0][cx0];
-      s_ext[1][tid] = s_pxy[0][max(cx1, cx0)];
-      s_ext[2][tid] = s_pxy[1][cy0];
-      s_ext[3][tid] = s_pxy[1][max(cy1, cy0)];
-    }
+    for (int i = tid; i < kTiles * kMaskWords; i += kThreads) s_shared[i] = 0u;
+    // pixel-centre extents of tile column / row t: s_pxy[.][8 t] .. s_pxy[.][min(8 t + 7, last)]
+    const int last_x = X1 - 1 - X0, last_y = Y1 - 1 - Y0;
     __syncthreads();
     if (tid < n) {
       const float *p = s_ent + tid * kEntryDw;
-      const uint2 bb = *(const uint2 *)(p + 16);
+      const uint2 box = *(const uint2 *)(p + 16);
       const float4 q0 = *(const float4 *)(p), q1 = *(const float4 *)(p + 4);
       const float m8 = p[8];
-      const int l = (int)(bb.x & 0xffffu), r = (int)(bb.x >> 16);
-      const int bt = (int)(bb.y & 0xffffu), tp = (int)(bb.y >> 16);
-      // tile range under the bbox, clipped to the region (the bin stage guarantees overlap)
-      const int tx0 = (max(l, X0) - X0) >> 3, tx1 = (min(r, X1) - 1 - X0) >> 3;
-      const int ty0 = (max(bt, Y0) - Y0) >> 3, ty1 = (min(tp, Y1) - 1 - Y0) >> 3;
+      // tile range under the bbox (already clipped to the region; never empty)
+      const int bl = (int)(box.x & 0xffffu), bb = (int)(box.x >> 16);
+      const int tx0 = bl >> 3, tx1 = (bl + (int)(box.y & 0xffffu)) >> 3;
+      const int ty0 = bb >> 3, ty1 = (bb + (int)(box.y >> 16)) >> 3;
       const unsigned bit = 1u << (tid & 31);
       const int word = tid >> 5;
       for (int ty = ty0; ty <= ty1; ++ty) {
-        const float ylo = s_ext[2][ty], yhi = s_ext[3][ty];
+        const float ylo = s_pxy[1][ty * 8], yhi = s_pxy[1][min(ty * 8 + 7, last_y)];
         for (int tx = tx0; tx <= tx1; ++tx) {
-          if (!rect_outside_triangle(q0, q1, m8, s_ext[0][tx], s_ext[1][tx], ylo, yhi))
+          if (!rect_outside_triangle(q0, q1, m8, s_pxy[0][tx * 8], s_pxy[0][min(tx * 8 + 7, last_x)], ylo, yhi))
             atomicOr(&s_tmask[ty * 8 + tx][word], bit);
         }
       }
@@ -505,6 +356,9 @@ __global__ __launch_bounds__(kThreads, 7) void k_raster(
       const size_t pix = img_px + (size_t)iy * W + ix;
       const float px = s_pxy[0][tx * 8 + (lane & 7)];
       const float py = s_pxy[1][ty * 8 + (lane >> 3)];
+      const v2f px2 = {px, px}, py2 = {py, py};
+      // region-relative pixel coordinates of this lane, packed (x | y << 16)
+      const unsigned lane_xy = (unsigned)(tx * 8 + (lane & 7)) | ((unsigned)(ty * 8 + (lane >> 3)) << 16);
       PixelState st;
       if (fresh) {
         st.z = 1.0f; st.b0 = 0.0f; st.b1 = 0.0f; st.b2 = 0.0f; st.id = 0;  // cpp:313-321
@@ -525,20 +379,21 @@ __global__ __launch_bounds__(kThreads, 7) void k_raster(
           const float *p = s_ent + (ebase + j) * kEntryDw;  // wave-uniform address
           const float4 q0 = *(const float4 *)(p), q1 = *(const float4 *)(p + 4);
           const float m8 = p[8];
-          const uint2 bb = *(const uint2 *)(p + 16);
-          const unsigned bbx = (unsigned)__builtin_amdgcn_readfirstlane((int)bb.x);
-          const unsigned bby = (unsigned)__builtin_amdgcn_readfirstlane((int)bb.y);
-          const int l = (int)(bbx & 0xffffu), wdt = (int)(bbx >> 16) - l;
-          const int bt = (int)(bby & 0xffffu), hgt = (int)(bby >> 16) - bt;
-          const float e0 = (q0.x * px + q0.y * py) + q0.z;  // cpp:46
-          const float e1 = (q0.w * px + q1.x * py) + q1.y;
-          const float e2 = (q1.z * px + q1.w * py) + m8;
-          const float s = (e0 + e1) + e2;
+          // bbox test, 3 VALU ops and no scalar work: (x - l, y - b) as packed u16 with
+          // wrap-around, then "<= (w - 1, h - 1)" on both halves at once via a packed min.
+          const uint2 box = *(const uint2 *)(p + 16);  // wave-uniform values
+          const unsigned dxy = pk_sub_u16(lane_xy, box.x);
+          const bool in_box = pk_min_u16(dxy, box.y) == dxy;
+          const v2f e01 = (v2f{q0.x, q0.y} * px2 + v2f{q0.z, q0.w} * py2) + v2f{q1.x, q1.y};  // cpp:46
+          float e2 = (q1.z * px + q1.w * py) + m8;
+          asm("" : "+v"(e2));  // keeps the vectoriser from pairing e2 with the sum below
+          const float s = (e01.x + e01.y) + e2;
           // cpp:96-97 (all >= 0 and some > 0  <=>  all >= 0 and s > 0), inside the bbox
-          const bool inside = (int)((unsigned)(ix - l) < (unsigned)wdt) &
-                              (int)((unsigned)(iy - bt) < (unsigned)hgt) & (int)(e0 >= 0.0f) &
-                              (int)(e1 >= 0.0f) & (int)(e2 >= 0.0f) & (int)(s > 0.0f);
-          mine |= inside ? (1u << j) : 0u;  // j is wave-uniform
+          const bool inside = (int)in_box & (int)(e01.x >= 0.0f) &
+                              (int)(e01.y >= 0.0f) & (int)(e2 >= 0.0f) & (int)(s > 0.0f);
+          unsigned with_j = mine | (1u << j);  // j is wave-uniform
+          asm("" : "+v"(with_j));              // v_or + v_cndmask (no v_mov of the bit)
+          mine = inside ? with_j : mine;
         }
         // (2) depth: every lane walks its own candidates in ascending id
         if (debug_skip & 8) { st.id += (int)mine; continue; }  // timing probe: coverage only
@@ -547,8 +402,9 @@ __global__ __launch_bounds__(kThreads, 7) void k_raster(
             const int e = ebase + (__ffs((int)mine) - 1);
             mine &= mine - 1u;
             const Entry t = read_entry(s_ent, e);  // per-lane LDS address
-            const float e0 = (t.q0.x * px + t.q0.y * py) + t.q0.z;  // same bits as in (1)
-            const float e1 = (t.q0.w * px + t.q1.x * py) + t.q1.y;
+            const v2f e01 = (v2f{t.q0.x, t.q0.y} * px2 + v2f{t.q0.z, t.q0.w} * py2) +
+                            v2f{t.q1.x, t.q1.y};                         // same bits as in (1)
+            const float e0 = e01.x, e1 = e01.y;
             const float e2 = (t.q1.z * px + t.q1.w * py) + t.q2.x;
             const float s = (e0 + e1) + e2;                              // cpp:384
             const float b0 = e0 / s, b1 = e1 / s, b2 = e2 / s;           // cpp:385-387
@@ -563,7 +419,7 @@ __global__ __launch_bounds__(kThreads, 7) void k_raster(
           }
         }
       }
-      if (in_image) {
+      if (in_image && !((debug_skip & 32) && st.z != 123.0f)) {  // 32: timing probe, no stores
         ids[pix] = st.id;
         zbuf[pix] = st.z;
         bary[3 * pix + 0] = st.b0;
@@ -633,7 +489,13 @@ __global__ __launch_bounds__(kThreads, 7) void k_raster(
           *(float4 *)(p + 4) = rp->b;
           *(float4 *)(p + 8) = rp->c;
           *(float4 *)(p + 12) = make_float4(q3.x, q3.y, q3.z, __builtin_bit_cast(float, t));
-          *(uint4 *)(p + 16) = make_uint4(bb[u].x, bb[u].y, (unsigned)c, (unsigned)rank);
+          const int l = (int)(bb[u].x & 0xffffu), r = (int)(bb[u].x >> 16);
+          const int bt = (int)(bb[u].y & 0xffffu), tp = (int)(bb[u].y >> 16);
+          // bbox clipped to the region, region-relative: (l | b << 16), (w - 1 | h - 1 << 16)
+          const int cl = max(l, X0), cb = max(bt, Y0);
+          const unsigned rel = (unsigned)(cl - X0) | ((unsigned)(cb - Y0) << 16);
+          const unsigned ext = (unsigned)(min(r, X1) - cl - 1) | ((unsigned)(min(tp, Y1) - cb - 1) << 16);
+          *(uint4 *)(p + 16) = make_uint4(rel, ext, (unsigned)c, (unsigned)rank);
         }
         if (lane == 0) s_chunk_count[c] = cnt;
         count += cnt;
@@ -717,7 +579,7 @@ size_t raster_forward_ws(int B, int V, int T, int W, int H) {
          align_up(cells * T * sizeof(int32_t), 256) + align_up(cells * sizeof(int32_t), 256);
 }
 
-int g_raster_tile_shape = 0;  // 0: two-phase kernel; 1, 2: first-generation kernel, 8x8 / 16x4 tiles
+int g_raster_tile_shape = 0;  // 0: normal; other values: timing probes (see mr_set_raster_tile_shape)
 hipEvent_t g_raster_ev_start = nullptr, g_raster_ev_stop = nullptr;  // mr_set_raster_profile_events
 
 int launch_raster_forward(const float *clip, const int32_t *tris, int B, int V, int T, int W,
@@ -756,14 +618,9 @@ int launch_raster_forward(const float *clip, const int32_t *tris, int B, int V, 
   const int n_regions = per_image * B;
   const int per_xcd = (n_regions + kXcds - 1) / kXcds;
   const dim3 grid((unsigned)(per_xcd * kXcds)), block(kThreads);
-#define MR_LAUNCH_RASTER(KERNEL)                                                         \
-  hipLaunchKernelGGL(KERNEL, grid, block, 0, s, recs, bbs, pxtab, pytab, T, W, H, regions_x, \
-                     per_image, n_regions, per_xcd, ids, bary, z)
   if (g_raster_ev_start) (void)hipEventRecord(g_raster_ev_start, s);
   switch (g_raster_tile_shape) {
-    case 1: MR_LAUNCH_RASTER((k_raster_v1<8, 8>)); break;
-    case 2: MR_LAUNCH_RASTER((k_raster_v1<16, 4>)); break;
-    case 3: case 4: case 5: case 10: case 18:  // timing probes (results are NOT valid)
+    case 3: case 4: case 5: case 10: case 18: case 34: case 42:  // timing probes (results are NOT valid)
       hipLaunchKernelGGL(k_raster, grid, block, 0, s, recs, bbs, pxtab, pytab, T, W, H, regions_x,
                          per_image, n_regions, per_xcd, cell_ids, cell_count, cells_x, cells_per_image,
                          ids, bary, z, g_raster_tile_shape - 2);
@@ -774,7 +631,6 @@ int launch_raster_forward(const float *clip, const int32_t *tris, int B, int V, 
                          ids, bary, z, 0);
       break;
   }
-#undef MR_LAUNCH_RASTER
   if (g_raster_ev_stop) (void)hipEventRecord(g_raster_ev_stop, s);
   return check_launch();
 }

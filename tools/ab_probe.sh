@@ -1,7 +1,10 @@
+# A/B of compile-time variants inside ONE gpurun call (box-to-box noise is ~5 %).
+#   gpurun -- 'bash tools/ab_probe.sh "-DMR_RASTER_WAVES=6" "-DMR_RASTER_WAVES=7"'
 set -e
 cd $GRAFT_REPO_ROOT
-for p in 1 2; do
+for flags in "$@"; do
   make -C pytorch_mesh_renderer_amd/csrc clean >/dev/null
-  make -C pytorch_mesh_renderer_amd/csrc EXTRA=-DMR_PROBE_ROWS=$p >/dev/null 2>&1
-  echo "--- probe $p"; timeout -k 5 120 python tools/shade_bench.py | tail -1
+  make -C pytorch_mesh_renderer_amd/csrc EXTRA="$flags" >/dev/null 2>&1
+  echo "--- $flags"
+  for v in 0 34 42; do timeout -k 5 100 python tools/raster_bench.py --variant $v 2>/dev/null | grep variant; done
 done

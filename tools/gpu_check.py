@@ -24,7 +24,7 @@ def check(name, clip, tris, W, H, time_it=False):
     print(f"{name}: ids={ok_ids} z={ok_z} bary={ok_b} mismatched_ids={(ids.cpu().numpy()!=o_ids).sum()} "
           f"bwd_maxerr={err:.3e} |grad|max={np.abs(o_dclip).max():.3e}", flush=True)
     if time_it:
-        for shape in (0, 1):
+        for shape in (0,):
             _native.lib().mr_set_raster_tile_shape(shape)
             for _ in range(3): _native.rasterize_forward(clip_d, tris_d, W, H)
             torch.cuda.synchronize(); t0 = time.perf_counter()
