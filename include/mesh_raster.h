@@ -171,10 +171,14 @@ int mr_soft_backward(const float *drgba, const float *rgba, const float *aux,
  * The loss the reference's optimisation tests and examples use,
  * torch.mean(torch.abs(render - target)) (src/mesh_renderer/mesh_renderer_test.py:250),
  * as one streaming pass each way.  a, b: n floats (16-byte aligned); loss: 1 float out;
- * upstream: 1 float (dL/dloss, read on the device); da: n floats out = upstream*sign(a-b)/n. */
-int mr_l1_loss_forward(const float *a, const float *b, size_t n, float *loss, void *stream);
-int mr_l1_loss_backward(const float *a, const float *b, size_t n, const float *upstream,
-                        float *da, void *stream);
+ * signs: (n + 3) / 4 bytes out, or NULL when no gradient is wanted -- byte i holds
+ * sign(a - b) of elements 4i .. 4i+3 as 2-bit codes (0: zero, 1: +1, 2: -1), so that the
+ * backward pass does not read the images again; upstream: 1 float (dL/dloss, read on the
+ * device); da: n floats out (16-byte aligned) = upstream * sign(a - b) / n. */
+int mr_l1_loss_forward(const float *a, const float *b, size_t n, float *loss, uint8_t *signs,
+                       void *stream);
+int mr_l1_loss_backward(const uint8_t *signs, size_t n, const float *upstream, float *da,
+                        void *stream);
 
 /* ---- stage-timing probe (no reference counterpart) -----------------------------
  * 0 = normal operation (default).  3, 4, 5, 10, 18, 34, 42 switch stages of the forward

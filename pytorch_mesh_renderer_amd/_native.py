@@ -84,9 +84,9 @@ def lib():
         L.mr_soft_forward.restype = ci
         L.mr_soft_backward.argtypes = [vp] * 10 + [ci] * 6 + [cf] * 3 + [vp] * 6 + [vp, sz, vp]
         L.mr_soft_backward.restype = ci
-        L.mr_l1_loss_forward.argtypes = [vp, vp, sz, vp, vp]
+        L.mr_l1_loss_forward.argtypes = [vp, vp, sz, vp, vp, vp]
         L.mr_l1_loss_forward.restype = ci
-        L.mr_l1_loss_backward.argtypes = [vp, vp, sz, vp, vp, vp]
+        L.mr_l1_loss_backward.argtypes = [vp, sz, vp, vp, vp]
         L.mr_l1_loss_backward.restype = ci
         _lib = L
     return _lib
@@ -329,23 +329,27 @@ def soft_backward(drgba, rgba, aux, clip, positions, normals, diffuse, triangles
     return dclip, dp, dn, dd, dlp, dli
 
 
-def l1_loss_forward(a, b):
-    """mean |a - b| over all elements -> 0-D tensor (device)."""
+def l1_loss_forward(a, b, want_signs=True):
+    """mean |a - b| over all elements -> (0-D tensor, packed signs or None), on the device.
+
+    The signs ((n + 3) // 4 bytes, 2 bits per element) are all the backward pass needs."""
     dev = _require_device(a, b)
     a, b = a.contiguous(), b.contiguous()
     out = torch.empty((), dtype=torch.float32, device=dev)
+    signs = torch.empty((a.numel() + 3) // 4, dtype=torch.uint8, device=dev) if want_signs else None
     with torch.cuda.device(dev):
-        rc = lib().mr_l1_loss_forward(_ptr(a), _ptr(b), a.numel(), _ptr(out), _stream(dev))
+        rc = lib().mr_l1_loss_forward(_ptr(a), _ptr(b), a.numel(), _ptr(out),
+                                      _ptr(signs) if want_signs else None, _stream(dev))
     _check(rc, "mr_l1_loss_forward")
-    return out
+    return out, signs
 
 
-def l1_loss_backward(a, b, upstream):
-    dev = _require_device(a, b, upstream)
-    a, b = a.contiguous(), b.contiguous()
-    da = torch.empty_like(a)
+def l1_loss_backward(signs, shape, upstream):
+    """upstream * sign(a - b) / n as a float32 tensor of `shape`, from the packed signs."""
+    dev = _require_device(signs, upstream)
+    da = torch.empty(shape, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        rc = lib().mr_l1_loss_backward(_ptr(a), _ptr(b), a.numel(), _ptr(upstream.contiguous()), _ptr(da),
+        rc = lib().mr_l1_loss_backward(_ptr(signs), da.numel(), _ptr(upstream.contiguous()), _ptr(da),
                                        _stream(dev))
     _check(rc, "mr_l1_loss_backward")
     return da

@@ -214,17 +214,17 @@ int mr_soft_backward(const float *drgba, const float *rgba, const float *aux, co
                                   dlight_intensities, workspace, (hipStream_t)stream);
 }
 
-int mr_l1_loss_forward(const float *a, const float *b, size_t n, float *loss, void *stream) {
+int mr_l1_loss_forward(const float *a, const float *b, size_t n, float *loss, uint8_t *signs,
+                       void *stream) {
   if (!loss || (n > 0 && (!a || !b))) return MR_EINVAL;
   if ((((uintptr_t)a | (uintptr_t)b) & 15u) != 0) return MR_EINVAL;
-  return mr::launch_l1_forward(a, b, n, loss, (hipStream_t)stream);
+  return mr::launch_l1_forward(a, b, n, loss, signs, (hipStream_t)stream);
 }
 
-int mr_l1_loss_backward(const float *a, const float *b, size_t n, const float *upstream, float *da,
-                        void *stream) {
-  if (n > 0 && (!a || !b || !upstream || !da)) return MR_EINVAL;
-  if ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)da) & 15u) != 0) return MR_EINVAL;
-  return mr::launch_l1_backward(a, b, n, upstream, da, (hipStream_t)stream);
+int mr_l1_loss_backward(const uint8_t *signs, size_t n, const float *upstream, float *da, void *stream) {
+  if (n > 0 && (!signs || !upstream || !da)) return MR_EINVAL;
+  if (((uintptr_t)da & 15u) != 0) return MR_EINVAL;
+  return mr::launch_l1_backward(signs, n, upstream, da, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -4,8 +4,9 @@
 // `torch.mean(torch.abs(render - target))` (src/mesh_renderer/mesh_renderer_test.py:250,
 // src/examples/example5.py:70-92).  In eager torch that is five full passes over the
 // [B,H,W,4] image (sub, abs, mean; sign, mul) -- 1.05 ms at 1024^2 x 32, more than the
-// rasterizer.  Here: one streaming pass forward (reads 2 x 16 B/px), one backward
-// (reads 2 x 16, writes 16 B/px); both HBM-bound, float4 per lane.
+// rasterizer.  Here: one streaming pass forward (reads 2 x 16 B/px, writes 1 B/px: the four
+// signs of a pixel's channels as 2-bit codes) and one backward that never re-reads the images
+// (reads 1 B/px, writes 16 B/px).  Both are HBM-bound; 49 B/px in total instead of 80.
 #include "mr_internal.h"
 
 namespace mr {
@@ -13,17 +14,35 @@ namespace {
 
 constexpr int kThreads = 256;
 
+// 2-bit sign code of d: 0 -> 0, 1 -> +1, 2 -> -1 (NaN -> 0, like (0 < d) - (d < 0)).
+__device__ __forceinline__ unsigned sign_code(float d) { return d > 0.f ? 1u : (d < 0.f ? 2u : 0u); }
+__device__ __forceinline__ float sign_value(unsigned code) {
+  return (code & 1u) ? 1.f : ((code & 2u) ? -1.f : 0.f);
+}
+
 __global__ __launch_bounds__(kThreads) void k_l1_forward(const float4 *__restrict__ a,
                                                          const float4 *__restrict__ b, size_t n4,
                                                          const float *__restrict__ a_tail,
                                                          const float *__restrict__ b_tail, int n_tail,
-                                                         float inv_n, float *__restrict__ out) {
+                                                         float inv_n, float *__restrict__ out,
+                                                         uint8_t *__restrict__ signs) {
   float s = 0.f;
   for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n4; i += (size_t)gridDim.x * kThreads) {
     const float4 x = a[i], y = b[i];
-    s += (fabsf(x.x - y.x) + fabsf(x.y - y.y)) + (fabsf(x.z - y.z) + fabsf(x.w - y.w));
+    const float d0 = x.x - y.x, d1 = x.y - y.y, d2 = x.z - y.z, d3 = x.w - y.w;
+    s += (fabsf(d0) + fabsf(d1)) + (fabsf(d2) + fabsf(d3));
+    if (signs)
+      signs[i] = (uint8_t)(sign_code(d0) | (sign_code(d1) << 2) | (sign_code(d2) << 4) | (sign_code(d3) << 6));
   }
-  if (blockIdx.x == 0 && (int)threadIdx.x < n_tail) s += fabsf(a_tail[threadIdx.x] - b_tail[threadIdx.x]);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && n_tail > 0) {  // the last n % 4 elements
+    unsigned code = 0u;
+    for (int k = 0; k < n_tail; ++k) {
+      const float d = a_tail[k] - b_tail[k];
+      s += fabsf(d);
+      code |= sign_code(d) << (2 * k);
+    }
+    if (signs) signs[n4] = (uint8_t)code;
+  }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
   __shared__ float s_part[kThreads / kWave];
@@ -37,21 +56,18 @@ __global__ __launch_bounds__(kThreads) void k_l1_forward(const float4 *__restric
   }
 }
 
-__device__ __forceinline__ float sgn(float d) { return d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f); }
-
-__global__ __launch_bounds__(kThreads) void k_l1_backward(const float4 *__restrict__ a,
-                                                          const float4 *__restrict__ b, size_t n4,
-                                                          const float *__restrict__ a_tail,
-                                                          const float *__restrict__ b_tail, int n_tail,
-                                                          const float *__restrict__ upstream, float inv_n,
-                                                          float4 *__restrict__ da, float *__restrict__ da_tail) {
+__global__ __launch_bounds__(kThreads) void k_l1_backward(const uint8_t *__restrict__ signs, size_t n4,
+                                                          int n_tail, const float *__restrict__ upstream,
+                                                          float inv_n, float4 *__restrict__ da,
+                                                          float *__restrict__ da_tail) {
   const float g = upstream[0] * inv_n;  // d loss / d mean, read on the device: no host sync
   for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n4; i += (size_t)gridDim.x * kThreads) {
-    const float4 x = a[i], y = b[i];
-    da[i] = make_float4(g * sgn(x.x - y.x), g * sgn(x.y - y.y), g * sgn(x.z - y.z), g * sgn(x.w - y.w));
+    const unsigned c = signs[i];
+    da[i] = make_float4(g * sign_value(c), g * sign_value(c >> 2), g * sign_value(c >> 4),
+                        g * sign_value(c >> 6));
   }
   if (blockIdx.x == 0 && (int)threadIdx.x < n_tail)
-    da_tail[threadIdx.x] = g * sgn(a_tail[threadIdx.x] - b_tail[threadIdx.x]);
+    da_tail[threadIdx.x] = g * sign_value((unsigned)signs[n4] >> (2 * threadIdx.x));
 }
 
 inline unsigned blocks_for(size_t n4) {
@@ -61,22 +77,21 @@ inline unsigned blocks_for(size_t n4) {
 
 }  // namespace
 
-int launch_l1_forward(const float *a, const float *b, size_t n, float *out, hipStream_t s) {
+int launch_l1_forward(const float *a, const float *b, size_t n, float *out, uint8_t *signs, hipStream_t s) {
   if (hipMemsetAsync(out, 0, sizeof(float), s) != hipSuccess) return check_launch();
   if (n == 0) return MR_OK;
   const size_t n4 = n / 4;
   hipLaunchKernelGGL(k_l1_forward, dim3(blocks_for(n4)), dim3(kThreads), 0, s, (const float4 *)a,
-                     (const float4 *)b, n4, a + 4 * n4, b + 4 * n4, (int)(n - 4 * n4), 1.0f / (float)n, out);
+                     (const float4 *)b, n4, a + 4 * n4, b + 4 * n4, (int)(n - 4 * n4), 1.0f / (float)n, out,
+                     signs);
   return check_launch();
 }
 
-int launch_l1_backward(const float *a, const float *b, size_t n, const float *upstream, float *da,
-                       hipStream_t s) {
+int launch_l1_backward(const uint8_t *signs, size_t n, const float *upstream, float *da, hipStream_t s) {
   if (n == 0) return MR_OK;
   const size_t n4 = n / 4;
-  hipLaunchKernelGGL(k_l1_backward, dim3(blocks_for(n4)), dim3(kThreads), 0, s, (const float4 *)a,
-                     (const float4 *)b, n4, a + 4 * n4, b + 4 * n4, (int)(n - 4 * n4), upstream,
-                     1.0f / (float)n, (float4 *)da, da + 4 * n4);
+  hipLaunchKernelGGL(k_l1_backward, dim3(blocks_for(n4)), dim3(kThreads), 0, s, signs, n4,
+                     (int)(n - 4 * n4), upstream, 1.0f / (float)n, (float4 *)da, da + 4 * n4);
   return check_launch();
 }
 

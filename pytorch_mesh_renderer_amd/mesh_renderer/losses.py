@@ -3,7 +3,8 @@
 The reference has no loss module; its tests and examples spell the loss out as
 `torch.mean(torch.abs(render - target))` (src/mesh_renderer/mesh_renderer_test.py:250,
 src/examples/example5.py:70-92).  In eager torch that is five passes over the image; this is
-the same quantity as one HIP pass forward and one backward.
+the same quantity as one HIP pass forward (which also packs sign(image - target), 2 bits per
+element) and one backward that reads only those signs.
 """
 import torch
 
@@ -13,16 +14,18 @@ from .. import _native
 class _MeanAbsError(torch.autograd.Function):
     @staticmethod
     def forward(ctx, image, target):
-        a, b = image.detach(), target.detach()
-        ctx.save_for_backward(a, b)
-        return _native.l1_loss_forward(a, b)
+        need_grad = any(ctx.needs_input_grad)
+        loss, signs = _native.l1_loss_forward(image.detach(), target.detach(), want_signs=need_grad)
+        if need_grad:
+            ctx.save_for_backward(signs)  # 1 byte per pixel instead of both images
+        ctx.shape = image.shape
+        return loss
 
     @staticmethod
     def backward(ctx, grad):
-        a, b = ctx.saved_tensors
-        da = _native.l1_loss_backward(a, b, grad.to(torch.float32).reshape(1))
-        db = -da if ctx.needs_input_grad[1] else None
-        return da, db
+        (signs,) = ctx.saved_tensors
+        da = _native.l1_loss_backward(signs, ctx.shape, grad.to(torch.float32).reshape(1))
+        return (da if ctx.needs_input_grad[0] else None), (-da if ctx.needs_input_grad[1] else None)
 
 
 def l1_loss(image, target):

@@ -266,7 +266,7 @@ def test_render_sphere_matches_oracle_at_256(device):
 def test_l1_loss_matches_torch(device):
     """losses.l1_loss == torch.mean(torch.abs(a - b)), value and both gradients."""
     gen = torch.Generator().manual_seed(4)
-    for shape in ((2, 48, 64, 4), (1, 7, 3, 4), (3, 5)):
+    for shape in ((2, 48, 64, 4), (1, 7, 3, 4), (3, 5), (1,), (2, 3, 3), (1030,)):
         a0, b0 = torch.rand(shape, generator=gen), torch.rand(shape, generator=gen)
         b0.view(-1)[0] = a0.view(-1)[0]  # an exact zero difference: sign(0) = 0
         a1, b1 = a0.clone().to(device).requires_grad_(True), b0.clone().to(device).requires_grad_(True)
@@ -278,3 +278,7 @@ def test_l1_loss_matches_torch(device):
         (3.0 * l2).backward()
         np.testing.assert_allclose(a1.grad.cpu().numpy(), a2.grad.cpu().numpy(), atol=1e-9, rtol=1e-6)
         np.testing.assert_allclose(b1.grad.cpu().numpy(), b2.grad.cpu().numpy(), atol=1e-9, rtol=1e-6)
+        # no gradient wanted: the sign buffer is skipped, the value is the same
+        with torch.no_grad():
+            l3 = mesh_renderer.losses.l1_loss(a1.detach(), b1.detach())
+        assert abs(float(l3) - float(l2)) < 1e-6
