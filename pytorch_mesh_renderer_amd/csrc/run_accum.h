@@ -152,6 +152,9 @@ __global__ __launch_bounds__(kRunThreads, Fn::kMinWavesPerSimd) void k_accumulat
 //      id changes the N-lane partial leaves as ONE contiguous global float atomic
 //      (144 B for N = 36) into acc[image][triangle][kStride].
 // Triangle data is still fetched once per vertical run and kept in registers.
+#ifndef MR_PROBE_ROWS
+#define MR_PROBE_ROWS 0
+#endif
 template <class Fn>
 __global__ __launch_bounds__(kRunThreads, Fn::kMinWavesPerSimd) void k_accumulate_rows(
     Fn fn, int T, int W, int H, int regions_x, int regions_per_image, int n_regions,
@@ -196,13 +199,15 @@ __global__ __launch_bounds__(kRunThreads, Fn::kMinWavesPerSimd) void k_accumulat
       run_tri = tri;
       fn.load_triangle(img, tri, tri_data);
     }
-    float v[N];
+    // Fn::accumulate ASSIGNS all N values of a valid pixel; rows of invalid pixels are never
+    // read back (segments consist of valid pixels only), so they are not written either.
+    if (valid) {
+      float v[N];
+      fn.accumulate(p, tri_data, v, image_sums);
+      float4 *row = (float4 *)(stage + lane * N);
 #pragma unroll
-    for (int k = 0; k < N; ++k) v[k] = 0.0f;
-    if (valid) fn.accumulate(p, tri_data, v, image_sums);
-    float4 *row = (float4 *)(stage + lane * N);
-#pragma unroll
-    for (int q = 0; q < N / 4; ++q) row[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+      for (int q = 0; q < N / 4; ++q) row[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    }
     const int my_tri = valid ? tri : -1;
     // segment heads along x: a valid pixel whose left neighbour holds another id (or none)
     const int left_tri = __shfl_up(my_tri, 1);
@@ -212,6 +217,9 @@ __global__ __launch_bounds__(kRunThreads, Fn::kMinWavesPerSimd) void k_accumulat
     __builtin_amdgcn_wave_barrier();  // LDS executes one wavefront's operations in order
     // transposed reduction: lane k < N sums element k over each segment of equal ids
     const float *col = stage + min(lane, N - 1);
+#if MR_PROBE_ROWS == 2  // timing probe: no transposed reduction, no atomics
+    heads = 0;
+#endif
     while (heads) {  // wave-uniform: ~3-4 segments per 64 pixels
       const int p0 = __builtin_ctzll(heads);
       heads &= heads - 1;
@@ -230,7 +238,11 @@ __global__ __launch_bounds__(kRunThreads, Fn::kMinWavesPerSimd) void k_accumulat
         for (int j = 0; j < 8; ++j) sum += r[j];
       }
       for (; p < p1; ++p) sum += col[p * N];
+#if MR_PROBE_ROWS == 1  // timing probe: reduction but no global atomics
+      if (lane < N && sum == 123.456f) atomicAdd(&acc_img[(size_t)t * STRIDE + lane], sum);
+#else
       if (lane < N) atomicAdd(&acc_img[(size_t)t * STRIDE + lane], sum);
+#endif
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -292,23 +304,29 @@ __device__ __forceinline__ void load_bwd_triangle(const BwdRec *r, BwdTriangle &
 }
 
 // The nine partials of rasterize_triangles.cpp:202-269 for one pixel, added into
-// acc[j*3 + c] (corner j, clip component c = x, y, w).  FMA contraction is switched
-// off inside: (-U b_j + S b_i b_j) is a small difference of large terms for small /
-// sliver triangles and must round as in the reference.
+// acc[j*3 + c] (corner j, clip component c = x, y, w).  The reference evaluates
+//   sum_i g_i * (-u_ic * b_j + s_c * b_i * b_j) / |det|
+// per (j, c); here b_j is factored out of the sum PER PIXEL (30 VALU ops instead of 150):
+//   b_j * [ sum_i g_i * (s_c * b_i - u_ic) ] / |det|.
+// The differences (s_c b_i - u_ic) are still formed per i and per pixel, as in the reference,
+// so the cancellation between them (severe for small / sliver triangles) rounds the same
+// way; only sums over PIXELS must never be factored (measured: 70x the error).
+// kAssign: acc[k] = value (the row kernel stages every pixel afresh) instead of acc[k] += value;
+// `inv` is 1/|det|, or 0 to switch the pixel off (cpp:162).
+template <bool kAssign = false>
 __device__ __forceinline__ void raster_pixel_partials(const F3 bary, const F3 g, const BwdTriangle &t,
-                                                      float *acc) {
-#pragma clang fp contract(off)
+                                                      const float inv, float *acc) {
   const float b[3] = {bary.x, bary.y, bary.z};
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    const float sb0 = t.s[c] * b[0], sb1 = t.s[c] * b[1], sb2 = t.s[c] * b[2];
+    const float w0 = t.s[c] * b[0] - t.u[0 + c];
+    const float w1 = t.s[c] * b[1] - t.u[3 + c];
+    const float w2 = t.s[c] * b[2] - t.u[6 + c];
+    const float q = ((g.x * w0 + g.y * w1) + g.z * w2) * inv;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      const float d0 = (-t.u[0 + c]) * b[j] + sb0 * b[j];
-      const float d1 = (-t.u[3 + c]) * b[j] + sb1 * b[j];
-      const float d2 = (-t.u[6 + c]) * b[j] + sb2 * b[j];
-      const float v = (g.x * d0 + g.y * d1) + g.z * d2;
-      acc[j * 3 + c] += v * t.inv;
+      if (kAssign) acc[j * 3 + c] = b[j] * q;
+      else acc[j * 3 + c] += b[j] * q;
     }
   }
 }

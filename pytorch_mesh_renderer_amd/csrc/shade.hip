@@ -65,6 +65,11 @@ __global__ __launch_bounds__(kThreads) void k_corner_setup(
   for (int q = 0; q < 8; ++q) out[gid].q[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
 }
 
+// 1-ulp hardware reciprocal / square root (v_rcp_f32, v_sqrt_f32): the IEEE-exact sequences
+// are ~10 VALU ops each and these kernels are VALU-bound; the parity budget is 1e-4 absolute.
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+
 // alpha = clamp(sum(2*bary), 0, 1); attr = alpha * interp + (1 - alpha) * (-1)
 // (rasterize.py:137-150 with render.py:197's background of -1).
 __device__ __forceinline__ void interpolate9(const Corners &cr, const F3 b, float &pre, float &alpha,
@@ -85,8 +90,8 @@ __device__ __forceinline__ float4 shade_pixel(const Corners &cr, const F3 b, con
   interpolate9(cr, b, pre, alpha, interp, at);
   const bool mask = (at[6] >= 0.0f) || (at[7] >= 0.0f) || (at[8] >= 0.0f);  // render.py:215
   if (!mask) return make_float4(0.f, 0.f, 0.f, 0.f);
-  const float nn = sqrtf(at[0] * at[0] + at[1] * at[1] + at[2] * at[2]);
-  const float inv_nn = 1.0f / fmaxf(nn, kNormEps);
+  const float nn = fast_sqrt(at[0] * at[0] + at[1] * at[1] + at[2] * at[2]);
+  const float inv_nn = fast_rcp(fmaxf(nn, kNormEps));
   const float nx = at[0] * inv_nn, ny = at[1] * inv_nn, nz = at[2] * inv_nn;
   float r = 0.f, g = 0.f, bl = 0.f;
   if (lights.amb) {  // render.py:298-301
@@ -97,7 +102,7 @@ __device__ __forceinline__ float4 shade_pixel(const Corners &cr, const F3 b, con
     const float *lp = lights.pos + ((size_t)img * lights.L + l) * 3;
     const float *li = lights.col + ((size_t)img * lights.L + l) * 3;
     const float vx = lp[0] - at[3], vy = lp[1] - at[4], vz = lp[2] - at[5];
-    const float inv_vn = 1.0f / fmaxf(sqrtf(vx * vx + vy * vy + vz * vz), kNormEps);
+    const float inv_vn = fast_rcp(fmaxf(fast_sqrt(vx * vx + vy * vy + vz * vz), kNormEps));
     const float ndl = fminf(fmaxf(nx * (vx * inv_vn) + ny * (vy * inv_vn) + nz * (vz * inv_vn), 0.0f), 1.0f);
     r += at[6] * ndl * li[0];
     g += at[7] * ndl * li[1];
@@ -156,7 +161,10 @@ struct ShadeGradFn {
   static constexpr int kN = 36;       // 27 attribute partials [corner][attr] + 9 clip partials
   static constexpr int kStride = 36;
   static constexpr int kSlots = 256;
-  static constexpr int kMinWavesPerSimd = 3;
+#ifndef MR_SHADE_WAVES
+#define MR_SHADE_WAVES 3
+#endif
+  static constexpr int kMinWavesPerSimd = MR_SHADE_WAVES;
   const float4 *__restrict__ drgba;   // [B,H,W,4], image rows (flipped w.r.t. the G-buffer)
   const int32_t *__restrict__ ids;
   const F3 *__restrict__ bary;
@@ -227,10 +235,12 @@ struct ShadeGradFn {
                                              Image &im) const {
     float pre, alpha, interp[9], at[9];
     interpolate9(t.cr, p.b, pre, alpha, interp, at);
-    if (!((at[6] >= 0.0f) || (at[7] >= 0.0f) || (at[8] >= 0.0f))) return;  // masked: where() -> 0
-    const float g[3] = {p.g.x, p.g.y, p.g.z};
-    const float nn = sqrtf(at[0] * at[0] + at[1] * at[1] + at[2] * at[2]);
-    const float inv_nn = 1.0f / fmaxf(nn, kNormEps);
+    // render.py:215 mask: where() sends no gradient to a masked pixel.  All 36 outputs are
+    // linear in g, so a masked pixel simply runs with g = 0 (every output must be assigned).
+    const bool mask = (at[6] >= 0.0f) || (at[7] >= 0.0f) || (at[8] >= 0.0f);
+    const float g[3] = {mask ? p.g.x : 0.f, mask ? p.g.y : 0.f, mask ? p.g.z : 0.f};
+    const float nn = fast_sqrt(at[0] * at[0] + at[1] * at[1] + at[2] * at[2]);
+    const float inv_nn = fast_rcp(fmaxf(nn, kNormEps));
     const float N[3] = {at[0] * inv_nn, at[1] * inv_nn, at[2] * inv_nn};
     float dN[3] = {0.f, 0.f, 0.f}, dP[3] = {0.f, 0.f, 0.f};
     float dKd[3] = {g[0] * im.amb[0], g[1] * im.amb[1], g[2] * im.amb[2]};
@@ -239,8 +249,8 @@ struct ShadeGradFn {
 #pragma unroll
     for (int l = 0; l < L; ++l) {
       const float v[3] = {im.lp[l][0] - at[3], im.lp[l][1] - at[4], im.lp[l][2] - at[5]};
-      const float vn = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-      const float inv_vn = 1.0f / fmaxf(vn, kNormEps);
+      const float vn = fast_sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+      const float inv_vn = fast_rcp(fmaxf(vn, kNormEps));
       const float D[3] = {v[0] * inv_vn, v[1] * inv_vn, v[2] * inv_vn};
       const float pre_l = N[0] * D[0] + N[1] * D[1] + N[2] * D[2];
       const float ndl = fminf(fmaxf(pre_l, 0.0f), 1.0f);
@@ -288,15 +298,15 @@ struct ShadeGradFn {
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         db[k] += di * t.cr.c[k][a];
-        acc[k * 9 + a] += di * bw[k];
+        acc[k * 9 + a] = di * bw[k];
       }
     }
     const float dpre = (pre >= 0.0f && pre <= 1.0f) ? 2.0f * dalpha : 0.0f;
     F3 dbary;
     dbary.x = db[0] + dpre; dbary.y = db[1] + dpre; dbary.z = db[2] + dpre;
     // rasterizer backward (cpp:162 skip rule, then cpp:202-269)
-    if (!(p.tri == 0 && (p.b.x + p.b.y) + p.b.z < kDegenerateCutoff))
-      raster_pixel_partials(p.b, dbary, t.bt, acc + 27);
+    const bool skip = p.tri == 0 && (p.b.x + p.b.y) + p.b.z < kDegenerateCutoff;
+    raster_pixel_partials<true>(p.b, dbary, t.bt, skip ? 0.f : t.bt.inv, acc + 27);
   }
 
   __device__ __forceinline__ void end_image(int img, Image &im) const {
