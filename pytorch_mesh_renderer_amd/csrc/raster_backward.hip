@@ -115,7 +115,7 @@ struct RasterGradFn {
   }
   __device__ __forceinline__ void accumulate(const Pixel &p, const Triangle &t, float (&acc)[kN],
                                              Image &) const {
-    raster_pixel_partials<false>(p.b, p.g, t, t.inv, acc);
+    raster_pixel_partials(p.b, p.g, t, acc);
   }
 };
 

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(kRunThreads, Fn::kMinWavesPerSimd) void k_accumulat
   __syncthreads();
 
   const int lane = tid & (kWave - 1);
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform (SGPR)
   const int x = rx * kWave + lane;
   const int y_begin = ry * kRunRegionH + wave * kRunRowsPerWave;
   const int y_end = min(y_begin + kRunRowsPerWave, H);
@@ -139,19 +139,27 @@ __global__ __launch_bounds__(kRunThreads, Fn::kMinWavesPerSimd) void k_accumulat
 }
 
 // ---------------------------------------------------------------------------------------
-// Row-transposed variant for functors with many sums per triangle (N = 36).
+// Row-transposed variant for functors whose N sums per triangle are PRODUCTS of a few
+// per-pixel factors (the fused shading backward: 36 sums = 3 barycentrics x 12 gradients).
 //
 // With 36 register accumulators per lane the run-based kernel above sits at 2-3 waves per
 // SIMD, and every row on which ANY lane finishes a run costs 36 ds_add_f32 wave-instructions
 // (~26 LDS cycles each on gfx950, whatever the number of active lanes): 0.8 ms of 1.17 ms at
 // 1024^2 x 32.  Here no sum lives in a pixel lane's registers:
-//   1. each lane evaluates its pixel's N values and parks them in an LDS row (N/4
-//      ds_write_b128, all lanes active, conflict-free at a 36-float stride);
+//   1. each lane evaluates its pixel's kFactors factors (NOT the N products) and parks them in
+//      an LDS row (kFactorStride / 4 ds_write_b128; a 20-float stride is bank-conflict-free);
 //   2. lanes 0..N-1 then walk the 64 parked pixels left to right -- uniform control flow,
-//      the pixel's triangle id comes from v_readlane -- summing element `lane`; where the
-//      id changes the N-lane partial leaves as ONE contiguous global float atomic
-//      (144 B for N = 36) into acc[image][triangle][kStride].
+//      the pixel's triangle id comes from v_readlane -- lane o accumulating
+//      factor[ia(o)] * factor[ib(o)] with one FMA per pixel; where the id changes the N-lane
+//      partial leaves as ONE contiguous global float atomic (144 B for N = 36) into
+//      acc[image][triangle][kStride].
+// Forming the products in the reduction instead of per pixel saves N multiplies and
+// (N - kFactors) / 4 LDS writes per pixel and, above all, N live registers in the pixel math.
 // Triangle data is still fetched once per vertical run and kept in registers.
+//
+// Extra functor members: kFactors, kFactorStride (multiple of 4, >= kFactors),
+//   static void factor_pair(int o, int &ia, int &ib);            // 0 <= o < kN
+//   void factors(const Pixel &, const Triangle &, float (&f)[kFactorStride], Image &) const;
 #ifndef MR_PROBE_ROWS
 #define MR_PROBE_ROWS 0
 #endif
@@ -159,9 +167,10 @@ template <class Fn>
 __global__ __launch_bounds__(kRunThreads, Fn::kMinWavesPerSimd) void k_accumulate_rows(
     Fn fn, int T, int W, int H, int regions_x, int regions_per_image, int n_regions,
     int regions_per_xcd, float *__restrict__ acc) {
-  constexpr int N = Fn::kN, STRIDE = Fn::kStride;
-  static_assert(N % 4 == 0 && N <= kWave && N <= STRIDE, "row-transposed flush needs N % 4 == 0");
-  __shared__ __attribute__((aligned(16))) float s_stage[kRunThreads / kWave][kWave * N];
+  constexpr int N = Fn::kN, STRIDE = Fn::kStride, F = Fn::kFactorStride;
+  static_assert(F % 4 == 0 && Fn::kFactors <= F && N <= kWave && N <= STRIDE, "row layout");
+  // 7 spare rows: the last, partial batch of a segment may read (never use) rows 64..70
+  __shared__ __attribute__((aligned(16))) float s_stage[kRunThreads / kWave][(kWave + 8) * F];
 
   const int region = xcd_contiguous_block((int)blockIdx.x, n_regions, regions_per_xcd);
   if (region < 0) return;
@@ -172,7 +181,7 @@ __global__ __launch_bounds__(kRunThreads, Fn::kMinWavesPerSimd) void k_accumulat
 
   const int tid = (int)threadIdx.x;
   const int lane = tid & (kWave - 1);
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform (SGPR)
   const int x = rx * kWave + lane;
   const bool in_range = x < W;
   const int xc = in_range ? x : W - 1;
@@ -180,6 +189,9 @@ __global__ __launch_bounds__(kRunThreads, Fn::kMinWavesPerSimd) void k_accumulat
   const int y_end = min(y_begin + kRunRowsPerWave, H);
   float *acc_img = acc + (size_t)img * T * STRIDE;
   float *stage = s_stage[wave];
+  int ia, ib;  // the two factors whose product this lane sums (lanes >= N idle along)
+  Fn::factor_pair(min(lane, N - 1), ia, ib);
+  const float *col_a = stage + ia, *col_b = stage + ib;
 
   typename Fn::Image image_sums;
   fn.begin_image(img, image_sums);
@@ -199,14 +211,13 @@ __global__ __launch_bounds__(kRunThreads, Fn::kMinWavesPerSimd) void k_accumulat
       run_tri = tri;
       fn.load_triangle(img, tri, tri_data);
     }
-    // Fn::accumulate ASSIGNS all N values of a valid pixel; rows of invalid pixels are never
-    // read back (segments consist of valid pixels only), so they are not written either.
+    // Rows of invalid pixels are never read back (segments consist of valid pixels only).
     if (valid) {
-      float v[N];
-      fn.accumulate(p, tri_data, v, image_sums);
-      float4 *row = (float4 *)(stage + lane * N);
+      float f[F];
+      fn.factors(p, tri_data, f, image_sums);
+      float4 *row = (float4 *)(stage + lane * F);
 #pragma unroll
-      for (int q = 0; q < N / 4; ++q) row[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+      for (int q = 0; q < F / 4; ++q) row[q] = make_float4(f[4 * q], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3]);
     }
     const int my_tri = valid ? tri : -1;
     // segment heads along x: a valid pixel whose left neighbour holds another id (or none)
@@ -215,8 +226,6 @@ __global__ __launch_bounds__(kRunThreads, Fn::kMinWavesPerSimd) void k_accumulat
     unsigned long long heads = __ballot(head);
     const unsigned long long valids = __ballot(valid);
     __builtin_amdgcn_wave_barrier();  // LDS executes one wavefront's operations in order
-    // transposed reduction: lane k < N sums element k over each segment of equal ids
-    const float *col = stage + min(lane, N - 1);
 #if MR_PROBE_ROWS == 2  // timing probe: no transposed reduction, no atomics
     heads = 0;
 #endif
@@ -229,18 +238,41 @@ __global__ __launch_bounds__(kRunThreads, Fn::kMinWavesPerSimd) void k_accumulat
       const int p1 = stop ? __builtin_ctzll(stop) : kWave;
       const int t = __builtin_amdgcn_readlane(my_tri, p0);
       float sum = 0.0f;
-      int p = p0;
-      for (; p + 8 <= p1; p += 8) {  // 8 independent LDS reads in flight
-        float r[8];
+      // batches of 8 pixels: 16 independent LDS reads in flight, one FMA per pixel
+      int pb = p0;
+      for (; pb + 8 <= p1; pb += 8) {
+        float ra[8], rb[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) r[j] = col[(p + j) * N];
+        for (int j = 0; j < 8; ++j) {
+          ra[j] = col_a[(pb + j) * F];
+          rb[j] = col_b[(pb + j) * F];
+        }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) sum += r[j];
+        for (int j = 0; j < 8; ++j) sum = fmaf(ra[j], rb[j], sum);
       }
-      for (; p < p1; ++p) sum += col[p * N];
+      if (pb < p1) {  // 1..7 pixels left: all reads are issued, a uniform switch uses the first r
+        float ra[8], rb[8];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+          ra[j] = col_a[(pb + j) * F];
+          rb[j] = col_b[(pb + j) * F];
+        }
+        switch (p1 - pb) {
+          case 7: sum = fmaf(ra[6], rb[6], sum); [[fallthrough]];
+          case 6: sum = fmaf(ra[5], rb[5], sum); [[fallthrough]];
+          case 5: sum = fmaf(ra[4], rb[4], sum); [[fallthrough]];
+          case 4: sum = fmaf(ra[3], rb[3], sum); [[fallthrough]];
+          case 3: sum = fmaf(ra[2], rb[2], sum); [[fallthrough]];
+          case 2: sum = fmaf(ra[1], rb[1], sum); [[fallthrough]];
+          default: sum = fmaf(ra[0], rb[0], sum);
+        }
+      }
 #if MR_PROBE_ROWS == 1  // timing probe: reduction but no global atomics
       if (lane < N && sum == 123.456f) atomicAdd(&acc_img[(size_t)t * STRIDE + lane], sum);
 #else
+      // One contiguous N-lane atomic per segment.  Parking partials in registers to merge a
+      // triangle's consecutive rows first was measured SLOWER (0.64 -> 0.69 ms with 6 slots):
+      // the scalar bookkeeping costs more than the L2 atomics it saves.
       if (lane < N) atomicAdd(&acc_img[(size_t)t * STRIDE + lane], sum);
 #endif
     }
@@ -311,23 +343,28 @@ __device__ __forceinline__ void load_bwd_triangle(const BwdRec *r, BwdTriangle &
 // The differences (s_c b_i - u_ic) are still formed per i and per pixel, as in the reference,
 // so the cancellation between them (severe for small / sliver triangles) rounds the same
 // way; only sums over PIXELS must never be factored (measured: 70x the error).
-// kAssign: acc[k] = value (the row kernel stages every pixel afresh) instead of acc[k] += value;
-// `inv` is 1/|det|, or 0 to switch the pixel off (cpp:162).
-template <bool kAssign = false>
+// raster_pixel_q returns the bracket q_c (c = x, y, w) -- the row kernel multiplies by b_j in
+// its reduction; `inv` is 1/|det|, or 0 to switch the pixel off (cpp:162).
+__device__ __forceinline__ void raster_pixel_q(const F3 bary, const F3 g, const BwdTriangle &t,
+                                               const float inv, float (&q)[3]) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float w0 = t.s[c] * bary.x - t.u[0 + c];
+    const float w1 = t.s[c] * bary.y - t.u[3 + c];
+    const float w2 = t.s[c] * bary.z - t.u[6 + c];
+    q[c] = ((g.x * w0 + g.y * w1) + g.z * w2) * inv;
+  }
+}
+
 __device__ __forceinline__ void raster_pixel_partials(const F3 bary, const F3 g, const BwdTriangle &t,
-                                                      const float inv, float *acc) {
+                                                      float *acc) {
+  float q[3];
+  raster_pixel_q(bary, g, t, t.inv, q);
   const float b[3] = {bary.x, bary.y, bary.z};
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    const float w0 = t.s[c] * b[0] - t.u[0 + c];
-    const float w1 = t.s[c] * b[1] - t.u[3 + c];
-    const float w2 = t.s[c] * b[2] - t.u[6 + c];
-    const float q = ((g.x * w0 + g.y * w1) + g.z * w2) * inv;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      if (kAssign) acc[j * 3 + c] = b[j] * q;
-      else acc[j * 3 + c] += b[j] * q;
-    }
+    for (int j = 0; j < 3; ++j) acc[j * 3 + c] += b[j] * q[c];
   }
 }
 

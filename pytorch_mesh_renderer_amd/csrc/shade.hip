@@ -160,6 +160,15 @@ template <int L>
 struct ShadeGradFn {
   static constexpr int kN = 36;       // 27 attribute partials [corner][attr] + 9 clip partials
   static constexpr int kStride = 36;
+  // per-pixel factors parked in LDS: b[3] | y[9] = alpha * d/d attr | q[3] = clip brackets
+  static constexpr int kFactors = 15;
+  static constexpr int kFactorStride = 20;
+  // sum o = corner * 9 + attr      -> b[corner] * y[attr]
+  //     o = 27 + corner * 3 + comp -> b[corner] * q[comp]
+  __device__ static void factor_pair(int o, int &ia, int &ib) {
+    if (o < 27) { ia = o / 9; ib = 3 + o % 9; }
+    else { ia = (o - 27) / 3; ib = 12 + (o - 27) % 3; }
+  }
   static constexpr int kSlots = 256;
 #ifndef MR_SHADE_WAVES
 #define MR_SHADE_WAVES 3
@@ -231,8 +240,8 @@ struct ShadeGradFn {
     load_bwd_triangle(recs + (size_t)img * T_ + tri, t.bt);
   }
 
-  __device__ __forceinline__ void accumulate(const Pixel &p, const Triangle &t, float (&acc)[kN],
-                                             Image &im) const {
+  __device__ __forceinline__ void factors(const Pixel &p, const Triangle &t, float (&f)[kFactorStride],
+                                          Image &im) const {
     float pre, alpha, interp[9], at[9];
     interpolate9(t.cr, p.b, pre, alpha, interp, at);
     // render.py:215 mask: where() sends no gradient to a masked pixel.  All 36 outputs are
@@ -289,24 +298,28 @@ struct ShadeGradFn {
       }
     }
     // interpolation backward (rasterize.py:137-150)
-    float dalpha = 0.f, db[3] = {0.f, 0.f, 0.f};
-    const float bw[3] = {p.b.x, p.b.y, p.b.z};
+    // d/d alpha = sum_a dat[a] * (interp[a] + 1) with interp[a] + 1 = (at[a] + 1) / alpha
+    // (alpha > 0 on every valid pixel): `interp` need not stay live across the shading math.
+    float dalpha_a = 0.f, db[3] = {0.f, 0.f, 0.f};
+    f[0] = p.b.x; f[1] = p.b.y; f[2] = p.b.z;
 #pragma unroll
     for (int a = 0; a < 9; ++a) {
       const float di = alpha * dat[a];
-      dalpha += dat[a] * (interp[a] + 1.0f);  // background is -1
+      dalpha_a += dat[a] * (at[a] + 1.0f);  // background is -1
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        db[k] += di * t.cr.c[k][a];
-        acc[k * 9 + a] = di * bw[k];
-      }
+      for (int k = 0; k < 3; ++k) db[k] += di * t.cr.c[k][a];
+      f[3 + a] = di;  // d/d attr[corner k][a] = b_k * di: the product is formed in the reduction
     }
-    const float dpre = (pre >= 0.0f && pre <= 1.0f) ? 2.0f * dalpha : 0.0f;
+    const float dpre = (pre >= 0.0f && pre <= 1.0f) ? 2.0f * dalpha_a * fast_rcp(alpha) : 0.0f;
     F3 dbary;
     dbary.x = db[0] + dpre; dbary.y = db[1] + dpre; dbary.z = db[2] + dpre;
     // rasterizer backward (cpp:162 skip rule, then cpp:202-269)
     const bool skip = p.tri == 0 && (p.b.x + p.b.y) + p.b.z < kDegenerateCutoff;
-    raster_pixel_partials<true>(p.b, dbary, t.bt, skip ? 0.f : t.bt.inv, acc + 27);
+    float q[3];
+    raster_pixel_q(p.b, dbary, t.bt, skip ? 0.f : t.bt.inv, q);
+    f[12] = q[0]; f[13] = q[1]; f[14] = q[2];
+#pragma unroll
+    for (int k = kFactors; k < kFactorStride; ++k) f[k] = 0.f;
   }
 
   __device__ __forceinline__ void end_image(int img, Image &im) const {
