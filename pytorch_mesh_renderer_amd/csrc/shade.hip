@@ -115,9 +115,15 @@ __device__ __forceinline__ float4 shade_pixel(const Corners &cr, const F3 b, con
 // thread shades kRows pixels of one column.  All G-buffer loads of the kRows pixels are
 // issued first, then all corner-record loads, then the arithmetic: the kernel is bound
 // by load latency (two dependent levels: id -> corner record), not by bandwidth or VALU.
-constexpr int kShadeRows = 4;
+#ifndef MR_SHADE_ROWS
+#define MR_SHADE_ROWS 2  // measured: 1 -> 0.290, 2 -> 0.264, 3 -> 0.282, 4 -> 0.293 ms (C3)
+#endif
+#ifndef MR_SHADE_FWD_WAVES
+#define MR_SHADE_FWD_WAVES 1
+#endif
+constexpr int kShadeRows = MR_SHADE_ROWS;
 
-__global__ __launch_bounds__(kThreads) void k_shade_forward(
+__global__ __launch_bounds__(kThreads, MR_SHADE_FWD_WAVES) void k_shade_forward(
     const int32_t *__restrict__ ids, const F3 *__restrict__ bary,
     const CornerRec *__restrict__ corners, Lights lights, int B, int T, int W, int H,
     int x_blocks, int y_blocks, float4 *__restrict__ out) {
