@@ -1,0 +1,18 @@
+# Run ON the GPU box (through gpurun) from the repo root: kernel-trace statistics and HBM
+# traffic counters of the bench command, one rocprofv3 pass each (PMC passes carry
+# --kernel-trace only, as the pool requires).  Outputs under gpurun_out/prof_final/;
+# tools/summarize_profiles.py turns them into the files committed under profiles/.
+#   gpurun --timeout 900 -- 'bash tools/collect_profiles.sh'
+set -e
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/prof_final
+rm -rf "$OUT" && mkdir -p "$OUT"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- \
+    python3 bench.py --steps 10 --warmup 3 > "$OUT/bench_under_rocprof.log" 2>&1
+for counter in WRITE_SIZE FETCH_SIZE; do
+  timeout -k 10 400 rocprofv3 --kernel-trace --pmc $counter --output-format csv -d "$OUT/pmc_$counter" -o run -- \
+      python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 > "$OUT/pmc_$counter.log" 2>&1
+done
+timeout -k 10 250 python3 bench.py > "$OUT/bench.log" 2>&1
+grep '"metric"' "$OUT/bench.log" | cut -c1-200
+find "$OUT" -name '*.csv' | sort

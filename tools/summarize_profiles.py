@@ -1,0 +1,72 @@
+"""Condense gpurun_out/prof_final (tools/collect_profiles.sh) into the files under profiles/.
+
+    python tools/summarize_profiles.py <tag>      # e.g. r01_h
+
+Writes profiles/<tag>_bench_kernel_stats.csv (rocprofv3 --stats, top kernels),
+profiles/<tag>_bench.json (the bench lines of the same box) and rewrites
+profiles/raster_traffic.json (HBM bytes per k_raster launch from the PMC passes; read by bench.py).
+"""
+import csv, glob, json, os, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "prof_final")
+tag = sys.argv[1]
+prof = os.path.join(ROOT, "profiles")
+
+
+def one(pattern):
+    hits = glob.glob(os.path.join(SRC, pattern), recursive=True)
+    if not hits:
+        raise SystemExit("missing " + pattern)
+    return hits[0]
+
+
+# 1. kernel statistics
+rows = list(csv.DictReader(open(one("stats/**/*kernel_stats.csv"))))
+with open(os.path.join(prof, tag + "_bench_kernel_stats.csv"), "w", newline="") as f:
+    w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+    w.writeheader()
+    for r in rows[:24]:
+        w.writerow(r)
+
+# 2. bench lines (plain and under rocprof)
+lines = {}
+for name in ("bench.log", "bench_under_rocprof.log"):
+    for line in open(os.path.join(SRC, name)):
+        if line.startswith('{"metric"'):
+            lines[name[:-4]] = json.loads(line)
+json.dump(lines, open(os.path.join(prof, tag + "_bench.json"), "w"), indent=1)
+
+# 3. HBM traffic of the kernels of interest, per launch
+wanted = {"k_raster": "k_raster(", "k_shade_forward": "k_shade_forward(", "ShadeGradFn": "ShadeGradFn",
+          "k_l1_forward": "k_l1_forward(", "k_l1_backward": "k_l1_backward("}
+raw = {k: {} for k in wanted}
+for counter in ("WRITE_SIZE", "FETCH_SIZE"):
+    acc = {k: [] for k in wanted}
+    for r in csv.DictReader(open(one("pmc_%s/**/*counter_collection.csv" % counter))):
+        if r["Counter_Name"] != counter:
+            continue
+        for k, needle in wanted.items():
+            if needle in r["Kernel_Name"]:
+                acc[k].append(float(r["Counter_Value"]))
+    for k, v in acc.items():
+        if v:
+            raw[k][counter] = sum(v) / len(v)
+            raw[k]["launches_" + counter] = len(v)
+kr = raw["k_raster"]
+bench = lines.get("bench", {})
+out = {
+    "kernel": "k_raster",
+    # gfx950: WRITE_SIZE counts KB as is, FETCH_SIZE is doubled (MI355X_MICROARCH.md, HBM section)
+    "bytes_per_launch": int(round((kr["WRITE_SIZE"] + 2.0 * kr["FETCH_SIZE"]) * 1024)),
+    "how": "rocprofv3 --kernel-trace --pmc WRITE_SIZE and --pmc FETCH_SIZE in separate passes over "
+           "`python3 bench.py --steps 3 --warmup 1 --cpu-sample 0` (tools/collect_profiles.sh), averaged over "
+           "the k_raster dispatches; bytes = (WRITE_SIZE + 2*FETCH_SIZE) * 1024 (FETCH_SIZE doubled as "
+           "MI355X_MICROARCH.md prescribes for gfx950; WRITE_SIZE is exact for k_shade_forward's 16-B "
+           "stores in the same run: 524288 KB = 537 MB)",
+    "raw": raw,
+    "algorithmic_bytes": bench.get("roofline", {}).get("algorithmic_bytes"),
+    "tag": tag,
+}
+json.dump(out, open(os.path.join(prof, "raster_traffic.json"), "w"), indent=1)
+print(json.dumps({k: v for k, v in out.items() if k != "how"}, indent=1))
