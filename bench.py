@@ -9,8 +9,9 @@ transform, G-buffer rasterization, attribute interpolation, Phong shading), the 
 image loss mean|image - target| against a fixed target, and backward to the world-space vertex
 positions.  All inputs are resident in HBM before the timed region starts.  With N
 ranks every rank renders its own 32 jobs (weak scaling; no data-path collective) and
-the finished images are handed over to rank 0 with one RCCL gather per step that
-overlaps the loss, the backward and the next forward.  Rank 0 prints ONE JSON line.
+the finished images are handed over to rank 0 as 8-bit frames (mesh_renderer.to_uint8: the
+conversion the reference's examples apply before writing a frame) with one RCCL gather per
+step that overlaps the loss, the backward and the next forward.  Rank 0 prints ONE JSON line.
 
 Extra objects in the line:
   roofline      the forward G-buffer kernel (k_raster): algorithmic bytes per launch
@@ -98,8 +99,9 @@ def make_step(job, device, gather):
         image = forward()
         if gather is not None:
             gather.wait()                # the previous step's hand-over (no-op the first time) ...
-            gather.start(image)          # ... then this one, on the side stream: it overlaps the loss,
-                                         # the backward and the next step's forward
+            # ... then this one: 8-bit frames (what the reference's examples write out), on the side
+            # stream, so that it overlaps the loss, the backward and the next step's forward
+            gather.start(mesh_renderer.to_uint8(image))
         loss = mesh_renderer.losses.l1_loss(image, target)   # mean |image - target|, one HIP pass each way
         loss.backward()
         return loss
@@ -147,7 +149,8 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    device = torch.device("cuda", local_rank)
+    # one GPU per rank; the modulo only matters for a gloo rehearsal of N ranks on fewer GPUs
+    device = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(device)
 
     job = synthetic.sphere_job(BATCH, WIDTH, HEIGHT, SPHERE_K)
@@ -204,7 +207,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[2]: 5k-tri UV sphere (V=%d, T=%d), %dx%d, batch=%d per GPU, "
                                    "mesh_renderer.render forward + L1 loss + backward to vertex positions; "
-                                   "image gather to rank 0 over RCCL when n_gpus>1" % (V, T, WIDTH, HEIGHT, BATCH),
+                                   "8-bit frames gathered to rank 0 over RCCL when n_gpus>1" % (V, T, WIDTH, HEIGHT, BATCH),
                        "global_batch": BATCH * world, "image": [HEIGHT, WIDTH], "triangles": T},
             "roofline": {"bound": "hbm", "kernel": "k_raster (forward G-buffer write)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -180,6 +180,14 @@ int mr_l1_loss_forward(const float *a, const float *b, size_t n, float *loss, ui
 int mr_l1_loss_backward(const uint8_t *signs, size_t n, const float *upstream, float *da,
                         void *stream);
 
+/* ---- 8-bit frame export ---------------------------------------------------------------
+ * The conversion the reference's examples apply on the host before writing PNG / GIF frames,
+ * (image * 255.0).astype(np.uint8) (src/examples/example1.py:52, example5.py:81), on the device:
+ * out[i] = (uint8) trunc(clamp(image[i], 0, 1) * 255), NaN -> 0.  image: n floats (16-byte
+ * aligned); out: n bytes (4-byte aligned).  Used for frames that leave the GPU (display, files,
+ * the multi-GPU hand-over): a quarter of the fp32 bytes. */
+int mr_export_u8(const float *image, size_t n, uint8_t *out, void *stream);
+
 /* ---- stage-timing probe (no reference counterpart) -----------------------------
  * 0 = normal operation (default).  3, 4, 5, 10, 18, 34, 42 switch stages of the forward
  * raster kernel off so that tools/raster_bench.py can time the rest: 3 = bin only,

@@ -88,6 +88,8 @@ def lib():
         L.mr_l1_loss_forward.restype = ci
         L.mr_l1_loss_backward.argtypes = [vp, sz, vp, vp, vp]
         L.mr_l1_loss_backward.restype = ci
+        L.mr_export_u8.argtypes = [vp, sz, vp, vp]
+        L.mr_export_u8.restype = ci
         _lib = L
     return _lib
 
@@ -353,3 +355,14 @@ def l1_loss_backward(signs, shape, upstream):
                                        _stream(dev))
     _check(rc, "mr_l1_loss_backward")
     return da
+
+
+def export_u8(image):
+    """trunc(clamp(image, 0, 1) * 255) as a uint8 tensor of the same shape (device)."""
+    dev = _require_device(image)
+    image = image.contiguous()
+    out = torch.empty(image.shape, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib().mr_export_u8(_ptr(image), image.numel(), _ptr(out), _stream(dev))
+    _check(rc, "mr_export_u8")
+    return out

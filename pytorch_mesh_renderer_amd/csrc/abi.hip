@@ -227,4 +227,10 @@ int mr_l1_loss_backward(const uint8_t *signs, size_t n, const float *upstream, f
   return mr::launch_l1_backward(signs, n, upstream, da, (hipStream_t)stream);
 }
 
+int mr_export_u8(const float *image, size_t n, uint8_t *out, void *stream) {
+  if (n > 0 && (!image || !out)) return MR_EINVAL;
+  if (((uintptr_t)image & 15u) != 0 || ((uintptr_t)out & 3u) != 0) return MR_EINVAL;
+  return mr::launch_export_u8(image, n, out, (hipStream_t)stream);
+}
+
 }  // extern "C"

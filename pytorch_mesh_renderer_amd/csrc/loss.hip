@@ -70,6 +70,25 @@ __global__ __launch_bounds__(kThreads) void k_l1_backward(const uint8_t *__restr
     da_tail[threadIdx.x] = g * sign_value((unsigned)signs[n4] >> (2 * threadIdx.x));
 }
 
+// 8-bit frame export: what the reference's examples do on the host before writing PNG / GIF
+// frames, `(image * 255.0).astype(np.uint8)` (src/examples/example1.py:52, example5.py:81), with the
+// value clamped to [0, 1] first (numpy's cast of an out-of-range float is undefined).  One pass,
+// 16 B read + 4 B written per RGBA pixel; NaN exports as 0.
+__device__ __forceinline__ unsigned to_u8(float v) {
+  const float c = fminf(fmaxf(v, 0.0f), 1.0f);  // fmaxf(NaN, 0) = 0
+  return (unsigned)(c * 255.0f);                 // truncation, like astype(np.uint8)
+}
+
+__global__ __launch_bounds__(kThreads) void k_export_u8(const float4 *__restrict__ in, size_t n4,
+                                                        const float *__restrict__ in_tail, int n_tail,
+                                                        uint32_t *__restrict__ out, uint8_t *__restrict__ out_tail) {
+  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n4; i += (size_t)gridDim.x * kThreads) {
+    const float4 v = in[i];
+    out[i] = to_u8(v.x) | (to_u8(v.y) << 8) | (to_u8(v.z) << 16) | (to_u8(v.w) << 24);
+  }
+  if (blockIdx.x == 0 && (int)threadIdx.x < n_tail) out_tail[threadIdx.x] = (uint8_t)to_u8(in_tail[threadIdx.x]);
+}
+
 inline unsigned blocks_for(size_t n4) {
   const size_t want = (n4 + kThreads - 1) / kThreads;
   return (unsigned)(want < 2048 ? (want ? want : 1) : 2048);
@@ -92,6 +111,14 @@ int launch_l1_backward(const uint8_t *signs, size_t n, const float *upstream, fl
   const size_t n4 = n / 4;
   hipLaunchKernelGGL(k_l1_backward, dim3(blocks_for(n4)), dim3(kThreads), 0, s, signs, n4,
                      (int)(n - 4 * n4), upstream, 1.0f / (float)n, (float4 *)da, da + 4 * n4);
+  return check_launch();
+}
+
+int launch_export_u8(const float *in, size_t n, uint8_t *out, hipStream_t s) {
+  if (n == 0) return MR_OK;
+  const size_t n4 = n / 4;
+  hipLaunchKernelGGL(k_export_u8, dim3(blocks_for(n4)), dim3(kThreads), 0, s, (const float4 *)in, n4,
+                     in + 4 * n4, (int)(n - 4 * n4), (uint32_t *)out, out + 4 * n4);
   return check_launch();
 }
 

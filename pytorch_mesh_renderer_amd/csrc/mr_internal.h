@@ -91,6 +91,7 @@ int launch_shade_backward(const float *drgba, const int32_t *ids, const float *b
 
 int launch_l1_forward(const float *a, const float *b, size_t n, float *out, uint8_t *signs, hipStream_t s);
 int launch_l1_backward(const uint8_t *signs, size_t n, const float *upstream, float *da, hipStream_t s);
+int launch_export_u8(const float *in, size_t n, uint8_t *out, hipStream_t s);
 int soft_max_lights();
 size_t soft_ws(int B, int V, int T, int W, int H);
 int launch_soft_forward(const float *clip, const float *positions, const float *normals,

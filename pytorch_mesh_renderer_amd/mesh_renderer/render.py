@@ -212,3 +212,14 @@ def tone_mapper(image, gamma):
     corrected = torch.pow(image, gamma)
     image_max = corrected.reshape(batch_size, -1).max(dim=1).values
     return torch.clamp(corrected / image_max.reshape(batch_size, 1, 1, 1), 0.0, 1.0)
+
+
+def to_uint8(image):
+    """8-bit frames for display, files and the multi-GPU hand-over: the conversion the
+    reference's examples apply on the host, `(image * 255.0).astype(np.uint8)`
+    (src/examples/example1.py:52, example5.py:81), as one HIP pass on the device (the value is
+    clamped to [0, 1] first; NaN exports as 0).  Not differentiable."""
+    from .. import _native
+    if image.dtype != torch.float32:
+        raise ValueError("to_uint8 expects a float32 image")
+    return _native.export_u8(image.detach())

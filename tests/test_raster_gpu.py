@@ -289,6 +289,9 @@ def test_rccl_image_gather_single_rank(device):
         r.wait()
         r.start(x + 1.0)              # back-to-back hand-overs, waited one step late
         assert torch.equal(r.wait(), x + 1.0)
+        frames = (x * 255).to(torch.uint8)   # 8-bit frames, as bench.py hands them over
+        r.start(frames)
+        assert torch.equal(r.wait(), frames)
         grad = torch.ones(5, 3, device=device)
         assert torch.equal(distributed.allreduce_shared_mesh_grad(grad.clone()), grad)
     finally:

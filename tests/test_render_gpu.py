@@ -282,3 +282,21 @@ def test_l1_loss_matches_torch(device):
         with torch.no_grad():
             l3 = mesh_renderer.losses.l1_loss(a1.detach(), b1.detach())
         assert abs(float(l3) - float(l2)) < 1e-6
+
+
+def test_to_uint8_matches_numpy_cast(device):
+    """to_uint8 == (clip(x, 0, 1) * 255.0).astype(np.uint8), the examples' frame conversion."""
+    gen = torch.Generator().manual_seed(9)
+    for shape in ((2, 33, 17, 4), (5,), (1, 3, 3, 3)):
+        x = torch.rand(shape, generator=gen) * 1.4 - 0.2          # some values outside [0, 1]
+        flat = x.view(-1)
+        flat[0] = 1.0
+        if flat.numel() > 4:
+            flat[1], flat[2], flat[3], flat[4] = 0.0, float("nan"), float("inf"), -float("inf")
+        got = mesh_renderer.to_uint8(x.to(device)).cpu().numpy()
+        xn = np.nan_to_num(x.numpy(), nan=0.0, posinf=1.0, neginf=0.0)
+        want = (np.clip(xn, 0.0, 1.0) * np.float32(255.0)).astype(np.uint8)
+        assert got.dtype == np.uint8 and got.shape == want.shape
+        np.testing.assert_array_equal(got, want)
+    with pytest.raises(ValueError):
+        mesh_renderer.to_uint8(torch.zeros(4, dtype=torch.float64, device=device))
