@@ -37,6 +37,7 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kTile = 16;          // pixels per tile edge
 constexpr int kListCap = 512;      // LDS candidate list (triangle ids) per pass
+constexpr int kSoftStride = 28;    // floats per parked row in k_soft_backward (25 used; 28 = conflict-free b128)
 constexpr int kMaxLights = 4;
 constexpr float kEps = 1e-10f;     // rasterize.py:211
 constexpr float kNormEps = 1e-12f;
@@ -325,6 +326,25 @@ __global__ __launch_bounds__(kThreads) void k_soft_backward(
   LightSet ls;
   load_lights(lpos, lint, g.img, L, ls);
   const int lane = (int)threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+
+  // Reduction of a triangle's 39 partials over the wavefront's 64 pixels (see the end of the
+  // candidate loop): every pixel lane parks kSoftFactors values in an LDS row, then lane o < 39
+  // sums factor[fa] * factor[fb] over the 64 rows.  27 of the 39 partials are outer products
+  // sb[corner] x (d/d normal, position, diffuse): they are parked as 3 + 9 factors and
+  // multiplied in the reduction; the 12 clip partials are parked as they are and multiplied by
+  // the constant 1 in slot 24.  (Before: 39 wave butterflies of 6 ds_bpermute + 6 adds each and
+  // 39 single-lane atomics per (wavefront, triangle).)
+  __shared__ __attribute__((aligned(16))) float s_stage[kThreads / 64][64 * kSoftStride];
+  float *stage = s_stage[wave];
+  const int o_corner = lane / 13, o_comp = lane - 13 * o_corner;   // output o = corner * 13 + comp
+  const int fa = (o_comp < 4) ? 12 + 4 * min(o_corner, 2) + o_comp : min(o_corner, 2);
+  const int fb = (o_comp < 4) ? 24 : 3 + (o_comp - 4);
+  const float *col_a = stage + fa, *col_b = stage + fb;
+  // where lane o's sum goes: dclip[.., 4] for comp 0..3, then dnormals / dpositions / ddiffuse [.., 3]
+  float *out_base = o_comp < 4 ? dclip : (o_comp < 7 ? dnormals : (o_comp < 10 ? dpositions : ddiffuse));
+  const int out_stride = o_comp < 4 ? 4 : 3;
+  const int out_off = o_comp < 4 ? o_comp : (o_comp - 4) % 3;
 
   float4 go = make_float4(0.f, 0.f, 0.f, 0.f), out = go, ax = make_float4(0.f, 1.f, 1.f, 0.f);
   if (g.in_image) {
@@ -349,13 +369,15 @@ __global__ __launch_bounds__(kThreads) void k_soft_backward(
         Pair p;
         const bool live = g.in_image && eval_pair(r, cr, ls, pr, g.px, g.py, p);
         if (!__ballot(live)) continue;  // no pixel of this wavefront touches the triangle
-        // gradient of this pixel's output w.r.t. the triangle's 39 inputs:
-        // gv[k][0..3] clip xyzw, [4..6] normal, [7..9] position, [10..12] diffuse
-        float gv[3][13];
+        // this lane's corner vertex id for the commit at the end (latency hidden by the math)
+        const int my_vertex = (lane < 39) ? tris[3 * t + o_corner] : 0;
+        // gradient of this pixel's output w.r.t. the triangle's 39 inputs, as parked factors:
+        // f[0..2] sb[corner] | f[3..11] d/d (normal, position, diffuse) before the sb factor |
+        // f[12 + 4 corner + c] d/d clip xyzw of the corner | f[24] = 1
+        float f[kSoftStride];
 #pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-          for (int c = 0; c < 13; ++c) gv[a][c] = 0.f;
+        for (int k = 0; k < kSoftStride; ++k) f[k] = 0.f;
+        f[24] = 1.0f;
         if (live) {
           const float e = expf(p.logit - m);
           const float wgt = p.D * e;
@@ -404,14 +426,17 @@ __global__ __launch_bounds__(kThreads) void k_soft_backward(
             for (int c = 0; c < 3; ++c) g_nraw[c] = (p.nn > kNormEps ? (g_N[c] - p.N[c] * nd) : g_N[c]) * inn;
           }
 #pragma unroll
-          for (int a = 0; a < 3; ++a) {
+          for (int c = 0; c < 3; ++c) {
+            f[3 + c] = g_nraw[c];
+            f[6 + c] = g_pos[c];
+            f[9 + c] = g_kd[c];
+          }
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-              gv[a][4 + c] = g_nraw[c] * p.sb[a];
-              gv[a][7 + c] = g_pos[c] * p.sb[a];
-              gv[a][10 + c] = g_kd[c] * p.sb[a];
+          for (int a = 0; a < 3; ++a) {
+            f[a] = p.sb[a];
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
               g_sb[a] += g_nraw[c] * cr.c[a][c] + g_pos[c] * cr.c[a][3 + c] + g_kd[c] * cr.c[a][6 + c];
-            }
           }
           // ---- depth: z = 0.5 - (sb . zn) / 2 ----
           float g_zn[3];
@@ -488,29 +513,36 @@ __global__ __launch_bounds__(kThreads) void k_soft_backward(
 #pragma unroll
           for (int a = 0; a < 3; ++a) {
             const float iw = 1.0f / r.w[a];
-            gv[a][0] = g_x2[a] * iw;
-            gv[a][1] = g_y2[a] * iw;
-            gv[a][2] = g_zn[a] * iw;
-            gv[a][3] = g_w4[a] - (g_x2[a] * r.x[a] + g_y2[a] * r.y[a] + g_zn[a] * r.zn[a]) * iw;
+            f[12 + 4 * a + 0] = g_x2[a] * iw;
+            f[12 + 4 * a + 1] = g_y2[a] * iw;
+            f[12 + 4 * a + 2] = g_zn[a] * iw;
+            f[12 + 4 * a + 3] = g_w4[a] - (g_x2[a] * r.x[a] + g_y2[a] * r.y[a] + g_zn[a] * r.zn[a]) * iw;
           }
         }
-        // sum the 39 partials over the wavefront's 64 pixels, one lane commits them
-        int vi[3] = {0, 0, 0};
-        if (lane == 0) { vi[0] = tris[3 * t]; vi[1] = tris[3 * t + 1]; vi[2] = tris[3 * t + 2]; }
+        // park the row (zeros for pixels the triangle does not touch), then lane o sums its
+        // product over the 64 rows and commits it with one atomic
+        {
+          float4 *row = (float4 *)(stage + lane * kSoftStride);
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-#pragma unroll
-          for (int c = 0; c < 13; ++c) {
-            const float s = wave_sum(gv[a][c]);
-            if (lane == 0 && s != 0.0f && (unsigned)vi[a] < (unsigned)V) {
-              const size_t vtx = (size_t)g.img * V + vi[a];
-              if (c < 4) atomicAdd(&dclip[vtx * 4 + c], s);
-              else if (c < 7) atomicAdd(&dnormals[vtx * 3 + (c - 4)], s);
-              else if (c < 10) atomicAdd(&dpositions[vtx * 3 + (c - 7)], s);
-              else atomicAdd(&ddiffuse[vtx * 3 + (c - 10)], s);
-            }
-          }
+          for (int q = 0; q < kSoftStride / 4; ++q)
+            row[q] = make_float4(f[4 * q], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3]);
         }
+        __builtin_amdgcn_wave_barrier();  // LDS executes one wavefront's operations in order
+        float sum = 0.0f;
+#pragma unroll
+        for (int pb = 0; pb < 64; pb += 8) {
+          float ra[8], rb[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            ra[j] = col_a[(pb + j) * kSoftStride];
+            rb[j] = col_b[(pb + j) * kSoftStride];
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) sum = fmaf(ra[j], rb[j], sum);
+        }
+        __builtin_amdgcn_wave_barrier();  // the next candidate overwrites the rows
+        if (lane < 39 && sum != 0.0f && (unsigned)my_vertex < (unsigned)V)
+          atomicAdd(out_base + ((size_t)g.img * V + my_vertex) * out_stride + out_off, sum);
       }
       n = 0;
       __syncthreads();
