@@ -481,11 +481,15 @@ __global__ __launch_bounds__(kThreads) void k_soft_backward(
           }
           // ---- squared distance and t of the nearest edge (rasterize.py:169-176) ----
           {
-            const int ia = p.edge, ib = (p.edge + 1) % 3;
-            const float ax2 = r.x[ia], ay2 = r.y[ia], bx = r.x[ib], by = r.y[ib];
+            // selects, not r.x[p.edge]: a dynamically indexed register array lives in scratch memory
+            const int ia = p.edge, ib = (ia == 0) ? 1 : (ia == 1 ? 2 : 0);
+            const float ax2 = ia == 0 ? r.x[0] : (ia == 1 ? r.x[1] : r.x[2]);
+            const float ay2 = ia == 0 ? r.y[0] : (ia == 1 ? r.y[1] : r.y[2]);
+            const float bx = ia == 0 ? r.x[1] : (ia == 1 ? r.x[2] : r.x[0]);
+            const float by = ia == 0 ? r.y[1] : (ia == 1 ? r.y[2] : r.y[0]);
             const float abx = bx - ax2, aby = by - ay2;
             const float L2 = abx * abx + aby * aby;
-            const float tt = p.t[p.edge];
+            const float tt = ia == 0 ? p.t[0] : (ia == 1 ? p.t[1] : p.t[2]);
             const float dvx = ax2 + tt * abx - g.px, dvy = ay2 + tt * aby - g.py;
             const float gxx = 2.0f * dvx * g_d2, gxy = 2.0f * dvy * g_d2;  // d/d nearest point
             float gax = gxx, gay = gxy;                                   // direct dependence on a
