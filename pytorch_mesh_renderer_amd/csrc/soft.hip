@@ -174,7 +174,9 @@ __device__ __forceinline__ bool eval_pair(const SoftRec &r, const Corners &cr, c
 #pragma unroll
   for (int c = 0; c < 3; ++c) o.N[c] = o.nraw[c] * inn;
   o.lum = 0.f;
-  for (int l = 0; l < ls.L; ++l) {  // rasterize.py:197-206
+#pragma unroll
+  for (int l = 0; l < kMaxLights; ++l) {  // rasterize.py:197-206 (unrolled: static register indices)
+    if (l >= ls.L) break;
     const float vx = ls.pos[l][0] - o.pos[0], vy = ls.pos[l][1] - o.pos[1], vz = ls.pos[l][2] - o.pos[2];
     const float ivn = 1.0f / fmaxf(sqrtf(vx * vx + vy * vy + vz * vz), kNormEps);
     const float ndl = fminf(fmaxf((vx * o.N[0] + vy * o.N[1] + vz * o.N[2]) * ivn, 0.0f), 1.0f);
@@ -309,7 +311,10 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-__global__ __launch_bounds__(kThreads) void k_soft_backward(
+#ifndef MR_SOFT_BWD_WAVES
+#define MR_SOFT_BWD_WAVES 1
+#endif
+__global__ __launch_bounds__(kThreads, MR_SOFT_BWD_WAVES) void k_soft_backward(
     const SoftRec *__restrict__ recs, const CornerRec *__restrict__ corners,
     const float *__restrict__ lpos, const float *__restrict__ lint, const int32_t *__restrict__ tris,
     int V, int T, int W, int H, int L, SoftParams pr, int tiles_x, int tiles_per_image, int n_tiles,
@@ -397,7 +402,9 @@ __global__ __launch_bounds__(kThreads) void k_soft_backward(
             g_kd[c] = g_c[c] * p.lum;
             g_lum += g_c[c] * p.kd[c];
           }
-          for (int l = 0; l < ls.L; ++l) {
+#pragma unroll
+          for (int l = 0; l < kMaxLights; ++l) {
+            if (l >= ls.L) break;
             const float v[3] = {ls.pos[l][0] - p.pos[0], ls.pos[l][1] - p.pos[1], ls.pos[l][2] - p.pos[2]};
             const float vn = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
             const float ivn = 1.0f / fmaxf(vn, kNormEps);
@@ -552,7 +559,10 @@ __global__ __launch_bounds__(kThreads) void k_soft_backward(
       __syncthreads();
     }
   }
-  for (int l = 0; l < L; ++l) {
+#pragma unroll
+  for (int l = 0; l < kMaxLights; ++l) {
+    if (l >= L) break;
+#pragma unroll
     for (int c = 0; c < 3; ++c) {
       const float s = wave_sum(g_lp[l][c]);
       if (lane == 0 && s != 0.0f) atomicAdd(&dlpos[((size_t)g.img * L + l) * 3 + c], s);
