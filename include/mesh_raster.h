@@ -137,6 +137,41 @@ int mr_shade_backward(const float *drgba, const int32_t *ids, const float *bary,
                       float *ddiffuse, float *light_grads, void *workspace,
                       size_t workspace_bytes, void *stream);
 
+/* ---- fused deferred shading with the specular term --------------------------------
+ * The same replacement as mr_shade_forward / mr_shade_backward for render() calls that pass
+ * specular_colors and shininess_coefficients (src/mesh_renderer/render.py:157-181, 199-228;
+ * phong_shader's specular term :326-372, including its L2 normalisation of the reflection .
+ * camera dot product ACROSS ALL PIXELS of an image, :342-348 -- one extra pass over the
+ * G-buffer each way).  Additional arguments:
+ *   specular         [B,V,3] f32  per-vertex specular colours
+ *   camera_position  [B,3]   f32  world-space eye
+ *   shininess        [B]     f32  one exponent per image (per-vertex exponents and exponents
+ *                                 that need a gradient are not covered by this entry point)
+ *   norms2           [B,L]   f32  forward: out, sum over all pixels of (reflection . camera)^2;
+ *                                 backward: in, the forward's values
+ *   dspecular        [B,V,3] f32 out
+ *   light_grads      [B, 6L+6] f32 out  per image: d light_positions (L x 3), d light_intensities
+ *                                 (L x 3), d ambient (3; 0 if NULL), d camera_position (3) */
+size_t mr_shade_specular_forward_workspace_bytes(int B, int V, int T, int W, int H);
+int mr_shade_specular_forward(const int32_t *ids, const float *bary, const float *normals,
+                              const float *positions, const float *diffuse, const float *specular,
+                              const int32_t *triangles, const float *light_positions,
+                              const float *light_intensities, const float *ambient,
+                              const float *camera_position, const float *shininess,
+                              int B, int V, int T, int W, int H, int L, float *rgba, float *norms2,
+                              void *workspace, size_t workspace_bytes, void *stream);
+size_t mr_shade_specular_backward_workspace_bytes(int B, int V, int T, int W, int H);
+int mr_shade_specular_backward(const float *drgba, const int32_t *ids, const float *bary,
+                               const float *clip, const float *normals, const float *positions,
+                               const float *diffuse, const float *specular,
+                               const int32_t *triangles, const float *light_positions,
+                               const float *light_intensities, const float *ambient,
+                               const float *camera_position, const float *shininess,
+                               const float *norms2, int B, int V, int T, int W, int H, int L,
+                               float *dclip, float *dnormals, float *dpositions, float *ddiffuse,
+                               float *dspecular, float *light_grads, void *workspace,
+                               size_t workspace_bytes, void *stream);
+
 /* ---- SoftRas renderer ---------------------------------------------------------------
  * Replaces rasterize_batch / rasterize of the reference's second renderer
  * (src/soft_mesh_renderer/rasterize.py:14-110, 212-424) and the autograd graph behind it.

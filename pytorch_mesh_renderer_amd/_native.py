@@ -88,6 +88,14 @@ def lib():
         L.mr_l1_loss_forward.restype = ci
         L.mr_l1_loss_backward.argtypes = [vp, sz, vp, vp, vp]
         L.mr_l1_loss_backward.restype = ci
+        L.mr_shade_specular_forward_workspace_bytes.argtypes = [ci] * 5
+        L.mr_shade_specular_forward_workspace_bytes.restype = sz
+        L.mr_shade_specular_forward.argtypes = [vp] * 12 + [ci] * 6 + [vp, vp, vp, sz, vp]
+        L.mr_shade_specular_forward.restype = ci
+        L.mr_shade_specular_backward_workspace_bytes.argtypes = [ci] * 5
+        L.mr_shade_specular_backward_workspace_bytes.restype = sz
+        L.mr_shade_specular_backward.argtypes = [vp] * 15 + [ci] * 6 + [vp] * 6 + [vp, sz, vp]
+        L.mr_shade_specular_backward.restype = ci
         L.mr_export_u8.argtypes = [vp, sz, vp, vp]
         L.mr_export_u8.restype = ci
         _lib = L
@@ -271,6 +279,66 @@ def shade_backward(drgba, ids, bary, clip, normals, positions, diffuse, triangle
     dlint = lg[:, 3 * nl:6 * nl].reshape(B, nl, 3)
     damb = lg[:, 6 * nl:] if ambient is not None else None
     return dclip, dn, dp, dd, dlpos, dlint, damb
+
+
+def shade_specular_forward(ids, bary, normals, positions, diffuse, specular, triangles, light_positions,
+                           light_intensities, ambient, camera_position, shininess):
+    """Fused interpolation + Phong with the specular term -> (rgba [B,H,W,4], norms2 [B,L])."""
+    tensors = [ids, bary, normals, positions, diffuse, specular, triangles, light_positions,
+               light_intensities, camera_position, shininess]
+    dev = _require_device(*(tensors + ([ambient] if ambient is not None else [])))
+    L = lib()
+    (ids, bary, normals, positions, diffuse, specular, triangles, light_positions, light_intensities,
+     camera_position, shininess) = [t.contiguous() for t in tensors]
+    ambient = ambient.contiguous() if ambient is not None else None
+    B, H, W = ids.shape
+    V, T, nl = normals.shape[1], triangles.shape[0], light_positions.shape[1]
+    rgba = torch.empty(B, H, W, 4, dtype=torch.float32, device=dev)
+    norms2 = torch.empty(B, nl, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        need = L.mr_shade_specular_forward_workspace_bytes(B, V, T, W, H)
+        ws, have = _workspace(dev, need)
+        rc = L.mr_shade_specular_forward(
+            _ptr(ids), _ptr(bary), _ptr(normals), _ptr(positions), _ptr(diffuse), _ptr(specular),
+            _ptr(triangles), _ptr(light_positions), _ptr(light_intensities), _ptr(ambient),
+            _ptr(camera_position), _ptr(shininess), B, V, T, W, H, nl, _ptr(rgba), _ptr(norms2),
+            _ptr(ws), have, _stream(dev))
+    _check(rc, "mr_shade_specular_forward")
+    return rgba, norms2
+
+
+def shade_specular_backward(drgba, ids, bary, clip, normals, positions, diffuse, specular, triangles,
+                            light_positions, light_intensities, ambient, camera_position, shininess,
+                            norms2):
+    """-> (dclip [B,V,4], dnormals, dpositions, ddiffuse, dspecular [B,V,3], dlight_positions,
+    dlight_intensities [B,L,3], dambient [B,3] or None, dcamera_position [B,3])."""
+    tensors = [drgba, ids, bary, clip, normals, positions, diffuse, specular, triangles,
+               light_positions, light_intensities, camera_position, shininess, norms2]
+    dev = _require_device(*(tensors + ([ambient] if ambient is not None else [])))
+    L = lib()
+    (drgba, ids, bary, clip, normals, positions, diffuse, specular, triangles, light_positions,
+     light_intensities, camera_position, shininess, norms2) = [t.contiguous() for t in tensors]
+    ambient = ambient.contiguous() if ambient is not None else None
+    B, H, W = ids.shape
+    V, T, nl = normals.shape[1], triangles.shape[0], light_positions.shape[1]
+    dclip = torch.empty(B, V, 4, dtype=torch.float32, device=dev)
+    dn, dp, dd, dsp = [torch.empty(B, V, 3, dtype=torch.float32, device=dev) for _ in range(4)]
+    lg = torch.empty(B, 6 * nl + 6, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        need = L.mr_shade_specular_backward_workspace_bytes(B, V, T, W, H)
+        ws, have = _workspace(dev, need)
+        rc = L.mr_shade_specular_backward(
+            _ptr(drgba), _ptr(ids), _ptr(bary), _ptr(clip), _ptr(normals), _ptr(positions),
+            _ptr(diffuse), _ptr(specular), _ptr(triangles), _ptr(light_positions),
+            _ptr(light_intensities), _ptr(ambient), _ptr(camera_position), _ptr(shininess),
+            _ptr(norms2), B, V, T, W, H, nl, _ptr(dclip), _ptr(dn), _ptr(dp), _ptr(dd), _ptr(dsp),
+            _ptr(lg), _ptr(ws), have, _stream(dev))
+    _check(rc, "mr_shade_specular_backward")
+    dlpos = lg[:, :3 * nl].reshape(B, nl, 3)
+    dlint = lg[:, 3 * nl:6 * nl].reshape(B, nl, 3)
+    damb = lg[:, 6 * nl:6 * nl + 3] if ambient is not None else None
+    dcam = lg[:, 6 * nl + 3:]
+    return dclip, dn, dp, dd, dsp, dlpos, dlint, damb, dcam
 
 
 def soft_max_lights():

@@ -166,6 +166,63 @@ int mr_shade_backward(const float *drgba, const int32_t *ids, const float *bary,
                                    (hipStream_t)stream);
 }
 
+size_t mr_shade_specular_forward_workspace_bytes(int B, int V, int T, int W, int H) {
+  if (bad_dims(B, V, T, W, H)) return 0;
+  return mr::shade_specular_forward_ws(B, V, T, W, H);
+}
+
+int mr_shade_specular_forward(const int32_t *ids, const float *bary, const float *normals,
+                              const float *positions, const float *diffuse, const float *specular,
+                              const int32_t *triangles, const float *light_positions,
+                              const float *light_intensities, const float *ambient,
+                              const float *camera_position, const float *shininess, int B, int V,
+                              int T, int W, int H, int L, float *rgba, float *norms2, void *workspace,
+                              size_t workspace_bytes, void *stream) {
+  if (bad_dims(B, V, T, W, H) || T < 1 || V < 1 || L < 1 || L > mr::shade_max_lights())
+    return MR_EINVAL;
+  if (B == 0) return MR_OK;
+  if (!ids || !bary || !normals || !positions || !diffuse || !specular || !triangles ||
+      !light_positions || !light_intensities || !camera_position || !shininess || !rgba || !norms2)
+    return MR_EINVAL;
+  const int rc = check_ws(workspace, workspace_bytes, mr::shade_specular_forward_ws(B, V, T, W, H));
+  if (rc != MR_OK) return rc;
+  return mr::launch_shade_specular_forward(ids, bary, normals, positions, diffuse, specular, triangles,
+                                           light_positions, light_intensities, ambient,
+                                           camera_position, shininess, B, V, T, W, H, L, rgba, norms2,
+                                           workspace, (hipStream_t)stream);
+}
+
+size_t mr_shade_specular_backward_workspace_bytes(int B, int V, int T, int W, int H) {
+  if (bad_dims(B, V, T, W, H)) return 0;
+  return mr::shade_specular_backward_ws(B, V, T, W, H);
+}
+
+int mr_shade_specular_backward(const float *drgba, const int32_t *ids, const float *bary,
+                               const float *clip, const float *normals, const float *positions,
+                               const float *diffuse, const float *specular,
+                               const int32_t *triangles, const float *light_positions,
+                               const float *light_intensities, const float *ambient,
+                               const float *camera_position, const float *shininess,
+                               const float *norms2, int B, int V, int T, int W, int H, int L,
+                               float *dclip, float *dnormals, float *dpositions, float *ddiffuse,
+                               float *dspecular, float *light_grads, void *workspace,
+                               size_t workspace_bytes, void *stream) {
+  if (bad_dims(B, V, T, W, H) || T < 1 || V < 1 || L < 1 || L > mr::shade_max_lights())
+    return MR_EINVAL;
+  if (B == 0) return MR_OK;
+  if (!drgba || !ids || !bary || !clip || !normals || !positions || !diffuse || !specular ||
+      !triangles || !light_positions || !light_intensities || !camera_position || !shininess ||
+      !norms2 || !dclip || !dnormals || !dpositions || !ddiffuse || !dspecular || !light_grads)
+    return MR_EINVAL;
+  const int rc = check_ws(workspace, workspace_bytes, mr::shade_specular_backward_ws(B, V, T, W, H));
+  if (rc != MR_OK) return rc;
+  return mr::launch_shade_specular_backward(drgba, ids, bary, clip, normals, positions, diffuse,
+                                            specular, triangles, light_positions, light_intensities,
+                                            ambient, camera_position, shininess, norms2, B, V, T, W,
+                                            H, L, dclip, dnormals, dpositions, ddiffuse, dspecular,
+                                            light_grads, workspace, (hipStream_t)stream);
+}
+
 int mr_soft_max_lights(void) { return mr::soft_max_lights(); }
 
 size_t mr_soft_workspace_bytes(int B, int V, int T, int W, int H) {

@@ -157,7 +157,8 @@ __global__ __launch_bounds__(kRunThreads, Fn::kMinWavesPerSimd) void k_accumulat
 // (N - kFactors) / 4 LDS writes per pixel and, above all, N live registers in the pixel math.
 // Triangle data is still fetched once per vertical run and kept in registers.
 //
-// Extra functor members: kFactors, kFactorStride (multiple of 4, >= kFactors),
+// Extra functor members: kCountBackground (if true, Image has an int n_bg that counts the pixels
+// prepare() rejected), kFactors, kFactorStride (multiple of 4, >= kFactors),
 //   static void factor_pair(int o, int &ia, int &ib);            // 0 <= o < kN
 //   void factors(const Pixel &, const Triangle &, float (&f)[kFactorStride], Image &) const;
 #ifndef MR_PROBE_ROWS
@@ -206,6 +207,7 @@ __global__ __launch_bounds__(kRunThreads, Fn::kMinWavesPerSimd) void k_accumulat
     int tri = -1;
     typename Fn::Pixel p;
     const bool valid = fn.prepare(raw, T, tri, p) && in_range;
+    if (Fn::kCountBackground && in_range && !valid) image_sums.n_bg += 1;  // see Fn::end_image
     if (!__ballot(valid)) continue;  // nothing in this row segment (background)
     if (valid && tri != run_tri) {
       run_tri = tri;

@@ -180,6 +180,7 @@ struct ShadeGradFn {
 #define MR_SHADE_WAVES 3
 #endif
   static constexpr int kMinWavesPerSimd = MR_SHADE_WAVES;
+  static constexpr bool kCountBackground = false;
   const float4 *__restrict__ drgba;   // [B,H,W,4], image rows (flipped w.r.t. the G-buffer)
   const int32_t *__restrict__ ids;
   const F3 *__restrict__ bary;
@@ -203,6 +204,7 @@ struct ShadeGradFn {
     BwdTriangle bt;
   };
   struct Image {
+    int n_bg;                              // unused (kCountBackground = false)
     float lp[L][3], li[L][3], amb[3];      // this image's lights (loaded once per lane)
     float dpos[L][3], dcol[L][3], damb[3];  // per-lane partial sums
   };

@@ -1,0 +1,679 @@
+// Fused deferred shading WITH the specular term, for gfx950 (MI355X).
+//
+// Same job as shade.hip (attribute interpolation + Phong straight from the G-buffer, forward
+// and backward) for render() calls that pass specular_colors / shininess_coefficients
+// (reference: src/mesh_renderer/render.py:157-181, 199-228 and phong_shader :326-372).
+// The reference's specular term has a global coupling: the per-pixel "reflection . camera
+// direction" dot product is L2-normalised ACROSS ALL PIXELS of an image, background included
+// (render.py:342-348, dim=2 is the pixel axis), before it is clamped and raised to the
+// shininess.  That costs one extra pass over the G-buffer each way:
+//
+//   forward   k_spec_pixels<L, kNorms>   sum over all pixels of rdc^2 per (image, light)
+//             k_spec_pixels<L, kShade>   RGBA, using those norms
+//   backward  k_spec_pixels<L, kGsum>    G = sum_p (dLoss/d rn_p) rdc_p per (image, light)
+//             k_accumulate_rows<SpecGradFn<L>>   everything else: the pixel's shading is
+//                                        recomputed and back-propagated to 12 interpolated
+//                                        attributes (normal, position, diffuse, specular), the
+//                                        barycentrics, the clip-space corners (cpp:202-269), the
+//                                        lights and the camera position; 45 sums per triangle
+//                                        (3 barycentrics x 15 factors) through the same
+//                                        parked-factor reduction as the diffuse kernel
+//             k_spec_scatter             45 sums per touched triangle -> vertex arrays
+//
+// Through the norm, EVERY pixel (masked ones and the background too) receives
+// d rdc_p = d rn_p / norm - rdc_p G / norm^3; background pixels all carry the same attributes
+// (-1), so their contribution to the light / camera gradients is evaluated once per lane and
+// multiplied by the number of background pixels the lane has seen.
+//
+// Scope of the fused path: shininess per image (float, 0-D or [B]; not differentiated), 1..4
+// lights; per-vertex shininess and a shininess that requires grad take the composed path.
+// fp32 with FMA contraction and 1-ulp v_rcp / v_sqrt / v_exp / v_log: parity budget 1e-4.
+#include "corner_rec.h"
+
+namespace mr {
+namespace {
+
+constexpr int kThreads = 256;
+constexpr float kNormEps = 1e-12f;         // torch.nn.functional.normalize default eps
+constexpr float kDegenerateCutoff = 0.9f;  // rasterize_triangles.cpp:13
+constexpr int kAttr = 12;                  // normal, position, diffuse, specular
+
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+
+// torch.pow(x, y) for x in [0, 1]: pow(x, 0) = 1, pow(0, y > 0) = 0, pow(0, y < 0) = inf.
+__device__ __forceinline__ float pow01(float x, float y) {
+  if (y == 0.0f) return 1.0f;
+  return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));  // log2(0) = -inf: exp2 gives 0 / inf
+}
+
+struct alignas(16) SpecCornerRec {
+  float4 q[9];  // 36 floats, row-major [corner][attribute]
+};
+struct SpecCorners {
+  float c[3][kAttr];
+};
+
+__device__ __forceinline__ void load_spec_corners(const SpecCornerRec *__restrict__ rec, SpecCorners &o) {
+#pragma unroll
+  for (int q = 0; q < 9; ++q) {
+    const float4 f = rec->q[q];
+    const float v[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o.c[(4 * q + j) / kAttr][(4 * q + j) % kAttr] = v[j];
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void k_spec_corner_setup(
+    const F3 *__restrict__ normals, const F3 *__restrict__ positions, const F3 *__restrict__ diffuse,
+    const F3 *__restrict__ specular, const int32_t *__restrict__ tris, int B, int V, int T,
+    SpecCornerRec *__restrict__ out) {
+  const long gid = (long)blockIdx.x * kThreads + threadIdx.x;
+  if (gid >= (long)B * T) return;
+  const int b = (int)(gid / T);
+  const int t = (int)(gid - (long)b * T);
+  float v[36];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    int vi = tris[3 * t + k];
+    if ((unsigned)vi >= (unsigned)V) vi = 0;
+    const size_t at = (size_t)b * V + vi;
+    const F3 n = normals[at], p = positions[at], d = diffuse[at], sp = specular[at];
+    v[k * 12 + 0] = n.x; v[k * 12 + 1] = n.y; v[k * 12 + 2] = n.z;
+    v[k * 12 + 3] = p.x; v[k * 12 + 4] = p.y; v[k * 12 + 5] = p.z;
+    v[k * 12 + 6] = d.x; v[k * 12 + 7] = d.y; v[k * 12 + 8] = d.z;
+    v[k * 12 + 9] = sp.x; v[k * 12 + 10] = sp.y; v[k * 12 + 11] = sp.z;
+  }
+#pragma unroll
+  for (int q = 0; q < 9; ++q) out[gid].q[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+}
+
+// Pointers to the per-image scene parameters (all wave-uniform once indexed by the image).
+struct SpecSceneIn {
+  const float *__restrict__ light_pos;   // [B,L,3]
+  const float *__restrict__ light_col;   // [B,L,3]
+  const float *__restrict__ ambient;     // [B,3] or nullptr
+  const float *__restrict__ camera;      // [B,3]
+  const float *__restrict__ shininess;   // [B]
+  const float *__restrict__ norms2;      // [B,L]  sum over pixels of rdc^2 (null in the norm pass)
+  const float *__restrict__ gsum;        // [B,L]  G (null outside the final backward pass)
+};
+
+template <int L>
+struct SpecScene {
+  float lp[L][3], li[L][3], amb[3], cam[3], shin;
+  float inv_norm[L];   // 1 / max(sqrt(norms2), eps)
+  float gcoef[L];      // G / norm^3, or 0 where the norm sits on its eps clamp
+};
+
+template <int L>
+__device__ __forceinline__ void load_scene(const SpecSceneIn &in, int img, SpecScene<L> &sc) {
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      sc.lp[l][c] = in.light_pos[((size_t)img * L + l) * 3 + c];
+      sc.li[l][c] = in.light_col[((size_t)img * L + l) * 3 + c];
+    }
+    float inv = 0.0f, gc = 0.0f;
+    if (in.norms2) {
+      const float nrm = fast_sqrt(in.norms2[(size_t)img * L + l]);
+      inv = fast_rcp(fmaxf(nrm, kNormEps));
+      if (in.gsum && nrm > kNormEps) gc = in.gsum[(size_t)img * L + l] * inv * inv * inv;
+    }
+    sc.inv_norm[l] = inv;
+    sc.gcoef[l] = gc;
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    sc.amb[c] = in.ambient ? in.ambient[(size_t)img * 3 + c] : 0.0f;
+    sc.cam[c] = in.camera[(size_t)img * 3 + c];
+  }
+  sc.shin = in.shininess[img];
+}
+
+// alpha = clamp(sum(2*bary), 0, 1); attr = alpha * interp + (1 - alpha) * (-1)
+// (rasterize.py:137-150 with render.py:197's background of -1).
+__device__ __forceinline__ void interpolate12(const SpecCorners &cr, const F3 b, float &pre, float &alpha,
+                                              float (&at)[kAttr]) {
+  pre = (2.0f * b.x + 2.0f * b.y) + 2.0f * b.z;
+  alpha = fminf(fmaxf(pre, 0.0f), 1.0f);
+  const float one_m = 1.0f - alpha;
+#pragma unroll
+  for (int a = 0; a < kAttr; ++a) {
+    const float interp = (cr.c[0][a] * b.x + cr.c[1][a] * b.y) + cr.c[2][a] * b.z;
+    at[a] = alpha * interp - one_m;
+  }
+}
+
+// Geometry of one pixel that does not depend on the light.
+struct PixelFrame {
+  float N[3], nn, inv_nn;     // normalised normal (render.py:201)
+  float Cd[3], cn, inv_cn;    // direction to the camera (render.py:333-336)
+};
+__device__ __forceinline__ void pixel_frame(const float *at, const float *cam, PixelFrame &f) {
+  f.nn = fast_sqrt(at[0] * at[0] + at[1] * at[1] + at[2] * at[2]);
+  f.inv_nn = fast_rcp(fmaxf(f.nn, kNormEps));
+  const float c[3] = {cam[0] - at[3], cam[1] - at[4], cam[2] - at[5]};
+  f.cn = fast_sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+  f.inv_cn = fast_rcp(fmaxf(f.cn, kNormEps));
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    f.N[k] = at[k] * f.inv_nn;
+    f.Cd[k] = c[k] * f.inv_cn;
+  }
+}
+
+// One light at one pixel (render.py:304-341).
+struct LightTerm {
+  float D[3], vn, inv_vn, pre, ndl;   // direction to the light, N . D and its clamp
+  float M[3], mn, inv_mn;             // mirror reflection direction
+  float rdc;                          // M . Cd, BEFORE the across-pixels normalisation
+};
+__device__ __forceinline__ void light_term(const float *at, const PixelFrame &f, const float *lp, LightTerm &o) {
+  const float v[3] = {lp[0] - at[3], lp[1] - at[4], lp[2] - at[5]};
+  o.vn = fast_sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+  o.inv_vn = fast_rcp(fmaxf(o.vn, kNormEps));
+#pragma unroll
+  for (int k = 0; k < 3; ++k) o.D[k] = v[k] * o.inv_vn;
+  o.pre = f.N[0] * o.D[0] + f.N[1] * o.D[1] + f.N[2] * o.D[2];
+  o.ndl = fminf(fmaxf(o.pre, 0.0f), 1.0f);
+  float m[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) m[k] = 2.0f * o.ndl * f.N[k] - o.D[k];
+  o.mn = fast_sqrt(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]);
+  o.inv_mn = fast_rcp(fmaxf(o.mn, kNormEps));
+#pragma unroll
+  for (int k = 0; k < 3; ++k) o.M[k] = m[k] * o.inv_mn;
+  o.rdc = o.M[0] * f.Cd[0] + o.M[1] * f.Cd[1] + o.M[2] * f.Cd[2];
+}
+
+// rn -> clamp -> where(ndl != 0) -> pow (render.py:342-366): value and d value / d rn.
+__device__ __forceinline__ void specularity(float rdc, float inv_norm, float ndl, float shin, float &spec,
+                                            float &dspec_drn) {
+  const float rn = rdc * inv_norm;
+  const float rc = fminf(fmaxf(rn, 0.0f), 1.0f);
+  const bool lit = ndl != 0.0f;
+  const float rw = lit ? rc : 0.0f;
+  spec = pow01(rw, shin);
+  // torch: d pow / d base = y * base^(y-1); clamp passes the gradient on [0, 1] inclusively
+  const float dpow = shin * pow01(rw, shin - 1.0f);
+  dspec_drn = (lit && rn >= 0.0f && rn <= 1.0f) ? dpow : 0.0f;
+}
+
+enum SpecPass { kNorms = 0, kShade = 1, kGsum = 2 };
+
+// One thread per pixel.  kNorms: per-(image, light) sum of rdc^2 over ALL pixels.  kShade: RGBA.
+// kGsum: per-(image, light) sum of (dLoss / d rn) * rdc.
+template <int L, int PASS>
+__global__ __launch_bounds__(kThreads) void k_spec_pixels(
+    const int32_t *__restrict__ ids, const F3 *__restrict__ bary,
+    const SpecCornerRec *__restrict__ corners, SpecSceneIn scene_in, int T, int W, int H, int x_blocks,
+    const float4 *__restrict__ drgba, float4 *__restrict__ rgba_out, float *__restrict__ sums_out) {
+  const int blk = (int)blockIdx.x;
+  const int img = blk / (x_blocks * H);
+  const int rem = blk - img * (x_blocks * H);
+  const int y = rem / x_blocks, xb = rem - y * x_blocks;
+  const int x = xb * kThreads + (int)threadIdx.x;
+  SpecScene<L> sc;
+  load_scene(scene_in, img, sc);
+  float part[L];
+#pragma unroll
+  for (int l = 0; l < L; ++l) part[l] = 0.0f;
+  if (x < W) {
+    const size_t pix = ((size_t)img * H + y) * W + x;
+    const F3 b = bary[pix];
+    int t = ids[pix];
+    float at[kAttr], pre = 0.0f, alpha = 0.0f;
+    const bool live = ((2.0f * b.x + 2.0f * b.y) + 2.0f * b.z) > 0.0f && (unsigned)t < (unsigned)T;
+    if (live) {
+      SpecCorners cr;
+      load_spec_corners(corners + (size_t)img * T + t, cr);
+      interpolate12(cr, b, pre, alpha, at);
+    } else {
+#pragma unroll
+      for (int a = 0; a < kAttr; ++a) at[a] = -1.0f;  // the background of render.py:197
+    }
+    const bool mask = (at[6] >= 0.0f) || (at[7] >= 0.0f) || (at[8] >= 0.0f);  // render.py:215
+    const size_t out_pix = ((size_t)img * H + (H - 1 - y)) * W + x;            // render.py:384-386 flip
+    if (PASS == kNorms || mask) {
+      PixelFrame f;
+      pixel_frame(at, sc.cam, f);
+      float rgb[3] = {sc.amb[0] * at[6], sc.amb[1] * at[7], sc.amb[2] * at[8]};
+      float g[3] = {0.f, 0.f, 0.f};
+      if (PASS == kGsum) {
+        const float4 gg = drgba[out_pix];
+        g[0] = gg.x; g[1] = gg.y; g[2] = gg.z;
+      }
+#pragma unroll
+      for (int l = 0; l < L; ++l) {
+        LightTerm lt;
+        light_term(at, f, sc.lp[l], lt);
+        if (PASS == kNorms) {
+          part[l] = lt.rdc * lt.rdc;
+        } else {
+          float spec, dspec_drn;
+          specularity(lt.rdc, sc.inv_norm[l], lt.ndl, sc.shin, spec, dspec_drn);
+          if (PASS == kShade) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) rgb[c] += (at[6 + c] * lt.ndl + at[9 + c] * spec) * sc.li[l][c];
+          } else {
+            const float dspec = (g[0] * at[9] * sc.li[l][0] + g[1] * at[10] * sc.li[l][1]) + g[2] * at[11] * sc.li[l][2];
+            part[l] = dspec * dspec_drn * lt.rdc;
+          }
+        }
+      }
+      if (PASS == kShade) rgba_out[out_pix] = make_float4(rgb[0], rgb[1], rgb[2], 1.0f);
+    } else if (PASS == kShade) {
+      rgba_out[out_pix] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  if (PASS != kShade) {  // workgroup-uniform
+    __shared__ float s_part[kThreads / kWave][L];
+    const int lane = (int)threadIdx.x & (kWave - 1), wave = (int)threadIdx.x >> 6;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      float v = part[l];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+      if (lane == 0) s_part[wave][l] = v;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < L) {
+      float v = 0.0f;
+#pragma unroll
+      for (int w = 0; w < kThreads / kWave; ++w) v += s_part[w][threadIdx.x];
+      if (v != 0.0f) atomicAdd(&sums_out[(size_t)img * L + threadIdx.x], v);
+    }
+  }
+}
+
+// ---- the final backward pass, inside k_accumulate_rows (run_accum.h) -----------------------
+template <int L>
+struct SpecGradFn {
+  static constexpr int kN = 45;       // 36 attribute partials [corner][attr] + 9 clip partials
+  static constexpr int kStride = 48;
+  static constexpr int kSlots = 256;
+  static constexpr int kMinWavesPerSimd = 2;
+  static constexpr bool kCountBackground = true;
+  // parked per pixel: b[3] | y[12] = alpha * d/d attr | q[3] = clip brackets
+  static constexpr int kFactors = 18;
+  static constexpr int kFactorStride = 20;
+  __device__ static void factor_pair(int o, int &ia, int &ib) {
+    if (o < 36) { ia = o / 12; ib = 3 + o % 12; }
+    else { ia = (o - 36) / 3; ib = 15 + (o - 36) % 3; }
+  }
+  const float4 *__restrict__ drgba;   // [B,H,W,4], image rows (flipped w.r.t. the G-buffer)
+  const int32_t *__restrict__ ids;
+  const F3 *__restrict__ bary;
+  const SpecCornerRec *__restrict__ corners;
+  const BwdRec *__restrict__ recs;
+  SpecSceneIn scene_in;
+  float *__restrict__ light_grads;    // [B][L*6 + 6]: dpos (L x 3), dcol (L x 3), dambient (3), dcamera (3)
+  int T_, W, H;
+
+  struct Pixel {
+    F3 b, g;
+    int tri;
+  };
+  struct Raw {
+    F3 b;
+    int t;
+    float4 g;
+  };
+  struct Triangle {
+    SpecCorners cr;
+    BwdTriangle bt;
+  };
+  struct Image {
+    SpecScene<L> sc;
+    float dpos[L][3], dcol[L][3], damb[3], dcam[3];  // per-lane partial sums
+    int n_bg;                                         // background pixels this lane has seen
+  };
+
+  __device__ __forceinline__ void begin_image(int img, Image &im) const {
+    load_scene(scene_in, img, im.sc);
+#pragma unroll
+    for (int l = 0; l < L; ++l)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { im.dpos[l][c] = 0.f; im.dcol[l][c] = 0.f; }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { im.damb[c] = 0.f; im.dcam[c] = 0.f; }
+    im.n_bg = 0;
+  }
+
+  __device__ __forceinline__ void fetch(int img, int x, int y, size_t pix, Raw &r) const {
+    r.b = bary[pix];
+    r.t = ids[pix];
+    r.g = drgba[((size_t)img * H + (H - 1 - y)) * W + x];  // un-flip
+  }
+  __device__ __forceinline__ bool prepare(const Raw &r, int T, int &tri, Pixel &p) const {
+    const float pre = (2.0f * r.b.x + 2.0f * r.b.y) + 2.0f * r.b.z;
+    if (!(pre > 0.0f)) return false;  // background: counted by the kernel, handled in end_image
+    if ((unsigned)r.t >= (unsigned)T) return false;
+    p.b = r.b;
+    p.g.x = r.g.x; p.g.y = r.g.y; p.g.z = r.g.z;  // d/d alpha is dropped: the mask is not differentiable
+    p.tri = r.t;
+    tri = r.t;
+    return true;
+  }
+  __device__ __forceinline__ void load_triangle(int img, int tri, Triangle &t) const {
+    load_spec_corners(corners + (size_t)img * T_ + tri, t.cr);
+    load_bwd_triangle(recs + (size_t)img * T_ + tri, t.bt);
+  }
+
+  // Back-propagates (g = dLoss/d rgb of this pixel, plus the norm coupling) to the interpolated
+  // attributes `dat`, accumulating light / ambient / camera gradients in `im` scaled by `weight`.
+  __device__ __forceinline__ void shade_backward(const float (&at)[kAttr], const float (&g)[3], float weight,
+                                                 Image &im, float (&dat)[kAttr]) const {
+    const SpecScene<L> &sc = im.sc;
+    PixelFrame f;
+    pixel_frame(at, sc.cam, f);
+    float dN[3] = {0.f, 0.f, 0.f}, dP[3] = {0.f, 0.f, 0.f}, dCd[3] = {0.f, 0.f, 0.f};
+    float dKd[3] = {g[0] * sc.amb[0], g[1] * sc.amb[1], g[2] * sc.amb[2]};
+    float dKs[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) im.damb[c] += weight * g[c] * at[6 + c];
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      LightTerm lt;
+      light_term(at, f, sc.lp[l], lt);
+      float spec, dspec_drn;
+      specularity(lt.rdc, sc.inv_norm[l], lt.ndl, sc.shin, spec, dspec_drn);
+      float t_l = 0.f, dspec = 0.f;  // d/d ndl of the diffuse term, d/d spec
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        dKd[c] += g[c] * lt.ndl * sc.li[l][c];
+        dKs[c] += g[c] * spec * sc.li[l][c];
+        im.dcol[l][c] += weight * g[c] * (at[6 + c] * lt.ndl + at[9 + c] * spec);
+        t_l += g[c] * at[6 + c] * sc.li[l][c];
+        dspec += g[c] * at[9 + c] * sc.li[l][c];
+      }
+      // rn = rdc / norm with norm = |rdc over all pixels|: d rdc = d rn / norm - rdc G / norm^3
+      const float d_rdc = dspec * dspec_drn * sc.inv_norm[l] - lt.rdc * sc.gcoef[l];
+      float dM[3], dot_m = 0.f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        dM[k] = d_rdc * f.Cd[k];
+        dCd[k] += d_rdc * lt.M[k];
+        dot_m += lt.M[k] * dM[k];
+      }
+      // backward of m / max(|m|, eps), m = 2 ndl N - D
+      float dm[3], n_dot_dm = 0.f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        dm[k] = (lt.mn > kNormEps ? (dM[k] - lt.M[k] * dot_m) : dM[k]) * lt.inv_mn;
+        n_dot_dm += f.N[k] * dm[k];
+      }
+      const float d_ndl = t_l + 2.0f * n_dot_dm;
+      float dD[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        dN[k] += 2.0f * lt.ndl * dm[k];
+        dD[k] = -dm[k];
+      }
+      if (lt.pre >= 0.0f && lt.pre <= 1.0f) {  // torch.clamp passes the gradient inclusively
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          dN[k] += d_ndl * lt.D[k];
+          dD[k] += d_ndl * f.N[k];
+        }
+      }
+      float dd = 0.f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) dd += lt.D[k] * dD[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float dv = (lt.vn > kNormEps ? (dD[k] - lt.D[k] * dd) : dD[k]) * lt.inv_vn;
+        im.dpos[l][k] += weight * dv;
+        dP[k] -= dv;
+      }
+    }
+    {  // Cd = c / max(|c|, eps), c = camera - P
+      float dc_dot = 0.f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) dc_dot += f.Cd[k] * dCd[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float dc = (f.cn > kNormEps ? (dCd[k] - f.Cd[k] * dc_dot) : dCd[k]) * f.inv_cn;
+        im.dcam[k] += weight * dc;
+        dP[k] -= dc;
+      }
+    }
+    {
+      const float nd = f.N[0] * dN[0] + f.N[1] * dN[1] + f.N[2] * dN[2];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        dat[c] = (f.nn > kNormEps ? (dN[c] - f.N[c] * nd) : dN[c]) * f.inv_nn;
+        dat[3 + c] = dP[c];
+        dat[6 + c] = dKd[c];
+        dat[9 + c] = dKs[c];
+      }
+    }
+  }
+
+  __device__ __forceinline__ void factors(const Pixel &p, const Triangle &t, float (&f)[kFactorStride],
+                                          Image &im) const {
+    float pre, alpha, at[kAttr];
+    interpolate12(t.cr, p.b, pre, alpha, at);
+    // render.py:215 mask: where() sends no rgb gradient to a masked pixel (the norm coupling
+    // still reaches it)
+    const bool mask = (at[6] >= 0.0f) || (at[7] >= 0.0f) || (at[8] >= 0.0f);
+    const float g[3] = {mask ? p.g.x : 0.f, mask ? p.g.y : 0.f, mask ? p.g.z : 0.f};
+    float dat[kAttr];
+    shade_backward(at, g, 1.0f, im, dat);
+    // interpolation backward (rasterize.py:137-150); interp[a] + 1 = (at[a] + 1) / alpha
+    float dalpha_a = 0.f, db[3] = {0.f, 0.f, 0.f};
+    f[0] = p.b.x; f[1] = p.b.y; f[2] = p.b.z;
+#pragma unroll
+    for (int a = 0; a < kAttr; ++a) {
+      const float di = alpha * dat[a];
+      dalpha_a += dat[a] * (at[a] + 1.0f);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) db[k] += di * t.cr.c[k][a];
+      f[3 + a] = di;
+    }
+    const float dpre = (pre >= 0.0f && pre <= 1.0f) ? 2.0f * dalpha_a * fast_rcp(alpha) : 0.0f;
+    F3 dbary;
+    dbary.x = db[0] + dpre; dbary.y = db[1] + dpre; dbary.z = db[2] + dpre;
+    // rasterizer backward (cpp:162 skip rule, then cpp:202-269)
+    const bool skip = p.tri == 0 && (p.b.x + p.b.y) + p.b.z < kDegenerateCutoff;
+    float q[3];
+    raster_pixel_q(p.b, dbary, t.bt, skip ? 0.f : t.bt.inv, q);
+    f[15] = q[0]; f[16] = q[1]; f[17] = q[2];
+    f[18] = 0.f; f[19] = 0.f;
+  }
+
+  __device__ __forceinline__ void end_image(int img, Image &im) const {
+    if (im.n_bg > 0) {  // all background pixels carry the attributes -1: evaluate once, weight by the count
+      float at[kAttr], dat[kAttr];
+#pragma unroll
+      for (int a = 0; a < kAttr; ++a) at[a] = -1.0f;
+      const float g[3] = {0.f, 0.f, 0.f};
+      shade_backward(at, g, (float)im.n_bg, im, dat);
+    }
+    float *dst = light_grads + (size_t)img * (L * 6 + 6);
+    const int lane = lane_id();
+    auto reduce_add = [&](float v, int slot) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+      if (lane == 0 && v != 0.0f) atomicAdd(&dst[slot], v);
+    };
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        reduce_add(im.dpos[l][c], l * 3 + c);
+        reduce_add(im.dcol[l][c], L * 3 + l * 3 + c);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      reduce_add(im.damb[c], L * 6 + c);
+      reduce_add(im.dcam[c], L * 6 + 3 + c);
+    }
+  }
+};
+
+__global__ __launch_bounds__(kThreads) void k_spec_scatter(
+    const float *__restrict__ acc, const int32_t *__restrict__ tris, int B, int V, int T,
+    float *__restrict__ dnormals, float *__restrict__ dpositions, float *__restrict__ ddiffuse,
+    float *__restrict__ dspecular, float *__restrict__ dclip) {
+  const long gid = (long)blockIdx.x * kThreads + threadIdx.x;
+  if (gid >= (long)B * T) return;
+  const float4 *row = (const float4 *)(acc + gid * 48);  // 192-byte rows, 16-byte aligned
+  float a[48];
+  bool any = false;
+#pragma unroll
+  for (int q = 0; q < 12; ++q) {
+    const float4 v = row[q];
+    a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+    any |= (v.x != 0.f) | (v.y != 0.f) | (v.z != 0.f) | (v.w != 0.f);
+  }
+  if (!any) return;
+  const int b = (int)(gid / T);
+  const int t = (int)(gid - (long)b * T);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int vi = tris[3 * t + k];
+    if ((unsigned)vi >= (unsigned)V) continue;
+    const size_t v3 = ((size_t)b * V + vi) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      atomicAdd(&dnormals[v3 + c], a[k * 12 + c]);
+      atomicAdd(&dpositions[v3 + c], a[k * 12 + 3 + c]);
+      atomicAdd(&ddiffuse[v3 + c], a[k * 12 + 6 + c]);
+      atomicAdd(&dspecular[v3 + c], a[k * 12 + 9 + c]);
+    }
+    float *dc = dclip + ((size_t)b * V + vi) * 4;
+    atomicAdd(&dc[0], a[36 + k * 3 + 0]);
+    atomicAdd(&dc[1], a[36 + k * 3 + 1]);
+    atomicAdd(&dc[3], a[36 + k * 3 + 2]);
+  }
+}
+
+inline size_t spec_corner_bytes(int B, int T) { return align_up((size_t)B * T * sizeof(SpecCornerRec), 256); }
+inline size_t spec_acc_bytes(int B, int T) { return align_up((size_t)B * T * 48 * sizeof(float), 256); }
+inline size_t spec_sums_bytes(int B) { return align_up((size_t)B * 4 * sizeof(float), 256); }
+
+int launch_spec_corner_setup(const float *normals, const float *positions, const float *diffuse,
+                             const float *specular, const int32_t *tris, int B, int V, int T,
+                             SpecCornerRec *out, hipStream_t s) {
+  const long nbt = (long)B * T;
+  hipLaunchKernelGGL(k_spec_corner_setup, dim3((unsigned)((nbt + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+                     s, (const F3 *)normals, (const F3 *)positions, (const F3 *)diffuse, (const F3 *)specular,
+                     tris, B, V, T, out);
+  return check_launch();
+}
+
+template <int PASS>
+int launch_spec_pixels(int L, const int32_t *ids, const float *bary, const SpecCornerRec *corners,
+                       const SpecSceneIn &scene, int B, int T, int W, int H, const float *drgba, float *rgba,
+                       float *sums, hipStream_t s) {
+  const int x_blocks = (W + kThreads - 1) / kThreads;
+  const dim3 grid((unsigned)((size_t)x_blocks * H * B)), block(kThreads);
+#define MR_SPEC_PIXELS(NL)                                                                          \
+  hipLaunchKernelGGL((k_spec_pixels<NL, PASS>), grid, block, 0, s, ids, (const F3 *)bary, corners, scene, \
+                     T, W, H, x_blocks, (const float4 *)drgba, (float4 *)rgba, sums)
+  switch (L) {
+    case 1: MR_SPEC_PIXELS(1); break;
+    case 2: MR_SPEC_PIXELS(2); break;
+    case 3: MR_SPEC_PIXELS(3); break;
+    case 4: MR_SPEC_PIXELS(4); break;
+    default: return MR_EINVAL;
+  }
+#undef MR_SPEC_PIXELS
+  return check_launch();
+}
+
+}  // namespace
+
+size_t shade_specular_forward_ws(int B, int V, int T, int W, int H) {
+  (void)V; (void)W; (void)H;
+  return spec_corner_bytes(B, T);
+}
+
+int launch_shade_specular_forward(const int32_t *ids, const float *bary, const float *normals,
+                                  const float *positions, const float *diffuse, const float *specular,
+                                  const int32_t *tris, const float *light_pos, const float *light_col,
+                                  const float *ambient, const float *camera, const float *shininess,
+                                  int B, int V, int T, int W, int H, int L, float *rgba, float *norms2,
+                                  void *ws, hipStream_t s) {
+  if ((size_t)B * W * H == 0) return MR_OK;
+  SpecCornerRec *corners = (SpecCornerRec *)ws;
+  int rc = launch_spec_corner_setup(normals, positions, diffuse, specular, tris, B, V, T, corners, s);
+  if (rc != MR_OK) return rc;
+  if (hipMemsetAsync(norms2, 0, (size_t)B * L * sizeof(float), s) != hipSuccess) return check_launch();
+  SpecSceneIn scene{light_pos, light_col, ambient, camera, shininess, nullptr, nullptr};
+  rc = launch_spec_pixels<kNorms>(L, ids, bary, corners, scene, B, T, W, H, nullptr, nullptr, norms2, s);
+  if (rc != MR_OK) return rc;
+  scene.norms2 = norms2;
+  return launch_spec_pixels<kShade>(L, ids, bary, corners, scene, B, T, W, H, nullptr, rgba, nullptr, s);
+}
+
+size_t shade_specular_backward_ws(int B, int V, int T, int W, int H) {
+  (void)V; (void)W; (void)H;
+  return spec_acc_bytes(B, T) + align_up((size_t)B * T * sizeof(BwdRec), 256) + spec_corner_bytes(B, T) +
+         spec_sums_bytes(B);
+}
+
+int launch_shade_specular_backward(const float *drgba, const int32_t *ids, const float *bary,
+                                   const float *clip, const float *normals, const float *positions,
+                                   const float *diffuse, const float *specular, const int32_t *tris,
+                                   const float *light_pos, const float *light_col, const float *ambient,
+                                   const float *camera, const float *shininess, const float *norms2,
+                                   int B, int V, int T, int W, int H, int L, float *dclip, float *dnormals,
+                                   float *dpositions, float *ddiffuse, float *dspecular, float *light_grads,
+                                   void *ws, hipStream_t s) {
+  if (B == 0) return MR_OK;
+  const size_t v3 = (size_t)B * V * 3 * sizeof(float);
+  if (V > 0) {
+    if (hipMemsetAsync(dclip, 0, (size_t)B * V * 4 * sizeof(float), s) != hipSuccess) return check_launch();
+    if (hipMemsetAsync(dnormals, 0, v3, s) != hipSuccess) return check_launch();
+    if (hipMemsetAsync(dpositions, 0, v3, s) != hipSuccess) return check_launch();
+    if (hipMemsetAsync(ddiffuse, 0, v3, s) != hipSuccess) return check_launch();
+    if (hipMemsetAsync(dspecular, 0, v3, s) != hipSuccess) return check_launch();
+  }
+  if (hipMemsetAsync(light_grads, 0, (size_t)B * (L * 6 + 6) * sizeof(float), s) != hipSuccess)
+    return check_launch();
+  if (T == 0 || V == 0 || (size_t)W * H == 0) return MR_OK;
+  char *p = (char *)ws;
+  float *acc = (float *)p;
+  p += spec_acc_bytes(B, T);
+  BwdRec *recs = (BwdRec *)p;
+  p += align_up((size_t)B * T * sizeof(BwdRec), 256);
+  SpecCornerRec *corners = (SpecCornerRec *)p;
+  p += spec_corner_bytes(B, T);
+  float *gsum = (float *)p;
+  if (hipMemsetAsync(acc, 0, (size_t)B * T * 48 * sizeof(float), s) != hipSuccess) return check_launch();
+  if (hipMemsetAsync(gsum, 0, (size_t)B * L * sizeof(float), s) != hipSuccess) return check_launch();
+  int rc = launch_bwd_setup(clip, tris, B, V, T, recs, s);
+  if (rc != MR_OK) return rc;
+  rc = launch_spec_corner_setup(normals, positions, diffuse, specular, tris, B, V, T, corners, s);
+  if (rc != MR_OK) return rc;
+  SpecSceneIn scene{light_pos, light_col, ambient, camera, shininess, norms2, nullptr};
+  rc = launch_spec_pixels<kGsum>(L, ids, bary, corners, scene, B, T, W, H, drgba, nullptr, gsum, s);
+  if (rc != MR_OK) return rc;
+  scene.gsum = gsum;
+#define MR_SPEC_BWD(NL)                                                                              \
+  {                                                                                                  \
+    SpecGradFn<NL> fn{(const float4 *)drgba, ids, (const F3 *)bary, corners, recs, scene, light_grads, \
+                      T, W, H};                                                                      \
+    rc = launch_accumulate_rows(fn, B, T, W, H, acc, s);                                             \
+  }
+  switch (L) {
+    case 1: MR_SPEC_BWD(1); break;
+    case 2: MR_SPEC_BWD(2); break;
+    case 3: MR_SPEC_BWD(3); break;
+    case 4: MR_SPEC_BWD(4); break;
+    default: return MR_EINVAL;
+  }
+#undef MR_SPEC_BWD
+  if (rc != MR_OK) return rc;
+  const long nbt = (long)B * T;
+  hipLaunchKernelGGL(k_spec_scatter, dim3((unsigned)((nbt + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
+                     acc, tris, B, V, T, dnormals, dpositions, ddiffuse, dspecular, dclip);
+  return check_launch();
+}
+
+}  // namespace mr

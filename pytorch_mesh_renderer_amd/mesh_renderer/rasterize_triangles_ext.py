@@ -105,3 +105,37 @@ class FusedPhongRenderer(torch.autograd.Function):
         dclip, dn, dp, dd, dlp, dli, damb = _native.shade_backward(
             drgba.contiguous(), ids, bary, clip, normals, positions, diffuse, triangles, lp, li, amb)
         return dclip, dp, dn, dd, None, dlp, dli, damb, None, None
+
+
+class FusedSpecularPhongRenderer(torch.autograd.Function):
+    """FusedPhongRenderer plus the specular term of phong_shader (src/mesh_renderer/render.py
+    :326-372) for a per-image shininess: two passes over the G-buffer each way (the reference
+    L2-normalises the reflection . camera dot product across all pixels of an image)."""
+
+    @staticmethod
+    def forward(ctx, clip, positions, normals, diffuse, specular, triangles, light_positions,
+                light_intensities, ambient, camera_position, shininess, image_width, image_height):
+        clip_d = clip.detach().contiguous()
+        ids, bary, _ = _native.rasterize_forward(clip_d, triangles, int(image_width), int(image_height))
+        attrs = [t.detach().contiguous() for t in (normals, positions, diffuse, specular)]
+        lp, li = light_positions.detach().contiguous(), light_intensities.detach().contiguous()
+        amb = ambient.detach().contiguous() if ambient is not None else None
+        cam, shin = camera_position.detach().contiguous(), shininess.detach().contiguous()
+        rgba, norms2 = _native.shade_specular_forward(ids, bary, attrs[0], attrs[1], attrs[2], attrs[3],
+                                                      triangles, lp, li, amb, cam, shin)
+        saved = [clip_d, ids, bary] + attrs + [triangles, lp, li, cam, shin, norms2]
+        if amb is not None:
+            saved.append(amb)
+        ctx.save_for_backward(*saved)
+        ctx.has_ambient = amb is not None
+        return rgba
+
+    @staticmethod
+    def backward(ctx, drgba):
+        saved = ctx.saved_tensors
+        clip, ids, bary, normals, positions, diffuse, specular, triangles, lp, li, cam, shin, norms2 = saved[:13]
+        amb = saved[13] if ctx.has_ambient else None
+        dclip, dn, dp, dd, dsp, dlp, dli, damb, dcam = _native.shade_specular_backward(
+            drgba.contiguous(), ids, bary, clip, normals, positions, diffuse, specular, triangles, lp, li,
+            amb, cam, shin, norms2)
+        return dclip, dp, dn, dd, dsp, None, dlp, dli, damb, dcam, None, None, None

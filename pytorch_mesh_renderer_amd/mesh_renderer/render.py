@@ -16,6 +16,13 @@ from ..common import camera_utils
 from .rasterize import rasterize
 
 
+# True: render() uses the fused HIP shading kernels whenever they cover the request.  False:
+# always the composed path (HIP rasterization + interpolation, torch Phong) -- the same results
+# within the parity budget, kept as a cross-check (tests) and for requests the fused kernels do
+# not cover.  Read at call time, like rasterize.USE_CPP_RASTERIZER.
+USE_FUSED_SHADING = True
+
+
 def _per_batch(value, batch_size, device, name):
     """float | 0-D tensor | [B] tensor -> [B] float32 tensor on `device`."""
     if isinstance(value, float):
@@ -76,11 +83,17 @@ def render(vertices, triangles, normals, diffuse_colors, camera_position, camera
     if shininess_coefficients is not None and specular_colors is None:
         raise ValueError("Shininess coefficients were supplied without specular colors.")
 
-    if specular_colors is None and _fused_path_applies(vertices, normals, diffuse_colors,
-                                                       light_positions):
-        return _render_fused(vertices, triangles, normals, diffuse_colors, camera_position,
-                             camera_lookat, camera_up, light_positions, light_intensities,
-                             image_width, image_height, ambient_color, fov_y, near_clip, far_clip)
+    if _fused_path_applies(vertices, normals, diffuse_colors, light_positions):
+        if specular_colors is None:
+            return _render_fused(vertices, triangles, normals, diffuse_colors, camera_position,
+                                 camera_lookat, camera_up, light_positions, light_intensities,
+                                 image_width, image_height, ambient_color, fov_y, near_clip, far_clip)
+        shininess = _per_image_shininess(shininess_coefficients, batch_size, device)
+        if shininess is not None and specular_colors.shape == vertices.shape:
+            return _render_fused(vertices, triangles, normals, diffuse_colors, camera_position,
+                                 camera_lookat, camera_up, light_positions, light_intensities,
+                                 image_width, image_height, ambient_color, fov_y, near_clip, far_clip,
+                                 specular_colors=specular_colors, shininess=shininess)
 
     pieces = [normals, vertices, diffuse_colors]  # attribute layout, render.py:171-181
     per_vertex_shininess = False
@@ -132,23 +145,46 @@ def render(vertices, triangles, normals, diffuse_colors, camera_position, camera
 
 
 def _fused_path_applies(vertices, normals, diffuse_colors, light_positions):
-    """The fused HIP shading kernels cover diffuse + ambient Phong with 1..4 lights on
-    float32 inputs of matching [B,V,3] shape; everything else takes the composed path."""
+    """The fused HIP shading kernels cover Phong shading (ambient, diffuse, and specular with a
+    per-image shininess) with 1..4 lights on float32 inputs of matching [B,V,3] shape;
+    everything else takes the composed path."""
     from .. import _native
-    return (vertices.dtype == torch.float32 and normals.shape == vertices.shape and
+    return (USE_FUSED_SHADING and vertices.dtype == torch.float32 and normals.shape == vertices.shape and
             diffuse_colors.shape == vertices.shape and
             1 <= light_positions.shape[1] <= _native.shade_max_lights())
 
 
+def _per_image_shininess(shininess_coefficients, batch_size, device):
+    """float | 0-D | [B] shininess -> [B] float32 tensor on `device`; None when the fused
+    specular kernels do not cover the request (per-vertex exponents, exponents that need a
+    gradient): those take the composed path."""
+    if isinstance(shininess_coefficients, float):
+        return torch.full((batch_size,), shininess_coefficients, dtype=torch.float32, device=device)
+    if not torch.is_tensor(shininess_coefficients) or shininess_coefficients.requires_grad:
+        return None
+    if len(shininess_coefficients.shape) == 0:
+        return shininess_coefficients.to(device=device, dtype=torch.float32).reshape(1).repeat(batch_size)
+    if list(shininess_coefficients.shape) == [batch_size]:
+        return shininess_coefficients.to(device=device, dtype=torch.float32)
+    return None
+
+
 def _render_fused(vertices, triangles, normals, diffuse_colors, camera_position, camera_lookat,
                   camera_up, light_positions, light_intensities, image_width, image_height,
-                  ambient_color, fov_y, near_clip, far_clip):
-    from .rasterize_triangles_ext import FusedPhongRenderer
+                  ambient_color, fov_y, near_clip, far_clip, specular_colors=None, shininess=None):
+    from .rasterize_triangles_ext import FusedPhongRenderer, FusedSpecularPhongRenderer
     device = vertices.device
     clip_space_transforms = camera_utils.clip_space_transforms(
         camera_position, camera_lookat, camera_up, fov_y, near_clip, far_clip,
         image_width / image_height, device)
     clip = camera_utils.transform_homogeneous(clip_space_transforms, vertices)
+    if specular_colors is not None:
+        return FusedSpecularPhongRenderer.apply(
+            clip, vertices, normals, diffuse_colors, specular_colors.to(torch.float32), triangles,
+            light_positions.to(device), light_intensities.to(device).to(torch.float32),
+            ambient_color.to(device) if ambient_color is not None else None,
+            camera_position.to(device=device, dtype=torch.float32), shininess,
+            image_width, image_height)
     return FusedPhongRenderer.apply(
         clip, vertices, normals, diffuse_colors, triangles, light_positions.to(device),
         light_intensities.to(device).to(torch.float32),

@@ -5,6 +5,7 @@ Counterparts of the reference's rasterize_triangles_test.py and mesh_renderer_te
 reference (tools/make_goldens.py).  Bar: RGBA and gradients within 1e-4 abs.
 """
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -93,10 +94,35 @@ def test_render_diffuse_goldens(device, name):
     _render_golden(name, device)
 
 
-@pytest.mark.parametrize("name", ["render_specular_cube_64x48.npz",
-                                  "render_specular_scalar_cube_64x48.npz"])
-def test_render_specular_goldens(device, name):
-    _render_golden(name, device)
+class _CountCalls:
+    """Counts the calls of a _native entry point (which path did render() take?)."""
+
+    def __init__(self, name):
+        from pytorch_mesh_renderer_amd import _native
+        self.mod, self.name, self.calls = _native, name, 0
+
+    def __enter__(self):
+        self.orig = getattr(self.mod, self.name)
+
+        def wrapper(*a, **k):
+            self.calls += 1
+            return self.orig(*a, **k)
+        setattr(self.mod, self.name, wrapper)
+        return self
+
+    def __exit__(self, *exc):
+        setattr(self.mod, self.name, self.orig)
+        return False
+
+
+@pytest.mark.parametrize("name,fused", [("render_specular_cube_64x48.npz", False),
+                                        ("render_specular_scalar_cube_64x48.npz", True)])
+def test_render_specular_goldens(device, name, fused):
+    """Reference-captured image and gradients.  Per-vertex shininess takes the composed path,
+    a scalar shininess the fused specular kernels."""
+    with _CountCalls("shade_specular_forward") as counter:
+        _render_golden(name, device)
+    assert counter.calls == (1 if fused else 0)
 
 
 def test_renders_simple_and_perspective_triangle_png(device):
@@ -300,3 +326,59 @@ def test_to_uint8_matches_numpy_cast(device):
         np.testing.assert_array_equal(got, want)
     with pytest.raises(ValueError):
         mesh_renderer.to_uint8(torch.zeros(4, dtype=torch.float64, device=device))
+
+
+def _specular_scene(device, requires_grad=True):
+    job = synthetic.sphere_job(2, 96, 80, 12)
+    gen = torch.Generator().manual_seed(3)
+    leaf = lambda t: t.clone().to(device).requires_grad_(requires_grad)
+    scene = {
+        "vertices": leaf(job["vertices"]), "normals": leaf(job["normals"]),
+        "diffuse": leaf(torch.rand(job["vertices"].shape, generator=gen)),
+        "specular": leaf(torch.rand(job["vertices"].shape, generator=gen)),
+        "light_positions": leaf(torch.tensor([[[2.0, 3.0, 4.0], [-3.0, 1.0, 2.5]],
+                                              [[0.5, -2.0, 3.0], [3.0, 3.0, -1.0]]])),
+        "light_intensities": leaf(torch.rand(2, 2, 3, generator=gen) + 0.2),
+        "ambient": leaf(torch.rand(2, 3, generator=gen) * 0.3),
+        "eye": leaf(job["eyes"]),
+    }
+    return job, scene
+
+
+def _render_specular(job, scene, device, shininess):
+    return mesh_renderer.render(
+        scene["vertices"], job["triangles"].to(device), scene["normals"], scene["diffuse"], scene["eye"],
+        torch.zeros(2, 3, device=device), torch.tensor([0.0, 1.0, 0.0], device=device),
+        scene["light_positions"], scene["light_intensities"], 96, 80,
+        specular_colors=scene["specular"], shininess_coefficients=shininess, ambient_color=scene["ambient"])
+
+
+def test_fused_specular_matches_composed_path(device):
+    """render() with a per-image shininess: fused HIP kernels vs the composed path (HIP raster +
+    interpolation, torch Phong and autograd), image and every gradient, 2 lights + ambient."""
+    render_mod = sys.modules["pytorch_mesh_renderer_amd.mesh_renderer.render"]
+    shininess = torch.tensor([1.0, 2.5], device=device)
+    gen = torch.Generator().manual_seed(5)
+    target = torch.rand(2, 80, 96, 4, generator=gen).to(device)
+    results = {}
+    for fused in (True, False):
+        job, scene = _specular_scene(device)
+        render_mod.USE_FUSED_SHADING = fused
+        try:
+            with _CountCalls("shade_specular_forward") as counter:
+                img = _render_specular(job, scene, device, shininess)
+        finally:
+            render_mod.USE_FUSED_SHADING = True
+        assert counter.calls == (1 if fused else 0)
+        # the specular term is tiny after the across-pixels normalisation: weight it up
+        (torch.mean(torch.abs(img - target)) * 50.0).backward()
+        results[fused] = (img.detach().cpu().numpy(), {k: v.grad.cpu().numpy() for k, v in scene.items()
+                                                       if v.grad is not None})
+    img_f, grads_f = results[True]
+    img_c, grads_c = results[False]
+    np.testing.assert_allclose(img_f, img_c, atol=ATOL, rtol=0)
+    assert set(grads_c) == set(grads_f) == set(("vertices", "normals", "diffuse", "specular", "light_positions",
+                                                  "light_intensities", "ambient", "eye"))
+    for k in grads_c:
+        assert np.isfinite(grads_f[k]).all() and np.abs(grads_c[k]).max() > 0, k
+        np.testing.assert_allclose(grads_f[k], grads_c[k], atol=ATOL, rtol=0, err_msg=k)
