@@ -1,4 +1,5 @@
-"""Quick on-GPU parity + timing probe (development aid; the real tests are tests/)."""
+"""Quick on-GPU parity + timing probe against the oracle (development aid; lives under tests/ because
+only tests, smoke() and bench.py's cpu_baseline may use the oracle).  python tests/gpu_check_tool.py"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
