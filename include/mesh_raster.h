@@ -126,7 +126,12 @@ int mr_shade_forward(const int32_t *ids, const float *bary, const float *normals
  *   dclip        [B,V,4]   f32 out  through the barycentrics (column z stays 0)
  *   dnormals, dpositions, ddiffuse [B,V,3] f32 out  through the interpolated attributes
  *   light_grads  [B, 6L+3] f32 out  per image: d light_positions (L x 3),
- *                               d light_intensities (L x 3), d ambient (3; 0 if NULL) */
+ *                               d light_intensities (L x 3), d ambient (3; 0 if NULL)
+ *   corner_records  NULL, or the first mr_shade_forward_workspace_bytes() bytes of the workspace
+ *                   mr_shade_forward ran with for the SAME inputs (128-byte aligned): its gathered
+ *                   per-triangle attribute records are then reused instead of rebuilt.
+ * dclip, dnormals, dpositions, ddiffuse, light_grads laid out back to back in that order are
+ * zeroed with a single memset. */
 size_t mr_shade_backward_workspace_bytes(int B, int V, int T, int W, int H);
 int mr_shade_backward(const float *drgba, const int32_t *ids, const float *bary,
                       const float *clip, const float *normals, const float *positions,
@@ -134,8 +139,8 @@ int mr_shade_backward(const float *drgba, const int32_t *ids, const float *bary,
                       const float *light_positions, const float *light_intensities,
                       const float *ambient, int B, int V, int T, int W, int H, int L,
                       float *dclip, float *dnormals, float *dpositions,
-                      float *ddiffuse, float *light_grads, void *workspace,
-                      size_t workspace_bytes, void *stream);
+                      float *ddiffuse, float *light_grads, const void *corner_records,
+                      void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- fused deferred shading with the specular term --------------------------------
  * The same replacement as mr_shade_forward / mr_shade_backward for render() calls that pass

@@ -74,7 +74,7 @@ def lib():
         L.mr_shade_forward.restype = ci
         L.mr_shade_backward_workspace_bytes.argtypes = [ci] * 5
         L.mr_shade_backward_workspace_bytes.restype = sz
-        L.mr_shade_backward.argtypes = [vp] * 11 + [ci] * 6 + [vp] * 6 + [sz, vp]
+        L.mr_shade_backward.argtypes = [vp] * 11 + [ci] * 6 + [vp] * 7 + [sz, vp]
         L.mr_shade_backward.restype = ci
         L.mr_soft_max_lights.restype = ci
         L.mr_soft_workspace_bytes.argtypes = [ci] * 5
@@ -225,9 +225,17 @@ def shade_max_lights():
     return int(lib().mr_shade_max_lights())
 
 
+def _aligned_bytes(nbytes, dev):
+    """A fresh uint8 tensor of `nbytes` whose data pointer is 256-byte aligned."""
+    raw = torch.empty(max(int(nbytes), 1) + 256, dtype=torch.uint8, device=dev)
+    off = (-raw.data_ptr()) % 256
+    return raw[off:off + max(int(nbytes), 1)]
+
+
 def shade_forward(ids, bary, normals, positions, diffuse, triangles, light_positions,
-                  light_intensities, ambient):
-    """Fused interpolation + diffuse/ambient Phong: -> rgba [B,H,W,4] (row 0 = top)."""
+                  light_intensities, ambient, keep_corner_records=False):
+    """Fused interpolation + diffuse/ambient Phong: -> rgba [B,H,W,4] (row 0 = top); with
+    keep_corner_records also the gathered per-triangle attribute records, for shade_backward."""
     tensors = [ids, bary, normals, positions, diffuse, triangles, light_positions, light_intensities]
     dev = _require_device(*(tensors + ([ambient] if ambient is not None else [])))
     L = lib()
@@ -239,17 +247,20 @@ def shade_forward(ids, bary, normals, positions, diffuse, triangles, light_posit
     rgba = torch.empty(B, H, W, 4, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         need = L.mr_shade_forward_workspace_bytes(B, V, T, W, H)
-        ws, have = _workspace(dev, need)
+        if keep_corner_records:   # own buffer (not the shared workspace): handed to the backward
+            ws, have = _aligned_bytes(need, dev), need
+        else:
+            ws, have = _workspace(dev, need)
         rc = L.mr_shade_forward(_ptr(ids), _ptr(bary), _ptr(normals), _ptr(positions), _ptr(diffuse),
                                 _ptr(triangles), _ptr(light_positions), _ptr(light_intensities),
                                 _ptr(ambient), B, V, T, W, H, nl, _ptr(rgba), _ptr(ws), have,
                                 _stream(dev))
     _check(rc, "mr_shade_forward")
-    return rgba
+    return (rgba, ws) if keep_corner_records else rgba
 
 
 def shade_backward(drgba, ids, bary, clip, normals, positions, diffuse, triangles, light_positions,
-                   light_intensities, ambient):
+                   light_intensities, ambient, corner_records=None):
     """-> (dclip [B,V,4], dnormals, dpositions, ddiffuse [B,V,3], dlight_positions,
     dlight_intensities [B,L,3], dambient [B,3] or None)."""
     tensors = [drgba, ids, bary, clip, normals, positions, diffuse, triangles, light_positions,
@@ -261,11 +272,14 @@ def shade_backward(drgba, ids, bary, clip, normals, positions, diffuse, triangle
     ambient = ambient.contiguous() if ambient is not None else None
     B, H, W = ids.shape
     V, T, nl = normals.shape[1], triangles.shape[0], light_positions.shape[1]
-    dclip = torch.empty(B, V, 4, dtype=torch.float32, device=dev)
-    dn = torch.empty(B, V, 3, dtype=torch.float32, device=dev)
-    dp = torch.empty(B, V, 3, dtype=torch.float32, device=dev)
-    dd = torch.empty(B, V, 3, dtype=torch.float32, device=dev)
-    lg = torch.empty(B, 6 * nl + 3, dtype=torch.float32, device=dev)
+    # one allocation, laid out back to back: the library then zeroes all outputs with one memset
+    n4, n3, nlg = B * V * 4, B * V * 3, B * (6 * nl + 3)
+    flat = torch.empty(n4 + 3 * n3 + nlg, dtype=torch.float32, device=dev)
+    dclip = flat[:n4].view(B, V, 4)
+    dn = flat[n4:n4 + n3].view(B, V, 3)
+    dp = flat[n4 + n3:n4 + 2 * n3].view(B, V, 3)
+    dd = flat[n4 + 2 * n3:n4 + 3 * n3].view(B, V, 3)
+    lg = flat[n4 + 3 * n3:].view(B, 6 * nl + 3)
     with torch.cuda.device(dev):
         need = L.mr_shade_backward_workspace_bytes(B, V, T, W, H)
         ws, have = _workspace(dev, need)
@@ -273,7 +287,7 @@ def shade_backward(drgba, ids, bary, clip, normals, positions, diffuse, triangle
                                  _ptr(positions), _ptr(diffuse), _ptr(triangles),
                                  _ptr(light_positions), _ptr(light_intensities), _ptr(ambient),
                                  B, V, T, W, H, nl, _ptr(dclip), _ptr(dn), _ptr(dp), _ptr(dd),
-                                 _ptr(lg), _ptr(ws), have, _stream(dev))
+                                 _ptr(lg), _ptr(corner_records), _ptr(ws), have, _stream(dev))
     _check(rc, "mr_shade_backward")
     dlpos = lg[:, :3 * nl].reshape(B, nl, 3)
     dlint = lg[:, 3 * nl:6 * nl].reshape(B, nl, 3)

@@ -149,8 +149,8 @@ int mr_shade_backward(const float *drgba, const int32_t *ids, const float *bary,
                       const int32_t *triangles, const float *light_positions,
                       const float *light_intensities, const float *ambient, int B, int V, int T,
                       int W, int H, int L, float *dclip, float *dnormals, float *dpositions,
-                      float *ddiffuse, float *light_grads, void *workspace, size_t workspace_bytes,
-                      void *stream) {
+                      float *ddiffuse, float *light_grads, const void *corner_records,
+                      void *workspace, size_t workspace_bytes, void *stream) {
   if (bad_dims(B, V, T, W, H) || T < 1 || V < 1 || L < 1 || L > mr::shade_max_lights())
     return MR_EINVAL;
   if (B == 0) return MR_OK;
@@ -158,12 +158,13 @@ int mr_shade_backward(const float *drgba, const int32_t *ids, const float *bary,
       !light_positions || !light_intensities || !dclip || !dnormals || !dpositions || !ddiffuse ||
       !light_grads)
     return MR_EINVAL;
+  if (((uintptr_t)corner_records & 127u) != 0) return MR_EINVAL;
   const int rc = check_ws(workspace, workspace_bytes, mr::shade_backward_ws(B, V, T, W, H));
   if (rc != MR_OK) return rc;
   return mr::launch_shade_backward(drgba, ids, bary, clip, normals, positions, diffuse, triangles,
                                    light_positions, light_intensities, ambient, B, V, T, W, H, L,
-                                   dclip, dnormals, dpositions, ddiffuse, light_grads, workspace,
-                                   (hipStream_t)stream);
+                                   dclip, dnormals, dpositions, ddiffuse, light_grads, corner_records,
+                                   workspace, (hipStream_t)stream);
 }
 
 size_t mr_shade_specular_forward_workspace_bytes(int B, int V, int T, int W, int H) {

@@ -89,8 +89,9 @@ class FusedPhongRenderer(torch.autograd.Function):
         args = [t.detach().contiguous() for t in (normals, positions, diffuse)]
         lp, li = light_positions.detach().contiguous(), light_intensities.detach().contiguous()
         amb = ambient.detach().contiguous() if ambient is not None else None
-        rgba = _native.shade_forward(ids, bary, args[0], args[1], args[2], triangles, lp, li, amb)
-        saved = [clip_d, ids, bary, args[0], args[1], args[2], triangles, lp, li]
+        rgba, corner_records = _native.shade_forward(ids, bary, args[0], args[1], args[2], triangles, lp, li,
+                                                     amb, keep_corner_records=True)
+        saved = [clip_d, ids, bary, args[0], args[1], args[2], triangles, lp, li, corner_records]
         if amb is not None:
             saved.append(amb)
         ctx.save_for_backward(*saved)
@@ -100,10 +101,11 @@ class FusedPhongRenderer(torch.autograd.Function):
     @staticmethod
     def backward(ctx, drgba):
         saved = ctx.saved_tensors
-        clip, ids, bary, normals, positions, diffuse, triangles, lp, li = saved[:9]
-        amb = saved[9] if ctx.has_ambient else None
+        clip, ids, bary, normals, positions, diffuse, triangles, lp, li, corner_records = saved[:10]
+        amb = saved[10] if ctx.has_ambient else None
         dclip, dn, dp, dd, dlp, dli, damb = _native.shade_backward(
-            drgba.contiguous(), ids, bary, clip, normals, positions, diffuse, triangles, lp, li, amb)
+            drgba.contiguous(), ids, bary, clip, normals, positions, diffuse, triangles, lp, li, amb,
+            corner_records=corner_records)
         return dclip, dp, dn, dd, None, dlp, dli, damb, None, None
 
 
