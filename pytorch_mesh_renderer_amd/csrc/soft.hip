@@ -275,7 +275,7 @@ __global__ __launch_bounds__(kThreads) void k_soft_forward(
     n = bin_chunk(img_recs, T, base, g.tx0, g.tx1, g.ty0, g.ty1, s_list, s_wave_count, n);
     if (n + kThreads > kListCap || base + kThreads >= T) {  // list (nearly) full or last chunk: walk it
       for (int k = 0; k < n; ++k) {
-        const int t = s_list[k];  // workgroup-uniform
+        const int t = __builtin_amdgcn_readfirstlane(s_list[k]);  // workgroup-uniform
         const SoftRec r = img_recs[t];
         Corners cr;
         load_corners(img_corners + t, cr);
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(kThreads, MR_SOFT_BWD_WAVES) void k_soft_backward(
     n = bin_chunk(img_recs, T, base, g.tx0, g.tx1, g.ty0, g.ty1, s_list, s_wave_count, n);
     if (n + kThreads > kListCap || base + kThreads >= T) {
       for (int k = 0; k < n; ++k) {
-        const int t = s_list[k];
+        const int t = __builtin_amdgcn_readfirstlane(s_list[k]);  // workgroup-uniform
         const SoftRec r = img_recs[t];
         Corners cr;
         load_corners(img_corners + t, cr);
