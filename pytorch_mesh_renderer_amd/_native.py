@@ -14,6 +14,7 @@ import torch
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(_CSRC, "libmesh_raster_hip.so")
 
+ABI_VERSION = 200
 MR_OK, MR_EINVAL, MR_EWORKSPACE, MR_ELAUNCH = 0, -1, -2, -3
 _ERR = {MR_EINVAL: "invalid argument", MR_EWORKSPACE: "workspace too small or misaligned",
         MR_ELAUNCH: "HIP launch failed"}
@@ -47,6 +48,9 @@ def lib():
         L = ctypes.CDLL(LIB_PATH)
         vp, ci, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
         L.mr_version.restype = ci
+        if L.mr_version() != ABI_VERSION:   # a stale .so would be called with the wrong signatures
+            raise NativeLibraryError("%s has ABI version %d, this package needs %d: rebuild it (make -C "
+                                     "pytorch_mesh_renderer_amd/csrc)" % (LIB_PATH, L.mr_version(), ABI_VERSION))
         L.mr_last_hip_error.restype = ci
         L.mr_set_raster_tile_shape.argtypes = [ci]
         L.mr_set_raster_tile_shape.restype = ci

@@ -25,7 +25,7 @@ extern hipEvent_t g_raster_ev_start, g_raster_ev_stop;
 
 extern "C" {
 
-int mr_version(void) { return 100; /* 0.1.0 */ }
+int mr_version(void) { return 200; /* 0.2.0: sign-coded L1 loss, specular shading, frame export, corner-record reuse */ }
 
 int mr_last_hip_error(void) { return mr::g_last_hip_error; }
 

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 9
     for name in names:
         assert hasattr(lib, name), "include/mesh_raster.h declares %s but the .so lacks it" % name
-    assert _native.lib().mr_version() >= 100
+    assert _native.lib().mr_version() == _native.ABI_VERSION
 
 
 def test_abi_argument_validation_without_gpu():
