@@ -130,6 +130,11 @@ int mr_shade_forward(const int32_t *ids, const float *bary, const float *normals
  *   corner_records  NULL, or the first mr_shade_forward_workspace_bytes() bytes of the workspace
  *                   mr_shade_forward ran with for the SAME inputs (128-byte aligned): its gathered
  *                   per-triangle attribute records are then reused instead of rebuilt.
+ *   vertex_offsets, vertex_entries  both NULL, or the CSR vertex -> (triangle, corner) adjacency of
+ *                   `triangles`: offsets [V+1] i32, entries [offsets[V]] i32 with entry = 3 *
+ *                   triangle + corner, grouped by vertex (corners whose index is outside [0, V)
+ *                   left out).  With it the per-triangle sums are GATHERED per vertex (no atomics,
+ *                   fixed summation order); without it they are scattered with float atomics.
  * dclip, dnormals, dpositions, ddiffuse, light_grads laid out back to back in that order are
  * zeroed with a single memset. */
 size_t mr_shade_backward_workspace_bytes(int B, int V, int T, int W, int H);
@@ -140,6 +145,7 @@ int mr_shade_backward(const float *drgba, const int32_t *ids, const float *bary,
                       const float *ambient, int B, int V, int T, int W, int H, int L,
                       float *dclip, float *dnormals, float *dpositions,
                       float *ddiffuse, float *light_grads, const void *corner_records,
+                      const int32_t *vertex_offsets, const int32_t *vertex_entries,
                       void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- fused deferred shading with the specular term --------------------------------

@@ -78,7 +78,7 @@ def lib():
         L.mr_shade_forward.restype = ci
         L.mr_shade_backward_workspace_bytes.argtypes = [ci] * 5
         L.mr_shade_backward_workspace_bytes.restype = sz
-        L.mr_shade_backward.argtypes = [vp] * 11 + [ci] * 6 + [vp] * 7 + [sz, vp]
+        L.mr_shade_backward.argtypes = [vp] * 11 + [ci] * 6 + [vp] * 9 + [sz, vp]
         L.mr_shade_backward.restype = ci
         L.mr_soft_max_lights.restype = ci
         L.mr_soft_workspace_bytes.argtypes = [ci] * 5
@@ -263,8 +263,30 @@ def shade_forward(ids, bary, normals, positions, diffuse, triangles, light_posit
     return (rgba, ws) if keep_corner_records else rgba
 
 
+def vertex_adjacency(triangles, vertex_count):
+    """CSR vertex -> (triangle, corner) adjacency of an int32 [T,3] triangle array on its device:
+    (offsets [V+1] i32, entries [n] i32), entry = 3 * triangle + corner grouped by vertex; corners
+    whose vertex index is out of range are left out.  Cached on the tensor object (keyed by its
+    version counter), so a mesh's topology is analysed once."""
+    cached = getattr(triangles, "_mr_adjacency", None)
+    if cached is not None and cached[0] == (triangles._version, int(vertex_count), triangles.data_ptr()):
+        return cached[1], cached[2]
+    flat = triangles.reshape(-1).to(torch.int64)
+    key = torch.where((flat >= 0) & (flat < vertex_count), flat, torch.full_like(flat, vertex_count))
+    order = torch.argsort(key, stable=True)
+    counts = torch.bincount(key, minlength=vertex_count + 1)[:vertex_count]
+    offsets = torch.zeros(vertex_count + 1, dtype=torch.int64, device=triangles.device)
+    offsets[1:] = torch.cumsum(counts, 0)
+    offsets, entries = offsets.to(torch.int32), order.to(torch.int32).contiguous()
+    try:
+        triangles._mr_adjacency = ((triangles._version, int(vertex_count), triangles.data_ptr()), offsets, entries)
+    except AttributeError:
+        pass
+    return offsets, entries
+
+
 def shade_backward(drgba, ids, bary, clip, normals, positions, diffuse, triangles, light_positions,
-                   light_intensities, ambient, corner_records=None):
+                   light_intensities, ambient, corner_records=None, adjacency=None):
     """-> (dclip [B,V,4], dnormals, dpositions, ddiffuse [B,V,3], dlight_positions,
     dlight_intensities [B,L,3], dambient [B,3] or None)."""
     tensors = [drgba, ids, bary, clip, normals, positions, diffuse, triangles, light_positions,
@@ -291,7 +313,10 @@ def shade_backward(drgba, ids, bary, clip, normals, positions, diffuse, triangle
                                  _ptr(positions), _ptr(diffuse), _ptr(triangles),
                                  _ptr(light_positions), _ptr(light_intensities), _ptr(ambient),
                                  B, V, T, W, H, nl, _ptr(dclip), _ptr(dn), _ptr(dp), _ptr(dd),
-                                 _ptr(lg), _ptr(corner_records), _ptr(ws), have, _stream(dev))
+                                 _ptr(lg), _ptr(corner_records),
+                                 _ptr(adjacency[0]) if adjacency is not None else None,
+                                 _ptr(adjacency[1]) if adjacency is not None else None,
+                                 _ptr(ws), have, _stream(dev))
     _check(rc, "mr_shade_backward")
     dlpos = lg[:, :3 * nl].reshape(B, nl, 3)
     dlint = lg[:, 3 * nl:6 * nl].reshape(B, nl, 3)

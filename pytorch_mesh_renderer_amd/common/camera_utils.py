@@ -88,9 +88,9 @@ def transform_homogeneous(matrices, vertices):
     if len(vertices.shape) != 3:
         raise ValueError(
             "vertices must have 3 dimensions (missing batch dimension?)")
-    ones = torch.ones(vertices.shape[0], vertices.shape[1], 1,
-                      dtype=vertices.dtype, device=vertices.device)
-    return torch.matmul(torch.cat([vertices, ones], 2), matrices.transpose(1, 2))
+    # [v, 1] M^T = v M[:, :, :3]^T + M[:, :, 3]: one fused batched GEMM instead of cat + matmul
+    # (and one GEMM instead of matmul + slice copies in the backward)
+    return torch.baddbmm(matrices[:, :, 3].unsqueeze(1), vertices, matrices[:, :, :3].transpose(1, 2))
 
 
 def clip_space_transforms(camera_position, camera_lookat, camera_up, fov_y, near_clip, far_clip,

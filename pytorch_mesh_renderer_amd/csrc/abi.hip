@@ -150,6 +150,7 @@ int mr_shade_backward(const float *drgba, const int32_t *ids, const float *bary,
                       const float *light_intensities, const float *ambient, int B, int V, int T,
                       int W, int H, int L, float *dclip, float *dnormals, float *dpositions,
                       float *ddiffuse, float *light_grads, const void *corner_records,
+                      const int32_t *vertex_offsets, const int32_t *vertex_entries,
                       void *workspace, size_t workspace_bytes, void *stream) {
   if (bad_dims(B, V, T, W, H) || T < 1 || V < 1 || L < 1 || L > mr::shade_max_lights())
     return MR_EINVAL;
@@ -159,12 +160,14 @@ int mr_shade_backward(const float *drgba, const int32_t *ids, const float *bary,
       !light_grads)
     return MR_EINVAL;
   if (((uintptr_t)corner_records & 127u) != 0) return MR_EINVAL;
+  if ((vertex_offsets == nullptr) != (vertex_entries == nullptr)) return MR_EINVAL;
+  if (vertex_offsets && ((uintptr_t)dclip & 15u) != 0) return MR_EINVAL;
   const int rc = check_ws(workspace, workspace_bytes, mr::shade_backward_ws(B, V, T, W, H));
   if (rc != MR_OK) return rc;
   return mr::launch_shade_backward(drgba, ids, bary, clip, normals, positions, diffuse, triangles,
                                    light_positions, light_intensities, ambient, B, V, T, W, H, L,
                                    dclip, dnormals, dpositions, ddiffuse, light_grads, corner_records,
-                                   workspace, (hipStream_t)stream);
+                                   vertex_offsets, vertex_entries, workspace, (hipStream_t)stream);
 }
 
 size_t mr_shade_specular_forward_workspace_bytes(int B, int V, int T, int W, int H) {

@@ -87,7 +87,8 @@ int launch_shade_backward(const float *drgba, const int32_t *ids, const float *b
                           const float *diffuse, const int32_t *tris, const float *light_pos,
                           const float *light_col, const float *ambient, int B, int V, int T, int W,
                           int H, int L, float *dclip, float *dnormals, float *dpositions,
-                          float *ddiffuse, float *light_grads, const void *corner_records, void *ws, hipStream_t s);
+                          float *ddiffuse, float *light_grads, const void *corner_records,
+                          const int32_t *vertex_offsets, const int32_t *vertex_entries, void *ws, hipStream_t s);
 
 size_t shade_specular_forward_ws(int B, int V, int T, int W, int H);
 int launch_shade_specular_forward(const int32_t *ids, const float *bary, const float *normals,

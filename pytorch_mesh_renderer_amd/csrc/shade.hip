@@ -389,6 +389,39 @@ __global__ __launch_bounds__(kThreads) void k_shade_scatter(
   }
 }
 
+// Vertex-centric alternative to k_shade_scatter: one thread per (image, vertex) sums the rows
+// of the triangles incident to its vertex (CSR adjacency built once per triangle array on the
+// host side: entry e = 3 * triangle + corner, grouped by vertex).  No atomics, every output is
+// written exactly once, the summation order is fixed.
+__global__ __launch_bounds__(kThreads) void k_shade_gather(
+    const float *__restrict__ acc, const int32_t *__restrict__ offsets, const int32_t *__restrict__ entries,
+    int B, int V, int T, float *__restrict__ dnormals, float *__restrict__ dpositions,
+    float *__restrict__ ddiffuse, float *__restrict__ dclip) {
+  const long gid = (long)blockIdx.x * kThreads + threadIdx.x;
+  if (gid >= (long)B * V) return;
+  const int b = (int)(gid / V);
+  const int v = (int)(gid - (long)b * V);
+  float a[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, c[3] = {0.f, 0.f, 0.f};
+  const int e1 = offsets[v + 1];
+  for (int i = offsets[v]; i < e1; ++i) {
+    const int e = entries[i];
+    const int t = e / 3, k = e - 3 * t;
+    const float *row = acc + ((size_t)b * T + t) * 36;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) a[j] += row[k * 9 + j];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) c[j] += row[27 + k * 3 + j];
+  }
+  const size_t v3 = (size_t)gid * 3;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    dnormals[v3 + j] = a[j];
+    dpositions[v3 + j] = a[3 + j];
+    ddiffuse[v3 + j] = a[6 + j];
+  }
+  ((float4 *)dclip)[gid] = make_float4(c[0], c[1], 0.0f, c[2]);  // column z stays 0
+}
+
 inline unsigned capped_blocks(size_t n) {
   const size_t want = (n + kThreads - 1) / kThreads;
   const size_t cap = 256u * 32u;
@@ -444,7 +477,8 @@ int launch_shade_backward(const float *drgba, const int32_t *ids, const float *b
                           const float *diffuse, const int32_t *tris, const float *light_pos,
                           const float *light_col, const float *ambient, int B, int V, int T, int W,
                           int H, int L, float *dclip, float *dnormals, float *dpositions,
-                          float *ddiffuse, float *light_grads, const void *corner_records, void *ws,
+                          float *ddiffuse, float *light_grads, const void *corner_records,
+                          const int32_t *vertex_offsets, const int32_t *vertex_entries, void *ws,
                           hipStream_t s) {
   if (B == 0) return MR_OK;
   const size_t v3 = (size_t)B * V * 3 * sizeof(float), v4 = (size_t)B * V * 4 * sizeof(float);
@@ -493,6 +527,12 @@ int launch_shade_backward(const float *drgba, const int32_t *ids, const float *b
   }
 #undef MR_SHADE_BWD
   if (rc != MR_OK) return rc;
+  if (vertex_offsets && vertex_entries) {
+    const long nbv = (long)B * V;
+    hipLaunchKernelGGL(k_shade_gather, dim3((unsigned)((nbv + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+                       s, acc, vertex_offsets, vertex_entries, B, V, T, dnormals, dpositions, ddiffuse, dclip);
+    return check_launch();
+  }
   const long nbt = (long)B * T;
   hipLaunchKernelGGL(k_shade_scatter, dim3((unsigned)((nbt + kThreads - 1) / kThreads)),
                      dim3(kThreads), 0, s, acc, tris, B, V, T, dnormals, dpositions, ddiffuse, dclip);

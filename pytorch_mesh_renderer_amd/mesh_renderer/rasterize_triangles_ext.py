@@ -91,7 +91,9 @@ class FusedPhongRenderer(torch.autograd.Function):
         amb = ambient.detach().contiguous() if ambient is not None else None
         rgba, corner_records = _native.shade_forward(ids, bary, args[0], args[1], args[2], triangles, lp, li,
                                                      amb, keep_corner_records=True)
-        saved = [clip_d, ids, bary, args[0], args[1], args[2], triangles, lp, li, corner_records]
+        offsets, entries = _native.vertex_adjacency(triangles, positions.shape[1])   # cached per mesh
+        saved = [clip_d, ids, bary, args[0], args[1], args[2], triangles, lp, li, corner_records,
+                 offsets, entries]
         if amb is not None:
             saved.append(amb)
         ctx.save_for_backward(*saved)
@@ -101,11 +103,12 @@ class FusedPhongRenderer(torch.autograd.Function):
     @staticmethod
     def backward(ctx, drgba):
         saved = ctx.saved_tensors
-        clip, ids, bary, normals, positions, diffuse, triangles, lp, li, corner_records = saved[:10]
-        amb = saved[10] if ctx.has_ambient else None
+        (clip, ids, bary, normals, positions, diffuse, triangles, lp, li, corner_records, offsets,
+         entries) = saved[:12]
+        amb = saved[12] if ctx.has_ambient else None
         dclip, dn, dp, dd, dlp, dli, damb = _native.shade_backward(
             drgba.contiguous(), ids, bary, clip, normals, positions, diffuse, triangles, lp, li, amb,
-            corner_records=corner_records)
+            corner_records=corner_records, adjacency=(offsets, entries))
         return dclip, dp, dn, dd, None, dlp, dli, damb, None, None
 
 

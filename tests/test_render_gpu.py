@@ -387,3 +387,23 @@ def test_fused_specular_matches_composed_path(device, n_lights, ambient):
     for k in grads_c:
         assert np.isfinite(grads_f[k]).all() and np.abs(grads_c[k]).max() > 0, k
         np.testing.assert_allclose(grads_f[k], grads_c[k], atol=ATOL, rtol=0, err_msg=k)
+
+
+def test_shade_backward_gather_matches_scatter(device):
+    """mr_shade_backward with the CSR vertex adjacency (per-vertex gather, what render() uses) vs
+    without it (float-atomic scatter), incl. a triangle with a repeated and an out-of-range vertex."""
+    from pytorch_mesh_renderer_amd import _native
+    job = synthetic.sphere_job(2, 120, 90, 10)
+    d = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in job.items()}
+    tris = d["triangles"].clone()
+    tris[3, 1] = tris[3, 0]                       # repeated vertex
+    tris[5, 2] = d["vertices"].shape[1] + 7       # out of range: ignored by both
+    ids, bary, _ = _native.rasterize_forward(d["clip"], tris, 120, 90)
+    args = (ids, bary, d["clip"], d["normals"], d["vertices"], d["diffuse"], tris, d["light_positions"],
+            d["light_intensities"], None)
+    g = torch.randn(2, 90, 120, 4, generator=torch.Generator().manual_seed(1)).to(device) / (90 * 120)
+    scatter = _native.shade_backward(g, *args)
+    gather = _native.shade_backward(g, *args, adjacency=_native.vertex_adjacency(tris, d["vertices"].shape[1]))
+    for name, a, b in zip(("dclip", "dnormals", "dpositions", "ddiffuse", "dlpos", "dlint"), scatter, gather):
+        assert float(a.abs().max()) > 0, name
+        np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), atol=1e-7, rtol=1e-5, err_msg=name)
