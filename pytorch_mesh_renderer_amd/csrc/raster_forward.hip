@@ -372,7 +372,8 @@ __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
         const int ebase = w * 32;
         // (1) coverage: wave-uniform entry, all lanes; one mask bit per candidate.  (Requesting
         //     the next candidate's entry before evaluating the current one was measured slower:
-        //     +5 VGPRs cost the seventh wave per SIMD, 0.371 -> 0.394 ms.)
+        //     +5 VGPRs cost the seventh wave per SIMD, 0.371 -> 0.394 ms; two candidates per trip
+        //     at 70 VGPRs changed nothing: the loop does not wait on LDS latency.)
         unsigned mine = 0u;
         while (todo) {
           const int j = __builtin_ctz(todo);
