@@ -263,6 +263,33 @@ __device__ __forceinline__ bool rect_outside_triangle(const float4 q0, const flo
 #ifndef MR_RASTER_WAVES
 #define MR_RASTER_WAVES 7  // register-allocation hint: yields 71 VGPRs (<= 72 = 7 waves per SIMD)
 #endif
+// b_i = e_i / s, correctly rounded, for three numerators over ONE denominator (cpp:385-387).
+// fp32 '/' lowers to  v_div_scale x2, v_rcp, 2 FMAs refining the reciprocal, v_mul + 3 FMAs
+// refining the quotient, v_div_fmas, v_div_fixup.  When the operands are far from the exponent
+// range's ends -- s in [2^-20, 2^20], every numerator in [2^-60, ~s] -- v_div_scale scales
+// nothing, v_div_fmas is a plain FMA and v_div_fixup returns its input, so the result is exactly
+// the FMA chain below; the refined reciprocal depends on s alone and is computed once (22 VALU
+// instructions and one v_rcp instead of 30 and three).  Anything else -- on-edge pixels with a
+// zero numerator, extreme magnitudes -- takes the ordinary division.
+__device__ __forceinline__ void div3_common_denominator(float n0, float n1, float n2, float s, float &q0,
+                                                        float &q1, float &q2) {
+  const bool plain = (__builtin_fminf(__builtin_fminf(n0, n1), n2) >= 0x1p-60f) &
+                     (__builtin_amdgcn_fmed3f(s, 0x1p-20f, 0x1p20f) == s);
+  if (plain) {
+    const float r0 = __builtin_amdgcn_rcpf(s);
+    const float r = __builtin_fmaf(__builtin_fmaf(-s, r0, 1.0f), r0, r0);
+    auto quotient = [&](const float n) {
+      float q = n * r;
+      q = __builtin_fmaf(__builtin_fmaf(-s, q, n), r, q);
+      q = __builtin_fmaf(__builtin_fmaf(-s, q, n), r, q);
+      return q;
+    };
+    q0 = quotient(n0); q1 = quotient(n1); q2 = quotient(n2);
+  } else {
+    q0 = n0 / s; q1 = n1 / s; q2 = n2 / s;
+  }
+}
+
 __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
     const TriRec *__restrict__ recs, const uint2 *__restrict__ bbs,
     const float *__restrict__ pxtab, const float *__restrict__ pytab, int T, int W, int H,
@@ -428,7 +455,8 @@ __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
             const float e0 = e01.x, e1 = e01.y;
             const float e2 = (t.q1.z * px + t.q1.w * py) + t.q2.x;
             const float s = (e0 + e1) + e2;                              // cpp:384
-            const float b0 = e0 / s, b1 = e1 / s, b2 = e2 / s;           // cpp:385-387
+            float b0, b1, b2;
+            div3_common_denominator(e0, e1, e2, s, b0, b1, b2);          // cpp:385-387
             const float cz = (b0 * t.q2.y + b1 * t.q2.z) + b2 * t.q2.w;  // cpp:395
             const float cw = (b0 * t.q3.x + b1 * t.q3.y) + b2 * t.q3.z;  // cpp:396
             const float zz = cz / cw;                                    // cpp:397
