@@ -127,8 +127,9 @@ __global__ __launch_bounds__(kThreads) void k_setup(
         // edge i = (m[3i], m[3i+1], m[3i+2]); edges 0 and 1 interleaved for packed fp32 math
         rec.a = make_float4(m0, m3, m1, m4);
         rec.b = make_float4(m2, m5, m6, m7);
-        rec.c = make_float4(m8, p0.z, p1.z, p2.z);
-        rec.d = make_float4(w0, w1, w2, 0.0f);
+        // (z_k, w_k) pairs: the depth loop forms clip z and clip w with packed fp32 math
+        rec.c = make_float4(m8, 0.0f, p0.z, w0);
+        rec.d = make_float4(p1.z, w1, p2.z, w2);
         recs[gid] = rec;
       }
     }
@@ -208,8 +209,8 @@ constexpr int kWaves = kThreads / kWave;
 constexpr int kBin2Cap = kSubCap * kWaves;
 static_assert(kSubCap >= kWave, "a 64-triangle chunk must always fit an empty sub-bin (progress)");
 
-// Entry layout (dwords): 0-3 a0 a1 b0 b1 | 4-7 c0 c1 a2 b2 | 8 c2 | 9-11 z0 z1 z2 | 12-14 w0 w1 w2 |
-// 15 id | 16 bbox clipped to the region, region-relative: l | bottom << 16 | 17 (w-1) | (h-1) << 16 |
+// Entry layout (dwords): 0-3 a0 a1 b0 b1 | 4-7 c0 c1 a2 b2 | 8 c2 | 9 id | 10-15 z0 w0 z1 w1 z2 w2 |
+// 16 bbox clipped to the region, region-relative: l | bottom << 16 | 17 (w-1) | (h-1) << 16 |
 // 18-19 scratch
 // where edge_i(px, py) = (a_i * px + b_i * py) + c_i  (cpp:46).
 struct Entry {
@@ -457,12 +458,14 @@ __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
             const float s = (e0 + e1) + e2;                              // cpp:384
             float b0, b1, b2;
             div3_common_denominator(e0, e1, e2, s, b0, b1, b2);          // cpp:385-387
-            const float cz = (b0 * t.q2.y + b1 * t.q2.z) + b2 * t.q2.w;  // cpp:395
-            const float cw = (b0 * t.q3.x + b1 * t.q3.y) + b2 * t.q3.z;  // cpp:396
+            // cpp:395-396: cz = (b0 z0 + b1 z1) + b2 z2 and cw likewise, as (z, w) pairs
+            const v2f zw = (v2f{t.q2.z, t.q2.w} * v2f{b0, b0} + v2f{t.q3.x, t.q3.y} * v2f{b1, b1}) +
+                           v2f{t.q3.z, t.q3.w} * v2f{b2, b2};
+            const float cz = zw.x, cw = zw.y;
             const float zz = cz / cw;                                    // cpp:397
             if (!(zz < -1.0f || zz > 1.0f || zz > st.z)) {               // cpp:401
               st.z = zz;
-              st.id = __builtin_bit_cast(int, t.q3.w);
+              st.id = __builtin_bit_cast(int, t.q2.y);
               st.b0 = b0; st.b1 = b1; st.b2 = b2;
             }
           }
@@ -532,11 +535,11 @@ __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
                                                           __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
           float *p = s_ent + (wave * kSubCap + count + rank) * kEntryDw;
           const TriRec *rp = img_recs + t;  // L1/L2-hot: just read by the reject test
-          const float4 q3 = rp->d;
+          const float4 q2 = rp->c;
           *(float4 *)(p) = rp->a;
           *(float4 *)(p + 4) = rp->b;
-          *(float4 *)(p + 8) = rp->c;
-          *(float4 *)(p + 12) = make_float4(q3.x, q3.y, q3.z, __builtin_bit_cast(float, t));
+          *(float4 *)(p + 8) = make_float4(q2.x, __builtin_bit_cast(float, t), q2.z, q2.w);
+          *(float4 *)(p + 12) = rp->d;
           const int l = (int)(bb[u].x & 0xffffu), r = (int)(bb[u].x >> 16);
           const int bt = (int)(bb[u].y & 0xffffu), tp = (int)(bb[u].y >> 16);
           // bbox clipped to the region, region-relative: (l | b << 16), (w - 1 | h - 1 << 16)
