@@ -99,9 +99,10 @@ def make_step(job, device, gather):
         image = forward()
         if gather is not None:
             gather.wait()                # the previous step's hand-over (no-op the first time) ...
-            # ... then this one: 8-bit frames (what the reference's examples write out), on the side
-            # stream, so that it overlaps the loss, the backward and the next step's forward
-            gather.start(mesh_renderer.to_uint8(image))
+            # ... then this one: 8-bit frames (what the reference's examples write out); conversion
+            # and transfer both run on the side stream, overlapping the loss, the backward and the
+            # next step's forward
+            gather.start(image, transform=mesh_renderer.to_uint8)
         loss = mesh_renderer.losses.l1_loss(image, target)   # mean |image - target|, one HIP pass each way
         loss.backward()
         return loss

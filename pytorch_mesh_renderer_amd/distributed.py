@@ -90,9 +90,12 @@ class ImageGather:
         self._out = None
         self._work = None
 
-    def start(self, local):
+    def start(self, local, transform=None):
+        """transform: optional callable applied to `local` ON THE SIDE STREAM before the
+        collective (e.g. mesh_renderer.to_uint8: the 8-bit conversion then overlaps the caller's
+        compute too instead of sitting on its stream)."""
         if self.world == 1 and not self.force:
-            self._out = local
+            self._out = transform(local) if transform is not None else local
             return
         max_count = max(self.counts)
         if local.shape[0] != self.counts[self.rank]:
@@ -106,6 +109,10 @@ class ImageGather:
         ctx = torch.cuda.stream(self._side) if on_gpu else _NullContext()
         with ctx:
             send = local.detach()
+            if transform is not None:
+                if on_gpu:
+                    send.record_stream(self._side)   # read by the side stream: keep it alive for it
+                send = transform(send)
             if send.shape[0] != max_count:
                 pad = torch.zeros((max_count - send.shape[0],) + tuple(send.shape[1:]),
                                   dtype=send.dtype, device=send.device)

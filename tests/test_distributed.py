@@ -41,7 +41,12 @@ def _root_worker(rank, world, port, n_total, out_dir):
         handle.start(_oracle_render(shard, 24, 20))
     full = handle.wait()
     assert (full is not None) == (rank == 0)
+    # the transform hook (bench.py hands over 8-bit frames): applied to the shard before the gather
+    to_u8 = lambda t: (t.clamp(0, 1) * 255).to(torch.uint8)
+    handle.start(_oracle_render(shard, 24, 20), transform=to_u8)
+    frames = handle.wait()
     if rank == 0:
+        assert frames.dtype == torch.uint8 and torch.equal(frames, to_u8(full))
         torch.save(full, os.path.join(out_dir, "root.pt"))
     dist.barrier()
     dist.destroy_process_group()
