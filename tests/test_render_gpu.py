@@ -407,3 +407,22 @@ def test_shade_backward_gather_matches_scatter(device):
     for name, a, b in zip(("dclip", "dnormals", "dpositions", "ddiffuse", "dlpos", "dlint"), scatter, gather):
         assert float(a.abs().max()) > 0, name
         np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), atol=1e-7, rtol=1e-5, err_msg=name)
+
+
+def test_step_is_capturable_into_a_hip_graph(device):
+    """render() + l1_loss + backward captured with torch.cuda.CUDAGraph (hipGraph) and replayed after an
+    in-place vertex update gives the eager result: the C ABI neither allocates nor synchronises."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import graph_bench
+    vertices, step = graph_bench.build(2, 96, 8, device)
+    graph, loss = graph_bench.capture(vertices, step)
+    with torch.no_grad():
+        vertices.mul_(1.03)                       # new input values, same storage
+    graph.replay()
+    torch.cuda.synchronize()
+    got_loss, got_grad = float(loss), vertices.grad.clone()
+    vertices.grad = None
+    want_loss = float(step().detach())
+    assert abs(got_loss - want_loss) < 1e-7
+    np.testing.assert_allclose(got_grad.cpu().numpy(), vertices.grad.cpu().numpy(), atol=1e-9, rtol=1e-5)
+    assert float(got_grad.abs().max()) > 0
