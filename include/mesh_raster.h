@@ -242,6 +242,12 @@ int mr_export_u8(const float *image, size_t n, uint8_t *out, void *stream);
  * UNDEFINED while a probe is selected; any other value returns MR_EINVAL. */
 int mr_set_raster_tile_shape(int shape);
 
+/* ---- region size of the forward raster kernel (test hook) -------------------------------
+ * The kernel walks 64x64-pixel regions per workgroup, or 32x32 when the launch is small (fewer than
+ * four 64x64 regions per CU).  0 = that automatic choice (default); 32 / 64 force one.  Results are
+ * bit-identical either way; the workspace queries follow the setting, so set it before querying. */
+int mr_set_raster_region_edge(int edge);
+
 /* ---- measurement hook -------------------------------------------------------
  * When both are non-NULL, every mr_rasterize_forward() records hipEvent `start`
  * immediately before and `stop` immediately after its G-buffer kernel (k_raster)

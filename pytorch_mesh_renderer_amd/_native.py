@@ -54,6 +54,8 @@ def lib():
         L.mr_last_hip_error.restype = ci
         L.mr_set_raster_tile_shape.argtypes = [ci]
         L.mr_set_raster_tile_shape.restype = ci
+        L.mr_set_raster_region_edge.argtypes = [ci]
+        L.mr_set_raster_region_edge.restype = ci
         L.mr_set_raster_profile_events.argtypes = [vp, vp]
         L.mr_set_raster_profile_events.restype = ci
         L.mr_rasterize_forward_workspace_bytes.argtypes = [ci] * 5

@@ -20,6 +20,7 @@ inline int check_ws(const void *ws, size_t have, size_t need) {
 
 namespace mr {
 extern int g_raster_tile_shape;
+extern int g_raster_region_edge;
 extern hipEvent_t g_raster_ev_start, g_raster_ev_stop;
 }
 
@@ -37,6 +38,14 @@ int mr_set_raster_tile_shape(int shape) {
   for (int v : kProbes) ok |= (v == shape);
   if (!ok) return MR_EINVAL;
   mr::g_raster_tile_shape = shape;
+  return MR_OK;
+}
+
+// Test hook: force the workgroup region edge of the forward raster kernel (0 = automatic choice
+// from the launch dimensions, 32, 64).  Results are identical; workspace queries follow it.
+int mr_set_raster_region_edge(int edge) {
+  if (edge != 0 && edge != 32 && edge != 64) return MR_EINVAL;
+  mr::g_raster_region_edge = edge;
   return MR_OK;
 }
 

@@ -7,7 +7,7 @@
 //   k_setup   one thread per (image, triangle): sign-corrected adjugate, clip z/w,
 //             pixel bbox (binary64 projection as in cpp:361-366), packed into a
 //             64-byte record; plus the binary64 pixel-centre tables (cpp:376-377).
-//   k_raster  one 256-thread workgroup per 64x64-pixel region, two stages:
+//   k_raster  one 256-thread workgroup per 64x64-pixel region (32x32 for small launches), two stages:
 //     bin    each wavefront scans a quarter of the image's triangle list (no barrier
 //            in the loop): bbox-vs-region test, then an EXACT trivial reject -- the
 //            reference's own edge function evaluated at the region's most favourable
@@ -43,8 +43,6 @@ thread_local int g_last_hip_error = 0;
 
 namespace {
 
-constexpr int kRegionW = 64;   // pixels per workgroup region
-constexpr int kRegionH = 64;
 constexpr int kThreads = 256;
 
 // x86 cvttss2si semantics for the reference's static_cast<int> (cpp:21,29):
@@ -142,20 +140,18 @@ __global__ __launch_bounds__(kThreads) void k_setup(
 // triangle-id order, the ids whose bbox touches the cell.  The raster kernel's regions
 // (4x4 per cell) then scan ~T * ((256 + d) / W)^2 ids instead of all T (d = triangle size).
 // ---------------------------------------------------------------------------------------
-constexpr int kCellRegions = 4;                       // regions per cell edge
-constexpr int kCellW = kCellRegions * kRegionW;       // 256
-constexpr int kCellH = kCellRegions * kRegionH;
+constexpr int kCellRegions = 4;                       // regions per cell edge (cell = 4 x 4 regions)
 constexpr int kCoarseThreads = 1024;
 
 __global__ __launch_bounds__(kCoarseThreads) void k_coarse(
-    const uint2 *__restrict__ bbs, int T, int W, int H, int cells_x, int cells_per_image,
+    const uint2 *__restrict__ bbs, int T, int W, int H, int cells_x, int cells_per_image, int cell_size,
     int32_t *__restrict__ cell_ids, int32_t *__restrict__ cell_count) {
   __shared__ int s_wave_count[kCoarseThreads / kWave];
   const int img = (int)blockIdx.x / cells_per_image;
   const int cell = (int)blockIdx.x - img * cells_per_image;
   const int cy = cell / cells_x, cx = cell - cy * cells_x;
-  const int X0 = cx * kCellW, Y0 = cy * kCellH;
-  const int X1 = min(X0 + kCellW, W), Y1 = min(Y0 + kCellH, H);
+  const int X0 = cx * cell_size, Y0 = cy * cell_size;
+  const int X1 = min(X0 + cell_size, W), Y1 = min(Y0 + cell_size, H);
   const int tid = (int)threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
   const uint2 *img_bbs = bbs + (size_t)img * T;
   int32_t *out = cell_ids + ((size_t)img * cells_per_image + cell) * T;
@@ -291,6 +287,10 @@ __device__ __forceinline__ void div3_common_denominator(float n0, float n1, floa
   }
 }
 
+// R = region edge in pixels: 64, or 32 for small launches (configs[1]: 8 x 256^2 is only 128
+// regions of 64^2 -- half the CUs idle and >256 candidates per region; 512 regions of 32^2 fill
+// the chip with one bin round each).
+template <int R>
 __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
     const TriRec *__restrict__ recs, const uint2 *__restrict__ bbs,
     const float *__restrict__ pxtab, const float *__restrict__ pytab, int T, int W, int H,
@@ -298,19 +298,22 @@ __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
     const int32_t *__restrict__ cell_ids, const int32_t *__restrict__ cell_count, int cells_x,
     int cells_per_image, int32_t *__restrict__ ids, float *__restrict__ bary,
     float *__restrict__ zbuf, int debug_skip) {
-  constexpr int kTiles = (kRegionW / 8) * (kRegionH / 8);  // 64 tiles of 8x8 pixels
+  static_assert(R == 64 || R == 32, "region edge");
+  constexpr int kTilesX = R / 8;
+  constexpr int kTiles = kTilesX * kTilesX;  // 8x8-pixel tiles per region: 64 or 16
   constexpr int kMaskWords = kBin2Cap / 32;
   __shared__ __attribute__((aligned(16))) float s_ent[kBin2Cap * kEntryDw];
-  // LDS budget: 20480 (entries) + 2048 (masks / bin bookkeeping) + 512 (pixel centres) = 23040 B
-  // = 18 allocation granules of 1280 B, so that SEVEN workgroups fit the 160 KB of a CU.  The
-  // bin-stage bookkeeping is dead by the time the tile masks are built and shares their storage.
-  __shared__ unsigned s_shared[kTiles * kMaskWords];
-  unsigned (*s_tmask)[kMaskWords] = (unsigned (*)[kMaskWords])s_shared;  // per tile: entries touching it
+  // LDS budget at R = 64: 20480 (entries) + 2048 (masks / bin bookkeeping) + 512 (pixel centres)
+  // = 23040 B = 18 allocation granules of 1280 B, so that SEVEN workgroups fit the 160 KB of a CU.
+  // The bin-stage bookkeeping is dead by the time the tile masks are built and shares their storage.
   constexpr int kRoundChunks = kThreads;  // chunks of 64 triangles scanned per round
+  constexpr int kSharedDw = kTiles * kMaskWords > kRoundChunks + 3 * kWaves ? kTiles * kMaskWords
+                                                                             : kRoundChunks + 3 * kWaves;
+  __shared__ __attribute__((aligned(16))) unsigned s_shared[kSharedDw];
+  unsigned (*s_tmask)[kMaskWords] = (unsigned (*)[kMaskWords])s_shared;  // per tile: entries touching it
   int *s_chunk_count = (int *)s_shared;   // [kRoundChunks]
   int *s_count = s_chunk_count + kRoundChunks, *s_stop = s_count + kWaves, *s_wave_total = s_stop + kWaves;
-  static_assert(kRoundChunks + 3 * kWaves <= kTiles * kMaskWords, "bookkeeping must fit the mask storage");
-  __shared__ float s_pxy[2][kRegionW];  // pixel centres of the region's columns / rows
+  __shared__ float s_pxy[2][R];  // pixel centres of the region's columns / rows
 
   const int region = xcd_contiguous_block((int)blockIdx.x, n_regions, regions_per_xcd);
   if (region < 0) return;  // padding block (whole workgroup)
@@ -318,8 +321,8 @@ __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
   const int rr = region - img * regions_per_image;
   const int ry = rr / regions_x;
   const int rx = rr - ry * regions_x;
-  const int X0 = rx * kRegionW, Y0 = ry * kRegionH;
-  const int X1 = min(X0 + kRegionW, W), Y1 = min(Y0 + kRegionH, H);
+  const int X0 = rx * R, Y0 = ry * R;
+  const int X1 = min(X0 + R, W), Y1 = min(Y0 + R, H);
 
   const int tid = (int)threadIdx.x;
   const int lane = tid & (kWave - 1);
@@ -337,16 +340,16 @@ __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
   // The region's pixel centres live in LDS: the tile loop must not issue global LOADS,
   // because vmcnt is in-order on gfx950 and a load's wait would also drain the previous
   // tile's G-buffer stores (measured: +0.1 ms at 1024^2 x 32).
-  static_assert(kRegionW == kRegionH && kRegionW == kWave, "one table slot per lane");
-  if (tid < kWave) s_pxy[0][tid] = pxtab[min(X0 + tid, W - 1)];
-  else if (tid < 2 * kWave) s_pxy[1][tid - kWave] = pytab[min(Y0 + tid - kWave, H - 1)];
+  static_assert(2 * R <= kThreads, "one thread per table slot");
+  if (tid < R) s_pxy[0][tid] = pxtab[min(X0 + tid, W - 1)];
+  else if (tid < 2 * R) s_pxy[1][tid - R] = pytab[min(Y0 + tid - R, H - 1)];
 
   // ---- stage 2a: which bin entries touch which 8x8 tile -------------------------------
   // One thread per bin entry walks the tiles under the entry's bbox and applies the exact
   // trivial reject against each; survivors set their bit in the tile's 256-bit mask.  This
   // costs ~(entries x tiles-per-entry) lane-tests per region instead of (tiles x entries).
   auto build_tile_masks = [&](const int n) {
-    for (int i = tid; i < kTiles * kMaskWords; i += kThreads) s_shared[i] = 0u;
+    for (int i = tid; i < kSharedDw; i += kThreads) s_shared[i] = 0u;
     // pixel-centre extents of tile column / row t: s_pxy[.][8 t] .. s_pxy[.][min(8 t + 7, last)]
     const int last_x = X1 - 1 - X0, last_y = Y1 - 1 - Y0;
     __syncthreads();
@@ -365,7 +368,7 @@ __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
         const float ylo = s_pxy[1][ty * 8], yhi = s_pxy[1][min(ty * 8 + 7, last_y)];
         for (int tx = tx0; tx <= tx1; ++tx) {
           if (!rect_outside_triangle(q0, q1, m8, s_pxy[0][tx * 8], s_pxy[0][min(tx * 8 + 7, last_x)], ylo, yhi))
-            atomicOr(&s_tmask[ty * 8 + tx][word], bit);
+            atomicOr(&s_tmask[ty * kTilesX + tx][word], bit);
         }
       }
     }
@@ -393,7 +396,7 @@ __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
   auto raster_pass = [&](const int n, const bool fresh) {
     const int n_words = (n + 31) >> 5;
     for (int tile = wave; tile < kTiles; tile += kWaves) {
-      const int ty = tile >> 3, tx = tile & 7;
+      const int ty = tile / kTilesX, tx = tile % kTilesX;
       const int x0 = X0 + tx * 8, y0 = Y0 + ty * 8;
       if (x0 >= X1 || y0 >= Y1) continue;  // wave-uniform
       const bool in_image = lx < W - x0 && ly < H - y0;
@@ -621,10 +624,22 @@ __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
 
 }  // namespace
 
+// Region edge for a launch: 64 pixels, or 32 when 64-pixel regions would leave the chip short of
+// workgroups (fewer than four per CU).  Pure function of the dimensions: the workspace query and
+// the launcher must agree on the cell grid.
+int g_raster_region_edge = 0;  // 0: automatic; 32 / 64: forced (mr_set_raster_region_edge, tests)
+
+static int region_edge(int B, int W, int H) {
+  if (g_raster_region_edge != 0) return g_raster_region_edge;
+  const long regions64 = (long)B * ((W + 63) / 64) * ((H + 63) / 64);
+  return regions64 < 4L * 256 ? 32 : 64;
+}
+
 size_t raster_forward_ws(int B, int V, int T, int W, int H) {
   (void)V;
   const size_t nbt = (size_t)B * T;
-  const size_t cells = (size_t)((W + kCellW - 1) / kCellW) * ((H + kCellH - 1) / kCellH) * B;
+  const int cell = kCellRegions * region_edge(B, W, H);
+  const size_t cells = (size_t)((W + cell - 1) / cell) * ((H + cell - 1) / cell) * B;
   return align_up(nbt * sizeof(TriRec), 256) + align_up(nbt * sizeof(uint2), 256) +
          align_up((size_t)W * sizeof(float), 256) + align_up((size_t)H * sizeof(float), 256) +
          align_up(cells * T * sizeof(int32_t), 256) + align_up(cells * sizeof(int32_t), 256);
@@ -645,7 +660,8 @@ int launch_raster_forward(const float *clip, const int32_t *tris, int B, int V, 
   p += align_up((size_t)W * sizeof(float), 256);
   float *pytab = (float *)p;
   p += align_up((size_t)H * sizeof(float), 256);
-  const int cells_x = (W + kCellW - 1) / kCellW, cells_y = (H + kCellH - 1) / kCellH;
+  const int edge = region_edge(B, W, H), cell = kCellRegions * edge;
+  const int cells_x = (W + cell - 1) / cell, cells_y = (H + cell - 1) / cell;
   const int cells_per_image = cells_x * cells_y;
   int32_t *cell_ids = (int32_t *)p;
   p += align_up((size_t)cells_per_image * B * T * sizeof(int32_t), 256);
@@ -659,28 +675,30 @@ int launch_raster_forward(const float *clip, const int32_t *tris, int B, int V, 
   if (rc != MR_OK) return rc;
   if (B == 0) return MR_OK;
   hipLaunchKernelGGL(k_coarse, dim3((unsigned)(cells_per_image * B)), dim3(kCoarseThreads), 0, s, bbs, T,
-                     W, H, cells_x, cells_per_image, cell_ids, cell_count);
+                     W, H, cells_x, cells_per_image, cell, cell_ids, cell_count);
   rc = check_launch();
   if (rc != MR_OK) return rc;
 
-  const int regions_x = (W + kRegionW - 1) / kRegionW;
-  const int regions_y = (H + kRegionH - 1) / kRegionH;
+  const int regions_x = (W + edge - 1) / edge;
+  const int regions_y = (H + edge - 1) / edge;
   const int per_image = regions_x * regions_y;
   const int n_regions = per_image * B;
   const int per_xcd = (n_regions + kXcds - 1) / kXcds;
   const dim3 grid((unsigned)(per_xcd * kXcds)), block(kThreads);
-  if (g_raster_ev_start) (void)hipEventRecord(g_raster_ev_start, s);
+  int probe = 0;  // timing probes (results are NOT valid), see mr_set_raster_tile_shape
   switch (g_raster_tile_shape) {
-    case 3: case 4: case 5: case 10: case 18: case 34: case 42:  // timing probes (results are NOT valid)
-      hipLaunchKernelGGL(k_raster, grid, block, 0, s, recs, bbs, pxtab, pytab, T, W, H, regions_x,
-                         per_image, n_regions, per_xcd, cell_ids, cell_count, cells_x, cells_per_image,
-                         ids, bary, z, g_raster_tile_shape - 2);
-      break;
-    default:
-      hipLaunchKernelGGL(k_raster, grid, block, 0, s, recs, bbs, pxtab, pytab, T, W, H, regions_x,
-                         per_image, n_regions, per_xcd, cell_ids, cell_count, cells_x, cells_per_image,
-                         ids, bary, z, 0);
-      break;
+    case 3: case 4: case 5: case 10: case 18: case 34: case 42: probe = g_raster_tile_shape - 2; break;
+    default: break;
+  }
+  if (g_raster_ev_start) (void)hipEventRecord(g_raster_ev_start, s);
+  if (edge == 32) {
+    hipLaunchKernelGGL(k_raster<32>, grid, block, 0, s, recs, bbs, pxtab, pytab, T, W, H, regions_x,
+                       per_image, n_regions, per_xcd, cell_ids, cell_count, cells_x, cells_per_image,
+                       ids, bary, z, probe);
+  } else {
+    hipLaunchKernelGGL(k_raster<64>, grid, block, 0, s, recs, bbs, pxtab, pytab, T, W, H, regions_x,
+                       per_image, n_regions, per_xcd, cell_ids, cell_count, cells_x, cells_per_image,
+                       ids, bary, z, probe);
   }
   if (g_raster_ev_stop) (void)hipEventRecord(g_raster_ev_stop, s);
   return check_launch();

@@ -15,9 +15,11 @@ from pytorch_mesh_renderer_amd import _native
 ap = argparse.ArgumentParser()
 ap.add_argument("--trials", type=int, default=300)
 ap.add_argument("--seed", type=int, default=1)
+ap.add_argument("--edge", type=int, default=0, help="force 32 / 64 pixel regions (0 = automatic)")
 args = ap.parse_args()
 rng = np.random.default_rng(args.seed)
 dev = torch.device("cuda:0")
+assert _native.lib().mr_set_raster_region_edge(args.edge) == 0
 bad = 0
 nan_only = 0   # trials whose only difference is the bit pattern of a NaN present on both sides
 t0 = time.time()

@@ -144,6 +144,30 @@ def test_sphere_1024_b32_config3_full_size(device):
     assert np.abs(d1).max() < 1e-4
 
 
+@pytest.mark.parametrize("edge", [32, 64])
+def test_both_region_sizes_are_bit_exact(device, edge):
+    """The forward kernel picks 32x32 or 64x64 regions from the launch size; force each on the same
+    inputs (soups with w <= 0, a 5k sphere, more triangles than one LDS bin holds)."""
+    L = _native.lib()
+    assert L.mr_set_raster_region_edge(48) == _native.MR_EINVAL
+    assert L.mr_set_raster_region_edge(edge) == _native.MR_OK
+    try:
+        rng = np.random.default_rng(123)
+        for trial in range(6):
+            V, T = int(rng.integers(3, 200)), int(rng.integers(1, 1500))
+            W, H = int(rng.integers(1, 300)), int(rng.integers(1, 260))
+            clip = rng.normal(size=(2, V, 4)).astype(np.float32)
+            if trial % 2:
+                clip[..., 3] = np.abs(clip[..., 3]) + 0.1
+            tris = rng.integers(0, V, size=(T, 3)).astype(np.int32)
+            assert_forward_bitwise(hip_forward(clip, tris, W, H, device), oracle.forward(clip, tris, W, H))
+        job = synthetic.sphere_job(3, 200, 136, 50)
+        assert_forward_bitwise(hip_forward(job["clip"].numpy(), job["triangles"].numpy(), 200, 136, device),
+                               oracle.forward(job["clip"].numpy(), job["triangles"].numpy(), 200, 136))
+    finally:
+        L.mr_set_raster_region_edge(0)
+
+
 def test_probe_hook_rejects_unknown_values(device):
     L = _native.lib()
     assert L.mr_set_raster_tile_shape(1) == _native.MR_EINVAL
