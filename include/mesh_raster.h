@@ -98,6 +98,25 @@ int mr_interpolate_backward(const float *dout, const int32_t *ids,
                             float *dattrs, float *dbary, void *workspace,
                             size_t workspace_bytes, void *stream);
 
+/* Backward of mr_interpolate_forward AND of the rasterizer underneath it in ONE pass over the
+ * G-buffer, for 1 <= A <= mr_interpolate_raster_max_attributes() (replaces the pair
+ * mr_interpolate_backward + mr_rasterize_backward, which needs ceil(A / 4) + 2 passes):
+ *   dout            [B,H,W,A] f32   dL/d(out of mr_interpolate_forward)
+ *   clip            [B,V,4]   f32   the clip-space vertices the G-buffer was made from
+ *   vertex_offsets, vertex_entries  CSR vertex -> (triangle, corner) adjacency of `triangles`
+ *                                   (see mr_shade_backward)
+ *   dattributes     [B,V,A]   f32 out, dclip [B,V,4] f32 out (16-byte aligned; column z stays 0);
+ *                                   both are written completely, no pre-zeroing needed */
+int mr_interpolate_raster_max_attributes(void);
+size_t mr_interpolate_raster_backward_workspace_bytes(int B, int V, int T, int W, int H, int A);
+int mr_interpolate_raster_backward(const float *dout, const int32_t *ids, const float *bary,
+                                   const float *clip, const float *attributes,
+                                   const int32_t *triangles, const float *background,
+                                   const int32_t *vertex_offsets, const int32_t *vertex_entries,
+                                   int B, int V, int T, int W, int H, int A, float *dattributes,
+                                   float *dclip, void *workspace, size_t workspace_bytes,
+                                   void *stream);
+
 /* ---- fused deferred shading (diffuse + ambient Phong) ---------------------------
  * Replaces, for render() without specular terms, attribute interpolation
  * (src/mesh_renderer/rasterize.py:118-150), the unpack / normalise / mask block of

@@ -94,6 +94,11 @@ def lib():
         L.mr_l1_loss_forward.restype = ci
         L.mr_l1_loss_backward.argtypes = [vp, sz, vp, vp, vp]
         L.mr_l1_loss_backward.restype = ci
+        L.mr_interpolate_raster_max_attributes.restype = ci
+        L.mr_interpolate_raster_backward_workspace_bytes.argtypes = [ci] * 6
+        L.mr_interpolate_raster_backward_workspace_bytes.restype = sz
+        L.mr_interpolate_raster_backward.argtypes = [vp] * 9 + [ci] * 6 + [vp, vp, vp, sz, vp]
+        L.mr_interpolate_raster_backward.restype = ci
         L.mr_shade_specular_forward_workspace_bytes.argtypes = [ci] * 5
         L.mr_shade_specular_forward_workspace_bytes.restype = sz
         L.mr_shade_specular_forward.argtypes = [vp] * 12 + [ci] * 6 + [vp, vp, vp, sz, vp]
@@ -263,6 +268,31 @@ def shade_forward(ids, bary, normals, positions, diffuse, triangles, light_posit
                                 _stream(dev))
     _check(rc, "mr_shade_forward")
     return (rgba, ws) if keep_corner_records else rgba
+
+
+def interpolate_raster_max_attributes():
+    return int(lib().mr_interpolate_raster_max_attributes())
+
+
+def interpolate_raster_backward(dout, ids, bary, clip, attrs, triangles, background, adjacency):
+    """One-pass backward of interpolation + rasterization -> (dattributes [B,V,A], dclip [B,V,4])."""
+    tensors = [dout, ids, bary, clip, attrs, triangles, background, adjacency[0], adjacency[1]]
+    dev = _require_device(*tensors)
+    L = lib()
+    dout, ids, bary, clip, attrs, triangles, background, offsets, entries = [t.contiguous() for t in tensors]
+    B, H, W = ids.shape
+    V, A, T = attrs.shape[1], attrs.shape[2], triangles.shape[0]
+    dattrs = torch.empty(B, V, A, dtype=torch.float32, device=dev)
+    dclip = torch.empty(B, V, 4, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        need = L.mr_interpolate_raster_backward_workspace_bytes(B, V, T, W, H, A)
+        ws, have = _workspace(dev, need)
+        rc = L.mr_interpolate_raster_backward(
+            _ptr(dout), _ptr(ids), _ptr(bary), _ptr(clip), _ptr(attrs), _ptr(triangles), _ptr(background),
+            _ptr(offsets), _ptr(entries), B, V, T, W, H, A, _ptr(dattrs), _ptr(dclip), _ptr(ws), have,
+            _stream(dev))
+    _check(rc, "mr_interpolate_raster_backward")
+    return dattrs, dclip
 
 
 def vertex_adjacency(triangles, vertex_count):

@@ -123,6 +123,35 @@ int mr_interpolate_backward(const float *dout, const int32_t *ids, const float *
                                     A, dattrs, dbary, workspace, (hipStream_t)stream);
 }
 
+int mr_interpolate_raster_max_attributes(void) { return mr::interp_raster_max_attrs(); }
+
+size_t mr_interpolate_raster_backward_workspace_bytes(int B, int V, int T, int W, int H, int A) {
+  if (bad_dims(B, V, T, W, H) || A < 0 || A > mr::interp_raster_max_attrs()) return 0;
+  return mr::interp_raster_backward_ws(B, V, T, W, H, A);
+}
+
+int mr_interpolate_raster_backward(const float *dout, const int32_t *ids, const float *bary,
+                                   const float *clip, const float *attributes,
+                                   const int32_t *triangles, const float *background,
+                                   const int32_t *vertex_offsets, const int32_t *vertex_entries, int B,
+                                   int V, int T, int W, int H, int A, float *dattributes, float *dclip,
+                                   void *workspace, size_t workspace_bytes, void *stream) {
+  if (bad_dims(B, V, T, W, H) || A < 0 || A > mr::interp_raster_max_attrs()) return MR_EINVAL;
+  if (B == 0 || V == 0) return MR_OK;
+  if (!dclip || (A > 0 && !dattributes)) return MR_EINVAL;
+  if (((uintptr_t)dclip & 15u) != 0) return MR_EINVAL;
+  if (T > 0 && A > 0 && (size_t)W * H > 0) {
+    if (!dout || !ids || !bary || !clip || !attributes || !triangles || !background || !vertex_offsets ||
+        !vertex_entries)
+      return MR_EINVAL;
+    const int rc = check_ws(workspace, workspace_bytes, mr::interp_raster_backward_ws(B, V, T, W, H, A));
+    if (rc != MR_OK) return rc;
+  }
+  return mr::launch_interp_raster_backward(dout, ids, bary, clip, attributes, triangles, background,
+                                           vertex_offsets, vertex_entries, B, V, T, W, H, A, dattributes,
+                                           dclip, workspace, (hipStream_t)stream);
+}
+
 int mr_shade_max_lights(void) { return mr::shade_max_lights(); }
 
 int mr_shade_forward(const int32_t *ids, const float *bary, const float *normals,

@@ -1,0 +1,253 @@
+// Backward of rasterize() -- attribute interpolation AND the rasterizer underneath it -- in ONE pass
+// over the G-buffer, for gfx950 (MI355X).
+//
+// Replaces, for mesh_renderer.rasterize / rasterize_clip_space with up to 16 attributes, the
+// autograd graph the reference builds behind src/mesh_renderer/rasterize.py:118-150 (corner
+// gather, multiply / sum, alpha clamp, background blend: index_put_(accumulate) into the
+// attributes and d/d barycentrics) chained into rasterize_triangles.cpp:131-273.  The composed
+// kernels of interpolate.hip + raster_backward.hip need ceil(A / 4) + 2 passes (4.4 ms at
+// 1024^2 x 32, A = 9); here the per-triangle sums are the outer product of the 3 barycentrics
+// with (A attribute gradients x alpha, 3 clip brackets), exactly the shape the row kernel of
+// run_accum.h reduces: each pixel parks 3 + A + 3 factors, 3 (A + 3) sums per triangle.
+//
+//   k_attr_corner_setup<AP>   one thread per (image, triangle): the three corners' attributes
+//                             as one record (the per-pixel kernels follow ONE pointer)
+//   k_accumulate_rows<AttrRowsFn<AP>>   reads dL/dout (4 A B/px) + id + barycentrics (16 B/px)
+//   k_attr_gather<AP>         one thread per (image, vertex): sums its incident triangles' rows
+//                             (CSR adjacency from the host side): dattributes, dclip
+//
+// AP = A rounded up to 4, 8, 12 or 16 (template parameter; the tail attributes are zeros).
+#include "run_accum.h"
+
+namespace mr {
+namespace {
+
+constexpr int kThreads = 256;
+constexpr float kDegenerateCutoff = 0.9f;  // rasterize_triangles.cpp:13
+
+template <int AP>
+struct AttrCorners {
+  float c[3][AP];
+};
+
+template <int AP>
+__global__ __launch_bounds__(kThreads) void k_attr_corner_setup(
+    const float *__restrict__ attrs, const int32_t *__restrict__ tris, int B, int V, int T, int A,
+    float *__restrict__ out) {
+  const long gid = (long)blockIdx.x * kThreads + threadIdx.x;
+  if (gid >= (long)B * T) return;
+  const int b = (int)(gid / T);
+  const int t = (int)(gid - (long)b * T);
+  float *rec = out + gid * (3 * AP);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    int vi = tris[3 * t + k];
+    if ((unsigned)vi >= (unsigned)V) vi = 0;
+    const float *src = attrs + ((size_t)b * V + vi) * A;
+#pragma unroll
+    for (int a = 0; a < AP; ++a) rec[k * AP + a] = a < A ? src[a] : 0.0f;
+  }
+}
+
+template <int AP>
+struct AttrRowsFn {
+  static constexpr int kN = 3 * AP + 9;          // [corner][attribute] partials + 9 clip partials
+  static constexpr int kStride = (kN + 3) & ~3;  // floats per acc row
+  static constexpr int kSlots = 256;
+  static constexpr int kMinWavesPerSimd = AP <= 8 ? 4 : 3;
+  static constexpr bool kCountBackground = false;
+  // parked per pixel: b[3] | y[AP] = alpha * dL/dout | q[3] = clip brackets
+  static constexpr int kFactors = AP + 6;
+  // multiple of 4 (ds_write_b128) and an ODD multiple of 4 (bank-conflict-free row stride)
+  static constexpr int kFactorStride = AP == 4 ? 12 : (AP <= 12 ? 20 : 28);
+  static_assert(kFactors <= kFactorStride && kN <= kWave, "row layout");
+  __device__ static void factor_pair(int o, int &ia, int &ib) {
+    if (o < 3 * AP) { ia = o / AP; ib = 3 + o % AP; }
+    else { ia = (o - 3 * AP) / 3; ib = 3 + AP + (o - 3 * AP) % 3; }
+  }
+  const float *__restrict__ dout;       // [B,H,W,A]
+  const int32_t *__restrict__ ids;
+  const F3 *__restrict__ bary;
+  const float *__restrict__ corners;    // [B,T,3*AP]
+  const BwdRec *__restrict__ recs;
+  const float *__restrict__ background; // [A]
+  int A, T_;
+
+  struct Pixel {
+    F3 b;
+    float g[AP];
+    int tri;
+  };
+  struct Raw {
+    F3 b;
+    int t;
+    float g[AP];
+  };
+  struct Triangle {
+    AttrCorners<AP> cr;
+    BwdTriangle bt;
+  };
+  struct Image {
+    int n_bg;  // unused (kCountBackground = false)
+  };
+
+  __device__ __forceinline__ void begin_image(int, Image &) const {}
+  __device__ __forceinline__ void end_image(int, Image &) const {}
+  __device__ __forceinline__ void fetch(int, int, int, size_t pix, Raw &r) const {
+    r.b = bary[pix];
+    r.t = ids[pix];
+    const float *g = dout + pix * A;
+#pragma unroll
+    for (int a = 0; a < AP; ++a) r.g[a] = a < A ? g[a] : 0.0f;  // wave-uniform test
+  }
+  __device__ __forceinline__ bool prepare(const Raw &r, int T, int &tri, Pixel &p) const {
+    const float pre = (2.0f * r.b.x + 2.0f * r.b.y) + 2.0f * r.b.z;
+    // alpha == 0: every attribute term is alpha * ... = 0 and the rasterizer skips the pixel
+    // (only triangle 0 can own a pixel with an all-zero barycentric sum, cpp:162)
+    if (!(pre > 0.0f)) return false;
+    if ((unsigned)r.t >= (unsigned)T) return false;
+    p.b = r.b;
+#pragma unroll
+    for (int a = 0; a < AP; ++a) p.g[a] = r.g[a];
+    p.tri = r.t;
+    tri = r.t;
+    return true;
+  }
+  __device__ __forceinline__ void load_triangle(int img, int tri, Triangle &t) const {
+    const float4 *src = (const float4 *)(corners + ((size_t)img * T_ + tri) * (3 * AP));
+#pragma unroll
+    for (int q = 0; q < 3 * AP / 4; ++q) {
+      const float4 f = src[q];
+      const float v[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) t.cr.c[(4 * q + j) / AP][(4 * q + j) % AP] = v[j];
+    }
+    load_bwd_triangle(recs + (size_t)img * T_ + tri, t.bt);
+  }
+
+  __device__ __forceinline__ void factors(const Pixel &p, const Triangle &t, float (&f)[kFactorStride],
+                                          Image &) const {
+    const float pre = (2.0f * p.b.x + 2.0f * p.b.y) + 2.0f * p.b.z;
+    const float alpha = fminf(fmaxf(pre, 0.0f), 1.0f);  // rasterize.py:145-147
+    float dalpha = 0.f, db[3] = {0.f, 0.f, 0.f};
+    f[0] = p.b.x; f[1] = p.b.y; f[2] = p.b.z;
+#pragma unroll
+    for (int a = 0; a < AP; ++a) {
+      const float go = p.g[a];
+      const float gv = alpha * go;  // d/d(interpolated value), rasterize.py:149-150
+      const float value = (t.cr.c[0][a] * p.b.x + t.cr.c[1][a] * p.b.y) + t.cr.c[2][a] * p.b.z;
+      dalpha += go * (value - (a < A ? background[a] : 0.0f));
+#pragma unroll
+      for (int k = 0; k < 3; ++k) db[k] += gv * t.cr.c[k][a];
+      f[3 + a] = gv;  // d/d attr[corner k][a] = b_k * gv: the product is formed in the reduction
+    }
+    // torch.clamp passes the gradient where min <= x <= max (inclusive)
+    const float dpre = (pre >= 0.0f && pre <= 1.0f) ? 2.0f * dalpha : 0.0f;
+    F3 dbary;
+    dbary.x = db[0] + dpre; dbary.y = db[1] + dpre; dbary.z = db[2] + dpre;
+    // rasterizer backward (cpp:162 skip rule, then cpp:202-269)
+    const bool skip = p.tri == 0 && (p.b.x + p.b.y) + p.b.z < kDegenerateCutoff;
+    float q[3];
+    raster_pixel_q(p.b, dbary, t.bt, skip ? 0.f : t.bt.inv, q);
+    f[3 + AP] = q[0]; f[4 + AP] = q[1]; f[5 + AP] = q[2];
+#pragma unroll
+    for (int k = kFactors; k < kFactorStride; ++k) f[k] = 0.f;
+  }
+};
+
+// One thread per (image, vertex): sums the rows of the triangles incident to its vertex (CSR
+// adjacency: entry = 3 * triangle + corner).  Every output is written exactly once, no atomics.
+template <int AP>
+__global__ __launch_bounds__(kThreads) void k_attr_gather(
+    const float *__restrict__ acc, const int32_t *__restrict__ offsets, const int32_t *__restrict__ entries,
+    int B, int V, int T, int A, float *__restrict__ dattrs, float *__restrict__ dclip) {
+  constexpr int STRIDE = AttrRowsFn<AP>::kStride;
+  const long gid = (long)blockIdx.x * kThreads + threadIdx.x;
+  if (gid >= (long)B * V) return;
+  const int b = (int)(gid / V);
+  const int v = (int)(gid - (long)b * V);
+  float a[AP], c[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < AP; ++j) a[j] = 0.f;
+  const int e1 = offsets[v + 1];
+  for (int i = offsets[v]; i < e1; ++i) {
+    const int e = entries[i];
+    const int t = e / 3, k = e - 3 * t;
+    const float *row = acc + ((size_t)b * T + t) * STRIDE;
+#pragma unroll
+    for (int j = 0; j < AP; ++j) a[j] += row[k * AP + j];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) c[j] += row[3 * AP + k * 3 + j];
+  }
+  float *dst = dattrs + (size_t)gid * A;
+#pragma unroll
+  for (int j = 0; j < AP; ++j)
+    if (j < A) dst[j] = a[j];
+  ((float4 *)dclip)[gid] = make_float4(c[0], c[1], 0.0f, c[2]);  // column z stays 0
+}
+
+inline int padded_attrs(int A) { return A <= 4 ? 4 : (A <= 8 ? 8 : (A <= 12 ? 12 : 16)); }
+inline size_t acc_bytes(int B, int T, int AP) {
+  const int stride = (3 * AP + 9 + 3) & ~3;
+  return align_up((size_t)B * T * stride * sizeof(float), 256);
+}
+inline size_t corner_bytes(int B, int T, int AP) { return align_up((size_t)B * T * 3 * AP * sizeof(float), 256); }
+
+template <int AP>
+int run(const float *dout, const int32_t *ids, const float *bary, const float *clip, const float *attrs,
+        const int32_t *tris, const float *bg, const int32_t *offsets, const int32_t *entries, int B, int V,
+        int T, int W, int H, int A, float *dattrs, float *dclip, void *ws, hipStream_t s) {
+  char *p = (char *)ws;
+  float *acc = (float *)p;
+  p += acc_bytes(B, T, AP);
+  BwdRec *recs = (BwdRec *)p;
+  p += align_up((size_t)B * T * sizeof(BwdRec), 256);
+  float *corners = (float *)p;
+  if (hipMemsetAsync(acc, 0, (size_t)B * T * AttrRowsFn<AP>::kStride * sizeof(float), s) != hipSuccess)
+    return check_launch();
+  int rc = launch_bwd_setup(clip, tris, B, V, T, recs, s);
+  if (rc != MR_OK) return rc;
+  const long nbt = (long)B * T;
+  hipLaunchKernelGGL(k_attr_corner_setup<AP>, dim3((unsigned)((nbt + kThreads - 1) / kThreads)), dim3(kThreads),
+                     0, s, attrs, tris, B, V, T, A, corners);
+  rc = check_launch();
+  if (rc != MR_OK) return rc;
+  AttrRowsFn<AP> fn{dout, ids, (const F3 *)bary, corners, recs, bg, A, T};
+  rc = launch_accumulate_rows(fn, B, T, W, H, acc, s);
+  if (rc != MR_OK) return rc;
+  const long nbv = (long)B * V;
+  hipLaunchKernelGGL(k_attr_gather<AP>, dim3((unsigned)((nbv + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
+                     acc, offsets, entries, B, V, T, A, dattrs, dclip);
+  return check_launch();
+}
+
+}  // namespace
+
+int interp_raster_max_attrs() { return 16; }
+
+size_t interp_raster_backward_ws(int B, int V, int T, int W, int H, int A) {
+  (void)V; (void)W; (void)H;
+  const int AP = padded_attrs(A);
+  return acc_bytes(B, T, AP) + align_up((size_t)B * T * sizeof(BwdRec), 256) + corner_bytes(B, T, AP);
+}
+
+int launch_interp_raster_backward(const float *dout, const int32_t *ids, const float *bary, const float *clip,
+                                  const float *attrs, const int32_t *tris, const float *bg,
+                                  const int32_t *offsets, const int32_t *entries, int B, int V, int T, int W,
+                                  int H, int A, float *dattrs, float *dclip, void *ws, hipStream_t s) {
+  if (B == 0 || V == 0) return MR_OK;
+  if (T == 0 || (size_t)W * H == 0 || A == 0) {  // nothing contributes: the outputs are zeros
+    if ((size_t)A > 0 && hipMemsetAsync(dattrs, 0, (size_t)B * V * A * sizeof(float), s) != hipSuccess)
+      return check_launch();
+    if (hipMemsetAsync(dclip, 0, (size_t)B * V * 4 * sizeof(float), s) != hipSuccess) return check_launch();
+    return MR_OK;
+  }
+  switch (padded_attrs(A)) {
+    case 4: return run<4>(dout, ids, bary, clip, attrs, tris, bg, offsets, entries, B, V, T, W, H, A, dattrs, dclip, ws, s);
+    case 8: return run<8>(dout, ids, bary, clip, attrs, tris, bg, offsets, entries, B, V, T, W, H, A, dattrs, dclip, ws, s);
+    case 12: return run<12>(dout, ids, bary, clip, attrs, tris, bg, offsets, entries, B, V, T, W, H, A, dattrs, dclip, ws, s);
+    default: return run<16>(dout, ids, bary, clip, attrs, tris, bg, offsets, entries, B, V, T, W, H, A, dattrs, dclip, ws, s);
+  }
+}
+
+}  // namespace mr

@@ -16,6 +16,12 @@ from ..common import camera_utils
 # convention and is not reproduced (SURVEY.md section 8, row A11).
 USE_CPP_RASTERIZER = True
 
+# True: rasterize_clip_space() with up to 16 float32 attributes is one autograd op whose backward
+# is a single pass over the G-buffer (attribute and vertex gradients together).  False: the composed
+# ops (BarycentricRasterizer + AttributeInterpolator; ceil(A / 4) + 2 passes) -- same results within
+# the parity budget, kept as a cross-check and for larger attribute counts.  Read at call time.
+USE_FUSED_BACKWARD = True
+
 
 def rasterize_barycentric(clip_space_vertices, triangles, image_width, image_height):
     """[V,4] (or [B,V,4]) clip-space vertices -> (triangle ids, barycentrics, z)."""
@@ -46,9 +52,15 @@ def rasterize_clip_space(clip_space_vertices, attributes, triangles,
     if len(clip_space_vertices.shape) != 3:
         raise ValueError("The vertex buffer must be 3D.")
     from . import rasterize_triangles_ext as ext
+    from .. import _native
 
-    ids, bary, _ = ext.BarycentricRasterizer.apply(
-        clip_space_vertices, triangles, image_width, image_height)
     background = torch.as_tensor(background_value).to(
         device=clip_space_vertices.device, dtype=torch.float32)
+    if (USE_FUSED_BACKWARD and clip_space_vertices.dtype == torch.float32 and
+            attributes.dtype == torch.float32 and len(attributes.shape) == 3 and
+            1 <= attributes.shape[2] <= _native.interpolate_raster_max_attributes()):
+        return ext.FusedAttributeRasterizer.apply(clip_space_vertices, attributes, triangles, background,
+                                                  image_width, image_height)
+    ids, bary, _ = ext.BarycentricRasterizer.apply(
+        clip_space_vertices, triangles, image_width, image_height)
     return ext.AttributeInterpolator.apply(ids, bary, attributes, triangles, background)

@@ -74,6 +74,36 @@ class AttributeInterpolator(torch.autograd.Function):
         return None, dbary, dattrs, None, dbackground
 
 
+class FusedAttributeRasterizer(torch.autograd.Function):
+    """rasterize_clip_space() as ONE differentiable op for up to 16 attributes: G-buffer
+    rasterization + attribute interpolation forward, and a single pass over the G-buffer backward
+    that yields dL/dattributes and dL/dclip together (src/mesh_renderer/rasterize.py:66-152 and
+    rasterize_triangles.cpp:131-273 behind it)."""
+
+    @staticmethod
+    def forward(ctx, clip, attributes, triangles, background, image_width, image_height):
+        clip_d = clip.detach().contiguous()
+        attrs_d, bg_d = attributes.detach().contiguous(), background.detach().contiguous()
+        ids, bary, _ = _native.rasterize_forward(clip_d, triangles, int(image_width), int(image_height))
+        out = _native.interpolate_forward(ids, bary, attrs_d, triangles, bg_d)
+        offsets, entries = _native.vertex_adjacency(triangles, clip_d.shape[1])   # cached per mesh
+        ctx.save_for_backward(clip_d, ids, bary, attrs_d, triangles, bg_d, offsets, entries)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        clip, ids, bary, attributes, triangles, background, offsets, entries = ctx.saved_tensors
+        dout = dout.contiguous()
+        dattrs, dclip = _native.interpolate_raster_backward(dout, ids, bary, clip, attributes, triangles,
+                                                            background, (offsets, entries))
+        dbackground = None
+        if ctx.needs_input_grad[3]:
+            # d/d background = sum over pixels of (1 - alpha) * dout  (rasterize.py:149-150)
+            alpha = torch.clamp(2.0 * bary.sum(-1, keepdim=True), 0.0, 1.0)
+            dbackground = ((1.0 - alpha) * dout).sum(dim=(0, 1, 2))
+        return dclip, dattrs, None, dbackground, None, None
+
+
 class FusedPhongRenderer(torch.autograd.Function):
     """G-buffer rasterization + attribute interpolation + diffuse/ambient Phong as ONE
     differentiable op: 2 kernels forward (k_raster, k_shade_forward), 1 pass over the

@@ -426,3 +426,31 @@ def test_step_is_capturable_into_a_hip_graph(device):
     assert abs(got_loss - want_loss) < 1e-7
     np.testing.assert_allclose(got_grad.cpu().numpy(), vertices.grad.cpu().numpy(), atol=1e-9, rtol=1e-5)
     assert float(got_grad.abs().max()) > 0
+
+
+@pytest.mark.parametrize("n_attrs", [1, 4, 7, 9, 13, 16, 17])
+def test_fused_rasterize_backward_matches_composed_ops(device, n_attrs):
+    """rasterize(): the one-pass fused backward (<= 16 attributes) vs the composed
+    BarycentricRasterizer + AttributeInterpolator ops, outputs and all gradients."""
+    rast_mod = sys.modules["pytorch_mesh_renderer_amd.mesh_renderer.rasterize"]
+    job = synthetic.sphere_job(2, 120, 88, 12)
+    gen = torch.Generator().manual_seed(n_attrs)
+    proj = synthetic.clip_transforms(job["eyes"], 120, 88).to(device)
+    target = torch.rand(2, 88, 120, n_attrs, generator=gen).to(device)
+    results = {}
+    for fused in (True, False):
+        v = job["vertices"].clone().to(device).requires_grad_(True)
+        a = torch.rand(2, v.shape[1], n_attrs, generator=torch.Generator().manual_seed(7)).to(device).requires_grad_(True)
+        bg = torch.linspace(-1.0, 0.5, n_attrs).to(device).requires_grad_(True)
+        rast_mod.USE_FUSED_BACKWARD = fused
+        try:
+            with _CountCalls("interpolate_raster_backward") as counter:
+                out = mesh_renderer.rasterize(v, a, job["triangles"].to(device), proj, 120, 88, bg)
+                torch.mean(torch.abs(out - target)).backward()
+        finally:
+            rast_mod.USE_FUSED_BACKWARD = True
+        assert counter.calls == (1 if fused and n_attrs <= 16 else 0)
+        results[fused] = [t.detach().cpu().numpy() for t in (out, v.grad, a.grad, bg.grad)]
+    for name, got, want in zip(("out", "dvertices", "dattributes", "dbackground"), results[True], results[False]):
+        assert np.abs(want).max() > 0, name
+        np.testing.assert_allclose(got, want, atol=ATOL * 1e-2, rtol=1e-4, err_msg=name)
