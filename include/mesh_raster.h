@@ -106,16 +106,26 @@ int mr_interpolate_backward(const float *dout, const int32_t *ids,
  *   vertex_offsets, vertex_entries  CSR vertex -> (triangle, corner) adjacency of `triangles`
  *                                   (see mr_shade_backward)
  *   dattributes     [B,V,A]   f32 out, dclip [B,V,4] f32 out (16-byte aligned; column z stays 0);
- *                                   both are written completely, no pre-zeroing needed */
+ *                                   both are written completely, no pre-zeroing needed
+ *   corner_records  NULL, or the `records` buffer mr_interpolate_forward_records filled for the
+ *                   SAME inputs: reused instead of rebuilt
+ * mr_interpolate_forward_records is mr_interpolate_forward for 1 <= A <= that maximum, through
+ * per-(image, triangle) corner records (two dependent load levels instead of three; `records`:
+ * mr_interpolate_records_bytes(B, T, A) bytes, 256-byte aligned, caller-owned). */
 int mr_interpolate_raster_max_attributes(void);
+size_t mr_interpolate_records_bytes(int B, int T, int A);
+int mr_interpolate_forward_records(const int32_t *ids, const float *bary, const float *attrs,
+                                   const int32_t *triangles, const float *background, int B, int V,
+                                   int T, int W, int H, int A, float *out, void *records,
+                                   size_t records_bytes, void *stream);
 size_t mr_interpolate_raster_backward_workspace_bytes(int B, int V, int T, int W, int H, int A);
 int mr_interpolate_raster_backward(const float *dout, const int32_t *ids, const float *bary,
                                    const float *clip, const float *attributes,
                                    const int32_t *triangles, const float *background,
                                    const int32_t *vertex_offsets, const int32_t *vertex_entries,
-                                   int B, int V, int T, int W, int H, int A, float *dattributes,
-                                   float *dclip, void *workspace, size_t workspace_bytes,
-                                   void *stream);
+                                   const void *corner_records, int B, int V, int T, int W, int H,
+                                   int A, float *dattributes, float *dclip, void *workspace,
+                                   size_t workspace_bytes, void *stream);
 
 /* ---- fused deferred shading (diffuse + ambient Phong) ---------------------------
  * Replaces, for render() without specular terms, attribute interpolation

@@ -97,7 +97,11 @@ def lib():
         L.mr_interpolate_raster_max_attributes.restype = ci
         L.mr_interpolate_raster_backward_workspace_bytes.argtypes = [ci] * 6
         L.mr_interpolate_raster_backward_workspace_bytes.restype = sz
-        L.mr_interpolate_raster_backward.argtypes = [vp] * 9 + [ci] * 6 + [vp, vp, vp, sz, vp]
+        L.mr_interpolate_records_bytes.argtypes = [ci] * 3
+        L.mr_interpolate_records_bytes.restype = sz
+        L.mr_interpolate_forward_records.argtypes = [vp] * 5 + [ci] * 6 + [vp, vp, sz, vp]
+        L.mr_interpolate_forward_records.restype = ci
+        L.mr_interpolate_raster_backward.argtypes = [vp] * 10 + [ci] * 6 + [vp, vp, vp, sz, vp]
         L.mr_interpolate_raster_backward.restype = ci
         L.mr_shade_specular_forward_workspace_bytes.argtypes = [ci] * 5
         L.mr_shade_specular_forward_workspace_bytes.restype = sz
@@ -274,7 +278,28 @@ def interpolate_raster_max_attributes():
     return int(lib().mr_interpolate_raster_max_attributes())
 
 
-def interpolate_raster_backward(dout, ids, bary, clip, attrs, triangles, background, adjacency):
+def interpolate_forward_records(ids, bary, attrs, triangles, background):
+    """interpolate_forward through per-(image, triangle) corner records, for at most
+    interpolate_raster_max_attributes() attributes -> (out [B,H,W,A], records for the backward)."""
+    dev = _require_device(ids, bary, attrs, triangles, background)
+    L = lib()
+    ids, bary, attrs = ids.contiguous(), bary.contiguous(), attrs.contiguous()
+    triangles, background = triangles.contiguous(), background.contiguous()
+    B, H, W = ids.shape
+    V, A, T = attrs.shape[1], attrs.shape[2], triangles.shape[0]
+    out = torch.empty(B, H, W, A, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        need = L.mr_interpolate_records_bytes(B, T, A)
+        records = _aligned_bytes(need, dev)
+        rc = L.mr_interpolate_forward_records(_ptr(ids), _ptr(bary), _ptr(attrs), _ptr(triangles),
+                                              _ptr(background), B, V, T, W, H, A, _ptr(out), _ptr(records),
+                                              need, _stream(dev))
+    _check(rc, "mr_interpolate_forward_records")
+    return out, records
+
+
+def interpolate_raster_backward(dout, ids, bary, clip, attrs, triangles, background, adjacency,
+                                corner_records=None):
     """One-pass backward of interpolation + rasterization -> (dattributes [B,V,A], dclip [B,V,4])."""
     tensors = [dout, ids, bary, clip, attrs, triangles, background, adjacency[0], adjacency[1]]
     dev = _require_device(*tensors)
@@ -289,8 +314,8 @@ def interpolate_raster_backward(dout, ids, bary, clip, attrs, triangles, backgro
         ws, have = _workspace(dev, need)
         rc = L.mr_interpolate_raster_backward(
             _ptr(dout), _ptr(ids), _ptr(bary), _ptr(clip), _ptr(attrs), _ptr(triangles), _ptr(background),
-            _ptr(offsets), _ptr(entries), B, V, T, W, H, A, _ptr(dattrs), _ptr(dclip), _ptr(ws), have,
-            _stream(dev))
+            _ptr(offsets), _ptr(entries), _ptr(corner_records), B, V, T, W, H, A, _ptr(dattrs), _ptr(dclip),
+            _ptr(ws), have, _stream(dev))
     _check(rc, "mr_interpolate_raster_backward")
     return dattrs, dclip
 

@@ -130,12 +130,32 @@ size_t mr_interpolate_raster_backward_workspace_bytes(int B, int V, int T, int W
   return mr::interp_raster_backward_ws(B, V, T, W, H, A);
 }
 
+size_t mr_interpolate_records_bytes(int B, int T, int A) {
+  if (B < 0 || T < 0 || A < 1 || A > mr::interp_raster_max_attrs()) return 0;
+  return mr::interp_records_bytes(B, T, A);
+}
+
+int mr_interpolate_forward_records(const int32_t *ids, const float *bary, const float *attrs,
+                                   const int32_t *triangles, const float *background, int B, int V,
+                                   int T, int W, int H, int A, float *out, void *records,
+                                   size_t records_bytes, void *stream) {
+  if (bad_dims(B, V, T, W, H) || A < 1 || A > mr::interp_raster_max_attrs() || T < 1 || V < 1)
+    return MR_EINVAL;
+  if (B == 0) return MR_OK;
+  if (!ids || !bary || !attrs || !triangles || !background || !out) return MR_EINVAL;
+  const int rc = check_ws(records, records_bytes, mr::interp_records_bytes(B, T, A));
+  if (rc != MR_OK) return rc;
+  return mr::launch_interp_forward_records(ids, bary, attrs, triangles, background, B, V, T, W, H, A, out,
+                                           records, (hipStream_t)stream);
+}
+
 int mr_interpolate_raster_backward(const float *dout, const int32_t *ids, const float *bary,
                                    const float *clip, const float *attributes,
                                    const int32_t *triangles, const float *background,
-                                   const int32_t *vertex_offsets, const int32_t *vertex_entries, int B,
-                                   int V, int T, int W, int H, int A, float *dattributes, float *dclip,
-                                   void *workspace, size_t workspace_bytes, void *stream) {
+                                   const int32_t *vertex_offsets, const int32_t *vertex_entries,
+                                   const void *corner_records, int B, int V, int T, int W, int H, int A,
+                                   float *dattributes, float *dclip, void *workspace,
+                                   size_t workspace_bytes, void *stream) {
   if (bad_dims(B, V, T, W, H) || A < 0 || A > mr::interp_raster_max_attrs()) return MR_EINVAL;
   if (B == 0 || V == 0) return MR_OK;
   if (!dclip || (A > 0 && !dattributes)) return MR_EINVAL;
@@ -147,9 +167,10 @@ int mr_interpolate_raster_backward(const float *dout, const int32_t *ids, const 
     const int rc = check_ws(workspace, workspace_bytes, mr::interp_raster_backward_ws(B, V, T, W, H, A));
     if (rc != MR_OK) return rc;
   }
+  if (((uintptr_t)corner_records & 15u) != 0) return MR_EINVAL;
   return mr::launch_interp_raster_backward(dout, ids, bary, clip, attributes, triangles, background,
-                                           vertex_offsets, vertex_entries, B, V, T, W, H, A, dattributes,
-                                           dclip, workspace, (hipStream_t)stream);
+                                           vertex_offsets, vertex_entries, corner_records, B, V, T, W, H, A,
+                                           dattributes, dclip, workspace, (hipStream_t)stream);
 }
 
 int mr_shade_max_lights(void) { return mr::shade_max_lights(); }

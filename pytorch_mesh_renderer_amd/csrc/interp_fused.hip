@@ -38,14 +38,70 @@ __global__ __launch_bounds__(kThreads) void k_attr_corner_setup(
   if (gid >= (long)B * T) return;
   const int b = (int)(gid / T);
   const int t = (int)(gid - (long)b * T);
-  float *rec = out + gid * (3 * AP);
+  float4 *rec = (float4 *)(out + gid * (3 * AP));  // 3 * AP floats, 16-byte aligned (AP % 4 == 0)
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     int vi = tris[3 * t + k];
     if ((unsigned)vi >= (unsigned)V) vi = 0;
     const float *src = attrs + ((size_t)b * V + vi) * A;
+    float v[AP];
 #pragma unroll
-    for (int a = 0; a < AP; ++a) rec[k * AP + a] = a < A ? src[a] : 0.0f;
+    for (int a = 0; a < AP; ++a) v[a] = a < A ? src[a] : 0.0f;
+#pragma unroll
+    for (int q = 0; q < AP / 4; ++q) rec[k * (AP / 4) + q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+  }
+}
+
+// Forward interpolation from the corner records: one thread per PIXEL (blockIdx.y = image: no
+// 64-bit divisions; the thread-per-element form spent 1.1 ms at 1024^2 x 32, A = 9, on index
+// arithmetic), two load levels (id -> record) instead of three (id -> vertex ids -> attributes).
+// A wavefront's 64 pixels form one contiguous run of 64 A floats in `out`: the lanes park their A
+// values in LDS and the run leaves as A fully coalesced 256-byte stores (each lane storing its own
+// A floats directly -- 64 scattered dwords per store instruction -- was 3x slower).  rasterize.py:137-150.
+template <int AP>
+__global__ __launch_bounds__(kThreads) void k_interp_forward_rec(
+    const int32_t *__restrict__ ids, const F3 *__restrict__ bary, const float *__restrict__ corners,
+    const float *__restrict__ background, unsigned px_per_image, int T, int A, float *__restrict__ out) {
+  __shared__ float s_stage[kThreads / kWave][kWave * AP];
+  const int img = (int)blockIdx.y;
+  const size_t img_px = (size_t)img * px_per_image;
+  const unsigned lane = threadIdx.x & (kWave - 1);
+  float *stage = s_stage[threadIdx.x >> 6];
+  float bg[AP];
+#pragma unroll
+  for (int a = 0; a < AP; ++a) bg[a] = a < A ? background[a] : 0.0f;
+  for (unsigned p0 = blockIdx.x * kThreads; p0 < px_per_image; p0 += gridDim.x * kThreads) {
+    const unsigned p = p0 + threadIdx.x;
+    if (p - lane >= px_per_image) break;            // whole wavefront beyond the image (wave-uniform)
+    const size_t pix = img_px + min(p, px_per_image - 1);  // lanes past the end recompute the last pixel
+    int t = ids[pix];
+    if ((unsigned)t >= (unsigned)T) t = 0;
+    const F3 b = bary[pix];
+    const float pre = (2.0f * b.x + 2.0f * b.y) + 2.0f * b.z;
+    const float alpha = fminf(fmaxf(pre, 0.0f), 1.0f);
+    const float one_m = 1.0f - alpha;
+    float c[3 * AP];
+    const float4 *src = (const float4 *)(corners + ((size_t)img * T + t) * (3 * AP));
+#pragma unroll
+    for (int q = 0; q < 3 * AP / 4; ++q) {
+      const float4 f = src[q];
+      c[4 * q] = f.x; c[4 * q + 1] = f.y; c[4 * q + 2] = f.z; c[4 * q + 3] = f.w;
+    }
+    // park the pixel's A values, then the wavefront writes its run of 64 A floats, coalesced
+    float *mine = stage + lane * A;
+#pragma unroll
+    for (int a = 0; a < AP; ++a) {
+      if (a < A) {  // wave-uniform
+        const float value = (c[a] * b.x + c[AP + a] * b.y) + c[2 * AP + a] * b.z;
+        mine[a] = alpha * value + one_m * bg[a];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();  // LDS executes one wavefront's operations in order
+    const unsigned wave_first = p - lane;                                  // first pixel of this wavefront
+    const unsigned n_here = min(64u, px_per_image - wave_first) * (unsigned)A;  // floats in its run
+    float *run = out + (img_px + wave_first) * A;
+    for (unsigned i = lane; i < n_here; i += 64u) run[i] = stage[i];
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -194,9 +250,31 @@ inline size_t acc_bytes(int B, int T, int AP) {
 inline size_t corner_bytes(int B, int T, int AP) { return align_up((size_t)B * T * 3 * AP * sizeof(float), 256); }
 
 template <int AP>
+int setup_records(const float *attrs, const int32_t *tris, int B, int V, int T, int A, float *corners,
+                  hipStream_t s) {
+  const long nbt = (long)B * T;
+  hipLaunchKernelGGL(k_attr_corner_setup<AP>, dim3((unsigned)((nbt + kThreads - 1) / kThreads)), dim3(kThreads),
+                     0, s, attrs, tris, B, V, T, A, corners);
+  return check_launch();
+}
+
+template <int AP>
+int run_forward(const int32_t *ids, const float *bary, const float *attrs, const int32_t *tris, const float *bg,
+                int B, int V, int T, int W, int H, int A, float *out, float *corners, hipStream_t s) {
+  int rc = setup_records<AP>(attrs, tris, B, V, T, A, corners, s);
+  if (rc != MR_OK) return rc;
+  const unsigned px_per_image = (unsigned)W * (unsigned)H;  // W, H <= 65535
+  const unsigned want = (px_per_image + kThreads - 1) / kThreads, cap = 2048u;
+  hipLaunchKernelGGL(k_interp_forward_rec<AP>, dim3(want < cap ? want : cap, (unsigned)B), dim3(kThreads), 0, s,
+                     ids, (const F3 *)bary, corners, bg, px_per_image, T, A, out);
+  return check_launch();
+}
+
+template <int AP>
 int run(const float *dout, const int32_t *ids, const float *bary, const float *clip, const float *attrs,
-        const int32_t *tris, const float *bg, const int32_t *offsets, const int32_t *entries, int B, int V,
-        int T, int W, int H, int A, float *dattrs, float *dclip, void *ws, hipStream_t s) {
+        const int32_t *tris, const float *bg, const int32_t *offsets, const int32_t *entries,
+        const float *corner_records, int B, int V, int T, int W, int H, int A, float *dattrs, float *dclip,
+        void *ws, hipStream_t s) {
   char *p = (char *)ws;
   float *acc = (float *)p;
   p += acc_bytes(B, T, AP);
@@ -207,11 +285,12 @@ int run(const float *dout, const int32_t *ids, const float *bary, const float *c
     return check_launch();
   int rc = launch_bwd_setup(clip, tris, B, V, T, recs, s);
   if (rc != MR_OK) return rc;
-  const long nbt = (long)B * T;
-  hipLaunchKernelGGL(k_attr_corner_setup<AP>, dim3((unsigned)((nbt + kThreads - 1) / kThreads)), dim3(kThreads),
-                     0, s, attrs, tris, B, V, T, A, corners);
-  rc = check_launch();
-  if (rc != MR_OK) return rc;
+  if (corner_records) {  // the forward's records (same inputs): skip the gather
+    corners = const_cast<float *>(corner_records);
+  } else {
+    rc = setup_records<AP>(attrs, tris, B, V, T, A, corners, s);
+    if (rc != MR_OK) return rc;
+  }
   AttrRowsFn<AP> fn{dout, ids, (const F3 *)bary, corners, recs, bg, A, T};
   rc = launch_accumulate_rows(fn, B, T, W, H, acc, s);
   if (rc != MR_OK) return rc;
@@ -231,10 +310,26 @@ size_t interp_raster_backward_ws(int B, int V, int T, int W, int H, int A) {
   return acc_bytes(B, T, AP) + align_up((size_t)B * T * sizeof(BwdRec), 256) + corner_bytes(B, T, AP);
 }
 
+size_t interp_records_bytes(int B, int T, int A) { return corner_bytes(B, T, padded_attrs(A)); }
+
+int launch_interp_forward_records(const int32_t *ids, const float *bary, const float *attrs, const int32_t *tris,
+                                  const float *bg, int B, int V, int T, int W, int H, int A, float *out,
+                                  void *records, hipStream_t s) {
+  if ((size_t)B * W * H * A == 0) return MR_OK;
+  float *corners = (float *)records;
+  switch (padded_attrs(A)) {
+    case 4: return run_forward<4>(ids, bary, attrs, tris, bg, B, V, T, W, H, A, out, corners, s);
+    case 8: return run_forward<8>(ids, bary, attrs, tris, bg, B, V, T, W, H, A, out, corners, s);
+    case 12: return run_forward<12>(ids, bary, attrs, tris, bg, B, V, T, W, H, A, out, corners, s);
+    default: return run_forward<16>(ids, bary, attrs, tris, bg, B, V, T, W, H, A, out, corners, s);
+  }
+}
+
 int launch_interp_raster_backward(const float *dout, const int32_t *ids, const float *bary, const float *clip,
                                   const float *attrs, const int32_t *tris, const float *bg,
-                                  const int32_t *offsets, const int32_t *entries, int B, int V, int T, int W,
-                                  int H, int A, float *dattrs, float *dclip, void *ws, hipStream_t s) {
+                                  const int32_t *offsets, const int32_t *entries, const void *corner_records,
+                                  int B, int V, int T, int W, int H, int A, float *dattrs, float *dclip,
+                                  void *ws, hipStream_t s) {
   if (B == 0 || V == 0) return MR_OK;
   if (T == 0 || (size_t)W * H == 0 || A == 0) {  // nothing contributes: the outputs are zeros
     if ((size_t)A > 0 && hipMemsetAsync(dattrs, 0, (size_t)B * V * A * sizeof(float), s) != hipSuccess)
@@ -242,11 +337,12 @@ int launch_interp_raster_backward(const float *dout, const int32_t *ids, const f
     if (hipMemsetAsync(dclip, 0, (size_t)B * V * 4 * sizeof(float), s) != hipSuccess) return check_launch();
     return MR_OK;
   }
+  const float *cr = (const float *)corner_records;
   switch (padded_attrs(A)) {
-    case 4: return run<4>(dout, ids, bary, clip, attrs, tris, bg, offsets, entries, B, V, T, W, H, A, dattrs, dclip, ws, s);
-    case 8: return run<8>(dout, ids, bary, clip, attrs, tris, bg, offsets, entries, B, V, T, W, H, A, dattrs, dclip, ws, s);
-    case 12: return run<12>(dout, ids, bary, clip, attrs, tris, bg, offsets, entries, B, V, T, W, H, A, dattrs, dclip, ws, s);
-    default: return run<16>(dout, ids, bary, clip, attrs, tris, bg, offsets, entries, B, V, T, W, H, A, dattrs, dclip, ws, s);
+    case 4: return run<4>(dout, ids, bary, clip, attrs, tris, bg, offsets, entries, cr, B, V, T, W, H, A, dattrs, dclip, ws, s);
+    case 8: return run<8>(dout, ids, bary, clip, attrs, tris, bg, offsets, entries, cr, B, V, T, W, H, A, dattrs, dclip, ws, s);
+    case 12: return run<12>(dout, ids, bary, clip, attrs, tris, bg, offsets, entries, cr, B, V, T, W, H, A, dattrs, dclip, ws, s);
+    default: return run<16>(dout, ids, bary, clip, attrs, tris, bg, offsets, entries, cr, B, V, T, W, H, A, dattrs, dclip, ws, s);
   }
 }
 

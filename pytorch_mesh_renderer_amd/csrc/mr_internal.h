@@ -92,10 +92,15 @@ int launch_shade_backward(const float *drgba, const int32_t *ids, const float *b
 
 int interp_raster_max_attrs();
 size_t interp_raster_backward_ws(int B, int V, int T, int W, int H, int A);
+size_t interp_records_bytes(int B, int T, int A);
+int launch_interp_forward_records(const int32_t *ids, const float *bary, const float *attrs, const int32_t *tris,
+                                  const float *bg, int B, int V, int T, int W, int H, int A, float *out,
+                                  void *records, hipStream_t s);
 int launch_interp_raster_backward(const float *dout, const int32_t *ids, const float *bary, const float *clip,
                                   const float *attrs, const int32_t *tris, const float *bg,
-                                  const int32_t *offsets, const int32_t *entries, int B, int V, int T, int W,
-                                  int H, int A, float *dattrs, float *dclip, void *ws, hipStream_t s);
+                                  const int32_t *offsets, const int32_t *entries, const void *corner_records,
+                                  int B, int V, int T, int W, int H, int A, float *dattrs, float *dclip,
+                                  void *ws, hipStream_t s);
 size_t shade_specular_forward_ws(int B, int V, int T, int W, int H);
 int launch_shade_specular_forward(const int32_t *ids, const float *bary, const float *normals,
                                   const float *positions, const float *diffuse, const float *specular,

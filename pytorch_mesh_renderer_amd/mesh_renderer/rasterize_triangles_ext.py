@@ -85,17 +85,18 @@ class FusedAttributeRasterizer(torch.autograd.Function):
         clip_d = clip.detach().contiguous()
         attrs_d, bg_d = attributes.detach().contiguous(), background.detach().contiguous()
         ids, bary, _ = _native.rasterize_forward(clip_d, triangles, int(image_width), int(image_height))
-        out = _native.interpolate_forward(ids, bary, attrs_d, triangles, bg_d)
+        out, records = _native.interpolate_forward_records(ids, bary, attrs_d, triangles, bg_d)
         offsets, entries = _native.vertex_adjacency(triangles, clip_d.shape[1])   # cached per mesh
-        ctx.save_for_backward(clip_d, ids, bary, attrs_d, triangles, bg_d, offsets, entries)
+        ctx.save_for_backward(clip_d, ids, bary, attrs_d, triangles, bg_d, offsets, entries, records)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        clip, ids, bary, attributes, triangles, background, offsets, entries = ctx.saved_tensors
+        clip, ids, bary, attributes, triangles, background, offsets, entries, records = ctx.saved_tensors
         dout = dout.contiguous()
         dattrs, dclip = _native.interpolate_raster_backward(dout, ids, bary, clip, attributes, triangles,
-                                                            background, (offsets, entries))
+                                                            background, (offsets, entries),
+                                                            corner_records=records)
         dbackground = None
         if ctx.needs_input_grad[3]:
             # d/d background = sum over pixels of (1 - alpha) * dout  (rasterize.py:149-150)

@@ -433,10 +433,10 @@ def test_fused_rasterize_backward_matches_composed_ops(device, n_attrs):
     """rasterize(): the one-pass fused backward (<= 16 attributes) vs the composed
     BarycentricRasterizer + AttributeInterpolator ops, outputs and all gradients."""
     rast_mod = sys.modules["pytorch_mesh_renderer_amd.mesh_renderer.rasterize"]
-    job = synthetic.sphere_job(2, 120, 88, 12)
+    job = synthetic.sphere_job(2, 121, 87, 12)   # 121 * 87 is not a multiple of 64: ragged last wavefront
     gen = torch.Generator().manual_seed(n_attrs)
-    proj = synthetic.clip_transforms(job["eyes"], 120, 88).to(device)
-    target = torch.rand(2, 88, 120, n_attrs, generator=gen).to(device)
+    proj = synthetic.clip_transforms(job["eyes"], 121, 87).to(device)
+    target = torch.rand(2, 87, 121, n_attrs, generator=gen).to(device)
     results = {}
     for fused in (True, False):
         v = job["vertices"].clone().to(device).requires_grad_(True)
@@ -445,7 +445,7 @@ def test_fused_rasterize_backward_matches_composed_ops(device, n_attrs):
         rast_mod.USE_FUSED_BACKWARD = fused
         try:
             with _CountCalls("interpolate_raster_backward") as counter:
-                out = mesh_renderer.rasterize(v, a, job["triangles"].to(device), proj, 120, 88, bg)
+                out = mesh_renderer.rasterize(v, a, job["triangles"].to(device), proj, 121, 87, bg)
                 torch.mean(torch.abs(out - target)).backward()
         finally:
             rast_mod.USE_FUSED_BACKWARD = True
