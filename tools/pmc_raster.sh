@@ -19,7 +19,7 @@ import csv, glob, collections
 acc = collections.defaultdict(list)
 for f in glob.glob("gpurun_out/pmc_raster/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "k_raster(" in r["Kernel_Name"]:
+        if "k_raster<" in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k in sorted(acc):
     v = acc[k]

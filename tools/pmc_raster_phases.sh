@@ -13,7 +13,7 @@ for v in (0, 3, 5, 18, 10, 34):
     acc = collections.defaultdict(list)
     for f in glob.glob("gpurun_out/pmc_phases/v%d/**/*counter_collection.csv" % v, recursive=True):
         for r in csv.DictReader(open(f)):
-            if "k_raster(" in r["Kernel_Name"]:
+            if "k_raster<" in r["Kernel_Name"]:
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     print("variant %2d " % v + "  ".join("%s=%.1fM" % (k[3:], sum(x) / len(x) / 1e6) for k, x in sorted(acc.items())))
 PY

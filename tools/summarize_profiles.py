@@ -38,7 +38,7 @@ for name in ("bench.log", "bench_under_rocprof.log"):
 json.dump(lines, open(os.path.join(prof, tag + "_bench.json"), "w"), indent=1)
 
 # 3. HBM traffic of the kernels of interest, per launch
-wanted = {"k_raster": "k_raster(", "k_shade_forward": "k_shade_forward(", "ShadeGradFn": "ShadeGradFn",
+wanted = {"k_raster": "k_raster<", "k_shade_forward": "k_shade_forward(", "ShadeGradFn": "ShadeGradFn",
           "k_l1_forward": "k_l1_forward(", "k_l1_backward": "k_l1_backward("}
 raw = {k: {} for k in wanted}
 for counter in ("WRITE_SIZE", "FETCH_SIZE"):
