@@ -331,9 +331,12 @@ def vertex_adjacency(triangles, vertex_count):
     flat = triangles.reshape(-1).to(torch.int64)
     key = torch.where((flat >= 0) & (flat < vertex_count), flat, torch.full_like(flat, vertex_count))
     order = torch.argsort(key, stable=True)
-    counts = torch.bincount(key, minlength=vertex_count + 1)[:vertex_count]
+    # scatter_add, not bincount: bincount reads the maximum back to the host (a device sync on every
+    # cache miss, e.g. when the caller passes a fresh `triangles.to(device)` each step)
+    counts = torch.zeros(vertex_count + 1, dtype=torch.int64, device=triangles.device)
+    counts.scatter_add_(0, key, torch.ones_like(key))
     offsets = torch.zeros(vertex_count + 1, dtype=torch.int64, device=triangles.device)
-    offsets[1:] = torch.cumsum(counts, 0)
+    offsets[1:] = torch.cumsum(counts[:vertex_count], 0)
     offsets, entries = offsets.to(torch.int32), order.to(torch.int32).contiguous()
     try:
         triangles._mr_adjacency = ((triangles._version, int(vertex_count), triangles.data_ptr()), offsets, entries)
