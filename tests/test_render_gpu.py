@@ -454,3 +454,25 @@ def test_fused_rasterize_backward_matches_composed_ops(device, n_attrs):
     for name, got, want in zip(("out", "dvertices", "dattributes", "dbackground"), results[True], results[False]):
         assert np.abs(want).max() > 0, name
         np.testing.assert_allclose(got, want, atol=ATOL * 1e-2, rtol=1e-4, err_msg=name)
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (7, 3), (65, 2), (63, 65)])
+def test_fused_rasterize_tiny_and_ragged_images(device, w, h):
+    """Fused rasterize() forward / backward on images smaller than a wavefront or a region."""
+    rast_mod = sys.modules["pytorch_mesh_renderer_amd.mesh_renderer.rasterize"]
+    job = synthetic.sphere_job(3, w, h, 6)
+    proj = synthetic.clip_transforms(job["eyes"], max(w, 2), max(h, 2)).to(device)
+    results = {}
+    for fused in (True, False):
+        v = job["vertices"].clone().to(device).requires_grad_(True)
+        a = torch.rand(3, v.shape[1], 5, generator=torch.Generator().manual_seed(1)).to(device).requires_grad_(True)
+        rast_mod.USE_FUSED_BACKWARD = fused
+        try:
+            out = mesh_renderer.rasterize(v, a, job["triangles"].to(device), proj, w, h, torch.full((5,), 0.25))
+            (out * out).mean().backward()
+        finally:
+            rast_mod.USE_FUSED_BACKWARD = True
+        assert out.shape == (3, h, w, 5)
+        results[fused] = [t.detach().cpu().numpy() for t in (out, v.grad, a.grad)]
+    for name, got, want in zip(("out", "dvertices", "dattributes"), results[True], results[False]):
+        np.testing.assert_allclose(got, want, atol=1e-6, rtol=1e-4, err_msg=name)
