@@ -58,11 +58,11 @@ class HipEvents:
 
     def arm(self, i):
         a, b = self.pairs[i]
-        _native.lib().mr_set_raster_profile_events(a, b)
+        _native.lib().mr_time_next_kernel(_native.TIMER_RASTER_FORWARD, a, b)
 
     @staticmethod
     def disarm():
-        _native.lib().mr_set_raster_profile_events(None, None)
+        _native.lib().mr_time_next_kernel(_native.TIMER_RASTER_FORWARD, None, None)
 
     def elapsed_ms(self):
         out = []

@@ -263,26 +263,18 @@ int mr_l1_loss_backward(const uint8_t *signs, size_t n, const float *upstream, f
  * the multi-GPU hand-over): a quarter of the fp32 bytes. */
 int mr_export_u8(const float *image, size_t n, uint8_t *out, void *stream);
 
-/* ---- stage-timing probe (no reference counterpart) -----------------------------
- * 0 = normal operation (default).  3, 4, 5, 10, 18, 34, 42 switch stages of the forward
- * raster kernel off so that tools/raster_bench.py can time the rest: 3 = bin only,
- * 4 = empty tile walk + stores, 5 = bin + tile masks, 10 = no depth loop, 18 = no
- * coverage loop, 34 = no stores, 42 = no depth loop and no stores.  The G-buffer is
- * UNDEFINED while a probe is selected; any other value returns MR_EINVAL. */
-int mr_set_raster_tile_shape(int shape);
-
-/* ---- region size of the forward raster kernel (test hook) -------------------------------
- * The kernel walks 64x64-pixel regions per workgroup, or 32x32 when the launch is small (fewer than
- * four 64x64 regions per CU).  0 = that automatic choice (default); 32 / 64 force one.  Results are
- * bit-identical either way; the workspace queries follow the setting, so set it before querying. */
-int mr_set_raster_region_edge(int edge);
-
-/* ---- measurement hook -------------------------------------------------------
- * When both are non-NULL, every mr_rasterize_forward() records hipEvent `start`
- * immediately before and `stop` immediately after its G-buffer kernel (k_raster)
- * on the call's stream, so a caller can time that kernel alone inside a larger
- * step (bench.py's roofline leg).  Pass NULLs to switch it off (the default). */
-int mr_set_raster_profile_events(void *start_event, void *stop_event);
+/* ---- kernel timing (measurement, no reference counterpart) ----------------------------
+ * Arms ONE measurement: the next launch of the named kernel made BY THE CALLING THREAD records
+ * hipEvent `start_event` immediately before and `stop_event` immediately after that kernel on
+ * the call's stream, then the slot clears itself (one-shot, thread-local: a forgotten or a
+ * concurrent caller's timer cannot attach to somebody else's launch).  bench.py's roofline legs
+ * time single kernels inside a full step this way.  Results are unaffected.  NULL, NULL disarms. */
+#define MR_TIMER_RASTER_FORWARD 0  /* k_raster: the forward G-buffer kernel of mr_rasterize_forward   */
+#define MR_TIMER_SHADE_BACKWARD 1  /* the pixel pass of mr_shade_backward (fused shading backward)    */
+#define MR_TIMER_SHADE_FORWARD 2   /* the pixel pass of mr_shade_forward                              */
+#define MR_TIMER_RASTER_BACKWARD 3 /* the pixel pass of mr_rasterize_backward                         */
+#define MR_TIMER_COUNT 4
+int mr_time_next_kernel(int which, void *start_event, void *stop_event);
 
 #ifdef __cplusplus
 }

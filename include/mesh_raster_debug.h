@@ -1,0 +1,35 @@
+/*
+ * mesh_raster_debug.h -- test and profiling hooks of libmesh_raster_hip.so.
+ *
+ * NOT part of the drop-in boundary (include/mesh_raster.h): nothing here has a counterpart in the
+ * reference, product code (the pytorch_mesh_renderer_amd package, bench.py's timed step) never calls it.
+ * All state is per calling thread.
+ */
+#ifndef MESH_RASTER_DEBUG_H_
+#define MESH_RASTER_DEBUG_H_
+
+#include "mesh_raster.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Region size of the forward raster kernel for the calling thread's next launches.  The kernel
+ * walks 64x64-pixel regions per workgroup, or 32x32 when the launch is small (fewer than four
+ * 64x64 regions per CU).  0 = that automatic choice (default); 32 / 64 force one so that the parity
+ * tests and the fuzz can run BOTH instantiations on the same inputs.  Results are bit-identical
+ * either way; the workspace query follows the setting, so set it before querying. */
+int mr_debug_set_raster_region_edge(int edge);
+
+/* Stage-timing probes of k_raster.  Only a library built with -DMR_PROBES (make probes ->
+ * libmesh_raster_hip_probes.so) contains the probe instantiations; the production library
+ * returns MR_EINVAL for every value but 0, its kernel has no probe code at all.
+ *   0 normal | 1 bin only | 2 empty tile walk + stores | 3 bin + tile masks | 8 no depth loop |
+ *   16 no coverage loop | 32 no stores | 40 no depth loop and no stores
+ * The G-buffer is UNDEFINED while a probe is selected. */
+int mr_debug_set_raster_probe(int probe);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MESH_RASTER_DEBUG_H_ */

@@ -12,9 +12,12 @@ import subprocess
 import torch
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-LIB_PATH = os.path.join(_CSRC, "libmesh_raster_hip.so")
+# MR_NATIVE_LIB_PATH: development only (tools/raster_bench.py --variant loads the stage-timing
+# build libmesh_raster_hip_probes.so this way); the product always loads the in-tree library.
+LIB_PATH = os.environ.get("MR_NATIVE_LIB_PATH") or os.path.join(_CSRC, "libmesh_raster_hip.so")
 
-ABI_VERSION = 200
+ABI_VERSION = 300
+TIMER_RASTER_FORWARD, TIMER_SHADE_BACKWARD, TIMER_SHADE_FORWARD, TIMER_RASTER_BACKWARD = 0, 1, 2, 3
 MR_OK, MR_EINVAL, MR_EWORKSPACE, MR_ELAUNCH = 0, -1, -2, -3
 _ERR = {MR_EINVAL: "invalid argument", MR_EWORKSPACE: "workspace too small or misaligned",
         MR_ELAUNCH: "HIP launch failed"}
@@ -52,12 +55,13 @@ def lib():
             raise NativeLibraryError("%s has ABI version %d, this package needs %d: rebuild it (make -C "
                                      "pytorch_mesh_renderer_amd/csrc)" % (LIB_PATH, L.mr_version(), ABI_VERSION))
         L.mr_last_hip_error.restype = ci
-        L.mr_set_raster_tile_shape.argtypes = [ci]
-        L.mr_set_raster_tile_shape.restype = ci
-        L.mr_set_raster_region_edge.argtypes = [ci]
-        L.mr_set_raster_region_edge.restype = ci
-        L.mr_set_raster_profile_events.argtypes = [vp, vp]
-        L.mr_set_raster_profile_events.restype = ci
+        L.mr_time_next_kernel.argtypes = [ci, vp, vp]
+        L.mr_time_next_kernel.restype = ci
+        # include/mesh_raster_debug.h (tests and tools only)
+        L.mr_debug_set_raster_probe.argtypes = [ci]
+        L.mr_debug_set_raster_probe.restype = ci
+        L.mr_debug_set_raster_region_edge.argtypes = [ci]
+        L.mr_debug_set_raster_region_edge.restype = ci
         L.mr_rasterize_forward_workspace_bytes.argtypes = [ci] * 5
         L.mr_rasterize_forward_workspace_bytes.restype = sz
         L.mr_rasterize_forward.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, sz, vp]

@@ -2,6 +2,7 @@
 // Argument validation lives here; kernels and launch geometry live in the
 // per-stage .hip files.  No allocation, no synchronisation, no exceptions.
 #include "mr_internal.h"
+#include "mesh_raster_debug.h"
 
 namespace {
 
@@ -19,41 +20,47 @@ inline int check_ws(const void *ws, size_t have, size_t need) {
 }  // namespace
 
 namespace mr {
-extern int g_raster_tile_shape;
-extern int g_raster_region_edge;
-extern hipEvent_t g_raster_ev_start, g_raster_ev_stop;
+extern thread_local int g_raster_region_edge;
+#ifdef MR_PROBES
+extern thread_local int g_raster_probe;
+#endif
+thread_local KernelTimerSlot g_kernel_timers[MR_TIMER_COUNT];
 }
 
 extern "C" {
 
-int mr_version(void) { return 200; /* 0.2.0: sign-coded L1 loss, specular shading, frame export, corner-record reuse */ }
+int mr_version(void) { return 300; /* 0.3.0: one-shot kernel timers, debug hooks in mesh_raster_debug.h */ }
 
 int mr_last_hip_error(void) { return mr::g_last_hip_error; }
 
-// Measurement hook (not part of the reference surface): 0 = normal operation; the other
-// accepted values switch stages of k_raster off for timing and leave the outputs undefined.
-int mr_set_raster_tile_shape(int shape) {
-  static const int kProbes[] = {0, 3, 4, 5, 10, 18, 34, 42};
-  bool ok = false;
-  for (int v : kProbes) ok |= (v == shape);
-  if (!ok) return MR_EINVAL;
-  mr::g_raster_tile_shape = shape;
+int mr_time_next_kernel(int which, void *start_event, void *stop_event) {
+  if (which < 0 || which >= MR_TIMER_COUNT) return MR_EINVAL;
+  if ((start_event == nullptr) != (stop_event == nullptr)) return MR_EINVAL;
+  mr::g_kernel_timers[which].start = (hipEvent_t)start_event;
+  mr::g_kernel_timers[which].stop = (hipEvent_t)stop_event;
   return MR_OK;
 }
 
-// Test hook: force the workgroup region edge of the forward raster kernel (0 = automatic choice
-// from the launch dimensions, 32, 64).  Results are identical; workspace queries follow it.
-int mr_set_raster_region_edge(int edge) {
+// ---- mesh_raster_debug.h ----------------------------------------------------------------
+int mr_debug_set_raster_region_edge(int edge) {
   if (edge != 0 && edge != 32 && edge != 64) return MR_EINVAL;
   mr::g_raster_region_edge = edge;
   return MR_OK;
 }
 
-int mr_set_raster_profile_events(void *start_event, void *stop_event) {
-  if ((start_event == nullptr) != (stop_event == nullptr)) return MR_EINVAL;
-  mr::g_raster_ev_start = (hipEvent_t)start_event;
-  mr::g_raster_ev_stop = (hipEvent_t)stop_event;
-  return MR_OK;
+int mr_debug_set_raster_probe(int probe) {
+#ifdef MR_PROBES
+  static const int kProbes[] = {0, 1, 2, 3, 8, 16, 32, 40};
+  for (int v : kProbes) {
+    if (v == probe) {
+      mr::g_raster_probe = probe;
+      return MR_OK;
+    }
+  }
+  return MR_EINVAL;
+#else
+  return probe == 0 ? MR_OK : MR_EINVAL;  // production build: no probe code in the kernel
+#endif
 }
 
 size_t mr_rasterize_forward_workspace_bytes(int B, int V, int T, int W, int H) {

@@ -58,6 +58,33 @@ inline int check_launch() {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// mr_time_next_kernel (mesh_raster.h): per-thread, one-shot pairs of HIP events recorded on the
+// launch stream immediately around one named kernel.  A caller arms a pair, the next launch of
+// that kernel ON THE ARMING THREAD consumes it; nothing is recorded otherwise.
+struct KernelTimerSlot {
+  hipEvent_t start = nullptr, stop = nullptr;
+};
+extern thread_local KernelTimerSlot g_kernel_timers[MR_TIMER_COUNT];
+
+class KernelTimer {
+ public:
+  KernelTimer(int which, hipStream_t s) : stream_(s) {
+    KernelTimerSlot &slot = g_kernel_timers[which];
+    stop_ = slot.stop;
+    if (slot.start) (void)hipEventRecord(slot.start, s);
+    slot = KernelTimerSlot{};
+  }
+  ~KernelTimer() {
+    if (stop_) (void)hipEventRecord(stop_, stream_);
+  }
+  KernelTimer(const KernelTimer &) = delete;
+  KernelTimer &operator=(const KernelTimer &) = delete;
+
+ private:
+  hipStream_t stream_;
+  hipEvent_t stop_;
+};
+
 // Host launchers (one per .hip file)
 int launch_raster_forward(const float *clip, const int32_t *tris, int B, int V, int T, int W,
                           int H, int32_t *ids, float *bary, float *z, void *ws, hipStream_t s);

@@ -35,6 +35,8 @@
 // Exactness: this file is compiled with -ffp-contract=off; every float expression
 // below is written in the reference's association order.
 // fp32 '/' lowers to the IEEE-correct v_div_scale/v_div_fmas/v_div_fixup sequence.
+#include <type_traits>
+
 #include "mr_internal.h"
 
 namespace mr {
@@ -290,14 +292,16 @@ __device__ __forceinline__ void div3_common_denominator(float n0, float n1, floa
 // R = region edge in pixels: 64, or 32 for small launches (configs[1]: 8 x 256^2 is only 128
 // regions of 64^2 -- half the CUs idle and >256 candidates per region; 512 regions of 32^2 fill
 // the chip with one bin round each).
-template <int R>
+// PROBE: 0 in production.  Non-zero values (only instantiated with -DMR_PROBES, see
+// mesh_raster_debug.h) switch stages off for stage timing and leave the outputs undefined.
+template <int R, int PROBE>
 __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
     const TriRec *__restrict__ recs, const uint2 *__restrict__ bbs,
     const float *__restrict__ pxtab, const float *__restrict__ pytab, int T, int W, int H,
     int regions_x, int regions_per_image, int n_regions, int regions_per_xcd,
     const int32_t *__restrict__ cell_ids, const int32_t *__restrict__ cell_count, int cells_x,
     int cells_per_image, int32_t *__restrict__ ids, float *__restrict__ bary,
-    float *__restrict__ zbuf, int debug_skip) {
+    float *__restrict__ zbuf) {
   static_assert(R == 64 || R == 32, "region edge");
   constexpr int kTilesX = R / 8;
   constexpr int kTiles = kTilesX * kTilesX;  // 8x8-pixel tiles per region: 64 or 16
@@ -309,11 +313,15 @@ __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
   constexpr int kRoundChunks = kThreads;  // chunks of 64 triangles scanned per round
   constexpr int kSharedDw = kTiles * kMaskWords > kRoundChunks + 3 * kWaves ? kTiles * kMaskWords
                                                                              : kRoundChunks + 3 * kWaves;
-  __shared__ __attribute__((aligned(16))) unsigned s_shared[kSharedDw];
+  // [0, 2R): pixel centres of the region's columns, then rows; [2R, 2R + kSharedDw): tile masks /
+  // bin bookkeeping.  One array: a lane's pixel-centre and mask-word addresses then differ by a
+  // constant and share one address register.
+  __shared__ __attribute__((aligned(16))) unsigned s_misc[2 * R + kSharedDw];
+  float (*s_pxy)[R] = (float (*)[R])s_misc;  // pixel centres of the region's columns / rows
+  unsigned *s_shared = s_misc + 2 * R;
   unsigned (*s_tmask)[kMaskWords] = (unsigned (*)[kMaskWords])s_shared;  // per tile: entries touching it
   int *s_chunk_count = (int *)s_shared;   // [kRoundChunks]
   int *s_count = s_chunk_count + kRoundChunks, *s_stop = s_count + kWaves, *s_wave_total = s_stop + kWaves;
-  __shared__ float s_pxy[2][R];  // pixel centres of the region's columns / rows
 
   const int region = xcd_contiguous_block((int)blockIdx.x, n_regions, regions_per_xcd);
   if (region < 0) return;  // padding block (whole workgroup)
@@ -393,8 +401,16 @@ __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
   const __amdgpu_buffer_rsrc_t rs_bary = __builtin_amdgcn_make_buffer_rsrc(bary + 3 * region_pix, 0, 0x7fffffff, kRsrcWord3);
   typedef float v3f __attribute__((ext_vector_type(3)));
   typedef unsigned v3u __attribute__((ext_vector_type(3)));
-  auto raster_pass = [&](const int n, const bool fresh) {
-    const int n_words = (n + 31) >> 5;
+  // Every wavefront of this kernel is fully populated (256-thread workgroups, padding workgroups
+  // leave as a whole), so EXEC is all ones in wave-uniform code: the coverage loop restores it
+  // with a constant after its v_cmpx chain.
+  static_assert(kThreads % kWave == 0, "full wavefronts only");
+  // lanes 0..7 fetch one of the tile's eight mask words each; a ballot of "non-zero" is then the
+  // list of words worth visiting (most of a tile's 256 mask bits are zero: ~3.6 candidates)
+  static_assert(kMaskWords == 8, "lane & 7 == lx indexes the tile's mask words");
+  const unsigned *lane_word = (const unsigned *)lane_px + 2 * R;  // &s_tmask[0][lx]
+  auto raster_pass = [&](auto fresh_tag) {
+    constexpr bool fresh = decltype(fresh_tag)::value;
     for (int tile = wave; tile < kTiles; tile += kWaves) {
       const int ty = tile / kTilesX, tx = tile % kTilesX;
       const int x0 = X0 + tx * 8, y0 = Y0 + ty * 8;
@@ -403,6 +419,7 @@ __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
       const int tile_pix = ty * 8 * W + tx * 8;  // wave-uniform, relative to the region
       const float px = lane_px[tx * 8];
       const float py = lane_py[ty * 8];
+      const unsigned my_word = lane_word[tile * kMaskWords];
       const v2f px2 = {px, px}, py2 = {py, py};
       // region-relative pixel coordinates of this lane, packed (x | y << 16)
       const unsigned lane_xy = lane_xy0 + ((unsigned)(tx * 8) | ((unsigned)(ty * 8) << 16));
@@ -416,16 +433,19 @@ __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
         st.b1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_bary, lane_pix * 12u + 4u, tile_pix * 12, 0));
         st.b2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_bary, lane_pix * 12u + 8u, tile_pix * 12, 0));
       }
-      for (int w = 0; w < n_words; ++w) {
-        unsigned todo = (unsigned)__builtin_amdgcn_readfirstlane((int)s_tmask[tile][w]);
-        if (todo == 0u || (debug_skip & 16)) continue;
+      unsigned words = (unsigned)__ballot(my_word != 0u) & ((1u << kMaskWords) - 1u);
+      if (PROBE & 16) words = 0u;  // timing probe: no coverage, no depth
+      while (words) {
+        const int w = __builtin_ctz(words);
+        words &= words - 1u;
+        unsigned todo = (unsigned)__builtin_amdgcn_readlane((int)my_word, w);
         const int ebase = w * 32;
         // (1) coverage: wave-uniform entry, all lanes; one mask bit per candidate.  (Requesting
         //     the next candidate's entry before evaluating the current one was measured slower:
         //     +5 VGPRs cost the seventh wave per SIMD, 0.371 -> 0.394 ms; two candidates per trip
         //     at 70 VGPRs changed nothing: the loop does not wait on LDS latency.)
         unsigned mine = 0u;
-        while (todo) {
+        do {
           const int j = __builtin_ctz(todo);
           todo &= todo - 1;
           const float *p = s_ent + (ebase + j) * kEntryDw;  // wave-uniform address
@@ -435,20 +455,32 @@ __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
           // wrap-around, then "<= (w - 1, h - 1)" on both halves at once via a packed min.
           const uint2 box = *(const uint2 *)(p + 16);  // wave-uniform values
           const unsigned dxy = pk_sub_u16(lane_xy, box.x);
-          const bool in_box = pk_min_u16(dxy, box.y) == dxy;
+          const unsigned dmin = pk_min_u16(dxy, box.y);
           const v2f e01 = (v2f{q0.x, q0.y} * px2 + v2f{q0.z, q0.w} * py2) + v2f{q1.x, q1.y};  // cpp:46
           float e2 = (q1.z * px + q1.w * py) + m8;
           asm("" : "+v"(e2));  // keeps the vectoriser from pairing e2 with the sum below
           const float s = (e01.x + e01.y) + e2;
-          // cpp:96-97 (all >= 0 and some > 0  <=>  all >= 0 and s > 0), inside the bbox
-          const bool inside = (int)in_box & (int)(e01.x >= 0.0f) &
-                              (int)(e01.y >= 0.0f) & (int)(e2 >= 0.0f) & (int)(s > 0.0f);
-          unsigned with_j = mine | (1u << j);  // j is wave-uniform
-          asm("" : "+v"(with_j));              // v_or + v_cndmask (no v_mov of the bit)
-          mine = inside ? with_j : mine;
-        }
+          // cpp:96-97: all three edge values >= 0 and some > 0, inside the bbox.  With every
+          // value >= 0 "some > 0" is s > 0; a NaN edge value makes s NaN and fails there, so
+          // min3's NaN-ignoring result is harmless.  The three tests narrow EXEC one after the
+          // other (v_cmpx) -- no scalar instructions combine lane masks (the scalar unit, one per
+          // CU, is this kernel's busiest pipe) -- the candidate's bit is set in the surviving
+          // lanes and EXEC is restored.
+          float emin;
+          asm volatile(
+              "v_min3_f32 %[emin], %[e0], %[e1], %[e2]\n\t"
+              "v_cmpx_le_f32_e32 vcc, 0, %[emin]\n\t"
+              "v_cmpx_lt_f32_e32 vcc, 0, %[s]\n\t"
+              "v_cmpx_eq_u32_e32 vcc, %[dmin], %[dxy]\n\t"
+              "v_lshl_or_b32 %[mine], 1, %[j], %[mine]\n\t"
+              "s_mov_b64 exec, -1"
+              : [mine] "+v"(mine), [emin] "=&v"(emin)
+              : [e0] "v"(e01.x), [e1] "v"(e01.y), [e2] "v"(e2), [s] "v"(s), [dmin] "v"(dmin), [dxy] "v"(dxy),
+                [j] "s"(j)
+              : "vcc");
+        } while (todo);
         // (2) depth: every lane walks its own candidates in ascending id
-        if (debug_skip & 8) { st.id += (int)mine; continue; }  // timing probe: coverage only
+        if (PROBE & 8) { st.id += (int)mine; continue; }  // timing probe: coverage only
         while (__ballot(mine != 0u)) {
           if (mine != 0u) {
             const int e = ebase + (__ffs((int)mine) - 1);
@@ -474,12 +506,18 @@ __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
           }
         }
       }
-      if (in_image && !((debug_skip & 32) && st.z != 123.0f)) {  // 32: timing probe, no stores
+      if (in_image && !((PROBE & 32) && st.z != 123.0f)) {  // 32: timing probe, no stores
         __builtin_amdgcn_raw_buffer_store_b32((unsigned)st.id, rs_ids, lane_pix * 4u, tile_pix * 4, 0);
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, st.z), rs_z, lane_pix * 4u, tile_pix * 4, 0);
         __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(v3u, v3f{st.b0, st.b1, st.b2}), rs_bary, lane_pix * 12u,
                                               tile_pix * 12, 0);
       }
+      // Later rounds re-LOAD the pixel state.  vmcnt is in order on gfx950, so the compiler's wait
+      // for such a load also drains the G-buffer stores behind it; draining explicitly here -- on
+      // this rare path only -- tells its dataflow that no load is pending where the two variants
+      // of the walk merge, which keeps the first round's loop free of vmcnt waits (its stores
+      // then retire under the next tiles' arithmetic).
+      if (!fresh) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     }
   };
 
@@ -608,12 +646,15 @@ __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
     }
     const int next_base = round_base + keep_chunks * kWave;
     __syncthreads();
-    if (debug_skip == 0 || debug_skip >= 8) {
+    if constexpr (PROBE == 0 || PROBE >= 8) {
       build_tile_masks(n);
-      raster_pass(n, first_pass);
-    } else if (debug_skip == 2) {
-      raster_pass(0, first_pass);  // timing probe: tile walk over an empty bin
-    } else if (debug_skip == 3) {
+      if (first_pass) raster_pass(std::true_type{});
+      else raster_pass(std::false_type{});
+    } else if constexpr (PROBE == 2) {
+      build_tile_masks(0);         // timing probe: tile walk over an empty bin
+      if (first_pass) raster_pass(std::true_type{});
+      else raster_pass(std::false_type{});
+    } else if constexpr (PROBE == 3) {
       build_tile_masks(n);         // timing probe: bin + tile masks, no walk
     }
     first_pass = false;
@@ -627,7 +668,7 @@ __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
 // Region edge for a launch: 64 pixels, or 32 when 64-pixel regions would leave the chip short of
 // workgroups (fewer than four per CU).  Pure function of the dimensions: the workspace query and
 // the launcher must agree on the cell grid.
-int g_raster_region_edge = 0;  // 0: automatic; 32 / 64: forced (mr_set_raster_region_edge, tests)
+thread_local int g_raster_region_edge = 0;  // 0: automatic; 32 / 64: forced (mr_debug_set_raster_region_edge)
 
 static int region_edge(int B, int W, int H) {
   if (g_raster_region_edge != 0) return g_raster_region_edge;
@@ -645,8 +686,43 @@ size_t raster_forward_ws(int B, int V, int T, int W, int H) {
          align_up(cells * T * sizeof(int32_t), 256) + align_up(cells * sizeof(int32_t), 256);
 }
 
-int g_raster_tile_shape = 0;  // 0: normal; other values: timing probes (see mr_set_raster_tile_shape)
-hipEvent_t g_raster_ev_start = nullptr, g_raster_ev_stop = nullptr;  // mr_set_raster_profile_events
+#ifdef MR_PROBES
+thread_local int g_raster_probe = 0;  // stage-timing probe of the NEXT launches on this thread (debug builds only)
+#endif
+
+namespace {
+struct RasterArgs {
+  const TriRec *recs; const uint2 *bbs; const float *pxtab, *pytab;
+  int T, W, H, regions_x, per_image, n_regions, per_xcd;
+  const int32_t *cell_ids, *cell_count;
+  int cells_x, cells_per_image;
+  int32_t *ids; float *bary, *z;
+};
+
+template <int R, int PROBE>
+void launch_k_raster(const RasterArgs &a, dim3 grid, hipStream_t s) {
+  hipLaunchKernelGGL((k_raster<R, PROBE>), grid, dim3(kThreads), 0, s, a.recs, a.bbs, a.pxtab, a.pytab, a.T, a.W,
+                     a.H, a.regions_x, a.per_image, a.n_regions, a.per_xcd, a.cell_ids, a.cell_count, a.cells_x,
+                     a.cells_per_image, a.ids, a.bary, a.z);
+}
+
+template <int R>
+void launch_k_raster_probe(const RasterArgs &a, dim3 grid, hipStream_t s) {
+#ifdef MR_PROBES
+  switch (g_raster_probe) {
+    case 1: return launch_k_raster<R, 1>(a, grid, s);
+    case 2: return launch_k_raster<R, 2>(a, grid, s);
+    case 3: return launch_k_raster<R, 3>(a, grid, s);
+    case 8: return launch_k_raster<R, 8>(a, grid, s);
+    case 16: return launch_k_raster<R, 16>(a, grid, s);
+    case 32: return launch_k_raster<R, 32>(a, grid, s);
+    case 40: return launch_k_raster<R, 40>(a, grid, s);
+    default: break;
+  }
+#endif
+  launch_k_raster<R, 0>(a, grid, s);
+}
+}  // namespace
 
 int launch_raster_forward(const float *clip, const int32_t *tris, int B, int V, int T, int W,
                           int H, int32_t *ids, float *bary, float *z, void *ws, hipStream_t s) {
@@ -684,23 +760,14 @@ int launch_raster_forward(const float *clip, const int32_t *tris, int B, int V, 
   const int per_image = regions_x * regions_y;
   const int n_regions = per_image * B;
   const int per_xcd = (n_regions + kXcds - 1) / kXcds;
-  const dim3 grid((unsigned)(per_xcd * kXcds)), block(kThreads);
-  int probe = 0;  // timing probes (results are NOT valid), see mr_set_raster_tile_shape
-  switch (g_raster_tile_shape) {
-    case 3: case 4: case 5: case 10: case 18: case 34: case 42: probe = g_raster_tile_shape - 2; break;
-    default: break;
+  const dim3 grid((unsigned)(per_xcd * kXcds));
+  const RasterArgs args{recs, bbs, pxtab, pytab, T, W, H, regions_x, per_image, n_regions, per_xcd,
+                        cell_ids, cell_count, cells_x, cells_per_image, ids, bary, z};
+  {
+    KernelTimer timer(MR_TIMER_RASTER_FORWARD, s);  // records only when a caller armed it
+    if (edge == 32) launch_k_raster_probe<32>(args, grid, s);
+    else launch_k_raster_probe<64>(args, grid, s);
   }
-  if (g_raster_ev_start) (void)hipEventRecord(g_raster_ev_start, s);
-  if (edge == 32) {
-    hipLaunchKernelGGL(k_raster<32>, grid, block, 0, s, recs, bbs, pxtab, pytab, T, W, H, regions_x,
-                       per_image, n_regions, per_xcd, cell_ids, cell_count, cells_x, cells_per_image,
-                       ids, bary, z, probe);
-  } else {
-    hipLaunchKernelGGL(k_raster<64>, grid, block, 0, s, recs, bbs, pxtab, pytab, T, W, H, regions_x,
-                       per_image, n_regions, per_xcd, cell_ids, cell_count, cells_x, cells_per_image,
-                       ids, bary, z, probe);
-  }
-  if (g_raster_ev_stop) (void)hipEventRecord(g_raster_ev_stop, s);
   return check_launch();
 }
 

@@ -19,7 +19,7 @@ ap.add_argument("--edge", type=int, default=0, help="force 32 / 64 pixel regions
 args = ap.parse_args()
 rng = np.random.default_rng(args.seed)
 dev = torch.device("cuda:0")
-assert _native.lib().mr_set_raster_region_edge(args.edge) == 0
+assert _native.lib().mr_debug_set_raster_region_edge(args.edge) == 0
 bad = 0
 nan_only = 0   # trials whose only difference is the bit pattern of a NaN present on both sides
 t0 = time.time()

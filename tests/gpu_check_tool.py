@@ -26,7 +26,7 @@ def check(name, clip, tris, W, H, time_it=False):
           f"bwd_maxerr={err:.3e} |grad|max={np.abs(o_dclip).max():.3e}", flush=True)
     if time_it:
         for shape in (0,):
-            _native.lib().mr_set_raster_tile_shape(shape)
+            _native.lib().mr_debug_set_raster_probe(shape)
             for _ in range(3): _native.rasterize_forward(clip_d, tris_d, W, H)
             torch.cuda.synchronize(); t0 = time.perf_counter()
             n = 10
@@ -34,7 +34,7 @@ def check(name, clip, tris, W, H, time_it=False):
             torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
             B = clip.shape[0]
             print(f"   fwd tile_shape={shape}: {dt*1e3:.3f} ms  -> {B*H*W*20/dt/1e9:.1f} GB/s G-buffer, {B*H*W/dt/1e6:.0f} Mpix/s", flush=True)
-        _native.lib().mr_set_raster_tile_shape(0)
+        _native.lib().mr_debug_set_raster_probe(0)
         dbary_d = dbary.to(dev)
         for _ in range(3): _native.rasterize_backward(dbary_d, clip_d, tris_d, ids, bary)
         torch.cuda.synchronize(); t0 = time.perf_counter()

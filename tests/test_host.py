@@ -15,9 +15,12 @@ import sys
 
 
 def _declared_symbols():
-    text = open(os.path.join(ROOT, "include", "mesh_raster.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(mr_[a-z_0-9]+)\s*\(", text)))
+    names = set()
+    for header in ("mesh_raster.h", "mesh_raster_debug.h"):
+        text = open(os.path.join(ROOT, "include", header)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(mr_[a-z_0-9]+)\s*\(", text))
+    return sorted(names)
 
 
 def test_library_exports_every_declared_symbol():
@@ -41,7 +44,8 @@ def test_abi_argument_validation_without_gpu():
     null = ctypes.c_void_p(0)
     assert L.mr_rasterize_forward(null, null, 1, 8, 12, 64, 64, null, null, null, null, 0, null) == _native.MR_EINVAL
     assert L.mr_rasterize_forward(null, null, -1, 8, 12, 64, 64, null, null, null, null, 0, null) == _native.MR_EINVAL
-    assert L.mr_set_raster_tile_shape(99) == _native.MR_EINVAL
+    assert L.mr_debug_set_raster_probe(99) == _native.MR_EINVAL
+    assert L.mr_time_next_kernel(99, null, null) == _native.MR_EINVAL
 
 
 def test_no_cpu_fallback():

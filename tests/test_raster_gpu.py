@@ -149,8 +149,8 @@ def test_both_region_sizes_are_bit_exact(device, edge):
     """The forward kernel picks 32x32 or 64x64 regions from the launch size; force each on the same
     inputs (soups with w <= 0, a 5k sphere, more triangles than one LDS bin holds)."""
     L = _native.lib()
-    assert L.mr_set_raster_region_edge(48) == _native.MR_EINVAL
-    assert L.mr_set_raster_region_edge(edge) == _native.MR_OK
+    assert L.mr_debug_set_raster_region_edge(48) == _native.MR_EINVAL
+    assert L.mr_debug_set_raster_region_edge(edge) == _native.MR_OK
     try:
         rng = np.random.default_rng(123)
         for trial in range(6):
@@ -165,13 +165,15 @@ def test_both_region_sizes_are_bit_exact(device, edge):
         assert_forward_bitwise(hip_forward(job["clip"].numpy(), job["triangles"].numpy(), 200, 136, device),
                                oracle.forward(job["clip"].numpy(), job["triangles"].numpy(), 200, 136))
     finally:
-        L.mr_set_raster_region_edge(0)
+        L.mr_debug_set_raster_region_edge(0)
 
 
-def test_probe_hook_rejects_unknown_values(device):
+def test_production_library_has_no_stage_probes(device):
+    """The stage-timing probes of k_raster exist only in the -DMR_PROBES build (make probes)."""
     L = _native.lib()
-    assert L.mr_set_raster_tile_shape(1) == _native.MR_EINVAL
-    assert L.mr_set_raster_tile_shape(0) == _native.MR_OK
+    for probe in (1, 2, 3, 8, 16, 32, 40, 99):
+        assert L.mr_debug_set_raster_probe(probe) == _native.MR_EINVAL
+    assert L.mr_debug_set_raster_probe(0) == _native.MR_OK
 
 
 @pytest.mark.parametrize("w,h", [(1, 1), (7, 3), (63, 65), (64, 64), (65, 129), (300, 200), (1000, 37)])

@@ -10,11 +10,12 @@ target=$1; old=$2; new=$3
 for v in "$old" "$new" "$old" "$new"; do
   cp "$v" "$target"
   make -C pytorch_mesh_renderer_amd/csrc clean >/dev/null
-  make -C pytorch_mesh_renderer_amd/csrc >/dev/null 2>&1
+  make -j8 -C pytorch_mesh_renderer_amd/csrc all >/dev/null 2>&1
+  make -j8 -C pytorch_mesh_renderer_amd/csrc probes >/dev/null 2>&1
   echo "--- $v"
   case "$AB_BENCH" in
     shade) timeout -k 5 100 python tools/shade_bench.py 2>/dev/null | grep shade ;;
     soft)  timeout -k 5 200 python tools/soft_bench.py 2>/dev/null | grep config5 ;;
-    *)     for k in 0 34 42; do timeout -k 5 100 python tools/raster_bench.py --variant $k 2>/dev/null | grep variant; done ;;
+    *)     for k in 0 32 40; do timeout -k 5 100 python tools/raster_bench.py --variant $k 2>/dev/null | grep variant; done ;;
   esac
 done

@@ -4,10 +4,11 @@ set -e
 cd $GRAFT_REPO_ROOT
 for flags in "$@"; do
   make -C pytorch_mesh_renderer_amd/csrc clean >/dev/null
-  make -C pytorch_mesh_renderer_amd/csrc EXTRA="$flags" >/dev/null 2>&1
+  make -j8 -C pytorch_mesh_renderer_amd/csrc EXTRA="$flags" all >/dev/null 2>&1
+  make -j8 -C pytorch_mesh_renderer_amd/csrc EXTRA="$flags" probes >/dev/null 2>&1
   echo "--- $flags"
   if [ "$AB_BENCH" = l1 ]; then timeout -k 5 100 python tools/l1_bench.py 2>/dev/null | grep -v amdgpu
   elif [ "$AB_BENCH" = soft ]; then timeout -k 5 200 python tools/soft_bench.py 2>/dev/null | grep config5
   elif [ "$AB_BENCH" = shade ]; then timeout -k 5 100 python tools/shade_bench.py 2>/dev/null | grep shade
-  else for v in 0 34 42; do timeout -k 5 100 python tools/raster_bench.py --variant $v 2>/dev/null | grep variant; done; fi
+  else for v in 0 32 40; do timeout -k 5 100 python tools/raster_bench.py --variant $v 2>/dev/null | grep variant; done; fi
 done

@@ -9,7 +9,8 @@ for group in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR" \
              "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" \
              "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" \
              "SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY" \
-             "SQ_INSTS_BRANCH SQ_IFETCH SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU"; do
+             "SQ_INSTS_BRANCH SQ_IFETCH SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU" \
+             "SQ_LEVEL_WAVES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_TRANS_F32 GRBM_GUI_ACTIVE"; do
   i=$((i+1))
   timeout -k 10 200 rocprofv3 --kernel-trace --pmc $group --output-format csv -d "$OUT/g$i" -o run -- \
       python3 tools/raster_bench.py --iters 5 > "$OUT/g$i.log" 2>&1 || { echo "group $i failed"; tail -3 "$OUT/g$i.log"; }

@@ -3,7 +3,11 @@
     python tools/raster_bench.py [--config c3|c2|c4] [--iters N] [--variant V] [--backward]
 """
 import argparse, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+if "--variant" in sys.argv:   # stage probes live in the -DMR_PROBES build only (make -C csrc probes)
+    os.environ.setdefault("MR_NATIVE_LIB_PATH", os.path.join(
+        ROOT, "pytorch_mesh_renderer_amd", "csrc", "libmesh_raster_hip_probes.so"))
 import torch
 from pytorch_mesh_renderer_amd import _native
 from pytorch_mesh_renderer_amd.common import synthetic
@@ -19,7 +23,7 @@ B, W, H, K = {"c2": (8, 256, 256, 50), "c3": (32, 1024, 1024, 50), "c4": (8, 204
 dev = torch.device("cuda:0")
 job = synthetic.sphere_job(B, W, H, K)
 clip, tris = job["clip"].to(dev), job["triangles"].to(dev)
-_native.lib().mr_set_raster_tile_shape(args.variant)
+assert _native.lib().mr_debug_set_raster_probe(args.variant) == 0, "unknown probe (see include/mesh_raster_debug.h)"
 for _ in range(3):
     ids, bary, z = _native.rasterize_forward(clip, tris, W, H)
 torch.cuda.synchronize()
