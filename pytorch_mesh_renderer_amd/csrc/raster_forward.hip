@@ -270,11 +270,14 @@ __device__ __forceinline__ bool rect_outside_triangle(const float4 q0, const flo
 // the FMA chain below; the refined reciprocal depends on s alone and is computed once (22 VALU
 // instructions and one v_rcp instead of 30 and three).  Anything else -- on-edge pixels with a
 // zero numerator, extreme magnitudes -- takes the ordinary division.
-__device__ __forceinline__ void div3_common_denominator(float n0, float n1, float n2, float s, float &q0,
-                                                        float &q1, float &q2) {
+__device__ __forceinline__ void div3_common_denominator(float n0, float n1, float n2, float s,
+                                                        unsigned long long valid, float &q0, float &q1,
+                                                        float &q2) {
   const bool plain = (__builtin_fminf(__builtin_fminf(n0, n1), n2) >= 0x1p-60f) &
                      (__builtin_amdgcn_fmed3f(s, 0x1p-20f, 0x1p20f) == s);
-  if (plain) {
+  // One path for the whole wavefront (the ordinary division is correct for every operand):
+  // lanes without a candidate (`valid` clear) must not force the slow one.
+  if ((__builtin_amdgcn_ballot_w64(!plain) & valid) == 0ull) {
     const float r0 = __builtin_amdgcn_rcpf(s);
     const float r = __builtin_fmaf(__builtin_fmaf(-s, r0, 1.0f), r0, r0);
     auto quotient = [&](const float n) {
@@ -424,6 +427,7 @@ __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
       // region-relative pixel coordinates of this lane, packed (x | y << 16)
       const unsigned lane_xy = lane_xy0 + ((unsigned)(tx * 8) | ((unsigned)(ty * 8) << 16));
       PixelState st;
+      unsigned long long pass_mask;  // scratch of the depth loop's compare
       if (fresh) {
         st.z = 1.0f; st.b0 = 0.0f; st.b1 = 0.0f; st.b2 = 0.0f; st.id = 0;  // cpp:313-321
       } else if (in_image) {
@@ -481,29 +485,45 @@ __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
         } while (todo);
         // (2) depth: every lane walks its own candidates in ascending id
         if (PROBE & 8) { st.id += (int)mine; continue; }  // timing probe: coverage only
-        while (__ballot(mine != 0u)) {
-          if (mine != 0u) {
-            const int e = ebase + (__ffs((int)mine) - 1);
-            mine &= mine - 1u;
-            const Entry t = read_entry(s_ent, e);  // per-lane LDS address
-            const v2f e01 = (v2f{t.q0.x, t.q0.y} * px2 + v2f{t.q0.z, t.q0.w} * py2) +
-                            v2f{t.q1.x, t.q1.y};                         // same bits as in (1)
-            const float e0 = e01.x, e1 = e01.y;
-            const float e2 = (t.q1.z * px + t.q1.w * py) + t.q2.x;
-            const float s = (e0 + e1) + e2;                              // cpp:384
-            float b0, b1, b2;
-            div3_common_denominator(e0, e1, e2, s, b0, b1, b2);          // cpp:385-387
-            // cpp:395-396: cz = (b0 z0 + b1 z1) + b2 z2 and cw likewise, as (z, w) pairs
-            const v2f zw = (v2f{t.q2.z, t.q2.w} * v2f{b0, b0} + v2f{t.q3.x, t.q3.y} * v2f{b1, b1}) +
-                           v2f{t.q3.z, t.q3.w} * v2f{b2, b2};
-            const float cz = zw.x, cw = zw.y;
-            const float zz = cz / cw;                                    // cpp:397
-            if (!(zz < -1.0f || zz > 1.0f || zz > st.z)) {               // cpp:401
-              st.z = zz;
-              st.id = __builtin_bit_cast(int, t.q2.y);
-              st.b0 = b0; st.b1 = b1; st.b2 = b2;
-            }
-          }
+        // The trip is straight-line code for the whole wavefront -- lanes that have run out of
+        // candidates ride along on a valid dummy entry and are masked out of the final select --
+        // because vector instructions cost the same whatever EXEC holds, and a divergent
+        // `if (mine)` made the compiler keep two copies of the pixel state (10 moves per trip).
+        for (;;) {
+          const unsigned long long valid = __ballot(mine != 0u);
+          if (!valid) break;
+          const unsigned bit = min((unsigned)(__ffs((int)mine) - 1), 31u);  // no candidate: slot 31
+          mine &= mine - 1u;
+          const Entry t = read_entry(s_ent, ebase + (int)bit);  // per-lane LDS address
+          const v2f e01 = (v2f{t.q0.x, t.q0.y} * px2 + v2f{t.q0.z, t.q0.w} * py2) +
+                          v2f{t.q1.x, t.q1.y};                         // same bits as in (1)
+          float e0 = e01.x, e1 = e01.y;
+          float e2 = (t.q1.z * px + t.q1.w * py) + t.q2.x;
+          asm("" : "+v"(e0), "+v"(e1), "+v"(e2));  // scalar from here on: no re-packing moves
+          const float s = (e0 + e1) + e2;                              // cpp:384
+          float b0, b1, b2;
+          div3_common_denominator(e0, e1, e2, s, valid, b0, b1, b2);   // cpp:385-387
+          // cpp:395-396: cz = (b0 z0 + b1 z1) + b2 z2 and cw likewise, as (z, w) pairs
+          const v2f zw = (v2f{t.q2.z, t.q2.w} * v2f{b0, b0} + v2f{t.q3.x, t.q3.y} * v2f{b1, b1}) +
+                         v2f{t.q3.z, t.q3.w} * v2f{b2, b2};
+          const float cz = zw.x, cw = zw.y;
+          const float zz = cz / cw;                                    // cpp:397
+          // cpp:401: the candidate loses if zz < -1 || zz > 1 || zz > zbuf; a NaN passes.  The
+          // winner's five values replace the pixel state in place.
+          asm volatile(
+              "v_cmp_ngt_f32_e64 vcc, |%[zz]|, 1.0\n\t"
+              "v_cmp_ngt_f32_e64 %[m], %[zz], %[z]\n\t"
+              "s_and_b64 vcc, vcc, %[valid]\n\t"
+              "s_and_b64 vcc, vcc, %[m]\n\t"
+              "v_cndmask_b32_e32 %[z], %[z], %[zz], vcc\n\t"
+              "v_cndmask_b32_e32 %[id], %[id], %[tid], vcc\n\t"
+              "v_cndmask_b32_e32 %[c0], %[c0], %[b0], vcc\n\t"
+              "v_cndmask_b32_e32 %[c1], %[c1], %[b1], vcc\n\t"
+              "v_cndmask_b32_e32 %[c2], %[c2], %[b2], vcc"
+              : [z] "+v"(st.z), [id] "+v"(st.id), [c0] "+v"(st.b0), [c1] "+v"(st.b1), [c2] "+v"(st.b2),
+                [m] "=&s"(pass_mask)
+              : [zz] "v"(zz), [tid] "v"(t.q2.y), [b0] "v"(b0), [b1] "v"(b1), [b2] "v"(b2), [valid] "s"(valid)
+              : "vcc");
         }
       }
       if (in_image && !((PROBE & 32) && st.z != 123.0f)) {  // 32: timing probe, no stores

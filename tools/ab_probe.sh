@@ -1,11 +1,11 @@
 # A/B of compile-time variants inside ONE gpurun call (box-to-box noise is ~5 %).
-#   gpurun -- 'bash tools/ab_probe.sh "-DMR_RASTER_WAVES=6" "-DMR_RASTER_WAVES=7"'
+#   gpurun -- 'bash tools/ab_probe.sh "EXTRA=-DMR_RASTER_WAVES=6" "RASTER_FWD_FLAGS=-fno-slp-vectorize"'
 set -e
 cd $GRAFT_REPO_ROOT
 for flags in "$@"; do
   make -C pytorch_mesh_renderer_amd/csrc clean >/dev/null
-  make -j8 -C pytorch_mesh_renderer_amd/csrc EXTRA="$flags" all >/dev/null 2>&1
-  make -j8 -C pytorch_mesh_renderer_amd/csrc EXTRA="$flags" probes >/dev/null 2>&1
+  make -j8 -C pytorch_mesh_renderer_amd/csrc $flags all >/dev/null 2>&1
+  make -j8 -C pytorch_mesh_renderer_amd/csrc $flags probes >/dev/null 2>&1
   echo "--- $flags"
   if [ "$AB_BENCH" = l1 ]; then timeout -k 5 100 python tools/l1_bench.py 2>/dev/null | grep -v amdgpu
   elif [ "$AB_BENCH" = soft ]; then timeout -k 5 200 python tools/soft_bench.py 2>/dev/null | grep config5
