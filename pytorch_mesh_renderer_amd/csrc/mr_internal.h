@@ -21,8 +21,15 @@ struct alignas(64) TriRec {
   float4 a, b, c, d;
 };
 
-// Pixel bbox [l, r) x [bot, top) packed as 4 x u16; an empty / culled triangle
-// is stored as all zeros so that no region ever selects it.
+// Per-(image, triangle) bbox record, 16 bytes: pixel bbox [l, r) x [bot, top) packed as 4 x u16
+// (an empty / culled triangle is all zeros so that no region ever selects it) and a lower bound
+// of the depth values the triangle can produce (-inf when none is proven: raster_forward.hip).
+struct alignas(16) TriBox {
+  unsigned lr, bt;
+  float zlo;
+  unsigned pad;
+};
+
 __device__ __forceinline__ uint2 pack_bbox(int l, int r, int bot, int top) {
   return make_uint2((unsigned)l | ((unsigned)r << 16), (unsigned)bot | ((unsigned)top << 16));
 }

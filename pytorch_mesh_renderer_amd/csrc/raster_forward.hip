@@ -60,9 +60,36 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) {
 __device__ __forceinline__ float max_std(float a, float b) { return (a < b) ? b : a; }
 __device__ __forceinline__ float min_std(float a, float b) { return (b < a) ? b : a; }
 
+// A proven lower bound of every depth value the rasterizer can compute for a "tame" triangle, or
+// -inf for any other.  Tame: all three w in [2^-60, 2^60], every |z| zero or in [2^-60, 2^60].
+// For an inside pixel the kernel evaluates (cpp:395-397), with rounded barycentrics b_i >= 0,
+//     zz = fl( fl(fl(b0 z0 + b1 z1) + b2 z2) / fl(fl(b0 w0 + b1 w1) + b2 w2) ),
+// every product and sum rounded once (no contraction).  With r_i = z_i / w_i, u = 2^-24 and
+// rho = max|z_i| / min w_i:  sum b_i z_i = sum (b_i w_i) r_i >= min(r) * sum b_i w_i, the rounded
+// numerator is off by at most 3u * sum b_i |z_i| <= 3u * rho * sum b_i w_i, the rounded denominator
+// by a factor within 1 +- 3u, the division by another 1 +- u, and |min r| <= rho, hence
+//     zz >= min(r) - 8.1 u rho            (plus < 2^-86 for products that underflow).
+// The bound below leaves twice that margin and is rounded towards -inf.  It also follows that a
+// tame triangle never produces a NaN or an infinite depth (its denominator is positive).
+// Used ONLY to order and skip work (front-to-back classes of the bin, see k_raster): results
+// stay bit-identical to the sequential z-buffer of the reference.
+__device__ __forceinline__ float depth_lower_bound(float z0, float z1, float z2, float w0, float w1,
+                                                   float w2) {
+  const float wmin = fminf(fminf(w0, w1), w2), wmax = fmaxf(fmaxf(w0, w1), w2);
+  const float zabs = fmaxf(fmaxf(fabsf(z0), fabsf(z1)), fabsf(z2));
+  auto z_ok = [](float z) { const float a = fabsf(z); return a == 0.0f || (a >= 0x1p-60f && a <= 0x1p60f); };
+  const bool tame = wmin >= 0x1p-60f && wmax <= 0x1p60f && z_ok(z0) && z_ok(z1) && z_ok(z2);
+  if (!tame) return -INFINITY;  // also taken for NaNs: every comparison above is false for them
+  const double rmin = fmin(fmin((double)z0 / (double)w0, (double)z1 / (double)w1), (double)z2 / (double)w2);
+  const double bound = rmin - 0x1p-20 * ((double)zabs / (double)wmin) - 0x1p-80;
+  float f = (float)bound;
+  if ((double)f > bound) f = nextafterf(f, -INFINITY);
+  return f;
+}
+
 __global__ __launch_bounds__(kThreads) void k_setup(
     const float4 *__restrict__ clip, const int32_t *__restrict__ tris, int B, int V, int T,
-    int W, int H, TriRec *__restrict__ recs, uint2 *__restrict__ bbs,
+    int W, int H, TriRec *__restrict__ recs, TriBox *__restrict__ bbs,
     float *__restrict__ pxtab, float *__restrict__ pytab) {
   const long gid = (long)blockIdx.x * kThreads + threadIdx.x;
   const long nbt = (long)B * T;
@@ -82,7 +109,7 @@ __global__ __launch_bounds__(kThreads) void k_setup(
   const int b = (int)(gid / T);
   const int t = (int)(gid - (long)b * T);
   const int i0 = tris[3 * t + 0], i1 = tris[3 * t + 1], i2 = tris[3 * t + 2];
-  uint2 bb = make_uint2(0u, 0u);
+  TriBox bb{0u, 0u, -INFINITY, 0u};
   if ((unsigned)i0 < (unsigned)V && (unsigned)i1 < (unsigned)V && (unsigned)i2 < (unsigned)V) {
     const float4 p0 = clip[(long)b * V + i0];
     const float4 p1 = clip[(long)b * V + i1];
@@ -122,7 +149,10 @@ __global__ __launch_bounds__(kThreads) void k_setup(
         top = clampi(cvt_trunc_x86(ceilf(max_std(max_std(y0, y1), y2))), 0, H);
       }
       if (r > l && top > bot) {
-        bb = pack_bbox(l, r, bot, top);
+        const uint2 box = pack_bbox(l, r, bot, top);
+        bb.lr = box.x;
+        bb.bt = box.y;
+        bb.zlo = depth_lower_bound(p0.z, p1.z, p2.z, w0, w1, w2);
         TriRec rec;
         // edge i = (m[3i], m[3i+1], m[3i+2]); edges 0 and 1 interleaved for packed fp32 math
         rec.a = make_float4(m0, m3, m1, m4);
@@ -146,32 +176,38 @@ constexpr int kCellRegions = 4;                       // regions per cell edge (
 constexpr int kCoarseThreads = 1024;
 
 __global__ __launch_bounds__(kCoarseThreads) void k_coarse(
-    const uint2 *__restrict__ bbs, int T, int W, int H, int cells_x, int cells_per_image, int cell_size,
-    int32_t *__restrict__ cell_ids, int32_t *__restrict__ cell_count) {
+    const TriBox *__restrict__ bbs, int T, int W, int H, int cells_x, int cells_per_image, int cell_size,
+    int32_t *__restrict__ cell_ids, int32_t *__restrict__ cell_count, float *__restrict__ cell_split) {
   __shared__ int s_wave_count[kCoarseThreads / kWave];
+  __shared__ float s_wave_lo[kCoarseThreads / kWave], s_wave_hi[kCoarseThreads / kWave];
   const int img = (int)blockIdx.x / cells_per_image;
   const int cell = (int)blockIdx.x - img * cells_per_image;
   const int cy = cell / cells_x, cx = cell - cy * cells_x;
   const int X0 = cx * cell_size, Y0 = cy * cell_size;
   const int X1 = min(X0 + cell_size, W), Y1 = min(Y0 + cell_size, H);
   const int tid = (int)threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
-  const uint2 *img_bbs = bbs + (size_t)img * T;
+  const TriBox *img_bbs = bbs + (size_t)img * T;
   int32_t *out = cell_ids + ((size_t)img * cells_per_image + cell) * T;
   int n = 0;  // workgroup-uniform
+  float lo = INFINITY, hi = -INFINITY;  // range of the depth bounds of this thread's hits
   constexpr int kUnroll = 4;
   for (int base = 0; base < T; base += kUnroll * kCoarseThreads) {
-    uint2 bb[kUnroll];
+    TriBox bb[kUnroll];
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
       const int t = base + u * kCoarseThreads + tid;
-      bb[u] = (t < T) ? img_bbs[t] : make_uint2(0u, 0u);
+      bb[u] = (t < T) ? img_bbs[t] : TriBox{0u, 0u, 0.0f, 0u};
     }
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
       const int t = base + u * kCoarseThreads + tid;
-      const int l = (int)(bb[u].x & 0xffffu), r = (int)(bb[u].x >> 16);
-      const int bt = (int)(bb[u].y & 0xffffu), tp = (int)(bb[u].y >> 16);
+      const int l = (int)(bb[u].lr & 0xffffu), r = (int)(bb[u].lr >> 16);
+      const int bt = (int)(bb[u].bt & 0xffffu), tp = (int)(bb[u].bt >> 16);
       const bool hit = (l < X1) && (r > X0) && (bt < Y1) && (tp > Y0);  // empty bbox = all zeros
+      if (hit) {
+        lo = fminf(lo, bb[u].zlo);  // -inf (a triangle that is not tame) sticks
+        hi = fmaxf(hi, bb[u].zlo);
+      }
       const unsigned long long m = __ballot(hit);
       if (lane == 0) s_wave_count[wave] = __builtin_popcountll(m);
       __syncthreads();
@@ -189,7 +225,28 @@ __global__ __launch_bounds__(kCoarseThreads) void k_coarse(
       __syncthreads();
     }
   }
-  if (tid == 0) cell_count[(size_t)img * cells_per_image + cell] = n;
+  // The cell's depth split: midway between the smallest and the largest depth bound of its
+  // triangles.  k_raster draws the triangles whose bound lies below it first ("near" class).
+  // NaN = some triangle of the cell is not tame: its regions keep strict triangle-id order.
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) {
+    lo = fminf(lo, __shfl_xor(lo, off));
+    hi = fmaxf(hi, __shfl_xor(hi, off));
+  }
+  if (lane == 0) {
+    s_wave_lo[wave] = lo;
+    s_wave_hi[wave] = hi;
+  }
+  __syncthreads();
+  if (tid == 0) {
+#pragma unroll
+    for (int w = 0; w < kCoarseThreads / kWave; ++w) {
+      lo = fminf(lo, s_wave_lo[w]);
+      hi = fmaxf(hi, s_wave_hi[w]);
+    }
+    cell_count[(size_t)img * cells_per_image + cell] = n;
+    cell_split[(size_t)img * cells_per_image + cell] = (n > 0 && lo > -INFINITY) ? 0.5f * lo + 0.5f * hi : NAN;
+  }
 }
 
 // Per-pixel running z-buffer state (registers).
@@ -299,10 +356,11 @@ __device__ __forceinline__ void div3_common_denominator(float n0, float n1, floa
 // mesh_raster_debug.h) switch stages off for stage timing and leave the outputs undefined.
 template <int R, int PROBE>
 __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
-    const TriRec *__restrict__ recs, const uint2 *__restrict__ bbs,
+    const TriRec *__restrict__ recs, const TriBox *__restrict__ bbs,
     const float *__restrict__ pxtab, const float *__restrict__ pytab, int T, int W, int H,
     int regions_x, int regions_per_image, int n_regions, int regions_per_xcd,
-    const int32_t *__restrict__ cell_ids, const int32_t *__restrict__ cell_count, int cells_x,
+    const int32_t *__restrict__ cell_ids, const int32_t *__restrict__ cell_count,
+    const float *__restrict__ cell_split, int cells_x,
     int cells_per_image, int32_t *__restrict__ ids, float *__restrict__ bary,
     float *__restrict__ zbuf) {
   static_assert(R == 64 || R == 32, "region edge");
@@ -339,12 +397,22 @@ __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
   const int lane = tid & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const TriRec *img_recs = recs + (size_t)img * T;
-  const uint2 *img_bbs = bbs + (size_t)img * T;
+  const TriBox *img_bbs = bbs + (size_t)img * T;
   const size_t img_px = (size_t)img * H * W;
   // this region's coarse cell: the id-ordered list of triangles whose bbox touches it
   const int cell = (ry / kCellRegions) * cells_x + (rx / kCellRegions);
   const int32_t *cand = cell_ids + ((size_t)img * cells_per_image + cell) * T;
   const int n_cand = cell_count[(size_t)img * cells_per_image + cell];
+  // Front-to-back classes (see depth_lower_bound): when every triangle of the cell is tame, the
+  // bin holds the candidates whose depth bound lies below the cell's split first ("near"), in id
+  // order, then the others ("far"), in id order.  A tile whose pixels all hold a depth below the
+  // split after its near words cannot be changed by any far candidate (each of those is at least
+  // as deep as the split) and skips them.  Because the classes break the id order, ties are
+  // resolved explicitly in that mode (equal depth -> larger id, as the sequential loop of
+  // cpp:401-409 does); otherwise (NaN split) there is one class and the reference's own test.
+  const float split_raw = cell_split[(size_t)img * cells_per_image + cell];
+  const bool ordered = split_raw == split_raw;  // workgroup-uniform
+  const float split = ordered ? split_raw : INFINITY;
 
   // pixel-centre extents of the region (tables are monotone in the pixel index)
   const float rpxlo = pxtab[X0], rpxhi = pxtab[X1 - 1], rpylo = pytab[Y0], rpyhi = pytab[Y1 - 1];
@@ -359,12 +427,12 @@ __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
   // One thread per bin entry walks the tiles under the entry's bbox and applies the exact
   // trivial reject against each; survivors set their bit in the tile's 256-bit mask.  This
   // costs ~(entries x tiles-per-entry) lane-tests per region instead of (tiles x entries).
-  auto build_tile_masks = [&](const int n) {
+  auto build_tile_masks = [&](const int n_near, const int far_base, const int n_far) {
     for (int i = tid; i < kSharedDw; i += kThreads) s_shared[i] = 0u;
     // pixel-centre extents of tile column / row t: s_pxy[.][8 t] .. s_pxy[.][min(8 t + 7, last)]
     const int last_x = X1 - 1 - X0, last_y = Y1 - 1 - Y0;
     __syncthreads();
-    if (tid < n) {
+    if (tid < n_near || (tid >= far_base && tid < far_base + n_far)) {
       const float *p = s_ent + tid * kEntryDw;
       const uint2 box = *(const uint2 *)(p + 16);
       const float4 q0 = *(const float4 *)(p), q1 = *(const float4 *)(p + 4);
@@ -412,7 +480,7 @@ __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
   // list of words worth visiting (most of a tile's 256 mask bits are zero: ~3.6 candidates)
   static_assert(kMaskWords == 8, "lane & 7 == lx indexes the tile's mask words");
   const unsigned *lane_word = (const unsigned *)lane_px + 2 * R;  // &s_tmask[0][lx]
-  auto raster_pass = [&](auto fresh_tag) {
+  auto raster_pass = [&](auto fresh_tag, const int far_word) {
     constexpr bool fresh = decltype(fresh_tag)::value;
     for (int tile = wave; tile < kTiles; tile += kWaves) {
       const int ty = tile / kTilesX, tx = tile % kTilesX;
@@ -427,9 +495,10 @@ __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
       // region-relative pixel coordinates of this lane, packed (x | y << 16)
       const unsigned lane_xy = lane_xy0 + ((unsigned)(tx * 8) | ((unsigned)(ty * 8) << 16));
       PixelState st;
-      unsigned long long pass_mask;  // scratch of the depth loop's compare
+      unsigned long long pass_mask, pass_mask2;  // scratch of the depth loop's compares
       if (fresh) {
-        st.z = 1.0f; st.b0 = 0.0f; st.b1 = 0.0f; st.b2 = 0.0f; st.id = 0;  // cpp:313-321
+        st.z = 1.0f; st.b0 = 0.0f; st.b1 = 0.0f; st.b2 = 0.0f;  // cpp:313-321
+        st.id = ordered ? -1 : 0;  // -1: "nothing drawn yet" loses every tie; stored as 0
       } else if (in_image) {
         st.z = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_z, lane_pix * 4u, tile_pix * 4, 0));
         st.id = (int)__builtin_amdgcn_raw_buffer_load_b32(rs_ids, lane_pix * 4u, tile_pix * 4, 0);
@@ -439,8 +508,14 @@ __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
       }
       unsigned words = (unsigned)__ballot(my_word != 0u) & ((1u << kMaskWords) - 1u);
       if (PROBE & 16) words = 0u;  // timing probe: no coverage, no depth
+      bool far_checked = false;
       while (words) {
         const int w = __builtin_ctz(words);
+        if (w >= far_word && !far_checked) {
+          // first word of the far class: done if no pixel of the tile could still be won
+          far_checked = true;
+          if (!__ballot(in_image && !(st.z < split))) break;
+        }
         words &= words - 1u;
         unsigned todo = (unsigned)__builtin_amdgcn_readlane((int)my_word, w);
         const int ebase = w * 32;
@@ -509,25 +584,49 @@ __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
           const float cz = zw.x, cw = zw.y;
           const float zz = cz / cw;                                    // cpp:397
           // cpp:401: the candidate loses if zz < -1 || zz > 1 || zz > zbuf; a NaN passes.  The
-          // winner's five values replace the pixel state in place.
-          asm volatile(
-              "v_cmp_ngt_f32_e64 vcc, |%[zz]|, 1.0\n\t"
-              "v_cmp_ngt_f32_e64 %[m], %[zz], %[z]\n\t"
-              "s_and_b64 vcc, vcc, %[valid]\n\t"
-              "s_and_b64 vcc, vcc, %[m]\n\t"
-              "v_cndmask_b32_e32 %[z], %[z], %[zz], vcc\n\t"
-              "v_cndmask_b32_e32 %[id], %[id], %[tid], vcc\n\t"
-              "v_cndmask_b32_e32 %[c0], %[c0], %[b0], vcc\n\t"
-              "v_cndmask_b32_e32 %[c1], %[c1], %[b1], vcc\n\t"
-              "v_cndmask_b32_e32 %[c2], %[c2], %[b2], vcc"
-              : [z] "+v"(st.z), [id] "+v"(st.id), [c0] "+v"(st.b0), [c1] "+v"(st.b1), [c2] "+v"(st.b2),
-                [m] "=&s"(pass_mask)
-              : [zz] "v"(zz), [tid] "v"(t.q2.y), [b0] "v"(b0), [b1] "v"(b1), [b2] "v"(b2), [valid] "s"(valid)
-              : "vcc");
+          // winner's five values replace the pixel state in place.  With front-to-back classes
+          // the candidates do not arrive in id order, so the tie the sequential loop resolves
+          // implicitly (equal depth: the later id overwrites) is tested explicitly; depths are
+          // finite in that mode.
+          if (ordered) {
+            asm volatile(
+                "v_cmp_ngt_f32_e64 vcc, |%[zz]|, 1.0\n\t"
+                "v_cmp_eq_f32_e64 %[m], %[zz], %[z]\n\t"
+                "s_and_b64 %[valid2], vcc, %[valid]\n\t"
+                "v_cmp_gt_i32_e64 vcc, %[tid], %[id]\n\t"
+                "s_and_b64 %[m], %[m], vcc\n\t"
+                "v_cmp_lt_f32_e64 vcc, %[zz], %[z]\n\t"
+                "s_or_b64 vcc, vcc, %[m]\n\t"
+                "s_and_b64 vcc, vcc, %[valid2]\n\t"
+                "v_cndmask_b32_e32 %[z], %[z], %[zz], vcc\n\t"
+                "v_cndmask_b32_e32 %[id], %[id], %[tid], vcc\n\t"
+                "v_cndmask_b32_e32 %[c0], %[c0], %[b0], vcc\n\t"
+                "v_cndmask_b32_e32 %[c1], %[c1], %[b1], vcc\n\t"
+                "v_cndmask_b32_e32 %[c2], %[c2], %[b2], vcc"
+                : [z] "+v"(st.z), [id] "+v"(st.id), [c0] "+v"(st.b0), [c1] "+v"(st.b1), [c2] "+v"(st.b2),
+                  [m] "=&s"(pass_mask), [valid2] "=&s"(pass_mask2)
+                : [zz] "v"(zz), [tid] "v"(t.q2.y), [b0] "v"(b0), [b1] "v"(b1), [b2] "v"(b2), [valid] "s"(valid)
+                : "vcc");
+          } else {
+            asm volatile(
+                "v_cmp_ngt_f32_e64 vcc, |%[zz]|, 1.0\n\t"
+                "v_cmp_ngt_f32_e64 %[m], %[zz], %[z]\n\t"
+                "s_and_b64 vcc, vcc, %[valid]\n\t"
+                "s_and_b64 vcc, vcc, %[m]\n\t"
+                "v_cndmask_b32_e32 %[z], %[z], %[zz], vcc\n\t"
+                "v_cndmask_b32_e32 %[id], %[id], %[tid], vcc\n\t"
+                "v_cndmask_b32_e32 %[c0], %[c0], %[b0], vcc\n\t"
+                "v_cndmask_b32_e32 %[c1], %[c1], %[b1], vcc\n\t"
+                "v_cndmask_b32_e32 %[c2], %[c2], %[b2], vcc"
+                : [z] "+v"(st.z), [id] "+v"(st.id), [c0] "+v"(st.b0), [c1] "+v"(st.b1), [c2] "+v"(st.b2),
+                  [m] "=&s"(pass_mask)
+                : [zz] "v"(zz), [tid] "v"(t.q2.y), [b0] "v"(b0), [b1] "v"(b1), [b2] "v"(b2), [valid] "s"(valid)
+                : "vcc");
+          }
         }
       }
       if (in_image && !((PROBE & 32) && st.z != 123.0f)) {  // 32: timing probe, no stores
-        __builtin_amdgcn_raw_buffer_store_b32((unsigned)st.id, rs_ids, lane_pix * 4u, tile_pix * 4, 0);
+        __builtin_amdgcn_raw_buffer_store_b32((unsigned)max(st.id, 0), rs_ids, lane_pix * 4u, tile_pix * 4, 0);
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, st.z), rs_z, lane_pix * 4u, tile_pix * 4, 0);
         __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(v3u, v3f{st.b0, st.b1, st.b2}), rs_bary, lane_pix * 12u,
                                               tile_pix * 12, 0);
@@ -556,7 +655,7 @@ __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
     int count = 0, stop = round_chunks;  // stop: first chunk this wavefront could not take
     constexpr int kUnroll = 2;  // chunks per trip: their loads are issued together
     for (int c0 = wave; c0 < round_chunks && stop == round_chunks; c0 += kUnroll * kWaves) {
-      uint2 bb[kUnroll];
+      TriBox bb[kUnroll];
       int tri[kUnroll];
       bool near[kUnroll];
 #pragma unroll
@@ -567,12 +666,12 @@ __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
       }
 #pragma unroll
       for (int u = 0; u < kUnroll; ++u) {
-        bb[u] = (tri[u] >= 0) ? img_bbs[tri[u]] : make_uint2(0u, 0u);
+        bb[u] = (tri[u] >= 0) ? img_bbs[tri[u]] : TriBox{0u, 0u, 0.0f, 0u};
       }
 #pragma unroll
       for (int u = 0; u < kUnroll; ++u) {
-        const int l = (int)(bb[u].x & 0xffffu), r = (int)(bb[u].x >> 16);
-        const int bt = (int)(bb[u].y & 0xffffu), tp = (int)(bb[u].y >> 16);
+        const int l = (int)(bb[u].lr & 0xffffu), r = (int)(bb[u].lr >> 16);
+        const int bt = (int)(bb[u].bt & 0xffffu), tp = (int)(bb[u].bt >> 16);
         near[u] = (l < X1) && (r > X0) && (bt < Y1) && (tp > Y0);  // empty bbox = all zeros
       }
 #pragma unroll
@@ -591,9 +690,17 @@ __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
           stop = c;
           continue;
         }
+        // depth class of the survivor (0 = near, 1 = far) and its rank inside (chunk, class)
+        const bool far = pass && !(bb[u].zlo < split);
+        const unsigned long long m_far = __ballot(far);
+        const int cnt_far = __builtin_popcountll(m_far);
         if (pass) {
           const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
                                                           __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+          const unsigned long long m_class = far ? m_far : (m & ~m_far);
+          const unsigned class_rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m_class >> 32),
+                                                                __builtin_amdgcn_mbcnt_lo((unsigned)m_class, 0u)) |
+                                      (far ? 0x80000000u : 0u);
           float *p = s_ent + (wave * kSubCap + count + rank) * kEntryDw;
           const TriRec *rp = img_recs + t;  // L1/L2-hot: just read by the reject test
           const float4 q2 = rp->c;
@@ -601,15 +708,15 @@ __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
           *(float4 *)(p + 4) = rp->b;
           *(float4 *)(p + 8) = make_float4(q2.x, __builtin_bit_cast(float, t), q2.z, q2.w);
           *(float4 *)(p + 12) = rp->d;
-          const int l = (int)(bb[u].x & 0xffffu), r = (int)(bb[u].x >> 16);
-          const int bt = (int)(bb[u].y & 0xffffu), tp = (int)(bb[u].y >> 16);
+          const int l = (int)(bb[u].lr & 0xffffu), r = (int)(bb[u].lr >> 16);
+          const int bt = (int)(bb[u].bt & 0xffffu), tp = (int)(bb[u].bt >> 16);
           // bbox clipped to the region, region-relative: (l | b << 16), (w - 1 | h - 1 << 16)
           const int cl = max(l, X0), cb = max(bt, Y0);
           const unsigned rel = (unsigned)(cl - X0) | ((unsigned)(cb - Y0) << 16);
           const unsigned ext = (unsigned)(min(r, X1) - cl - 1) | ((unsigned)(min(tp, Y1) - cb - 1) << 16);
-          *(uint4 *)(p + 16) = make_uint4(rel, ext, (unsigned)c, (unsigned)rank);
+          *(uint4 *)(p + 16) = make_uint4(rel, ext, (unsigned)c, class_rank);
         }
-        if (lane == 0) s_chunk_count[c] = cnt;
+        if (lane == 0) s_chunk_count[c] = (cnt - cnt_far) | (cnt_far << 16);  // near | far << 16
         count += cnt;
       }
     }
@@ -622,8 +729,9 @@ __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
     int keep_chunks = round_chunks;
 #pragma unroll
     for (int w = 0; w < kWaves; ++w) keep_chunks = min(keep_chunks, s_stop[w]);
-    // exclusive prefix sum of the kept chunks' survivor counts (thread t <-> chunk t)
-    int n;
+    // exclusive prefix sums of the kept chunks' survivor counts, both classes at once in the
+    // two halves of one register (thread t <-> chunk t; totals never exceed kBin2Cap)
+    int n_near, n_far, far_base;
     {
       const int v = (tid < keep_chunks) ? s_chunk_count[tid] : 0;
       int incl = v;
@@ -634,17 +742,22 @@ __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
       }
       if (lane == kWave - 1) s_wave_total[wave] = incl;
       __syncthreads();
-      int wave_off = 0;
-      n = 0;
+      int wave_off = 0, total = 0;
 #pragma unroll
       for (int w = 0; w < kWaves; ++w) {
         const int tot = s_wave_total[w];
         if (w < wave) wave_off += tot;
-        n += tot;
+        total += tot;
       }
-      s_chunk_count[tid] = wave_off + incl - v;  // now: offset of chunk tid in the sorted bin
+      s_chunk_count[tid] = wave_off + incl - v;  // now: offsets of chunk tid inside the two classes
+      n_near = total & 0xffff;
+      n_far = total >> 16;
+      // the far class starts on a mask-word boundary when the bin has room for the gap, so that
+      // "first far word" is a clean cut for the tile walk
+      far_base = (n_near + 31) & ~31;
+      if (far_base + n_far > kBin2Cap) far_base = n_near;
     }
-    // move every kept entry to its id-ordered slot (in place, via registers)
+    // move every kept entry to its slot: (class, id) order (in place, via registers)
     Entry mine;
     unsigned my_chunk = 0u, my_rank = 0u;
     const int my_slot = (tid >> 6) * kSubCap + (tid & (kWave - 1));  // sub-bin of wave tid/64
@@ -657,7 +770,10 @@ __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
     }
     __syncthreads();
     if (have && (int)my_chunk < keep_chunks) {
-      float *p = s_ent + (s_chunk_count[my_chunk] + (int)my_rank) * kEntryDw;
+      const int offs = s_chunk_count[my_chunk];
+      const int slot = (my_rank & 0x80000000u) ? far_base + (offs >> 16) + (int)(my_rank & 0xffffu)
+                                               : (offs & 0xffff) + (int)my_rank;
+      float *p = s_ent + slot * kEntryDw;
       *(float4 *)(p) = mine.q0;
       *(float4 *)(p + 4) = mine.q1;
       *(float4 *)(p + 8) = mine.q2;
@@ -666,16 +782,18 @@ __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
     }
     const int next_base = round_base + keep_chunks * kWave;
     __syncthreads();
+    // mask word that starts the far class (kMaskWords: no clean cut, the walk never skips)
+    const int far_word = (ordered && n_far > 0 && (far_base & 31) == 0) ? far_base >> 5 : kMaskWords;
     if constexpr (PROBE == 0 || PROBE >= 8) {
-      build_tile_masks(n);
-      if (first_pass) raster_pass(std::true_type{});
-      else raster_pass(std::false_type{});
+      build_tile_masks(n_near, far_base, n_far);
+      if (first_pass) raster_pass(std::true_type{}, far_word);
+      else raster_pass(std::false_type{}, far_word);
     } else if constexpr (PROBE == 2) {
-      build_tile_masks(0);         // timing probe: tile walk over an empty bin
-      if (first_pass) raster_pass(std::true_type{});
-      else raster_pass(std::false_type{});
+      build_tile_masks(0, 0, 0);   // timing probe: tile walk over an empty bin
+      if (first_pass) raster_pass(std::true_type{}, far_word);
+      else raster_pass(std::false_type{}, far_word);
     } else if constexpr (PROBE == 3) {
-      build_tile_masks(n);         // timing probe: bin + tile masks, no walk
+      build_tile_masks(n_near, far_base, n_far);  // timing probe: bin + tile masks, no walk
     }
     first_pass = false;
     round_base = next_base;
@@ -701,9 +819,9 @@ size_t raster_forward_ws(int B, int V, int T, int W, int H) {
   const size_t nbt = (size_t)B * T;
   const int cell = kCellRegions * region_edge(B, W, H);
   const size_t cells = (size_t)((W + cell - 1) / cell) * ((H + cell - 1) / cell) * B;
-  return align_up(nbt * sizeof(TriRec), 256) + align_up(nbt * sizeof(uint2), 256) +
+  return align_up(nbt * sizeof(TriRec), 256) + align_up(nbt * sizeof(TriBox), 256) +
          align_up((size_t)W * sizeof(float), 256) + align_up((size_t)H * sizeof(float), 256) +
-         align_up(cells * T * sizeof(int32_t), 256) + align_up(cells * sizeof(int32_t), 256);
+         align_up(cells * T * sizeof(int32_t), 256) + 2 * align_up(cells * sizeof(int32_t), 256);
 }
 
 #ifdef MR_PROBES
@@ -712,9 +830,10 @@ thread_local int g_raster_probe = 0;  // stage-timing probe of the NEXT launches
 
 namespace {
 struct RasterArgs {
-  const TriRec *recs; const uint2 *bbs; const float *pxtab, *pytab;
+  const TriRec *recs; const TriBox *bbs; const float *pxtab, *pytab;
   int T, W, H, regions_x, per_image, n_regions, per_xcd;
   const int32_t *cell_ids, *cell_count;
+  const float *cell_split;
   int cells_x, cells_per_image;
   int32_t *ids; float *bary, *z;
 };
@@ -722,7 +841,7 @@ struct RasterArgs {
 template <int R, int PROBE>
 void launch_k_raster(const RasterArgs &a, dim3 grid, hipStream_t s) {
   hipLaunchKernelGGL((k_raster<R, PROBE>), grid, dim3(kThreads), 0, s, a.recs, a.bbs, a.pxtab, a.pytab, a.T, a.W,
-                     a.H, a.regions_x, a.per_image, a.n_regions, a.per_xcd, a.cell_ids, a.cell_count, a.cells_x,
+                     a.H, a.regions_x, a.per_image, a.n_regions, a.per_xcd, a.cell_ids, a.cell_count, a.cell_split, a.cells_x,
                      a.cells_per_image, a.ids, a.bary, a.z);
 }
 
@@ -750,8 +869,8 @@ int launch_raster_forward(const float *clip, const int32_t *tris, int B, int V, 
   char *p = (char *)ws;
   TriRec *recs = (TriRec *)p;
   p += align_up(nbt * sizeof(TriRec), 256);
-  uint2 *bbs = (uint2 *)p;
-  p += align_up(nbt * sizeof(uint2), 256);
+  TriBox *bbs = (TriBox *)p;
+  p += align_up(nbt * sizeof(TriBox), 256);
   float *pxtab = (float *)p;
   p += align_up((size_t)W * sizeof(float), 256);
   float *pytab = (float *)p;
@@ -762,6 +881,8 @@ int launch_raster_forward(const float *clip, const int32_t *tris, int B, int V, 
   int32_t *cell_ids = (int32_t *)p;
   p += align_up((size_t)cells_per_image * B * T * sizeof(int32_t), 256);
   int32_t *cell_count = (int32_t *)p;
+  p += align_up((size_t)cells_per_image * B * sizeof(int32_t), 256);
+  float *cell_split = (float *)p;
 
   const long setup_threads = (long)nbt + W + H;
   const unsigned setup_blocks = (unsigned)((setup_threads + kThreads - 1) / kThreads);
@@ -771,7 +892,7 @@ int launch_raster_forward(const float *clip, const int32_t *tris, int B, int V, 
   if (rc != MR_OK) return rc;
   if (B == 0) return MR_OK;
   hipLaunchKernelGGL(k_coarse, dim3((unsigned)(cells_per_image * B)), dim3(kCoarseThreads), 0, s, bbs, T,
-                     W, H, cells_x, cells_per_image, cell, cell_ids, cell_count);
+                     W, H, cells_x, cells_per_image, cell, cell_ids, cell_count, cell_split);
   rc = check_launch();
   if (rc != MR_OK) return rc;
 
@@ -782,7 +903,7 @@ int launch_raster_forward(const float *clip, const int32_t *tris, int B, int V, 
   const int per_xcd = (n_regions + kXcds - 1) / kXcds;
   const dim3 grid((unsigned)(per_xcd * kXcds));
   const RasterArgs args{recs, bbs, pxtab, pytab, T, W, H, regions_x, per_image, n_regions, per_xcd,
-                        cell_ids, cell_count, cells_x, cells_per_image, ids, bary, z};
+                        cell_ids, cell_count, cell_split, cells_x, cells_per_image, ids, bary, z};
   {
     KernelTimer timer(MR_TIMER_RASTER_FORWARD, s);  // records only when a caller armed it
     if (edge == 32) launch_k_raster_probe<32>(args, grid, s);
