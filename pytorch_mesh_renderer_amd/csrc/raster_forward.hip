@@ -480,13 +480,20 @@ __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
   // list of words worth visiting (most of a tile's 256 mask bits are zero: ~3.6 candidates)
   static_assert(kMaskWords == 8, "lane & 7 == lx indexes the tile's mask words");
   const unsigned *lane_word = (const unsigned *)lane_px + 2 * R;  // &s_tmask[0][lx]
-  auto raster_pass = [&](auto fresh_tag, const int far_word) {
-    constexpr bool fresh = decltype(fresh_tag)::value;
-    for (int tile = wave; tile < kTiles; tile += kWaves) {
-      const int ty = tile / kTilesX, tx = tile % kTilesX;
-      const int x0 = X0 + tx * 8, y0 = Y0 + ty * 8;
-      if (x0 >= X1 || y0 >= Y1) continue;  // wave-uniform
-      const bool in_image = lx < W - x0 && ly < H - y0;
+  // `full`: the region lies wholly inside the image (all but the last column / row of regions of
+  // an image whose size is not a multiple of R): no per-tile or per-lane bounds tests at all.
+  auto raster_pass = [&](auto fresh_tag, auto full_tag, const int far_word) {
+    constexpr bool fresh = decltype(fresh_tag)::value, full = decltype(full_tag)::value;
+    const unsigned near_words = (1u << far_word) - 1u;  // far_word == kMaskWords: every word
+    // wavefront w walks tiles w, w + 4, ... of every tile row
+    for (int ty = 0; ty < kTilesX; ++ty) {
+    const int y0 = Y0 + ty * 8;
+    if (!full && y0 >= Y1) break;  // wave-uniform
+    for (int tx = wave; tx < kTilesX; tx += kWaves) {
+      const int tile = ty * kTilesX + tx;
+      const int x0 = X0 + tx * 8;
+      if (!full && x0 >= X1) continue;  // wave-uniform
+      const bool in_image = full || (lx < W - x0 && ly < H - y0);
       const int tile_pix = ty * 8 * W + tx * 8;  // wave-uniform, relative to the region
       const float px = lane_px[tx * 8];
       const float py = lane_py[ty * 8];
@@ -506,16 +513,13 @@ __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
         st.b1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_bary, lane_pix * 12u + 4u, tile_pix * 12, 0));
         st.b2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_bary, lane_pix * 12u + 8u, tile_pix * 12, 0));
       }
-      unsigned words = (unsigned)__ballot(my_word != 0u) & ((1u << kMaskWords) - 1u);
-      if (PROBE & 16) words = 0u;  // timing probe: no coverage, no depth
-      bool far_checked = false;
+      const unsigned all_words = (PROBE & 16) ? 0u  // timing probe: no coverage, no depth
+                                              : (unsigned)__ballot(my_word != 0u) & ((1u << kMaskWords) - 1u);
+      // near words first; the far ones only if some pixel of the tile could still be won by them
+      unsigned words = all_words & near_words, far_words = all_words & ~near_words;
+      for (;;) {
       while (words) {
         const int w = __builtin_ctz(words);
-        if (w >= far_word && !far_checked) {
-          // first word of the far class: done if no pixel of the tile could still be won
-          far_checked = true;
-          if (!__ballot(in_image && !(st.z < split))) break;
-        }
         words &= words - 1u;
         unsigned todo = (unsigned)__builtin_amdgcn_readlane((int)my_word, w);
         const int ebase = w * 32;
@@ -625,6 +629,10 @@ __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
           }
         }
       }
+      if (far_words == 0u || !__ballot(in_image && !(st.z < split))) break;
+      words = far_words;
+      far_words = 0u;
+      }
       if (in_image && !((PROBE & 32) && st.z != 123.0f)) {  // 32: timing probe, no stores
         __builtin_amdgcn_raw_buffer_store_b32((unsigned)max(st.id, 0), rs_ids, lane_pix * 4u, tile_pix * 4, 0);
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, st.z), rs_z, lane_pix * 4u, tile_pix * 4, 0);
@@ -637,6 +645,7 @@ __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
       // of the walk merge, which keeps the first round's loop free of vmcnt waits (its stores
       // then retire under the next tiles' arithmetic).
       if (!fresh) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    }
     }
   };
 
@@ -784,14 +793,17 @@ __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
     __syncthreads();
     // mask word that starts the far class (kMaskWords: no clean cut, the walk never skips)
     const int far_word = (ordered && n_far > 0 && (far_base & 31) == 0) ? far_base >> 5 : kMaskWords;
+    auto walk = [&]() {
+      if (!first_pass) raster_pass(std::false_type{}, std::false_type{}, far_word);
+      else if (X1 - X0 == R && Y1 - Y0 == R) raster_pass(std::true_type{}, std::true_type{}, far_word);
+      else raster_pass(std::true_type{}, std::false_type{}, far_word);
+    };
     if constexpr (PROBE == 0 || PROBE >= 8) {
       build_tile_masks(n_near, far_base, n_far);
-      if (first_pass) raster_pass(std::true_type{}, far_word);
-      else raster_pass(std::false_type{}, far_word);
+      walk();
     } else if constexpr (PROBE == 2) {
       build_tile_masks(0, 0, 0);   // timing probe: tile walk over an empty bin
-      if (first_pass) raster_pass(std::true_type{}, far_word);
-      else raster_pass(std::false_type{}, far_word);
+      walk();
     } else if constexpr (PROBE == 3) {
       build_tile_masks(n_near, far_base, n_far);  // timing probe: bin + tile masks, no walk
     }

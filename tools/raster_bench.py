@@ -17,6 +17,7 @@ ap.add_argument("--config", default="c3")
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--variant", type=int, default=0)
 ap.add_argument("--backward", action="store_true")
+ap.add_argument("--edge", type=int, default=0, help="force 32 / 64 pixel regions")
 args = ap.parse_args()
 B, W, H, K = {"c2": (8, 256, 256, 50), "c3": (32, 1024, 1024, 50), "c4": (8, 2048, 2048, 158),
               "c3s": (4, 1024, 1024, 50)}[args.config]
@@ -24,6 +25,7 @@ dev = torch.device("cuda:0")
 job = synthetic.sphere_job(B, W, H, K)
 clip, tris = job["clip"].to(dev), job["triangles"].to(dev)
 assert _native.lib().mr_debug_set_raster_probe(args.variant) == 0, "unknown probe (see include/mesh_raster_debug.h)"
+assert _native.lib().mr_debug_set_raster_region_edge(args.edge) == 0
 for _ in range(3):
     ids, bary, z = _native.rasterize_forward(clip, tris, W, H)
 torch.cuda.synchronize()
