@@ -15,7 +15,7 @@
 //            proves every pixel of the region fails that edge.  Survivors are copied,
 //            in triangle-id order, as 80-byte entries (adjugate, z, w, id, bbox) into
 //            an LDS bin; 80 B = 20 banks keeps per-lane ds_read_b128 conflict-free.
-//     tiles  each wavefront walks 8x8 pixel tiles, one pixel per lane.  Per tile:
+//     tiles  each wavefront walks 16x4-pixel tiles, one pixel per lane.  Per tile:
 //            (0) once per region, one thread per bin entry walks the tiles under the
 //                entry's bbox, applies the same exact trivial reject per tile and sets
 //                its bit in that tile's 256-bit LDS mask;
@@ -316,6 +316,9 @@ __device__ __forceinline__ bool rect_outside_triangle(const float4 q0, const flo
          (int)rect_outside_edge(q1.z, q1.w, m8, pxlo, pxhi, pylo, pyhi);
 }
 
+#ifndef MR_TILE_W
+#define MR_TILE_W 16  // pixels per tile row (tile = MR_TILE_W x 64 / MR_TILE_W), see k_raster
+#endif
 #ifndef MR_RASTER_WAVES
 #define MR_RASTER_WAVES 7  // register-allocation hint: yields 71 VGPRs (<= 72 = 7 waves per SIMD)
 #endif
@@ -364,8 +367,14 @@ __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
     int cells_per_image, int32_t *__restrict__ ids, float *__restrict__ bary,
     float *__restrict__ zbuf) {
   static_assert(R == 64 || R == 32, "region edge");
-  constexpr int kTilesX = R / 8;
-  constexpr int kTiles = kTilesX * kTilesX;  // 8x8-pixel tiles per region: 64 or 16
+  // A wavefront's tile is kTileW x kTileH pixels, one per lane.  16 x 4: every row of a tile's
+  // G-buffer stores is a whole, aligned 64-byte sector (16 ids / depths) or three of them (16
+  // barycentric triples); with 8 x 8 tiles two wavefronts shared each sector and the L2 had to
+  // merge their halves (measured: the kernel ran FASTER with fewer workgroups in flight).
+  constexpr int kTileW = MR_TILE_W, kTileH = kWave / kTileW;
+  static_assert(kTileW == 8 || kTileW == 16, "tile width");
+  constexpr int kTilesX = R / kTileW, kTilesY = R / kTileH;
+  constexpr int kTiles = kTilesX * kTilesY;  // tiles per region: 64 or 16
   constexpr int kMaskWords = kBin2Cap / 32;
   __shared__ __attribute__((aligned(16))) float s_ent[kBin2Cap * kEntryDw];
   // LDS budget at R = 64: 20480 (entries) + 2048 (masks / bin bookkeeping) + 512 (pixel centres)
@@ -423,13 +432,13 @@ __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
   if (tid < R) s_pxy[0][tid] = pxtab[min(X0 + tid, W - 1)];
   else if (tid < 2 * R) s_pxy[1][tid - R] = pytab[min(Y0 + tid - R, H - 1)];
 
-  // ---- stage 2a: which bin entries touch which 8x8 tile -------------------------------
+  // ---- stage 2a: which bin entries touch which tile ------------------------------------
   // One thread per bin entry walks the tiles under the entry's bbox and applies the exact
   // trivial reject against each; survivors set their bit in the tile's 256-bit mask.  This
   // costs ~(entries x tiles-per-entry) lane-tests per region instead of (tiles x entries).
   auto build_tile_masks = [&](const int n_near, const int far_base, const int n_far) {
     for (int i = tid; i < kSharedDw; i += kThreads) s_shared[i] = 0u;
-    // pixel-centre extents of tile column / row t: s_pxy[.][8 t] .. s_pxy[.][min(8 t + 7, last)]
+    // pixel-centre extents of tile column t: s_pxy[0][t kTileW] .. s_pxy[0][min(t kTileW + kTileW - 1, last)]
     const int last_x = X1 - 1 - X0, last_y = Y1 - 1 - Y0;
     __syncthreads();
     if (tid < n_near || (tid >= far_base && tid < far_base + n_far)) {
@@ -439,14 +448,15 @@ __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
       const float m8 = p[8];
       // tile range under the bbox (already clipped to the region; never empty)
       const int bl = (int)(box.x & 0xffffu), bb = (int)(box.x >> 16);
-      const int tx0 = bl >> 3, tx1 = (bl + (int)(box.y & 0xffffu)) >> 3;
-      const int ty0 = bb >> 3, ty1 = (bb + (int)(box.y >> 16)) >> 3;
+      const int tx0 = bl / kTileW, tx1 = (bl + (int)(box.y & 0xffffu)) / kTileW;
+      const int ty0 = bb / kTileH, ty1 = (bb + (int)(box.y >> 16)) / kTileH;
       const unsigned bit = 1u << (tid & 31);
       const int word = tid >> 5;
       for (int ty = ty0; ty <= ty1; ++ty) {
-        const float ylo = s_pxy[1][ty * 8], yhi = s_pxy[1][min(ty * 8 + 7, last_y)];
+        const float ylo = s_pxy[1][ty * kTileH], yhi = s_pxy[1][min(ty * kTileH + kTileH - 1, last_y)];
         for (int tx = tx0; tx <= tx1; ++tx) {
-          if (!rect_outside_triangle(q0, q1, m8, s_pxy[0][tx * 8], s_pxy[0][min(tx * 8 + 7, last_x)], ylo, yhi))
+          if (!rect_outside_triangle(q0, q1, m8, s_pxy[0][tx * kTileW],
+                                     s_pxy[0][min(tx * kTileW + kTileW - 1, last_x)], ylo, yhi))
             atomicOr(&s_tmask[ty * kTilesX + tx][word], bit);
         }
       }
@@ -455,13 +465,13 @@ __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
   };
 
   // ---- stage 2b: the tile walk --------------------------------------------------------
-  // Per-lane constants of the tile walk: lane (lx, ly) of an 8x8 tile.  The G-buffer is
+  // Per-lane constants of the tile walk: lane (lx, ly) of a tile.  The G-buffer is
   // addressed through three raw buffer descriptors anchored at this REGION's first pixel (scalar
   // registers, built once): a tile's accesses are then  descriptor + scalar tile offset +
   // 32-bit per-lane offset, and the tile loop spends no vector instructions on address
   // arithmetic (16.7 M of the kernel's 131.6 M VALU instructions per launch at 1024^2 x 32 were
   // tile-loop overhead).  Offsets stay below 64 rows x 65535 px x 12 B = 50 MB.
-  const int lx = lane & 7, ly = lane >> 3;
+  const int lx = lane % kTileW, ly = lane / kTileW;
   const unsigned lane_pix = (unsigned)(ly * W + lx);  // pixel offset inside a tile
   const unsigned lane_xy0 = (unsigned)lx | ((unsigned)ly << 16);
   const float *lane_px = &s_pxy[0][lx], *lane_py = &s_pxy[1][ly];
@@ -478,29 +488,31 @@ __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
   static_assert(kThreads % kWave == 0, "full wavefronts only");
   // lanes 0..7 fetch one of the tile's eight mask words each; a ballot of "non-zero" is then the
   // list of words worth visiting (most of a tile's 256 mask bits are zero: ~3.6 candidates)
-  static_assert(kMaskWords == 8, "lane & 7 == lx indexes the tile's mask words");
+  // (lanes 8.. of a 16-wide tile fetch words of the next tiles -- the last tile's reach a few
+  // dwords past the masks, never past the workgroup's LDS -- and are masked out of the ballot)
+  static_assert(kMaskWords == 8 && kTileW >= 8, "lx == lane for lanes 0..7: it indexes the tile's mask words");
   const unsigned *lane_word = (const unsigned *)lane_px + 2 * R;  // &s_tmask[0][lx]
   // `full`: the region lies wholly inside the image (all but the last column / row of regions of
   // an image whose size is not a multiple of R): no per-tile or per-lane bounds tests at all.
   auto raster_pass = [&](auto fresh_tag, auto full_tag, const int far_word) {
     constexpr bool fresh = decltype(fresh_tag)::value, full = decltype(full_tag)::value;
     const unsigned near_words = (1u << far_word) - 1u;  // far_word == kMaskWords: every word
-    // wavefront w walks tiles w, w + 4, ... of every tile row
-    for (int ty = 0; ty < kTilesX; ++ty) {
-    const int y0 = Y0 + ty * 8;
-    if (!full && y0 >= Y1) break;  // wave-uniform
-    for (int tx = wave; tx < kTilesX; tx += kWaves) {
-      const int tile = ty * kTilesX + tx;
-      const int x0 = X0 + tx * 8;
-      if (!full && x0 >= X1) continue;  // wave-uniform
+    // wavefront w walks tiles w, w + 4, ... (row-major tile numbering).  (Walking pairs of
+    // horizontally adjacent tiles back to back, so that both halves of a 128-byte line come from
+    // one wavefront, was measured: no difference.)
+    {
+    for (int tile = wave; tile < kTiles; tile += kWaves) {
+      const int ty = tile / kTilesX, tx = tile % kTilesX;
+      const int x0 = X0 + tx * kTileW, y0 = Y0 + ty * kTileH;
+      if (!full && (x0 >= X1 || y0 >= Y1)) continue;  // wave-uniform
       const bool in_image = full || (lx < W - x0 && ly < H - y0);
-      const int tile_pix = ty * 8 * W + tx * 8;  // wave-uniform, relative to the region
-      const float px = lane_px[tx * 8];
-      const float py = lane_py[ty * 8];
+      const int tile_pix = ty * kTileH * W + tx * kTileW;  // wave-uniform, relative to the region
+      const float px = lane_px[tx * kTileW];
+      const float py = lane_py[ty * kTileH];
       const unsigned my_word = lane_word[tile * kMaskWords];
       const v2f px2 = {px, px}, py2 = {py, py};
       // region-relative pixel coordinates of this lane, packed (x | y << 16)
-      const unsigned lane_xy = lane_xy0 + ((unsigned)(tx * 8) | ((unsigned)(ty * 8) << 16));
+      const unsigned lane_xy = lane_xy0 + ((unsigned)(tx * kTileW) | ((unsigned)(ty * kTileH) << 16));
       PixelState st;
       unsigned long long pass_mask, pass_mask2;  // scratch of the depth loop's compares
       if (fresh) {

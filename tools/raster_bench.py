@@ -14,7 +14,7 @@ from pytorch_mesh_renderer_amd.common import synthetic
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--config", default="c3")
-ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--iters", type=int, default=40)
 ap.add_argument("--variant", type=int, default=0)
 ap.add_argument("--backward", action="store_true")
 ap.add_argument("--edge", type=int, default=0, help="force 32 / 64 pixel regions")
