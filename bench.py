@@ -1,31 +1,45 @@
 """Headline benchmark: Mpixels/s forward+backward, 5k-tri mesh, 1024x1024, batch 32.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c4] [--handover u8|f32]
 
-One "step" = one pass of the hot path over one batch of synthetic render jobs
-(BASELINE.json configs[2]): mesh_renderer.render() forward (clip
-transform, G-buffer rasterization, attribute interpolation, Phong shading), the L1
-image loss mean|image - target| against a fixed target, and backward to the world-space vertex
-positions.  All inputs are resident in HBM before the timed region starts.  With N
-ranks every rank renders its own 32 jobs (weak scaling; no data-path collective) and
-the finished images are handed over to rank 0 as 8-bit frames (mesh_renderer.to_uint8: the
-conversion the reference's examples apply before writing a frame) with one RCCL gather per
-step that overlaps the loss, the backward and the next forward.  Rank 0 prints ONE JSON line.
+With --gpus N > 1 and no WORLD_SIZE in the environment this process only LAUNCHES the N ranks
+(`python -m torch.distributed.run`, fresh children, before anything here has touched a GPU), relays
+rank 0's JSON line and exits with the children's status; under an external torchrun
+(`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`) it is a rank.
+
+One "step" = one pass of the hot path over one batch of synthetic render jobs:
+mesh_renderer.render() forward (clip transform, G-buffer rasterization, attribute interpolation,
+Phong shading), the L1 image loss mean|image - target| against a fixed target, and backward to the
+world-space vertex positions.  All inputs are resident in HBM before the timed region starts.
+
+  --config c3 (default)  BASELINE.json configs[2]: 5k-tri sphere, 1024x1024, 32 images per GPU
+  --config c4            BASELINE.json configs[3]: 50k-tri sphere, 2048x2048, 8 images per GPU
+                         (batch 64 over 8 GPUs)
+
+With N ranks every rank renders its own batch (weak scaling; no data-path collective) and the
+finished images are handed over to rank 0 with one RCCL gather per step that overlaps the loss, the
+backward and the next forward: as 8-bit frames (--handover u8, default: mesh_renderer.to_uint8,
+the conversion the reference's examples apply before writing a frame) or as the fp32 images
+(--handover f32, 4x the bytes).
 
 Extra objects in the line:
-  roofline      the forward G-buffer kernel (k_raster): algorithmic bytes per launch
-                (20 B/px written + clip and triangle reads) / its average duration,
-                measured with HIP events recorded around that kernel on its stream.
-  cpu_baseline  the same step on the host cores for a bounded sample of the batch:
-                torch-CPU eager restatement of the reference's render path
-                (oracle/shading.py) over the reference's own compiled C++ kernel
-                (oracle/_ref) when present, else over oracle/mr_oracle.c.
+  roofline                 the forward G-buffer kernel (k_raster): algorithmic bytes per launch
+                           (20 B/px written + clip and triangle reads) / its average duration,
+                           measured with HIP events recorded around that kernel on its stream.
+  roofline_shade_backward  same for the pixel pass of the fused shading backward, the kernel that
+                           takes the largest share of the step (32 B/px read).
+  cpu_baseline             the same step on the host cores for a bounded sample of the batch (torch-CPU
+                           eager restatement of the reference's render path, oracle/shading.py, over the
+                           reference's own compiled C++ kernel oracle/_ref when present), plus the
+                           kernel-level figures of SURVEY.md 8(d): the C restatement of the
+                           rasterizer forward / backward with 1 thread and with all host threads.
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -38,17 +52,45 @@ if ROOT not in sys.path:
 from pytorch_mesh_renderer_amd import _native, distributed, mesh_renderer  # noqa: E402
 from pytorch_mesh_renderer_amd.common import synthetic  # noqa: E402
 
-BATCH, WIDTH, HEIGHT, SPHERE_K = 32, 1024, 1024, 50   # BASELINE.json configs[2]
+CONFIGS = {
+    # key: (BASELINE.json entry, images per GPU, width, height, sphere resolution K)
+    "c3": ("configs[2]", 32, 1024, 1024, 50),
+    "c4": ("configs[3]", 8, 2048, 2048, 158),
+}
 HBM_PEAK_GBPS = 8000.0                                # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
 
-class HipEvents:
-    """Raw hipEvent pairs (torch.cuda.Event only sees torch's bookkeeping)."""
+def spawn_ranks(args):
+    """Parent of a self-launched multi-GPU run: starts the ranks as fresh child processes and relays
+    rank 0's line.  Nothing in this process has initialised a GPU (importing torch does not)."""
+    with socket.socket() as s:                         # a free rendezvous port
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes)
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out_line in proc.stdout.splitlines():
+        if out_line.startswith("{") and '"metric"' in out_line:
+            line = out_line
+        else:
+            print(out_line, file=sys.stderr)
+    if proc.returncode != 0 or line is None:
+        raise SystemExit(proc.returncode or 1)
+    print(line, flush=True)
 
-    def __init__(self, n):
+
+class KernelEvents:
+    """Raw hipEvent pairs around single kernels (torch.cuda.Event only sees torch's bookkeeping):
+    armed through the library's one-shot, thread-local mr_time_next_kernel."""
+
+    def __init__(self, n, which):
         self.hip = ctypes.CDLL("libamdhip64.so")
         self.hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p,
                                                  ctypes.c_void_p]
+        self.which = which
         self.pairs = []
         for _ in range(n):
             a, b = ctypes.c_void_p(), ctypes.c_void_p()
@@ -57,23 +99,22 @@ class HipEvents:
             self.pairs.append((a, b))
 
     def arm(self, i):
-        a, b = self.pairs[i]
-        _native.lib().mr_time_next_kernel(_native.TIMER_RASTER_FORWARD, a, b)
+        a, b = self.pairs[i % len(self.pairs)]
+        _native.time_next_kernel(self.which, a, b)
 
-    @staticmethod
-    def disarm():
-        _native.lib().mr_time_next_kernel(_native.TIMER_RASTER_FORWARD, None, None)
-
-    def elapsed_ms(self):
+    def mean_ms(self, used):
         out = []
-        for a, b in self.pairs:
+        for a, b in self.pairs[:used]:
             ms = ctypes.c_float()
             if self.hip.hipEventElapsedTime(ctypes.byref(ms), a, b) == 0:
                 out.append(ms.value)
-        return out
+        return sum(out) / len(out) if out else 0.0
 
 
-def make_step(job, device, gather):
+def make_step(job, device, gather, handover="u8"):
+    """Returns (step, vertices, state): state["image"] / state["target"] hold the last rendered
+    batch and the fixed target (the full-size parity test checks them against the oracle)."""
+    width, height = job["width"], job["height"]
     tri = job["triangles"].to(device)
     vertices = job["vertices"].to(device).requires_grad_(True)
     normals, diffuse = job["normals"].to(device), job["diffuse"].to(device)
@@ -81,10 +122,11 @@ def make_step(job, device, gather):
     center = torch.zeros_like(eyes)
     up = torch.tensor([0.0, 1.0, 0.0])
     lpos, lint = job["light_positions"].to(device), job["light_intensities"].to(device)
+    transform = mesh_renderer.to_uint8 if handover == "u8" else None
 
     def forward():
         return mesh_renderer.render(vertices, tri, normals, diffuse, eyes, center, up, lpos, lint,
-                                    WIDTH, HEIGHT)
+                                    width, height)
 
     # fixed target: the same scene with the mesh slightly rotated (mirrors the reference's
     # optimisation tests), rendered once outside the timed region
@@ -92,78 +134,132 @@ def make_step(job, device, gather):
         c, s = torch.cos(torch.tensor(0.2)), torch.sin(torch.tensor(0.2))
         rot = torch.tensor([[c, 0.0, s], [0.0, 1.0, 0.0], [-s, 0.0, c]], device=device)
         target = mesh_renderer.render(vertices @ rot.T, tri, normals @ rot.T, diffuse, eyes, center, up,
-                                      lpos, lint, WIDTH, HEIGHT)
+                                      lpos, lint, width, height)
+    state = {"target": target, "image": None}
 
     def step():
         vertices.grad = None
         image = forward()
+        state["image"] = image
         if gather is not None:
             gather.wait()                # the previous step's hand-over (no-op the first time) ...
-            # ... then this one: 8-bit frames (what the reference's examples write out); conversion
-            # and transfer both run on the side stream, overlapping the loss, the backward and the
-            # next step's forward
-            gather.start(image, transform=mesh_renderer.to_uint8)
+            # ... then this one; conversion (u8) and transfer both run on the side stream,
+            # overlapping the loss, the backward and the next step's forward
+            gather.start(image, transform=transform)
         loss = mesh_renderer.losses.l1_loss(image, target)   # mean |image - target|, one HIP pass each way
         loss.backward()
         return loss
 
-    return step, vertices
+    return step, vertices, state
 
 
-def cpu_baseline(sample_images):
-    """The same step (render fwd + L1 + bwd to vertices) on host cores, bounded sample."""
+def cpu_baseline(batch, width, height, sphere_k, sample_images):
+    """The same step (render fwd + L1 + bwd to vertices) on host cores for a bounded sample, and the
+    kernel-level rasterizer figures (C restatement, 1 thread and all threads)."""
+    import numpy as np
     import oracle
     from oracle import shading
     use_ref = oracle.have_reference_kernel()
-    job = synthetic.sphere_job(BATCH, WIDTH, HEIGHT, SPHERE_K)
+    job = synthetic.sphere_job(batch, width, height, sphere_k)
+    sample_images = min(sample_images, batch)
     sl = slice(0, sample_images)
     v = job["vertices"][sl].clone().requires_grad_(True)
     args = (job["triangles"], job["normals"][sl], job["diffuse"][sl], job["eyes"][sl],
             torch.zeros(sample_images, 3), torch.tensor([[0.0, 1.0, 0.0]]).repeat(sample_images, 1),
-            job["light_positions"][sl], job["light_intensities"][sl], WIDTH, HEIGHT)
-    target = torch.zeros(sample_images, HEIGHT, WIDTH, 4)
+            job["light_positions"][sl], job["light_intensities"][sl], width, height)
+    # the GPU step's target is the render of the rotated mesh; on the host it only has to be SOME
+    # fixed image of the same shape (the cost of |img - target| does not depend on its values)
+    target = torch.rand(sample_images, height, width, 4, generator=torch.Generator().manual_seed(0))
     t0 = time.perf_counter()
     img = shading.render(v, *args, use_reference_kernel=use_ref)
     torch.mean(torch.abs(img - target)).backward()
     dt = time.perf_counter() - t0
+
+    # kernel level (SURVEY.md 8d): the C restatement of the rasterizer alone
+    clip, tris = job["clip"].numpy(), job["triangles"].numpy()
+    threads = oracle.max_threads()
+    n_par = min(batch, max(threads, 1))
+    rng = np.random.default_rng(0)
+
+    def timed(fn):
+        t = time.perf_counter()
+        out = fn()
+        return out, time.perf_counter() - t
+
+    (ids1, bary1, _), f1 = timed(lambda: oracle.forward(clip[:1], tris, width, height, threads=1))
+    g1 = (rng.standard_normal(bary1.shape) / (width * height)).astype(np.float32)
+    _, b1 = timed(lambda: oracle.backward(g1, clip[:1], tris, ids1, bary1, threads=1))
+    (idsn, baryn, _), fn_ = timed(lambda: oracle.forward(clip[:n_par], tris, width, height, threads=threads))
+    gn = np.repeat(g1, n_par, 0)
+    _, bn = timed(lambda: oracle.backward(gn, clip[:n_par], tris, idsn, baryn, threads=threads))
+    px = width * height
     return {
-        "value": round(sample_images * WIDTH * HEIGHT / dt / 1e6, 4), "unit": "Mpixels/s",
+        "value": round(sample_images * px / dt / 1e6, 4), "unit": "Mpixels/s",
         "cores": torch.get_num_threads(), "kind": "port",
-        "sample": "%d of the %d images of the workload, render fwd+bwd, %.1f s; eager torch-CPU "
+        "sample": "%d of the %d images of the workload, render fwd + L1 + bwd, %.1f s; eager torch-CPU "
                   "restatement of the reference's render path over %s" % (
-                      sample_images, BATCH, dt,
-                      "the reference's compiled C++ kernel (oracle/_ref)" if use_ref
-                      else "oracle/mr_oracle.c"),
+                      sample_images, batch, dt,
+                      "the reference's compiled C++ kernel (oracle/_ref)" if use_ref else "oracle/mr_oracle.c"),
+        "kernel_level": {
+            "what": "oracle/mr_oracle.c (C restatement of rasterize_triangles.cpp), rasterizer forward + "
+                    "backward only, Mpixels/s = pixels / (t_fwd + t_bwd)",
+            "threads_1": {"images": 1, "forward_ms": round(f1 * 1e3, 1), "backward_ms": round(b1 * 1e3, 1),
+                          "value": round(px / (f1 + b1) / 1e6, 3)},
+            "threads_max": {"threads": threads, "images": n_par, "forward_ms": round(fn_ * 1e3, 1),
+                            "backward_ms": round(bn * 1e3, 1),
+                            "value": round(n_par * px / (fn_ + bn) / 1e6, 3)},
+        },
     }
+
+
+def roofline(kernel, algorithmic, avg_ms, traffic_key):
+    achieved = algorithmic / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    out = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+           "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+           "algorithmic_bytes": algorithmic, "avg_kernel_ms": round(avg_ms, 4)}
+    pmc_path = os.path.join(ROOT, "profiles", "kernel_traffic.json")
+    if os.path.exists(pmc_path):   # written from separate rocprofv3 --pmc passes over this command
+        pmc = json.load(open(pmc_path))
+        if traffic_key in pmc.get("kernels", {}):
+            out["traffic"] = pmc["kernels"][traffic_key]["bytes_per_launch"]
+            out["traffic_source"] = ("profiles/kernel_traffic.json: rocprofv3 --pmc passes over `%s` at %s, NOT "
+                                     "this run" % (pmc.get("command", "bench.py"), pmc.get("tag", "?")))
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c3")
+    ap.add_argument("--handover", choices=("u8", "f32"), default="u8",
+                    help="what the ranks hand over to rank 0 when --gpus > 1")
     ap.add_argument("--cpu-sample", type=int, default=12, help="images timed for cpu_baseline (0 = skip)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args)          # before any GPU call: the ranks are fresh processes
+
     rank, world, local_rank = distributed.init_from_env()
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     # one GPU per rank; the modulo only matters for a gloo rehearsal of N ranks on fewer GPUs
     device = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(device)
 
-    job = synthetic.sphere_job(BATCH, WIDTH, HEIGHT, SPHERE_K)
-    if world > 1:  # every rank renders its own BATCH jobs: rotate the orbit per rank
-        shift = (rank * 7) % BATCH
+    entry, batch, width, height, sphere_k = CONFIGS[args.config]
+    job = synthetic.sphere_job(batch, width, height, sphere_k)
+    if world > 1:  # every rank renders its own `batch` jobs: rotate the orbit per rank
+        shift = (rank * 7) % batch
         job = {k: (torch.roll(v, shift, 0) if torch.is_tensor(v) and k != "triangles" else v)
                for k, v in job.items()}
     # images are handed over to rank 0 (RCCL gather): the root receives its N-1 shards over N-1
     # xGMI links at once; an all-gather would move N times the bytes for nothing
-    gather = distributed.ImageGather(BATCH * world, mode="root") if world > 1 else None
-    # ImageGather shards n_total evenly: each rank contributes exactly BATCH images
-    step, vertices = make_step(job, device, gather)
+    gather = distributed.ImageGather(batch * world, mode="root") if world > 1 else None
+    step, vertices, _ = make_step(job, device, gather, args.handover)
 
     def barrier():
         if world > 1:
@@ -172,17 +268,20 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    events = HipEvents(args.steps)
+    n_ev = min(args.steps, 64)             # kernel timers on the first n_ev timed steps
+    ev_raster = KernelEvents(n_ev, _native.TIMER_RASTER_FORWARD)
+    ev_shade = KernelEvents(n_ev, _native.TIMER_SHADE_BACKWARD)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        events.arm(i)
+        if i < n_ev:
+            ev_raster.arm(i)
+            ev_shade.arm(i)
         step()
     if gather is not None:
         gather.wait()                    # the last step's hand-over belongs to the timed region
     barrier()
     elapsed = time.perf_counter() - t0
-    events.disarm()
 
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -191,32 +290,29 @@ def main():
     assert vertices.grad is not None and bool(torch.isfinite(vertices.grad).all())
 
     if rank == 0:
-        raster_ms = events.elapsed_ms()
         V, T = job["vertices"].shape[1], job["triangles"].shape[0]
-        algorithmic = BATCH * WIDTH * HEIGHT * 20 + BATCH * V * 16 + T * 12   # bytes per launch
-        avg_ms = sum(raster_ms) / max(len(raster_ms), 1)
-        achieved = algorithmic / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "raster_traffic.json")
-        if os.path.exists(pmc_path):   # written from a separate rocprofv3 --pmc run of this command
-            traffic = json.load(open(pmc_path)).get("bytes_per_launch")
+        px = batch * width * height
         line = {
-            "metric": "Mpixels/sec forward+backward, 1024x1024 batch=32",
-            "value": round(world * BATCH * WIDTH * HEIGHT * args.steps / elapsed / 1e6, 2),
+            "metric": "Mpixels/sec forward+backward, %dx%d batch=%d" % (width, height, batch),
+            "value": round(world * px * args.steps / elapsed / 1e6, 2),
             "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[2]: 5k-tri UV sphere (V=%d, T=%d), %dx%d, batch=%d per GPU, "
+            "config": {"workload": "%s: %dk-tri UV sphere (V=%d, T=%d), %dx%d, batch=%d per GPU, "
                                    "mesh_renderer.render forward + L1 loss + backward to vertex positions; "
-                                   "8-bit frames gathered to rank 0 over RCCL when n_gpus>1" % (V, T, WIDTH, HEIGHT, BATCH),
-                       "global_batch": BATCH * world, "image": [HEIGHT, WIDTH], "triangles": T},
-            "roofline": {"bound": "hbm", "kernel": "k_raster (forward G-buffer write)",
-                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                         "algorithmic_bytes": algorithmic, "avg_kernel_ms": round(avg_ms, 4)},
+                                   "%s frames gathered to rank 0 over RCCL when n_gpus>1" % (
+                                       entry, round(T / 1000), V, T, width, height, batch,
+                                       "8-bit" if args.handover == "u8" else "fp32"),
+                       "global_batch": batch * world, "image": [height, width], "triangles": T,
+                       "handover": args.handover},
+            "roofline": roofline("k_raster (forward G-buffer write)", px * 20 + batch * V * 16 + T * 12,
+                                 ev_raster.mean_ms(n_ev), "k_raster"),
+            "roofline_shade_backward": roofline(
+                "k_accumulate_rows<ShadeGradFn> (fused shading backward, pixel pass)",
+                px * 32 + batch * T * (128 + 64), ev_shade.mean_ms(n_ev), "shade_backward"),
         }
         if world == 1 and args.cpu_sample > 0:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_sample)
+            line["cpu_baseline"] = cpu_baseline(batch, width, height, sphere_k, args.cpu_sample)
         print(json.dumps(line), flush=True)
 
     if world > 1:

@@ -24,6 +24,22 @@ _ERR = {MR_EINVAL: "invalid argument", MR_EWORKSPACE: "workspace too small or mi
 
 _lib = None
 _workspaces = {}
+_pending_timers = {}
+
+
+def time_next_kernel(which, start_event, stop_event):
+    """Measurement (bench.py): HIP events (ctypes.c_void_p) to record around the NEXT launch of
+    kernel `which` (TIMER_*) made through this module, from whatever thread makes it -- autograd runs
+    backward passes on its own thread, and the library's one-shot timers are per thread, so the pair
+    is handed to mr_time_next_kernel by the launching wrapper itself."""
+    _pending_timers[which] = (start_event, stop_event)
+
+
+def _arm_timer(which):
+    pair = _pending_timers.pop(which, None)
+    if pair is not None:
+        lib().mr_time_next_kernel(which, pair[0], pair[1])
+
 
 
 class NativeLibraryError(RuntimeError):
@@ -176,6 +192,7 @@ def rasterize_forward(clip, triangles, width, height):
     with torch.cuda.device(dev):
         need = L.mr_rasterize_forward_workspace_bytes(B, V, T, width, height)
         ws, have = _workspace(dev, need)
+        _arm_timer(TIMER_RASTER_FORWARD)
         rc = L.mr_rasterize_forward(_ptr(clip), _ptr(triangles), B, V, T, width, height,
                                     _ptr(ids), _ptr(bary), _ptr(z), _ptr(ws), have, _stream(dev))
     _check(rc, "mr_rasterize_forward")
@@ -195,6 +212,7 @@ def rasterize_backward(dbary, clip, triangles, ids, bary):
     with torch.cuda.device(dev):
         need = L.mr_rasterize_backward_workspace_bytes(B, V, T, W, H)
         ws, have = _workspace(dev, need)
+        _arm_timer(TIMER_RASTER_BACKWARD)
         rc = L.mr_rasterize_backward(_ptr(dbary), _ptr(clip), _ptr(triangles), _ptr(ids),
                                      _ptr(bary), B, V, T, W, H, _ptr(dclip), _ptr(ws), have,
                                      _stream(dev))
@@ -270,6 +288,7 @@ def shade_forward(ids, bary, normals, positions, diffuse, triangles, light_posit
             ws, have = _aligned_bytes(need, dev), need
         else:
             ws, have = _workspace(dev, need)
+        _arm_timer(TIMER_SHADE_FORWARD)
         rc = L.mr_shade_forward(_ptr(ids), _ptr(bary), _ptr(normals), _ptr(positions), _ptr(diffuse),
                                 _ptr(triangles), _ptr(light_positions), _ptr(light_intensities),
                                 _ptr(ambient), B, V, T, W, H, nl, _ptr(rgba), _ptr(ws), have,
@@ -373,6 +392,7 @@ def shade_backward(drgba, ids, bary, clip, normals, positions, diffuse, triangle
     with torch.cuda.device(dev):
         need = L.mr_shade_backward_workspace_bytes(B, V, T, W, H)
         ws, have = _workspace(dev, need)
+        _arm_timer(TIMER_SHADE_BACKWARD)
         rc = L.mr_shade_backward(_ptr(drgba), _ptr(ids), _ptr(bary), _ptr(clip), _ptr(normals),
                                  _ptr(positions), _ptr(diffuse), _ptr(triangles),
                                  _ptr(light_positions), _ptr(light_intensities), _ptr(ambient),

@@ -166,7 +166,10 @@ int launch_raster_backward(const float *dbary, const float *clip, const int32_t 
   int rc = launch_bwd_setup(clip, tris, B, V, T, recs, s);
   if (rc != MR_OK) return rc;
   RasterGradFn fn{(const F3 *)dbary, ids, (const F3 *)bary, recs, T};
-  rc = launch_accumulate_runs(fn, B, T, W, H, acc, s);
+  {
+    KernelTimer timer(MR_TIMER_RASTER_BACKWARD, s);
+    rc = launch_accumulate_runs(fn, B, T, W, H, acc, s);
+  }
   if (rc != MR_OK) return rc;
   const long nbt = (long)B * T;
   hipLaunchKernelGGL(k_bwd_scatter, dim3((unsigned)((nbt + kThreads - 1) / kThreads)), dim3(kThreads),

@@ -461,9 +461,12 @@ int launch_shade_forward(const int32_t *ids, const float *bary, const float *nor
   if (rc != MR_OK) return rc;
   Lights lights{light_pos, light_col, ambient, L};
   const int x_blocks = (W + kThreads - 1) / kThreads, y_blocks = (H + kShadeRows - 1) / kShadeRows;
-  hipLaunchKernelGGL(k_shade_forward, dim3((unsigned)(x_blocks * y_blocks * B)), dim3(kThreads), 0, s,
-                     ids, (const F3 *)bary, corners, lights, B, T, W, H, x_blocks, y_blocks,
-                     (float4 *)rgba);
+  {
+    KernelTimer timer(MR_TIMER_SHADE_FORWARD, s);
+    hipLaunchKernelGGL(k_shade_forward, dim3((unsigned)(x_blocks * y_blocks * B)), dim3(kThreads), 0, s,
+                       ids, (const F3 *)bary, corners, lights, B, T, W, H, x_blocks, y_blocks,
+                       (float4 *)rgba);
+  }
   return check_launch();
 }
 
@@ -516,6 +519,7 @@ int launch_shade_backward(const float *drgba, const int32_t *ids, const float *b
   {                                                                                             \
     ShadeGradFn<NL> fn{(const float4 *)drgba, ids, (const F3 *)bary, corners, recs, lights,     \
                        light_grads, T, W, H};                                                   \
+    KernelTimer timer(MR_TIMER_SHADE_BACKWARD, s);                                              \
     rc = launch_accumulate_rows(fn, B, T, W, H, acc, s);                                        \
   }
   switch (L) {

@@ -147,6 +147,9 @@ class ImageGather:
             torch.cuda.current_stream().wait_stream(self._side)
         if self._out is None:              # mode "root" on a non-root rank
             return None
+        if self._out.is_cuda:
+            # allocated on the side stream, consumed on the caller's: tell the caching allocator
+            self._out.record_stream(torch.cuda.current_stream(self._out.device))
         if all(c == self._max_count for c in self.counts):
             return self._out
         pieces = [self._out[r * self._max_count: r * self._max_count + c]

@@ -101,3 +101,21 @@ def test_shard_bounds_cover_and_balance():
 def test_single_process_gather_is_identity():
     x = torch.arange(24.0).reshape(2, 3, 4, 1)
     assert torch.equal(distributed.gather_images(x, 2), x)
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no WORLD_SIZE must start the two ranks itself (fresh children
+    under torch.distributed.run) and propagate their status.  Here there is no GPU: both ranks come up,
+    find no MI355X, refuse to fall back, and the parent exits non-zero with their message."""
+    import subprocess
+    import sys
+    if torch.cuda.is_available():
+        pytest.skip("the no-GPU behaviour is what this test pins")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    proc = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1",
+                           "--warmup", "0", "--cpu-sample", "0"], env=env, capture_output=True, text=True,
+                          timeout=300)
+    assert proc.returncode != 0
+    assert "needs an MI355X" in proc.stderr
+    assert '"metric"' not in proc.stdout

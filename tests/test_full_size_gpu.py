@@ -1,0 +1,185 @@
+"""GPU parity at the BASELINE configurations' REAL sizes.
+
+The smaller parity tests pin the arithmetic; these pin the code paths that only go live at
+size -- saturated LDS tables, 32-image grids, XCD remapping with padding blocks, 64 coarse cells,
+~1000-entry cell lists -- by comparing single images of the full-size launches with the CPU oracle
+(oracle/mr_oracle.c bit for bit, oracle/shading.py and oracle/soft.py within the north_star
+tolerance of 1e-4 abs, plus a relative bound where 1e-4 would be vacuous)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import ROOT, seeded_dbary
+from oracle import shading
+from oracle import soft as oracle_soft
+from pytorch_mesh_renderer_amd import _native, mesh_renderer, soft_mesh_renderer
+from pytorch_mesh_renderer_amd.common import camera_utils, synthetic
+
+pytestmark = pytest.mark.gpu
+ATOL = 1e-4  # north_star: shaded RGBA and gradients within 1e-4 abs
+
+
+def assert_close_abs_and_rel(got, want, what, rel=2e-3):
+    """1e-4 abs (the bar) AND |delta| <= rel * max|want|: gradients of a mean over 10^8 elements are
+    ~1e-8, so the absolute bar alone would pass anything."""
+    got, want = np.asarray(got), np.asarray(want)
+    assert np.isfinite(got).all(), what
+    scale = float(np.abs(want).max())
+    assert scale > 0, what + ": oracle gradient is identically zero"
+    err = float(np.abs(got - want).max())
+    assert err <= ATOL, "%s: max|d| = %.3e" % (what, err)
+    assert err <= rel * scale, "%s: max|d| = %.3e vs max|want| = %.3e" % (what, err, scale)
+
+
+def device_clip_bits(job, device):
+    """The clip-space vertices exactly as render() forms them on the device (render.py's
+    _render_fused: host-side camera matrices, one baddbmm on the device), back on the host."""
+    b = job["vertices"].shape[0]
+    full = lambda v: torch.full((b,), float(v))
+    transforms = camera_utils.clip_space_transforms(
+        job["eyes"], torch.zeros(b, 3), torch.tensor([[0.0, 1.0, 0.0]]).repeat(b, 1), full(40.0), full(0.01),
+        full(10.0), job["width"] / job["height"], device)
+    return camera_utils.transform_homogeneous(transforms, job["vertices"].to(device)).cpu()
+
+
+def oracle_step_for_image(job, b, upstream_b, clip_bits):
+    """oracle/shading.py render of image b, then backward of the loss's gradient image to that
+    image's vertices; the rasterizer sees the device's clip-space bits.  upstream_b is
+    d mean|img - target| / d img = sign(img - target) / N formed from the DEVICE's image: the sphere
+    is rotation-symmetric, so image and (rotated-mesh) target differ by tessellation noise only and a
+    pixel whose difference is below fp32 resolution would otherwise flip its sign -- and its whole
+    gradient contribution -- between the two sides."""
+    one = lambda t: t[b:b + 1].clone()
+    v = one(job["vertices"]).requires_grad_(True)
+    w, h = job["width"], job["height"]
+    img = shading.render(v, job["triangles"], one(job["normals"]), one(job["diffuse"]), one(job["eyes"]),
+                         torch.zeros(1, 3), torch.tensor([[0.0, 1.0, 0.0]]), one(job["light_positions"]),
+                         one(job["light_intensities"]), w, h,
+                         use_reference_kernel=False, clip_bits=clip_bits[b:b + 1])
+    img.backward(gradient=upstream_b)
+    return img.detach().numpy()[0], v.grad.numpy()[0]
+
+
+def test_bench_step_configs2_full_size(device):
+    """The EXACT step bench.py times (configs[2]: 5k tris, 1024x1024, batch 32; fused render forward +
+    L1 loss + backward): images 5 and 21 and their vertex gradients against the oracle."""
+    sys.path.insert(0, ROOT)
+    import bench
+    _, batch, width, height, k = bench.CONFIGS["c3"]
+    assert (batch, width, height) == (32, 1024, 1024)
+    job = synthetic.sphere_job(batch, width, height, k)
+    step, vertices, state = bench.make_step(job, device, None)
+    loss = step()
+    image = state["image"].detach()
+    assert image.shape == (32, 1024, 1024, 4) and bool(torch.isfinite(loss))
+    grad = vertices.grad.detach().cpu().numpy()
+    n_loss = image.numel()
+    clip_bits = device_clip_bits(job, device)
+    for b in (5, 21):
+        upstream_b = (torch.sign(image[b:b + 1] - state["target"][b:b + 1]) / n_loss).cpu()
+        want_img, want_grad = oracle_step_for_image(job, b, upstream_b, clip_bits)
+        got_img = image[b].cpu().numpy()
+        np.testing.assert_array_equal(got_img[..., 3], want_img[..., 3])      # coverage mask: exact
+        np.testing.assert_allclose(got_img, want_img, atol=ATOL, rtol=0)
+        assert_close_abs_and_rel(grad[b], want_grad, "d loss / d vertices[%d]" % b)
+    # every image took part: no all-zero gradient rows, loss equals the mean of the per-image means
+    assert (np.abs(grad).reshape(32, -1).max(1) > 0).all()
+    per_image = torch.abs(image - state["target"]).mean(dim=(1, 2, 3))
+    assert abs(float(per_image.mean()) - float(loss)) < 1e-6
+
+
+def test_config4_shape_backward_and_render(device):
+    """configs[3] per-GPU share: 50k-tri sphere (K=158), 2048x2048, 8 images.  Rasterizer forward for
+    the batch (image 6 bit-exact vs the oracle), rasterizer backward for all 8 images vs the oracle,
+    render() forward + backward with image 3 vs oracle/shading.py."""
+    B, W, H, K = 8, 2048, 2048, 158
+    job = synthetic.sphere_job(B, W, H, K)
+    assert job["triangles"].shape[0] == 49928
+    clip, tris = job["clip"], job["triangles"]
+    clip_d, tris_d = clip.to(device), tris.to(device)
+    ids, bary, z = _native.rasterize_forward(clip_d, tris_d, W, H)
+    o_ids, o_bary, o_z = oracle.forward(clip[6].numpy(), tris.numpy(), W, H)
+    assert ids[6].cpu().numpy().tobytes() == o_ids.tobytes()
+    assert bary[6].cpu().numpy().tobytes() == o_bary.tobytes()
+    assert z[6].cpu().numpy().tobytes() == o_z.tobytes()
+    covered = bary.sum(-1) > 0.5
+    assert 0.70 < float(covered.float().mean()) < 0.78
+    # rasterizer backward, all 8 images, upstream gradient randn / (H W)
+    dbary = torch.stack([seeded_dbary((H, W, 3), seed=b) for b in range(B)])
+    d = _native.rasterize_backward(dbary.to(device), clip_d, tris_d, ids, bary).cpu().numpy()
+    want = oracle.backward(dbary.numpy(), clip.numpy(), tris.numpy(), ids.cpu().numpy(), bary.cpu().numpy(),
+                           threads=min(8, oracle.max_threads()))
+    assert_close_abs_and_rel(d, want, "config4 rasterizer backward")
+    assert np.all(d[:, :, 2] == 0)
+    del dbary, d, want
+    # render() forward + L1 + backward on the batch; image 3 against the oracle
+    leaves = {k2: job[k2].clone().to(device).requires_grad_(True) for k2 in ("vertices", "normals", "diffuse")}
+    up = torch.tensor([0.0, 1.0, 0.0])
+    img = mesh_renderer.render(leaves["vertices"], tris_d, leaves["normals"], leaves["diffuse"], job["eyes"],
+                               torch.zeros(B, 3), up, job["light_positions"].to(device),
+                               job["light_intensities"].to(device), W, H)
+    target = torch.rand(1, H, W, 4, generator=torch.Generator().manual_seed(3))
+    target_d = target.to(device).expand(B, H, W, 4)
+    mesh_renderer.losses.l1_loss(img, target_d.contiguous()).backward()
+    b = 3
+    one = lambda t: t[b:b + 1].clone()
+    cpu = {k2: one(job[k2]).requires_grad_(True) for k2 in leaves}
+    ref = shading.render(cpu["vertices"], tris, cpu["normals"], cpu["diffuse"], one(job["eyes"]), torch.zeros(1, 3),
+                         up.unsqueeze(0), one(job["light_positions"]), one(job["light_intensities"]), W, H,
+                         clip_bits=device_clip_bits(job, device)[b:b + 1])
+    ref.backward(gradient=(torch.sign(img[b:b + 1].detach().cpu() - target) / img.numel()))
+    np.testing.assert_allclose(img[b].detach().cpu().numpy(), ref[0].detach().numpy(), atol=ATOL, rtol=0)
+    for k2 in leaves:
+        assert_close_abs_and_rel(leaves[k2].grad[b].cpu().numpy(), cpu[k2].grad[0].numpy(), "config4 d/d" + k2)
+
+
+def test_config5_soft_renderer_full_batch(device):
+    """configs[4]: SoftRas, 5k-tri sphere, 512x512, batch 16, forward + full backward AT SIZE; the
+    oracle (a dense [triangles x pixels] torch evaluation) checks image 9 on a 96x96 crop-free
+    rerender of the same job at a size it can afford, and batch-consistency pins the rest."""
+    B, W, H, K = 16, 512, 512, 50
+    job = synthetic.sphere_job(B, W, H, K)
+    tris_d = job["triangles"].to(device)
+    v = job["vertices"].to(device).requires_grad_(True)
+    up = torch.tensor([0.0, 1.0, 0.0], device=device)
+    args = (job["diffuse"].to(device), job["eyes"].to(device), torch.zeros(B, 3, device=device), up,
+            job["light_positions"].to(device), torch.ones(B, 1, device=device))
+    img = soft_mesh_renderer.render(v, tris_d, *args, W, H)
+    assert img.shape == (B, H, W, 4) and bool(torch.isfinite(img).all())
+    alpha = img[..., 3]
+    frac = (alpha > 0.5).float().mean(dim=(1, 2))
+    assert bool(((frac > 0.70) & (frac < 0.78)).all())          # every image shows the sphere's silhouette
+    w8 = torch.rand(img.shape, generator=torch.Generator().manual_seed(8)).to(device) / img.numel()
+    (img * w8).sum().backward()
+    g_full = v.grad.detach().clone()
+    assert bool(torch.isfinite(g_full).all()) and bool((g_full.abs().reshape(B, -1).max(1).values > 0).all())
+    # batch consistency: image 9 rendered alone (B = 1) gives the same pixels and the same gradient
+    b = 9
+    v1 = job["vertices"][b:b + 1].to(device).requires_grad_(True)
+    img1 = soft_mesh_renderer.render(v1, tris_d, *[a[b:b + 1] if a.dim() > 1 else a for a in args], W, H)
+    np.testing.assert_allclose(img1[0].detach().cpu().numpy(), img[b].detach().cpu().numpy(), atol=1e-6, rtol=0)
+    (img1 * w8[b:b + 1]).sum().backward()
+    scale = float(g_full[b].abs().max())
+    assert float((v1.grad[0] - g_full[b]).abs().max()) <= 1e-3 * scale
+    # the same camera / mesh at 96x96 against the oracle (5000 triangles x 9216 pixels, dense)
+    Ws = Hs = 96
+    small = synthetic.sphere_job(B, Ws, Hs, K)
+    one = lambda t: t[b:b + 1].clone()
+    vg = one(small["vertices"]).to(device).requires_grad_(True)
+    soft = dict(sigma_val=1e-4, gamma_val=1e-2)   # sub-pixel triangles at 96x96: the softer blend of SURVEY P15
+    got = soft_mesh_renderer.render(vg, tris_d, one(small["diffuse"]).to(device), one(small["eyes"]).to(device),
+                                    torch.zeros(1, 3, device=device), up, one(small["light_positions"]).to(device),
+                                    torch.ones(1, 1, device=device), Ws, Hs, **soft)
+    vc = one(small["vertices"]).requires_grad_(True)
+    want = oracle_soft.render(vc, small["triangles"], one(small["diffuse"]), one(small["eyes"]), torch.zeros(1, 3),
+                              torch.tensor([[0.0, 1.0, 0.0]]), one(small["light_positions"]), torch.ones(1, 1),
+                              Ws, Hs, **soft)
+    np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().numpy(), atol=ATOL, rtol=0)
+    wts = torch.rand(want.shape, generator=torch.Generator().manual_seed(2)) / want.numel()
+    (want * wts).sum().backward()
+    (got * wts.to(device)).sum().backward()
+    assert_close_abs_and_rel(vg.grad.cpu().numpy(), vc.grad.numpy(), "config5 d/dvertices (96x96)", rel=5e-3)
