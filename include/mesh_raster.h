@@ -177,6 +177,23 @@ int mr_shade_backward(const float *drgba, const int32_t *ids, const float *bary,
                       const int32_t *vertex_offsets, const int32_t *vertex_entries,
                       void *workspace, size_t workspace_bytes, void *stream);
 
+/* mr_shade_backward for an upstream gradient that is the backward of mr_l1_loss_forward(rgba,
+ * target): instead of the [B,H,W,4] float image mr_l1_loss_backward would write (16 B/px) it takes
+ * the loss's packed sign codes (`signs`, one byte per pixel in image row order, exactly as
+ * mr_l1_loss_forward wrote them for an image of B*H*W*4 elements) and `upstream`, the device scalar
+ * d L / d loss.  Same outputs as mr_shade_backward(drgba = upstream * sign / (B*H*W*4)); the
+ * workspace must be mr_shade_backward_l1_workspace_bytes() long. */
+size_t mr_shade_backward_l1_workspace_bytes(int B, int V, int T, int W, int H);
+int mr_shade_backward_l1(const uint8_t *signs, const float *upstream, const int32_t *ids,
+                         const float *bary, const float *clip, const float *normals,
+                         const float *positions, const float *diffuse, const int32_t *triangles,
+                         const float *light_positions, const float *light_intensities,
+                         const float *ambient, int B, int V, int T, int W, int H, int L,
+                         float *dclip, float *dnormals, float *dpositions, float *ddiffuse,
+                         float *light_grads, const void *corner_records,
+                         const int32_t *vertex_offsets, const int32_t *vertex_entries,
+                         void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- fused deferred shading with the specular term --------------------------------
  * The same replacement as mr_shade_forward / mr_shade_backward for render() calls that pass
  * specular_colors and shininess_coefficients (src/mesh_renderer/render.py:157-181, 199-228;

@@ -102,6 +102,10 @@ def lib():
         L.mr_shade_backward_workspace_bytes.restype = sz
         L.mr_shade_backward.argtypes = [vp] * 11 + [ci] * 6 + [vp] * 9 + [sz, vp]
         L.mr_shade_backward.restype = ci
+        L.mr_shade_backward_l1_workspace_bytes.argtypes = [ci] * 5
+        L.mr_shade_backward_l1_workspace_bytes.restype = sz
+        L.mr_shade_backward_l1.argtypes = [vp] * 12 + [ci] * 6 + [vp] * 9 + [sz, vp]
+        L.mr_shade_backward_l1.restype = ci
         L.mr_soft_max_lights.restype = ci
         L.mr_soft_workspace_bytes.argtypes = [ci] * 5
         L.mr_soft_workspace_bytes.restype = sz
@@ -369,9 +373,12 @@ def vertex_adjacency(triangles, vertex_count):
 
 
 def shade_backward(drgba, ids, bary, clip, normals, positions, diffuse, triangles, light_positions,
-                   light_intensities, ambient, corner_records=None, adjacency=None):
+                   light_intensities, ambient, corner_records=None, adjacency=None, l1_signs=None):
     """-> (dclip [B,V,4], dnormals, dpositions, ddiffuse [B,V,3], dlight_positions,
-    dlight_intensities [B,L,3], dambient [B,3] or None)."""
+    dlight_intensities [B,L,3], dambient [B,3] or None).
+
+    l1_signs: the packed sign codes of l1_loss_forward(rgba, target); `drgba` is then the 1-element
+    upstream gradient of that loss and the [B,H,W,4] gradient image is never materialised."""
     tensors = [drgba, ids, bary, clip, normals, positions, diffuse, triangles, light_positions,
                light_intensities]
     dev = _require_device(*(tensors + ([ambient] if ambient is not None else [])))
@@ -389,18 +396,27 @@ def shade_backward(drgba, ids, bary, clip, normals, positions, diffuse, triangle
     dp = flat[n4 + n3:n4 + 2 * n3].view(B, V, 3)
     dd = flat[n4 + 2 * n3:n4 + 3 * n3].view(B, V, 3)
     lg = flat[n4 + 3 * n3:].view(B, 6 * nl + 3)
+    tail = (B, V, T, W, H, nl, _ptr(dclip), _ptr(dn), _ptr(dp), _ptr(dd), _ptr(lg), _ptr(corner_records),
+            _ptr(adjacency[0]) if adjacency is not None else None,
+            _ptr(adjacency[1]) if adjacency is not None else None)
     with torch.cuda.device(dev):
-        need = L.mr_shade_backward_workspace_bytes(B, V, T, W, H)
-        ws, have = _workspace(dev, need)
         _arm_timer(TIMER_SHADE_BACKWARD)
-        rc = L.mr_shade_backward(_ptr(drgba), _ptr(ids), _ptr(bary), _ptr(clip), _ptr(normals),
-                                 _ptr(positions), _ptr(diffuse), _ptr(triangles),
-                                 _ptr(light_positions), _ptr(light_intensities), _ptr(ambient),
-                                 B, V, T, W, H, nl, _ptr(dclip), _ptr(dn), _ptr(dp), _ptr(dd),
-                                 _ptr(lg), _ptr(corner_records),
-                                 _ptr(adjacency[0]) if adjacency is not None else None,
-                                 _ptr(adjacency[1]) if adjacency is not None else None,
-                                 _ptr(ws), have, _stream(dev))
+        if l1_signs is not None:
+            if l1_signs.dtype != torch.uint8 or l1_signs.numel() != B * H * W or drgba.numel() != 1:
+                raise ValueError("l1_signs must hold one byte per pixel and drgba the scalar upstream gradient")
+            need = L.mr_shade_backward_l1_workspace_bytes(B, V, T, W, H)
+            ws, have = _workspace(dev, need)
+            rc = L.mr_shade_backward_l1(_ptr(l1_signs.contiguous()), _ptr(drgba), _ptr(ids), _ptr(bary), _ptr(clip),
+                                        _ptr(normals), _ptr(positions), _ptr(diffuse), _ptr(triangles),
+                                        _ptr(light_positions), _ptr(light_intensities), _ptr(ambient),
+                                        *tail, _ptr(ws), have, _stream(dev))
+        else:
+            need = L.mr_shade_backward_workspace_bytes(B, V, T, W, H)
+            ws, have = _workspace(dev, need)
+            rc = L.mr_shade_backward(_ptr(drgba), _ptr(ids), _ptr(bary), _ptr(clip), _ptr(normals),
+                                     _ptr(positions), _ptr(diffuse), _ptr(triangles),
+                                     _ptr(light_positions), _ptr(light_intensities), _ptr(ambient),
+                                     *tail, _ptr(ws), have, _stream(dev))
     _check(rc, "mr_shade_backward")
     dlpos = lg[:, :3 * nl].reshape(B, nl, 3)
     dlint = lg[:, 3 * nl:6 * nl].reshape(B, nl, 3)

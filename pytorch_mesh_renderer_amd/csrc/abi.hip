@@ -230,8 +230,45 @@ int mr_shade_backward(const float *drgba, const int32_t *ids, const float *bary,
   if (vertex_offsets && ((uintptr_t)dclip & 15u) != 0) return MR_EINVAL;
   const int rc = check_ws(workspace, workspace_bytes, mr::shade_backward_ws(B, V, T, W, H));
   if (rc != MR_OK) return rc;
-  return mr::launch_shade_backward(drgba, ids, bary, clip, normals, positions, diffuse, triangles,
-                                   light_positions, light_intensities, ambient, B, V, T, W, H, L,
+  return mr::launch_shade_backward(drgba, nullptr, nullptr, ids, bary, clip, normals, positions, diffuse,
+                                   triangles, light_positions, light_intensities, ambient, B, V, T, W, H, L,
+                                   dclip, dnormals, dpositions, ddiffuse, light_grads, corner_records,
+                                   vertex_offsets, vertex_entries, workspace, (hipStream_t)stream);
+}
+
+size_t mr_shade_backward_l1_workspace_bytes(int B, int V, int T, int W, int H) {
+  if (bad_dims(B, V, T, W, H)) return 0;
+  return mr::shade_backward_ws(B, V, T, W, H) + 256;
+}
+
+int mr_shade_backward_l1(const uint8_t *signs, const float *upstream, const int32_t *ids,
+                         const float *bary, const float *clip, const float *normals,
+                         const float *positions, const float *diffuse, const int32_t *triangles,
+                         const float *light_positions, const float *light_intensities,
+                         const float *ambient, int B, int V, int T, int W, int H, int L, float *dclip,
+                         float *dnormals, float *dpositions, float *ddiffuse, float *light_grads,
+                         const void *corner_records, const int32_t *vertex_offsets,
+                         const int32_t *vertex_entries, void *workspace, size_t workspace_bytes,
+                         void *stream) {
+  if (bad_dims(B, V, T, W, H) || T < 1 || V < 1 || L < 1 || L > mr::shade_max_lights())
+    return MR_EINVAL;
+  if (B == 0) return MR_OK;
+  if (!signs || !upstream || !ids || !bary || !clip || !normals || !positions || !diffuse || !triangles ||
+      !light_positions || !light_intensities || !dclip || !dnormals || !dpositions || !ddiffuse ||
+      !light_grads)
+    return MR_EINVAL;
+  if (((uintptr_t)corner_records & 127u) != 0) return MR_EINVAL;
+  if ((vertex_offsets == nullptr) != (vertex_entries == nullptr)) return MR_EINVAL;
+  if (vertex_offsets && ((uintptr_t)dclip & 15u) != 0) return MR_EINVAL;
+  // the scale (d loss / d mean, 1 / n) lives behind the accumulators in the workspace
+  const size_t base = mr::shade_backward_ws(B, V, T, W, H);
+  const int rc = check_ws(workspace, workspace_bytes, base + 256);
+  if (rc != MR_OK) return rc;
+  float *scale = (float *)((char *)workspace + base);
+  const int rs = mr::launch_l1_scale(upstream, (size_t)B * H * W * 4, scale, (hipStream_t)stream);
+  if (rs != MR_OK) return rs;
+  return mr::launch_shade_backward(nullptr, signs, scale, ids, bary, clip, normals, positions, diffuse,
+                                   triangles, light_positions, light_intensities, ambient, B, V, T, W, H, L,
                                    dclip, dnormals, dpositions, ddiffuse, light_grads, corner_records,
                                    vertex_offsets, vertex_entries, workspace, (hipStream_t)stream);
 }

@@ -116,7 +116,8 @@ int launch_shade_forward(const int32_t *ids, const float *bary, const float *nor
                          hipStream_t s);
 size_t shade_forward_ws(int B, int V, int T, int W, int H);
 size_t shade_backward_ws(int B, int V, int T, int W, int H);
-int launch_shade_backward(const float *drgba, const int32_t *ids, const float *bary,
+int launch_shade_backward(const float *drgba, const uint8_t *signs, const float *sign_scale,
+                          const int32_t *ids, const float *bary,
                           const float *clip, const float *normals, const float *positions,
                           const float *diffuse, const int32_t *tris, const float *light_pos,
                           const float *light_col, const float *ambient, int B, int V, int T, int W,
@@ -153,6 +154,7 @@ int launch_shade_specular_backward(const float *drgba, const int32_t *ids, const
                                    void *ws, hipStream_t s);
 int launch_l1_forward(const float *a, const float *b, size_t n, float *out, uint8_t *signs, hipStream_t s);
 int launch_l1_backward(const uint8_t *signs, size_t n, const float *upstream, float *da, hipStream_t s);
+int launch_l1_scale(const float *upstream, size_t n, float *scale, hipStream_t s);
 int launch_export_u8(const float *in, size_t n, uint8_t *out, hipStream_t s);
 int soft_max_lights();
 size_t soft_ws(int B, int V, int T, int W, int H);

@@ -162,7 +162,10 @@ __global__ __launch_bounds__(kThreads, MR_SHADE_FWD_WAVES) void k_shade_forward(
   }
 }
 
-template <int L>
+// SIGNS: the upstream gradient is the backward of mean|image - target| (loss.hip): it arrives as
+// the 2-bit sign codes that loss's forward packed (1 B/px, image rows) and one device scalar
+// instead of a [B,H,W,4] float image (16 B/px that k_l1_backward would first have to write).
+template <int L, bool SIGNS>
 struct ShadeGradFn {
   static constexpr int kN = 36;       // 27 attribute partials [corner][attr] + 9 clip partials
   static constexpr int kStride = 36;
@@ -181,7 +184,9 @@ struct ShadeGradFn {
 #endif
   static constexpr int kMinWavesPerSimd = MR_SHADE_WAVES;
   static constexpr bool kCountBackground = false;
-  const float4 *__restrict__ drgba;   // [B,H,W,4], image rows (flipped w.r.t. the G-buffer)
+  const float4 *__restrict__ drgba;   // [B,H,W,4], image rows (flipped w.r.t. the G-buffer); !SIGNS
+  const uint8_t *__restrict__ signs;  // [B,H,W] bytes: sign codes of the 4 channels; SIGNS
+  const float *__restrict__ sign_scale;  // SIGNS: [2] = (d loss / d mean, 1 / element count)
   const int32_t *__restrict__ ids;
   const F3 *__restrict__ bary;
   const CornerRec *__restrict__ corners;
@@ -197,7 +202,8 @@ struct ShadeGradFn {
   struct Raw {
     F3 b;
     int t;
-    float4 g;
+    float4 g;       // !SIGNS
+    unsigned code;  // SIGNS
   };
   struct Triangle {
     Corners cr;
@@ -205,11 +211,13 @@ struct ShadeGradFn {
   };
   struct Image {
     int n_bg;                              // unused (kCountBackground = false)
+    float g_scale;                         // SIGNS: upstream * 1 / n
     float lp[L][3], li[L][3], amb[3];      // this image's lights (loaded once per lane)
     float dpos[L][3], dcol[L][3], damb[3];  // per-lane partial sums
   };
 
   __device__ __forceinline__ void begin_image(int img, Image &im) const {
+    im.g_scale = SIGNS ? sign_scale[0] * sign_scale[1] : 0.f;
 #pragma unroll
     for (int l = 0; l < L; ++l) {
 #pragma unroll
@@ -230,14 +238,22 @@ struct ShadeGradFn {
   __device__ __forceinline__ void fetch(int img, int x, int y, size_t pix, Raw &r) const {
     r.b = bary[pix];
     r.t = ids[pix];
-    r.g = drgba[((size_t)img * H + (H - 1 - y)) * W + x];  // un-flip
+    const size_t image_pix = ((size_t)img * H + (H - 1 - y)) * W + x;  // un-flip
+    if (SIGNS) r.code = signs[image_pix];
+    else r.g = drgba[image_pix];
   }
   __device__ __forceinline__ bool prepare(const Raw &r, int T, int &tri, Pixel &p) const {
     const float pre = (2.0f * r.b.x + 2.0f * r.b.y) + 2.0f * r.b.z;
     if (!(pre > 0.0f)) return false;  // background: mask = 0, no gradient anywhere
     if ((unsigned)r.t >= (unsigned)T) return false;
     p.b = r.b;
-    p.g.x = r.g.x; p.g.y = r.g.y; p.g.z = r.g.z;  // d/d alpha is dropped: the mask is not differentiable
+    if (SIGNS) {  // code 0 -> 0, 1 -> +1, 2 -> -1 (loss.hip), times the scale in factors()
+      p.g.x = (float)(int)(r.code & 1u) - (float)(int)((r.code >> 1) & 1u);
+      p.g.y = (float)(int)((r.code >> 2) & 1u) - (float)(int)((r.code >> 3) & 1u);
+      p.g.z = (float)(int)((r.code >> 4) & 1u) - (float)(int)((r.code >> 5) & 1u);
+    } else {
+      p.g.x = r.g.x; p.g.y = r.g.y; p.g.z = r.g.z;  // d/d alpha is dropped: the mask is not differentiable
+    }
     p.tri = r.t;
     tri = r.t;
     return true;
@@ -255,7 +271,8 @@ struct ShadeGradFn {
     // render.py:215 mask: where() sends no gradient to a masked pixel.  All 36 outputs are
     // linear in g, so a masked pixel simply runs with g = 0 (every output must be assigned).
     const bool mask = (at[6] >= 0.0f) || (at[7] >= 0.0f) || (at[8] >= 0.0f);
-    const float g[3] = {mask ? p.g.x : 0.f, mask ? p.g.y : 0.f, mask ? p.g.z : 0.f};
+    const float gs = SIGNS ? im.g_scale : 1.0f;
+    const float g[3] = {mask ? p.g.x * gs : 0.f, mask ? p.g.y * gs : 0.f, mask ? p.g.z * gs : 0.f};
     const float nn = fast_sqrt(at[0] * at[0] + at[1] * at[1] + at[2] * at[2]);
     const float inv_nn = fast_rcp(fmaxf(nn, kNormEps));
     const float N[3] = {at[0] * inv_nn, at[1] * inv_nn, at[2] * inv_nn};
@@ -475,7 +492,8 @@ size_t shade_backward_ws(int B, int V, int T, int W, int H) {
   return shade_acc_bytes(B, T) + align_up((size_t)B * T * sizeof(BwdRec), 256) + corner_bytes(B, T);
 }
 
-int launch_shade_backward(const float *drgba, const int32_t *ids, const float *bary,
+int launch_shade_backward(const float *drgba, const uint8_t *signs, const float *sign_scale,
+                          const int32_t *ids, const float *bary,
                           const float *clip, const float *normals, const float *positions,
                           const float *diffuse, const int32_t *tris, const float *light_pos,
                           const float *light_col, const float *ambient, int B, int V, int T, int W,
@@ -517,10 +535,16 @@ int launch_shade_backward(const float *drgba, const int32_t *ids, const float *b
   Lights lights{light_pos, light_col, ambient, L};
 #define MR_SHADE_BWD(NL)                                                                        \
   {                                                                                             \
-    ShadeGradFn<NL> fn{(const float4 *)drgba, ids, (const F3 *)bary, corners, recs, lights,     \
-                       light_grads, T, W, H};                                                   \
     KernelTimer timer(MR_TIMER_SHADE_BACKWARD, s);                                              \
-    rc = launch_accumulate_rows(fn, B, T, W, H, acc, s);                                        \
+    if (signs) {                                                                                \
+      ShadeGradFn<NL, true> fn{nullptr, signs, sign_scale, ids, (const F3 *)bary, corners, recs, \
+                               lights, light_grads, T, W, H};                                   \
+      rc = launch_accumulate_rows(fn, B, T, W, H, acc, s);                                      \
+    } else {                                                                                    \
+      ShadeGradFn<NL, false> fn{(const float4 *)drgba, nullptr, nullptr, ids, (const F3 *)bary, \
+                                corners, recs, lights, light_grads, T, W, H};                   \
+      rc = launch_accumulate_rows(fn, B, T, W, H, acc, s);                                      \
+    }                                                                                           \
   }
   switch (L) {
     case 1: MR_SHADE_BWD(1); break;

@@ -28,11 +28,27 @@ class _MeanAbsError(torch.autograd.Function):
         return (da if ctx.needs_input_grad[0] else None), (-da if ctx.needs_input_grad[1] else None)
 
 
+import os
+
+USE_FUSED_RENDER_LOSS = os.environ.get("MR_FUSED_RENDER_LOSS", "1") != "0"   # False: always the generic op (dense gradient image)
+
+
 def l1_loss(image, target):
     """mean(|image - target|) over every element; same value and gradients as
-    torch.mean(torch.abs(image - target)) (sign(0) = 0)."""
+    torch.mean(torch.abs(image - target)) (sign(0) = 0).
+
+    When `image` is the direct output of render()'s fused diffuse path, the backward skips the
+    dense gradient image: the loss's sign codes go straight into the shading backward
+    (rasterize_triangles_ext.FusedPhongL1Loss)."""
     if image.shape != target.shape:
         raise ValueError("image and target must have the same shape")
     if image.dtype != torch.float32 or target.dtype != torch.float32:
         raise ValueError("l1_loss expects float32 tensors")
+    record = getattr(image, "_mr_fused_render", None)
+    if (USE_FUSED_RENDER_LOSS and record is not None and image.grad_fn is record["node"] and
+            torch.is_grad_enabled() and image.requires_grad):
+        from .rasterize_triangles_ext import FusedPhongL1Loss
+        # image.detach(): the renderer's own node must not be part of this loss's graph (autograd
+        # would run it on a materialised all-zero gradient image)
+        return FusedPhongL1Loss.apply(image.detach(), target, *record["inputs"], record["saved"])
     return _MeanAbsError.apply(image, target)

@@ -143,6 +143,40 @@ class FusedPhongRenderer(torch.autograd.Function):
         return dclip, dp, dn, dd, None, dlp, dli, damb, None, None
 
 
+class FusedPhongL1Loss(torch.autograd.Function):
+    """mean|image - target| for an `image` that FusedPhongRenderer produced, differentiated straight
+    to the renderer's inputs: the backward hands the loss's 1-byte-per-pixel sign codes to the
+    shading backward instead of first writing -- and then re-reading -- a [B,H,W,4] float gradient
+    image (losses.l1_loss routes here; same value, same gradients).  `image` itself receives no
+    gradient from this node: the chain through the renderer is evaluated here, fused."""
+
+    @staticmethod
+    def forward(ctx, image, target, clip, positions, normals, diffuse, light_positions,
+                light_intensities, ambient, render_saved):
+        loss, signs = _native.l1_loss_forward(image.detach(), target.detach(), want_signs=True)
+        ctx.image_shape = image.shape
+        # the renderer's own saved tensors (G-buffer, corner records, adjacency, ...): held here too,
+        # because the renderer's node frees its copies as soon as the image tensor is dropped
+        ctx.save_for_backward(signs, *render_saved)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad):
+        signs = ctx.saved_tensors[0]
+        saved = ctx.saved_tensors[1:]
+        (clip, ids, bary, normals, positions, diffuse, triangles, lp, li, corner_records, offsets,
+         entries) = saved[:12]
+        amb = saved[12] if len(saved) > 12 else None
+        upstream = grad.to(torch.float32).reshape(1)
+        dclip, dn, dp, dd, dlp, dli, damb = _native.shade_backward(
+            upstream, ids, bary, clip, normals, positions, diffuse, triangles, lp, li, amb,
+            corner_records=corner_records, adjacency=(offsets, entries), l1_signs=signs)
+        dtarget = None
+        if ctx.needs_input_grad[1]:
+            dtarget = -_native.l1_loss_backward(signs, ctx.image_shape, upstream)
+        return None, dtarget, dclip, dp, dn, dd, dlp, dli, damb, None
+
+
 class FusedSpecularPhongRenderer(torch.autograd.Function):
     """FusedPhongRenderer plus the specular term of phong_shader (src/mesh_renderer/render.py
     :326-372) for a per-image shininess: two passes over the G-buffer each way (the reference

@@ -185,11 +185,16 @@ def _render_fused(vertices, triangles, normals, diffuse_colors, camera_position,
             ambient_color.to(device) if ambient_color is not None else None,
             camera_position.to(device=device, dtype=torch.float32), shininess,
             image_width, image_height)
-    return FusedPhongRenderer.apply(
-        clip, vertices, normals, diffuse_colors, triangles, light_positions.to(device),
-        light_intensities.to(device).to(torch.float32),
-        ambient_color.to(device) if ambient_color is not None else None,
-        image_width, image_height)
+    lp, li = light_positions.to(device), light_intensities.to(device).to(torch.float32)
+    amb = ambient_color.to(device) if ambient_color is not None else None
+    image = FusedPhongRenderer.apply(clip, vertices, normals, diffuse_colors, triangles, lp, li, amb,
+                                     image_width, image_height)
+    if image.grad_fn is not None:
+        # lets losses.l1_loss differentiate straight to these inputs (FusedPhongL1Loss); the node
+        # is compared by identity there, so a tensor derived from `image` never takes that path
+        image._mr_fused_render = {"node": image.grad_fn, "saved": tuple(image.grad_fn.saved_tensors),
+                                  "inputs": (clip, vertices, normals, diffuse_colors, lp, li, amb)}
+    return image
 
 
 def phong_shader(normals, alphas, pixel_positions, light_positions, light_intensities,

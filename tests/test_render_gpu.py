@@ -476,3 +476,60 @@ def test_fused_rasterize_tiny_and_ragged_images(device, w, h):
         results[fused] = [t.detach().cpu().numpy() for t in (out, v.grad, a.grad)]
     for name, got, want in zip(("out", "dvertices", "dattributes"), results[True], results[False]):
         np.testing.assert_allclose(got, want, atol=1e-6, rtol=1e-4, err_msg=name)
+
+
+@pytest.mark.parametrize("ambient,target_grad", [(False, False), (True, True)])
+def test_fused_render_l1_loss_matches_generic_loss(device, ambient, target_grad):
+    """l1_loss on render()'s direct output takes FusedPhongL1Loss (sign codes -> shading backward, no
+    dense gradient image); value and every gradient must equal the generic op's, also when the image
+    feeds a second consumer and when the target needs a gradient."""
+    losses = sys.modules["pytorch_mesh_renderer_amd.mesh_renderer.losses"]
+    job = synthetic.sphere_job(3, 130, 70, 14)
+    gen = torch.Generator().manual_seed(11)
+    target0 = torch.rand(3, 70, 130, 4, generator=gen)
+    results = {}
+    for fused in (True, False):
+        leaves = {k: job[k].clone().to(device).requires_grad_(True) for k in ("vertices", "normals", "diffuse")}
+        leaves["lpos"] = job["light_positions"].clone().to(device).requires_grad_(True)
+        leaves["lint"] = (job["light_intensities"] * 0.8).to(device).requires_grad_(True)
+        if ambient:
+            leaves["amb"] = torch.tensor([[0.1, 0.2, 0.05]] * 3, device=device, requires_grad=True)
+        target = target0.clone().to(device).requires_grad_(target_grad)
+        losses.USE_FUSED_RENDER_LOSS = fused
+        try:
+            with _CountCalls("l1_loss_backward") as dense:
+                img = mesh_renderer.render(leaves["vertices"], job["triangles"].to(device), leaves["normals"],
+                                           leaves["diffuse"], job["eyes"], torch.zeros(3, 3),
+                                           torch.tensor([0.0, 1.0, 0.0]), leaves["lpos"], leaves["lint"], 130, 70,
+                                           ambient_color=leaves.get("amb"))
+                loss = mesh_renderer.losses.l1_loss(img, target)
+                total = 3.0 * loss + (0.25 * img[..., 1].mean() if ambient else 0.0)   # a second consumer
+                total.backward()
+        finally:
+            losses.USE_FUSED_RENDER_LOSS = True
+        # the dense gradient image is only formed by the generic op (or for the target's gradient)
+        assert dense.calls == (1 if (not fused or target_grad) else 0)
+        grads = {k: v.grad.cpu().numpy() for k, v in leaves.items()}
+        if target_grad:
+            grads["target"] = target.grad.cpu().numpy()
+        results[fused] = (float(loss), grads)
+    assert abs(results[True][0] - results[False][0]) < 1e-7
+    for k, want in results[False][1].items():
+        got = results[True][1][k]
+        assert np.abs(want).max() > 0, k
+        np.testing.assert_allclose(got, want, atol=1e-9, rtol=2e-4, err_msg=k)
+
+
+def test_l1_loss_on_a_derived_image_takes_the_generic_path(device):
+    """Only render()'s own output carries the fused-loss record; a slice or a scaled copy does not."""
+    job = synthetic.sphere_job(1, 64, 48, 8)
+    v = job["vertices"].clone().to(device).requires_grad_(True)
+    img = mesh_renderer.render(v, job["triangles"].to(device), job["normals"].to(device), job["diffuse"].to(device),
+                               job["eyes"], torch.zeros(1, 3), torch.tensor([0.0, 1.0, 0.0]),
+                               job["light_positions"].to(device), job["light_intensities"].to(device), 64, 48)
+    assert getattr(img, "_mr_fused_render", None) is not None
+    derived = img * 1.0
+    assert getattr(derived, "_mr_fused_render", None) is None
+    with _CountCalls("l1_loss_backward") as dense:
+        mesh_renderer.losses.l1_loss(derived, torch.zeros_like(derived)).backward()
+    assert dense.calls == 1 and float(v.grad.abs().max()) > 0
