@@ -280,6 +280,16 @@ int mr_l1_loss_backward(const uint8_t *signs, size_t n, const float *upstream, f
  * the multi-GPU hand-over): a quarter of the fp32 bytes. */
 int mr_export_u8(const float *image, size_t n, uint8_t *out, void *stream);
 
+/* ---- tone_mapper ------------------------------------------------------------------------
+ * Replaces tone_mapper (src/mesh_renderer/render.py:389-419): per image,
+ *   out = clamp(image^gamma / max(image^gamma), 0, 1)     (torch.pow / torch.max / torch.clamp
+ * semantics, NaNs included).  image: B images of `elements_per_image` floats each; max_scratch: B
+ * ints (device, overwritten: the per-image maxima as float bits); exactly one of out_f32 (same
+ * shape as image) and out_u8 (8-bit frames, the examples' `(x * 255).astype(np.uint8)` applied to
+ * the tone-mapped value) is non-NULL. */
+int mr_tone_map(const float *image, int B, size_t elements_per_image, float gamma, int32_t *max_scratch,
+                float *out_f32, uint8_t *out_u8, void *stream);
+
 /* ---- kernel timing (measurement, no reference counterpart) ----------------------------
  * Arms ONE measurement: the next launch of the named kernel made BY THE CALLING THREAD records
  * hipEvent `start_event` immediately before and `stop_event` immediately after that kernel on

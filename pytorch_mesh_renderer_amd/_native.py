@@ -137,6 +137,8 @@ def lib():
         L.mr_shade_specular_backward.restype = ci
         L.mr_export_u8.argtypes = [vp, sz, vp, vp]
         L.mr_export_u8.restype = ci
+        L.mr_tone_map.argtypes = [vp, ci, sz, cf, vp, vp, vp, vp]
+        L.mr_tone_map.restype = ci
         _lib = L
     return _lib
 
@@ -159,6 +161,48 @@ def _require_device(*tensors):
         if t.device != dev:
             raise RuntimeError("all tensors must be on the same device")
     return dev
+
+
+def _chk(name, t, dtype, *shape):
+    """One argument of a C-ABI call: dtype as the reference's accessor<> demands (RuntimeError, like
+    c10::Error there), rank and extents as the call's other arguments imply (ValueError, like the
+    reference's Python layer).  The library takes raw device pointers: a tensor of another dtype or
+    shape would be read as garbage or out of bounds, so NOTHING reaches it unchecked.  None in
+    `shape` = any extent."""
+    if not torch.is_tensor(t):
+        raise TypeError("%s must be a tensor" % name)
+    if t.dtype != dtype:
+        raise RuntimeError("%s must be %s, got %s" % (name, str(dtype).replace("torch.", ""),
+                                                      str(t.dtype).replace("torch.", "")))
+    if t.dim() != len(shape) or any(want is not None and want != have for want, have in zip(shape, t.shape)):
+        raise ValueError("%s must have shape [%s], got %s" % (
+            name, ", ".join("*" if d is None else str(d) for d in shape), list(t.shape)))
+
+
+_F32, _I32, _U8 = torch.float32, torch.int32, torch.uint8
+
+
+def _chk_mesh(clip, triangles):
+    _chk("clip-space vertices", clip, _F32, None, None, 4)
+    _chk("triangles", triangles, _I32, None, 3)
+    return clip.shape[0], clip.shape[1], triangles.shape[0]
+
+
+def _chk_gbuffer(ids, bary, B):
+    _chk("triangle ids", ids, _I32, B, None, None)
+    _chk("barycentrics", bary, _F32, B, ids.shape[1], ids.shape[2], 3)
+    return ids.shape[1], ids.shape[2]
+
+
+def _chk_lights(light_positions, light_intensities, ambient, B, max_lights):
+    _chk("light_positions", light_positions, _F32, B, None, 3)
+    L = light_positions.shape[1]
+    if not 1 <= L <= max_lights:
+        raise ValueError("1..%d lights are supported, got %d" % (max_lights, L))
+    _chk("light_intensities", light_intensities, _F32, B, L, 3)
+    if ambient is not None:
+        _chk("ambient_color", ambient, _F32, B, 3)
+    return L
 
 
 def _workspace(dev, nbytes):
@@ -184,6 +228,7 @@ def _ptr(t):
 
 def rasterize_forward(clip, triangles, width, height):
     """clip [B,V,4] f32, triangles [T,3] i32 (device) -> ids [B,H,W] i32, bary [B,H,W,3], z [B,H,W]."""
+    _chk_mesh(clip, triangles)
     dev = _require_device(clip, triangles)
     L = lib()
     clip = clip.contiguous()
@@ -205,6 +250,9 @@ def rasterize_forward(clip, triangles, width, height):
 
 def rasterize_backward(dbary, clip, triangles, ids, bary):
     """-> dclip [B,V,4] f32."""
+    B, _, _ = _chk_mesh(clip, triangles)
+    h, w = _chk_gbuffer(ids, bary, B)
+    _chk("df_dbarycentric_coords", dbary, _F32, B, h, w, 3)
     dev = _require_device(dbary, clip, triangles, ids, bary)
     L = lib()
     dbary, clip, triangles = dbary.contiguous(), clip.contiguous(), triangles.contiguous()
@@ -226,6 +274,10 @@ def rasterize_backward(dbary, clip, triangles, ids, bary):
 
 def interpolate_forward(ids, bary, attrs, triangles, background):
     """attrs [B,V,A], background [A] -> [B,H,W,A]."""
+    _chk("triangles", triangles, _I32, None, 3)
+    _chk("attributes", attrs, _F32, None, None, None)
+    _chk_gbuffer(ids, bary, attrs.shape[0])
+    _chk("background", background, _F32, attrs.shape[2])
     dev = _require_device(ids, bary, attrs, triangles, background)
     L = lib()
     ids, bary, attrs = ids.contiguous(), bary.contiguous(), attrs.contiguous()
@@ -243,6 +295,11 @@ def interpolate_forward(ids, bary, attrs, triangles, background):
 
 def interpolate_backward(dout, ids, bary, attrs, triangles, background):
     """-> (dattrs [B,V,A], dbary [B,H,W,3])."""
+    _chk("triangles", triangles, _I32, None, 3)
+    _chk("attributes", attrs, _F32, None, None, None)
+    h, w = _chk_gbuffer(ids, bary, attrs.shape[0])
+    _chk("background", background, _F32, attrs.shape[2])
+    _chk("upstream gradient", dout, _F32, attrs.shape[0], h, w, attrs.shape[2])
     dev = _require_device(dout, ids, bary, attrs, triangles, background)
     L = lib()
     dout, ids, bary = dout.contiguous(), ids.contiguous(), bary.contiguous()
@@ -278,6 +335,13 @@ def shade_forward(ids, bary, normals, positions, diffuse, triangles, light_posit
     """Fused interpolation + diffuse/ambient Phong: -> rgba [B,H,W,4] (row 0 = top); with
     keep_corner_records also the gathered per-triangle attribute records, for shade_backward."""
     tensors = [ids, bary, normals, positions, diffuse, triangles, light_positions, light_intensities]
+    _chk("triangles", triangles, _I32, None, 3)
+    _chk("positions", positions, _F32, None, None, 3)
+    B, V = positions.shape[0], positions.shape[1]
+    _chk("normals", normals, _F32, B, V, 3)
+    _chk("diffuse colors", diffuse, _F32, B, V, 3)
+    _chk_gbuffer(ids, bary, B)
+    _chk_lights(light_positions, light_intensities, ambient, B, shade_max_lights())
     dev = _require_device(*(tensors + ([ambient] if ambient is not None else [])))
     L = lib()
     ids, bary, normals, positions, diffuse, triangles, light_positions, light_intensities = [
@@ -308,6 +372,12 @@ def interpolate_raster_max_attributes():
 def interpolate_forward_records(ids, bary, attrs, triangles, background):
     """interpolate_forward through per-(image, triangle) corner records, for at most
     interpolate_raster_max_attributes() attributes -> (out [B,H,W,A], records for the backward)."""
+    _chk("triangles", triangles, _I32, None, 3)
+    _chk("attributes", attrs, _F32, None, None, None)
+    _chk_gbuffer(ids, bary, attrs.shape[0])
+    _chk("background", background, _F32, attrs.shape[2])
+    if not 1 <= attrs.shape[2] <= interpolate_raster_max_attributes():
+        raise ValueError("1..%d attributes are supported here" % interpolate_raster_max_attributes())
     dev = _require_device(ids, bary, attrs, triangles, background)
     L = lib()
     ids, bary, attrs = ids.contiguous(), bary.contiguous(), attrs.contiguous()
@@ -329,6 +399,13 @@ def interpolate_raster_backward(dout, ids, bary, clip, attrs, triangles, backgro
                                 corner_records=None):
     """One-pass backward of interpolation + rasterization -> (dattributes [B,V,A], dclip [B,V,4])."""
     tensors = [dout, ids, bary, clip, attrs, triangles, background, adjacency[0], adjacency[1]]
+    B, V, _ = _chk_mesh(clip, triangles)
+    _chk("attributes", attrs, _F32, B, V, None)
+    h, w = _chk_gbuffer(ids, bary, B)
+    _chk("background", background, _F32, attrs.shape[2])
+    _chk("upstream gradient", dout, _F32, B, h, w, attrs.shape[2])
+    _chk("adjacency offsets", adjacency[0], _I32, V + 1)
+    _chk("adjacency entries", adjacency[1], _I32, None)
     dev = _require_device(*tensors)
     L = lib()
     dout, ids, bary, clip, attrs, triangles, background, offsets, entries = [t.contiguous() for t in tensors]
@@ -381,6 +458,18 @@ def shade_backward(drgba, ids, bary, clip, normals, positions, diffuse, triangle
     upstream gradient of that loss and the [B,H,W,4] gradient image is never materialised."""
     tensors = [drgba, ids, bary, clip, normals, positions, diffuse, triangles, light_positions,
                light_intensities]
+    B, V, _ = _chk_mesh(clip, triangles)
+    for name, t in (("normals", normals), ("positions", positions), ("diffuse colors", diffuse)):
+        _chk(name, t, _F32, B, V, 3)
+    h, w = _chk_gbuffer(ids, bary, B)
+    _chk_lights(light_positions, light_intensities, ambient, B, shade_max_lights())
+    if l1_signs is None:
+        _chk("upstream gradient", drgba, _F32, B, h, w, 4)
+    else:
+        _chk("upstream gradient of the loss", drgba, _F32, 1)
+    if adjacency is not None:
+        _chk("adjacency offsets", adjacency[0], _I32, V + 1)
+        _chk("adjacency entries", adjacency[1], _I32, None)
     dev = _require_device(*(tensors + ([ambient] if ambient is not None else [])))
     L = lib()
     (drgba, ids, bary, clip, normals, positions, diffuse, triangles, light_positions,
@@ -429,6 +518,15 @@ def shade_specular_forward(ids, bary, normals, positions, diffuse, specular, tri
     """Fused interpolation + Phong with the specular term -> (rgba [B,H,W,4], norms2 [B,L])."""
     tensors = [ids, bary, normals, positions, diffuse, specular, triangles, light_positions,
                light_intensities, camera_position, shininess]
+    _chk("triangles", triangles, _I32, None, 3)
+    _chk("positions", positions, _F32, None, None, 3)
+    B, V = positions.shape[0], positions.shape[1]
+    for name, t in (("normals", normals), ("diffuse colors", diffuse), ("specular colors", specular)):
+        _chk(name, t, _F32, B, V, 3)
+    _chk_gbuffer(ids, bary, B)
+    _chk_lights(light_positions, light_intensities, ambient, B, shade_max_lights())
+    _chk("camera_position", camera_position, _F32, B, 3)
+    _chk("shininess", shininess, _F32, B)
     dev = _require_device(*(tensors + ([ambient] if ambient is not None else [])))
     L = lib()
     (ids, bary, normals, positions, diffuse, specular, triangles, light_positions, light_intensities,
@@ -457,6 +555,16 @@ def shade_specular_backward(drgba, ids, bary, clip, normals, positions, diffuse,
     dlight_intensities [B,L,3], dambient [B,3] or None, dcamera_position [B,3])."""
     tensors = [drgba, ids, bary, clip, normals, positions, diffuse, specular, triangles,
                light_positions, light_intensities, camera_position, shininess, norms2]
+    B, V, _ = _chk_mesh(clip, triangles)
+    for name, t in (("normals", normals), ("positions", positions), ("diffuse colors", diffuse),
+                    ("specular colors", specular)):
+        _chk(name, t, _F32, B, V, 3)
+    h, w = _chk_gbuffer(ids, bary, B)
+    nl_ = _chk_lights(light_positions, light_intensities, ambient, B, shade_max_lights())
+    _chk("upstream gradient", drgba, _F32, B, h, w, 4)
+    _chk("camera_position", camera_position, _F32, B, 3)
+    _chk("shininess", shininess, _F32, B)
+    _chk("norms2", norms2, _F32, B, nl_)
     dev = _require_device(*(tensors + ([ambient] if ambient is not None else [])))
     L = lib()
     (drgba, ids, bary, clip, normals, positions, diffuse, specular, triangles, light_positions,
@@ -492,6 +600,13 @@ def soft_forward(clip, positions, normals, diffuse, triangles, light_positions, 
                  width, height, sigma, gamma, blur):
     """SoftRas forward: -> (rgba [B,H,W,4] with row 0 = top, aux [B,H,W,4] for the backward)."""
     tensors = [clip, positions, normals, diffuse, triangles, light_positions, light_intensities]
+    B, V, _ = _chk_mesh(clip, triangles)
+    for name, t in (("positions", positions), ("normals", normals), ("diffuse colors", diffuse)):
+        _chk(name, t, _F32, B, V, 3)
+    _chk("light_positions", light_positions, _F32, B, None, 3)
+    _chk("light_intensities", light_intensities, _F32, B, light_positions.shape[1])
+    if not 1 <= light_positions.shape[1] <= soft_max_lights():
+        raise ValueError("the soft rasterizer supports 1..%d lights" % soft_max_lights())
     dev = _require_device(*tensors)
     L = lib()
     clip, positions, normals, diffuse, triangles, light_positions, light_intensities = [
@@ -517,6 +632,14 @@ def soft_backward(drgba, rgba, aux, clip, positions, normals, diffuse, triangles
     dlight_intensities [B,L])."""
     tensors = [drgba, rgba, aux, clip, positions, normals, diffuse, triangles, light_positions,
                light_intensities]
+    B, V, _ = _chk_mesh(clip, triangles)
+    for name, t in (("positions", positions), ("normals", normals), ("diffuse colors", diffuse)):
+        _chk(name, t, _F32, B, V, 3)
+    _chk("light_positions", light_positions, _F32, B, None, 3)
+    _chk("light_intensities", light_intensities, _F32, B, light_positions.shape[1])
+    _chk("rgba", rgba, _F32, B, None, None, 4)
+    _chk("aux", aux, _F32, B, rgba.shape[1], rgba.shape[2], 4)
+    _chk("upstream gradient", drgba, _F32, B, rgba.shape[1], rgba.shape[2], 4)
     dev = _require_device(*tensors)
     L = lib()
     (drgba, rgba, aux, clip, positions, normals, diffuse, triangles, light_positions,
@@ -546,6 +669,10 @@ def l1_loss_forward(a, b, want_signs=True):
     """mean |a - b| over all elements -> (0-D tensor, packed signs or None), on the device.
 
     The signs ((n + 3) // 4 bytes, 2 bits per element) are all the backward pass needs."""
+    if a.dtype != _F32 or b.dtype != _F32:
+        raise RuntimeError("l1_loss expects float32 tensors")
+    if a.shape != b.shape:
+        raise ValueError("image and target must have the same shape")
     dev = _require_device(a, b)
     a, b = a.contiguous(), b.contiguous()
     out = torch.empty((), dtype=torch.float32, device=dev)
@@ -559,6 +686,8 @@ def l1_loss_forward(a, b, want_signs=True):
 
 def l1_loss_backward(signs, shape, upstream):
     """upstream * sign(a - b) / n as a float32 tensor of `shape`, from the packed signs."""
+    _chk("signs", signs, _U8, None)
+    _chk("upstream gradient of the loss", upstream, _F32, 1)
     dev = _require_device(signs, upstream)
     da = torch.empty(shape, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
@@ -576,4 +705,23 @@ def export_u8(image):
     with torch.cuda.device(dev):
         rc = lib().mr_export_u8(_ptr(image), image.numel(), _ptr(out), _stream(dev))
     _check(rc, "mr_export_u8")
+    return out
+
+
+def tone_map(image, gamma, as_uint8=False):
+    """tone_mapper of the reference on the device: clamp(image ** gamma / per-image max, 0, 1) for a
+    [B, ...] float32 image -> float32 tensor of the same shape, or uint8 frames (as_uint8)."""
+    if not torch.is_tensor(image) or image.dim() < 1:
+        raise ValueError("image must be a [batch, ...] tensor")
+    _chk("image", image, _F32, *([None] * image.dim()))
+    dev = _require_device(image)
+    image = image.contiguous()
+    B = image.shape[0]
+    per_image = image.numel() // B if B else 0
+    scratch = torch.empty(max(B, 1), dtype=torch.int32, device=dev)
+    out = torch.empty(image.shape, dtype=torch.uint8 if as_uint8 else torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib().mr_tone_map(_ptr(image), B, per_image, float(gamma), _ptr(scratch),
+                               None if as_uint8 else _ptr(out), _ptr(out) if as_uint8 else None, _stream(dev))
+    _check(rc, "mr_tone_map")
     return out

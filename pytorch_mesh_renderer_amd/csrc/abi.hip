@@ -391,6 +391,15 @@ int mr_l1_loss_backward(const uint8_t *signs, size_t n, const float *upstream, f
   return mr::launch_l1_backward(signs, n, upstream, da, (hipStream_t)stream);
 }
 
+int mr_tone_map(const float *image, int B, size_t elements_per_image, float gamma, int32_t *max_scratch,
+                float *out_f32, uint8_t *out_u8, void *stream) {
+  if (B < 0) return MR_EINVAL;
+  if (B == 0 || elements_per_image == 0) return MR_OK;
+  if (!image || !max_scratch || ((out_f32 == nullptr) == (out_u8 == nullptr))) return MR_EINVAL;
+  return mr::launch_tone_map(image, B, elements_per_image, gamma, (int *)max_scratch, out_f32, out_u8,
+                             (hipStream_t)stream);
+}
+
 int mr_export_u8(const float *image, size_t n, uint8_t *out, void *stream) {
   if (n > 0 && (!image || !out)) return MR_EINVAL;
   if (((uintptr_t)image & 15u) != 0 || ((uintptr_t)out & 3u) != 0) return MR_EINVAL;

@@ -95,6 +95,45 @@ __global__ void k_l1_scale(const float *__restrict__ upstream, float inv_n, floa
   scale[1] = inv_n;
 }
 
+// ---- tone_mapper (src/mesh_renderer/render.py:389-419): out = clamp(image^gamma / max, 0, 1) with
+// max taken per image over image^gamma.  Two streaming passes: (1) per-image maximum of the powers
+// -- they are non-negative or NaN, so their bit patterns order like signed integers with NaN on
+// top: one integer atomicMax per workgroup also reproduces torch.max's NaN propagation; (2) the
+// powers are recomputed (cheaper than 4 B/element of scratch traffic), scaled with an IEEE
+// division as torch does, clamped, and stored as fp32 or straight as 8-bit frames.
+__device__ __forceinline__ float tone_power(float v, float gamma) {
+  const float p = powf(v, gamma);
+  return p != p ? __int_as_float(0x7fc00000) : p;  // canonical NaN: positive as an integer
+}
+
+__global__ __launch_bounds__(kThreads) void k_tone_max(const float *__restrict__ image, size_t per_image,
+                                                       float gamma, int *__restrict__ max_bits) {
+  const float *img = image + (size_t)blockIdx.y * per_image;
+  int best = 0;  // bits of +0.0
+  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < per_image; i += (size_t)gridDim.x * kThreads)
+    best = max(best, __float_as_int(tone_power(img[i], gamma)) & 0x7fffffff);  // (-0.0 -> +0.0)
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) best = max(best, __shfl_down(best, off));
+  if ((threadIdx.x & (kWave - 1)) == 0 && best != 0) atomicMax(&max_bits[blockIdx.y], best);
+}
+
+template <bool U8>
+__global__ __launch_bounds__(kThreads) void k_tone_map(const float *__restrict__ image, size_t per_image,
+                                                       float gamma, const int *__restrict__ max_bits,
+                                                       float *__restrict__ out, uint8_t *__restrict__ out_u8) {
+  const size_t base = (size_t)blockIdx.y * per_image;
+  const float image_max = __int_as_float(max_bits[blockIdx.y]);
+  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < per_image; i += (size_t)gridDim.x * kThreads) {
+    const float scaled = tone_power(image[base + i], gamma) / image_max;
+    if (U8) {
+      out_u8[base + i] = (uint8_t)to_u8(scaled);
+    } else {
+      // torch.clamp: NaN stays NaN
+      out[base + i] = scaled != scaled ? scaled : fminf(fmaxf(scaled, 0.0f), 1.0f);
+    }
+  }
+}
+
 inline unsigned blocks_for(size_t n4) {
   const size_t want = (n4 + kThreads - 1) / kThreads;
   return (unsigned)(want < 2048 ? (want ? want : 1) : 2048);
@@ -122,6 +161,20 @@ int launch_l1_backward(const uint8_t *signs, size_t n, const float *upstream, fl
 
 int launch_l1_scale(const float *upstream, size_t n, float *scale, hipStream_t s) {
   hipLaunchKernelGGL(k_l1_scale, dim3(1), dim3(1), 0, s, upstream, n ? 1.0f / (float)n : 0.0f, scale);
+  return check_launch();
+}
+
+int launch_tone_map(const float *image, int B, size_t per_image, float gamma, int *max_bits, float *out,
+                    uint8_t *out_u8, hipStream_t s) {
+  if (B == 0 || per_image == 0) return MR_OK;
+  if (hipMemsetAsync(max_bits, 0, (size_t)B * sizeof(int), s) != hipSuccess) return check_launch();
+  const size_t want = (per_image + kThreads - 1) / kThreads;
+  const dim3 grid((unsigned)(want < 512 ? want : 512), (unsigned)B);
+  hipLaunchKernelGGL(k_tone_max, grid, dim3(kThreads), 0, s, image, per_image, gamma, max_bits);
+  int rc = check_launch();
+  if (rc != MR_OK) return rc;
+  if (out_u8) hipLaunchKernelGGL(k_tone_map<true>, grid, dim3(kThreads), 0, s, image, per_image, gamma, max_bits, out, out_u8);
+  else hipLaunchKernelGGL(k_tone_map<false>, grid, dim3(kThreads), 0, s, image, per_image, gamma, max_bits, out, out_u8);
   return check_launch();
 }
 

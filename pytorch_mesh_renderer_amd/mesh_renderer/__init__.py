@@ -1,5 +1,5 @@
 """Same export surface as the reference's src/mesh_renderer/__init__.py:1-5."""
-from .render import render, tone_mapper, to_uint8
+from .render import render, tone_mapper, tone_mapper_uint8, to_uint8
 from .rasterize import rasterize
 from . import losses
 

@@ -248,11 +248,30 @@ def phong_shader(normals, alphas, pixel_positions, light_positions, light_intens
 
 def tone_mapper(image, gamma):
     """image_out = A * image_in ** gamma with A chosen per image so that max == 1;
-    clipped to [0, 1].  image [B,H,W,C]."""
+    clipped to [0, 1].  image [B,H,W,C].  Counterpart of src/mesh_renderer/render.py:389-419.
+
+    On a HIP device this is two streaming kernels (per-image max of the powers, then scale /
+    clamp).  When a gradient is wanted -- the reference's version is differentiable through
+    autograd -- the same expression is evaluated with torch ops on the device instead."""
+    from .. import _native
+    needs_grad = torch.is_grad_enabled() and (image.requires_grad or
+                                              (torch.is_tensor(gamma) and gamma.requires_grad))
+    if image.is_cuda and image.dtype == torch.float32 and not needs_grad:
+        return _native.tone_map(image, float(gamma))
     batch_size = image.shape[0]
     corrected = torch.pow(image, gamma)
     image_max = corrected.reshape(batch_size, -1).max(dim=1).values
     return torch.clamp(corrected / image_max.reshape(batch_size, 1, 1, 1), 0.0, 1.0)
+
+
+def tone_mapper_uint8(image, gamma):
+    """tone_mapper followed by the examples' 8-bit frame conversion, `(x * 255.0).astype(np.uint8)`,
+    in the same two kernels: 4 B/element read twice, 1 B/element written (display / file / hand-over
+    frames; not differentiable)."""
+    from .. import _native
+    if image.dtype != torch.float32:
+        raise ValueError("tone_mapper_uint8 expects a float32 image")
+    return _native.tone_map(image.detach(), float(gamma), as_uint8=True)
 
 
 def to_uint8(image):

@@ -172,3 +172,61 @@ def test_synthetic_job_is_deterministic():
     a, b = synthetic.sphere_job(3, 64, 48, 6), synthetic.sphere_job(3, 64, 48, 6)
     assert torch.equal(a["clip"], b["clip"]) and a["clip"].shape == (3, 38, 4)
     assert torch.allclose(a["eyes"].norm(dim=1), torch.full((3,), 3.0), atol=1e-5)
+
+
+def test_native_wrappers_validate_dtypes_and_shapes_before_anything_reaches_the_library():
+    """The C ABI takes raw pointers: an int64 triangle array would be read as int32 pairs, float64
+    attributes as float32 bits, a light tensor of another batch size out of bounds.  Every _native
+    wrapper therefore checks dtype (RuntimeError, like the reference's accessor<>) and shape
+    (ValueError, like its Python layer) first -- also on CPU tensors, which lets this run here."""
+    B, V, T, H, W, L = 2, 5, 4, 6, 7, 1
+    f = lambda *shape: torch.zeros(*shape)
+    clip, tris = f(B, V, 4), torch.zeros(T, 3, dtype=torch.int32)
+    ids, bary = torch.zeros(B, H, W, dtype=torch.int32), f(B, H, W, 3)
+    n, p, kd = f(B, V, 3), f(B, V, 3), f(B, V, 3)
+    lp, li = f(B, L, 3), f(B, L, 3)
+    rgba = f(B, H, W, 4)
+    ok_shade = (ids, bary, n, p, kd, tris, lp, li, None)
+    cases = [
+        (_native.rasterize_forward, (clip, tris.long(), W, H), RuntimeError, "int32"),
+        (_native.rasterize_forward, (clip.double(), tris, W, H), RuntimeError, "float32"),
+        (_native.rasterize_forward, (clip[..., :3], tris, W, H), ValueError, "shape"),
+        (_native.rasterize_forward, (clip, tris[:, :2], W, H), ValueError, "shape"),
+        (_native.rasterize_backward, (f(B, H, W, 3), clip, tris, ids.long(), bary), RuntimeError, "int32"),
+        (_native.rasterize_backward, (f(B, H, W + 1, 3), clip, tris, ids, bary), ValueError, "shape"),
+        (_native.interpolate_forward, (ids, bary, f(B, V, 3).double(), tris, f(3)), RuntimeError, "float32"),
+        (_native.interpolate_forward, (ids, bary, f(B, V, 3), tris, f(4)), ValueError, "background"),
+        (_native.interpolate_forward, (ids, bary, f(B + 1, V, 3), tris, f(3)), ValueError, "shape"),
+        (_native.shade_forward, ok_shade[:5] + (tris.long(),) + ok_shade[6:], RuntimeError, "int32"),
+        (_native.shade_forward, (ids, bary, n.double(), p, kd, tris, lp, li, None), RuntimeError, "float32"),
+        (_native.shade_forward, (ids, bary, n, p, f(B, V + 1, 3), tris, lp, li, None), ValueError, "diffuse"),
+        (_native.shade_forward, (ids, bary, n, p, kd, tris, f(B + 1, L, 3), li, None), ValueError, "light_positions"),
+        (_native.shade_forward, (ids, bary, n, p, kd, tris, lp, f(B, L + 1, 3), None), ValueError, "light_intensities"),
+        (_native.shade_forward, (ids, bary, n, p, kd, tris, f(B, 9, 3), f(B, 9, 3), None), ValueError, "lights"),
+        (_native.shade_forward, (ids, bary, n, p, kd, tris, lp, li, f(B + 1, 3)), ValueError, "ambient"),
+        (_native.shade_backward, (rgba.double(), ids, bary, clip, n, p, kd, tris, lp, li, None), RuntimeError, "float32"),
+        (_native.shade_backward, (rgba, ids, bary, f(B, V + 2, 4), n, p, kd, tris, lp, li, None), ValueError, "shape"),
+        (_native.shade_specular_forward, (ids, bary, n, p, kd, kd, tris, lp, li, None, f(B, 3), f(B + 1)), ValueError, "shininess"),
+        (_native.soft_forward, (clip, p, n, kd, tris.long(), lp, f(B, L), W, H, 1e-4, 1e-2, 0.01), RuntimeError, "int32"),
+        (_native.soft_forward, (clip, p, n, kd, tris, lp, f(B, L + 1), W, H, 1e-4, 1e-2, 0.01), ValueError, "light_intensities"),
+        (_native.l1_loss_forward, (rgba, rgba.double()), RuntimeError, "float32"),
+        (_native.l1_loss_forward, (rgba, f(B, H, W, 3)), ValueError, "shape"),
+    ]
+    for fn, args, exc, word in cases:
+        with pytest.raises(exc, match=word):
+            fn(*args)
+    # well-formed CPU tensors get past the checks and are refused for the device only
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _native.shade_forward(*ok_shade)
+
+
+def test_render_refuses_mismatched_inputs_on_the_host():
+    """render() / rasterize() level: what used to reach the fused HIP path unchecked."""
+    v, n, kd = torch.zeros(1, 4, 3), torch.zeros(1, 4, 3), torch.zeros(1, 4, 3)
+    tris = torch.zeros(2, 3, dtype=torch.int64)      # int64: the reference's accessor<int, 2> raises too
+    eye, center, up = torch.tensor([[0.0, 0.0, 3.0]]), torch.zeros(1, 3), torch.tensor([[0.0, 1.0, 0.0]])
+    lp, li = torch.zeros(1, 1, 3), torch.ones(1, 1, 3)
+    with pytest.raises(RuntimeError, match="int32"):
+        mesh_renderer.render(v, tris, n, kd, eye, center, up, lp, li, 8, 8)
+    with pytest.raises(ValueError):
+        mesh_renderer.render(v, tris.int()[:, :2], n, kd, eye, center, up, lp, li, 8, 8)

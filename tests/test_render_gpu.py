@@ -533,3 +533,33 @@ def test_l1_loss_on_a_derived_image_takes_the_generic_path(device):
     with _CountCalls("l1_loss_backward") as dense:
         mesh_renderer.losses.l1_loss(derived, torch.zeros_like(derived)).backward()
     assert dense.calls == 1 and float(v.grad.abs().max()) > 0
+
+
+def test_tone_mapper_hip_matches_reference_golden_and_torch(device):
+    """tone_mapper (render.py:389-419) as HIP passes: the reference's captured output, then torch's
+    own pow / max / clamp semantics on images with zeros, values > 1, a negative entry (NaN power ->
+    NaN maximum -> NaN image, as torch.max propagates it) and an all-zero image (0 / 0)."""
+    g = golden_npz("camera_utils.npz")
+    got = mesh_renderer.tone_mapper(torch.tensor(g["tone_in"], device=device), 0.7)
+    assert got.is_cuda and got.dtype == torch.float32
+    np.testing.assert_allclose(got.cpu().numpy(), g["tone_out"], atol=1e-6, rtol=0)
+
+    gen = torch.Generator().manual_seed(3)
+    x = torch.rand(4, 37, 29, 4, generator=gen) * 2.5
+    x[0, 0, 0, 0] = 0.0
+    x[1] = 0.0                      # all-zero image: 0 / 0
+    x[2, 5, 5, 1] = -0.25           # negative base: NaN for a fractional gamma
+    for gamma in (0.7, 1.0, 2.2):
+        want = torch.clamp(torch.pow(x, gamma) / torch.pow(x, gamma).reshape(4, -1).max(dim=1).values
+                           .reshape(4, 1, 1, 1), 0.0, 1.0).numpy()
+        got = mesh_renderer.tone_mapper(x.to(device), gamma).cpu().numpy()
+        assert np.array_equal(np.isnan(got), np.isnan(want)), gamma
+        np.testing.assert_allclose(np.nan_to_num(got), np.nan_to_num(want), atol=2e-6, rtol=0)
+        # fused 8-bit frames == the examples' host-side cast of the tone-mapped image
+        frames = mesh_renderer.tone_mapper_uint8(x.to(device), gamma).cpu().numpy()
+        ref = (np.clip(np.nan_to_num(got, nan=0.0), 0.0, 1.0) * np.float32(255.0)).astype(np.uint8)
+        assert frames.dtype == np.uint8 and np.abs(frames.astype(int) - ref.astype(int)).max() <= 0
+    # a gradient request takes the torch expression (the reference's op is differentiable)
+    xg = (torch.rand(2, 8, 8, 3, generator=gen) + 0.1).to(device).requires_grad_(True)
+    mesh_renderer.tone_mapper(xg, 0.7).sum().backward()
+    assert xg.grad is not None and bool(torch.isfinite(xg.grad).all())
