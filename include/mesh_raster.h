@@ -280,6 +280,23 @@ int mr_l1_loss_backward(const uint8_t *signs, size_t n, const float *upstream, f
  * the multi-GPU hand-over): a quarter of the fp32 bytes. */
 int mr_export_u8(const float *image, size_t n, uint8_t *out, void *stream);
 
+/* ---- vertex normals ---------------------------------------------------------------------
+ * Replaces compute_vertex_normals (src/common/meshes.py:3-35): for every triangle corner the
+ * area-weighted face normal (next - this) x (next_next - this) is added to the corner's vertex and
+ * the sums are normalised (eps 1e-6).  Gather form over the CSR vertex -> (triangle, corner)
+ * adjacency of `triangles` (vertex_offsets [V+1], vertex_entries, entry = 3 * triangle + corner,
+ * see mr_shade_backward): no atomics, fixed summation order.  Triangles with a vertex id outside
+ * [0, V) are skipped.
+ *   vertices [B,V,3] f32;  sums [B,V,3] f32 out (the un-normalised sums, input of the backward);
+ *   normals [B,V,3] f32 out;  backward: dnormals in, dsums [B,V,3] scratch, dvertices [B,V,3] out. */
+int mr_vertex_normals_forward(const float *vertices, const int32_t *triangles,
+                              const int32_t *vertex_offsets, const int32_t *vertex_entries, int B, int V,
+                              int T, float *sums, float *normals, void *stream);
+int mr_vertex_normals_backward(const float *dnormals, const float *vertices, const float *sums,
+                               const int32_t *triangles, const int32_t *vertex_offsets,
+                               const int32_t *vertex_entries, int B, int V, int T, float *dsums,
+                               float *dvertices, void *stream);
+
 /* ---- tone_mapper ------------------------------------------------------------------------
  * Replaces tone_mapper (src/mesh_renderer/render.py:389-419): per image,
  *   out = clamp(image^gamma / max(image^gamma), 0, 1)     (torch.pow / torch.max / torch.clamp

@@ -139,6 +139,10 @@ def lib():
         L.mr_export_u8.restype = ci
         L.mr_tone_map.argtypes = [vp, ci, sz, cf, vp, vp, vp, vp]
         L.mr_tone_map.restype = ci
+        L.mr_vertex_normals_forward.argtypes = [vp] * 4 + [ci] * 3 + [vp, vp, vp]
+        L.mr_vertex_normals_forward.restype = ci
+        L.mr_vertex_normals_backward.argtypes = [vp] * 6 + [ci] * 3 + [vp, vp, vp]
+        L.mr_vertex_normals_backward.restype = ci
         _lib = L
     return _lib
 
@@ -725,3 +729,38 @@ def tone_map(image, gamma, as_uint8=False):
                                None if as_uint8 else _ptr(out), _ptr(out) if as_uint8 else None, _stream(dev))
     _check(rc, "mr_tone_map")
     return out
+
+
+def vertex_normals_forward(vertices, triangles):
+    """-> (normals [B,V,3], sums [B,V,3]); compute_vertex_normals of the reference as a per-vertex gather."""
+    _chk("vertices", vertices, _F32, None, None, 3)
+    _chk("triangles", triangles, _I32, None, 3)
+    dev = _require_device(vertices, triangles)
+    vertices, triangles = vertices.contiguous(), triangles.contiguous()
+    B, V, _ = vertices.shape
+    offsets, entries = vertex_adjacency(triangles, V)
+    sums, normals = torch.empty_like(vertices), torch.empty_like(vertices)
+    with torch.cuda.device(dev):
+        rc = lib().mr_vertex_normals_forward(_ptr(vertices), _ptr(triangles), _ptr(offsets), _ptr(entries), B, V,
+                                             triangles.shape[0], _ptr(sums), _ptr(normals), _stream(dev))
+    _check(rc, "mr_vertex_normals_forward")
+    return normals, sums
+
+
+def vertex_normals_backward(dnormals, vertices, sums, triangles):
+    """-> dvertices [B,V,3]."""
+    _chk("vertices", vertices, _F32, None, None, 3)
+    B, V, _ = vertices.shape
+    _chk("dnormals", dnormals, _F32, B, V, 3)
+    _chk("sums", sums, _F32, B, V, 3)
+    _chk("triangles", triangles, _I32, None, 3)
+    dev = _require_device(dnormals, vertices, sums, triangles)
+    dnormals, vertices, sums, triangles = [t.contiguous() for t in (dnormals, vertices, sums, triangles)]
+    offsets, entries = vertex_adjacency(triangles, V)
+    dsums, dvertices = torch.empty_like(vertices), torch.empty_like(vertices)
+    with torch.cuda.device(dev):
+        rc = lib().mr_vertex_normals_backward(_ptr(dnormals), _ptr(vertices), _ptr(sums), _ptr(triangles),
+                                              _ptr(offsets), _ptr(entries), B, V, triangles.shape[0], _ptr(dsums),
+                                              _ptr(dvertices), _stream(dev))
+    _check(rc, "mr_vertex_normals_backward")
+    return dvertices

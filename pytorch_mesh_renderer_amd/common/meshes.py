@@ -1,23 +1,43 @@
 """Mesh utilities on the device of their inputs.
 
 Counterpart of src/common/meshes.py:3-35 (compute_vertex_normals): area-weighted face
-normals accumulated on the incident vertices with index_add, then normalised (eps 1e-6).
-Batched instead of the reference's Python loop over the batch; differentiable.
+normals accumulated on the incident vertices, then normalised (eps 1e-6).  On a HIP device
+this is a per-vertex gather kernel over the mesh's cached CSR adjacency (csrc/mesh_ops.hip:
+no atomics, forward and hand-derived backward); host tensors -- the CPU test-suite, mesh
+preparation before upload -- take the equivalent batched torch expression.  Differentiable
+either way.
 """
 import torch
 
 
+class _VertexNormals(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, vertices, triangles):
+        from .. import _native
+        v = vertices.detach().contiguous()
+        normals, sums = _native.vertex_normals_forward(v, triangles)
+        ctx.save_for_backward(v, sums, triangles)
+        return normals
+
+    @staticmethod
+    def backward(ctx, dnormals):
+        from .. import _native
+        v, sums, triangles = ctx.saved_tensors
+        return _native.vertex_normals_backward(dnormals.contiguous(), v, sums, triangles), None
+
+
 def compute_vertex_normals(vertices, triangles):
     """vertices [B,V,3], triangles [T,3] -> unit vertex normals [B,V,3]."""
+    if vertices.is_cuda and vertices.dtype == torch.float32:
+        if triangles.dtype != torch.int32:
+            raise RuntimeError("triangles must be int32")
+        return _VertexNormals.apply(vertices, triangles.to(vertices.device))
     tri = triangles.long()
     corner_index = tri.t().reshape(-1)                                   # [3T]: all first corners, then ...
-    # index_select, not vertices[:, idx]: its backward is one atomic index_add instead of a sort-based
-    # index_put per gather (21 small kernels per call on the GPU)
     corners = vertices.index_select(1, corner_index).reshape(vertices.shape[0], 3, -1, 3)
     v0, v1, v2 = corners[:, 0], corners[:, 1], corners[:, 2]             # [B,T,3]
     # The reference evaluates (b - a) x (c - a) once per corner (meshes.py:24-33); the three are the
-    # same area-weighted face normal, so it is computed once and added to all three vertices with a
-    # single index_add (a third of the kernels, forward and backward).
+    # same area-weighted face normal up to rounding, so the host expression computes it once.
     face = torch.cross(v1 - v0, v2 - v0, dim=-1)
     normals = torch.zeros_like(vertices).index_add(1, corner_index, face.repeat(1, 3, 1))
     return torch.nn.functional.normalize(normals, eps=1e-6, p=2, dim=-1)

@@ -156,6 +156,11 @@ int launch_l1_forward(const float *a, const float *b, size_t n, float *out, uint
 int launch_l1_backward(const uint8_t *signs, size_t n, const float *upstream, float *da, hipStream_t s);
 int launch_l1_scale(const float *upstream, size_t n, float *scale, hipStream_t s);
 int launch_export_u8(const float *in, size_t n, uint8_t *out, hipStream_t s);
+int launch_vertex_normals(const float *vertices, const int32_t *tris, const int32_t *offsets,
+                          const int32_t *entries, int B, int V, float *sums, float *normals, hipStream_t s);
+int launch_vertex_normals_backward(const float *dnormals, const float *vertices, const float *sums,
+                                   const int32_t *tris, const int32_t *offsets, const int32_t *entries,
+                                   int B, int V, float *dsums, float *dvertices, hipStream_t s);
 int launch_tone_map(const float *image, int B, size_t per_image, float gamma, int *max_bits, float *out,
                     uint8_t *out_u8, hipStream_t s);
 int soft_max_lights();
