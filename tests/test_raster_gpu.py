@@ -405,3 +405,35 @@ def test_vertex_normals_kernel_matches_reference(device):
     assert bool(torch.isfinite(meshes.compute_vertex_normals(v.detach(), bad)).all())
     with pytest.raises(RuntimeError):
         meshes.compute_vertex_normals(v.detach(), tris.long())
+
+
+def test_rasterize_triangles_cpp_shim_is_a_drop_in(device):
+    """`import rasterize_triangles_cpp` + the exact call sequence of the reference's
+    rasterize_triangles_ext.py:37-59 against the shim module, on device tensors."""
+    import importlib
+    import os
+    import sys
+    shim_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                            "pytorch_mesh_renderer_amd", "shims")
+    sys.path.insert(0, shim_dir)
+    try:
+        sys.modules.pop("rasterize_triangles_cpp", None)
+        rasterize_triangles_cpp = importlib.import_module("rasterize_triangles_cpp")
+    finally:
+        sys.path.remove(shim_dir)
+    g = golden_npz("raster_cube64.npz")
+    clip_space_vertices = torch.tensor(g["clip"], device=device)
+    triangles = torch.tensor(g["triangles"], device=device)
+    px_triangle_ids, px_barycentric_coords, z_buffer = rasterize_triangles_cpp.forward(
+        clip_space_vertices, triangles, 64, 64)
+    assert bits_equal(px_triangle_ids.cpu().numpy(), g["ids"])
+    assert bits_equal(px_barycentric_coords.cpu().numpy(), g["bary"])
+    assert bits_equal(z_buffer.cpu().numpy(), g["z"])
+    output = rasterize_triangles_cpp.backward(torch.tensor(g["dbary"], device=device), clip_space_vertices,
+                                              triangles, px_triangle_ids, px_barycentric_coords)
+    df_dvertices = output[0]
+    assert isinstance(output, list) and df_dvertices.shape == (8, 4)
+    np.testing.assert_allclose(df_dvertices.cpu().numpy(), g["dclip"], atol=GRAD_ATOL, rtol=0)
+    with pytest.raises(RuntimeError):
+        rasterize_triangles_cpp.forward(clip_space_vertices, triangles.long(), 64, 64)
+    sys.modules.pop("rasterize_triangles_cpp", None)
