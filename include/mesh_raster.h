@@ -266,9 +266,12 @@ int mr_soft_backward(const float *drgba, const float *rgba, const float *aux,
  * signs: (n + 3) / 4 bytes out, or NULL when no gradient is wanted -- byte i holds
  * sign(a - b) of elements 4i .. 4i+3 as 2-bit codes (0: zero, 1: +1, 2: -1), so that the
  * backward pass does not read the images again; upstream: 1 float (dL/dloss, read on the
- * device); da: n floats out (16-byte aligned) = upstream * sign(a - b) / n. */
+ * device); da: n floats out (16-byte aligned) = upstream * sign(a - b) / n.
+ * partials: MR_L1_PARTIALS floats of scratch: the workgroups' partial sums, added in a fixed
+ * order by one wavefront -- the loss value is bit-identical from run to run. */
+#define MR_L1_PARTIALS 2048
 int mr_l1_loss_forward(const float *a, const float *b, size_t n, float *loss, uint8_t *signs,
-                       void *stream);
+                       float *partials, void *stream);
 int mr_l1_loss_backward(const uint8_t *signs, size_t n, const float *upstream, float *da,
                         void *stream);
 
@@ -306,6 +309,21 @@ int mr_vertex_normals_backward(const float *dnormals, const float *vertices, con
  * the tone-mapped value) is non-NULL. */
 int mr_tone_map(const float *image, int B, size_t elements_per_image, float gamma, int32_t *max_scratch,
                 float *out_f32, uint8_t *out_u8, void *stream);
+
+/* ---- deterministic mode ------------------------------------------------------------------
+ * The reference accumulates its gradients sequentially (rasterize_triangles.cpp:156-157, 232-269) and
+ * is bit-reproducible; the default kernels here end in float atomics, whose sums depend on the order
+ * in which wavefronts commit (last-bit differences from run to run).  mr_set_deterministic(1) makes
+ * the calling thread's later mr_shade_backward / mr_shade_backward_l1 / mr_rasterize_backward calls
+ * accumulate in 64-bit FIXED POINT with integer atomics instead -- integer addition is associative,
+ * so the result is independent of that order -- followed by fixed-order per-vertex gathers.  The
+ * fixed-point scale is a power of two derived on the device from the largest upstream gradient g:
+ * contributions below g * 2^-42 are rounded away, a per-triangle total may reach g * 2^21.  About
+ * 10 % slower (8-byte atomics, one extra pass to find g when the upstream is a dense image).
+ * mr_shade_backward needs the vertex adjacency in this mode (MR_EINVAL without).  The other
+ * entry points (interpolation, specular and soft-renderer backward passes) are not covered and keep
+ * float atomics.  mr_l1_loss_forward is always deterministic.  Returns the previous setting. */
+int mr_set_deterministic(int on);
 
 /* ---- kernel timing (measurement, no reference counterpart) ----------------------------
  * Arms ONE measurement: the next launch of the named kernel made BY THE CALLING THREAD records

@@ -16,7 +16,7 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 # build libmesh_raster_hip_probes.so this way); the product always loads the in-tree library.
 LIB_PATH = os.environ.get("MR_NATIVE_LIB_PATH") or os.path.join(_CSRC, "libmesh_raster_hip.so")
 
-ABI_VERSION = 300
+ABI_VERSION = 310
 TIMER_RASTER_FORWARD, TIMER_SHADE_BACKWARD, TIMER_SHADE_FORWARD, TIMER_RASTER_BACKWARD = 0, 1, 2, 3
 MR_OK, MR_EINVAL, MR_EWORKSPACE, MR_ELAUNCH = 0, -1, -2, -3
 _ERR = {MR_EINVAL: "invalid argument", MR_EWORKSPACE: "workspace too small or misaligned",
@@ -25,6 +25,25 @@ _ERR = {MR_EINVAL: "invalid argument", MR_EWORKSPACE: "workspace too small or mi
 _lib = None
 _workspaces = {}
 _pending_timers = {}
+
+
+_deterministic = False
+
+
+def set_deterministic(on):
+    """Bit-reproducible gradients for the fused render / rasterize backward passes (see
+    mr_set_deterministic in include/mesh_raster.h): fixed-point integer accumulation instead of float
+    atomics, ~10 % slower.  Process-wide on the Python side: the flag is handed to the library by
+    whichever thread launches a backward kernel (autograd runs them on its own thread).  Returns the
+    previous setting."""
+    global _deterministic
+    before = _deterministic
+    _deterministic = bool(on)
+    return before
+
+
+def _sync_deterministic():
+    lib().mr_set_deterministic(1 if _deterministic else 0)
 
 
 def time_next_kernel(which, start_event, stop_event):
@@ -71,6 +90,8 @@ def lib():
             raise NativeLibraryError("%s has ABI version %d, this package needs %d: rebuild it (make -C "
                                      "pytorch_mesh_renderer_amd/csrc)" % (LIB_PATH, L.mr_version(), ABI_VERSION))
         L.mr_last_hip_error.restype = ci
+        L.mr_set_deterministic.argtypes = [ci]
+        L.mr_set_deterministic.restype = ci
         L.mr_time_next_kernel.argtypes = [ci, vp, vp]
         L.mr_time_next_kernel.restype = ci
         # include/mesh_raster_debug.h (tests and tools only)
@@ -114,7 +135,7 @@ def lib():
         L.mr_soft_forward.restype = ci
         L.mr_soft_backward.argtypes = [vp] * 10 + [ci] * 6 + [cf] * 3 + [vp] * 6 + [vp, sz, vp]
         L.mr_soft_backward.restype = ci
-        L.mr_l1_loss_forward.argtypes = [vp, vp, sz, vp, vp, vp]
+        L.mr_l1_loss_forward.argtypes = [vp, vp, sz, vp, vp, vp, vp]
         L.mr_l1_loss_forward.restype = ci
         L.mr_l1_loss_backward.argtypes = [vp, sz, vp, vp, vp]
         L.mr_l1_loss_backward.restype = ci
@@ -269,6 +290,7 @@ def rasterize_backward(dbary, clip, triangles, ids, bary):
         need = L.mr_rasterize_backward_workspace_bytes(B, V, T, W, H)
         ws, have = _workspace(dev, need)
         _arm_timer(TIMER_RASTER_BACKWARD)
+        _sync_deterministic()
         rc = L.mr_rasterize_backward(_ptr(dbary), _ptr(clip), _ptr(triangles), _ptr(ids),
                                      _ptr(bary), B, V, T, W, H, _ptr(dclip), _ptr(ws), have,
                                      _stream(dev))
@@ -494,6 +516,7 @@ def shade_backward(drgba, ids, bary, clip, normals, positions, diffuse, triangle
             _ptr(adjacency[1]) if adjacency is not None else None)
     with torch.cuda.device(dev):
         _arm_timer(TIMER_SHADE_BACKWARD)
+        _sync_deterministic()
         if l1_signs is not None:
             if l1_signs.dtype != torch.uint8 or l1_signs.numel() != B * H * W or drgba.numel() != 1:
                 raise ValueError("l1_signs must hold one byte per pixel and drgba the scalar upstream gradient")
@@ -681,9 +704,10 @@ def l1_loss_forward(a, b, want_signs=True):
     a, b = a.contiguous(), b.contiguous()
     out = torch.empty((), dtype=torch.float32, device=dev)
     signs = torch.empty((a.numel() + 3) // 4, dtype=torch.uint8, device=dev) if want_signs else None
+    partials = torch.empty(2048, dtype=torch.float32, device=dev)   # MR_L1_PARTIALS
     with torch.cuda.device(dev):
         rc = lib().mr_l1_loss_forward(_ptr(a), _ptr(b), a.numel(), _ptr(out),
-                                      _ptr(signs) if want_signs else None, _stream(dev))
+                                      _ptr(signs) if want_signs else None, _ptr(partials), _stream(dev))
     _check(rc, "mr_l1_loss_forward")
     return out, signs
 

@@ -25,13 +25,20 @@ extern thread_local int g_raster_region_edge;
 extern thread_local int g_raster_probe;
 #endif
 thread_local KernelTimerSlot g_kernel_timers[MR_TIMER_COUNT];
+extern thread_local int g_deterministic;
 }
 
 extern "C" {
 
-int mr_version(void) { return 300; /* 0.3.0: one-shot kernel timers, debug hooks in mesh_raster_debug.h */ }
+int mr_version(void) { return 310; /* 0.3.1: deterministic mode, tone map, vertex normals, sign-coded shading backward */ }
 
 int mr_last_hip_error(void) { return mr::g_last_hip_error; }
+
+int mr_set_deterministic(int on) {
+  const int before = mr::g_deterministic;
+  mr::g_deterministic = on ? 1 : 0;
+  return before;
+}
 
 int mr_time_next_kernel(int which, void *start_event, void *stop_event) {
   if (which < 0 || which >= MR_TIMER_COUNT) return MR_EINVAL;
@@ -379,10 +386,10 @@ int mr_soft_backward(const float *drgba, const float *rgba, const float *aux, co
 }
 
 int mr_l1_loss_forward(const float *a, const float *b, size_t n, float *loss, uint8_t *signs,
-                       void *stream) {
-  if (!loss || (n > 0 && (!a || !b))) return MR_EINVAL;
+                       float *partials, void *stream) {
+  if (!loss || (n > 0 && (!a || !b || !partials))) return MR_EINVAL;
   if ((((uintptr_t)a | (uintptr_t)b) & 15u) != 0) return MR_EINVAL;
-  return mr::launch_l1_forward(a, b, n, loss, signs, (hipStream_t)stream);
+  return mr::launch_l1_forward(a, b, n, loss, signs, partials, (hipStream_t)stream);
 }
 
 int mr_l1_loss_backward(const uint8_t *signs, size_t n, const float *upstream, float *da, void *stream) {

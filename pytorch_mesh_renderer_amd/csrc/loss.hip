@@ -24,7 +24,7 @@ __global__ __launch_bounds__(kThreads) void k_l1_forward(const float4 *__restric
                                                          const float4 *__restrict__ b, size_t n4,
                                                          const float *__restrict__ a_tail,
                                                          const float *__restrict__ b_tail, int n_tail,
-                                                         float inv_n, float *__restrict__ out,
+                                                         float inv_n, float *__restrict__ partials,
                                                          uint8_t *__restrict__ signs) {
   float s = 0.f;
   for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n4; i += (size_t)gridDim.x * kThreads) {
@@ -52,8 +52,19 @@ __global__ __launch_bounds__(kThreads) void k_l1_forward(const float4 *__restric
   if (threadIdx.x == 0) {
     float t = 0.f;
     for (int w = 0; w < kThreads / kWave; ++w) t += s_part[w];
-    atomicAdd(out, t * inv_n);  // one atomic per workgroup (<= 2048 of them)
+    partials[blockIdx.x] = t * inv_n;  // summed in a fixed order by k_l1_finish: reproducible bits
   }
+}
+
+// One wavefront adds the workgroups' partial sums in a fixed order (no float atomics: the loss
+// value is bit-identical from run to run).
+__global__ __launch_bounds__(kWave) void k_l1_finish(const float *__restrict__ partials, int n,
+                                                     float *__restrict__ out) {
+  float s = 0.f;
+  for (int i = (int)threadIdx.x; i < n; i += kWave) s += partials[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+  if (threadIdx.x == 0) out[0] = s;
 }
 
 __global__ __launch_bounds__(kThreads) void k_l1_backward(const uint8_t *__restrict__ signs, size_t n4,
@@ -141,13 +152,20 @@ inline unsigned blocks_for(size_t n4) {
 
 }  // namespace
 
-int launch_l1_forward(const float *a, const float *b, size_t n, float *out, uint8_t *signs, hipStream_t s) {
-  if (hipMemsetAsync(out, 0, sizeof(float), s) != hipSuccess) return check_launch();
-  if (n == 0) return MR_OK;
+int launch_l1_forward(const float *a, const float *b, size_t n, float *out, uint8_t *signs, float *partials,
+                      hipStream_t s) {
+  if (n == 0) {
+    if (hipMemsetAsync(out, 0, sizeof(float), s) != hipSuccess) return check_launch();
+    return MR_OK;
+  }
   const size_t n4 = n / 4;
-  hipLaunchKernelGGL(k_l1_forward, dim3(blocks_for(n4)), dim3(kThreads), 0, s, (const float4 *)a,
-                     (const float4 *)b, n4, a + 4 * n4, b + 4 * n4, (int)(n - 4 * n4), 1.0f / (float)n, out,
+  const unsigned blocks = blocks_for(n4);
+  hipLaunchKernelGGL(k_l1_forward, dim3(blocks), dim3(kThreads), 0, s, (const float4 *)a,
+                     (const float4 *)b, n4, a + 4 * n4, b + 4 * n4, (int)(n - 4 * n4), 1.0f / (float)n, partials,
                      signs);
+  int rc = check_launch();
+  if (rc != MR_OK) return rc;
+  hipLaunchKernelGGL(k_l1_finish, dim3(1), dim3(kWave), 0, s, partials, (int)blocks, out);
   return check_launch();
 }
 

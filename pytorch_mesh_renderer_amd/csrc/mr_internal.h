@@ -152,7 +152,8 @@ int launch_shade_specular_backward(const float *drgba, const int32_t *ids, const
                                    int B, int V, int T, int W, int H, int L, float *dclip, float *dnormals,
                                    float *dpositions, float *ddiffuse, float *dspecular, float *light_grads,
                                    void *ws, hipStream_t s);
-int launch_l1_forward(const float *a, const float *b, size_t n, float *out, uint8_t *signs, hipStream_t s);
+int launch_l1_forward(const float *a, const float *b, size_t n, float *out, uint8_t *signs, float *partials,
+                      hipStream_t s);
 int launch_l1_backward(const uint8_t *signs, size_t n, const float *upstream, float *da, hipStream_t s);
 int launch_l1_scale(const float *upstream, size_t n, float *scale, hipStream_t s);
 int launch_export_u8(const float *in, size_t n, uint8_t *out, hipStream_t s);

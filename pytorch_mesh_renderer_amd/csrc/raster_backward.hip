@@ -145,13 +145,70 @@ __global__ __launch_bounds__(kThreads) void k_bwd_scatter(
   }
 }
 
-inline size_t acc_bytes(int B, int T) { return align_up((size_t)B * T * kStride * sizeof(float), 256); }
+// 8 bytes per element: room for the deterministic mode's fixed-point accumulators
+inline size_t acc_bytes(int B, int T) { return align_up((size_t)B * T * kStride * sizeof(long long), 256); }
+inline size_t dclip_fixed_bytes(int B, int V) { return align_up((size_t)B * V * 4 * sizeof(long long), 256); }
+
+// ---- deterministic mode (mr_set_deterministic): fixed point end to end -----------------------
+__global__ __launch_bounds__(kThreads) void k_abs_max_f(const float *__restrict__ x, size_t n, int *__restrict__ max_bits) {
+  int best = 0;
+  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (size_t)gridDim.x * kThreads)
+    best = max(best, __float_as_int(fabsf(x[i])));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) best = max(best, __shfl_down(best, off));
+  if ((threadIdx.x & (kWave - 1)) == 0 && best != 0) atomicMax(max_bits, best);
+}
+
+__global__ void k_det_scale_from_max(const int *__restrict__ max_bits, float *__restrict__ det_scale) {
+  const float g = __int_as_float(max_bits[0]);
+  int e = 0;
+  if (g > 0.0f && g < INFINITY) (void)frexpf(g, &e);
+  const int k = min(max(41 - e, -100), 100);
+  det_scale[0] = ldexpf(1.0f, k);
+  det_scale[1] = ldexpf(1.0f, -k);
+}
+
+// per-triangle fixed-point sums -> per-vertex fixed-point sums (integer atomics: order-free)
+__global__ __launch_bounds__(kThreads) void k_bwd_scatter_fixed(
+    const long long *__restrict__ acc, const int32_t *__restrict__ tris, int B, int V, int T,
+    long long *__restrict__ dclip_fixed) {
+  const long gid = (long)blockIdx.x * kThreads + threadIdx.x;
+  if (gid >= (long)B * T) return;
+  long long a[9];
+  bool any = false;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    a[k] = acc[gid * kStride + k];
+    any |= (a[k] != 0);
+  }
+  if (!any) return;
+  const int b = (int)(gid / T);
+  const int t = (int)(gid - (long)b * T);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int vi = tris[3 * t + j];
+    if ((unsigned)vi >= (unsigned)V) continue;
+    unsigned long long *dst = (unsigned long long *)dclip_fixed + ((long)b * V + vi) * 4;
+    atomicAdd(&dst[0], (unsigned long long)a[j * 3 + 0]);
+    atomicAdd(&dst[1], (unsigned long long)a[j * 3 + 1]);
+    atomicAdd(&dst[3], (unsigned long long)a[j * 3 + 2]);
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void k_from_fixed(const long long *__restrict__ fixed,
+                                                         const float *__restrict__ det_scale, long n,
+                                                         float *__restrict__ out) {
+  const long i = (long)blockIdx.x * kThreads + threadIdx.x;
+  if (i < n) out[i] = (float)fixed[i] * det_scale[1];
+}
 
 }  // namespace
 
+extern thread_local int g_deterministic;
+
 size_t raster_backward_ws(int B, int V, int T, int W, int H) {
-  (void)V; (void)W; (void)H;
-  return acc_bytes(B, T) + align_up((size_t)B * T * sizeof(BwdRec), 256);
+  (void)W; (void)H;
+  return acc_bytes(B, T) + align_up((size_t)B * T * sizeof(BwdRec), 256) + dclip_fixed_bytes(B, V) + 256;
 }
 
 int launch_raster_backward(const float *dbary, const float *clip, const int32_t *tris,
@@ -162,10 +219,36 @@ int launch_raster_backward(const float *dbary, const float *clip, const int32_t 
   if (T == 0) return MR_OK;
   float *acc = (float *)ws;
   BwdRec *recs = (BwdRec *)((char *)ws + acc_bytes(B, T));
-  if (hipMemsetAsync(acc, 0, (size_t)B * T * kStride * sizeof(float), s) != hipSuccess) return check_launch();
+  const bool det = g_deterministic != 0;
+  if (hipMemsetAsync(acc, 0, (size_t)B * T * kStride * (det ? sizeof(long long) : sizeof(float)), s) != hipSuccess)
+    return check_launch();
   int rc = launch_bwd_setup(clip, tris, B, V, T, recs, s);
   if (rc != MR_OK) return rc;
   RasterGradFn fn{(const F3 *)dbary, ids, (const F3 *)bary, recs, T};
+  if (det) {
+    long long *dclip_fixed = (long long *)((char *)recs + align_up((size_t)B * T * sizeof(BwdRec), 256));
+    float *det_scale = (float *)((char *)dclip_fixed + dclip_fixed_bytes(B, V));
+    int *max_bits = (int *)(det_scale + 4);
+    if (hipMemsetAsync(dclip_fixed, 0, dclip_fixed_bytes(B, V) + 256, s) != hipSuccess) return check_launch();
+    const size_t n = (size_t)B * H * W * 3;
+    const size_t want = (n + kThreads - 1) / kThreads;
+    hipLaunchKernelGGL(k_abs_max_f, dim3((unsigned)(want < 8192 ? want : 8192)), dim3(kThreads), 0, s, dbary, n, max_bits);
+    if ((rc = check_launch()) != MR_OK) return rc;
+    hipLaunchKernelGGL(k_det_scale_from_max, dim3(1), dim3(1), 0, s, max_bits, det_scale);
+    if ((rc = check_launch()) != MR_OK) return rc;
+    {
+      KernelTimer timer(MR_TIMER_RASTER_BACKWARD, s);
+      rc = launch_accumulate_runs_fixed(fn, B, T, W, H, acc, det_scale, s);
+    }
+    if (rc != MR_OK) return rc;
+    const long nbt = (long)B * T, nv4 = (long)B * V * 4;
+    hipLaunchKernelGGL(k_bwd_scatter_fixed, dim3((unsigned)((nbt + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
+                       (const long long *)acc, tris, B, V, T, dclip_fixed);
+    if ((rc = check_launch()) != MR_OK) return rc;
+    hipLaunchKernelGGL(k_from_fixed, dim3((unsigned)((nv4 + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
+                       dclip_fixed, det_scale, nv4, dclip);
+    return check_launch();
+  }
   {
     KernelTimer timer(MR_TIMER_RASTER_BACKWARD, s);
     rc = launch_accumulate_runs(fn, B, T, W, H, acc, s);

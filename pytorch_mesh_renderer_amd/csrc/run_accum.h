@@ -34,6 +34,8 @@
 // Per-triangle data (e.g. the adjugate) is fetched once per run, not per pixel.
 #pragma once
 
+#include <type_traits>
+
 #include "mr_internal.h"
 
 namespace mr {
@@ -42,6 +44,17 @@ constexpr int kRunThreads = 256;
 constexpr int kRunRowsPerWave = 32;                                  // pixels each lane walks
 constexpr int kRunRegionH = kRunRowsPerWave * (kRunThreads / kWave);  // 128 rows / workgroup
 constexpr int kRunMaxProbe = 16;
+
+// Deterministic mode (mr_set_deterministic): sums are accumulated in 64-bit FIXED POINT with
+// integer atomics.  Integer addition is associative (also through two's-complement wrap-around),
+// so the result no longer depends on the order in which lanes and wavefronts commit: bit-identical
+// from run to run, where float atomics differ in the last bits.  det_scale[0] = 2^k converts to
+// fixed point (a power of two: exact), det_scale[1] = 2^-k back; k is derived on the device from the
+// largest upstream gradient g so that g maps to about 2^41: values down to g * 2^-42 are resolved and
+// a triangle's total may reach g * 2^21 before the 64-bit range ends.
+__device__ __forceinline__ void atomic_add_fixed(long long *p, float v, float to_fixed) {
+  atomicAdd((unsigned long long *)p, (unsigned long long)__float2ll_rn(v * to_fixed));
+}
 
 template <int SLOTS>
 __device__ __forceinline__ int run_find_slot(int *keys, int tri) {
@@ -55,30 +68,32 @@ __device__ __forceinline__ int run_find_slot(int *keys, int tri) {
   return -1;
 }
 
-template <int N, int STRIDE, int SLOTS>
-__device__ __forceinline__ void run_flush(int *keys, float *vals, float *acc_img, int tri,
-                                          float (&a)[N]) {
+// VAL = float (float atomics) or long long (deterministic mode: fixed point, `scale` = 2^k)
+template <int N, int STRIDE, int SLOTS, class VAL>
+__device__ __forceinline__ void run_flush(int *keys, VAL *vals, VAL *acc_img, int tri,
+                                          float (&a)[N], float scale) {
   if (tri < 0) return;
   const int slot = run_find_slot<SLOTS>(keys, tri);
-  if (slot >= 0) {
+  VAL *dst = slot >= 0 ? &vals[slot * N] : &acc_img[(size_t)tri * STRIDE];  // saturated table: straight to HBM
 #pragma unroll
-    for (int k = 0; k < N; ++k) atomicAdd(&vals[slot * N + k], a[k]);
-  } else {  // table saturated (very dense mesh): straight to HBM
-#pragma unroll
-    for (int k = 0; k < N; ++k) atomicAdd(&acc_img[(size_t)tri * STRIDE + k], a[k]);
+  for (int k = 0; k < N; ++k) {
+    if constexpr (sizeof(VAL) == 8) atomic_add_fixed((long long *)&dst[k], a[k], scale);
+    else atomicAdd(&dst[k], a[k]);
   }
 #pragma unroll
   for (int k = 0; k < N; ++k) a[k] = 0.0f;
 }
 
-template <class Fn>
-__global__ __launch_bounds__(kRunThreads, Fn::kMinWavesPerSimd) void k_accumulate_runs(
+template <class Fn, bool DET>
+__global__ __launch_bounds__(kRunThreads, DET ? 1 : Fn::kMinWavesPerSimd) void k_accumulate_runs(
     Fn fn, int T, int W, int H, int regions_x, int regions_per_image, int n_regions,
-    int regions_per_xcd, float *__restrict__ acc) {
+    int regions_per_xcd, float *__restrict__ acc, const float *__restrict__ det_scale) {
   constexpr int N = Fn::kN, STRIDE = Fn::kStride, SLOTS = Fn::kSlots;
   static_assert(N <= STRIDE, "accumulator row too small");
+  using VAL = typename std::conditional<DET, long long, float>::type;
   __shared__ int s_keys[SLOTS];
-  __shared__ float s_vals[SLOTS * N];
+  __shared__ VAL s_vals[SLOTS * N];
+  const float scale = DET ? det_scale[0] : 0.0f;
 
   const int region = xcd_contiguous_block((int)blockIdx.x, n_regions, regions_per_xcd);
   if (region < 0) return;
@@ -89,7 +104,7 @@ __global__ __launch_bounds__(kRunThreads, Fn::kMinWavesPerSimd) void k_accumulat
 
   const int tid = (int)threadIdx.x;
   for (int i = tid; i < SLOTS; i += kRunThreads) s_keys[i] = -1;
-  for (int i = tid; i < SLOTS * N; i += kRunThreads) s_vals[i] = 0.0f;
+  for (int i = tid; i < SLOTS * N; i += kRunThreads) s_vals[i] = (VAL)0;
   __syncthreads();
 
   const int lane = tid & (kWave - 1);
@@ -97,7 +112,7 @@ __global__ __launch_bounds__(kRunThreads, Fn::kMinWavesPerSimd) void k_accumulat
   const int x = rx * kWave + lane;
   const int y_begin = ry * kRunRegionH + wave * kRunRowsPerWave;
   const int y_end = min(y_begin + kRunRowsPerWave, H);
-  float *acc_img = acc + (size_t)img * T * STRIDE;
+  VAL *acc_img = (VAL *)acc + (size_t)img * T * STRIDE;
 
   typename Fn::Image image_sums;
   fn.begin_image(img, image_sums);
@@ -117,13 +132,13 @@ __global__ __launch_bounds__(kRunThreads, Fn::kMinWavesPerSimd) void k_accumulat
       typename Fn::Pixel p;
       if (!fn.prepare(raw, T, tri, p)) continue;
       if (tri != run_tri) {
-        run_flush<N, STRIDE, SLOTS>(s_keys, s_vals, acc_img, run_tri, a);
+        run_flush<N, STRIDE, SLOTS, VAL>(s_keys, s_vals, acc_img, run_tri, a, scale);
         run_tri = tri;
         fn.load_triangle(img, tri, tri_data);
       }
       fn.accumulate(p, tri_data, a, image_sums);
     }
-    run_flush<N, STRIDE, SLOTS>(s_keys, s_vals, acc_img, run_tri, a);
+    run_flush<N, STRIDE, SLOTS, VAL>(s_keys, s_vals, acc_img, run_tri, a, scale);
   }
   fn.end_image(img, image_sums);  // every lane takes part (wave-level reduction inside)
   __syncthreads();
@@ -134,7 +149,11 @@ __global__ __launch_bounds__(kRunThreads, Fn::kMinWavesPerSimd) void k_accumulat
   for (int i = tid; i < SLOTS * kLanesPerSlot; i += kRunThreads) {
     const int slot = i / kLanesPerSlot, k = i % kLanesPerSlot;
     const int tri = s_keys[slot];
-    if (tri >= 0 && k < N) atomicAdd(&acc_img[(size_t)tri * STRIDE + k], s_vals[slot * N + k]);
+    if (tri >= 0 && k < N) {
+      if constexpr (DET) atomicAdd((unsigned long long *)&acc_img[(size_t)tri * STRIDE + k],
+                                   (unsigned long long)s_vals[slot * N + k]);
+      else atomicAdd(&acc_img[(size_t)tri * STRIDE + k], s_vals[slot * N + k]);
+    }
   }
 }
 
@@ -164,10 +183,10 @@ __global__ __launch_bounds__(kRunThreads, Fn::kMinWavesPerSimd) void k_accumulat
 #ifndef MR_PROBE_ROWS
 #define MR_PROBE_ROWS 0
 #endif
-template <class Fn>
+template <class Fn, bool DET>
 __global__ __launch_bounds__(kRunThreads, Fn::kMinWavesPerSimd) void k_accumulate_rows(
     Fn fn, int T, int W, int H, int regions_x, int regions_per_image, int n_regions,
-    int regions_per_xcd, float *__restrict__ acc) {
+    int regions_per_xcd, float *__restrict__ acc, const float *__restrict__ det_scale) {
   constexpr int N = Fn::kN, STRIDE = Fn::kStride, F = Fn::kFactorStride;
   static_assert(F % 4 == 0 && Fn::kFactors <= F && N <= kWave && N <= STRIDE, "row layout");
   // 7 spare rows: the last, partial batch of a segment may read (never use) rows 64..70
@@ -189,6 +208,8 @@ __global__ __launch_bounds__(kRunThreads, Fn::kMinWavesPerSimd) void k_accumulat
   const int y_begin = ry * kRunRegionH + wave * kRunRowsPerWave;
   const int y_end = min(y_begin + kRunRowsPerWave, H);
   float *acc_img = acc + (size_t)img * T * STRIDE;
+  long long *acc_fixed = (long long *)acc + (size_t)img * T * STRIDE;  // DET: 8-byte elements
+  const float to_fixed = DET ? det_scale[0] : 0.0f;
   float *stage = s_stage[wave];
   int ia, ib;  // the two factors whose product this lane sums (lanes >= N idle along)
   Fn::factor_pair(min(lane, N - 1), ia, ib);
@@ -275,7 +296,10 @@ __global__ __launch_bounds__(kRunThreads, Fn::kMinWavesPerSimd) void k_accumulat
       // One contiguous N-lane atomic per segment.  Parking partials in registers to merge a
       // triangle's consecutive rows first was measured SLOWER (0.64 -> 0.69 ms with 6 slots):
       // the scalar bookkeeping costs more than the L2 atomics it saves.
-      if (lane < N) atomicAdd(&acc_img[(size_t)t * STRIDE + lane], sum);
+      if (lane < N) {
+        if (DET) atomic_add_fixed(&acc_fixed[(size_t)t * STRIDE + lane], sum, to_fixed);
+        else atomicAdd(&acc_img[(size_t)t * STRIDE + lane], sum);
+      }
 #endif
     }
     __builtin_amdgcn_wave_barrier();
@@ -283,17 +307,24 @@ __global__ __launch_bounds__(kRunThreads, Fn::kMinWavesPerSimd) void k_accumulat
   fn.end_image(img, image_sums);
 }
 
+// det_scale: nullptr = float atomics; else the device pair (2^k, 2^-k) of the deterministic mode and
+// `acc` holds 8-byte fixed-point elements.
 template <class Fn>
 inline int launch_accumulate_rows(const Fn &fn, int B, int T, int W, int H, float *acc,
-                                  hipStream_t s) {
+                                  hipStream_t s, const float *det_scale = nullptr) {
   const int regions_x = (W + kWave - 1) / kWave;
   const int regions_y = (H + kRunRegionH - 1) / kRunRegionH;
   const int per_image = regions_x * regions_y;
   const int n_regions = per_image * B;
   const int per_xcd = (n_regions + kXcds - 1) / kXcds;
-  hipLaunchKernelGGL((k_accumulate_rows<Fn>), dim3((unsigned)(per_xcd * kXcds)),
-                     dim3(kRunThreads), 0, s, fn, T, W, H, regions_x, per_image, n_regions,
-                     per_xcd, acc);
+  if (det_scale)
+    hipLaunchKernelGGL((k_accumulate_rows<Fn, true>), dim3((unsigned)(per_xcd * kXcds)),
+                       dim3(kRunThreads), 0, s, fn, T, W, H, regions_x, per_image, n_regions,
+                       per_xcd, acc, det_scale);
+  else
+    hipLaunchKernelGGL((k_accumulate_rows<Fn, false>), dim3((unsigned)(per_xcd * kXcds)),
+                       dim3(kRunThreads), 0, s, fn, T, W, H, regions_x, per_image, n_regions,
+                       per_xcd, acc, det_scale);
   return check_launch();
 }
 
@@ -305,9 +336,24 @@ inline int launch_accumulate_runs(const Fn &fn, int B, int T, int W, int H, floa
   const int per_image = regions_x * regions_y;
   const int n_regions = per_image * B;
   const int per_xcd = (n_regions + kXcds - 1) / kXcds;
-  hipLaunchKernelGGL((k_accumulate_runs<Fn>), dim3((unsigned)(per_xcd * kXcds)),
+  hipLaunchKernelGGL((k_accumulate_runs<Fn, false>), dim3((unsigned)(per_xcd * kXcds)),
                      dim3(kRunThreads), 0, s, fn, T, W, H, regions_x, per_image, n_regions,
-                     per_xcd, acc);
+                     per_xcd, acc, (const float *)nullptr);
+  return check_launch();
+}
+
+// Deterministic mode: `acc` holds 8-byte fixed-point elements, det_scale = device (2^k, 2^-k).
+template <class Fn>
+inline int launch_accumulate_runs_fixed(const Fn &fn, int B, int T, int W, int H, float *acc,
+                                        const float *det_scale, hipStream_t s) {
+  const int regions_x = (W + kWave - 1) / kWave;
+  const int regions_y = (H + kRunRegionH - 1) / kRunRegionH;
+  const int per_image = regions_x * regions_y;
+  const int n_regions = per_image * B;
+  const int per_xcd = (n_regions + kXcds - 1) / kXcds;
+  hipLaunchKernelGGL((k_accumulate_runs<Fn, true>), dim3((unsigned)(per_xcd * kXcds)),
+                     dim3(kRunThreads), 0, s, fn, T, W, H, regions_x, per_image, n_regions,
+                     per_xcd, acc, det_scale);
   return check_launch();
 }
 

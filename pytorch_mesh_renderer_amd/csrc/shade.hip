@@ -194,6 +194,8 @@ struct ShadeGradFn {
   Lights lights;
   float *__restrict__ light_grads;    // [B][L*6 + 3]: dpos (L x 3), dcol (L x 3), dambient (3)
   int T_, W, H;
+  long long *__restrict__ light_fixed;   // deterministic mode: the same sums in fixed point, else nullptr
+  const float *__restrict__ det_scale;   // deterministic mode: (2^k, 2^-k), see run_accum.h
 
   struct Pixel {
     F3 b, g;
@@ -349,11 +351,16 @@ struct ShadeGradFn {
 
   __device__ __forceinline__ void end_image(int img, Image &im) const {
     float *dst = light_grads + (size_t)img * (L * 6 + 3);
+    long long *dst_fixed = light_fixed ? light_fixed + (size_t)img * (L * 6 + 3) : nullptr;
+    const float to_fixed = light_fixed ? det_scale[0] : 0.0f;
     const int lane = lane_id();
     auto reduce_add = [&](float v, int slot) {
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-      if (lane == 0 && v != 0.0f) atomicAdd(&dst[slot], v);
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);  // fixed tree: deterministic
+      if (lane == 0 && v != 0.0f) {
+        if (dst_fixed) atomic_add_fixed(&dst_fixed[slot], v, to_fixed);
+        else atomicAdd(&dst[slot], v);
+      }
     };
 #pragma unroll
     for (int l = 0; l < L; ++l) {
@@ -410,10 +417,11 @@ __global__ __launch_bounds__(kThreads) void k_shade_scatter(
 // of the triangles incident to its vertex (CSR adjacency built once per triangle array on the
 // host side: entry e = 3 * triangle + corner, grouped by vertex).  No atomics, every output is
 // written exactly once, the summation order is fixed.
+template <bool DET>
 __global__ __launch_bounds__(kThreads) void k_shade_gather(
-    const float *__restrict__ acc, const int32_t *__restrict__ offsets, const int32_t *__restrict__ entries,
-    int B, int V, int T, float *__restrict__ dnormals, float *__restrict__ dpositions,
-    float *__restrict__ ddiffuse, float *__restrict__ dclip) {
+    const float *__restrict__ acc, const float *__restrict__ det_scale, const int32_t *__restrict__ offsets,
+    const int32_t *__restrict__ entries, int B, int V, int T, float *__restrict__ dnormals,
+    float *__restrict__ dpositions, float *__restrict__ ddiffuse, float *__restrict__ dclip) {
   const long gid = (long)blockIdx.x * kThreads + threadIdx.x;
   if (gid >= (long)B * V) return;
   const int b = (int)(gid / V);
@@ -423,11 +431,20 @@ __global__ __launch_bounds__(kThreads) void k_shade_gather(
   for (int i = offsets[v]; i < e1; ++i) {
     const int e = entries[i];
     const int t = e / 3, k = e - 3 * t;
-    const float *row = acc + ((size_t)b * T + t) * 36;
+    if (DET) {  // fixed-point rows (8-byte elements) back to float, then the same fixed-order sums
+      const long long *row = (const long long *)acc + ((size_t)b * T + t) * 36;
+      const float from_fixed = det_scale[1];
 #pragma unroll
-    for (int j = 0; j < 9; ++j) a[j] += row[k * 9 + j];
+      for (int j = 0; j < 9; ++j) a[j] += (float)row[k * 9 + j] * from_fixed;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) c[j] += row[27 + k * 3 + j];
+      for (int j = 0; j < 3; ++j) c[j] += (float)row[27 + k * 3 + j] * from_fixed;
+    } else {
+      const float *row = acc + ((size_t)b * T + t) * 36;
+#pragma unroll
+      for (int j = 0; j < 9; ++j) a[j] += row[k * 9 + j];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) c[j] += row[27 + k * 3 + j];
+    }
   }
   const size_t v3 = (size_t)gid * 3;
 #pragma unroll
@@ -445,7 +462,41 @@ inline unsigned capped_blocks(size_t n) {
   return (unsigned)(want < cap ? (want ? want : 1) : cap);
 }
 
-inline size_t shade_acc_bytes(int B, int T) { return align_up((size_t)B * T * 36 * sizeof(float), 256); }
+// 8 bytes per element: room for the deterministic mode's fixed-point accumulators
+inline size_t shade_acc_bytes(int B, int T) { return align_up((size_t)B * T * 36 * sizeof(long long), 256); }
+constexpr size_t kDetMiscBytes = 512;  // det_scale (2 floats), max bits (1 int)
+inline size_t light_fixed_bytes(int B) { return align_up((size_t)B * (kMaxLights * 6 + 3) * sizeof(long long), 256); }
+
+// ---- deterministic mode helpers -------------------------------------------------------------
+// largest |x| of an array as float bits (non-negative floats order like integers; a NaN sorts on top)
+__global__ __launch_bounds__(kThreads) void k_abs_max(const float4 *__restrict__ x, size_t n4, int *__restrict__ max_bits) {
+  int best = 0;
+  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n4; i += (size_t)gridDim.x * kThreads) {
+    const float4 v = x[i];
+    best = max(max(best, __float_as_int(fabsf(v.x))), max(__float_as_int(fabsf(v.y)), __float_as_int(fabsf(v.z))));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) best = max(best, __shfl_down(best, off));
+  if ((threadIdx.x & (kWave - 1)) == 0 && best != 0) atomicMax(max_bits, best);
+}
+
+// (2^k, 2^-k) with k such that the largest upstream gradient maps to about 2^41
+__global__ void k_det_scale(const int *__restrict__ max_bits, const float *__restrict__ sign_scale,
+                            float *__restrict__ det_scale) {
+  const float g = sign_scale ? fabsf(sign_scale[0] * sign_scale[1]) : __int_as_float(max_bits[0]);
+  int e = 0;
+  if (g > 0.0f && g < INFINITY) (void)frexpf(g, &e);  // g = m * 2^e, m in [0.5, 1)
+  const int k = min(max(41 - e, -100), 100);
+  det_scale[0] = ldexpf(1.0f, k);
+  det_scale[1] = ldexpf(1.0f, -k);
+}
+
+__global__ __launch_bounds__(kThreads) void k_light_from_fixed(const long long *__restrict__ fixed,
+                                                               const float *__restrict__ det_scale, int n,
+                                                               float *__restrict__ out) {
+  const int i = (int)(blockIdx.x * kThreads + threadIdx.x);
+  if (i < n) out[i] = (float)fixed[i] * det_scale[1];
+}
 
 inline size_t corner_bytes(int B, int T) { return align_up((size_t)B * T * sizeof(CornerRec), 256); }
 
@@ -489,8 +540,11 @@ int launch_shade_forward(const int32_t *ids, const float *bary, const float *nor
 
 size_t shade_backward_ws(int B, int V, int T, int W, int H) {
   (void)V; (void)W; (void)H;
-  return shade_acc_bytes(B, T) + align_up((size_t)B * T * sizeof(BwdRec), 256) + corner_bytes(B, T);
+  return shade_acc_bytes(B, T) + align_up((size_t)B * T * sizeof(BwdRec), 256) + corner_bytes(B, T) +
+         light_fixed_bytes(B) + kDetMiscBytes;
 }
+
+thread_local int g_deterministic = 0;  // mr_set_deterministic
 
 int launch_shade_backward(const float *drgba, const uint8_t *signs, const float *sign_scale,
                           const int32_t *ids, const float *bary,
@@ -523,8 +577,25 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
   float *acc = (float *)ws;
   BwdRec *recs = (BwdRec *)((char *)ws + shade_acc_bytes(B, T));
   CornerRec *corners = (CornerRec *)((char *)recs + align_up((size_t)B * T * sizeof(BwdRec), 256));
-  if (hipMemsetAsync(acc, 0, (size_t)B * T * 36 * sizeof(float), s) != hipSuccess) return check_launch();
-  int rc = launch_bwd_setup(clip, tris, B, V, T, recs, s);
+  long long *light_fixed = (long long *)((char *)corners + corner_bytes(B, T));
+  float *det_scale = (float *)((char *)light_fixed + light_fixed_bytes(B));
+  int *max_bits = (int *)(det_scale + 4);
+  const bool det = g_deterministic != 0;
+  if (det && !(vertex_offsets && vertex_entries)) return MR_EINVAL;  // the scatter path is atomics only
+  const size_t acc_bytes = (size_t)B * T * 36 * (det ? sizeof(long long) : sizeof(float));
+  if (hipMemsetAsync(acc, 0, acc_bytes, s) != hipSuccess) return check_launch();
+  int rc = MR_OK;
+  if (det) {
+    if (hipMemsetAsync(light_fixed, 0, light_fixed_bytes(B) + kDetMiscBytes, s) != hipSuccess) return check_launch();
+    if (!signs) {
+      const size_t n4 = (size_t)B * H * W;
+      hipLaunchKernelGGL(k_abs_max, dim3(capped_blocks(n4)), dim3(kThreads), 0, s, (const float4 *)drgba, n4, max_bits);
+      if ((rc = check_launch()) != MR_OK) return rc;
+    }
+    hipLaunchKernelGGL(k_det_scale, dim3(1), dim3(1), 0, s, max_bits, sign_scale, det_scale);
+    if ((rc = check_launch()) != MR_OK) return rc;
+  }
+  rc = launch_bwd_setup(clip, tris, B, V, T, recs, s);
   if (rc != MR_OK) return rc;
   if (corner_records) {  // the forward's records (same inputs): skip the gather
     corners = (CornerRec *)corner_records;
@@ -538,12 +609,13 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
     KernelTimer timer(MR_TIMER_SHADE_BACKWARD, s);                                              \
     if (signs) {                                                                                \
       ShadeGradFn<NL, true> fn{nullptr, signs, sign_scale, ids, (const F3 *)bary, corners, recs, \
-                               lights, light_grads, T, W, H};                                   \
-      rc = launch_accumulate_rows(fn, B, T, W, H, acc, s);                                      \
+                               lights, light_grads, T, W, H, det ? light_fixed : nullptr, det_scale}; \
+      rc = launch_accumulate_rows(fn, B, T, W, H, acc, s, det ? det_scale : nullptr);           \
     } else {                                                                                    \
       ShadeGradFn<NL, false> fn{(const float4 *)drgba, nullptr, nullptr, ids, (const F3 *)bary, \
-                                corners, recs, lights, light_grads, T, W, H};                   \
-      rc = launch_accumulate_rows(fn, B, T, W, H, acc, s);                                      \
+                                corners, recs, lights, light_grads, T, W, H,                    \
+                                det ? light_fixed : nullptr, det_scale};                        \
+      rc = launch_accumulate_rows(fn, B, T, W, H, acc, s, det ? det_scale : nullptr);           \
     }                                                                                           \
   }
   switch (L) {
@@ -557,8 +629,18 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
   if (rc != MR_OK) return rc;
   if (vertex_offsets && vertex_entries) {
     const long nbv = (long)B * V;
-    hipLaunchKernelGGL(k_shade_gather, dim3((unsigned)((nbv + kThreads - 1) / kThreads)), dim3(kThreads), 0,
-                       s, acc, vertex_offsets, vertex_entries, B, V, T, dnormals, dpositions, ddiffuse, dclip);
+    const dim3 grid((unsigned)((nbv + kThreads - 1) / kThreads));
+    if (det) {
+      hipLaunchKernelGGL(k_shade_gather<true>, grid, dim3(kThreads), 0, s, acc, det_scale, vertex_offsets,
+                         vertex_entries, B, V, T, dnormals, dpositions, ddiffuse, dclip);
+      if ((rc = check_launch()) != MR_OK) return rc;
+      const int n_light = B * (L * 6 + 3);
+      hipLaunchKernelGGL(k_light_from_fixed, dim3((unsigned)((n_light + kThreads - 1) / kThreads)), dim3(kThreads),
+                         0, s, light_fixed, det_scale, n_light, light_grads);
+    } else {
+      hipLaunchKernelGGL(k_shade_gather<false>, grid, dim3(kThreads), 0, s, acc, det_scale, vertex_offsets,
+                         vertex_entries, B, V, T, dnormals, dpositions, ddiffuse, dclip);
+    }
     return check_launch();
   }
   const long nbt = (long)B * T;

@@ -183,3 +183,36 @@ def test_config5_soft_renderer_full_batch(device):
     (want * wts).sum().backward()
     (got * wts.to(device)).sum().backward()
     assert_close_abs_and_rel(vg.grad.cpu().numpy(), vc.grad.numpy(), "config5 d/dvertices (96x96)", rel=5e-3)
+
+
+def test_deterministic_mode_is_bit_reproducible_at_configs2(device):
+    """mr_set_deterministic: the reference accumulates sequentially and is reproducible
+    (rasterize_triangles.cpp:156-157, 232-269); with the flag set, two runs of the benchmarked step
+    (configs[2], render + L1 + backward) and of the rasterizer backward give IDENTICAL bits, and the
+    values agree with the default float-atomic kernels far inside the parity tolerance."""
+    sys.path.insert(0, ROOT)
+    import bench
+    _, batch, width, height, k = bench.CONFIGS["c3"]
+    job = synthetic.sphere_job(batch, width, height, k)
+    step, vertices, state = bench.make_step(job, device, None)
+    step()
+    default_grad = vertices.grad.detach().clone()
+    clip_d, tris_d = job["clip"].to(device), job["triangles"].to(device)
+    ids, bary, _ = _native.rasterize_forward(clip_d, tris_d, width, height)
+    dbary = torch.stack([seeded_dbary((height, width, 3), seed=b) for b in range(batch)]).to(device)
+    default_dclip = _native.rasterize_backward(dbary, clip_d, tris_d, ids, bary)
+    before = _native.set_deterministic(True)
+    try:
+        runs = []
+        for _ in range(2):
+            loss = step()
+            runs.append((float(loss), vertices.grad.detach().clone(),
+                         _native.rasterize_backward(dbary, clip_d, tris_d, ids, bary)))
+    finally:
+        _native.set_deterministic(before)
+    assert runs[0][0] == runs[1][0]
+    assert torch.equal(runs[0][1], runs[1][1]), "vertex gradients differ between two deterministic runs"
+    assert torch.equal(runs[0][2], runs[1][2]), "rasterizer backward differs between two deterministic runs"
+    assert_close_abs_and_rel(runs[0][1].cpu().numpy(), default_grad.cpu().numpy(), "deterministic vs default step", rel=1e-4)
+    assert_close_abs_and_rel(runs[0][2].cpu().numpy(), default_dclip.cpu().numpy(), "deterministic vs default raster bwd",
+                             rel=1e-4)
