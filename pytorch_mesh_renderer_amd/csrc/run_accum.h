@@ -183,6 +183,9 @@ __global__ __launch_bounds__(kRunThreads, DET ? 1 : Fn::kMinWavesPerSimd) void k
 #ifndef MR_PROBE_ROWS
 #define MR_PROBE_ROWS 0
 #endif
+#ifndef MR_ROWS_MERGE_SLOTS
+#define MR_ROWS_MERGE_SLOTS 16  // per-wavefront merge table of k_accumulate_rows (0: commit every segment)
+#endif
 template <class Fn, bool DET>
 __global__ __launch_bounds__(kRunThreads, Fn::kMinWavesPerSimd) void k_accumulate_rows(
     Fn fn, int T, int W, int H, int regions_x, int regions_per_image, int n_regions,
@@ -191,6 +194,15 @@ __global__ __launch_bounds__(kRunThreads, Fn::kMinWavesPerSimd) void k_accumulat
   static_assert(F % 4 == 0 && Fn::kFactors <= F && N <= kWave && N <= STRIDE, "row layout");
   // 7 spare rows: the last, partial batch of a segment may read (never use) rows 64..70
   __shared__ __attribute__((aligned(16))) float s_stage[kRunThreads / kWave][(kWave + 8) * F];
+  // Per-wavefront merge table: a triangle's segments of consecutive rows are summed here, in LDS,
+  // and leave as ONE N-lane global atomic per (wavefront, triangle) instead of one per (row,
+  // segment).  Global float atomics run at one wave-instruction per ~50 ns per CU whatever their
+  // width (MI355X_MICROARCH.md): at 1024^2 x 32 the ~3.5 commits per 64-pixel row were 7000 of them
+  // per CU -- as long as the kernel itself.  The table is private to its wavefront (LDS executes a
+  // wavefront's operations in order: plain read-add-write, no LDS atomics); lane i of `merge_keys`
+  // holds the triangle id of slot i, so a lookup is one compare + ballot.
+  constexpr int kMergeSlots = MR_ROWS_MERGE_SLOTS;
+  __shared__ float s_merge[kRunThreads / kWave][kMergeSlots > 0 ? kMergeSlots * N : 1];
 
   const int region = xcd_contiguous_block((int)blockIdx.x, n_regions, regions_per_xcd);
   if (region < 0) return;
@@ -214,6 +226,22 @@ __global__ __launch_bounds__(kRunThreads, Fn::kMinWavesPerSimd) void k_accumulat
   int ia, ib;  // the two factors whose product this lane sums (lanes >= N idle along)
   Fn::factor_pair(min(lane, N - 1), ia, ib);
   const float *col_a = stage + ia, *col_b = stage + ib;
+
+  float *merge = s_merge[wave];
+  int merge_keys = -1;   // lane i < kMergeSlots: triangle id held by slot i (-1: free)
+  int merge_count = 0;   // slots in use, wave-uniform
+  auto commit = [&](const int t, const float v) {  // one contiguous N-lane atomic into the triangle's row
+    if (lane < N) {
+      if (DET) atomic_add_fixed(&acc_fixed[(size_t)t * STRIDE + lane], v, to_fixed);
+      else atomicAdd(&acc_img[(size_t)t * STRIDE + lane], v);
+    }
+  };
+  auto flush_merge_table = [&]() {
+    for (int slot = 0; slot < merge_count; ++slot)
+      commit(__builtin_amdgcn_readlane(merge_keys, slot), merge[slot * N + min(lane, N - 1)]);
+    merge_count = 0;
+    merge_keys = -1;
+  };
 
   typename Fn::Image image_sums;
   fn.begin_image(img, image_sums);
@@ -260,6 +288,11 @@ __global__ __launch_bounds__(kRunThreads, Fn::kMinWavesPerSimd) void k_accumulat
       const unsigned long long stop = (heads | ~valids) & after;
       const int p1 = stop ? __builtin_ctzll(stop) : kWave;
       const int t = __builtin_amdgcn_readlane(my_tri, p0);
+      // the triangle's slot in the merge table, its running sum requested before the reduction
+      const unsigned hit = kMergeSlots > 0 ? (unsigned)__ballot(merge_keys == t) : 0u;
+      const int hit_slot = hit ? __builtin_ctz(hit) : 0;
+      float merged = 0.0f;
+      if (hit) merged = merge[hit_slot * N + min(lane, N - 1)];
       float sum = 0.0f;
       // batches of 8 pixels: 16 independent LDS reads in flight, one FMA per pixel
       int pb = p0;
@@ -293,17 +326,21 @@ __global__ __launch_bounds__(kRunThreads, Fn::kMinWavesPerSimd) void k_accumulat
 #if MR_PROBE_ROWS == 1  // timing probe: reduction but no global atomics
       if (lane < N && sum == 123.456f) atomicAdd(&acc_img[(size_t)t * STRIDE + lane], sum);
 #else
-      // One contiguous N-lane atomic per segment.  Parking partials in registers to merge a
-      // triangle's consecutive rows first was measured SLOWER (0.64 -> 0.69 ms with 6 slots):
-      // the scalar bookkeeping costs more than the L2 atomics it saves.
-      if (lane < N) {
-        if (DET) atomic_add_fixed(&acc_fixed[(size_t)t * STRIDE + lane], sum, to_fixed);
-        else atomicAdd(&acc_img[(size_t)t * STRIDE + lane], sum);
+      if (kMergeSlots == 0) {
+        commit(t, sum);  // one contiguous N-lane atomic per segment
+      } else if (hit) {
+        if (lane < N) merge[hit_slot * N + lane] = merged + sum;
+      } else {
+        if (merge_count == kMergeSlots) flush_merge_table();  // full: everything leaves, start over
+        if (lane == merge_count) merge_keys = t;
+        if (lane < N) merge[merge_count * N + lane] = sum;
+        merge_count += 1;
       }
 #endif
     }
     __builtin_amdgcn_wave_barrier();
   }
+  flush_merge_table();
   fn.end_image(img, image_sums);
 }
 

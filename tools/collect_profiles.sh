@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_final
 rm -rf "$OUT" && mkdir -p "$OUT"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- \
-    python3 bench.py --steps 10 --warmup 3 > "$OUT/bench_under_rocprof.log" 2>&1
+    python3 bench.py --steps 20 --warmup 3 --cpu-sample 0 > "$OUT/bench_under_rocprof.log" 2>&1
 for counter in WRITE_SIZE FETCH_SIZE; do
   timeout -k 10 400 rocprofv3 --kernel-trace --pmc $counter --output-format csv -d "$OUT/pmc_$counter" -o run -- \
       python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 > "$OUT/pmc_$counter.log" 2>&1

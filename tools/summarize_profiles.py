@@ -4,7 +4,8 @@
 
 Writes profiles/<tag>_bench_kernel_stats.csv (rocprofv3 --stats, top kernels),
 profiles/<tag>_bench.json (the bench lines of the same box) and rewrites
-profiles/raster_traffic.json (HBM bytes per k_raster launch from the PMC passes; read by bench.py).
+profiles/kernel_traffic.json (HBM bytes per launch of k_raster and of the shading backward from the PMC
+passes; read by bench.py, which labels it as an offline value).
 """
 import csv, glob, json, os, sys
 
@@ -53,20 +54,28 @@ for counter in ("WRITE_SIZE", "FETCH_SIZE"):
         if v:
             raw[k][counter] = sum(v) / len(v)
             raw[k]["launches_" + counter] = len(v)
-kr = raw["k_raster"]
 bench = lines.get("bench", {})
-out = {
-    "kernel": "k_raster",
+
+
+def traffic(entry):
     # gfx950: WRITE_SIZE counts KB as is, FETCH_SIZE is doubled (MI355X_MICROARCH.md, HBM section)
-    "bytes_per_launch": int(round((kr["WRITE_SIZE"] + 2.0 * kr["FETCH_SIZE"]) * 1024)),
-    "how": "rocprofv3 --kernel-trace --pmc WRITE_SIZE and --pmc FETCH_SIZE in separate passes over "
-           "`python3 bench.py --steps 3 --warmup 1 --cpu-sample 0` (tools/collect_profiles.sh), averaged over "
-           "the k_raster dispatches; bytes = (WRITE_SIZE + 2*FETCH_SIZE) * 1024 (FETCH_SIZE doubled as "
-           "MI355X_MICROARCH.md prescribes for gfx950; WRITE_SIZE is exact for k_shade_forward's 16-B "
-           "stores in the same run: 524288 KB = 537 MB)",
-    "raw": raw,
-    "algorithmic_bytes": bench.get("roofline", {}).get("algorithmic_bytes"),
+    return int(round((entry.get("WRITE_SIZE", 0.0) + 2.0 * entry.get("FETCH_SIZE", 0.0)) * 1024))
+
+
+out = {
+    "command": "python3 bench.py --steps 3 --warmup 1 --cpu-sample 0",
     "tag": tag,
+    "how": "rocprofv3 --kernel-trace --pmc WRITE_SIZE and --pmc FETCH_SIZE in separate passes over the command "
+           "(tools/collect_profiles.sh), averaged over each kernel's dispatches; bytes = (WRITE_SIZE + "
+           "2*FETCH_SIZE) * 1024 (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; WRITE_SIZE is "
+           "exact for k_shade_forward's 16-B stores in the same run: 524288 KB = 537 MB)",
+    "kernels": {
+        "k_raster": {"bytes_per_launch": traffic(raw["k_raster"]),
+                     "algorithmic_bytes": bench.get("roofline", {}).get("algorithmic_bytes")},
+        "shade_backward": {"bytes_per_launch": traffic(raw["ShadeGradFn"]),
+                           "algorithmic_bytes": bench.get("roofline_shade_backward", {}).get("algorithmic_bytes")},
+    },
+    "raw": raw,
 }
-json.dump(out, open(os.path.join(prof, "raster_traffic.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(prof, "kernel_traffic.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k != "how"}, indent=1))
