@@ -186,14 +186,43 @@ __global__ __launch_bounds__(kRunThreads, DET ? 1 : Fn::kMinWavesPerSimd) void k
 #ifndef MR_ROWS_MERGE_SLOTS
 #define MR_ROWS_MERGE_SLOTS 16  // per-wavefront merge table of k_accumulate_rows (0: commit every segment)
 #endif
+// 8-byte LDS reads for the transposed reduction, written as inline assembly: left to itself hipcc
+// pairs neighbouring 8-byte reads into ds_read2_b64, which moves 128 B/clk where ds_read_b64 moves
+// 256 B/clk (MI355X_MICROARCH.md, LDS table) -- exactly the factor the factor-major layout is for.
+// Each statement waits for its own reads (lgkmcnt(0)): outputs are valid when it ends.
+typedef float lds_v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned lds_address(const float *p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) float *)p;
+}
+__device__ __forceinline__ void lds_read_pair(unsigned addr_a, unsigned addr_b, lds_v2f &a, lds_v2f &b) {
+  asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(a), "=&v"(b) : "v"(addr_a), "v"(addr_b) : "memory");
+}
+__device__ __forceinline__ void lds_read_pairs4(unsigned addr_a, unsigned addr_b, lds_v2f (&a)[4], lds_v2f (&b)[4]) {
+  asm volatile(
+      "ds_read_b64 %0, %8\n\tds_read_b64 %4, %9\n\t"
+      "ds_read_b64 %1, %8 offset:8\n\tds_read_b64 %5, %9 offset:8\n\t"
+      "ds_read_b64 %2, %8 offset:16\n\tds_read_b64 %6, %9 offset:16\n\t"
+      "ds_read_b64 %3, %8 offset:24\n\tds_read_b64 %7, %9 offset:24\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3])
+      : "v"(addr_a), "v"(addr_b) : "memory");
+}
+
 template <class Fn, bool DET>
 __global__ __launch_bounds__(kRunThreads, Fn::kMinWavesPerSimd) void k_accumulate_rows(
     Fn fn, int T, int W, int H, int regions_x, int regions_per_image, int n_regions,
     int regions_per_xcd, float *__restrict__ acc, const float *__restrict__ det_scale) {
   constexpr int N = Fn::kN, STRIDE = Fn::kStride, F = Fn::kFactorStride;
   static_assert(F % 4 == 0 && Fn::kFactors <= F && N <= kWave && N <= STRIDE, "row layout");
-  // 7 spare rows: the last, partial batch of a segment may read (never use) rows 64..70
-  __shared__ __attribute__((aligned(16))) float s_stage[kRunThreads / kWave][(kWave + 8) * F];
+  // Parked factors, FACTOR-major: row f holds factor f of the wavefront's 64 pixels, so that a
+  // reducing lane fetches TWO consecutive pixels of its factor with one ds_read_b64 (256 B/clk
+  // instead of the 128 B/clk of ds_read_b32: the reduction is bound by LDS reads).  Row stride 74
+  // floats: consecutive rows start 10 banks apart (mod 64: 32 distinct even offsets), pairs never
+  // collide; 6 spare columns behind a row absorb the last batch's over-read.
+  constexpr int kRowStride = 74;
+  static_assert(Fn::kFactors <= 32, "bank layout of the parked rows: 32 distinct even bank offsets");
+  __shared__ __attribute__((aligned(16))) float s_stage[kRunThreads / kWave][Fn::kFactors * kRowStride];
   // Per-wavefront merge table: a triangle's segments of consecutive rows are summed here, in LDS,
   // and leave as ONE N-lane global atomic per (wavefront, triangle) instead of one per (row,
   // segment).  Global float atomics run at one wave-instruction per ~50 ns per CU whatever their
@@ -225,7 +254,8 @@ __global__ __launch_bounds__(kRunThreads, Fn::kMinWavesPerSimd) void k_accumulat
   float *stage = s_stage[wave];
   int ia, ib;  // the two factors whose product this lane sums (lanes >= N idle along)
   Fn::factor_pair(min(lane, N - 1), ia, ib);
-  const float *col_a = stage + ia, *col_b = stage + ib;
+  const unsigned row_a = lds_address(stage + ia * kRowStride), row_b = lds_address(stage + ib * kRowStride);
+  typedef lds_v2f v2f;
 
   float *merge = s_merge[wave];
   int merge_keys = -1;   // lane i < kMergeSlots: triangle id held by slot i (-1: free)
@@ -266,9 +296,8 @@ __global__ __launch_bounds__(kRunThreads, Fn::kMinWavesPerSimd) void k_accumulat
     if (valid) {
       float f[F];
       fn.factors(p, tri_data, f, image_sums);
-      float4 *row = (float4 *)(stage + lane * F);
 #pragma unroll
-      for (int q = 0; q < F / 4; ++q) row[q] = make_float4(f[4 * q], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3]);
+      for (int k = 0; k < Fn::kFactors; ++k) stage[k * kRowStride + lane] = f[k];
     }
     const int my_tri = valid ? tri : -1;
     // segment heads along x: a valid pixel whose left neighbour holds another id (or none)
@@ -294,33 +323,31 @@ __global__ __launch_bounds__(kRunThreads, Fn::kMinWavesPerSimd) void k_accumulat
       float merged = 0.0f;
       if (hit) merged = merge[hit_slot * N + min(lane, N - 1)];
       float sum = 0.0f;
-      // batches of 8 pixels: 16 independent LDS reads in flight, one FMA per pixel
-      int pb = p0;
+      int pb = p0 & ~1;  // pixel pairs: (pb, pb + 1), 8-byte aligned in every row
+      if (p0 & 1) {      // the segment starts on an odd pixel: only the pair's second element
+        v2f a, b;
+        lds_read_pair(row_a + 4u * pb, row_b + 4u * pb, a, b);
+        sum = a.y * b.y;
+        pb += 2;
+      }
+      // batches of 8 pixels: 8 independent 8-byte LDS reads in flight, one FMA per pixel
       for (; pb + 8 <= p1; pb += 8) {
-        float ra[8], rb[8];
+        v2f ra[4], rb[4];
+        lds_read_pairs4(row_a + 4u * pb, row_b + 4u * pb, ra, rb);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          ra[j] = col_a[(pb + j) * F];
-          rb[j] = col_b[(pb + j) * F];
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) sum = fmaf(ra[j], rb[j], sum);
+        for (int j = 0; j < 4; ++j) sum = fmaf(ra[j].y, rb[j].y, fmaf(ra[j].x, rb[j].x, sum));
       }
       if (pb < p1) {  // 1..7 pixels left: all reads are issued, a uniform switch uses the first r
-        float ra[8], rb[8];
-#pragma unroll
-        for (int j = 0; j < 7; ++j) {
-          ra[j] = col_a[(pb + j) * F];
-          rb[j] = col_b[(pb + j) * F];
-        }
+        v2f ra[4], rb[4];
+        lds_read_pairs4(row_a + 4u * pb, row_b + 4u * pb, ra, rb);
         switch (p1 - pb) {
-          case 7: sum = fmaf(ra[6], rb[6], sum); [[fallthrough]];
-          case 6: sum = fmaf(ra[5], rb[5], sum); [[fallthrough]];
-          case 5: sum = fmaf(ra[4], rb[4], sum); [[fallthrough]];
-          case 4: sum = fmaf(ra[3], rb[3], sum); [[fallthrough]];
-          case 3: sum = fmaf(ra[2], rb[2], sum); [[fallthrough]];
-          case 2: sum = fmaf(ra[1], rb[1], sum); [[fallthrough]];
-          default: sum = fmaf(ra[0], rb[0], sum);
+          case 7: sum = fmaf(ra[3].x, rb[3].x, sum); [[fallthrough]];
+          case 6: sum = fmaf(ra[2].y, rb[2].y, sum); [[fallthrough]];
+          case 5: sum = fmaf(ra[2].x, rb[2].x, sum); [[fallthrough]];
+          case 4: sum = fmaf(ra[1].y, rb[1].y, sum); [[fallthrough]];
+          case 3: sum = fmaf(ra[1].x, rb[1].x, sum); [[fallthrough]];
+          case 2: sum = fmaf(ra[0].y, rb[0].y, sum); [[fallthrough]];
+          default: sum = fmaf(ra[0].x, rb[0].x, sum);
         }
       }
 #if MR_PROBE_ROWS == 1  // timing probe: reduction but no global atomics
