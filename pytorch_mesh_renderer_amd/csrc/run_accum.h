@@ -292,10 +292,16 @@ __global__ __launch_bounds__(kRunThreads, Fn::kMinWavesPerSimd) void k_accumulat
       run_tri = tri;
       fn.load_triangle(img, tri, tri_data);
     }
-    // Rows of invalid pixels are never read back (segments consist of valid pixels only).
-    if (valid) {
+    // Every lane parks its factors; lanes without a covered pixel park zeros, so that a segment
+    // may simply run on to the next head: what lies between adds nothing.
+    {
       float f[F];
-      fn.factors(p, tri_data, f, image_sums);
+      if (valid) {
+        fn.factors(p, tri_data, f, image_sums);
+      } else {
+#pragma unroll
+        for (int k = 0; k < Fn::kFactors; ++k) f[k] = 0.0f;
+      }
 #pragma unroll
       for (int k = 0; k < Fn::kFactors; ++k) stage[k * kRowStride + lane] = f[k];
     }
@@ -309,62 +315,57 @@ __global__ __launch_bounds__(kRunThreads, Fn::kMinWavesPerSimd) void k_accumulat
 #if MR_PROBE_ROWS == 2  // timing probe: no transposed reduction, no atomics
     heads = 0;
 #endif
-    while (heads) {  // wave-uniform: ~3-4 segments per 64 pixels
-      const int p0 = __builtin_ctzll(heads);
-      heads &= heads - 1;
-      // the segment ends at the next head or at the first invalid pixel after p0
-      const unsigned long long after = ~0ull << p0;
-      const unsigned long long stop = (heads | ~valids) & after;
-      const int p1 = stop ? __builtin_ctzll(stop) : kWave;
-      const int t = __builtin_amdgcn_readlane(my_tri, p0);
-      // the triangle's slot in the merge table, its running sum requested before the reduction
-      const unsigned hit = kMergeSlots > 0 ? (unsigned)__ballot(merge_keys == t) : 0u;
-      const int hit_slot = hit ? __builtin_ctz(hit) : 0;
-      float merged = 0.0f;
-      if (hit) merged = merge[hit_slot * N + min(lane, N - 1)];
-      float sum = 0.0f;
-      int pb = p0 & ~1;  // pixel pairs: (pb, pb + 1), 8-byte aligned in every row
-      if (p0 & 1) {      // the segment starts on an odd pixel: only the pair's second element
-        v2f a, b;
-        lds_read_pair(row_a + 4u * pb, row_b + 4u * pb, a, b);
-        sum = a.y * b.y;
-        pb += 2;
-      }
-      // batches of 8 pixels: 8 independent 8-byte LDS reads in flight, one FMA per pixel
-      for (; pb + 8 <= p1; pb += 8) {
-        v2f ra[4], rb[4];
-        lds_read_pairs4(row_a + 4u * pb, row_b + 4u * pb, ra, rb);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) sum = fmaf(ra[j].y, rb[j].y, fmaf(ra[j].x, rb[j].x, sum));
-      }
-      if (pb < p1) {  // 1..7 pixels left: all reads are issued, a uniform switch uses the first r
-        v2f ra[4], rb[4];
-        lds_read_pairs4(row_a + 4u * pb, row_b + 4u * pb, ra, rb);
-        switch (p1 - pb) {
-          case 7: sum = fmaf(ra[3].x, rb[3].x, sum); [[fallthrough]];
-          case 6: sum = fmaf(ra[2].y, rb[2].y, sum); [[fallthrough]];
-          case 5: sum = fmaf(ra[2].x, rb[2].x, sum); [[fallthrough]];
-          case 4: sum = fmaf(ra[1].y, rb[1].y, sum); [[fallthrough]];
-          case 3: sum = fmaf(ra[1].x, rb[1].x, sum); [[fallthrough]];
-          case 2: sum = fmaf(ra[0].y, rb[0].y, sum); [[fallthrough]];
-          default: sum = fmaf(ra[0].x, rb[0].x, sum);
-        }
-      }
+    // ONE pass over the row's pixels in groups of eight (four 8-byte reads per factor): a group
+    // without a head is eight FMAs straight; only at a head (~3.5 per row) the running sum is
+    // closed -- into the merge table -- and restarted.  No per-segment loops, no masks, no tails.
+    int cur_t = -1;           // triangle of the running segment, wave-uniform
+    unsigned cur_hit = 0u;    // its merge-table slot (bit mask; 0: none yet) ...
+    float merged = 0.0f;      // ... and that slot's value, requested when the segment starts
+    float sum = 0.0f;
+    auto close_segment = [&]() {
+      if (cur_t < 0) return;
 #if MR_PROBE_ROWS == 1  // timing probe: reduction but no global atomics
-      if (lane < N && sum == 123.456f) atomicAdd(&acc_img[(size_t)t * STRIDE + lane], sum);
+      if (lane < N && sum == 123.456f) atomicAdd(&acc_img[(size_t)cur_t * STRIDE + lane], sum);
 #else
       if (kMergeSlots == 0) {
-        commit(t, sum);  // one contiguous N-lane atomic per segment
-      } else if (hit) {
-        if (lane < N) merge[hit_slot * N + lane] = merged + sum;
+        commit(cur_t, sum);  // one contiguous N-lane atomic per segment
+      } else if (cur_hit) {
+        if (lane < N) merge[__builtin_ctz(cur_hit) * N + lane] = merged + sum;
       } else {
         if (merge_count == kMergeSlots) flush_merge_table();  // full: everything leaves, start over
-        if (lane == merge_count) merge_keys = t;
+        if (lane == merge_count) merge_keys = cur_t;
         if (lane < N) merge[merge_count * N + lane] = sum;
         merge_count += 1;
       }
 #endif
+    };
+    auto open_segment = [&](const int pixel) {
+      close_segment();
+      cur_t = __builtin_amdgcn_readlane(my_tri, pixel);
+      cur_hit = kMergeSlots > 0 ? (unsigned)__ballot(merge_keys == cur_t) : 0u;
+      merged = cur_hit ? merge[__builtin_ctz(cur_hit) * N + min(lane, N - 1)] : 0.0f;
+      sum = 0.0f;
+    };
+    const int first_group = heads ? (int)(__builtin_ctzll(heads) >> 3) : 8;
+    const int last_group = valids ? (63 - (int)__builtin_clzll(valids)) >> 3 : -1;
+    for (int g = first_group; g <= last_group; ++g) {
+      v2f ra[4], rb[4];
+      lds_read_pairs4(row_a + 32u * g, row_b + 32u * g, ra, rb);
+      const unsigned hg = (unsigned)(heads >> (8 * g)) & 0xffu;
+      if (hg == 0u) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sum = fmaf(ra[j].y, rb[j].y, fmaf(ra[j].x, rb[j].x, sum));
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (hg & (1u << (2 * j))) open_segment(8 * g + 2 * j);
+          sum = fmaf(ra[j].x, rb[j].x, sum);
+          if (hg & (2u << (2 * j))) open_segment(8 * g + 2 * j + 1);
+          sum = fmaf(ra[j].y, rb[j].y, sum);
+        }
+      }
     }
+    close_segment();
     __builtin_amdgcn_wave_barrier();
   }
   flush_merge_table();
