@@ -267,6 +267,7 @@ __global__ __launch_bounds__(kRunThreads, Fn::kMinWavesPerSimd) void k_accumulat
     }
   };
   auto flush_merge_table = [&]() {
+#pragma unroll 1
     for (int slot = 0; slot < merge_count; ++slot)
       commit(__builtin_amdgcn_readlane(merge_keys, slot), merge[slot * N + min(lane, N - 1)]);
     merge_count = 0;
@@ -331,11 +332,12 @@ __global__ __launch_bounds__(kRunThreads, Fn::kMinWavesPerSimd) void k_accumulat
         commit(cur_t, sum);  // one contiguous N-lane atomic per segment
       } else if (cur_hit) {
         if (lane < N) merge[__builtin_ctz(cur_hit) * N + lane] = merged + sum;
-      } else {
-        if (merge_count == kMergeSlots) flush_merge_table();  // full: everything leaves, start over
+      } else if (merge_count < kMergeSlots) {  // (the table was emptied before the pass if it was short of room)
         if (lane == merge_count) merge_keys = cur_t;
         if (lane < N) merge[merge_count * N + lane] = sum;
         merge_count += 1;
+      } else {
+        commit(cur_t, sum);  // more segments in one row than the table has slots: straight out
       }
 #endif
     };
@@ -346,6 +348,9 @@ __global__ __launch_bounds__(kRunThreads, Fn::kMinWavesPerSimd) void k_accumulat
       merged = cur_hit ? merge[__builtin_ctz(cur_hit) * N + min(lane, N - 1)] : 0.0f;
       sum = 0.0f;
     };
+    // each head may claim a slot of the merge table: if they might not all fit, everything in the
+    // table leaves now (once per row at most, instead of a check per segment)
+    if (kMergeSlots > 0 && merge_count + (int)__builtin_popcountll(heads) > kMergeSlots) flush_merge_table();
     const int first_group = heads ? (int)(__builtin_ctzll(heads) >> 3) : 8;
     const int last_group = valids ? (63 - (int)__builtin_clzll(valids)) >> 3 : -1;
     for (int g = first_group; g <= last_group; ++g) {
