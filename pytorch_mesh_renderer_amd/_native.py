@@ -230,11 +230,23 @@ def _chk_lights(light_positions, light_intensities, ambient, B, max_lights):
     return L
 
 
+_WORKSPACE_LIMIT_BYTES = 64 << 30   # refuse absurd scratch requests instead of trying to allocate them
+
+
 def _workspace(dev, nbytes):
-    """Per-(device, stream) scratch tensor, grown on demand.  Reuse is safe because
-    every consumer is enqueued on the same stream."""
+    """Per-(device, stream) scratch tensor, grown on demand.  Reuse is safe because every consumer is
+    enqueued on the same stream.  While a stream is being captured into a HIP graph the scratch comes
+    from the capture's own memory pool and is NOT cached: a tensor of that pool must not outlive the
+    graph or be handed to eager launches.  At most one buffer per (device, stream) is kept; a
+    request beyond _WORKSPACE_LIMIT_BYTES (sizes: INTEGRATION.md, "Scratch memory") is an error."""
     if nbytes == 0:
         return None, 0
+    if nbytes > _WORKSPACE_LIMIT_BYTES:
+        raise RuntimeError("this call needs %.1f GiB of scratch memory (limit %.0f GiB): split the batch"
+                           % (nbytes / 2.0 ** 30, _WORKSPACE_LIMIT_BYTES / 2.0 ** 30))
+    if torch.cuda.is_current_stream_capturing():
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        return ws, ws.numel()
     key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
