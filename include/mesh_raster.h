@@ -202,20 +202,28 @@ int mr_shade_backward_l1(const uint8_t *signs, const float *upstream, const int3
  * G-buffer each way).  Additional arguments:
  *   specular         [B,V,3] f32  per-vertex specular colours
  *   camera_position  [B,3]   f32  world-space eye
- *   shininess        [B]     f32  one exponent per image (per-vertex exponents and exponents
- *                                 that need a gradient are not covered by this entry point)
+ *   shininess        [B] f32 one exponent per image, or, with shininess_per_vertex != 0,
+ *                    [B,V] f32 one per vertex (interpolated as a 13th attribute, render.py
+ *                                 :171-181, 222-224)
  *   norms2           [B,L]   f32  forward: out, sum over all pixels of (reflection . camera)^2;
  *                                 backward: in, the forward's values
  *   dspecular        [B,V,3] f32 out
- *   light_grads      [B, 6L+6] f32 out  per image: d light_positions (L x 3), d light_intensities
- *                                 (L x 3), d ambient (3; 0 if NULL), d camera_position (3) */
+ *   dshininess       [B,V]   f32 out  d per-vertex shininess; used (and required) only with
+ *                                 shininess_per_vertex != 0
+ *   light_grads      [B, 6L+7] f32 out  per image: d light_positions (L x 3), d light_intensities
+ *                                 (L x 3), d ambient (3; 0 if NULL), d camera_position (3),
+ *                                 d per-image shininess (1; 0 with per-vertex exponents)
+ * Only pixels that pass render()'s mask (render.py:215) evaluate the power; the reference's
+ * autograd multiplies the masked pixels' zero gradient by pow(0, -1) = inf of the background
+ * exponent -1 and returns NaN for every per-vertex-shininess call with a background pixel. */
 size_t mr_shade_specular_forward_workspace_bytes(int B, int V, int T, int W, int H);
 int mr_shade_specular_forward(const int32_t *ids, const float *bary, const float *normals,
                               const float *positions, const float *diffuse, const float *specular,
                               const int32_t *triangles, const float *light_positions,
                               const float *light_intensities, const float *ambient,
                               const float *camera_position, const float *shininess,
-                              int B, int V, int T, int W, int H, int L, float *rgba, float *norms2,
+                              int shininess_per_vertex, int B, int V, int T, int W, int H, int L,
+                              float *rgba, float *norms2,
                               void *workspace, size_t workspace_bytes, void *stream);
 size_t mr_shade_specular_backward_workspace_bytes(int B, int V, int T, int W, int H);
 int mr_shade_specular_backward(const float *drgba, const int32_t *ids, const float *bary,
@@ -224,10 +232,11 @@ int mr_shade_specular_backward(const float *drgba, const int32_t *ids, const flo
                                const int32_t *triangles, const float *light_positions,
                                const float *light_intensities, const float *ambient,
                                const float *camera_position, const float *shininess,
-                               const float *norms2, int B, int V, int T, int W, int H, int L,
-                               float *dclip, float *dnormals, float *dpositions, float *ddiffuse,
-                               float *dspecular, float *light_grads, void *workspace,
-                               size_t workspace_bytes, void *stream);
+                               int shininess_per_vertex, const float *norms2, int B, int V, int T,
+                               int W, int H, int L, float *dclip, float *dnormals, float *dpositions,
+                               float *ddiffuse, float *dspecular, float *dshininess,
+                               float *light_grads, void *workspace, size_t workspace_bytes,
+                               void *stream);
 
 /* ---- SoftRas renderer ---------------------------------------------------------------
  * Replaces rasterize_batch / rasterize of the reference's second renderer

@@ -16,7 +16,7 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 # build libmesh_raster_hip_probes.so this way); the product always loads the in-tree library.
 LIB_PATH = os.environ.get("MR_NATIVE_LIB_PATH") or os.path.join(_CSRC, "libmesh_raster_hip.so")
 
-ABI_VERSION = 310
+ABI_VERSION = 320
 TIMER_RASTER_FORWARD, TIMER_SHADE_BACKWARD, TIMER_SHADE_FORWARD, TIMER_RASTER_BACKWARD = 0, 1, 2, 3
 MR_OK, MR_EINVAL, MR_EWORKSPACE, MR_ELAUNCH = 0, -1, -2, -3
 _ERR = {MR_EINVAL: "invalid argument", MR_EWORKSPACE: "workspace too small or misaligned",
@@ -150,11 +150,11 @@ def lib():
         L.mr_interpolate_raster_backward.restype = ci
         L.mr_shade_specular_forward_workspace_bytes.argtypes = [ci] * 5
         L.mr_shade_specular_forward_workspace_bytes.restype = sz
-        L.mr_shade_specular_forward.argtypes = [vp] * 12 + [ci] * 6 + [vp, vp, vp, sz, vp]
+        L.mr_shade_specular_forward.argtypes = [vp] * 12 + [ci] * 7 + [vp, vp, vp, sz, vp]
         L.mr_shade_specular_forward.restype = ci
         L.mr_shade_specular_backward_workspace_bytes.argtypes = [ci] * 5
         L.mr_shade_specular_backward_workspace_bytes.restype = sz
-        L.mr_shade_specular_backward.argtypes = [vp] * 15 + [ci] * 6 + [vp] * 6 + [vp, sz, vp]
+        L.mr_shade_specular_backward.argtypes = [vp] * 14 + [ci, vp] + [ci] * 6 + [vp] * 7 + [vp, sz, vp]
         L.mr_shade_specular_backward.restype = ci
         L.mr_export_u8.argtypes = [vp, sz, vp, vp]
         L.mr_export_u8.restype = ci
@@ -228,6 +228,15 @@ def _chk_lights(light_positions, light_intensities, ambient, B, max_lights):
     if ambient is not None:
         _chk("ambient_color", ambient, _F32, B, 3)
     return L
+
+
+def _chk_shininess(shininess, B, V):
+    """[B] -> False (one exponent per image), [B,V] -> True (per vertex)."""
+    if torch.is_tensor(shininess) and shininess.dim() == 2:
+        _chk("shininess", shininess, _F32, B, V)
+        return True
+    _chk("shininess", shininess, _F32, B)
+    return False
 
 
 _WORKSPACE_LIMIT_BYTES = 64 << 30   # refuse absurd scratch requests instead of trying to allocate them
@@ -554,7 +563,8 @@ def shade_backward(drgba, ids, bary, clip, normals, positions, diffuse, triangle
 
 def shade_specular_forward(ids, bary, normals, positions, diffuse, specular, triangles, light_positions,
                            light_intensities, ambient, camera_position, shininess):
-    """Fused interpolation + Phong with the specular term -> (rgba [B,H,W,4], norms2 [B,L])."""
+    """Fused interpolation + Phong with the specular term -> (rgba [B,H,W,4], norms2 [B,L]).
+    shininess: [B] (one exponent per image) or [B,V] (per vertex)."""
     tensors = [ids, bary, normals, positions, diffuse, specular, triangles, light_positions,
                light_intensities, camera_position, shininess]
     _chk("triangles", triangles, _I32, None, 3)
@@ -565,7 +575,7 @@ def shade_specular_forward(ids, bary, normals, positions, diffuse, specular, tri
     _chk_gbuffer(ids, bary, B)
     _chk_lights(light_positions, light_intensities, ambient, B, shade_max_lights())
     _chk("camera_position", camera_position, _F32, B, 3)
-    _chk("shininess", shininess, _F32, B)
+    per_vertex = _chk_shininess(shininess, B, V)
     dev = _require_device(*(tensors + ([ambient] if ambient is not None else [])))
     L = lib()
     (ids, bary, normals, positions, diffuse, specular, triangles, light_positions, light_intensities,
@@ -581,8 +591,8 @@ def shade_specular_forward(ids, bary, normals, positions, diffuse, specular, tri
         rc = L.mr_shade_specular_forward(
             _ptr(ids), _ptr(bary), _ptr(normals), _ptr(positions), _ptr(diffuse), _ptr(specular),
             _ptr(triangles), _ptr(light_positions), _ptr(light_intensities), _ptr(ambient),
-            _ptr(camera_position), _ptr(shininess), B, V, T, W, H, nl, _ptr(rgba), _ptr(norms2),
-            _ptr(ws), have, _stream(dev))
+            _ptr(camera_position), _ptr(shininess), int(per_vertex), B, V, T, W, H, nl, _ptr(rgba),
+            _ptr(norms2), _ptr(ws), have, _stream(dev))
     _check(rc, "mr_shade_specular_forward")
     return rgba, norms2
 
@@ -591,7 +601,8 @@ def shade_specular_backward(drgba, ids, bary, clip, normals, positions, diffuse,
                             light_positions, light_intensities, ambient, camera_position, shininess,
                             norms2):
     """-> (dclip [B,V,4], dnormals, dpositions, ddiffuse, dspecular [B,V,3], dlight_positions,
-    dlight_intensities [B,L,3], dambient [B,3] or None, dcamera_position [B,3])."""
+    dlight_intensities [B,L,3], dambient [B,3] or None, dcamera_position [B,3], dshininess shaped
+    like shininess ([B] or [B,V]))."""
     tensors = [drgba, ids, bary, clip, normals, positions, diffuse, specular, triangles,
                light_positions, light_intensities, camera_position, shininess, norms2]
     B, V, _ = _chk_mesh(clip, triangles)
@@ -602,7 +613,7 @@ def shade_specular_backward(drgba, ids, bary, clip, normals, positions, diffuse,
     nl_ = _chk_lights(light_positions, light_intensities, ambient, B, shade_max_lights())
     _chk("upstream gradient", drgba, _F32, B, h, w, 4)
     _chk("camera_position", camera_position, _F32, B, 3)
-    _chk("shininess", shininess, _F32, B)
+    per_vertex = _chk_shininess(shininess, B, V)
     _chk("norms2", norms2, _F32, B, nl_)
     dev = _require_device(*(tensors + ([ambient] if ambient is not None else [])))
     L = lib()
@@ -613,7 +624,8 @@ def shade_specular_backward(drgba, ids, bary, clip, normals, positions, diffuse,
     V, T, nl = normals.shape[1], triangles.shape[0], light_positions.shape[1]
     dclip = torch.empty(B, V, 4, dtype=torch.float32, device=dev)
     dn, dp, dd, dsp = [torch.empty(B, V, 3, dtype=torch.float32, device=dev) for _ in range(4)]
-    lg = torch.empty(B, 6 * nl + 6, dtype=torch.float32, device=dev)
+    lg = torch.empty(B, 6 * nl + 7, dtype=torch.float32, device=dev)
+    dshin_v = torch.empty(B, V, dtype=torch.float32, device=dev) if per_vertex else None
     with torch.cuda.device(dev):
         need = L.mr_shade_specular_backward_workspace_bytes(B, V, T, W, H)
         ws, have = _workspace(dev, need)
@@ -621,14 +633,15 @@ def shade_specular_backward(drgba, ids, bary, clip, normals, positions, diffuse,
             _ptr(drgba), _ptr(ids), _ptr(bary), _ptr(clip), _ptr(normals), _ptr(positions),
             _ptr(diffuse), _ptr(specular), _ptr(triangles), _ptr(light_positions),
             _ptr(light_intensities), _ptr(ambient), _ptr(camera_position), _ptr(shininess),
-            _ptr(norms2), B, V, T, W, H, nl, _ptr(dclip), _ptr(dn), _ptr(dp), _ptr(dd), _ptr(dsp),
-            _ptr(lg), _ptr(ws), have, _stream(dev))
+            int(per_vertex), _ptr(norms2), B, V, T, W, H, nl, _ptr(dclip), _ptr(dn), _ptr(dp), _ptr(dd),
+            _ptr(dsp), _ptr(dshin_v), _ptr(lg), _ptr(ws), have, _stream(dev))
     _check(rc, "mr_shade_specular_backward")
     dlpos = lg[:, :3 * nl].reshape(B, nl, 3)
     dlint = lg[:, 3 * nl:6 * nl].reshape(B, nl, 3)
     damb = lg[:, 6 * nl:6 * nl + 3] if ambient is not None else None
-    dcam = lg[:, 6 * nl + 3:]
-    return dclip, dn, dp, dd, dsp, dlpos, dlint, damb, dcam
+    dcam = lg[:, 6 * nl + 3:6 * nl + 6]
+    dshin = dshin_v if per_vertex else lg[:, 6 * nl + 6]
+    return dclip, dn, dp, dd, dsp, dlpos, dlint, damb, dcam, dshin
 
 
 def soft_max_lights():

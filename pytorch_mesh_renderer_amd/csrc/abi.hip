@@ -30,7 +30,7 @@ extern thread_local int g_deterministic;
 
 extern "C" {
 
-int mr_version(void) { return 310; /* 0.3.1: deterministic mode, tone map, vertex normals, sign-coded shading backward */ }
+int mr_version(void) { return 320; /* 0.3.1: deterministic mode, tone map, vertex normals, sign-coded shading backward */ }
 
 int mr_last_hip_error(void) { return mr::g_last_hip_error; }
 
@@ -289,9 +289,10 @@ int mr_shade_specular_forward(const int32_t *ids, const float *bary, const float
                               const float *positions, const float *diffuse, const float *specular,
                               const int32_t *triangles, const float *light_positions,
                               const float *light_intensities, const float *ambient,
-                              const float *camera_position, const float *shininess, int B, int V,
-                              int T, int W, int H, int L, float *rgba, float *norms2, void *workspace,
-                              size_t workspace_bytes, void *stream) {
+                              const float *camera_position, const float *shininess,
+                              int shininess_per_vertex, int B, int V, int T, int W, int H, int L,
+                              float *rgba, float *norms2, void *workspace, size_t workspace_bytes,
+                              void *stream) {
   if (bad_dims(B, V, T, W, H) || T < 1 || V < 1 || L < 1 || L > mr::shade_max_lights())
     return MR_EINVAL;
   if (B == 0) return MR_OK;
@@ -302,7 +303,8 @@ int mr_shade_specular_forward(const int32_t *ids, const float *bary, const float
   if (rc != MR_OK) return rc;
   return mr::launch_shade_specular_forward(ids, bary, normals, positions, diffuse, specular, triangles,
                                            light_positions, light_intensities, ambient,
-                                           camera_position, shininess, B, V, T, W, H, L, rgba, norms2,
+                                           camera_position, shininess, shininess_per_vertex, B, V, T, W,
+                                           H, L, rgba, norms2,
                                            workspace, (hipStream_t)stream);
 }
 
@@ -317,24 +319,27 @@ int mr_shade_specular_backward(const float *drgba, const int32_t *ids, const flo
                                const int32_t *triangles, const float *light_positions,
                                const float *light_intensities, const float *ambient,
                                const float *camera_position, const float *shininess,
-                               const float *norms2, int B, int V, int T, int W, int H, int L,
-                               float *dclip, float *dnormals, float *dpositions, float *ddiffuse,
-                               float *dspecular, float *light_grads, void *workspace,
-                               size_t workspace_bytes, void *stream) {
+                               int shininess_per_vertex, const float *norms2, int B, int V, int T,
+                               int W, int H, int L, float *dclip, float *dnormals, float *dpositions,
+                               float *ddiffuse, float *dspecular, float *dshininess,
+                               float *light_grads, void *workspace, size_t workspace_bytes,
+                               void *stream) {
   if (bad_dims(B, V, T, W, H) || T < 1 || V < 1 || L < 1 || L > mr::shade_max_lights())
     return MR_EINVAL;
   if (B == 0) return MR_OK;
   if (!drgba || !ids || !bary || !clip || !normals || !positions || !diffuse || !specular ||
       !triangles || !light_positions || !light_intensities || !camera_position || !shininess ||
-      !norms2 || !dclip || !dnormals || !dpositions || !ddiffuse || !dspecular || !light_grads)
+      !norms2 || !dclip || !dnormals || !dpositions || !ddiffuse || !dspecular || !light_grads ||
+      (shininess_per_vertex && !dshininess))
     return MR_EINVAL;
   const int rc = check_ws(workspace, workspace_bytes, mr::shade_specular_backward_ws(B, V, T, W, H));
   if (rc != MR_OK) return rc;
   return mr::launch_shade_specular_backward(drgba, ids, bary, clip, normals, positions, diffuse,
                                             specular, triangles, light_positions, light_intensities,
-                                            ambient, camera_position, shininess, norms2, B, V, T, W,
-                                            H, L, dclip, dnormals, dpositions, ddiffuse, dspecular,
-                                            light_grads, workspace, (hipStream_t)stream);
+                                            ambient, camera_position, shininess, shininess_per_vertex,
+                                            norms2, B, V, T, W, H, L, dclip, dnormals, dpositions,
+                                            ddiffuse, dspecular, dshininess, light_grads, workspace,
+                                            (hipStream_t)stream);
 }
 
 int mr_soft_max_lights(void) { return mr::soft_max_lights(); }

@@ -9,6 +9,10 @@
 // (reads 1 B/px, writes 16 B/px).  Both are HBM-bound; 49 B/px in total instead of 80.
 #include "mr_internal.h"
 
+#ifndef MR_L1_REVERSE
+#define MR_L1_REVERSE 1
+#endif
+
 namespace mr {
 namespace {
 
@@ -27,7 +31,14 @@ __global__ __launch_bounds__(kThreads) void k_l1_forward(const float4 *__restric
                                                          float inv_n, float *__restrict__ partials,
                                                          uint8_t *__restrict__ signs) {
   float s = 0.f;
-  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n4; i += (size_t)gridDim.x * kThreads) {
+  for (size_t j = (size_t)blockIdx.x * kThreads + threadIdx.x; j < n4; j += (size_t)gridDim.x * kThreads) {
+#if MR_L1_REVERSE
+    // back to front: the tail of `a` is what the producer (the renderer) wrote last, so part of it
+    // is still in the 256 MB Infinity Cache
+    const size_t i = n4 - 1 - j;
+#else
+    const size_t i = j;
+#endif
     const float4 x = a[i], y = b[i];
     const float d0 = x.x - y.x, d1 = x.y - y.y, d2 = x.z - y.z, d3 = x.w - y.w;
     s += (fabsf(d0) + fabsf(d1)) + (fabsf(d2) + fabsf(d3));

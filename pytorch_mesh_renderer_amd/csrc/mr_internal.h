@@ -141,16 +141,18 @@ int launch_shade_specular_forward(const int32_t *ids, const float *bary, const f
                                   const float *positions, const float *diffuse, const float *specular,
                                   const int32_t *tris, const float *light_pos, const float *light_col,
                                   const float *ambient, const float *camera, const float *shininess,
-                                  int B, int V, int T, int W, int H, int L, float *rgba, float *norms2,
+                                  int shininess_per_vertex, int B, int V, int T, int W, int H, int L,
+                                  float *rgba, float *norms2,
                                   void *ws, hipStream_t s);
 size_t shade_specular_backward_ws(int B, int V, int T, int W, int H);
 int launch_shade_specular_backward(const float *drgba, const int32_t *ids, const float *bary,
                                    const float *clip, const float *normals, const float *positions,
                                    const float *diffuse, const float *specular, const int32_t *tris,
                                    const float *light_pos, const float *light_col, const float *ambient,
-                                   const float *camera, const float *shininess, const float *norms2,
-                                   int B, int V, int T, int W, int H, int L, float *dclip, float *dnormals,
-                                   float *dpositions, float *ddiffuse, float *dspecular, float *light_grads,
+                                   const float *camera, const float *shininess, int shininess_per_vertex,
+                                   const float *norms2, int B, int V, int T, int W, int H, int L, float *dclip,
+                                   float *dnormals, float *dpositions, float *ddiffuse, float *dspecular,
+                                   float *dshininess, float *light_grads,
                                    void *ws, hipStream_t s);
 int launch_l1_forward(const float *a, const float *b, size_t n, float *out, uint8_t *signs, float *partials,
                       hipStream_t s);

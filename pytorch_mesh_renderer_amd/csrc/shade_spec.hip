@@ -25,8 +25,13 @@
 // (-1), so their contribution to the light / camera gradients is evaluated once per lane and
 // multiplied by the number of background pixels the lane has seen.
 //
-// Scope of the fused path: shininess per image (float, 0-D or [B]; not differentiated), 1..4
-// lights; per-vertex shininess and a shininess that requires grad take the composed path.
+// Shininess: one exponent per image (float, 0-D or [B]) or, PV = true, per vertex ([B,V]: a 13th
+// interpolated attribute, render.py:171-181, 222-224).  Both are differentiated (torch.pow's
+// exponent rule: result * ln(base), 0 where base == 0 and exponent >= 0).  Only pixels that pass
+// the render.py:215 mask evaluate the power: the reference multiplies the masked pixels' zero
+// upstream gradient with pow(0, -1) = inf of the background's exponent -1 and returns NaN
+// gradients for every per-vertex-shininess call with a background pixel; here those pixels
+// contribute exactly what the mask says, nothing.  1..4 lights.
 // fp32 with FMA contraction and 1-ulp v_rcp / v_sqrt / v_exp / v_log: parity budget 1e-4.
 #include "corner_rec.h"
 
@@ -36,56 +41,64 @@ namespace {
 constexpr int kThreads = 256;
 constexpr float kNormEps = 1e-12f;         // torch.nn.functional.normalize default eps
 constexpr float kDegenerateCutoff = 0.9f;  // rasterize_triangles.cpp:13
-constexpr int kAttr = 12;                  // normal, position, diffuse, specular
+constexpr int kAttrMax = 13;               // normal, position, diffuse, specular (+ shininess)
+constexpr int attr_count(bool pv) { return pv ? 13 : 12; }
+constexpr float kLn2 = 0.6931471805599453f;
 
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 
-// torch.pow(x, y) for x in [0, 1]: pow(x, 0) = 1, pow(0, y > 0) = 0, pow(0, y < 0) = inf.
-__device__ __forceinline__ float pow01(float x, float y) {
-  if (y == 0.0f) return 1.0f;
-  return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));  // log2(0) = -inf: exp2 gives 0 / inf
-}
-
+// The triangle's corner attributes, row-major [corner][attribute]: 36 floats in 9 float4, or 39
+// (+1 pad) in 10 with the per-vertex shininess.
+template <int A>
 struct alignas(16) SpecCornerRec {
-  float4 q[9];  // 36 floats, row-major [corner][attribute]
+  static constexpr int kQuads = (3 * A + 3) / 4;
+  float4 q[kQuads];
 };
+template <int A>
 struct SpecCorners {
-  float c[3][kAttr];
+  float c[3][A];
 };
 
-__device__ __forceinline__ void load_spec_corners(const SpecCornerRec *__restrict__ rec, SpecCorners &o) {
+template <int A>
+__device__ __forceinline__ void load_spec_corners(const SpecCornerRec<A> *__restrict__ rec, SpecCorners<A> &o) {
 #pragma unroll
-  for (int q = 0; q < 9; ++q) {
+  for (int q = 0; q < SpecCornerRec<A>::kQuads; ++q) {
     const float4 f = rec->q[q];
     const float v[4] = {f.x, f.y, f.z, f.w};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o.c[(4 * q + j) / kAttr][(4 * q + j) % kAttr] = v[j];
+    for (int j = 0; j < 4; ++j)
+      if (4 * q + j < 3 * A) o.c[(4 * q + j) / A][(4 * q + j) % A] = v[j];
   }
 }
 
+template <int A>
 __global__ __launch_bounds__(kThreads) void k_spec_corner_setup(
     const F3 *__restrict__ normals, const F3 *__restrict__ positions, const F3 *__restrict__ diffuse,
-    const F3 *__restrict__ specular, const int32_t *__restrict__ tris, int B, int V, int T,
-    SpecCornerRec *__restrict__ out) {
+    const F3 *__restrict__ specular, const float *__restrict__ shininess_v, const int32_t *__restrict__ tris,
+    int B, int V, int T, SpecCornerRec<A> *__restrict__ out) {
   const long gid = (long)blockIdx.x * kThreads + threadIdx.x;
   if (gid >= (long)B * T) return;
   const int b = (int)(gid / T);
   const int t = (int)(gid - (long)b * T);
-  float v[36];
+  float v[4 * SpecCornerRec<A>::kQuads];
+#pragma unroll
+  for (int k = 3 * A; k < 4 * SpecCornerRec<A>::kQuads; ++k) v[k] = 0.0f;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     int vi = tris[3 * t + k];
     if ((unsigned)vi >= (unsigned)V) vi = 0;
     const size_t at = (size_t)b * V + vi;
     const F3 n = normals[at], p = positions[at], d = diffuse[at], sp = specular[at];
-    v[k * 12 + 0] = n.x; v[k * 12 + 1] = n.y; v[k * 12 + 2] = n.z;
-    v[k * 12 + 3] = p.x; v[k * 12 + 4] = p.y; v[k * 12 + 5] = p.z;
-    v[k * 12 + 6] = d.x; v[k * 12 + 7] = d.y; v[k * 12 + 8] = d.z;
-    v[k * 12 + 9] = sp.x; v[k * 12 + 10] = sp.y; v[k * 12 + 11] = sp.z;
+    v[k * A + 0] = n.x; v[k * A + 1] = n.y; v[k * A + 2] = n.z;
+    v[k * A + 3] = p.x; v[k * A + 4] = p.y; v[k * A + 5] = p.z;
+    v[k * A + 6] = d.x; v[k * A + 7] = d.y; v[k * A + 8] = d.z;
+    v[k * A + 9] = sp.x; v[k * A + 10] = sp.y; v[k * A + 11] = sp.z;
+    if (A == 13) v[k * A + 12] = shininess_v[at];
   }
 #pragma unroll
-  for (int q = 0; q < 9; ++q) out[gid].q[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+  for (int q = 0; q < SpecCornerRec<A>::kQuads; ++q)
+    out[gid].q[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
 }
 
 // Pointers to the per-image scene parameters (all wave-uniform once indexed by the image).
@@ -94,7 +107,7 @@ struct SpecSceneIn {
   const float *__restrict__ light_col;   // [B,L,3]
   const float *__restrict__ ambient;     // [B,3] or nullptr
   const float *__restrict__ camera;      // [B,3]
-  const float *__restrict__ shininess;   // [B]
+  const float *__restrict__ shininess;   // [B]; null with per-vertex exponents (they ride the corner records)
   const float *__restrict__ norms2;      // [B,L]  sum over pixels of rdc^2 (null in the norm pass)
   const float *__restrict__ gsum;        // [B,L]  G (null outside the final backward pass)
 };
@@ -129,18 +142,19 @@ __device__ __forceinline__ void load_scene(const SpecSceneIn &in, int img, SpecS
     sc.amb[c] = in.ambient ? in.ambient[(size_t)img * 3 + c] : 0.0f;
     sc.cam[c] = in.camera[(size_t)img * 3 + c];
   }
-  sc.shin = in.shininess[img];
+  sc.shin = in.shininess ? in.shininess[img] : 0.0f;
 }
 
 // alpha = clamp(sum(2*bary), 0, 1); attr = alpha * interp + (1 - alpha) * (-1)
 // (rasterize.py:137-150 with render.py:197's background of -1).
-__device__ __forceinline__ void interpolate12(const SpecCorners &cr, const F3 b, float &pre, float &alpha,
-                                              float (&at)[kAttr]) {
+template <int A>
+__device__ __forceinline__ void interpolate_attrs(const SpecCorners<A> &cr, const F3 b, float &pre, float &alpha,
+                                                  float (&at)[A]) {
   pre = (2.0f * b.x + 2.0f * b.y) + 2.0f * b.z;
   alpha = fminf(fmaxf(pre, 0.0f), 1.0f);
   const float one_m = 1.0f - alpha;
 #pragma unroll
-  for (int a = 0; a < kAttr; ++a) {
+  for (int a = 0; a < A; ++a) {
     const float interp = (cr.c[0][a] * b.x + cr.c[1][a] * b.y) + cr.c[2][a] * b.z;
     at[a] = alpha * interp - one_m;
   }
@@ -188,33 +202,41 @@ __device__ __forceinline__ void light_term(const float *at, const PixelFrame &f,
   o.rdc = o.M[0] * f.Cd[0] + o.M[1] * f.Cd[1] + o.M[2] * f.Cd[2];
 }
 
-// rn -> clamp -> where(ndl != 0) -> pow (render.py:342-366): value and d value / d rn.
-__device__ __forceinline__ void specularity(float rdc, float inv_norm, float ndl, float shin, float &spec,
-                                            float &dspec_drn) {
+// rn -> clamp -> where(ndl != 0) -> pow (render.py:342-366): value, d value / d rn and
+// d value / d shininess.  torch.pow(x, y) for x in [0, 1]: pow(x, 0) = 1, pow(0, y > 0) = 0,
+// pow(0, y < 0) = inf; v_log_f32(0) = -inf makes v_exp_f32 give the 0 / inf.
+struct SpecTerm {
+  float spec, dspec_drn, dspec_dshin;
+};
+__device__ __forceinline__ void specularity(float rdc, float inv_norm, float ndl, float shin, SpecTerm &o) {
   const float rn = rdc * inv_norm;
   const float rc = fminf(fmaxf(rn, 0.0f), 1.0f);
   const bool lit = ndl != 0.0f;
   const float rw = lit ? rc : 0.0f;
-  spec = pow01(rw, shin);
-  // torch: d pow / d base = y * base^(y-1); clamp passes the gradient on [0, 1] inclusively
-  const float dpow = shin * pow01(rw, shin - 1.0f);
-  dspec_drn = (lit && rn >= 0.0f && rn <= 1.0f) ? dpow : 0.0f;
+  const float lg = __builtin_amdgcn_logf(rw);  // log2
+  o.spec = shin == 0.0f ? 1.0f : __builtin_amdgcn_exp2f(shin * lg);
+  // torch: d pow / d base = y * base^(y-1), 0 where y == 0; clamp passes the gradient on [0, 1] inclusively
+  const float dpow = shin == 0.0f ? 0.0f : shin * (shin == 1.0f ? 1.0f : __builtin_amdgcn_exp2f((shin - 1.0f) * lg));
+  o.dspec_drn = (lit && rn >= 0.0f && rn <= 1.0f) ? dpow : 0.0f;
+  // torch: d pow / d exponent = result * ln(base), 0 where base == 0 and exponent >= 0
+  o.dspec_dshin = (rw == 0.0f && shin >= 0.0f) ? 0.0f : o.spec * (lg * kLn2);
 }
 
 enum SpecPass { kNorms = 0, kShade = 1, kGsum = 2 };
 
 // One thread per pixel.  kNorms: per-(image, light) sum of rdc^2 over ALL pixels.  kShade: RGBA.
 // kGsum: per-(image, light) sum of (dLoss / d rn) * rdc.
-template <int L, int PASS>
+template <int L, int PASS, bool PV>
 __global__ __launch_bounds__(kThreads) void k_spec_pixels(
     const int32_t *__restrict__ ids, const F3 *__restrict__ bary,
-    const SpecCornerRec *__restrict__ corners, SpecSceneIn scene_in, int T, int W, int H, int x_blocks,
+    const SpecCornerRec<attr_count(PV)> *__restrict__ corners, SpecSceneIn scene_in, int T, int W, int H, int x_blocks,
     const float4 *__restrict__ drgba, float4 *__restrict__ rgba_out, float *__restrict__ sums_out) {
   const int blk = (int)blockIdx.x;
   const int img = blk / (x_blocks * H);
   const int rem = blk - img * (x_blocks * H);
   const int y = rem / x_blocks, xb = rem - y * x_blocks;
   const int x = xb * kThreads + (int)threadIdx.x;
+  constexpr int A = attr_count(PV);
   SpecScene<L> sc;
   load_scene(scene_in, img, sc);
   float part[L];
@@ -224,15 +246,15 @@ __global__ __launch_bounds__(kThreads) void k_spec_pixels(
     const size_t pix = ((size_t)img * H + y) * W + x;
     const F3 b = bary[pix];
     int t = ids[pix];
-    float at[kAttr], pre = 0.0f, alpha = 0.0f;
+    float at[A], pre = 0.0f, alpha = 0.0f;
     const bool live = ((2.0f * b.x + 2.0f * b.y) + 2.0f * b.z) > 0.0f && (unsigned)t < (unsigned)T;
     if (live) {
-      SpecCorners cr;
+      SpecCorners<A> cr;
       load_spec_corners(corners + (size_t)img * T + t, cr);
-      interpolate12(cr, b, pre, alpha, at);
+      interpolate_attrs(cr, b, pre, alpha, at);
     } else {
 #pragma unroll
-      for (int a = 0; a < kAttr; ++a) at[a] = -1.0f;  // the background of render.py:197
+      for (int a = 0; a < A; ++a) at[a] = -1.0f;  // the background of render.py:197
     }
     const bool mask = (at[6] >= 0.0f) || (at[7] >= 0.0f) || (at[8] >= 0.0f);  // render.py:215
     const size_t out_pix = ((size_t)img * H + (H - 1 - y)) * W + x;            // render.py:384-386 flip
@@ -252,14 +274,14 @@ __global__ __launch_bounds__(kThreads) void k_spec_pixels(
         if (PASS == kNorms) {
           part[l] = lt.rdc * lt.rdc;
         } else {
-          float spec, dspec_drn;
-          specularity(lt.rdc, sc.inv_norm[l], lt.ndl, sc.shin, spec, dspec_drn);
+          SpecTerm st;  // only masked-in pixels get here
+          specularity(lt.rdc, sc.inv_norm[l], lt.ndl, PV ? at[A - 1] : sc.shin, st);
           if (PASS == kShade) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) rgb[c] += (at[6 + c] * lt.ndl + at[9 + c] * spec) * sc.li[l][c];
+            for (int c = 0; c < 3; ++c) rgb[c] += (at[6 + c] * lt.ndl + at[9 + c] * st.spec) * sc.li[l][c];
           } else {
             const float dspec = (g[0] * at[9] * sc.li[l][0] + g[1] * at[10] * sc.li[l][1]) + g[2] * at[11] * sc.li[l][2];
-            part[l] = dspec * dspec_drn * lt.rdc;
+            part[l] = dspec * st.dspec_drn * lt.rdc;
           }
         }
       }
@@ -289,27 +311,30 @@ __global__ __launch_bounds__(kThreads) void k_spec_pixels(
 }
 
 // ---- the final backward pass, inside k_accumulate_rows (run_accum.h) -----------------------
-template <int L>
+template <int L, bool PV>
 struct SpecGradFn {
-  static constexpr int kN = 45;       // 36 attribute partials [corner][attr] + 9 clip partials
+  static constexpr int kA = attr_count(PV);
+  static constexpr int kN = 3 * kA + 9;  // attribute partials [corner][attr] + 9 clip partials: 45 / 48
   static constexpr int kStride = 48;
   static constexpr int kSlots = 256;
   static constexpr int kMinWavesPerSimd = 2;
   static constexpr bool kCountBackground = true;
-  // parked per pixel: b[3] | y[12] = alpha * d/d attr | q[3] = clip brackets
-  static constexpr int kFactors = 18;
+  // parked per pixel: b[3] | y[kA] = alpha * d/d attr | q[3] = clip brackets
+  static constexpr int kFactors = kA + 6;
   static constexpr int kFactorStride = 20;
   __device__ static void factor_pair(int o, int &ia, int &ib) {
-    if (o < 36) { ia = o / 12; ib = 3 + o % 12; }
-    else { ia = (o - 36) / 3; ib = 15 + (o - 36) % 3; }
+    if (o < 3 * kA) { ia = o / kA; ib = 3 + o % kA; }
+    else { ia = (o - 3 * kA) / 3; ib = 3 + kA + (o - 3 * kA) % 3; }
   }
+  static constexpr int kLightRow = L * 6 + 7;
   const float4 *__restrict__ drgba;   // [B,H,W,4], image rows (flipped w.r.t. the G-buffer)
   const int32_t *__restrict__ ids;
   const F3 *__restrict__ bary;
-  const SpecCornerRec *__restrict__ corners;
+  const SpecCornerRec<kA> *__restrict__ corners;
   const BwdRec *__restrict__ recs;
   SpecSceneIn scene_in;
-  float *__restrict__ light_grads;    // [B][L*6 + 6]: dpos (L x 3), dcol (L x 3), dambient (3), dcamera (3)
+  // [B][L*6 + 7]: dpos (L x 3), dcol (L x 3), dambient (3), dcamera (3), d per-image shininess (1)
+  float *__restrict__ light_grads;
   int T_, W, H;
 
   struct Pixel {
@@ -322,12 +347,12 @@ struct SpecGradFn {
     float4 g;
   };
   struct Triangle {
-    SpecCorners cr;
+    SpecCorners<kA> cr;
     BwdTriangle bt;
   };
   struct Image {
     SpecScene<L> sc;
-    float dpos[L][3], dcol[L][3], damb[3], dcam[3];  // per-lane partial sums
+    float dpos[L][3], dcol[L][3], damb[3], dcam[3], dshin;  // per-lane partial sums
     int n_bg;                                         // background pixels this lane has seen
   };
 
@@ -339,6 +364,7 @@ struct SpecGradFn {
       for (int c = 0; c < 3; ++c) { im.dpos[l][c] = 0.f; im.dcol[l][c] = 0.f; }
 #pragma unroll
     for (int c = 0; c < 3; ++c) { im.damb[c] = 0.f; im.dcam[c] = 0.f; }
+    im.dshin = 0.f;
     im.n_bg = 0;
   }
 
@@ -364,9 +390,11 @@ struct SpecGradFn {
 
   // Back-propagates (g = dLoss/d rgb of this pixel, plus the norm coupling) to the interpolated
   // attributes `dat`, accumulating light / ambient / camera gradients in `im` scaled by `weight`.
-  __device__ __forceinline__ void shade_backward(const float (&at)[kAttr], const float (&g)[3], float weight,
-                                                 Image &im, float (&dat)[kAttr]) const {
+  // `shaded` = the pixel passed the render.py:215 mask; the others have g = 0 and only feel the norm.
+  __device__ __forceinline__ void shade_backward(const float (&at)[kA], const float (&g)[3], bool shaded,
+                                                 float weight, Image &im, float (&dat)[kA]) const {
     const SpecScene<L> &sc = im.sc;
+    float dshin = 0.f;
     PixelFrame f;
     pixel_frame(at, sc.cam, f);
     float dN[3] = {0.f, 0.f, 0.f}, dP[3] = {0.f, 0.f, 0.f}, dCd[3] = {0.f, 0.f, 0.f};
@@ -378,19 +406,20 @@ struct SpecGradFn {
     for (int l = 0; l < L; ++l) {
       LightTerm lt;
       light_term(at, f, sc.lp[l], lt);
-      float spec, dspec_drn;
-      specularity(lt.rdc, sc.inv_norm[l], lt.ndl, sc.shin, spec, dspec_drn);
+      SpecTerm st{0.f, 0.f, 0.f};
+      if (shaded) specularity(lt.rdc, sc.inv_norm[l], lt.ndl, PV ? at[kA - 1] : sc.shin, st);
       float t_l = 0.f, dspec = 0.f;  // d/d ndl of the diffuse term, d/d spec
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         dKd[c] += g[c] * lt.ndl * sc.li[l][c];
-        dKs[c] += g[c] * spec * sc.li[l][c];
-        im.dcol[l][c] += weight * g[c] * (at[6 + c] * lt.ndl + at[9 + c] * spec);
+        dKs[c] += g[c] * st.spec * sc.li[l][c];
+        im.dcol[l][c] += weight * g[c] * (at[6 + c] * lt.ndl + at[9 + c] * st.spec);
         t_l += g[c] * at[6 + c] * sc.li[l][c];
         dspec += g[c] * at[9 + c] * sc.li[l][c];
       }
+      dshin += dspec * st.dspec_dshin;
       // rn = rdc / norm with norm = |rdc over all pixels|: d rdc = d rn / norm - rdc G / norm^3
-      const float d_rdc = dspec * dspec_drn * sc.inv_norm[l] - lt.rdc * sc.gcoef[l];
+      const float d_rdc = dspec * st.dspec_drn * sc.inv_norm[l] - lt.rdc * sc.gcoef[l];
       float dM[3], dot_m = 0.f;
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
@@ -449,24 +478,26 @@ struct SpecGradFn {
         dat[6 + c] = dKd[c];
         dat[9 + c] = dKs[c];
       }
+      if (PV) dat[kA - 1] = dshin;
+      else im.dshin += weight * dshin;
     }
   }
 
   __device__ __forceinline__ void factors(const Pixel &p, const Triangle &t, float (&f)[kFactorStride],
                                           Image &im) const {
-    float pre, alpha, at[kAttr];
-    interpolate12(t.cr, p.b, pre, alpha, at);
+    float pre, alpha, at[kA];
+    interpolate_attrs(t.cr, p.b, pre, alpha, at);
     // render.py:215 mask: where() sends no rgb gradient to a masked pixel (the norm coupling
     // still reaches it)
     const bool mask = (at[6] >= 0.0f) || (at[7] >= 0.0f) || (at[8] >= 0.0f);
     const float g[3] = {mask ? p.g.x : 0.f, mask ? p.g.y : 0.f, mask ? p.g.z : 0.f};
-    float dat[kAttr];
-    shade_backward(at, g, 1.0f, im, dat);
+    float dat[kA];
+    shade_backward(at, g, mask, 1.0f, im, dat);
     // interpolation backward (rasterize.py:137-150); interp[a] + 1 = (at[a] + 1) / alpha
     float dalpha_a = 0.f, db[3] = {0.f, 0.f, 0.f};
     f[0] = p.b.x; f[1] = p.b.y; f[2] = p.b.z;
 #pragma unroll
-    for (int a = 0; a < kAttr; ++a) {
+    for (int a = 0; a < kA; ++a) {
       const float di = alpha * dat[a];
       dalpha_a += dat[a] * (at[a] + 1.0f);
 #pragma unroll
@@ -480,19 +511,20 @@ struct SpecGradFn {
     const bool skip = p.tri == 0 && (p.b.x + p.b.y) + p.b.z < kDegenerateCutoff;
     float q[3];
     raster_pixel_q(p.b, dbary, t.bt, skip ? 0.f : t.bt.inv, q);
-    f[15] = q[0]; f[16] = q[1]; f[17] = q[2];
-    f[18] = 0.f; f[19] = 0.f;
+    f[3 + kA] = q[0]; f[4 + kA] = q[1]; f[5 + kA] = q[2];
+#pragma unroll
+    for (int k = kFactors; k < kFactorStride; ++k) f[k] = 0.f;
   }
 
   __device__ __forceinline__ void end_image(int img, Image &im) const {
     if (im.n_bg > 0) {  // all background pixels carry the attributes -1: evaluate once, weight by the count
-      float at[kAttr], dat[kAttr];
+      float at[kA], dat[kA];
 #pragma unroll
-      for (int a = 0; a < kAttr; ++a) at[a] = -1.0f;
+      for (int a = 0; a < kA; ++a) at[a] = -1.0f;
       const float g[3] = {0.f, 0.f, 0.f};
-      shade_backward(at, g, (float)im.n_bg, im, dat);
+      shade_backward(at, g, false, (float)im.n_bg, im, dat);
     }
-    float *dst = light_grads + (size_t)img * (L * 6 + 6);
+    float *dst = light_grads + (size_t)img * kLightRow;
     const int lane = lane_id();
     auto reduce_add = [&](float v, int slot) {
 #pragma unroll
@@ -512,13 +544,15 @@ struct SpecGradFn {
       reduce_add(im.damb[c], L * 6 + c);
       reduce_add(im.dcam[c], L * 6 + 3 + c);
     }
+    if (!PV) reduce_add(im.dshin, L * 6 + 6);
   }
 };
 
+template <int A>
 __global__ __launch_bounds__(kThreads) void k_spec_scatter(
     const float *__restrict__ acc, const int32_t *__restrict__ tris, int B, int V, int T,
     float *__restrict__ dnormals, float *__restrict__ dpositions, float *__restrict__ ddiffuse,
-    float *__restrict__ dspecular, float *__restrict__ dclip) {
+    float *__restrict__ dspecular, float *__restrict__ dshininess, float *__restrict__ dclip) {
   const long gid = (long)blockIdx.x * kThreads + threadIdx.x;
   if (gid >= (long)B * T) return;
   const float4 *row = (const float4 *)(acc + gid * 48);  // 192-byte rows, 16-byte aligned
@@ -540,41 +574,47 @@ __global__ __launch_bounds__(kThreads) void k_spec_scatter(
     const size_t v3 = ((size_t)b * V + vi) * 3;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      atomicAdd(&dnormals[v3 + c], a[k * 12 + c]);
-      atomicAdd(&dpositions[v3 + c], a[k * 12 + 3 + c]);
-      atomicAdd(&ddiffuse[v3 + c], a[k * 12 + 6 + c]);
-      atomicAdd(&dspecular[v3 + c], a[k * 12 + 9 + c]);
+      atomicAdd(&dnormals[v3 + c], a[k * A + c]);
+      atomicAdd(&dpositions[v3 + c], a[k * A + 3 + c]);
+      atomicAdd(&ddiffuse[v3 + c], a[k * A + 6 + c]);
+      atomicAdd(&dspecular[v3 + c], a[k * A + 9 + c]);
     }
+    if (A == 13) atomicAdd(&dshininess[(size_t)b * V + vi], a[k * A + 12]);
     float *dc = dclip + ((size_t)b * V + vi) * 4;
-    atomicAdd(&dc[0], a[36 + k * 3 + 0]);
-    atomicAdd(&dc[1], a[36 + k * 3 + 1]);
-    atomicAdd(&dc[3], a[36 + k * 3 + 2]);
+    atomicAdd(&dc[0], a[3 * A + k * 3 + 0]);
+    atomicAdd(&dc[1], a[3 * A + k * 3 + 1]);
+    atomicAdd(&dc[3], a[3 * A + k * 3 + 2]);
   }
 }
 
-inline size_t spec_corner_bytes(int B, int T) { return align_up((size_t)B * T * sizeof(SpecCornerRec), 256); }
+inline size_t spec_corner_bytes(int B, int T) {
+  return align_up((size_t)B * T * sizeof(SpecCornerRec<kAttrMax>), 256);
+}
 inline size_t spec_acc_bytes(int B, int T) { return align_up((size_t)B * T * 48 * sizeof(float), 256); }
 inline size_t spec_sums_bytes(int B) { return align_up((size_t)B * 4 * sizeof(float), 256); }
 
+template <bool PV>
 int launch_spec_corner_setup(const float *normals, const float *positions, const float *diffuse,
-                             const float *specular, const int32_t *tris, int B, int V, int T,
-                             SpecCornerRec *out, hipStream_t s) {
+                             const float *specular, const float *shininess_v, const int32_t *tris, int B, int V,
+                             int T, void *out, hipStream_t s) {
+  constexpr int A = attr_count(PV);
   const long nbt = (long)B * T;
-  hipLaunchKernelGGL(k_spec_corner_setup, dim3((unsigned)((nbt + kThreads - 1) / kThreads)), dim3(kThreads), 0,
-                     s, (const F3 *)normals, (const F3 *)positions, (const F3 *)diffuse, (const F3 *)specular,
-                     tris, B, V, T, out);
+  hipLaunchKernelGGL((k_spec_corner_setup<A>), dim3((unsigned)((nbt + kThreads - 1) / kThreads)), dim3(kThreads),
+                     0, s, (const F3 *)normals, (const F3 *)positions, (const F3 *)diffuse, (const F3 *)specular,
+                     shininess_v, tris, B, V, T, (SpecCornerRec<A> *)out);
   return check_launch();
 }
 
-template <int PASS>
-int launch_spec_pixels(int L, const int32_t *ids, const float *bary, const SpecCornerRec *corners,
+template <int PASS, bool PV>
+int launch_spec_pixels(int L, const int32_t *ids, const float *bary, const void *corners,
                        const SpecSceneIn &scene, int B, int T, int W, int H, const float *drgba, float *rgba,
                        float *sums, hipStream_t s) {
   const int x_blocks = (W + kThreads - 1) / kThreads;
   const dim3 grid((unsigned)((size_t)x_blocks * H * B)), block(kThreads);
-#define MR_SPEC_PIXELS(NL)                                                                          \
-  hipLaunchKernelGGL((k_spec_pixels<NL, PASS>), grid, block, 0, s, ids, (const F3 *)bary, corners, scene, \
-                     T, W, H, x_blocks, (const float4 *)drgba, (float4 *)rgba, sums)
+#define MR_SPEC_PIXELS(NL)                                                                        \
+  hipLaunchKernelGGL((k_spec_pixels<NL, PASS, PV>), grid, block, 0, s, ids, (const F3 *)bary,     \
+                     (const SpecCornerRec<attr_count(PV)> *)corners, scene, T, W, H, x_blocks,    \
+                     (const float4 *)drgba, (float4 *)rgba, sums)
   switch (L) {
     case 1: MR_SPEC_PIXELS(1); break;
     case 2: MR_SPEC_PIXELS(2); break;
@@ -583,6 +623,70 @@ int launch_spec_pixels(int L, const int32_t *ids, const float *bary, const SpecC
     default: return MR_EINVAL;
   }
 #undef MR_SPEC_PIXELS
+  return check_launch();
+}
+
+template <bool PV>
+int spec_forward(const int32_t *ids, const float *bary, const float *normals, const float *positions,
+                 const float *diffuse, const float *specular, const int32_t *tris, const float *light_pos,
+                 const float *light_col, const float *ambient, const float *camera, const float *shininess,
+                 int B, int V, int T, int W, int H, int L, float *rgba, float *norms2, void *ws, hipStream_t s) {
+  int rc = launch_spec_corner_setup<PV>(normals, positions, diffuse, specular, PV ? shininess : nullptr, tris, B, V,
+                                        T, ws, s);
+  if (rc != MR_OK) return rc;
+  if (hipMemsetAsync(norms2, 0, (size_t)B * L * sizeof(float), s) != hipSuccess) return check_launch();
+  SpecSceneIn scene{light_pos, light_col, ambient, camera, PV ? nullptr : shininess, nullptr, nullptr};
+  rc = launch_spec_pixels<kNorms, PV>(L, ids, bary, ws, scene, B, T, W, H, nullptr, nullptr, norms2, s);
+  if (rc != MR_OK) return rc;
+  scene.norms2 = norms2;
+  return launch_spec_pixels<kShade, PV>(L, ids, bary, ws, scene, B, T, W, H, nullptr, rgba, nullptr, s);
+}
+
+template <bool PV>
+int spec_backward(const float *drgba, const int32_t *ids, const float *bary, const float *clip,
+                  const float *normals, const float *positions, const float *diffuse, const float *specular,
+                  const int32_t *tris, const float *light_pos, const float *light_col, const float *ambient,
+                  const float *camera, const float *shininess, const float *norms2, int B, int V, int T, int W,
+                  int H, int L, float *dclip, float *dnormals, float *dpositions, float *ddiffuse,
+                  float *dspecular, float *dshininess, float *light_grads, void *ws, hipStream_t s) {
+  constexpr int A = attr_count(PV);
+  char *p = (char *)ws;
+  float *acc = (float *)p;
+  p += spec_acc_bytes(B, T);
+  BwdRec *recs = (BwdRec *)p;
+  p += align_up((size_t)B * T * sizeof(BwdRec), 256);
+  void *corners = p;
+  p += spec_corner_bytes(B, T);
+  float *gsum = (float *)p;
+  if (hipMemsetAsync(acc, 0, (size_t)B * T * 48 * sizeof(float), s) != hipSuccess) return check_launch();
+  if (hipMemsetAsync(gsum, 0, (size_t)B * L * sizeof(float), s) != hipSuccess) return check_launch();
+  int rc = launch_bwd_setup(clip, tris, B, V, T, recs, s);
+  if (rc != MR_OK) return rc;
+  rc = launch_spec_corner_setup<PV>(normals, positions, diffuse, specular, PV ? shininess : nullptr, tris, B, V, T,
+                                    corners, s);
+  if (rc != MR_OK) return rc;
+  SpecSceneIn scene{light_pos, light_col, ambient, camera, PV ? nullptr : shininess, norms2, nullptr};
+  rc = launch_spec_pixels<kGsum, PV>(L, ids, bary, corners, scene, B, T, W, H, drgba, nullptr, gsum, s);
+  if (rc != MR_OK) return rc;
+  scene.gsum = gsum;
+#define MR_SPEC_BWD(NL)                                                                               \
+  {                                                                                                   \
+    SpecGradFn<NL, PV> fn{(const float4 *)drgba, ids, (const F3 *)bary, (const SpecCornerRec<A> *)corners, \
+                          recs, scene, light_grads, T, W, H};                                         \
+    rc = launch_accumulate_rows(fn, B, T, W, H, acc, s);                                              \
+  }
+  switch (L) {
+    case 1: MR_SPEC_BWD(1); break;
+    case 2: MR_SPEC_BWD(2); break;
+    case 3: MR_SPEC_BWD(3); break;
+    case 4: MR_SPEC_BWD(4); break;
+    default: return MR_EINVAL;
+  }
+#undef MR_SPEC_BWD
+  if (rc != MR_OK) return rc;
+  const long nbt = (long)B * T;
+  hipLaunchKernelGGL((k_spec_scatter<A>), dim3((unsigned)((nbt + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
+                     acc, tris, B, V, T, dnormals, dpositions, ddiffuse, dspecular, dshininess, dclip);
   return check_launch();
 }
 
@@ -597,18 +701,14 @@ int launch_shade_specular_forward(const int32_t *ids, const float *bary, const f
                                   const float *positions, const float *diffuse, const float *specular,
                                   const int32_t *tris, const float *light_pos, const float *light_col,
                                   const float *ambient, const float *camera, const float *shininess,
-                                  int B, int V, int T, int W, int H, int L, float *rgba, float *norms2,
-                                  void *ws, hipStream_t s) {
+                                  int shininess_per_vertex, int B, int V, int T, int W, int H, int L,
+                                  float *rgba, float *norms2, void *ws, hipStream_t s) {
   if ((size_t)B * W * H == 0) return MR_OK;
-  SpecCornerRec *corners = (SpecCornerRec *)ws;
-  int rc = launch_spec_corner_setup(normals, positions, diffuse, specular, tris, B, V, T, corners, s);
-  if (rc != MR_OK) return rc;
-  if (hipMemsetAsync(norms2, 0, (size_t)B * L * sizeof(float), s) != hipSuccess) return check_launch();
-  SpecSceneIn scene{light_pos, light_col, ambient, camera, shininess, nullptr, nullptr};
-  rc = launch_spec_pixels<kNorms>(L, ids, bary, corners, scene, B, T, W, H, nullptr, nullptr, norms2, s);
-  if (rc != MR_OK) return rc;
-  scene.norms2 = norms2;
-  return launch_spec_pixels<kShade>(L, ids, bary, corners, scene, B, T, W, H, nullptr, rgba, nullptr, s);
+  return shininess_per_vertex
+             ? spec_forward<true>(ids, bary, normals, positions, diffuse, specular, tris, light_pos, light_col,
+                                  ambient, camera, shininess, B, V, T, W, H, L, rgba, norms2, ws, s)
+             : spec_forward<false>(ids, bary, normals, positions, diffuse, specular, tris, light_pos, light_col,
+                                   ambient, camera, shininess, B, V, T, W, H, L, rgba, norms2, ws, s);
 }
 
 size_t shade_specular_backward_ws(int B, int V, int T, int W, int H) {
@@ -621,10 +721,10 @@ int launch_shade_specular_backward(const float *drgba, const int32_t *ids, const
                                    const float *clip, const float *normals, const float *positions,
                                    const float *diffuse, const float *specular, const int32_t *tris,
                                    const float *light_pos, const float *light_col, const float *ambient,
-                                   const float *camera, const float *shininess, const float *norms2,
-                                   int B, int V, int T, int W, int H, int L, float *dclip, float *dnormals,
-                                   float *dpositions, float *ddiffuse, float *dspecular, float *light_grads,
-                                   void *ws, hipStream_t s) {
+                                   const float *camera, const float *shininess, int shininess_per_vertex,
+                                   const float *norms2, int B, int V, int T, int W, int H, int L, float *dclip,
+                                   float *dnormals, float *dpositions, float *ddiffuse, float *dspecular,
+                                   float *dshininess, float *light_grads, void *ws, hipStream_t s) {
   if (B == 0) return MR_OK;
   const size_t v3 = (size_t)B * V * 3 * sizeof(float);
   if (V > 0) {
@@ -633,47 +733,20 @@ int launch_shade_specular_backward(const float *drgba, const int32_t *ids, const
     if (hipMemsetAsync(dpositions, 0, v3, s) != hipSuccess) return check_launch();
     if (hipMemsetAsync(ddiffuse, 0, v3, s) != hipSuccess) return check_launch();
     if (hipMemsetAsync(dspecular, 0, v3, s) != hipSuccess) return check_launch();
+    if (shininess_per_vertex &&
+        hipMemsetAsync(dshininess, 0, (size_t)B * V * sizeof(float), s) != hipSuccess)
+      return check_launch();
   }
-  if (hipMemsetAsync(light_grads, 0, (size_t)B * (L * 6 + 6) * sizeof(float), s) != hipSuccess)
+  if (hipMemsetAsync(light_grads, 0, (size_t)B * (L * 6 + 7) * sizeof(float), s) != hipSuccess)
     return check_launch();
   if (T == 0 || V == 0 || (size_t)W * H == 0) return MR_OK;
-  char *p = (char *)ws;
-  float *acc = (float *)p;
-  p += spec_acc_bytes(B, T);
-  BwdRec *recs = (BwdRec *)p;
-  p += align_up((size_t)B * T * sizeof(BwdRec), 256);
-  SpecCornerRec *corners = (SpecCornerRec *)p;
-  p += spec_corner_bytes(B, T);
-  float *gsum = (float *)p;
-  if (hipMemsetAsync(acc, 0, (size_t)B * T * 48 * sizeof(float), s) != hipSuccess) return check_launch();
-  if (hipMemsetAsync(gsum, 0, (size_t)B * L * sizeof(float), s) != hipSuccess) return check_launch();
-  int rc = launch_bwd_setup(clip, tris, B, V, T, recs, s);
-  if (rc != MR_OK) return rc;
-  rc = launch_spec_corner_setup(normals, positions, diffuse, specular, tris, B, V, T, corners, s);
-  if (rc != MR_OK) return rc;
-  SpecSceneIn scene{light_pos, light_col, ambient, camera, shininess, norms2, nullptr};
-  rc = launch_spec_pixels<kGsum>(L, ids, bary, corners, scene, B, T, W, H, drgba, nullptr, gsum, s);
-  if (rc != MR_OK) return rc;
-  scene.gsum = gsum;
-#define MR_SPEC_BWD(NL)                                                                              \
-  {                                                                                                  \
-    SpecGradFn<NL> fn{(const float4 *)drgba, ids, (const F3 *)bary, corners, recs, scene, light_grads, \
-                      T, W, H};                                                                      \
-    rc = launch_accumulate_rows(fn, B, T, W, H, acc, s);                                             \
-  }
-  switch (L) {
-    case 1: MR_SPEC_BWD(1); break;
-    case 2: MR_SPEC_BWD(2); break;
-    case 3: MR_SPEC_BWD(3); break;
-    case 4: MR_SPEC_BWD(4); break;
-    default: return MR_EINVAL;
-  }
-#undef MR_SPEC_BWD
-  if (rc != MR_OK) return rc;
-  const long nbt = (long)B * T;
-  hipLaunchKernelGGL(k_spec_scatter, dim3((unsigned)((nbt + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
-                     acc, tris, B, V, T, dnormals, dpositions, ddiffuse, dspecular, dclip);
-  return check_launch();
+  return shininess_per_vertex
+             ? spec_backward<true>(drgba, ids, bary, clip, normals, positions, diffuse, specular, tris, light_pos,
+                                   light_col, ambient, camera, shininess, norms2, B, V, T, W, H, L, dclip,
+                                   dnormals, dpositions, ddiffuse, dspecular, dshininess, light_grads, ws, s)
+             : spec_backward<false>(drgba, ids, bary, clip, normals, positions, diffuse, specular, tris, light_pos,
+                                    light_col, ambient, camera, shininess, norms2, B, V, T, W, H, L, dclip,
+                                    dnormals, dpositions, ddiffuse, dspecular, dshininess, light_grads, ws, s);
 }
 
 }  // namespace mr

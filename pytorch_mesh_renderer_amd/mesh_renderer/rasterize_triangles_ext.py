@@ -179,8 +179,10 @@ class FusedPhongL1Loss(torch.autograd.Function):
 
 class FusedSpecularPhongRenderer(torch.autograd.Function):
     """FusedPhongRenderer plus the specular term of phong_shader (src/mesh_renderer/render.py
-    :326-372) for a per-image shininess: two passes over the G-buffer each way (the reference
-    L2-normalises the reflection . camera dot product across all pixels of an image)."""
+    :326-372): two passes over the G-buffer each way (the reference L2-normalises the
+    reflection . camera dot product across all pixels of an image).  shininess is [B] (one
+    exponent per image) or [B,V] (per vertex, interpolated like the other attributes) and is
+    differentiated either way."""
 
     @staticmethod
     def forward(ctx, clip, positions, normals, diffuse, specular, triangles, light_positions,
@@ -205,7 +207,7 @@ class FusedSpecularPhongRenderer(torch.autograd.Function):
         saved = ctx.saved_tensors
         clip, ids, bary, normals, positions, diffuse, specular, triangles, lp, li, cam, shin, norms2 = saved[:13]
         amb = saved[13] if ctx.has_ambient else None
-        dclip, dn, dp, dd, dsp, dlp, dli, damb, dcam = _native.shade_specular_backward(
+        dclip, dn, dp, dd, dsp, dlp, dli, damb, dcam, dshin = _native.shade_specular_backward(
             drgba.contiguous(), ids, bary, clip, normals, positions, diffuse, specular, triangles, lp, li,
             amb, cam, shin, norms2)
-        return dclip, dp, dn, dd, dsp, None, dlp, dli, damb, dcam, None, None, None
+        return dclip, dp, dn, dd, dsp, None, dlp, dli, damb, dcam, dshin, None, None

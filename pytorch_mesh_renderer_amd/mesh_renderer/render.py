@@ -88,7 +88,7 @@ def render(vertices, triangles, normals, diffuse_colors, camera_position, camera
             return _render_fused(vertices, triangles, normals, diffuse_colors, camera_position,
                                  camera_lookat, camera_up, light_positions, light_intensities,
                                  image_width, image_height, ambient_color, fov_y, near_clip, far_clip)
-        shininess = _per_image_shininess(shininess_coefficients, batch_size, device)
+        shininess = _fused_shininess(shininess_coefficients, batch_size, vertices.shape[1], device)
         if shininess is not None and specular_colors.shape == vertices.shape:
             return _render_fused(vertices, triangles, normals, diffuse_colors, camera_position,
                                  camera_lookat, camera_up, light_positions, light_intensities,
@@ -145,27 +145,29 @@ def render(vertices, triangles, normals, diffuse_colors, camera_position, camera
 
 
 def _fused_path_applies(vertices, normals, diffuse_colors, light_positions):
-    """The fused HIP shading kernels cover Phong shading (ambient, diffuse, and specular with a
-    per-image shininess) with 1..4 lights on float32 inputs of matching [B,V,3] shape;
-    everything else takes the composed path."""
+    """The fused HIP shading kernels cover Phong shading (ambient, diffuse, and specular with
+    per-image or per-vertex shininess) with 1..4 lights on float32 inputs of matching [B,V,3]
+    shape; everything else takes the composed path."""
     from .. import _native
     return (USE_FUSED_SHADING and vertices.dtype == torch.float32 and normals.shape == vertices.shape and
             diffuse_colors.shape == vertices.shape and
             1 <= light_positions.shape[1] <= _native.shade_max_lights())
 
 
-def _per_image_shininess(shininess_coefficients, batch_size, device):
-    """float | 0-D | [B] shininess -> [B] float32 tensor on `device`; None when the fused
-    specular kernels do not cover the request (per-vertex exponents, exponents that need a
-    gradient): those take the composed path."""
+def _fused_shininess(shininess_coefficients, batch_size, vertex_count, device):
+    """float | 0-D | [B] shininess -> [B] float32 tensor on `device` (one exponent per image);
+    [B,V] -> itself (per vertex).  Differentiable views of the argument.  None for anything the
+    fused specular kernels do not take (other shapes go to the composed path, which raises the
+    reference's errors)."""
     if isinstance(shininess_coefficients, float):
         return torch.full((batch_size,), shininess_coefficients, dtype=torch.float32, device=device)
-    if not torch.is_tensor(shininess_coefficients) or shininess_coefficients.requires_grad:
+    if not torch.is_tensor(shininess_coefficients):
         return None
-    if len(shininess_coefficients.shape) == 0:
-        return shininess_coefficients.to(device=device, dtype=torch.float32).reshape(1).repeat(batch_size)
-    if list(shininess_coefficients.shape) == [batch_size]:
-        return shininess_coefficients.to(device=device, dtype=torch.float32)
+    shin = shininess_coefficients.to(device=device, dtype=torch.float32)
+    if shin.dim() == 0:
+        return shin.reshape(1).expand(batch_size)
+    if list(shin.shape) in ([batch_size], [batch_size, vertex_count]):
+        return shin
     return None
 
 

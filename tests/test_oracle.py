@@ -171,6 +171,27 @@ def test_shading_oracle_render(name):
         np.testing.assert_allclose(amb.grad.numpy(), g["d_ambient"], atol=2e-6, rtol=0)
 
 
+@pytest.mark.parametrize("name", ["render_shininess_vertex_filled_64x48.npz", "render_shininess_vertex_64x48.npz",
+                                  "render_shininess_image_64x48.npz"])
+def test_shading_oracle_shininess_gradient(name):
+    """Row F1: a shininess that requires grad (per vertex / per image).  With a background pixel the
+    reference's per-vertex case returns NaN for some gradients; the oracle reproduces that."""
+    g = golden_npz(name)
+    keys = ("vertices", "normals", "diffuse", "specular", "light_positions", "light_intensities", "ambient",
+            "shininess")
+    leaves = {k: _t(g[k], True) for k in keys}
+    img = shading.render(leaves["vertices"], _t(g["triangles"]), leaves["normals"], leaves["diffuse"],
+                         _t(g["eye"]), _t(g["center"]), _t(g["up"]), leaves["light_positions"],
+                         leaves["light_intensities"], 64, 48, specular_colors=leaves["specular"],
+                         shininess_coefficients=leaves["shininess"], ambient_color=leaves["ambient"],
+                         fov_y=float(g["fov_y"]))
+    np.testing.assert_allclose(img.detach().numpy(), g["image"], atol=2e-6, rtol=0)
+    (float(g["loss_weight"]) * torch.mean(torch.abs(img - _t(g["target"])))).backward()
+    for k, t in leaves.items():
+        np.testing.assert_allclose(t.grad.numpy(), g["d_" + k], atol=1e-5, rtol=0, err_msg=k)
+    assert np.abs(np.nan_to_num(g["d_shininess"])).max() > 1e-4
+
+
 # ---- SoftRas oracle (torch CPU restatement of src/soft_mesh_renderer) -----------------------------
 
 def test_soft_oracle_single_triangle_known_answers():

@@ -56,8 +56,10 @@ def test_rasterize_unlit_cube_golden(device):
 
 
 def _assert_close_where_reference_is_finite(got, want, what):
-    """With per-vertex shininess the reference's own gradients are NaN (pow(0, s) *
-    log(0) in torch-CPU autograd); those entries pin nothing and are skipped."""
+    """With per-vertex shininess and a background pixel some of the reference's own gradients are
+    NaN (0 * pow(0, -1) in torch autograd, see shade_spec.hip); those entries pin nothing beyond
+    ours being finite."""
+    assert np.isfinite(got).all(), what
     ok = np.isfinite(want)
     np.testing.assert_allclose(got[ok], want[ok], atol=ATOL, rtol=0, err_msg=what)
 
@@ -115,14 +117,41 @@ class _CountCalls:
         return False
 
 
-@pytest.mark.parametrize("name,fused", [("render_specular_cube_64x48.npz", False),
-                                        ("render_specular_scalar_cube_64x48.npz", True)])
-def test_render_specular_goldens(device, name, fused):
-    """Reference-captured image and gradients.  Per-vertex shininess takes the composed path,
-    a scalar shininess the fused specular kernels."""
+@pytest.mark.parametrize("name", ["render_specular_cube_64x48.npz", "render_specular_scalar_cube_64x48.npz"])
+def test_render_specular_goldens(device, name):
+    """Reference-captured image and gradients, per-vertex and scalar shininess: both take the fused
+    specular kernels.  (Where the reference's gradient is NaN -- per-vertex shininess with a
+    background pixel -- only finiteness is asked of ours.)"""
     with _CountCalls("shade_specular_forward") as counter:
         _render_golden(name, device)
-    assert counter.calls == (1 if fused else 0)
+    assert counter.calls == 1
+
+
+@pytest.mark.parametrize("name", ["render_shininess_vertex_filled_64x48.npz", "render_shininess_vertex_64x48.npz",
+                                  "render_shininess_image_64x48.npz"])
+def test_render_shininess_gradient_goldens(device, name):
+    """Row F1: shininess_coefficients that require grad, per vertex ([B,V]; mesh filling the frame, and
+    with background where the reference is partly NaN) and per image ([B]), against the reference's
+    image and gradients -- d shininess included."""
+    g = golden_npz(name)
+    keys = ("vertices", "normals", "diffuse", "specular", "light_positions", "light_intensities", "ambient",
+            "shininess")
+    leaves = {k: _leaf(g, k, device) for k in keys}
+    dev = lambda k: torch.tensor(g[k], device=device)
+    with _CountCalls("shade_specular_backward") as counter:
+        img = mesh_renderer.render(leaves["vertices"], dev("triangles"), leaves["normals"], leaves["diffuse"],
+                                   dev("eye"), dev("center"), dev("up"), leaves["light_positions"],
+                                   leaves["light_intensities"], 64, 48, specular_colors=leaves["specular"],
+                                   shininess_coefficients=leaves["shininess"], ambient_color=leaves["ambient"],
+                                   fov_y=float(g["fov_y"]))
+        np.testing.assert_allclose(img.detach().cpu().numpy(), g["image"], atol=ATOL, rtol=0)
+        (float(g["loss_weight"]) * torch.mean(torch.abs(img - dev("target")))).backward()
+    assert counter.calls == 1
+    assert np.abs(np.nan_to_num(g["d_shininess"])).max() > 1e-4
+    for k, t in leaves.items():
+        _assert_close_where_reference_is_finite(t.grad.cpu().numpy(), g["d_" + k], k)
+    if "filled" in name or "image" in name:
+        assert all(np.isfinite(g["d_" + k]).all() for k in keys)
 
 
 def test_renders_simple_and_perspective_triangle_png(device):
@@ -349,12 +378,13 @@ def _specular_scene(device, n_lights=2, ambient=True):
     return job, scene
 
 
-def _render_specular(job, scene, device, shininess):
+def _render_specular(job, scene, device, shininess, fov_y=40.0):
     return mesh_renderer.render(
         scene["vertices"], job["triangles"].to(device), scene["normals"], scene["diffuse"], scene["eye"],
         torch.zeros(2, 3, device=device), torch.tensor([0.0, 1.0, 0.0], device=device),
         scene["light_positions"], scene["light_intensities"], 96, 80,
-        specular_colors=scene["specular"], shininess_coefficients=shininess, ambient_color=scene["ambient"])
+        specular_colors=scene["specular"], shininess_coefficients=shininess, ambient_color=scene["ambient"],
+        fov_y=fov_y)
 
 
 @pytest.mark.parametrize("n_lights,ambient", [(1, False), (2, True), (4, True)])
@@ -386,6 +416,43 @@ def test_fused_specular_matches_composed_path(device, n_lights, ambient):
     assert set(grads_c) == set(grads_f) == (expected | {"ambient"} if ambient else expected)
     for k in grads_c:
         assert np.isfinite(grads_f[k]).all() and np.abs(grads_c[k]).max() > 0, k
+        np.testing.assert_allclose(grads_f[k], grads_c[k], atol=ATOL, rtol=0, err_msg=k)
+
+
+@pytest.mark.parametrize("kind", ["vertex", "image", "scalar"])
+def test_fused_specular_shininess_gradient_matches_composed_path(device, kind):
+    """A shininess that requires grad -- [B,V], [B] or 0-D -- through the fused kernels vs torch autograd
+    over the composed path, on the 5k-style sphere zoomed in until it fills the frame (no background pixel,
+    where the composed per-vertex path, like the reference, returns NaN)."""
+    render_mod = sys.modules["pytorch_mesh_renderer_amd.mesh_renderer.render"]
+    gen = torch.Generator().manual_seed(5)
+    target = torch.rand(2, 80, 96, 4, generator=gen).to(device)
+    results = {}
+    for fused in (True, False):
+        job, scene = _specular_scene(device, 3, True)
+        g2 = torch.Generator().manual_seed(17)
+        base = {"vertex": 0.3 + 1.2 * torch.rand(2, scene["vertices"].shape[1], generator=g2),
+                "image": torch.tensor([0.5, 1.5]), "scalar": torch.tensor(0.8)}[kind]
+        scene["shininess"] = base.to(device).requires_grad_(True)
+        render_mod.USE_FUSED_SHADING = fused
+        try:
+            with _CountCalls("shade_specular_backward") as counter:
+                img = _render_specular(job, scene, device, scene["shininess"], fov_y=12.0)
+                assert float(img.detach()[..., 3].min()) == 1.0     # the sphere fills the frame
+                (torch.mean(torch.abs(img - target)) * 50.0).backward()
+        finally:
+            render_mod.USE_FUSED_SHADING = True
+        assert counter.calls == (1 if fused else 0)
+        results[fused] = (img.detach().cpu().numpy(), {k: v.grad.cpu().numpy() for k, v in scene.items()
+                                                       if v is not None and v.grad is not None})
+    img_f, grads_f = results[True]
+    img_c, grads_c = results[False]
+    np.testing.assert_allclose(img_f, img_c, atol=ATOL, rtol=0)
+    assert set(grads_c) == set(grads_f) and "shininess" in grads_f
+    assert grads_f["shininess"].shape == grads_c["shininess"].shape
+    for k in grads_c:
+        assert np.isfinite(grads_c[k]).all() and np.isfinite(grads_f[k]).all(), k
+        assert np.abs(grads_c[k]).max() > 0, k
         np.testing.assert_allclose(grads_f[k], grads_c[k], atol=ATOL, rtol=0, err_msg=k)
 
 
