@@ -289,6 +289,17 @@ def main():
         elapsed = float(t.item())
     assert vertices.grad is not None and bool(torch.isfinite(vertices.grad).all())
 
+    # Outside the timed region: the G-buffer kernel on its own (what rasterize_barycentric() and the
+    # non-fused paths launch; the step's forward runs it with the shading epilogue attached).
+    n_gb = 20
+    ev_gbuffer = KernelEvents(n_gb, _native.TIMER_RASTER_FORWARD)
+    clip_d, tri_d = job["clip"].to(device), job["triangles"].to(device)
+    for i in range(n_gb + 2):
+        if i >= 2:
+            ev_gbuffer.arm(i - 2)
+        _native.rasterize_forward(clip_d, tri_d, width, height)
+    torch.cuda.synchronize(device)
+
     if rank == 0:
         V, T = job["vertices"].shape[1], job["triangles"].shape[0]
         px = batch * width * height
@@ -305,11 +316,18 @@ def main():
                                        "8-bit" if args.handover == "u8" else "fp32"),
                        "global_batch": batch * world, "image": [height, width], "triangles": T,
                        "handover": args.handover},
-            "roofline": roofline("k_raster (forward G-buffer write)", px * 20 + batch * V * 16 + T * 12,
-                                 ev_raster.mean_ms(n_ev), "k_raster"),
+            # the step's forward kernel: G-buffer (20 B/px) + RGBA (16 B/px) written, clip-space
+            # vertices, triangle list and the per-triangle attribute records (128 B) read
+            "roofline": roofline("k_raster<shade> (forward: G-buffer + shaded RGBA write)",
+                                 px * 36 + batch * V * 16 + T * 12 + batch * T * 128,
+                                 ev_raster.mean_ms(n_ev), "k_raster_shade"),
+            "roofline_gbuffer": roofline("k_raster (G-buffer write alone, %d launches after the timed region)" % n_gb,
+                                         px * 20 + batch * V * 16 + T * 12, ev_gbuffer.mean_ms(n_gb), "k_raster"),
+            # ids + barycentrics (16 B/px) and the loss's sign codes (1 B/px) read, the triangles'
+            # attribute and adjugate records (128 + 64 B) read
             "roofline_shade_backward": roofline(
                 "k_accumulate_rows<ShadeGradFn> (fused shading backward, pixel pass)",
-                px * 32 + batch * T * (128 + 64), ev_shade.mean_ms(n_ev), "shade_backward"),
+                px * 17 + batch * T * (128 + 64), ev_shade.mean_ms(n_ev), "shade_backward"),
         }
         if world == 1 and args.cpu_sample > 0:
             line["cpu_baseline"] = cpu_baseline(batch, width, height, sphere_k, args.cpu_sample)

@@ -148,6 +148,22 @@ int mr_shade_forward(const int32_t *ids, const float *bary, const float *normals
                      int B, int V, int T, int W, int H, int L, float *rgba,
                      void *workspace, size_t workspace_bytes, void *stream);
 
+/* mr_rasterize_forward and mr_shade_forward in ONE pass over the pixels: the shading runs as the
+ * epilogue of the rasterizer's tile walk, on the pixel state still held in registers, so the
+ * G-buffer is not read back (and the id -> corner-record gather has one dependent level less).
+ * What FusedPhongRenderer (render() without a specular term) calls.  Outputs: the G-buffer of
+ * mr_rasterize_forward (ids, bary, z) and the image of mr_shade_forward (rgba), bit-identical
+ * G-buffer, RGBA within the shading's 1e-4 budget.
+ *   corner_records  out, mr_shade_forward_workspace_bytes() bytes, 128-byte aligned: the gathered
+ *                   per-triangle attribute records; may be handed to mr_shade_backward.
+ *   workspace       mr_rasterize_forward_workspace_bytes() bytes */
+int mr_render_forward(const float *clip, const float *normals, const float *positions,
+                      const float *diffuse, const int32_t *triangles,
+                      const float *light_positions, const float *light_intensities,
+                      const float *ambient, int B, int V, int T, int W, int H, int L,
+                      int32_t *ids, float *bary, float *z, float *rgba, void *corner_records,
+                      void *workspace, size_t workspace_bytes, void *stream);
+
 /* Backward of mr_shade_forward AND of the rasterizer underneath it, in one pass
  * over the G-buffer (reads 32 B/px).  All outputs are zeroed here.
  *   drgba        [B,H,W,4] f32  dL/d(rgba); the alpha channel's gradient is ignored

@@ -148,6 +148,8 @@ def lib():
         L.mr_interpolate_forward_records.restype = ci
         L.mr_interpolate_raster_backward.argtypes = [vp] * 10 + [ci] * 6 + [vp, vp, vp, sz, vp]
         L.mr_interpolate_raster_backward.restype = ci
+        L.mr_render_forward.argtypes = [vp] * 8 + [ci] * 6 + [vp] * 6 + [sz, vp]
+        L.mr_render_forward.restype = ci
         L.mr_shade_specular_forward_workspace_bytes.argtypes = [ci] * 5
         L.mr_shade_specular_forward_workspace_bytes.restype = sz
         L.mr_shade_specular_forward.argtypes = [vp] * 12 + [ci] * 7 + [vp, vp, vp, sz, vp]
@@ -410,6 +412,38 @@ def shade_forward(ids, bary, normals, positions, diffuse, triangles, light_posit
                                 _stream(dev))
     _check(rc, "mr_shade_forward")
     return (rgba, ws) if keep_corner_records else rgba
+
+
+def render_forward(clip, normals, positions, diffuse, triangles, light_positions, light_intensities,
+                   ambient, width, height):
+    """rasterize_forward + shade_forward in one pass over the pixels (the shading is the epilogue
+    of the rasterizer's tile walk) -> (ids, bary, z, rgba, corner_records)."""
+    tensors = [clip, normals, positions, diffuse, triangles, light_positions, light_intensities]
+    B, V, T = _chk_mesh(clip, triangles)
+    for name, t in (("normals", normals), ("positions", positions), ("diffuse colors", diffuse)):
+        _chk(name, t, _F32, B, V, 3)
+    _chk_lights(light_positions, light_intensities, ambient, B, shade_max_lights())
+    dev = _require_device(*(tensors + ([ambient] if ambient is not None else [])))
+    L = lib()
+    clip, normals, positions, diffuse, triangles, light_positions, light_intensities = [
+        t.contiguous() for t in tensors]
+    ambient = ambient.contiguous() if ambient is not None else None
+    nl = light_positions.shape[1]
+    ids = torch.empty(B, height, width, dtype=torch.int32, device=dev)
+    bary = torch.empty(B, height, width, 3, dtype=torch.float32, device=dev)
+    z = torch.empty(B, height, width, dtype=torch.float32, device=dev)
+    rgba = torch.empty(B, height, width, 4, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        records = _aligned_bytes(L.mr_shade_forward_workspace_bytes(B, V, T, width, height), dev)
+        need = L.mr_rasterize_forward_workspace_bytes(B, V, T, width, height)
+        ws, have = _workspace(dev, need)
+        _arm_timer(TIMER_RASTER_FORWARD)
+        rc = L.mr_render_forward(_ptr(clip), _ptr(normals), _ptr(positions), _ptr(diffuse), _ptr(triangles),
+                                 _ptr(light_positions), _ptr(light_intensities), _ptr(ambient), B, V, T,
+                                 width, height, nl, _ptr(ids), _ptr(bary), _ptr(z), _ptr(rgba), _ptr(records),
+                                 _ptr(ws), have, _stream(dev))
+    _check(rc, "mr_render_forward")
+    return ids, bary, z, rgba, records
 
 
 def interpolate_raster_max_attributes():

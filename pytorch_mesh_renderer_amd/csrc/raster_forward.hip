@@ -38,6 +38,7 @@
 #include <type_traits>
 
 #include "mr_internal.h"
+#include "shade_pixel.h"
 
 namespace mr {
 
@@ -357,7 +358,17 @@ __device__ __forceinline__ void div3_common_denominator(float n0, float n1, floa
 // the chip with one bin round each).
 // PROBE: 0 in production.  Non-zero values (only instantiated with -DMR_PROBES, see
 // mesh_raster_debug.h) switch stages off for stage timing and leave the outputs undefined.
-template <int R, int PROBE>
+// SHADE: render()'s deferred shading (shade_pixel.h) runs as the epilogue of a region's LAST bin round,
+// on the pixel state the walk still holds in registers, and the RGBA image leaves next to the
+// G-buffer: the separate k_shade_forward pass (16 B/px read again + a second dependent gather level,
+// id -> corner record) disappears.
+struct RasterShade {
+  const CornerRec *__restrict__ corners;  // [B*T] (k_corner_setup)
+  Lights lights;
+  float *__restrict__ rgba;               // [B,H,W,4], image rows (row 0 = top)
+};
+
+template <int R, int PROBE, bool SHADE>
 __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
     const TriRec *__restrict__ recs, const TriBox *__restrict__ bbs,
     const float *__restrict__ pxtab, const float *__restrict__ pytab, int T, int W, int H,
@@ -365,8 +376,9 @@ __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
     const int32_t *__restrict__ cell_ids, const int32_t *__restrict__ cell_count,
     const float *__restrict__ cell_split, int cells_x,
     int cells_per_image, int32_t *__restrict__ ids, float *__restrict__ bary,
-    float *__restrict__ zbuf) {
+    float *__restrict__ zbuf, const RasterShade shade) {
   static_assert(R == 64 || R == 32, "region edge");
+  static_assert(!SHADE || PROBE == 0, "the shading epilogue has no timing probes");
   // A wavefront's tile is kTileW x kTileH pixels, one per lane.  16 x 4: every row of a tile's
   // G-buffer stores is a whole, aligned 64-byte sector (16 ids / depths) or three of them (16
   // barycentric triples); with 8 x 8 tiles two wavefronts shared each sector and the L2 had to
@@ -480,6 +492,17 @@ __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
   const __amdgpu_buffer_rsrc_t rs_ids = __builtin_amdgcn_make_buffer_rsrc(ids + region_pix, 0, 0x7fffffff, kRsrcWord3);
   const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc(zbuf + region_pix, 0, 0x7fffffff, kRsrcWord3);
   const __amdgpu_buffer_rsrc_t rs_bary = __builtin_amdgcn_make_buffer_rsrc(bary + 3 * region_pix, 0, 0x7fffffff, kRsrcWord3);
+  // RGBA rows are flipped (render.py:384-386: image row H-1-y shows G-buffer row y).  The descriptor
+  // is anchored at the image row of the region's LAST G-buffer row -- the lowest address the region
+  // writes; for a ragged top region that row lies above the image and only serves as an origin --
+  // so that tile and lane offsets are non-negative: tile (tx, ty), lane (lx, ly) ->
+  // ((R - kTileH - ty kTileH) W + tx kTileW) + ((kTileH - 1 - ly) W + lx) pixels.
+  const __amdgpu_buffer_rsrc_t rs_rgba = __builtin_amdgcn_make_buffer_rsrc(
+      SHADE ? shade.rgba + 4 * ((ptrdiff_t)img_px + ((ptrdiff_t)H - R - Y0) * W + X0) : nullptr, 0, 0x7fffffff,
+      kRsrcWord3);
+  const CornerRec *img_corners = SHADE ? shade.corners + (size_t)img * T : nullptr;
+  LightsInRegisters lights;
+  if (SHADE) lights.load(shade.lights, img);
   typedef float v3f __attribute__((ext_vector_type(3)));
   typedef unsigned v3u __attribute__((ext_vector_type(3)));
   // Every wavefront of this kernel is fully populated (256-thread workgroups, padding workgroups
@@ -494,7 +517,7 @@ __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
   const unsigned *lane_word = (const unsigned *)lane_px + 2 * R;  // &s_tmask[0][lx]
   // `full`: the region lies wholly inside the image (all but the last column / row of regions of
   // an image whose size is not a multiple of R): no per-tile or per-lane bounds tests at all.
-  auto raster_pass = [&](auto fresh_tag, auto full_tag, const int far_word) {
+  auto raster_pass = [&](auto fresh_tag, auto full_tag, const int far_word, const bool last_round) {
     constexpr bool fresh = decltype(fresh_tag)::value, full = decltype(full_tag)::value;
     const unsigned near_words = (1u << far_word) - 1u;  // far_word == kMaskWords: every word
     // wavefront w walks tiles w, w + 4, ... (row-major tile numbering).  (Walking pairs of
@@ -644,6 +667,76 @@ __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
       if (far_words == 0u || !__ballot(in_image && !(st.z < split))) break;
       words = far_words;
       far_words = 0u;
+      }
+      if (SHADE && last_round) {  // workgroup-uniform
+        // the rule of k_shade_forward: a pixel is shaded iff alpha = clamp(2 sum(bary)) > 0
+        const bool live = in_image && ((2.0f * st.b0 + 2.0f * st.b1) + 2.0f * st.b2) > 0.0f;
+        float4 rgba = make_float4(0.f, 0.f, 0.f, 0.f);
+        // The corner attributes come through the SCALAR cache, one winning triangle of the tile at
+        // a time (a 64-pixel tile shows ~3 of them): scalar loads count on lgkmcnt, so their wait
+        // leaves the G-buffer stores of the previous tile alone -- vector loads count on vmcnt
+        // with the stores, in order, and cost +0.1 ms (measured: per-lane gather 0.420 ms, one
+        // shared record 0.377, no loads 0.321).
+        float interp[9];
+#pragma unroll
+        for (int a = 0; a < 9; ++a) interp[a] = 0.0f;
+        unsigned long long todo = __ballot(live);
+        while (todo) {  // wave-uniform
+          const int src = __builtin_ctzll(todo);
+          const int t = __builtin_amdgcn_readlane(st.id, src);
+          const bool mine = live && st.id == t;
+          const unsigned tc = min((unsigned)max(t, 0), (unsigned)(T - 1));
+          ConstFloats rec = (ConstFloats)(uintptr_t)(img_corners + tc);
+          const float bk[3] = {st.b0, st.b1, st.b2};
+          // the whole 128-byte record with one wait (explicit: left to itself the compiler turns a
+          // 27-dword uniform read into per-lane vector loads)
+          typedef float v16f __attribute__((ext_vector_type(16)));
+          typedef float v8f __attribute__((ext_vector_type(8)));
+          typedef float v4f __attribute__((ext_vector_type(4)));
+          v16f r0;
+          v8f r1;
+          v4f r2;
+          asm volatile(
+              "s_load_dwordx16 %0, %3, 0x0\n\t"
+              "s_load_dwordx8 %1, %3, 0x40\n\t"
+              "s_load_dwordx4 %2, %3, 0x60\n\t"
+              "s_waitcnt lgkmcnt(0)"
+              : "=&s"(r0), "=&s"(r1), "=&s"(r2)
+              : "s"(rec));
+          float c[28];
+#pragma unroll
+          for (int a = 0; a < 16; ++a) c[a] = r0[a];
+#pragma unroll
+          for (int a = 0; a < 8; ++a) c[16 + a] = r1[a];
+#pragma unroll
+          for (int a = 0; a < 4; ++a) c[24 + a] = r2[a];
+          if (mine) {
+#pragma clang fp contract(fast)
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+              for (int a = 0; a < 9; ++a) interp[a] = c[k * 9 + a] * bk[k] + interp[a];
+          }
+          todo &= ~__ballot(mine);
+        }
+        if (live) {
+#pragma clang fp contract(fast)
+          // interpolate9's blend with the -1 background (alpha is 1 on every covered pixel up to rounding)
+          const float pre = (2.0f * st.b0 + 2.0f * st.b1) + 2.0f * st.b2;
+          const float alpha = fminf(fmaxf(pre, 0.0f), 1.0f), one_m = 1.0f - alpha;
+          float at[9];
+#pragma unroll
+          for (int a = 0; a < 9; ++a) at[a] = alpha * interp[a] + one_m * -1.0f;
+          rgba = shade_attributes(at, lights);
+        }
+        if (in_image) {
+          typedef float v4f __attribute__((ext_vector_type(4)));
+          typedef unsigned v4u __attribute__((ext_vector_type(4)));
+          const unsigned lane_rgba = (unsigned)((kTileH - 1 - ly) * W + lx) * 16u;
+          const int tile_rgba = ((R - kTileH - ty * kTileH) * W + tx * kTileW) * 16;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v4f{rgba.x, rgba.y, rgba.z, rgba.w}), rs_rgba,
+                                                 lane_rgba, tile_rgba, 0);
+        }
       }
       if (in_image && !((PROBE & 32) && st.z != 123.0f)) {  // 32: timing probe, no stores
         __builtin_amdgcn_raw_buffer_store_b32((unsigned)max(st.id, 0), rs_ids, lane_pix * 4u, tile_pix * 4, 0);
@@ -805,10 +898,11 @@ __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
     __syncthreads();
     // mask word that starts the far class (kMaskWords: no clean cut, the walk never skips)
     const int far_word = (ordered && n_far > 0 && (far_base & 31) == 0) ? far_base >> 5 : kMaskWords;
+    const bool last_round = next_base >= n_cand;
     auto walk = [&]() {
-      if (!first_pass) raster_pass(std::false_type{}, std::false_type{}, far_word);
-      else if (X1 - X0 == R && Y1 - Y0 == R) raster_pass(std::true_type{}, std::true_type{}, far_word);
-      else raster_pass(std::true_type{}, std::false_type{}, far_word);
+      if (!first_pass) raster_pass(std::false_type{}, std::false_type{}, far_word, last_round);
+      else if (X1 - X0 == R && Y1 - Y0 == R) raster_pass(std::true_type{}, std::true_type{}, far_word, last_round);
+      else raster_pass(std::true_type{}, std::false_type{}, far_word, last_round);
     };
     if constexpr (PROBE == 0 || PROBE >= 8) {
       build_tile_masks(n_near, far_base, n_far);
@@ -860,17 +954,19 @@ struct RasterArgs {
   const float *cell_split;
   int cells_x, cells_per_image;
   int32_t *ids; float *bary, *z;
+  RasterShade shade;  // rgba == nullptr: G-buffer only
 };
 
-template <int R, int PROBE>
+template <int R, int PROBE, bool SHADE = false>
 void launch_k_raster(const RasterArgs &a, dim3 grid, hipStream_t s) {
-  hipLaunchKernelGGL((k_raster<R, PROBE>), grid, dim3(kThreads), 0, s, a.recs, a.bbs, a.pxtab, a.pytab, a.T, a.W,
-                     a.H, a.regions_x, a.per_image, a.n_regions, a.per_xcd, a.cell_ids, a.cell_count, a.cell_split, a.cells_x,
-                     a.cells_per_image, a.ids, a.bary, a.z);
+  hipLaunchKernelGGL((k_raster<R, PROBE, SHADE>), grid, dim3(kThreads), 0, s, a.recs, a.bbs, a.pxtab, a.pytab, a.T,
+                     a.W, a.H, a.regions_x, a.per_image, a.n_regions, a.per_xcd, a.cell_ids, a.cell_count,
+                     a.cell_split, a.cells_x, a.cells_per_image, a.ids, a.bary, a.z, a.shade);
 }
 
 template <int R>
 void launch_k_raster_probe(const RasterArgs &a, dim3 grid, hipStream_t s) {
+  if (a.shade.rgba) return launch_k_raster<R, 0, true>(a, grid, s);
 #ifdef MR_PROBES
   switch (g_raster_probe) {
     case 1: return launch_k_raster<R, 1>(a, grid, s);
@@ -887,8 +983,9 @@ void launch_k_raster_probe(const RasterArgs &a, dim3 grid, hipStream_t s) {
 }
 }  // namespace
 
-int launch_raster_forward(const float *clip, const int32_t *tris, int B, int V, int T, int W,
-                          int H, int32_t *ids, float *bary, float *z, void *ws, hipStream_t s) {
+namespace {
+int raster_forward(const float *clip, const int32_t *tris, int B, int V, int T, int W, int H, int32_t *ids,
+                   float *bary, float *z, const RasterShade &shade, void *ws, hipStream_t s) {
   const size_t nbt = (size_t)B * T;
   char *p = (char *)ws;
   TriRec *recs = (TriRec *)p;
@@ -927,13 +1024,34 @@ int launch_raster_forward(const float *clip, const int32_t *tris, int B, int V, 
   const int per_xcd = (n_regions + kXcds - 1) / kXcds;
   const dim3 grid((unsigned)(per_xcd * kXcds));
   const RasterArgs args{recs, bbs, pxtab, pytab, T, W, H, regions_x, per_image, n_regions, per_xcd,
-                        cell_ids, cell_count, cell_split, cells_x, cells_per_image, ids, bary, z};
+                        cell_ids, cell_count, cell_split, cells_x, cells_per_image, ids, bary, z, shade};
   {
     KernelTimer timer(MR_TIMER_RASTER_FORWARD, s);  // records only when a caller armed it
     if (edge == 32) launch_k_raster_probe<32>(args, grid, s);
     else launch_k_raster_probe<64>(args, grid, s);
   }
   return check_launch();
+}
+}  // namespace
+
+int launch_raster_forward(const float *clip, const int32_t *tris, int B, int V, int T, int W,
+                          int H, int32_t *ids, float *bary, float *z, void *ws, hipStream_t s) {
+  return raster_forward(clip, tris, B, V, T, W, H, ids, bary, z, RasterShade{nullptr, Lights{nullptr, nullptr, nullptr, 0}, nullptr},
+                        ws, s);
+}
+
+// render()'s forward in one pass over the pixels: G-buffer + shaded RGBA (see RasterShade).
+// `corner_records`: shade_forward_ws() bytes, filled here (and reusable by the shading backward).
+int launch_render_forward(const float *clip, const float *normals, const float *positions, const float *diffuse,
+                          const int32_t *tris, const float *light_pos, const float *light_col,
+                          const float *ambient, int B, int V, int T, int W, int H, int L, int32_t *ids,
+                          float *bary, float *z, float *rgba, void *corner_records, void *ws, hipStream_t s) {
+  if ((size_t)B * W * H == 0) return MR_OK;
+  CornerRec *corners = (CornerRec *)corner_records;
+  const int rc = launch_corner_setup(normals, positions, diffuse, tris, B, V, T, corners, s);
+  if (rc != MR_OK) return rc;
+  return raster_forward(clip, tris, B, V, T, W, H, ids, bary, z,
+                        RasterShade{corners, Lights{light_pos, light_col, ambient, L}, rgba}, ws, s);
 }
 
 }  // namespace mr

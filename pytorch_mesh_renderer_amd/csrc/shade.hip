@@ -24,22 +24,13 @@
 //                      per-lane sums reduced once per wave.
 //   k_shade_scatter    one thread per touched (image, triangle): atomics into
 //                      dnormals / dpositions / ddiffuse [B,V,3] and dclip [B,V,4].
-#include "corner_rec.h"
+#include "shade_pixel.h"
 
 namespace mr {
 namespace {
 
 constexpr int kThreads = 256;
-constexpr float kNormEps = 1e-12f;         // torch.nn.functional.normalize default eps
 constexpr float kDegenerateCutoff = 0.9f;  // rasterize_triangles.cpp:13
-constexpr int kMaxLights = 4;              // fused path; more lights use the composed path
-
-struct Lights {
-  const float *__restrict__ pos;  // [B,L,3]
-  const float *__restrict__ col;  // [B,L,3]
-  const float *__restrict__ amb;  // [B,3] or nullptr
-  int L;
-};
 
 __global__ __launch_bounds__(kThreads) void k_corner_setup(
     const F3 *__restrict__ normals, const F3 *__restrict__ positions, const F3 *__restrict__ diffuse,
@@ -63,52 +54,6 @@ __global__ __launch_bounds__(kThreads) void k_corner_setup(
   for (int i = 27; i < 32; ++i) v[i] = 0.f;
 #pragma unroll
   for (int q = 0; q < 8; ++q) out[gid].q[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-}
-
-// 1-ulp hardware reciprocal / square root (v_rcp_f32, v_sqrt_f32): the IEEE-exact sequences
-// are ~10 VALU ops each and these kernels are VALU-bound; the parity budget is 1e-4 absolute.
-__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
-__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
-
-// alpha = clamp(sum(2*bary), 0, 1); attr = alpha * interp + (1 - alpha) * (-1)
-// (rasterize.py:137-150 with render.py:197's background of -1).
-__device__ __forceinline__ void interpolate9(const Corners &cr, const F3 b, float &pre, float &alpha,
-                                             float (&interp)[9], float (&attr)[9]) {
-  pre = (2.0f * b.x + 2.0f * b.y) + 2.0f * b.z;
-  alpha = fminf(fmaxf(pre, 0.0f), 1.0f);
-  const float one_m = 1.0f - alpha;
-#pragma unroll
-  for (int a = 0; a < 9; ++a) {
-    interp[a] = (cr.c[0][a] * b.x + cr.c[1][a] * b.y) + cr.c[2][a] * b.z;
-    attr[a] = alpha * interp[a] + one_m * -1.0f;
-  }
-}
-
-// Shading of one covered pixel from its interpolated attributes (render.py:201-215, 298-323).
-__device__ __forceinline__ float4 shade_pixel(const Corners &cr, const F3 b, const Lights &lights, int img) {
-  float pre, alpha, interp[9], at[9];
-  interpolate9(cr, b, pre, alpha, interp, at);
-  const bool mask = (at[6] >= 0.0f) || (at[7] >= 0.0f) || (at[8] >= 0.0f);  // render.py:215
-  if (!mask) return make_float4(0.f, 0.f, 0.f, 0.f);
-  const float nn = fast_sqrt(at[0] * at[0] + at[1] * at[1] + at[2] * at[2]);
-  const float inv_nn = fast_rcp(fmaxf(nn, kNormEps));
-  const float nx = at[0] * inv_nn, ny = at[1] * inv_nn, nz = at[2] * inv_nn;
-  float r = 0.f, g = 0.f, bl = 0.f;
-  if (lights.amb) {  // render.py:298-301
-    const float *am = lights.amb + (size_t)img * 3;
-    r = am[0] * at[6]; g = am[1] * at[7]; bl = am[2] * at[8];
-  }
-  for (int l = 0; l < lights.L; ++l) {  // render.py:304-323
-    const float *lp = lights.pos + ((size_t)img * lights.L + l) * 3;
-    const float *li = lights.col + ((size_t)img * lights.L + l) * 3;
-    const float vx = lp[0] - at[3], vy = lp[1] - at[4], vz = lp[2] - at[5];
-    const float inv_vn = fast_rcp(fmaxf(fast_sqrt(vx * vx + vy * vy + vz * vz), kNormEps));
-    const float ndl = fminf(fmaxf(nx * (vx * inv_vn) + ny * (vy * inv_vn) + nz * (vz * inv_vn), 0.0f), 1.0f);
-    r += at[6] * ndl * li[0];
-    g += at[7] * ndl * li[1];
-    bl += at[8] * ndl * li[2];
-  }
-  return make_float4(r, g, bl, 1.0f);
 }
 
 // One workgroup = 256 consecutive pixels of a row segment x kRows consecutive rows; each

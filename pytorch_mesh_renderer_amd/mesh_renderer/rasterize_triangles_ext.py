@@ -6,6 +6,8 @@ rasterizes ONE image per call; this one also accepts a batch ([B,V,4]) so that
 rasterize_clip_space does not need a Python loop over images
 (src/mesh_renderer/rasterize.py:112-121) -- on MI355X the batch is the grid.
 """
+import os
+
 import torch
 
 from .. import _native
@@ -105,10 +107,15 @@ class FusedAttributeRasterizer(torch.autograd.Function):
         return dclip, dattrs, None, dbackground, None, None
 
 
+# FusedPhongRenderer's forward: True = one pass over the pixels (mr_render_forward: the shading is the
+# epilogue of the rasterizer's tile walk); False = k_raster, then k_shade_forward over the G-buffer.
+USE_SHADING_EPILOGUE = os.environ.get("MR_SHADING_EPILOGUE", "1") != "0"
+
+
 class FusedPhongRenderer(torch.autograd.Function):
     """G-buffer rasterization + attribute interpolation + diffuse/ambient Phong as ONE
-    differentiable op: 2 kernels forward (k_raster, k_shade_forward), 1 pass over the
-    G-buffer backward.  Used by render() when no specular term is requested; covers
+    differentiable op: 1 pass over the pixels forward (k_raster with the shading epilogue), 1 pass
+    over the G-buffer backward.  Used by render() when no specular term is requested; covers
     src/mesh_renderer/rasterize.py:66-152 and src/mesh_renderer/render.py:199-228,
     287-323, 373-386 and their autograd graph."""
 
@@ -116,12 +123,16 @@ class FusedPhongRenderer(torch.autograd.Function):
     def forward(ctx, clip, positions, normals, diffuse, triangles, light_positions,
                 light_intensities, ambient, image_width, image_height):
         clip_d = clip.detach().contiguous()
-        ids, bary, _ = _native.rasterize_forward(clip_d, triangles, int(image_width), int(image_height))
         args = [t.detach().contiguous() for t in (normals, positions, diffuse)]
         lp, li = light_positions.detach().contiguous(), light_intensities.detach().contiguous()
         amb = ambient.detach().contiguous() if ambient is not None else None
-        rgba, corner_records = _native.shade_forward(ids, bary, args[0], args[1], args[2], triangles, lp, li,
-                                                     amb, keep_corner_records=True)
+        if USE_SHADING_EPILOGUE:
+            ids, bary, _, rgba, corner_records = _native.render_forward(
+                clip_d, args[0], args[1], args[2], triangles, lp, li, amb, int(image_width), int(image_height))
+        else:
+            ids, bary, _ = _native.rasterize_forward(clip_d, triangles, int(image_width), int(image_height))
+            rgba, corner_records = _native.shade_forward(ids, bary, args[0], args[1], args[2], triangles, lp,
+                                                         li, amb, keep_corner_records=True)
         offsets, entries = _native.vertex_adjacency(triangles, positions.shape[1])   # cached per mesh
         saved = [clip_d, ids, bary, args[0], args[1], args[2], triangles, lp, li, corner_records,
                  offsets, entries]
