@@ -290,14 +290,22 @@ def main():
     assert vertices.grad is not None and bool(torch.isfinite(vertices.grad).all())
 
     # Outside the timed region: the G-buffer kernel on its own (what rasterize_barycentric() and the
-    # non-fused paths launch; the step's forward runs it with the shading epilogue attached).
+    # non-fused paths launch; the step's forward runs it with the shading epilogue attached), timed
+    # inside the same step with the epilogue switched off (k_raster, then k_shade_forward).
     n_gb = 20
     ev_gbuffer = KernelEvents(n_gb, _native.TIMER_RASTER_FORWARD)
-    clip_d, tri_d = job["clip"].to(device), job["triangles"].to(device)
-    for i in range(n_gb + 2):
-        if i >= 2:
-            ev_gbuffer.arm(i - 2)
-        _native.rasterize_forward(clip_d, tri_d, width, height)
+    ext = sys.modules["pytorch_mesh_renderer_amd.mesh_renderer.rasterize_triangles_ext"]
+    epilogue_was = ext.USE_SHADING_EPILOGUE
+    ext.USE_SHADING_EPILOGUE = False
+    try:
+        for i in range(n_gb + 2):
+            if i >= 2:
+                ev_gbuffer.arm(i - 2)
+            step()
+    finally:
+        ext.USE_SHADING_EPILOGUE = epilogue_was
+    if gather is not None:
+        gather.wait()
     torch.cuda.synchronize(device)
 
     if rank == 0:
@@ -321,7 +329,7 @@ def main():
             "roofline": roofline("k_raster<shade> (forward: G-buffer + shaded RGBA write)",
                                  px * 36 + batch * V * 16 + T * 12 + batch * T * 128,
                                  ev_raster.mean_ms(n_ev), "k_raster_shade"),
-            "roofline_gbuffer": roofline("k_raster (G-buffer write alone, %d launches after the timed region)" % n_gb,
+            "roofline_gbuffer": roofline("k_raster (G-buffer write alone: %d steps with the shading epilogue off, after the timed region)" % n_gb,
                                          px * 20 + batch * V * 16 + T * 12, ev_gbuffer.mean_ms(n_gb), "k_raster"),
             # ids + barycentrics (16 B/px) and the loss's sign codes (1 B/px) read, the triangles'
             # attribute and adjugate records (128 + 64 B) read

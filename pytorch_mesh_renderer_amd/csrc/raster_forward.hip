@@ -368,8 +368,11 @@ struct RasterShade {
   float *__restrict__ rgba;               // [B,H,W,4], image rows (row 0 = top)
 };
 
+#ifndef MR_RASTER_SHADE_WAVES
+#define MR_RASTER_SHADE_WAVES 6  // measured against 7 (more spills) and 5: 0.336 / 0.352 / 0.347 ms at 1024^2 x 32
+#endif
 template <int R, int PROBE, bool SHADE>
-__global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
+__global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : MR_RASTER_WAVES) void k_raster(
     const TriRec *__restrict__ recs, const TriBox *__restrict__ bbs,
     const float *__restrict__ pxtab, const float *__restrict__ pytab, int T, int W, int H,
     int regions_x, int regions_per_image, int n_regions, int regions_per_xcd,
@@ -687,6 +690,7 @@ __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
           const bool mine = live && st.id == t;
           const unsigned tc = min((unsigned)max(t, 0), (unsigned)(T - 1));
           ConstFloats rec = (ConstFloats)(uintptr_t)(img_corners + tc);
+          todo &= ~__ballot(mine);
           const float bk[3] = {st.b0, st.b1, st.b2};
           // the whole 128-byte record with one wait (explicit: left to itself the compiler turns a
           // 27-dword uniform read into per-lane vector loads)
@@ -696,6 +700,8 @@ __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
           v16f r0;
           v8f r1;
           v4f r2;
+          // (one asm block from the first load to the wait: the compiler does not track loads it did
+          // not issue and must not be given a chance to reuse their destination registers early)
           asm volatile(
               "s_load_dwordx16 %0, %3, 0x0\n\t"
               "s_load_dwordx8 %1, %3, 0x40\n\t"
@@ -717,7 +723,6 @@ __global__ __launch_bounds__(kThreads, MR_RASTER_WAVES) void k_raster(
 #pragma unroll
               for (int a = 0; a < 9; ++a) interp[a] = c[k * 9 + a] * bk[k] + interp[a];
           }
-          todo &= ~__ballot(mine);
         }
         if (live) {
 #pragma clang fp contract(fast)

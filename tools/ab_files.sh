@@ -16,6 +16,7 @@ for v in "$old" "$new" "$old" "$new"; do
   case "$AB_BENCH" in
     shade) timeout -k 5 100 python tools/shade_bench.py 2>/dev/null | grep shade ;;
     soft)  timeout -k 5 200 python tools/soft_bench.py 2>/dev/null | grep config5 ;;
+    bench) timeout -k 5 200 python bench.py --cpu-sample 0 --steps 100 2>/dev/null | grep -o "ms_per_step[^,]*\|avg_kernel_ms[^,]*" | tr '\n' ' '; echo ;;
     *)     for k in 0 32 40; do timeout -k 5 100 python tools/raster_bench.py --variant $k 2>/dev/null | grep variant; done ;;
   esac
 done
