@@ -230,8 +230,10 @@ __global__ __launch_bounds__(kRunThreads, Fn::kMinWavesPerSimd) void k_accumulat
   // per CU -- as long as the kernel itself.  The table is private to its wavefront (LDS executes a
   // wavefront's operations in order: plain read-add-write, no LDS atomics); lane i of `merge_keys`
   // holds the triangle id of slot i, so a lookup is one compare + ballot.
+  // A slot is a whole 64-float row (lanes >= N carry along a copy of lane N-1's sum): reads and
+  // writes of a slot then need no lane mask.
   constexpr int kMergeSlots = MR_ROWS_MERGE_SLOTS;
-  __shared__ float s_merge[kRunThreads / kWave][kMergeSlots > 0 ? kMergeSlots * N : 1];
+  __shared__ float s_merge[kRunThreads / kWave][kMergeSlots > 0 ? kMergeSlots * kWave : 1];
 
   const int region = xcd_contiguous_block((int)blockIdx.x, n_regions, regions_per_xcd);
   if (region < 0) return;
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(kRunThreads, Fn::kMinWavesPerSimd) void k_accumulat
   auto flush_merge_table = [&]() {
 #pragma unroll 1
     for (int slot = 0; slot < merge_count; ++slot)
-      commit(__builtin_amdgcn_readlane(merge_keys, slot), merge[slot * N + min(lane, N - 1)]);
+      commit(__builtin_amdgcn_readlane(merge_keys, slot), merge[slot * kWave + lane]);
     merge_count = 0;
     merge_keys = -1;
   };
@@ -320,32 +322,32 @@ __global__ __launch_bounds__(kRunThreads, Fn::kMinWavesPerSimd) void k_accumulat
     // without a head is eight FMAs straight; only at a head (~3.5 per row) the running sum is
     // closed -- into the merge table -- and restarted.  No per-segment loops, no masks, no tails.
     int cur_t = -1;           // triangle of the running segment, wave-uniform
-    unsigned cur_hit = 0u;    // its merge-table slot (bit mask; 0: none yet) ...
-    float merged = 0.0f;      // ... and that slot's value, requested when the segment starts
+    int cur_slot = -1;        // its merge-table slot, claimed when the segment starts (-1: none) ...
+    float merged = 0.0f;      // ... and that slot's value so far, requested at the same time
     float sum = 0.0f;
     auto close_segment = [&]() {
-      if (cur_t < 0) return;
 #if MR_PROBE_ROWS == 1  // timing probe: reduction but no global atomics
-      if (lane < N && sum == 123.456f) atomicAdd(&acc_img[(size_t)cur_t * STRIDE + lane], sum);
+      if (cur_t >= 0 && lane < N && sum == 123.456f) atomicAdd(&acc_img[(size_t)cur_t * STRIDE + lane], sum);
 #else
-      if (kMergeSlots == 0) {
-        commit(cur_t, sum);  // one contiguous N-lane atomic per segment
-      } else if (cur_hit) {
-        if (lane < N) merge[__builtin_ctz(cur_hit) * N + lane] = merged + sum;
-      } else if (merge_count < kMergeSlots) {  // (the table was emptied before the pass if it was short of room)
-        if (lane == merge_count) merge_keys = cur_t;
-        if (lane < N) merge[merge_count * N + lane] = sum;
-        merge_count += 1;
-      } else {
-        commit(cur_t, sum);  // more segments in one row than the table has slots: straight out
-      }
+      if (cur_slot >= 0) merge[cur_slot * kWave + lane] = merged + sum;
+      else if (cur_t >= 0) commit(cur_t, sum);  // no table, or more segments in one row than it has slots
 #endif
     };
     auto open_segment = [&](const int pixel) {
       close_segment();
       cur_t = __builtin_amdgcn_readlane(my_tri, pixel);
-      cur_hit = kMergeSlots > 0 ? (unsigned)__ballot(merge_keys == cur_t) : 0u;
-      merged = cur_hit ? merge[__builtin_ctz(cur_hit) * N + min(lane, N - 1)] : 0.0f;
+      const unsigned hit = kMergeSlots > 0 ? (unsigned)__ballot(merge_keys == cur_t) : 0u;
+      merged = 0.0f;
+      if (hit) {
+        cur_slot = __builtin_ctz(hit);
+        merged = merge[cur_slot * kWave + lane];
+      } else if (merge_count < kMergeSlots) {  // (the table was emptied before the pass if it was short of room)
+        cur_slot = merge_count;
+        if (lane == merge_count) merge_keys = cur_t;
+        merge_count += 1;
+      } else {
+        cur_slot = -1;
+      }
       sum = 0.0f;
     };
     // each head may claim a slot of the merge table: if they might not all fit, everything in the
@@ -353,22 +355,32 @@ __global__ __launch_bounds__(kRunThreads, Fn::kMinWavesPerSimd) void k_accumulat
     if (kMergeSlots > 0 && merge_count + (int)__builtin_popcountll(heads) > kMergeSlots) flush_merge_table();
     const int first_group = heads ? (int)(__builtin_ctzll(heads) >> 3) : 8;
     const int last_group = valids ? (63 - (int)__builtin_clzll(valids)) >> 3 : -1;
-    for (int g = first_group; g <= last_group; ++g) {
-      v2f ra[4], rb[4];
-      lds_read_pairs4(row_a + 32u * g, row_b + 32u * g, ra, rb);
-      const unsigned hg = (unsigned)(heads >> (8 * g)) & 0xffu;
-      if (hg == 0u) {
+    // Runs of head-free groups go through a loop of their own (8 reads, 8 FMAs, two address
+    // increments: as one loop with the head handling, the compiler spent 14 scalar and 12 vector
+    // instructions per group on loop-carried copies of the segment state).
+    for (int g = first_group; g <= last_group;) {
+      const unsigned long long rest = heads >> (8 * g);  // heads at or after group g
+      const int plain = min(rest ? (int)(__builtin_ctzll(rest) >> 3) : 8, last_group + 1 - g);
+      unsigned addr_a = row_a + 32u * g, addr_b = row_b + 32u * g;
+      for (int k = 0; k < plain; ++k, addr_a += 32u, addr_b += 32u) {
+        v2f ra[4], rb[4];
+        lds_read_pairs4(addr_a, addr_b, ra, rb);
 #pragma unroll
         for (int j = 0; j < 4; ++j) sum = fmaf(ra[j].y, rb[j].y, fmaf(ra[j].x, rb[j].x, sum));
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (hg & (1u << (2 * j))) open_segment(8 * g + 2 * j);
-          sum = fmaf(ra[j].x, rb[j].x, sum);
-          if (hg & (2u << (2 * j))) open_segment(8 * g + 2 * j + 1);
-          sum = fmaf(ra[j].y, rb[j].y, sum);
-        }
       }
+      g += plain;
+      if (g > last_group) break;
+      v2f ra[4], rb[4];  // group g holds a head
+      lds_read_pairs4(addr_a, addr_b, ra, rb);
+      const unsigned hg = (unsigned)(heads >> (8 * g)) & 0xffu;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (hg & (1u << (2 * j))) open_segment(8 * g + 2 * j);
+        sum = fmaf(ra[j].x, rb[j].x, sum);
+        if (hg & (2u << (2 * j))) open_segment(8 * g + 2 * j + 1);
+        sum = fmaf(ra[j].y, rb[j].y, sum);
+      }
+      ++g;
     }
     close_segment();
     __builtin_amdgcn_wave_barrier();

@@ -358,47 +358,58 @@ __global__ __launch_bounds__(kThreads) void k_shade_scatter(
   }
 }
 
-// Vertex-centric alternative to k_shade_scatter: one thread per (image, vertex) sums the rows
-// of the triangles incident to its vertex (CSR adjacency built once per triangle array on the
-// host side: entry e = 3 * triangle + corner, grouped by vertex).  No atomics, every output is
-// written exactly once, the summation order is fixed.
+// Vertex-centric alternative to k_shade_scatter: the rows of the triangles incident to a vertex
+// are summed per (image, vertex) (CSR adjacency built once per triangle array on the host side:
+// entry e = 3 * triangle + corner, grouped by vertex).  No atomics, every output is written
+// exactly once, the summation order is fixed.  Sixteen lanes per (image, vertex), one per output
+// float (9 attribute gradients, 3 clip gradients, the clip z column's 0, 3 idle); the incident
+// corners are fetched kChunk at a time, all loads of a chunk in flight together: the kernel is a
+// chain of dependent load round trips (offsets -> entries -> rows), and as long as its longest
+// chain -- the poles of a UV sphere have 50-100 incident triangles.
+#ifndef MR_GATHER_CHUNK
+#define MR_GATHER_CHUNK 8   // measured at 32 x 2502 vertices: 8 -> 31.6, 16 -> 33.1, 32 -> 41.8, 64 -> 74.9 us
+#endif
 template <bool DET>
 __global__ __launch_bounds__(kThreads) void k_shade_gather(
     const float *__restrict__ acc, const float *__restrict__ det_scale, const int32_t *__restrict__ offsets,
     const int32_t *__restrict__ entries, int B, int V, int T, float *__restrict__ dnormals,
     float *__restrict__ dpositions, float *__restrict__ ddiffuse, float *__restrict__ dclip) {
-  const long gid = (long)blockIdx.x * kThreads + threadIdx.x;
-  if (gid >= (long)B * V) return;
+  const long tid = (long)blockIdx.x * kThreads + threadIdx.x;
+  const long gid = tid >> 4;   // (image, vertex)
+  const int j = (int)(tid & 15);
+  if (gid >= (long)B * V || j > 12) return;
   const int b = (int)(gid / V);
   const int v = (int)(gid - (long)b * V);
-  float a[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, c[3] = {0.f, 0.f, 0.f};
-  const int e1 = offsets[v + 1];
-  for (int i = offsets[v]; i < e1; ++i) {
-    const int e = entries[i];
-    const int t = e / 3, k = e - 3 * t;
-    if (DET) {  // fixed-point rows (8-byte elements) back to float, then the same fixed-order sums
-      const long long *row = (const long long *)acc + ((size_t)b * T + t) * 36;
-      const float from_fixed = det_scale[1];
+  float sum = 0.f;
+  if (j < 12) {
+    const int e1 = offsets[v + 1];
+    constexpr int kChunk = MR_GATHER_CHUNK;
+    // this lane's float inside a triangle's 36-float row is  col0 + k * colk  for corner k
+    const unsigned col0 = j < 9 ? (unsigned)j : 27u + (unsigned)(j - 9), colk = j < 9 ? 9u : 3u;
+    const float *acc_f = acc + (size_t)b * T * 36;                                  // 32-bit offsets from here:
+    const long long *acc_x = (const long long *)acc + (size_t)b * T * 36;          // T * 36 < 2^31
+    for (int i = offsets[v]; i < e1; i += kChunk) {
+      int e[kChunk];
+      float val[kChunk];
 #pragma unroll
-      for (int j = 0; j < 9; ++j) a[j] += (float)row[k * 9 + j] * from_fixed;
+      for (int u = 0; u < kChunk; ++u) e[u] = i + u < e1 ? entries[i + u] : -1;
 #pragma unroll
-      for (int j = 0; j < 3; ++j) c[j] += (float)row[27 + k * 3 + j] * from_fixed;
-    } else {
-      const float *row = acc + ((size_t)b * T + t) * 36;
+      for (int u = 0; u < kChunk; ++u) {
+        const unsigned t = (unsigned)e[u] / 3u, k = (unsigned)e[u] - 3u * t;
+        const unsigned at = t * 36u + col0 + k * colk;
+        // DET: fixed-point rows (8-byte elements) back to float, then the same fixed-order sums
+        val[u] = e[u] < 0 ? 0.f : DET ? (float)acc_x[at] * det_scale[1] : acc_f[at];
+      }
 #pragma unroll
-      for (int j = 0; j < 9; ++j) a[j] += row[k * 9 + j];
-#pragma unroll
-      for (int j = 0; j < 3; ++j) c[j] += row[27 + k * 3 + j];
+      for (int u = 0; u < kChunk; ++u) sum += val[u];
     }
   }
-  const size_t v3 = (size_t)gid * 3;
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    dnormals[v3 + j] = a[j];
-    dpositions[v3 + j] = a[3 + j];
-    ddiffuse[v3 + j] = a[6 + j];
-  }
-  ((float4 *)dclip)[gid] = make_float4(c[0], c[1], 0.0f, c[2]);  // column z stays 0
+  float *out = j < 3 ? dnormals + gid * 3 + j
+             : j < 6 ? dpositions + gid * 3 + (j - 3)
+             : j < 9 ? ddiffuse + gid * 3 + (j - 6)
+             : j < 11 ? dclip + gid * 4 + (j - 9)
+             : j == 11 ? dclip + gid * 4 + 3 : dclip + gid * 4 + 2;  // j == 12: column z stays 0
+  *out = sum;
 }
 
 inline unsigned capped_blocks(size_t n) {
@@ -573,7 +584,7 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
 #undef MR_SHADE_BWD
   if (rc != MR_OK) return rc;
   if (vertex_offsets && vertex_entries) {
-    const long nbv = (long)B * V;
+    const long nbv = (long)B * V * 16;  // sixteen lanes per vertex
     const dim3 grid((unsigned)((nbv + kThreads - 1) / kThreads));
     if (det) {
       hipLaunchKernelGGL(k_shade_gather<true>, grid, dim3(kThreads), 0, s, acc, det_scale, vertex_offsets,
