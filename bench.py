@@ -324,10 +324,11 @@ def main():
                                        "8-bit" if args.handover == "u8" else "fp32"),
                        "global_batch": batch * world, "image": [height, width], "triangles": T,
                        "handover": args.handover},
-            # the step's forward kernel: G-buffer (20 B/px) + RGBA (16 B/px) written, clip-space
-            # vertices, triangle list and the per-triangle attribute records (128 B) read
-            "roofline": roofline("k_raster<shade> (forward: G-buffer + shaded RGBA write)",
-                                 px * 36 + batch * V * 16 + T * 12 + batch * T * 128,
+            # the step's forward kernel: ids + barycentrics (16 B/px; render() does not ask for the
+            # depth plane) + RGBA (16 B/px) written, clip-space vertices, triangle list and the
+            # per-triangle attribute records (128 B) read
+            "roofline": roofline("k_raster<shade> (forward: ids + barycentrics + shaded RGBA write)",
+                                 px * 32 + batch * V * 16 + T * 12 + batch * T * 128,
                                  ev_raster.mean_ms(n_ev), "k_raster_shade"),
             "roofline_gbuffer": roofline("k_raster (G-buffer write alone: %d steps with the shading epilogue off, after the timed region)" % n_gb,
                                          px * 20 + batch * V * 16 + T * 12, ev_gbuffer.mean_ms(n_gb), "k_raster"),

@@ -154,6 +154,10 @@ int mr_shade_forward(const int32_t *ids, const float *bary, const float *normals
  * What FusedPhongRenderer (render() without a specular term) calls.  Outputs: the G-buffer of
  * mr_rasterize_forward (ids, bary, z) and the image of mr_shade_forward (rgba), bit-identical
  * G-buffer, RGBA within the shading's 1e-4 budget.
+ *   z, want_z       z is always a [B,H,W] buffer; with want_z == 0 the caller declares that it will
+ *                   not read it (render() does not): the depth plane is then written only where a
+ *                   crowded region needs it as state between its bin rounds, 4 B/px of stores less,
+ *                   and its contents after the call are undefined.
  *   corner_records  out, mr_shade_forward_workspace_bytes() bytes, 128-byte aligned: the gathered
  *                   per-triangle attribute records; may be handed to mr_shade_backward.
  *   workspace       mr_rasterize_forward_workspace_bytes() bytes */
@@ -161,8 +165,8 @@ int mr_render_forward(const float *clip, const float *normals, const float *posi
                       const float *diffuse, const int32_t *triangles,
                       const float *light_positions, const float *light_intensities,
                       const float *ambient, int B, int V, int T, int W, int H, int L,
-                      int32_t *ids, float *bary, float *z, float *rgba, void *corner_records,
-                      void *workspace, size_t workspace_bytes, void *stream);
+                      int32_t *ids, float *bary, float *z, int want_z, float *rgba,
+                      void *corner_records, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Backward of mr_shade_forward AND of the rasterizer underneath it, in one pass
  * over the G-buffer (reads 32 B/px).  All outputs are zeroed here.

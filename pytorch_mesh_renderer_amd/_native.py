@@ -148,7 +148,7 @@ def lib():
         L.mr_interpolate_forward_records.restype = ci
         L.mr_interpolate_raster_backward.argtypes = [vp] * 10 + [ci] * 6 + [vp, vp, vp, sz, vp]
         L.mr_interpolate_raster_backward.restype = ci
-        L.mr_render_forward.argtypes = [vp] * 8 + [ci] * 6 + [vp] * 6 + [sz, vp]
+        L.mr_render_forward.argtypes = [vp] * 8 + [ci] * 6 + [vp, vp, vp, ci] + [vp] * 3 + [sz, vp]
         L.mr_render_forward.restype = ci
         L.mr_shade_specular_forward_workspace_bytes.argtypes = [ci] * 5
         L.mr_shade_specular_forward_workspace_bytes.restype = sz
@@ -415,9 +415,10 @@ def shade_forward(ids, bary, normals, positions, diffuse, triangles, light_posit
 
 
 def render_forward(clip, normals, positions, diffuse, triangles, light_positions, light_intensities,
-                   ambient, width, height):
+                   ambient, width, height, want_z=True):
     """rasterize_forward + shade_forward in one pass over the pixels (the shading is the epilogue
-    of the rasterizer's tile walk) -> (ids, bary, z, rgba, corner_records)."""
+    of the rasterizer's tile walk) -> (ids, bary, z, rgba, corner_records); with want_z=False the
+    depth plane is not written (z is returned as None)."""
     tensors = [clip, normals, positions, diffuse, triangles, light_positions, light_intensities]
     B, V, T = _chk_mesh(clip, triangles)
     for name, t in (("normals", normals), ("positions", positions), ("diffuse colors", diffuse)):
@@ -440,10 +441,10 @@ def render_forward(clip, normals, positions, diffuse, triangles, light_positions
         _arm_timer(TIMER_RASTER_FORWARD)
         rc = L.mr_render_forward(_ptr(clip), _ptr(normals), _ptr(positions), _ptr(diffuse), _ptr(triangles),
                                  _ptr(light_positions), _ptr(light_intensities), _ptr(ambient), B, V, T,
-                                 width, height, nl, _ptr(ids), _ptr(bary), _ptr(z), _ptr(rgba), _ptr(records),
-                                 _ptr(ws), have, _stream(dev))
+                                 width, height, nl, _ptr(ids), _ptr(bary), _ptr(z), int(bool(want_z)), _ptr(rgba),
+                                 _ptr(records), _ptr(ws), have, _stream(dev))
     _check(rc, "mr_render_forward")
-    return ids, bary, z, rgba, records
+    return ids, bary, (z if want_z else None), rgba, records
 
 
 def interpolate_raster_max_attributes():

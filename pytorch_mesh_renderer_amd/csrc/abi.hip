@@ -210,7 +210,7 @@ int mr_shade_forward(const int32_t *ids, const float *bary, const float *normals
 int mr_render_forward(const float *clip, const float *normals, const float *positions,
                       const float *diffuse, const int32_t *triangles, const float *light_positions,
                       const float *light_intensities, const float *ambient, int B, int V, int T, int W,
-                      int H, int L, int32_t *ids, float *bary, float *z, float *rgba,
+                      int H, int L, int32_t *ids, float *bary, float *z, int want_z, float *rgba,
                       void *corner_records, void *workspace, size_t workspace_bytes, void *stream) {
   if (bad_dims(B, V, T, W, H) || T < 1 || V < 1 || L < 1 || L > mr::shade_max_lights())
     return MR_EINVAL;
@@ -222,8 +222,8 @@ int mr_render_forward(const float *clip, const float *normals, const float *posi
   const int rc = check_ws(workspace, workspace_bytes, mr::raster_forward_ws(B, V, T, W, H));
   if (rc != MR_OK) return rc;
   return mr::launch_render_forward(clip, normals, positions, diffuse, triangles, light_positions,
-                                   light_intensities, ambient, B, V, T, W, H, L, ids, bary, z, rgba,
-                                   corner_records, workspace, (hipStream_t)stream);
+                                   light_intensities, ambient, B, V, T, W, H, L, ids, bary, z, want_z,
+                                   rgba, corner_records, workspace, (hipStream_t)stream);
 }
 
 size_t mr_shade_forward_workspace_bytes(int B, int V, int T, int W, int H) {

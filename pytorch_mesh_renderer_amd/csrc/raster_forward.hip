@@ -366,6 +366,8 @@ struct RasterShade {
   const CornerRec *__restrict__ corners;  // [B*T] (k_corner_setup)
   Lights lights;
   float *__restrict__ rgba;               // [B,H,W,4], image rows (row 0 = top)
+  int keep_z;                             // 0: the caller does not want the depth plane -- it is then only
+                                          // written between the bin rounds of a crowded region (as state)
 };
 
 #ifndef MR_RASTER_SHADE_WAVES
@@ -745,7 +747,8 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : MR_RASTER
       }
       if (in_image && !((PROBE & 32) && st.z != 123.0f)) {  // 32: timing probe, no stores
         __builtin_amdgcn_raw_buffer_store_b32((unsigned)max(st.id, 0), rs_ids, lane_pix * 4u, tile_pix * 4, 0);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, st.z), rs_z, lane_pix * 4u, tile_pix * 4, 0);
+        if (!SHADE || !last_round || shade.keep_z)  // workgroup-uniform
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, st.z), rs_z, lane_pix * 4u, tile_pix * 4, 0);
         __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(v3u, v3f{st.b0, st.b1, st.b2}), rs_bary, lane_pix * 12u,
                                               tile_pix * 12, 0);
       }
@@ -1041,8 +1044,8 @@ int raster_forward(const float *clip, const int32_t *tris, int B, int V, int T, 
 
 int launch_raster_forward(const float *clip, const int32_t *tris, int B, int V, int T, int W,
                           int H, int32_t *ids, float *bary, float *z, void *ws, hipStream_t s) {
-  return raster_forward(clip, tris, B, V, T, W, H, ids, bary, z, RasterShade{nullptr, Lights{nullptr, nullptr, nullptr, 0}, nullptr},
-                        ws, s);
+  return raster_forward(clip, tris, B, V, T, W, H, ids, bary, z,
+                        RasterShade{nullptr, Lights{nullptr, nullptr, nullptr, 0}, nullptr, 1}, ws, s);
 }
 
 // render()'s forward in one pass over the pixels: G-buffer + shaded RGBA (see RasterShade).
@@ -1050,13 +1053,14 @@ int launch_raster_forward(const float *clip, const int32_t *tris, int B, int V, 
 int launch_render_forward(const float *clip, const float *normals, const float *positions, const float *diffuse,
                           const int32_t *tris, const float *light_pos, const float *light_col,
                           const float *ambient, int B, int V, int T, int W, int H, int L, int32_t *ids,
-                          float *bary, float *z, float *rgba, void *corner_records, void *ws, hipStream_t s) {
+                          float *bary, float *z, int want_z, float *rgba, void *corner_records, void *ws,
+                          hipStream_t s) {
   if ((size_t)B * W * H == 0) return MR_OK;
   CornerRec *corners = (CornerRec *)corner_records;
   const int rc = launch_corner_setup(normals, positions, diffuse, tris, B, V, T, corners, s);
   if (rc != MR_OK) return rc;
   return raster_forward(clip, tris, B, V, T, W, H, ids, bary, z,
-                        RasterShade{corners, Lights{light_pos, light_col, ambient, L}, rgba}, ws, s);
+                        RasterShade{corners, Lights{light_pos, light_col, ambient, L}, rgba, want_z}, ws, s);
 }
 
 }  // namespace mr

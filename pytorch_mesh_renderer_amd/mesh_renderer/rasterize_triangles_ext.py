@@ -128,7 +128,8 @@ class FusedPhongRenderer(torch.autograd.Function):
         amb = ambient.detach().contiguous() if ambient is not None else None
         if USE_SHADING_EPILOGUE:
             ids, bary, _, rgba, corner_records = _native.render_forward(
-                clip_d, args[0], args[1], args[2], triangles, lp, li, amb, int(image_width), int(image_height))
+                clip_d, args[0], args[1], args[2], triangles, lp, li, amb, int(image_width), int(image_height),
+                want_z=False)
         else:
             ids, bary, _ = _native.rasterize_forward(clip_d, triangles, int(image_width), int(image_height))
             rgba, corner_records = _native.shade_forward(ids, bary, args[0], args[1], args[2], triangles, lp,

@@ -456,6 +456,38 @@ def test_fused_specular_shininess_gradient_matches_composed_path(device, kind):
         np.testing.assert_allclose(grads_f[k], grads_c[k], atol=ATOL, rtol=0, err_msg=k)
 
 
+@pytest.mark.parametrize("w,h,res,n_lights,ambient", [(96, 80, 12, 1, False), (130, 67, 10, 3, True),
+                                                        (64, 64, 120, 2, True), (33, 31, 6, 4, False)])
+def test_render_forward_matches_raster_then_shade(device, w, h, res, n_lights, ambient):
+    """mr_render_forward (shading as the epilogue of the rasterizer's tile walk) vs mr_rasterize_forward +
+    mr_shade_forward: the G-buffer bit for bit, RGBA within the shading budget.  Ragged image sizes, 1-4
+    lights, ambient, and a 64x64 image with 28k triangles: its regions need several bin rounds, so the
+    pixel state makes the round trip through the G-buffer before it is shaded."""
+    from pytorch_mesh_renderer_amd import _native
+    job = synthetic.sphere_job(2, w, h, res)
+    d = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in job.items()}
+    gen = torch.Generator().manual_seed(3)
+    diffuse = torch.rand(d["vertices"].shape, generator=gen).to(device)
+    lp = (torch.rand(2, n_lights, 3, generator=gen) * 6 - 3).to(device)
+    li = (torch.rand(2, n_lights, 3, generator=gen) + 0.2).to(device)
+    amb = (torch.rand(2, 3, generator=gen) * 0.3).to(device) if ambient else None
+    ids, bary, z = _native.rasterize_forward(d["clip"], d["triangles"], w, h)
+    rgba = _native.shade_forward(ids, bary, d["normals"], d["vertices"], diffuse, d["triangles"], lp, li, amb)
+    assert float(rgba[..., 3].mean()) > 0.2
+    for want_z in (True, False):
+        ids2, bary2, z2, rgba2, records = _native.render_forward(
+            d["clip"], d["normals"], d["vertices"], diffuse, d["triangles"], lp, li, amb, w, h, want_z=want_z)
+        assert torch.equal(ids2, ids) and torch.equal(bary2, bary)
+        assert (z2 is None) if not want_z else torch.equal(z2, z)
+        np.testing.assert_allclose(rgba2.cpu().numpy(), rgba.cpu().numpy(), atol=1e-6, rtol=0)
+    # the records it leaves behind are the ones the shading backward would build itself
+    g = torch.randn(2, h, w, 4, generator=torch.Generator().manual_seed(1)).to(device) / (h * w)
+    args = (g, ids, bary, d["clip"], d["normals"], d["vertices"], diffuse, d["triangles"], lp, li, amb)
+    for a, b in zip(_native.shade_backward(*args), _native.shade_backward(*args, corner_records=records)):
+        if a is not None:
+            np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), atol=1e-7, rtol=1e-5)
+
+
 def test_shade_backward_gather_matches_scatter(device):
     """mr_shade_backward with the CSR vertex adjacency (per-vertex gather, what render() uses) vs
     without it (float-atomic scatter), incl. a triangle with a repeated and an out-of-range vertex."""
