@@ -286,14 +286,9 @@ int mr_shade_backward_l1(const uint8_t *signs, const float *upstream, const int3
   if (((uintptr_t)corner_records & 127u) != 0) return MR_EINVAL;
   if ((vertex_offsets == nullptr) != (vertex_entries == nullptr)) return MR_EINVAL;
   if (vertex_offsets && ((uintptr_t)dclip & 15u) != 0) return MR_EINVAL;
-  // the scale (d loss / d mean, 1 / n) lives behind the accumulators in the workspace
-  const size_t base = mr::shade_backward_ws(B, V, T, W, H);
-  const int rc = check_ws(workspace, workspace_bytes, base + 256);
+  const int rc = check_ws(workspace, workspace_bytes, mr::shade_backward_ws(B, V, T, W, H) + 256);
   if (rc != MR_OK) return rc;
-  float *scale = (float *)((char *)workspace + base);
-  const int rs = mr::launch_l1_scale(upstream, (size_t)B * H * W * 4, scale, (hipStream_t)stream);
-  if (rs != MR_OK) return rs;
-  return mr::launch_shade_backward(nullptr, signs, scale, ids, bary, clip, normals, positions, diffuse,
+  return mr::launch_shade_backward(nullptr, signs, upstream, ids, bary, clip, normals, positions, diffuse,
                                    triangles, light_positions, light_intensities, ambient, B, V, T, W, H, L,
                                    dclip, dnormals, dpositions, ddiffuse, light_grads, corner_records,
                                    vertex_offsets, vertex_entries, workspace, (hipStream_t)stream);

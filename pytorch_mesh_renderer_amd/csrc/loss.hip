@@ -138,12 +138,6 @@ __global__ __launch_bounds__(kThreads) void k_export_u8(const float4 *__restrict
   if (blockIdx.x == 0 && (int)threadIdx.x < n_tail) out_tail[threadIdx.x] = (uint8_t)to_u8(in_tail[threadIdx.x]);
 }
 
-// (d loss / d mean, 1 / n) as two device floats for the kernels that consume the sign codes directly
-__global__ void k_l1_scale(const float *__restrict__ upstream, float inv_n, float *__restrict__ scale) {
-  scale[0] = upstream[0];
-  scale[1] = inv_n;
-}
-
 // ---- tone_mapper (src/mesh_renderer/render.py:389-419): out = clamp(image^gamma / max, 0, 1) with
 // max taken per image over image^gamma.  Two streaming passes: (1) per-image maximum of the powers
 // -- they are non-negative or NaN, so their bit patterns order like signed integers with NaN on
@@ -212,11 +206,6 @@ int launch_l1_backward(const uint8_t *signs, size_t n, const float *upstream, fl
   const size_t n4 = n / 4;
   hipLaunchKernelGGL(k_l1_backward, dim3(blocks_for(n4)), dim3(kThreads), 0, s, signs, n4,
                      (int)(n - 4 * n4), upstream, 1.0f / (float)n, (float4 *)da, da + 4 * n4);
-  return check_launch();
-}
-
-int launch_l1_scale(const float *upstream, size_t n, float *scale, hipStream_t s) {
-  hipLaunchKernelGGL(k_l1_scale, dim3(1), dim3(1), 0, s, upstream, n ? 1.0f / (float)n : 0.0f, scale);
   return check_launch();
 }
 

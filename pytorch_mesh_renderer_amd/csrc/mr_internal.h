@@ -116,7 +116,7 @@ int launch_shade_forward(const int32_t *ids, const float *bary, const float *nor
                          hipStream_t s);
 size_t shade_forward_ws(int B, int V, int T, int W, int H);
 size_t shade_backward_ws(int B, int V, int T, int W, int H);
-int launch_shade_backward(const float *drgba, const uint8_t *signs, const float *sign_scale,
+int launch_shade_backward(const float *drgba, const uint8_t *signs, const float *sign_upstream,
                           const int32_t *ids, const float *bary,
                           const float *clip, const float *normals, const float *positions,
                           const float *diffuse, const int32_t *tris, const float *light_pos,
@@ -162,7 +162,6 @@ int launch_shade_specular_backward(const float *drgba, const int32_t *ids, const
 int launch_l1_forward(const float *a, const float *b, size_t n, float *out, uint8_t *signs, float *partials,
                       hipStream_t s);
 int launch_l1_backward(const uint8_t *signs, size_t n, const float *upstream, float *da, hipStream_t s);
-int launch_l1_scale(const float *upstream, size_t n, float *scale, hipStream_t s);
 int launch_export_u8(const float *in, size_t n, uint8_t *out, hipStream_t s);
 int launch_vertex_normals(const float *vertices, const int32_t *tris, const int32_t *offsets,
                           const int32_t *entries, int B, int V, float *sums, float *normals, hipStream_t s);

@@ -29,11 +29,17 @@
 
 namespace mr {
 
+// Optional chores for the caller's accumulation pass, so that it needs no memset launches of its
+// own (~5 us each): thread (image, triangle) clears the triangle's accumulator row (`zero_row_quads`
+// float4 per row), and the grid clears `zero_tail_count` floats at `zero_tail` between its threads.
 __global__ __launch_bounds__(256) void k_bwd_setup(
     const float4 *__restrict__ clip, const int32_t *__restrict__ tris, int B, int V, int T,
-    BwdRec *__restrict__ recs) {
+    BwdRec *__restrict__ recs, float4 *__restrict__ zero_rows, int zero_row_quads,
+    float *__restrict__ zero_tail, int zero_tail_count) {
   const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  for (long i = gid; i < zero_tail_count; i += (long)gridDim.x * 256) zero_tail[i] = 0.0f;
   if (gid >= (long)B * T) return;
+  for (int q = 0; q < zero_row_quads; ++q) zero_rows[gid * zero_row_quads + q] = make_float4(0.f, 0.f, 0.f, 0.f);
   const int b = (int)(gid / T);
   const int t = (int)(gid - (long)b * T);
   const int i0 = tris[3 * t], i1 = tris[3 * t + 1], i2 = tris[3 * t + 2];
@@ -60,11 +66,14 @@ __global__ __launch_bounds__(256) void k_bwd_setup(
 }
 
 int launch_bwd_setup(const float *clip, const int32_t *tris, int B, int V, int T, BwdRec *recs,
-                     hipStream_t s) {
+                     hipStream_t s, void *zero_rows, size_t zero_row_bytes, float *zero_tail,
+                     int zero_tail_count) {
   const long nbt = (long)B * T;
   if (nbt == 0) return MR_OK;
+  if (zero_row_bytes % 16 != 0) return MR_EINVAL;
   hipLaunchKernelGGL(k_bwd_setup, dim3((unsigned)((nbt + 255) / 256)), dim3(256), 0, s,
-                     (const float4 *)clip, tris, B, V, T, recs);
+                     (const float4 *)clip, tris, B, V, T, recs, (float4 *)zero_rows,
+                     zero_rows ? (int)(zero_row_bytes / 16) : 0, zero_tail, zero_tail ? zero_tail_count : 0);
   return check_launch();
 }
 

@@ -499,9 +499,9 @@ __device__ __forceinline__ void raster_pixel_partials(const F3 bary, const F3 g,
 }
 
 // One thread per (image, triangle): fills BwdRec from clip-space vertices.
-__global__ void k_bwd_setup(const float4 *__restrict__ clip, const int32_t *__restrict__ tris, int B,
-                            int V, int T, BwdRec *__restrict__ recs);
+// zero_rows / zero_tail: see k_bwd_setup (raster_backward.hip); zero_row_bytes is a multiple of 16.
 int launch_bwd_setup(const float *clip, const int32_t *tris, int B, int V, int T, BwdRec *recs,
-                     hipStream_t s);
+                     hipStream_t s, void *zero_rows = nullptr, size_t zero_row_bytes = 0,
+                     float *zero_tail = nullptr, int zero_tail_count = 0);
 
 }  // namespace mr

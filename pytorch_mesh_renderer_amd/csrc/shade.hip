@@ -131,7 +131,8 @@ struct ShadeGradFn {
   static constexpr bool kCountBackground = false;
   const float4 *__restrict__ drgba;   // [B,H,W,4], image rows (flipped w.r.t. the G-buffer); !SIGNS
   const uint8_t *__restrict__ signs;  // [B,H,W] bytes: sign codes of the 4 channels; SIGNS
-  const float *__restrict__ sign_scale;  // SIGNS: [2] = (d loss / d mean, 1 / element count)
+  const float *__restrict__ sign_upstream;  // SIGNS: d loss / d mean, one device float ...
+  float sign_inv_n;                         // ... and 1 / element count of the mean
   const int32_t *__restrict__ ids;
   const F3 *__restrict__ bary;
   const CornerRec *__restrict__ corners;
@@ -164,7 +165,7 @@ struct ShadeGradFn {
   };
 
   __device__ __forceinline__ void begin_image(int img, Image &im) const {
-    im.g_scale = SIGNS ? sign_scale[0] * sign_scale[1] : 0.f;
+    im.g_scale = SIGNS ? sign_upstream[0] * sign_inv_n : 0.f;
 #pragma unroll
     for (int l = 0; l < L; ++l) {
 #pragma unroll
@@ -437,9 +438,9 @@ __global__ __launch_bounds__(kThreads) void k_abs_max(const float4 *__restrict__
 }
 
 // (2^k, 2^-k) with k such that the largest upstream gradient maps to about 2^41
-__global__ void k_det_scale(const int *__restrict__ max_bits, const float *__restrict__ sign_scale,
-                            float *__restrict__ det_scale) {
-  const float g = sign_scale ? fabsf(sign_scale[0] * sign_scale[1]) : __int_as_float(max_bits[0]);
+__global__ void k_det_scale(const int *__restrict__ max_bits, const float *__restrict__ sign_upstream,
+                            float sign_inv_n, float *__restrict__ det_scale) {
+  const float g = sign_upstream ? fabsf(sign_upstream[0] * sign_inv_n) : __int_as_float(max_bits[0]);
   int e = 0;
   if (g > 0.0f && g < INFINITY) (void)frexpf(g, &e);  // g = m * 2^e, m in [0.5, 1)
   const int k = min(max(41 - e, -100), 100);
@@ -502,7 +503,7 @@ size_t shade_backward_ws(int B, int V, int T, int W, int H) {
 
 thread_local int g_deterministic = 0;  // mr_set_deterministic
 
-int launch_shade_backward(const float *drgba, const uint8_t *signs, const float *sign_scale,
+int launch_shade_backward(const float *drgba, const uint8_t *signs, const float *sign_upstream,
                           const int32_t *ids, const float *bary,
                           const float *clip, const float *normals, const float *positions,
                           const float *diffuse, const int32_t *tris, const float *light_pos,
@@ -514,11 +515,19 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
   if (B == 0) return MR_OK;
   const size_t v3 = (size_t)B * V * 3 * sizeof(float), v4 = (size_t)B * V * 4 * sizeof(float);
   const size_t lg = (size_t)B * (L * 6 + 3) * sizeof(float);
-  // The outputs are zeroed here.  A caller that lays them out back to back (dclip, dnormals,
-  // dpositions, ddiffuse, light_grads -- _native.py does) gets ONE memset instead of five
-  // launch-bound ones (~5 us each, 2 % of a 1024^2 x 32 step).
-  if ((char *)dnormals == (char *)dclip + v4 && (char *)dpositions == (char *)dnormals + v3 &&
-      (char *)ddiffuse == (char *)dpositions + v3 && (char *)light_grads == (char *)ddiffuse + v3) {
+  const bool det = g_deterministic != 0;
+  const float sign_inv_n = 1.0f / (float)((size_t)B * H * W * 4);  // the L1 mean runs over the whole image
+  // With the vertex adjacency the gather writes every vertex output exactly once, and k_bwd_setup
+  // clears the accumulator rows and light_grads on the side: no memset launches at all (two of
+  // ~6 us each before).  (Not in the deterministic mode: its fixed-point side buffers are cleared
+  // the plain way.)
+  const bool fused_clear = vertex_offsets && vertex_entries && !det && T > 0 && V > 0;
+  // Otherwise the outputs are zeroed here.  A caller that lays them out back to back (dclip,
+  // dnormals, dpositions, ddiffuse, light_grads -- _native.py does) gets ONE memset instead of five
+  // launch-bound ones.
+  if (fused_clear) {
+  } else if ((char *)dnormals == (char *)dclip + v4 && (char *)dpositions == (char *)dnormals + v3 &&
+             (char *)ddiffuse == (char *)dpositions + v3 && (char *)light_grads == (char *)ddiffuse + v3) {
     if (hipMemsetAsync(dclip, 0, v4 + 3 * v3 + lg, s) != hipSuccess) return check_launch();
   } else {
     if (V > 0) {
@@ -536,10 +545,9 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
   long long *light_fixed = (long long *)((char *)corners + corner_bytes(B, T));
   float *det_scale = (float *)((char *)light_fixed + light_fixed_bytes(B));
   int *max_bits = (int *)(det_scale + 4);
-  const bool det = g_deterministic != 0;
   if (det && !(vertex_offsets && vertex_entries)) return MR_EINVAL;  // the scatter path is atomics only
   const size_t acc_bytes = (size_t)B * T * 36 * (det ? sizeof(long long) : sizeof(float));
-  if (hipMemsetAsync(acc, 0, acc_bytes, s) != hipSuccess) return check_launch();
+  if (!fused_clear && hipMemsetAsync(acc, 0, acc_bytes, s) != hipSuccess) return check_launch();
   int rc = MR_OK;
   if (det) {
     if (hipMemsetAsync(light_fixed, 0, light_fixed_bytes(B) + kDetMiscBytes, s) != hipSuccess) return check_launch();
@@ -548,10 +556,12 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
       hipLaunchKernelGGL(k_abs_max, dim3(capped_blocks(n4)), dim3(kThreads), 0, s, (const float4 *)drgba, n4, max_bits);
       if ((rc = check_launch()) != MR_OK) return rc;
     }
-    hipLaunchKernelGGL(k_det_scale, dim3(1), dim3(1), 0, s, max_bits, sign_scale, det_scale);
+    hipLaunchKernelGGL(k_det_scale, dim3(1), dim3(1), 0, s, max_bits, sign_upstream, sign_inv_n, det_scale);
     if ((rc = check_launch()) != MR_OK) return rc;
   }
-  rc = launch_bwd_setup(clip, tris, B, V, T, recs, s);
+  rc = fused_clear ? launch_bwd_setup(clip, tris, B, V, T, recs, s, acc, 36 * sizeof(float), light_grads,
+                                      B * (L * 6 + 3))
+                   : launch_bwd_setup(clip, tris, B, V, T, recs, s);
   if (rc != MR_OK) return rc;
   if (corner_records) {  // the forward's records (same inputs): skip the gather
     corners = (CornerRec *)corner_records;
@@ -564,11 +574,11 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
   {                                                                                             \
     KernelTimer timer(MR_TIMER_SHADE_BACKWARD, s);                                              \
     if (signs) {                                                                                \
-      ShadeGradFn<NL, true> fn{nullptr, signs, sign_scale, ids, (const F3 *)bary, corners, recs, \
+      ShadeGradFn<NL, true> fn{nullptr, signs, sign_upstream, sign_inv_n, ids, (const F3 *)bary, corners, recs, \
                                lights, light_grads, T, W, H, det ? light_fixed : nullptr, det_scale}; \
       rc = launch_accumulate_rows(fn, B, T, W, H, acc, s, det ? det_scale : nullptr);           \
     } else {                                                                                    \
-      ShadeGradFn<NL, false> fn{(const float4 *)drgba, nullptr, nullptr, ids, (const F3 *)bary, \
+      ShadeGradFn<NL, false> fn{(const float4 *)drgba, nullptr, nullptr, 0.0f, ids, (const F3 *)bary, \
                                 corners, recs, lights, light_grads, T, W, H,                    \
                                 det ? light_fixed : nullptr, det_scale};                        \
       rc = launch_accumulate_rows(fn, B, T, W, H, acc, s, det ? det_scale : nullptr);           \
