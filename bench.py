@@ -294,7 +294,7 @@ def main():
     # inside the same step with the epilogue switched off (k_raster, then k_shade_forward).
     n_gb = 20
     ev_gbuffer = KernelEvents(n_gb, _native.TIMER_RASTER_FORWARD)
-    ext = sys.modules["pytorch_mesh_renderer_amd.mesh_renderer.rasterize_triangles_ext"]
+    from pytorch_mesh_renderer_amd.mesh_renderer import rasterize_triangles_ext as ext
     epilogue_was = ext.USE_SHADING_EPILOGUE
     ext.USE_SHADING_EPILOGUE = False
     try:

@@ -148,12 +148,27 @@ int mr_shade_forward(const int32_t *ids, const float *bary, const float *normals
                      int B, int V, int T, int W, int H, int L, float *rgba,
                      void *workspace, size_t workspace_bytes, void *stream);
 
-/* mr_rasterize_forward and mr_shade_forward in ONE pass over the pixels: the shading runs as the
- * epilogue of the rasterizer's tile walk, on the pixel state still held in registers, so the
- * G-buffer is not read back (and the id -> corner-record gather has one dependent level less).
- * What FusedPhongRenderer (render() without a specular term) calls.  Outputs: the G-buffer of
- * mr_rasterize_forward (ids, bary, z) and the image of mr_shade_forward (rgba), bit-identical
- * G-buffer, RGBA within the shading's 1e-4 budget.
+/* clip[b,v] = transforms[b] . (vertices[b,v], 1): the clip-space transform render() applies before
+ * rasterizing (camera_utils.transform_homogeneous, src/common/camera_utils.py:142-170), one thread
+ * per vertex; each row is evaluated as ((m0 x + m1 y) + m2 z) + m3 without contraction.
+ *   vertices [B,V,3] f32, transforms [B,4,4] f32 row-major (16-byte aligned), clip [B,V,4] f32 out
+ *   (16-byte aligned). */
+int mr_vertex_transform(const float *vertices, const float *transforms, int B, int V, float *clip,
+                        void *stream);
+
+/* render()'s forward from world-space vertices to the image (src/mesh_renderer/render.py:183-228
+ * without a specular term): the clip-space transform of camera_utils.transform_homogeneous
+ * (src/common/camera_utils.py:142-170), mr_rasterize_forward and mr_shade_forward, the last two in
+ * ONE pass over the pixels: the shading runs as the epilogue of the rasterizer's tile walk, on the
+ * pixel state still held in registers, so the G-buffer is not read back (and the id ->
+ * corner-record gather has one dependent level less).  What FusedPhongRenderer calls.  Outputs:
+ * the G-buffer of mr_rasterize_forward run on `clip` (ids, bary, z; bit-identical) and the image
+ * of mr_shade_forward (rgba, within the shading's 1e-4 budget).
+ *   vertices        [B,V,3] f32  world-space positions (also the shading's `positions`)
+ *   transforms      [B,4,4] f32  row-major clip-space transforms, 16-byte aligned
+ *   clip            [B,V,4] f32 out  transforms[b] . (vertices[b,v], 1), evaluated per row as
+ *                   ((m0 x + m1 y) + m2 z) + m3 without contraction; 16-byte aligned.  The
+ *                   backward entry points take it as their `clip` argument.
  *   z, want_z       z is always a [B,H,W] buffer; with want_z == 0 the caller declares that it will
  *                   not read it (render() does not): the depth plane is then written only where a
  *                   crowded region needs it as state between its bin rounds, 4 B/px of stores less,
@@ -161,11 +176,11 @@ int mr_shade_forward(const int32_t *ids, const float *bary, const float *normals
  *   corner_records  out, mr_shade_forward_workspace_bytes() bytes, 128-byte aligned: the gathered
  *                   per-triangle attribute records; may be handed to mr_shade_backward.
  *   workspace       mr_rasterize_forward_workspace_bytes() bytes */
-int mr_render_forward(const float *clip, const float *normals, const float *positions,
+int mr_render_forward(const float *vertices, const float *transforms, const float *normals,
                       const float *diffuse, const int32_t *triangles,
                       const float *light_positions, const float *light_intensities,
                       const float *ambient, int B, int V, int T, int W, int H, int L,
-                      int32_t *ids, float *bary, float *z, int want_z, float *rgba,
+                      float *clip, int32_t *ids, float *bary, float *z, int want_z, float *rgba,
                       void *corner_records, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Backward of mr_shade_forward AND of the rasterizer underneath it, in one pass
@@ -184,8 +199,15 @@ int mr_render_forward(const float *clip, const float *normals, const float *posi
  *                   triangle + corner, grouped by vertex (corners whose index is outside [0, V)
  *                   left out).  With it the per-triangle sums are GATHERED per vertex (no atomics,
  *                   fixed summation order); without it they are scattered with float atomics.
+ *   transforms      NULL, or the [B,4,4] row-major clip-space transforms that `clip` was made with
+ *                   (clip = transforms . (positions, 1), as mr_render_forward does): dpositions then
+ *                   also receives the clip-space gradient pulled back through that product, i.e.
+ *                   it becomes the whole gradient w.r.t. the world-space vertices; dclip is still
+ *                   written (a caller that differentiates the transforms needs it).  Requires the
+ *                   vertex adjacency.
  * dclip, dnormals, dpositions, ddiffuse, light_grads laid out back to back in that order are
- * zeroed with a single memset. */
+ * zeroed with a single memset (none at all with the vertex adjacency: every output is written
+ * exactly once). */
 size_t mr_shade_backward_workspace_bytes(int B, int V, int T, int W, int H);
 int mr_shade_backward(const float *drgba, const int32_t *ids, const float *bary,
                       const float *clip, const float *normals, const float *positions,
@@ -195,7 +217,7 @@ int mr_shade_backward(const float *drgba, const int32_t *ids, const float *bary,
                       float *dclip, float *dnormals, float *dpositions,
                       float *ddiffuse, float *light_grads, const void *corner_records,
                       const int32_t *vertex_offsets, const int32_t *vertex_entries,
-                      void *workspace, size_t workspace_bytes, void *stream);
+                      const float *transforms, void *workspace, size_t workspace_bytes, void *stream);
 
 /* mr_shade_backward for an upstream gradient that is the backward of mr_l1_loss_forward(rgba,
  * target): instead of the [B,H,W,4] float image mr_l1_loss_backward would write (16 B/px) it takes
@@ -212,7 +234,8 @@ int mr_shade_backward_l1(const uint8_t *signs, const float *upstream, const int3
                          float *dclip, float *dnormals, float *dpositions, float *ddiffuse,
                          float *light_grads, const void *corner_records,
                          const int32_t *vertex_offsets, const int32_t *vertex_entries,
-                         void *workspace, size_t workspace_bytes, void *stream);
+                         const float *transforms, void *workspace, size_t workspace_bytes,
+                         void *stream);
 
 /* ---- fused deferred shading with the specular term --------------------------------
  * The same replacement as mr_shade_forward / mr_shade_backward for render() calls that pass

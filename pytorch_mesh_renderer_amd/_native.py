@@ -16,7 +16,7 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 # build libmesh_raster_hip_probes.so this way); the product always loads the in-tree library.
 LIB_PATH = os.environ.get("MR_NATIVE_LIB_PATH") or os.path.join(_CSRC, "libmesh_raster_hip.so")
 
-ABI_VERSION = 320
+ABI_VERSION = 330
 TIMER_RASTER_FORWARD, TIMER_SHADE_BACKWARD, TIMER_SHADE_FORWARD, TIMER_RASTER_BACKWARD = 0, 1, 2, 3
 MR_OK, MR_EINVAL, MR_EWORKSPACE, MR_ELAUNCH = 0, -1, -2, -3
 _ERR = {MR_EINVAL: "invalid argument", MR_EWORKSPACE: "workspace too small or misaligned",
@@ -121,11 +121,11 @@ def lib():
         L.mr_shade_forward.restype = ci
         L.mr_shade_backward_workspace_bytes.argtypes = [ci] * 5
         L.mr_shade_backward_workspace_bytes.restype = sz
-        L.mr_shade_backward.argtypes = [vp] * 11 + [ci] * 6 + [vp] * 9 + [sz, vp]
+        L.mr_shade_backward.argtypes = [vp] * 11 + [ci] * 6 + [vp] * 10 + [sz, vp]
         L.mr_shade_backward.restype = ci
         L.mr_shade_backward_l1_workspace_bytes.argtypes = [ci] * 5
         L.mr_shade_backward_l1_workspace_bytes.restype = sz
-        L.mr_shade_backward_l1.argtypes = [vp] * 12 + [ci] * 6 + [vp] * 9 + [sz, vp]
+        L.mr_shade_backward_l1.argtypes = [vp] * 12 + [ci] * 6 + [vp] * 10 + [sz, vp]
         L.mr_shade_backward_l1.restype = ci
         L.mr_soft_max_lights.restype = ci
         L.mr_soft_workspace_bytes.argtypes = [ci] * 5
@@ -148,7 +148,9 @@ def lib():
         L.mr_interpolate_forward_records.restype = ci
         L.mr_interpolate_raster_backward.argtypes = [vp] * 10 + [ci] * 6 + [vp, vp, vp, sz, vp]
         L.mr_interpolate_raster_backward.restype = ci
-        L.mr_render_forward.argtypes = [vp] * 8 + [ci] * 6 + [vp, vp, vp, ci] + [vp] * 3 + [sz, vp]
+        L.mr_vertex_transform.argtypes = [vp, vp, ci, ci, vp, vp]
+        L.mr_vertex_transform.restype = ci
+        L.mr_render_forward.argtypes = [vp] * 8 + [ci] * 6 + [vp, vp, vp, vp, ci] + [vp] * 3 + [sz, vp]
         L.mr_render_forward.restype = ci
         L.mr_shade_specular_forward_workspace_bytes.argtypes = [ci] * 5
         L.mr_shade_specular_forward_workspace_bytes.restype = sz
@@ -414,22 +416,41 @@ def shade_forward(ids, bary, normals, positions, diffuse, triangles, light_posit
     return (rgba, ws) if keep_corner_records else rgba
 
 
-def render_forward(clip, normals, positions, diffuse, triangles, light_positions, light_intensities,
+def vertex_transform(vertices, transforms):
+    """clip [B,V,4] = transforms [B,4,4] . (vertices [B,V,3], 1), as render_forward forms it."""
+    _chk("vertices", vertices, _F32, None, None, 3)
+    B, V = vertices.shape[0], vertices.shape[1]
+    _chk("clip-space transforms", transforms, _F32, B, 4, 4)
+    dev = _require_device(vertices, transforms)
+    vertices, transforms = vertices.contiguous(), transforms.contiguous()
+    clip = torch.empty(B, V, 4, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib().mr_vertex_transform(_ptr(vertices), _ptr(transforms), B, V, _ptr(clip), _stream(dev))
+    _check(rc, "mr_vertex_transform")
+    return clip
+
+
+def render_forward(vertices, transforms, normals, diffuse, triangles, light_positions, light_intensities,
                    ambient, width, height, want_z=True):
-    """rasterize_forward + shade_forward in one pass over the pixels (the shading is the epilogue
-    of the rasterizer's tile walk) -> (ids, bary, z, rgba, corner_records); with want_z=False the
-    depth plane is not written (z is returned as None)."""
-    tensors = [clip, normals, positions, diffuse, triangles, light_positions, light_intensities]
-    B, V, T = _chk_mesh(clip, triangles)
-    for name, t in (("normals", normals), ("positions", positions), ("diffuse colors", diffuse)):
+    """render()'s forward from world-space vertices: clip-space transform, rasterizer and shading
+    (the shading is the epilogue of the rasterizer's tile walk: one pass over the pixels)
+    -> (clip, ids, bary, z, rgba, corner_records); with want_z=False the depth plane is not written
+    (z is returned as None)."""
+    tensors = [vertices, transforms, normals, diffuse, triangles, light_positions, light_intensities]
+    _chk("vertices", vertices, _F32, None, None, 3)
+    _chk("triangles", triangles, _I32, None, 3)
+    B, V, T = vertices.shape[0], vertices.shape[1], triangles.shape[0]
+    _chk("clip-space transforms", transforms, _F32, B, 4, 4)
+    for name, t in (("normals", normals), ("diffuse colors", diffuse)):
         _chk(name, t, _F32, B, V, 3)
     _chk_lights(light_positions, light_intensities, ambient, B, shade_max_lights())
     dev = _require_device(*(tensors + ([ambient] if ambient is not None else [])))
     L = lib()
-    clip, normals, positions, diffuse, triangles, light_positions, light_intensities = [
+    vertices, transforms, normals, diffuse, triangles, light_positions, light_intensities = [
         t.contiguous() for t in tensors]
     ambient = ambient.contiguous() if ambient is not None else None
     nl = light_positions.shape[1]
+    clip = torch.empty(B, V, 4, dtype=torch.float32, device=dev)
     ids = torch.empty(B, height, width, dtype=torch.int32, device=dev)
     bary = torch.empty(B, height, width, 3, dtype=torch.float32, device=dev)
     z = torch.empty(B, height, width, dtype=torch.float32, device=dev)
@@ -439,12 +460,12 @@ def render_forward(clip, normals, positions, diffuse, triangles, light_positions
         need = L.mr_rasterize_forward_workspace_bytes(B, V, T, width, height)
         ws, have = _workspace(dev, need)
         _arm_timer(TIMER_RASTER_FORWARD)
-        rc = L.mr_render_forward(_ptr(clip), _ptr(normals), _ptr(positions), _ptr(diffuse), _ptr(triangles),
+        rc = L.mr_render_forward(_ptr(vertices), _ptr(transforms), _ptr(normals), _ptr(diffuse), _ptr(triangles),
                                  _ptr(light_positions), _ptr(light_intensities), _ptr(ambient), B, V, T,
-                                 width, height, nl, _ptr(ids), _ptr(bary), _ptr(z), int(bool(want_z)), _ptr(rgba),
-                                 _ptr(records), _ptr(ws), have, _stream(dev))
+                                 width, height, nl, _ptr(clip), _ptr(ids), _ptr(bary), _ptr(z), int(bool(want_z)),
+                                 _ptr(rgba), _ptr(records), _ptr(ws), have, _stream(dev))
     _check(rc, "mr_render_forward")
-    return ids, bary, (z if want_z else None), rgba, records
+    return clip, ids, bary, (z if want_z else None), rgba, records
 
 
 def interpolate_raster_max_attributes():
@@ -532,9 +553,13 @@ def vertex_adjacency(triangles, vertex_count):
 
 
 def shade_backward(drgba, ids, bary, clip, normals, positions, diffuse, triangles, light_positions,
-                   light_intensities, ambient, corner_records=None, adjacency=None, l1_signs=None):
+                   light_intensities, ambient, corner_records=None, adjacency=None, l1_signs=None,
+                   transforms=None):
     """-> (dclip [B,V,4], dnormals, dpositions, ddiffuse [B,V,3], dlight_positions,
     dlight_intensities [B,L,3], dambient [B,3] or None).
+
+    transforms ([B,4,4], needs `adjacency`): clip = transforms . (positions, 1); dpositions then also
+    holds the clip-space gradient pulled back through that product (the whole d / d world vertices).
 
     l1_signs: the packed sign codes of l1_loss_forward(rgba, target); `drgba` is then the 1-element
     upstream gradient of that loss and the [B,H,W,4] gradient image is never materialised."""
@@ -552,10 +577,16 @@ def shade_backward(drgba, ids, bary, clip, normals, positions, diffuse, triangle
     if adjacency is not None:
         _chk("adjacency offsets", adjacency[0], _I32, V + 1)
         _chk("adjacency entries", adjacency[1], _I32, None)
+    if transforms is not None:
+        if adjacency is None:
+            raise ValueError("transforms are applied by the per-vertex gather: pass the adjacency too")
+        _chk("clip-space transforms", transforms, _F32, B, 4, 4)
+        tensors = tensors + [transforms]
+        transforms = transforms.contiguous()
     dev = _require_device(*(tensors + ([ambient] if ambient is not None else [])))
     L = lib()
     (drgba, ids, bary, clip, normals, positions, diffuse, triangles, light_positions,
-     light_intensities) = [t.contiguous() for t in tensors]
+     light_intensities) = [t.contiguous() for t in tensors[:10]]
     ambient = ambient.contiguous() if ambient is not None else None
     B, H, W = ids.shape
     V, T, nl = normals.shape[1], triangles.shape[0], light_positions.shape[1]
@@ -569,7 +600,7 @@ def shade_backward(drgba, ids, bary, clip, normals, positions, diffuse, triangle
     lg = flat[n4 + 3 * n3:].view(B, 6 * nl + 3)
     tail = (B, V, T, W, H, nl, _ptr(dclip), _ptr(dn), _ptr(dp), _ptr(dd), _ptr(lg), _ptr(corner_records),
             _ptr(adjacency[0]) if adjacency is not None else None,
-            _ptr(adjacency[1]) if adjacency is not None else None)
+            _ptr(adjacency[1]) if adjacency is not None else None, _ptr(transforms))
     with torch.cuda.device(dev):
         _arm_timer(TIMER_SHADE_BACKWARD)
         _sync_deterministic()

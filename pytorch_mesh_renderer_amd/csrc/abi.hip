@@ -30,7 +30,7 @@ extern thread_local int g_deterministic;
 
 extern "C" {
 
-int mr_version(void) { return 320; /* 0.3.1: deterministic mode, tone map, vertex normals, sign-coded shading backward */ }
+int mr_version(void) { return 330; /* 0.3.1: deterministic mode, tone map, vertex normals, sign-coded shading backward */ }
 
 int mr_last_hip_error(void) { return mr::g_last_hip_error; }
 
@@ -207,23 +207,33 @@ int mr_shade_forward(const int32_t *ids, const float *bary, const float *normals
                                   (hipStream_t)stream);
 }
 
-int mr_render_forward(const float *clip, const float *normals, const float *positions,
+int mr_vertex_transform(const float *vertices, const float *transforms, int B, int V, float *clip,
+                        void *stream) {
+  if (B < 0 || V < 0) return MR_EINVAL;
+  if ((size_t)B * V == 0) return MR_OK;
+  if (!vertices || !transforms || !clip || ((uintptr_t)clip & 15u) || ((uintptr_t)transforms & 15u))
+    return MR_EINVAL;
+  return mr::launch_vertex_transform(vertices, transforms, B, V, clip, (hipStream_t)stream);
+}
+
+int mr_render_forward(const float *vertices, const float *transforms, const float *normals,
                       const float *diffuse, const int32_t *triangles, const float *light_positions,
                       const float *light_intensities, const float *ambient, int B, int V, int T, int W,
-                      int H, int L, int32_t *ids, float *bary, float *z, int want_z, float *rgba,
-                      void *corner_records, void *workspace, size_t workspace_bytes, void *stream) {
+                      int H, int L, float *clip, int32_t *ids, float *bary, float *z, int want_z,
+                      float *rgba, void *corner_records, void *workspace, size_t workspace_bytes,
+                      void *stream) {
   if (bad_dims(B, V, T, W, H) || T < 1 || V < 1 || L < 1 || L > mr::shade_max_lights())
     return MR_EINVAL;
   if (B == 0) return MR_OK;
-  if (!clip || !normals || !positions || !diffuse || !triangles || !light_positions ||
-      !light_intensities || !ids || !bary || !z || !rgba || !corner_records ||
-      ((uintptr_t)corner_records & 127u))
+  if (!vertices || !transforms || !normals || !diffuse || !triangles || !light_positions ||
+      !light_intensities || !clip || !ids || !bary || !z || !rgba || !corner_records ||
+      ((uintptr_t)corner_records & 127u) || ((uintptr_t)clip & 15u) || ((uintptr_t)transforms & 15u))
     return MR_EINVAL;
   const int rc = check_ws(workspace, workspace_bytes, mr::raster_forward_ws(B, V, T, W, H));
   if (rc != MR_OK) return rc;
-  return mr::launch_render_forward(clip, normals, positions, diffuse, triangles, light_positions,
-                                   light_intensities, ambient, B, V, T, W, H, L, ids, bary, z, want_z,
-                                   rgba, corner_records, workspace, (hipStream_t)stream);
+  return mr::launch_render_forward(vertices, transforms, normals, diffuse, triangles, light_positions,
+                                   light_intensities, ambient, B, V, T, W, H, L, clip, ids, bary, z,
+                                   want_z, rgba, corner_records, workspace, (hipStream_t)stream);
 }
 
 size_t mr_shade_forward_workspace_bytes(int B, int V, int T, int W, int H) {
@@ -243,7 +253,7 @@ int mr_shade_backward(const float *drgba, const int32_t *ids, const float *bary,
                       int W, int H, int L, float *dclip, float *dnormals, float *dpositions,
                       float *ddiffuse, float *light_grads, const void *corner_records,
                       const int32_t *vertex_offsets, const int32_t *vertex_entries,
-                      void *workspace, size_t workspace_bytes, void *stream) {
+                      const float *transforms, void *workspace, size_t workspace_bytes, void *stream) {
   if (bad_dims(B, V, T, W, H) || T < 1 || V < 1 || L < 1 || L > mr::shade_max_lights())
     return MR_EINVAL;
   if (B == 0) return MR_OK;
@@ -254,12 +264,13 @@ int mr_shade_backward(const float *drgba, const int32_t *ids, const float *bary,
   if (((uintptr_t)corner_records & 127u) != 0) return MR_EINVAL;
   if ((vertex_offsets == nullptr) != (vertex_entries == nullptr)) return MR_EINVAL;
   if (vertex_offsets && ((uintptr_t)dclip & 15u) != 0) return MR_EINVAL;
+  if (transforms && (!vertex_offsets || ((uintptr_t)transforms & 3u) != 0)) return MR_EINVAL;
   const int rc = check_ws(workspace, workspace_bytes, mr::shade_backward_ws(B, V, T, W, H));
   if (rc != MR_OK) return rc;
   return mr::launch_shade_backward(drgba, nullptr, nullptr, ids, bary, clip, normals, positions, diffuse,
                                    triangles, light_positions, light_intensities, ambient, B, V, T, W, H, L,
                                    dclip, dnormals, dpositions, ddiffuse, light_grads, corner_records,
-                                   vertex_offsets, vertex_entries, workspace, (hipStream_t)stream);
+                                   vertex_offsets, vertex_entries, transforms, workspace, (hipStream_t)stream);
 }
 
 size_t mr_shade_backward_l1_workspace_bytes(int B, int V, int T, int W, int H) {
@@ -274,8 +285,8 @@ int mr_shade_backward_l1(const uint8_t *signs, const float *upstream, const int3
                          const float *ambient, int B, int V, int T, int W, int H, int L, float *dclip,
                          float *dnormals, float *dpositions, float *ddiffuse, float *light_grads,
                          const void *corner_records, const int32_t *vertex_offsets,
-                         const int32_t *vertex_entries, void *workspace, size_t workspace_bytes,
-                         void *stream) {
+                         const int32_t *vertex_entries, const float *transforms, void *workspace,
+                         size_t workspace_bytes, void *stream) {
   if (bad_dims(B, V, T, W, H) || T < 1 || V < 1 || L < 1 || L > mr::shade_max_lights())
     return MR_EINVAL;
   if (B == 0) return MR_OK;
@@ -286,12 +297,13 @@ int mr_shade_backward_l1(const uint8_t *signs, const float *upstream, const int3
   if (((uintptr_t)corner_records & 127u) != 0) return MR_EINVAL;
   if ((vertex_offsets == nullptr) != (vertex_entries == nullptr)) return MR_EINVAL;
   if (vertex_offsets && ((uintptr_t)dclip & 15u) != 0) return MR_EINVAL;
+  if (transforms && (!vertex_offsets || ((uintptr_t)transforms & 3u) != 0)) return MR_EINVAL;
   const int rc = check_ws(workspace, workspace_bytes, mr::shade_backward_ws(B, V, T, W, H) + 256);
   if (rc != MR_OK) return rc;
   return mr::launch_shade_backward(nullptr, signs, upstream, ids, bary, clip, normals, positions, diffuse,
                                    triangles, light_positions, light_intensities, ambient, B, V, T, W, H, L,
                                    dclip, dnormals, dpositions, ddiffuse, light_grads, corner_records,
-                                   vertex_offsets, vertex_entries, workspace, (hipStream_t)stream);
+                                   vertex_offsets, vertex_entries, transforms, workspace, (hipStream_t)stream);
 }
 
 size_t mr_shade_specular_forward_workspace_bytes(int B, int V, int T, int W, int H) {

@@ -123,7 +123,8 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
                           const float *light_col, const float *ambient, int B, int V, int T, int W,
                           int H, int L, float *dclip, float *dnormals, float *dpositions,
                           float *ddiffuse, float *light_grads, const void *corner_records,
-                          const int32_t *vertex_offsets, const int32_t *vertex_entries, void *ws, hipStream_t s);
+                          const int32_t *vertex_offsets, const int32_t *vertex_entries,
+                          const float *transforms, void *ws, hipStream_t s);
 
 int interp_raster_max_attrs();
 size_t interp_raster_backward_ws(int B, int V, int T, int W, int H, int A);
@@ -136,11 +137,13 @@ int launch_interp_raster_backward(const float *dout, const int32_t *ids, const f
                                   const int32_t *offsets, const int32_t *entries, const void *corner_records,
                                   int B, int V, int T, int W, int H, int A, float *dattrs, float *dclip,
                                   void *ws, hipStream_t s);
-int launch_render_forward(const float *clip, const float *normals, const float *positions, const float *diffuse,
-                          const int32_t *tris, const float *light_pos, const float *light_col,
-                          const float *ambient, int B, int V, int T, int W, int H, int L, int32_t *ids,
-                          float *bary, float *z, int want_z, float *rgba, void *corner_records, void *ws,
-                          hipStream_t s);
+int launch_vertex_transform(const float *vertices, const float *transforms, int B, int V, float *clip,
+                            hipStream_t s);
+int launch_render_forward(const float *vertices, const float *transforms, const float *normals,
+                          const float *diffuse, const int32_t *tris, const float *light_pos,
+                          const float *light_col, const float *ambient, int B, int V, int T, int W, int H,
+                          int L, float *clip, int32_t *ids, float *bary, float *z, int want_z, float *rgba,
+                          void *corner_records, void *ws, hipStream_t s);
 size_t shade_specular_forward_ws(int B, int V, int T, int W, int H);
 int launch_shade_specular_forward(const int32_t *ids, const float *bary, const float *normals,
                                   const float *positions, const float *diffuse, const float *specular,

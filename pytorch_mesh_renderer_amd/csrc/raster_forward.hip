@@ -88,10 +88,36 @@ __device__ __forceinline__ float depth_lower_bound(float z0, float z1, float z2,
   return f;
 }
 
+// clip = transform (row-major 4x4 per image) applied to (vertex, 1): what render() feeds the
+// rasterizer (camera_utils.transform_homogeneous, src/common/camera_utils.py:142-170), one thread per
+// (image, vertex) instead of a concatenation, a batched GEMM and their autograd nodes.
+__global__ __launch_bounds__(kThreads) void k_vertex_transform(
+    const F3 *__restrict__ vertices, const float4 *__restrict__ transforms, int B, int V,
+    float4 *__restrict__ clip) {
+  const long gid = (long)blockIdx.x * kThreads + threadIdx.x;
+  if (gid >= (long)B * V) return;
+  const int b = (int)(gid / V);
+  const F3 p = vertices[gid];
+  float o[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float4 m = transforms[(size_t)b * 4 + r];
+    o[r] = ((m.x * p.x + m.y * p.y) + m.z * p.z) + m.w;
+  }
+  clip[gid] = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+// The attribute arrays of render()'s shading, for launches that also want the per-triangle corner
+// records (corner_rec.h) built on the side: `corners` == nullptr switches that off.
+struct SetupAttributes {
+  const F3 *__restrict__ normals, *__restrict__ positions, *__restrict__ diffuse;
+  CornerRec *__restrict__ corners;
+};
+
 __global__ __launch_bounds__(kThreads) void k_setup(
     const float4 *__restrict__ clip, const int32_t *__restrict__ tris, int B, int V, int T,
     int W, int H, TriRec *__restrict__ recs, TriBox *__restrict__ bbs,
-    float *__restrict__ pxtab, float *__restrict__ pytab) {
+    float *__restrict__ pxtab, float *__restrict__ pytab, const SetupAttributes attrs) {
   const long gid = (long)blockIdx.x * kThreads + threadIdx.x;
   const long nbt = (long)B * T;
   const float hw = (float)(0.5 * (double)W);  // cpp:309
@@ -109,6 +135,7 @@ __global__ __launch_bounds__(kThreads) void k_setup(
   }
   const int b = (int)(gid / T);
   const int t = (int)(gid - (long)b * T);
+  if (attrs.corners) fill_corner_record(attrs.normals, attrs.positions, attrs.diffuse, tris, b, t, V, attrs.corners + gid);
   const int i0 = tris[3 * t + 0], i1 = tris[3 * t + 1], i2 = tris[3 * t + 2];
   TriBox bb{0u, 0u, -INFINITY, 0u};
   if ((unsigned)i0 < (unsigned)V && (unsigned)i1 < (unsigned)V && (unsigned)i2 < (unsigned)V) {
@@ -993,7 +1020,8 @@ void launch_k_raster_probe(const RasterArgs &a, dim3 grid, hipStream_t s) {
 
 namespace {
 int raster_forward(const float *clip, const int32_t *tris, int B, int V, int T, int W, int H, int32_t *ids,
-                   float *bary, float *z, const RasterShade &shade, void *ws, hipStream_t s) {
+                   float *bary, float *z, const RasterShade &shade, const SetupAttributes &attrs, void *ws,
+                   hipStream_t s) {
   const size_t nbt = (size_t)B * T;
   char *p = (char *)ws;
   TriRec *recs = (TriRec *)p;
@@ -1016,7 +1044,7 @@ int raster_forward(const float *clip, const int32_t *tris, int B, int V, int T, 
   const long setup_threads = (long)nbt + W + H;
   const unsigned setup_blocks = (unsigned)((setup_threads + kThreads - 1) / kThreads);
   hipLaunchKernelGGL(k_setup, dim3(setup_blocks), dim3(kThreads), 0, s, (const float4 *)clip, tris,
-                     B, V, T, W, H, recs, bbs, pxtab, pytab);
+                     B, V, T, W, H, recs, bbs, pxtab, pytab, attrs);
   int rc = check_launch();
   if (rc != MR_OK) return rc;
   if (B == 0) return MR_OK;
@@ -1045,22 +1073,36 @@ int raster_forward(const float *clip, const int32_t *tris, int B, int V, int T, 
 int launch_raster_forward(const float *clip, const int32_t *tris, int B, int V, int T, int W,
                           int H, int32_t *ids, float *bary, float *z, void *ws, hipStream_t s) {
   return raster_forward(clip, tris, B, V, T, W, H, ids, bary, z,
-                        RasterShade{nullptr, Lights{nullptr, nullptr, nullptr, 0}, nullptr, 1}, ws, s);
+                        RasterShade{nullptr, Lights{nullptr, nullptr, nullptr, 0}, nullptr, 1},
+                        SetupAttributes{nullptr, nullptr, nullptr, nullptr}, ws, s);
 }
 
-// render()'s forward in one pass over the pixels: G-buffer + shaded RGBA (see RasterShade).
-// `corner_records`: shade_forward_ws() bytes, filled here (and reusable by the shading backward).
-int launch_render_forward(const float *clip, const float *normals, const float *positions, const float *diffuse,
-                          const int32_t *tris, const float *light_pos, const float *light_col,
-                          const float *ambient, int B, int V, int T, int W, int H, int L, int32_t *ids,
-                          float *bary, float *z, int want_z, float *rgba, void *corner_records, void *ws,
-                          hipStream_t s) {
+int launch_vertex_transform(const float *vertices, const float *transforms, int B, int V, float *clip,
+                            hipStream_t s) {
+  const long nbv = (long)B * V;
+  if (nbv == 0) return MR_OK;
+  hipLaunchKernelGGL(k_vertex_transform, dim3((unsigned)((nbv + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
+                     (const F3 *)vertices, (const float4 *)transforms, B, V, (float4 *)clip);
+  return check_launch();
+}
+
+// render()'s forward from world-space vertices to the image, four launches: the clip-space transform,
+// the per-triangle setup (rasterizer records AND the shading's corner records), the coarse cell lists,
+// and ONE pass over the pixels that leaves the G-buffer and the shaded RGBA (see RasterShade).
+// `clip` (out) and `corner_records` (out, shade_forward_ws() bytes) are what the backward needs.
+int launch_render_forward(const float *vertices, const float *transforms, const float *normals,
+                          const float *diffuse, const int32_t *tris, const float *light_pos,
+                          const float *light_col, const float *ambient, int B, int V, int T, int W, int H,
+                          int L, float *clip, int32_t *ids, float *bary, float *z, int want_z, float *rgba,
+                          void *corner_records, void *ws, hipStream_t s) {
+  const int rc = launch_vertex_transform(vertices, transforms, B, V, clip, s);
+  if (rc != MR_OK) return rc;
   if ((size_t)B * W * H == 0) return MR_OK;
   CornerRec *corners = (CornerRec *)corner_records;
-  const int rc = launch_corner_setup(normals, positions, diffuse, tris, B, V, T, corners, s);
-  if (rc != MR_OK) return rc;
   return raster_forward(clip, tris, B, V, T, W, H, ids, bary, z,
-                        RasterShade{corners, Lights{light_pos, light_col, ambient, L}, rgba, want_z}, ws, s);
+                        RasterShade{corners, Lights{light_pos, light_col, ambient, L}, rgba, want_z},
+                        SetupAttributes{(const F3 *)normals, (const F3 *)vertices, (const F3 *)diffuse, corners}, ws,
+                        s);
 }
 
 }  // namespace mr

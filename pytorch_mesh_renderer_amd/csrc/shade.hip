@@ -39,21 +39,7 @@ __global__ __launch_bounds__(kThreads) void k_corner_setup(
   if (gid >= (long)B * T) return;
   const int b = (int)(gid / T);
   const int t = (int)(gid - (long)b * T);
-  float v[32];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    int vi = tris[3 * t + k];
-    if ((unsigned)vi >= (unsigned)V) vi = 0;
-    const size_t at = (size_t)b * V + vi;
-    const F3 n = normals[at], p = positions[at], d = diffuse[at];
-    v[k * 9 + 0] = n.x; v[k * 9 + 1] = n.y; v[k * 9 + 2] = n.z;
-    v[k * 9 + 3] = p.x; v[k * 9 + 4] = p.y; v[k * 9 + 5] = p.z;
-    v[k * 9 + 6] = d.x; v[k * 9 + 7] = d.y; v[k * 9 + 8] = d.z;
-  }
-#pragma unroll
-  for (int i = 27; i < 32; ++i) v[i] = 0.f;
-#pragma unroll
-  for (int q = 0; q < 8; ++q) out[gid].q[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+  fill_corner_record(normals, positions, diffuse, tris, b, t, V, out + gid);
 }
 
 // One workgroup = 256 consecutive pixels of a row segment x kRows consecutive rows; each
@@ -374,7 +360,8 @@ template <bool DET>
 __global__ __launch_bounds__(kThreads) void k_shade_gather(
     const float *__restrict__ acc, const float *__restrict__ det_scale, const int32_t *__restrict__ offsets,
     const int32_t *__restrict__ entries, int B, int V, int T, float *__restrict__ dnormals,
-    float *__restrict__ dpositions, float *__restrict__ ddiffuse, float *__restrict__ dclip) {
+    float *__restrict__ dpositions, float *__restrict__ ddiffuse, float *__restrict__ dclip,
+    const float *__restrict__ transforms) {
   const long tid = (long)blockIdx.x * kThreads + threadIdx.x;
   const long gid = tid >> 4;   // (image, vertex)
   const int j = (int)(tid & 15);
@@ -403,6 +390,16 @@ __global__ __launch_bounds__(kThreads) void k_shade_gather(
       }
 #pragma unroll
       for (int u = 0; u < kChunk; ++u) sum += val[u];
+    }
+  }
+  if (transforms) {
+    // clip = transforms[b] . (position, 1): the clip-space gradient (lanes 9, 10, 11 of this vertex:
+    // x, y, w; the z column is 0) is pulled back onto the position gradient of lanes 3..5
+    const int base = (int)(threadIdx.x & (kWave - 1)) & ~15;
+    const float dx = __shfl(sum, base + 9), dy = __shfl(sum, base + 10), dw = __shfl(sum, base + 11);
+    if (j >= 3 && j < 6) {
+      const float *m = transforms + (size_t)b * 16 + (j - 3);
+      sum += (m[0] * dx + m[4] * dy) + m[12] * dw;
     }
   }
   float *out = j < 3 ? dnormals + gid * 3 + j
@@ -510,9 +507,10 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
                           const float *light_col, const float *ambient, int B, int V, int T, int W,
                           int H, int L, float *dclip, float *dnormals, float *dpositions,
                           float *ddiffuse, float *light_grads, const void *corner_records,
-                          const int32_t *vertex_offsets, const int32_t *vertex_entries, void *ws,
-                          hipStream_t s) {
+                          const int32_t *vertex_offsets, const int32_t *vertex_entries,
+                          const float *transforms, void *ws, hipStream_t s) {
   if (B == 0) return MR_OK;
+  if (transforms && !(vertex_offsets && vertex_entries)) return MR_EINVAL;  // the gather applies them
   const size_t v3 = (size_t)B * V * 3 * sizeof(float), v4 = (size_t)B * V * 4 * sizeof(float);
   const size_t lg = (size_t)B * (L * 6 + 3) * sizeof(float);
   const bool det = g_deterministic != 0;
@@ -598,14 +596,14 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
     const dim3 grid((unsigned)((nbv + kThreads - 1) / kThreads));
     if (det) {
       hipLaunchKernelGGL(k_shade_gather<true>, grid, dim3(kThreads), 0, s, acc, det_scale, vertex_offsets,
-                         vertex_entries, B, V, T, dnormals, dpositions, ddiffuse, dclip);
+                         vertex_entries, B, V, T, dnormals, dpositions, ddiffuse, dclip, transforms);
       if ((rc = check_launch()) != MR_OK) return rc;
       const int n_light = B * (L * 6 + 3);
       hipLaunchKernelGGL(k_light_from_fixed, dim3((unsigned)((n_light + kThreads - 1) / kThreads)), dim3(kThreads),
                          0, s, light_fixed, det_scale, n_light, light_grads);
     } else {
       hipLaunchKernelGGL(k_shade_gather<false>, grid, dim3(kThreads), 0, s, acc, det_scale, vertex_offsets,
-                         vertex_entries, B, V, T, dnormals, dpositions, ddiffuse, dclip);
+                         vertex_entries, B, V, T, dnormals, dpositions, ddiffuse, dclip, transforms);
     }
     return check_launch();
   }

@@ -113,30 +113,36 @@ USE_SHADING_EPILOGUE = os.environ.get("MR_SHADING_EPILOGUE", "1") != "0"
 
 
 class FusedPhongRenderer(torch.autograd.Function):
-    """G-buffer rasterization + attribute interpolation + diffuse/ambient Phong as ONE
-    differentiable op: 1 pass over the pixels forward (k_raster with the shading epilogue), 1 pass
-    over the G-buffer backward.  Used by render() when no specular term is requested; covers
-    src/mesh_renderer/rasterize.py:66-152 and src/mesh_renderer/render.py:199-228,
-    287-323, 373-386 and their autograd graph."""
+    """World-space vertices -> shaded image as ONE differentiable op: clip-space transform,
+    G-buffer rasterization, attribute interpolation and diffuse/ambient Phong in four launches
+    forward (one pass over the pixels: k_raster with the shading epilogue), one pass over the
+    G-buffer backward.  Used by render() when no specular term is requested; covers
+    src/common/camera_utils.py:142-170, src/mesh_renderer/rasterize.py:66-152 and
+    src/mesh_renderer/render.py:199-228, 287-323, 373-386 and their autograd graph.
+
+    transforms [B,4,4]: the clip-space transforms (perspective . look_at); differentiable -- the
+    examples optimise cameras through them -- via one small batched product in the backward."""
 
     @staticmethod
-    def forward(ctx, clip, positions, normals, diffuse, triangles, light_positions,
+    def forward(ctx, vertices, transforms, normals, diffuse, triangles, light_positions,
                 light_intensities, ambient, image_width, image_height):
-        clip_d = clip.detach().contiguous()
-        args = [t.detach().contiguous() for t in (normals, positions, diffuse)]
+        verts, xf = vertices.detach().contiguous(), transforms.detach().contiguous()
+        args = [t.detach().contiguous() for t in (normals, diffuse)]
         lp, li = light_positions.detach().contiguous(), light_intensities.detach().contiguous()
         amb = ambient.detach().contiguous() if ambient is not None else None
         if USE_SHADING_EPILOGUE:
-            ids, bary, _, rgba, corner_records = _native.render_forward(
-                clip_d, args[0], args[1], args[2], triangles, lp, li, amb, int(image_width), int(image_height),
+            clip, ids, bary, _, rgba, corner_records = _native.render_forward(
+                verts, xf, args[0], args[1], triangles, lp, li, amb, int(image_width), int(image_height),
                 want_z=False)
         else:
-            ids, bary, _ = _native.rasterize_forward(clip_d, triangles, int(image_width), int(image_height))
-            rgba, corner_records = _native.shade_forward(ids, bary, args[0], args[1], args[2], triangles, lp,
+            from ..common import camera_utils
+            clip = camera_utils.transform_homogeneous(xf, verts).contiguous()
+            ids, bary, _ = _native.rasterize_forward(clip, triangles, int(image_width), int(image_height))
+            rgba, corner_records = _native.shade_forward(ids, bary, args[0], verts, args[1], triangles, lp,
                                                          li, amb, keep_corner_records=True)
-        offsets, entries = _native.vertex_adjacency(triangles, positions.shape[1])   # cached per mesh
-        saved = [clip_d, ids, bary, args[0], args[1], args[2], triangles, lp, li, corner_records,
-                 offsets, entries]
+        offsets, entries = _native.vertex_adjacency(triangles, vertices.shape[1])   # cached per mesh
+        saved = [clip, ids, bary, args[0], verts, args[1], triangles, lp, li, corner_records,
+                 offsets, entries, xf]
         if amb is not None:
             saved.append(amb)
         ctx.save_for_backward(*saved)
@@ -144,15 +150,25 @@ class FusedPhongRenderer(torch.autograd.Function):
         return rgba
 
     @staticmethod
+    def _input_grads(saved, needs_transform_grad, upstream, l1_signs=None):
+        """The shading backward on the tensors forward() saved -> gradients in the order of forward()'s
+        tensor arguments (vertices, transforms, normals, diffuse, None, lights..., ambient)."""
+        (clip, ids, bary, normals, verts, diffuse, triangles, lp, li, corner_records, offsets,
+         entries, xf) = saved[:13]
+        amb = saved[13] if len(saved) > 13 else None
+        dclip, dn, dverts, dd, dlp, dli, damb = _native.shade_backward(
+            upstream, ids, bary, clip, normals, verts, diffuse, triangles, lp, li, amb,
+            corner_records=corner_records, adjacency=(offsets, entries), l1_signs=l1_signs, transforms=xf)
+        dxf = None
+        if needs_transform_grad:  # d clip[b,v,r] / d xf[b,r,k] = (vertex, 1)[k]
+            ones = torch.ones(verts.shape[0], verts.shape[1], 1, dtype=verts.dtype, device=verts.device)
+            dxf = torch.matmul(dclip.transpose(1, 2), torch.cat([verts, ones], dim=2))
+        return dverts, dxf, dn, dd, None, dlp, dli, damb
+
+    @staticmethod
     def backward(ctx, drgba):
-        saved = ctx.saved_tensors
-        (clip, ids, bary, normals, positions, diffuse, triangles, lp, li, corner_records, offsets,
-         entries) = saved[:12]
-        amb = saved[12] if ctx.has_ambient else None
-        dclip, dn, dp, dd, dlp, dli, damb = _native.shade_backward(
-            drgba.contiguous(), ids, bary, clip, normals, positions, diffuse, triangles, lp, li, amb,
-            corner_records=corner_records, adjacency=(offsets, entries))
-        return dclip, dp, dn, dd, None, dlp, dli, damb, None, None
+        grads = FusedPhongRenderer._input_grads(ctx.saved_tensors, ctx.needs_input_grad[1], drgba.contiguous())
+        return grads + (None, None)
 
 
 class FusedPhongL1Loss(torch.autograd.Function):
@@ -163,7 +179,7 @@ class FusedPhongL1Loss(torch.autograd.Function):
     gradient from this node: the chain through the renderer is evaluated here, fused."""
 
     @staticmethod
-    def forward(ctx, image, target, clip, positions, normals, diffuse, light_positions,
+    def forward(ctx, image, target, vertices, transforms, normals, diffuse, light_positions,
                 light_intensities, ambient, render_saved):
         loss, signs = _native.l1_loss_forward(image.detach(), target.detach(), want_signs=True)
         ctx.image_shape = image.shape
@@ -175,18 +191,13 @@ class FusedPhongL1Loss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad):
         signs = ctx.saved_tensors[0]
-        saved = ctx.saved_tensors[1:]
-        (clip, ids, bary, normals, positions, diffuse, triangles, lp, li, corner_records, offsets,
-         entries) = saved[:12]
-        amb = saved[12] if len(saved) > 12 else None
         upstream = grad.to(torch.float32).reshape(1)
-        dclip, dn, dp, dd, dlp, dli, damb = _native.shade_backward(
-            upstream, ids, bary, clip, normals, positions, diffuse, triangles, lp, li, amb,
-            corner_records=corner_records, adjacency=(offsets, entries), l1_signs=signs)
+        dverts, dxf, dn, dd, _, dlp, dli, damb = FusedPhongRenderer._input_grads(
+            ctx.saved_tensors[1:], ctx.needs_input_grad[3], upstream, l1_signs=signs)
         dtarget = None
         if ctx.needs_input_grad[1]:
             dtarget = -_native.l1_loss_backward(signs, ctx.image_shape, upstream)
-        return None, dtarget, dclip, dp, dn, dd, dlp, dli, damb, None
+        return None, dtarget, dverts, dxf, dn, dd, dlp, dli, damb, None
 
 
 class FusedSpecularPhongRenderer(torch.autograd.Function):

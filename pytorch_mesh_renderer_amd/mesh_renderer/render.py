@@ -179,8 +179,8 @@ def _render_fused(vertices, triangles, normals, diffuse_colors, camera_position,
     clip_space_transforms = camera_utils.clip_space_transforms(
         camera_position, camera_lookat, camera_up, fov_y, near_clip, far_clip,
         image_width / image_height, device)
-    clip = camera_utils.transform_homogeneous(clip_space_transforms, vertices)
     if specular_colors is not None:
+        clip = camera_utils.transform_homogeneous(clip_space_transforms, vertices)
         return FusedSpecularPhongRenderer.apply(
             clip, vertices, normals, diffuse_colors, specular_colors.to(torch.float32), triangles,
             light_positions.to(device), light_intensities.to(device).to(torch.float32),
@@ -189,13 +189,14 @@ def _render_fused(vertices, triangles, normals, diffuse_colors, camera_position,
             image_width, image_height)
     lp, li = light_positions.to(device), light_intensities.to(device).to(torch.float32)
     amb = ambient_color.to(device) if ambient_color is not None else None
-    image = FusedPhongRenderer.apply(clip, vertices, normals, diffuse_colors, triangles, lp, li, amb,
+    transforms = clip_space_transforms.to(torch.float32)
+    image = FusedPhongRenderer.apply(vertices, transforms, normals, diffuse_colors, triangles, lp, li, amb,
                                      image_width, image_height)
     if image.grad_fn is not None:
         # lets losses.l1_loss differentiate straight to these inputs (FusedPhongL1Loss); the node
         # is compared by identity there, so a tensor derived from `image` never takes that path
         image._mr_fused_render = {"node": image.grad_fn, "saved": tuple(image.grad_fn.saved_tensors),
-                                  "inputs": (clip, vertices, normals, diffuse_colors, lp, li, amb)}
+                                  "inputs": (vertices, transforms, normals, diffuse_colors, lp, li, amb)}
     return image
 
 

@@ -37,13 +37,14 @@ def assert_close_abs_and_rel(got, want, what, rel=2e-3):
 
 def device_clip_bits(job, device):
     """The clip-space vertices exactly as render() forms them on the device (render.py's
-    _render_fused: host-side camera matrices, one baddbmm on the device), back on the host."""
+    _render_fused: host-side camera matrices, then the library's own per-vertex transform -- the
+    first stage of mr_render_forward), back on the host."""
     b = job["vertices"].shape[0]
     full = lambda v: torch.full((b,), float(v))
     transforms = camera_utils.clip_space_transforms(
         job["eyes"], torch.zeros(b, 3), torch.tensor([[0.0, 1.0, 0.0]]).repeat(b, 1), full(40.0), full(0.01),
         full(10.0), job["width"] / job["height"], device)
-    return camera_utils.transform_homogeneous(transforms, job["vertices"].to(device)).cpu()
+    return _native.vertex_transform(job["vertices"].to(device), transforms.to(torch.float32)).cpu()
 
 
 def oracle_step_for_image(job, b, upstream_b, clip_bits):

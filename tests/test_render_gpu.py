@@ -456,6 +456,37 @@ def test_fused_specular_shininess_gradient_matches_composed_path(device, kind):
         np.testing.assert_allclose(grads_f[k], grads_c[k], atol=ATOL, rtol=0, err_msg=k)
 
 
+def test_render_with_and_without_shading_epilogue(device):
+    """render() + L1 loss + backward with FusedPhongRenderer's one-pass forward (mr_render_forward) and with
+    its two-kernel forward (torch clip transform, k_raster, k_shade_forward): same image, same gradients --
+    camera gradient included (the transforms are differentiated through one batched product)."""
+    import importlib
+    ext = importlib.import_module("pytorch_mesh_renderer_amd.mesh_renderer.rasterize_triangles_ext")
+    job = synthetic.sphere_job(2, 120, 90, 14)
+    target = torch.rand(2, 90, 120, 4, generator=torch.Generator().manual_seed(2)).to(device)
+    results = {}
+    for epilogue in (True, False):
+        leaves = {k: job[k].clone().to(device).requires_grad_(True)
+                  for k in ("vertices", "normals", "diffuse", "light_positions", "eyes")}
+        ext.USE_SHADING_EPILOGUE = epilogue
+        try:
+            with _CountCalls("render_forward") as counter:
+                img = mesh_renderer.render(leaves["vertices"], job["triangles"].to(device), leaves["normals"],
+                                           leaves["diffuse"], leaves["eyes"], torch.zeros(2, 3, device=device),
+                                           torch.tensor([0.0, 1.0, 0.0], device=device), leaves["light_positions"],
+                                           job["light_intensities"].to(device), 120, 90)
+                mesh_renderer.losses.l1_loss(img, target).backward()
+        finally:
+            ext.USE_SHADING_EPILOGUE = True
+        assert counter.calls == (1 if epilogue else 0)
+        results[epilogue] = (img.detach().cpu().numpy(), {k: v.grad.cpu().numpy() for k, v in leaves.items()})
+    np.testing.assert_allclose(results[True][0], results[False][0], atol=ATOL, rtol=0)
+    assert np.array_equal(results[True][0][..., 3], results[False][0][..., 3])
+    for k, want in results[False][1].items():
+        assert np.abs(want).max() > 0, k
+        np.testing.assert_allclose(results[True][1][k], want, atol=ATOL, rtol=0, err_msg=k)
+
+
 @pytest.mark.parametrize("w,h,res,n_lights,ambient", [(96, 80, 12, 1, False), (130, 67, 10, 3, True),
                                                         (64, 64, 120, 2, True), (33, 31, 6, 4, False)])
 def test_render_forward_matches_raster_then_shade(device, w, h, res, n_lights, ambient):
@@ -471,21 +502,34 @@ def test_render_forward_matches_raster_then_shade(device, w, h, res, n_lights, a
     lp = (torch.rand(2, n_lights, 3, generator=gen) * 6 - 3).to(device)
     li = (torch.rand(2, n_lights, 3, generator=gen) + 0.2).to(device)
     amb = (torch.rand(2, 3, generator=gen) * 0.3).to(device) if ambient else None
-    ids, bary, z = _native.rasterize_forward(d["clip"], d["triangles"], w, h)
+    xf = synthetic.clip_transforms(job["eyes"], w, h).to(device)
+    clip = _native.vertex_transform(d["vertices"], xf)
+    np.testing.assert_allclose(clip.cpu().numpy(), job["clip"].numpy(), atol=2e-6, rtol=1e-6)
+    ids, bary, z = _native.rasterize_forward(clip, d["triangles"], w, h)
     rgba = _native.shade_forward(ids, bary, d["normals"], d["vertices"], diffuse, d["triangles"], lp, li, amb)
     assert float(rgba[..., 3].mean()) > 0.2
     for want_z in (True, False):
-        ids2, bary2, z2, rgba2, records = _native.render_forward(
-            d["clip"], d["normals"], d["vertices"], diffuse, d["triangles"], lp, li, amb, w, h, want_z=want_z)
+        clip2, ids2, bary2, z2, rgba2, records = _native.render_forward(
+            d["vertices"], xf, d["normals"], diffuse, d["triangles"], lp, li, amb, w, h, want_z=want_z)
+        assert torch.equal(clip2, clip)
         assert torch.equal(ids2, ids) and torch.equal(bary2, bary)
         assert (z2 is None) if not want_z else torch.equal(z2, z)
         np.testing.assert_allclose(rgba2.cpu().numpy(), rgba.cpu().numpy(), atol=1e-6, rtol=0)
     # the records it leaves behind are the ones the shading backward would build itself
     g = torch.randn(2, h, w, 4, generator=torch.Generator().manual_seed(1)).to(device) / (h * w)
-    args = (g, ids, bary, d["clip"], d["normals"], d["vertices"], diffuse, d["triangles"], lp, li, amb)
-    for a, b in zip(_native.shade_backward(*args), _native.shade_backward(*args, corner_records=records)):
+    args = (g, ids, bary, clip, d["normals"], d["vertices"], diffuse, d["triangles"], lp, li, amb)
+    plain = _native.shade_backward(*args)
+    for a, b in zip(plain, _native.shade_backward(*args, corner_records=records)):
         if a is not None:
             np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), atol=1e-7, rtol=1e-5)
+    # with the transforms, dpositions also carries the clip-space gradient pulled back through them
+    adjacency = _native.vertex_adjacency(d["triangles"], d["vertices"].shape[1])
+    gathered = _native.shade_backward(*args, adjacency=adjacency)
+    pulled = _native.shade_backward(*args, adjacency=adjacency, transforms=xf)
+    want = gathered[2] + torch.matmul(gathered[0], xf)[..., :3]
+    np.testing.assert_allclose(pulled[2].cpu().numpy(), want.cpu().numpy(), atol=1e-7, rtol=1e-5)
+    for k in (0, 1, 3):
+        np.testing.assert_allclose(pulled[k].cpu().numpy(), gathered[k].cpu().numpy(), atol=1e-8, rtol=1e-5)
 
 
 def test_shade_backward_gather_matches_scatter(device):
