@@ -212,7 +212,7 @@ def cpu_baseline(batch, width, height, sphere_k, sample_images):
     }
 
 
-def roofline(kernel, algorithmic, avg_ms, traffic_key):
+def roofline(kernel, algorithmic, avg_ms, traffic_key, config="c3"):
     achieved = algorithmic / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     out = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
@@ -220,7 +220,8 @@ def roofline(kernel, algorithmic, avg_ms, traffic_key):
     pmc_path = os.path.join(ROOT, "profiles", "kernel_traffic.json")
     if os.path.exists(pmc_path):   # written from separate rocprofv3 --pmc passes over this command
         pmc = json.load(open(pmc_path))
-        if traffic_key in pmc.get("kernels", {}):
+        # (the counters were collected on the default configuration only)
+        if config == "c3" and traffic_key in pmc.get("kernels", {}):
             out["traffic"] = pmc["kernels"][traffic_key]["bytes_per_launch"]
             out["traffic_source"] = ("profiles/kernel_traffic.json: rocprofv3 --pmc passes over `%s` at %s, NOT "
                                      "this run" % (pmc.get("command", "bench.py"), pmc.get("tag", "?")))
@@ -329,14 +330,15 @@ def main():
             # per-triangle attribute records (128 B) read
             "roofline": roofline("k_raster<shade> (forward: ids + barycentrics + shaded RGBA write)",
                                  px * 32 + batch * V * 16 + T * 12 + batch * T * 128,
-                                 ev_raster.mean_ms(n_ev), "k_raster_shade"),
+                                 ev_raster.mean_ms(n_ev), "k_raster_shade", args.config),
             "roofline_gbuffer": roofline("k_raster (G-buffer write alone: %d steps with the shading epilogue off, after the timed region)" % n_gb,
-                                         px * 20 + batch * V * 16 + T * 12, ev_gbuffer.mean_ms(n_gb), "k_raster"),
+                                         px * 20 + batch * V * 16 + T * 12, ev_gbuffer.mean_ms(n_gb), "k_raster",
+                                         args.config),
             # ids + barycentrics (16 B/px) and the loss's sign codes (1 B/px) read, the triangles'
             # attribute and adjugate records (128 + 64 B) read
             "roofline_shade_backward": roofline(
                 "k_accumulate_rows<ShadeGradFn> (fused shading backward, pixel pass)",
-                px * 17 + batch * T * (128 + 64), ev_shade.mean_ms(n_ev), "shade_backward"),
+                px * 17 + batch * T * (128 + 64), ev_shade.mean_ms(n_ev), "shade_backward", args.config),
         }
         if world == 1 and args.cpu_sample > 0:
             line["cpu_baseline"] = cpu_baseline(batch, width, height, sphere_k, args.cpu_sample)

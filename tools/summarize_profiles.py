@@ -4,7 +4,7 @@
 
 Writes profiles/<tag>_bench_kernel_stats.csv (rocprofv3 --stats, top kernels),
 profiles/<tag>_bench.json (the bench lines of the same box) and rewrites
-profiles/kernel_traffic.json (HBM bytes per launch of k_raster and of the shading backward from the PMC
+profiles/kernel_traffic.json (HBM bytes per launch of the forward kernels and of the shading backward from the PMC
 passes; read by bench.py, which labels it as an offline value).
 """
 import csv, glob, json, os, sys
@@ -39,7 +39,10 @@ for name in ("bench.log", "bench_under_rocprof.log"):
 json.dump(lines, open(os.path.join(prof, tag + "_bench.json"), "w"), indent=1)
 
 # 3. HBM traffic of the kernels of interest, per launch
-wanted = {"k_raster": "k_raster<", "k_shade_forward": "k_shade_forward(", "ShadeGradFn": "ShadeGradFn",
+# k_raster<R, PROBE, SHADE>: "true>" = with the shading epilogue (the step's forward), "false>" = the
+# G-buffer kernel alone (bench.py runs 22 such steps after its timed region)
+wanted = {"k_raster_shade": "k_raster<64, 0, true>", "k_raster": "k_raster<64, 0, false>",
+          "k_shade_forward": "k_shade_forward(", "ShadeGradFn": "ShadeGradFn",
           "k_l1_forward": "k_l1_forward(", "k_l1_backward": "k_l1_backward("}
 raw = {k: {} for k in wanted}
 for counter in ("WRITE_SIZE", "FETCH_SIZE"):
@@ -70,8 +73,10 @@ out = {
            "2*FETCH_SIZE) * 1024 (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; WRITE_SIZE is "
            "exact for k_shade_forward's 16-B stores in the same run: 524288 KB = 537 MB)",
     "kernels": {
+        "k_raster_shade": {"bytes_per_launch": traffic(raw["k_raster_shade"]),
+                           "algorithmic_bytes": bench.get("roofline", {}).get("algorithmic_bytes")},
         "k_raster": {"bytes_per_launch": traffic(raw["k_raster"]),
-                     "algorithmic_bytes": bench.get("roofline", {}).get("algorithmic_bytes")},
+                     "algorithmic_bytes": bench.get("roofline_gbuffer", {}).get("algorithmic_bytes")},
         "shade_backward": {"bytes_per_launch": traffic(raw["ShadeGradFn"]),
                            "algorithmic_bytes": bench.get("roofline_shade_backward", {}).get("algorithmic_bytes")},
     },
