@@ -12,6 +12,12 @@
 #ifndef MR_L1_REVERSE
 #define MR_L1_REVERSE 1
 #endif
+#ifndef MR_L1_NT
+#define MR_L1_NT 2  // nontemporal loads of both streams: the step is 3-4 % faster (same-box A/B: 0 / target only / both)
+#endif
+#ifndef MR_L1_NT_STORE
+#define MR_L1_NT_STORE 1
+#endif
 #ifndef MR_L1_UNROLL
 #define MR_L1_UNROLL 2  // measured alone at 1024^2 x 32: 1 -> 0.216, 2 -> 0.211, 4 -> 0.248, 8 -> 0.241 ms
 #endif
@@ -20,6 +26,12 @@ namespace mr {
 namespace {
 
 constexpr int kThreads = 256;
+
+__device__ __forceinline__ float4 nt_load(const float4 *p) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const v4f v = __builtin_nontemporal_load((const v4f *)p);
+  return make_float4(v.x, v.y, v.z, v.w);
+}
 
 // 2-bit sign code of d: 0 -> 0, 1 -> +1, 2 -> -1 (NaN -> 0, like (0 < d) - (d < 0)).
 __device__ __forceinline__ unsigned sign_code(float d) { return d > 0.f ? 1u : (d < 0.f ? 2u : 0u); }
@@ -48,17 +60,31 @@ __global__ __launch_bounds__(kThreads) void k_l1_forward(const float4 *__restric
       const size_t ju = j + u * stride;
       const size_t jc = ju < n4 ? ju : j;   // out of range: re-read the first (adds nothing below)
       idx[u] = MR_L1_REVERSE ? n4 - 1 - jc : jc;
+#if MR_L1_NT == 1
+      x[u] = a[idx[u]];
+      y[u] = nt_load(&b[idx[u]]);
+#elif MR_L1_NT == 2
+      x[u] = nt_load(&a[idx[u]]);
+      y[u] = nt_load(&b[idx[u]]);
+#else
       x[u] = a[idx[u]];
       y[u] = b[idx[u]];
+#endif
     }
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
       if (u > 0 && j + u * stride >= n4) break;
       const float d0 = x[u].x - y[u].x, d1 = x[u].y - y[u].y, d2 = x[u].z - y[u].z, d3 = x[u].w - y[u].w;
       s += (fabsf(d0) + fabsf(d1)) + (fabsf(d2) + fabsf(d3));
-      if (signs)
-        signs[idx[u]] =
+      if (signs) {
+        const uint8_t code =
             (uint8_t)(sign_code(d0) | (sign_code(d1) << 2) | (sign_code(d2) << 4) | (sign_code(d3) << 6));
+#if MR_L1_NT_STORE
+        __builtin_nontemporal_store(code, &signs[idx[u]]);
+#else
+        signs[idx[u]] = code;
+#endif
+      }
     }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0 && n_tail > 0) {  // the last n % 4 elements

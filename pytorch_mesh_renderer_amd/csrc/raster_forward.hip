@@ -397,6 +397,10 @@ struct RasterShade {
                                           // written between the bin rounds of a crowded region (as state)
 };
 
+#ifndef MR_RASTER_STORE_AUX
+#define MR_RASTER_STORE_AUX 2  // cache policy of the G-buffer / RGBA stores: 2 = nontemporal (written once, read by a
+                                // later kernel from HBM anyway): kernel -5 %, step -2 % against 0 (same-box A/B)
+#endif
 #ifndef MR_RASTER_SHADE_WAVES
 #define MR_RASTER_SHADE_WAVES 6  // measured against 7 (more spills) and 5: 0.336 / 0.352 / 0.347 ms at 1024^2 x 32
 #endif
@@ -769,15 +773,15 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : MR_RASTER
           const unsigned lane_rgba = (unsigned)((kTileH - 1 - ly) * W + lx) * 16u;
           const int tile_rgba = ((R - kTileH - ty * kTileH) * W + tx * kTileW) * 16;
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v4f{rgba.x, rgba.y, rgba.z, rgba.w}), rs_rgba,
-                                                 lane_rgba, tile_rgba, 0);
+                                                 lane_rgba, tile_rgba, MR_RASTER_STORE_AUX);
         }
       }
       if (in_image && !((PROBE & 32) && st.z != 123.0f)) {  // 32: timing probe, no stores
-        __builtin_amdgcn_raw_buffer_store_b32((unsigned)max(st.id, 0), rs_ids, lane_pix * 4u, tile_pix * 4, 0);
+        __builtin_amdgcn_raw_buffer_store_b32((unsigned)max(st.id, 0), rs_ids, lane_pix * 4u, tile_pix * 4, MR_RASTER_STORE_AUX);
         if (!SHADE || !last_round || shade.keep_z)  // workgroup-uniform
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, st.z), rs_z, lane_pix * 4u, tile_pix * 4, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, st.z), rs_z, lane_pix * 4u, tile_pix * 4, MR_RASTER_STORE_AUX);
         __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(v3u, v3f{st.b0, st.b1, st.b2}), rs_bary, lane_pix * 12u,
-                                              tile_pix * 12, 0);
+                                              tile_pix * 12, MR_RASTER_STORE_AUX);
       }
       // Later rounds re-LOAD the pixel state.  vmcnt is in order on gfx950, so the compiler's wait
       // for such a load also drains the G-buffer stores behind it; draining explicitly here -- on

@@ -96,6 +96,9 @@ __global__ __launch_bounds__(kThreads, MR_SHADE_FWD_WAVES) void k_shade_forward(
 // SIGNS: the upstream gradient is the backward of mean|image - target| (loss.hip): it arrives as
 // the 2-bit sign codes that loss's forward packed (1 B/px, image rows) and one device scalar
 // instead of a [B,H,W,4] float image (16 B/px that k_l1_backward would first have to write).
+#ifndef MR_SHADE_NT
+#define MR_SHADE_NT 1
+#endif
 template <int L, bool SIGNS>
 struct ShadeGradFn {
   static constexpr int kN = 36;       // 27 attribute partials [corner][attr] + 9 clip partials
@@ -170,10 +173,18 @@ struct ShadeGradFn {
   }
 
   __device__ __forceinline__ void fetch(int img, int x, int y, size_t pix, Raw &r) const {
+#if MR_SHADE_NT
+    // streamed once, never reused: nontemporal
+    r.b.x = __builtin_nontemporal_load(&bary[pix].x);
+    r.b.y = __builtin_nontemporal_load(&bary[pix].y);
+    r.b.z = __builtin_nontemporal_load(&bary[pix].z);
+    r.t = __builtin_nontemporal_load(&ids[pix]);
+#else
     r.b = bary[pix];
     r.t = ids[pix];
+#endif
     const size_t image_pix = ((size_t)img * H + (H - 1 - y)) * W + x;  // un-flip
-    if (SIGNS) r.code = signs[image_pix];
+    if (SIGNS) r.code = MR_SHADE_NT ? __builtin_nontemporal_load(&signs[image_pix]) : signs[image_pix];
     else r.g = drgba[image_pix];
   }
   __device__ __forceinline__ bool prepare(const Raw &r, int T, int &tri, Pixel &p) const {
