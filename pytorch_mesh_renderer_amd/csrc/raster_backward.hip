@@ -83,6 +83,9 @@ constexpr int kThreads = 256;
 constexpr float kDegenerateCutoff = 0.9f;  // cpp:13
 constexpr int kStride = 12;                // floats per acc row (9 used): 48 B
 
+#ifndef MR_RASTER_BWD_NT
+#define MR_RASTER_BWD_NT 1
+#endif
 struct RasterGradFn {
   static constexpr int kN = 9;  // [corner j][component c] partials
   static constexpr int kStride = mr::kStride;
@@ -107,9 +110,15 @@ struct RasterGradFn {
   __device__ __forceinline__ void begin_image(int, Image &) const {}
   __device__ __forceinline__ void end_image(int, Image &) const {}
   __device__ __forceinline__ void fetch(int, int, int, size_t pix, Raw &r) const {
+#if MR_RASTER_BWD_NT
+    r.t = __builtin_nontemporal_load(&ids[pix]);
+    r.b = load_streamed(&bary[pix]);
+    r.g = load_streamed(&dbary[pix]);
+#else
     r.t = ids[pix];
     r.b = bary[pix];
     r.g = dbary[pix];
+#endif
   }
   __device__ __forceinline__ bool prepare(const Raw &r, int T, int &tri, Pixel &p) const {
     if ((unsigned)r.t >= (unsigned)T) return false;                             // foreign id

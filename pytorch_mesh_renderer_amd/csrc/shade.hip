@@ -53,6 +53,9 @@ __global__ __launch_bounds__(kThreads) void k_corner_setup(
 #define MR_SHADE_FWD_WAVES 1
 #endif
 constexpr int kShadeRows = MR_SHADE_ROWS;
+#ifndef MR_SHADE_FWD_NT
+#define MR_SHADE_FWD_NT 1
+#endif
 
 __global__ __launch_bounds__(kThreads, MR_SHADE_FWD_WAVES) void k_shade_forward(
     const int32_t *__restrict__ ids, const F3 *__restrict__ bary,
@@ -72,8 +75,13 @@ __global__ __launch_bounds__(kThreads, MR_SHADE_FWD_WAVES) void k_shade_forward(
   for (int r = 0; r < kShadeRows; ++r) {
     const int y = min(y0 + r, H - 1);
     const size_t pix = ((size_t)img * H + y) * W + x;
+#if MR_SHADE_FWD_NT
+    b[r] = load_streamed(&bary[pix]);
+    t[r] = __builtin_nontemporal_load(&ids[pix]);
+#else
     b[r] = bary[pix];
     t[r] = ids[pix];
+#endif
   }
   Corners cr[kShadeRows];
 #pragma unroll
@@ -89,7 +97,12 @@ __global__ __launch_bounds__(kThreads, MR_SHADE_FWD_WAVES) void k_shade_forward(
     if (y >= H) break;
     const float4 rgba = live[r] ? shade_pixel(cr[r], b[r], lights, img) : make_float4(0.f, 0.f, 0.f, 0.f);
     // render.py:384-386: the image is flipped vertically (G-buffer row 0 is the bottom)
+#if MR_SHADE_FWD_NT
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store(v4f{rgba.x, rgba.y, rgba.z, rgba.w}, (v4f *)&out[((size_t)img * H + (H - 1 - y)) * W + x]);
+#else
     out[((size_t)img * H + (H - 1 - y)) * W + x] = rgba;
+#endif
   }
 }
 
@@ -175,9 +188,7 @@ struct ShadeGradFn {
   __device__ __forceinline__ void fetch(int img, int x, int y, size_t pix, Raw &r) const {
 #if MR_SHADE_NT
     // streamed once, never reused: nontemporal
-    r.b.x = __builtin_nontemporal_load(&bary[pix].x);
-    r.b.y = __builtin_nontemporal_load(&bary[pix].y);
-    r.b.z = __builtin_nontemporal_load(&bary[pix].z);
+    r.b = load_streamed(&bary[pix]);
     r.t = __builtin_nontemporal_load(&ids[pix]);
 #else
     r.b = bary[pix];
