@@ -317,6 +317,8 @@ __global__ __launch_bounds__(kRunThreads, Fn::kMinWavesPerSimd) void k_accumulat
     __builtin_amdgcn_wave_barrier();  // LDS executes one wavefront's operations in order
 #if MR_PROBE_ROWS == 2  // timing probe: no transposed reduction, no atomics
     heads = 0;
+#elif MR_PROBE_ROWS == 3  // timing probe: one segment per row (the first head only)
+    heads &= -heads;
 #endif
     // ONE pass over the row's pixels in groups of eight (four 8-byte reads per factor): a group
     // without a head is eight FMAs straight; only at a head (~3.5 per row) the running sum is
