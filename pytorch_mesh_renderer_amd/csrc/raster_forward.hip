@@ -757,16 +757,10 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : MR_RASTER
               for (int a = 0; a < 9; ++a) interp[a] = c[k * 9 + a] * bk[k] + interp[a];
           }
         }
-        if (live) {
-#pragma clang fp contract(fast)
-          // interpolate9's blend with the -1 background (alpha is 1 on every covered pixel up to rounding)
-          const float pre = (2.0f * st.b0 + 2.0f * st.b1) + 2.0f * st.b2;
-          const float alpha = fminf(fmaxf(pre, 0.0f), 1.0f), one_m = 1.0f - alpha;
-          float at[9];
-#pragma unroll
-          for (int a = 0; a < 9; ++a) at[a] = alpha * interp[a] + one_m * -1.0f;
-          rgba = shade_attributes(at, lights);
-        }
+        // interpolate9's blend with the -1 background is the identity here: these barycentrics were
+        // just normalised by this kernel (their sum is 1 up to three roundings), so alpha = clamp(2 sum
+        // b, 0, 1) is exactly 1 and 1 * x + 0 * (-1) = x -- the same bits k_shade_forward produces
+        if (live) rgba = shade_attributes(interp, lights);
         if (in_image) {
           typedef float v4f __attribute__((ext_vector_type(4)));
           typedef unsigned v4u __attribute__((ext_vector_type(4)));

@@ -17,7 +17,7 @@ done
 python3 - <<'PY' | tee gpurun_out/pmc_step/summary.txt
 import csv, glob, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-keys = ("k_accumulate_rows", "k_raster", "k_l1_forward", "k_shade_gather")
+keys = ("k_accumulate_rows", "k_raster<64, 0, true>", "k_raster<64, 0, false>", "k_l1_forward", "k_shade_gather")
 for f in glob.glob("gpurun_out/pmc_step/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         for key in keys:
