@@ -34,6 +34,45 @@ def test_library_exports_every_declared_symbol():
     assert _native.lib().mr_version() == _native.ABI_VERSION
 
 
+def _declared_prototypes():
+    """name -> list of parameter declarations, parsed from the public headers."""
+    protos = {}
+    for header in ("mesh_raster.h", "mesh_raster_debug.h"):
+        text = open(os.path.join(ROOT, "include", header)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        for name, params in re.findall(r"\b(mr_[a-z_0-9]+)\s*\(([^)]*)\)\s*;", text):
+            params = " ".join(params.split())
+            protos[name] = [] if params in ("", "void") else [p.strip() for p in params.split(",")]
+    return protos
+
+
+def test_ctypes_signatures_match_the_header():
+    """Every prototype _native.py declares to ctypes has the header's parameter count, pointers where
+    the header has pointers and C ints where it has ints: an ABI drift (an argument added on one side
+    only) would otherwise show up as garbage pointers on the device."""
+    L = _native.lib()
+    protos = _declared_prototypes()
+    checked = 0
+    for name, params in protos.items():
+        fn = getattr(L, name)
+        if fn.argtypes is None:
+            continue                      # not bound with a signature (e.g. debug hooks)
+        assert len(fn.argtypes) == len(params), "%s: ctypes has %d arguments, the header %d" % (
+            name, len(fn.argtypes), len(params))
+        for i, (ct, decl) in enumerate(zip(fn.argtypes, params)):
+            what = "%s argument %d (%s)" % (name, i, decl)
+            if "*" in decl:
+                assert ct is ctypes.c_void_p, what
+            elif decl.startswith("size_t"):
+                assert ct is ctypes.c_size_t, what
+            elif decl.startswith("float"):
+                assert ct is ctypes.c_float, what
+            elif decl.startswith("int") or decl.startswith("unsigned"):
+                assert ct in (ctypes.c_int, ctypes.c_uint), what
+        checked += 1
+    assert checked >= 25
+
+
 def test_abi_argument_validation_without_gpu():
     L = _native.lib()
     # bad sizes are rejected before anything touches a device
