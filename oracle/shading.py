@@ -121,9 +121,17 @@ def rasterize(world_vertices, attributes, triangles, camera_matrices, width, hei
 def render(vertices, triangles, normals, diffuse_colors, camera_position, camera_lookat,
            camera_up, light_positions, light_intensities, width, height,
            specular_colors=None, shininess_coefficients=None, ambient_color=None,
-           fov_y=40.0, near_clip=0.01, far_clip=10.0, use_reference_kernel=False, clip_bits=None):
+           fov_y=40.0, near_clip=0.01, far_clip=10.0, use_reference_kernel=False, clip_bits=None,
+           power_inside_mask_only=False):
     """Inputs already batched ([B,3] cameras); shininess: None, 0-D tensor or [B,V]; clip_bits: see
-    rasterize()."""
+    rasterize().
+
+    power_inside_mask_only: NOT the reference's arithmetic -- the specular power is evaluated on
+    (base, exponent) = (0, 1) wherever render.py:215's mask is off.  The values are the same (those
+    pixels are zeroed by the mask anyway), but autograd no longer multiplies their zero upstream
+    gradient by pow(0, -1) = inf of the background's exponent -1, which is how the reference comes
+    to return NaN gradients for per-vertex shininess.  This is the semantics the HIP kernels define
+    at those entries (shade_spec.hip); the tests compare them with it there."""
     batch = vertices.shape[0]
     pieces = [normals, vertices, diffuse_colors]
     per_vertex_shine = False
@@ -163,7 +171,12 @@ def render(vertices, triangles, normals, diffuse_colors, camera_position, camera
         rv = torch.clamp(torch.nn.functional.normalize(rv, p=2, dim=2), 0.0, 1.0)  # over pixels
         rv = torch.where(ndl != 0.0, rv, torch.zeros_like(rv))
         rv = rv.reshape(batch, -1, height, width)
-        spec = torch.pow(rv, shine.unsqueeze(1)).reshape(batch, -1, P, 1)
+        exponent = shine.unsqueeze(1)
+        if power_inside_mask_only:
+            inside = mask.reshape(batch, 1, height, width) > 0.5
+            rv = torch.where(inside, rv, torch.zeros_like(rv))
+            exponent = torch.where(inside, exponent.expand_as(rv), torch.ones_like(rv))
+        spec = torch.pow(rv, exponent).reshape(batch, -1, P, 1)
         rgb = rgb + (ks.unsqueeze(1) * spec * light_intensities.unsqueeze(2)).sum(1)
     rgb = rgb.reshape(batch, height, width, 3)
     alpha = mask.reshape(batch, height, width, 1)
