@@ -446,6 +446,15 @@ struct F3 {
 };
 // A 12-byte element of a plane that is streamed once and never reused: nontemporal (the streaming
 // kernels of this package ran 1-5 % faster with it, same-box A/Bs).
+__device__ __forceinline__ float4 load_streamed(const float4 *p) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const v4f v = __builtin_nontemporal_load((const v4f *)p);
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void store_streamed(float4 *p, const float4 v) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  __builtin_nontemporal_store(v4f{v.x, v.y, v.z, v.w}, (v4f *)p);
+}
 __device__ __forceinline__ F3 load_streamed(const F3 *p) {
   F3 v;
   v.x = __builtin_nontemporal_load(&p->x);

@@ -35,6 +35,10 @@
 // fp32 with FMA contraction and 1-ulp v_rcp / v_sqrt / v_exp / v_log: parity budget 1e-4.
 #include "corner_rec.h"
 
+#ifndef MR_SPEC_NT
+#define MR_SPEC_NT 1  // nontemporal access to the streamed planes
+#endif
+
 namespace mr {
 namespace {
 
@@ -244,8 +248,8 @@ __global__ __launch_bounds__(kThreads) void k_spec_pixels(
   for (int l = 0; l < L; ++l) part[l] = 0.0f;
   if (x < W) {
     const size_t pix = ((size_t)img * H + y) * W + x;
-    const F3 b = bary[pix];
-    int t = ids[pix];
+    const F3 b = MR_SPEC_NT ? load_streamed(&bary[pix]) : bary[pix];
+    int t = MR_SPEC_NT ? __builtin_nontemporal_load(&ids[pix]) : ids[pix];
     float at[A], pre = 0.0f, alpha = 0.0f;
     const bool live = ((2.0f * b.x + 2.0f * b.y) + 2.0f * b.z) > 0.0f && (unsigned)t < (unsigned)T;
     if (live) {
@@ -264,7 +268,7 @@ __global__ __launch_bounds__(kThreads) void k_spec_pixels(
       float rgb[3] = {sc.amb[0] * at[6], sc.amb[1] * at[7], sc.amb[2] * at[8]};
       float g[3] = {0.f, 0.f, 0.f};
       if (PASS == kGsum) {
-        const float4 gg = drgba[out_pix];
+        const float4 gg = MR_SPEC_NT ? load_streamed(&drgba[out_pix]) : drgba[out_pix];
         g[0] = gg.x; g[1] = gg.y; g[2] = gg.z;
       }
 #pragma unroll
@@ -285,9 +289,13 @@ __global__ __launch_bounds__(kThreads) void k_spec_pixels(
           }
         }
       }
-      if (PASS == kShade) rgba_out[out_pix] = make_float4(rgb[0], rgb[1], rgb[2], 1.0f);
+      if (PASS == kShade) {
+        if (MR_SPEC_NT) store_streamed(&rgba_out[out_pix], make_float4(rgb[0], rgb[1], rgb[2], 1.0f));
+        else rgba_out[out_pix] = make_float4(rgb[0], rgb[1], rgb[2], 1.0f);
+      }
     } else if (PASS == kShade) {
-      rgba_out[out_pix] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (MR_SPEC_NT) store_streamed(&rgba_out[out_pix], make_float4(0.f, 0.f, 0.f, 0.f));
+      else rgba_out[out_pix] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
   if (PASS != kShade) {  // workgroup-uniform
@@ -369,9 +377,10 @@ struct SpecGradFn {
   }
 
   __device__ __forceinline__ void fetch(int img, int x, int y, size_t pix, Raw &r) const {
-    r.b = bary[pix];
-    r.t = ids[pix];
-    r.g = drgba[((size_t)img * H + (H - 1 - y)) * W + x];  // un-flip
+    r.b = MR_SPEC_NT ? load_streamed(&bary[pix]) : bary[pix];
+    r.t = MR_SPEC_NT ? __builtin_nontemporal_load(&ids[pix]) : ids[pix];
+    const float4 *gp = &drgba[((size_t)img * H + (H - 1 - y)) * W + x];  // un-flip
+    r.g = MR_SPEC_NT ? load_streamed(gp) : *gp;
   }
   __device__ __forceinline__ bool prepare(const Raw &r, int T, int &tri, Pixel &p) const {
     const float pre = (2.0f * r.b.x + 2.0f * r.b.y) + 2.0f * r.b.z;
