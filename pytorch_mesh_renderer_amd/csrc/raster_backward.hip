@@ -38,8 +38,14 @@ __global__ __launch_bounds__(256) void k_bwd_setup(
     float *__restrict__ zero_tail, int zero_tail_count) {
   const long gid = (long)blockIdx.x * 256 + threadIdx.x;
   for (long i = gid; i < zero_tail_count; i += (long)gridDim.x * 256) zero_tail[i] = 0.0f;
+  {  // the workgroup's 256 rows are one contiguous range: cleared with coalesced 16-byte stores
+    const long first = (long)blockIdx.x * 256 * zero_row_quads, end = (long)B * T * zero_row_quads;
+    for (int q = 0; q < zero_row_quads; ++q) {
+      const long i = first + (long)q * 256 + threadIdx.x;
+      if (i < end) zero_rows[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
   if (gid >= (long)B * T) return;
-  for (int q = 0; q < zero_row_quads; ++q) zero_rows[gid * zero_row_quads + q] = make_float4(0.f, 0.f, 0.f, 0.f);
   const int b = (int)(gid / T);
   const int t = (int)(gid - (long)b * T);
   const int i0 = tris[3 * t], i1 = tris[3 * t + 1], i2 = tris[3 * t + 2];
