@@ -123,6 +123,11 @@ def make_step(job, device, gather, handover="u8"):
     up = torch.tensor([0.0, 1.0, 0.0])
     lpos, lint = job["light_positions"].to(device), job["light_intensities"].to(device)
     transform = mesh_renderer.to_uint8 if handover == "u8" else None
+    if gather is not None and handover == "u8":
+        # every frame is handed over: let the forward kernel write the 8-bit frames itself (4 B/px)
+        # instead of converting the float image in a pass of its own on the side stream
+        from pytorch_mesh_renderer_amd.mesh_renderer import rasterize_triangles_ext
+        rasterize_triangles_ext.EMIT_UINT8_FRAMES = True
 
     def forward():
         return mesh_renderer.render(vertices, tri, normals, diffuse, eyes, center, up, lpos, lint,

@@ -169,6 +169,10 @@ int mr_vertex_transform(const float *vertices, const float *transforms, int B, i
  *   clip            [B,V,4] f32 out  transforms[b] . (vertices[b,v], 1), evaluated per row as
  *                   ((m0 x + m1 y) + m2 z) + m3 without contraction; 16-byte aligned.  The
  *                   backward entry points take it as their `clip` argument.
+ *   rgba_u8         NULL, or [B,H,W,4] u8 out (4-byte aligned): the same image as 8-bit frames, exactly
+ *                   what mr_export_u8 would make of `rgba` -- for callers that hand frames over or
+ *                   write them to files and would otherwise read the float image back (4 B/px of
+ *                   stores instead of a 20 B/px pass)
  *   z, want_z       z is always a [B,H,W] buffer; with want_z == 0 the caller declares that it will
  *                   not read it (render() does not): the depth plane is then written only where a
  *                   crowded region needs it as state between its bin rounds, 4 B/px of stores less,
@@ -181,7 +185,8 @@ int mr_render_forward(const float *vertices, const float *transforms, const floa
                       const float *light_positions, const float *light_intensities,
                       const float *ambient, int B, int V, int T, int W, int H, int L,
                       float *clip, int32_t *ids, float *bary, float *z, int want_z, float *rgba,
-                      void *corner_records, void *workspace, size_t workspace_bytes, void *stream);
+                      uint8_t *rgba_u8, void *corner_records, void *workspace, size_t workspace_bytes,
+                      void *stream);
 
 /* Backward of mr_shade_forward AND of the rasterizer underneath it, in one pass
  * over the G-buffer (reads 32 B/px).  All outputs are zeroed here.

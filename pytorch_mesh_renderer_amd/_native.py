@@ -16,7 +16,7 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 # build libmesh_raster_hip_probes.so this way); the product always loads the in-tree library.
 LIB_PATH = os.environ.get("MR_NATIVE_LIB_PATH") or os.path.join(_CSRC, "libmesh_raster_hip.so")
 
-ABI_VERSION = 330
+ABI_VERSION = 331
 TIMER_RASTER_FORWARD, TIMER_SHADE_BACKWARD, TIMER_SHADE_FORWARD, TIMER_RASTER_BACKWARD = 0, 1, 2, 3
 MR_OK, MR_EINVAL, MR_EWORKSPACE, MR_ELAUNCH = 0, -1, -2, -3
 _ERR = {MR_EINVAL: "invalid argument", MR_EWORKSPACE: "workspace too small or misaligned",
@@ -150,7 +150,7 @@ def lib():
         L.mr_interpolate_raster_backward.restype = ci
         L.mr_vertex_transform.argtypes = [vp, vp, ci, ci, vp, vp]
         L.mr_vertex_transform.restype = ci
-        L.mr_render_forward.argtypes = [vp] * 8 + [ci] * 6 + [vp, vp, vp, vp, ci] + [vp] * 3 + [sz, vp]
+        L.mr_render_forward.argtypes = [vp] * 8 + [ci] * 6 + [vp, vp, vp, vp, ci] + [vp] * 4 + [sz, vp]
         L.mr_render_forward.restype = ci
         L.mr_shade_specular_forward_workspace_bytes.argtypes = [ci] * 5
         L.mr_shade_specular_forward_workspace_bytes.restype = sz
@@ -431,11 +431,12 @@ def vertex_transform(vertices, transforms):
 
 
 def render_forward(vertices, transforms, normals, diffuse, triangles, light_positions, light_intensities,
-                   ambient, width, height, want_z=True):
+                   ambient, width, height, want_z=True, want_u8=False):
     """render()'s forward from world-space vertices: clip-space transform, rasterizer and shading
     (the shading is the epilogue of the rasterizer's tile walk: one pass over the pixels)
     -> (clip, ids, bary, z, rgba, corner_records); with want_z=False the depth plane is not written
-    (z is returned as None)."""
+    (z is returned as None); with want_u8=True a seventh value follows, the image as [B,H,W,4] uint8
+    frames (what export_u8(rgba) would return)."""
     tensors = [vertices, transforms, normals, diffuse, triangles, light_positions, light_intensities]
     _chk("vertices", vertices, _F32, None, None, 3)
     _chk("triangles", triangles, _I32, None, 3)
@@ -455,6 +456,7 @@ def render_forward(vertices, transforms, normals, diffuse, triangles, light_posi
     bary = torch.empty(B, height, width, 3, dtype=torch.float32, device=dev)
     z = torch.empty(B, height, width, dtype=torch.float32, device=dev)
     rgba = torch.empty(B, height, width, 4, dtype=torch.float32, device=dev)
+    frames = torch.empty(B, height, width, 4, dtype=torch.uint8, device=dev) if want_u8 else None
     with torch.cuda.device(dev):
         records = _aligned_bytes(L.mr_shade_forward_workspace_bytes(B, V, T, width, height), dev)
         need = L.mr_rasterize_forward_workspace_bytes(B, V, T, width, height)
@@ -463,8 +465,10 @@ def render_forward(vertices, transforms, normals, diffuse, triangles, light_posi
         rc = L.mr_render_forward(_ptr(vertices), _ptr(transforms), _ptr(normals), _ptr(diffuse), _ptr(triangles),
                                  _ptr(light_positions), _ptr(light_intensities), _ptr(ambient), B, V, T,
                                  width, height, nl, _ptr(clip), _ptr(ids), _ptr(bary), _ptr(z), int(bool(want_z)),
-                                 _ptr(rgba), _ptr(records), _ptr(ws), have, _stream(dev))
+                                 _ptr(rgba), _ptr(frames), _ptr(records), _ptr(ws), have, _stream(dev))
     _check(rc, "mr_render_forward")
+    if want_u8:
+        return clip, ids, bary, (z if want_z else None), rgba, records, frames
     return clip, ids, bary, (z if want_z else None), rgba, records
 
 

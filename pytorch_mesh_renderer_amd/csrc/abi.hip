@@ -30,7 +30,7 @@ extern thread_local int g_deterministic;
 
 extern "C" {
 
-int mr_version(void) { return 330; /* 0.3.1: deterministic mode, tone map, vertex normals, sign-coded shading backward */ }
+int mr_version(void) { return 331; /* 0.3.1: deterministic mode, tone map, vertex normals, sign-coded shading backward */ }
 
 int mr_last_hip_error(void) { return mr::g_last_hip_error; }
 
@@ -220,20 +220,21 @@ int mr_render_forward(const float *vertices, const float *transforms, const floa
                       const float *diffuse, const int32_t *triangles, const float *light_positions,
                       const float *light_intensities, const float *ambient, int B, int V, int T, int W,
                       int H, int L, float *clip, int32_t *ids, float *bary, float *z, int want_z,
-                      float *rgba, void *corner_records, void *workspace, size_t workspace_bytes,
-                      void *stream) {
+                      float *rgba, uint8_t *rgba_u8, void *corner_records, void *workspace,
+                      size_t workspace_bytes, void *stream) {
   if (bad_dims(B, V, T, W, H) || T < 1 || V < 1 || L < 1 || L > mr::shade_max_lights())
     return MR_EINVAL;
   if (B == 0) return MR_OK;
   if (!vertices || !transforms || !normals || !diffuse || !triangles || !light_positions ||
       !light_intensities || !clip || !ids || !bary || !z || !rgba || !corner_records ||
-      ((uintptr_t)corner_records & 127u) || ((uintptr_t)clip & 15u) || ((uintptr_t)transforms & 15u))
+      ((uintptr_t)corner_records & 127u) || ((uintptr_t)clip & 15u) || ((uintptr_t)transforms & 15u) ||
+      ((uintptr_t)rgba_u8 & 3u))
     return MR_EINVAL;
   const int rc = check_ws(workspace, workspace_bytes, mr::raster_forward_ws(B, V, T, W, H));
   if (rc != MR_OK) return rc;
   return mr::launch_render_forward(vertices, transforms, normals, diffuse, triangles, light_positions,
                                    light_intensities, ambient, B, V, T, W, H, L, clip, ids, bary, z,
-                                   want_z, rgba, corner_records, workspace, (hipStream_t)stream);
+                                   want_z, rgba, rgba_u8, corner_records, workspace, (hipStream_t)stream);
 }
 
 size_t mr_shade_forward_workspace_bytes(int B, int V, int T, int W, int H) {

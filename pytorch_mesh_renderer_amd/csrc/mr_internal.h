@@ -143,7 +143,7 @@ int launch_render_forward(const float *vertices, const float *transforms, const 
                           const float *diffuse, const int32_t *tris, const float *light_pos,
                           const float *light_col, const float *ambient, int B, int V, int T, int W, int H,
                           int L, float *clip, int32_t *ids, float *bary, float *z, int want_z, float *rgba,
-                          void *corner_records, void *ws, hipStream_t s);
+                          uint8_t *rgba_u8, void *corner_records, void *ws, hipStream_t s);
 size_t shade_specular_forward_ws(int B, int V, int T, int W, int H);
 int launch_shade_specular_forward(const int32_t *ids, const float *bary, const float *normals,
                                   const float *positions, const float *diffuse, const float *specular,

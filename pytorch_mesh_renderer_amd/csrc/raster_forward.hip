@@ -393,6 +393,8 @@ struct RasterShade {
   const CornerRec *__restrict__ corners;  // [B*T] (k_corner_setup)
   Lights lights;
   float *__restrict__ rgba;               // [B,H,W,4], image rows (row 0 = top)
+  uint32_t *__restrict__ rgba8;           // nullptr, or [B,H,W] 8-bit RGBA frames of the same image (the
+                                          // examples' `(image * 255.0).astype(np.uint8)`, loss.hip's to_u8)
   int keep_z;                             // 0: the caller does not want the depth plane -- it is then only
                                           // written between the bin rounds of a crowded region (as state)
 };
@@ -768,6 +770,12 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : MR_RASTER
           const int tile_rgba = ((R - kTileH - ty * kTileH) * W + tx * kTileW) * 16;
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v4f{rgba.x, rgba.y, rgba.z, rgba.w}), rs_rgba,
                                                  lane_rgba, tile_rgba, MR_RASTER_STORE_AUX);
+          if (shade.rgba8) {  // workgroup-uniform: the 8-bit frame for the multi-GPU hand-over, 4 B/px
+            auto u8 = [](float v) { return (unsigned)(fminf(fmaxf(v, 0.0f), 1.0f) * 255.0f); };  // NaN -> 0
+            const unsigned packed = u8(rgba.x) | (u8(rgba.y) << 8) | (u8(rgba.z) << 16) | (u8(rgba.w) << 24);
+            const int y = Y0 + ty * kTileH + ly, x = X0 + tx * kTileW + lx;
+            __builtin_nontemporal_store(packed, &shade.rgba8[img_px + (size_t)(H - 1 - y) * W + x]);
+          }
         }
       }
       if (in_image && !((PROBE & 32) && st.z != 123.0f)) {  // 32: timing probe, no stores
@@ -1071,7 +1079,7 @@ int raster_forward(const float *clip, const int32_t *tris, int B, int V, int T, 
 int launch_raster_forward(const float *clip, const int32_t *tris, int B, int V, int T, int W,
                           int H, int32_t *ids, float *bary, float *z, void *ws, hipStream_t s) {
   return raster_forward(clip, tris, B, V, T, W, H, ids, bary, z,
-                        RasterShade{nullptr, Lights{nullptr, nullptr, nullptr, 0}, nullptr, 1},
+                        RasterShade{nullptr, Lights{nullptr, nullptr, nullptr, 0}, nullptr, nullptr, 1},
                         SetupAttributes{nullptr, nullptr, nullptr, nullptr}, ws, s);
 }
 
@@ -1092,13 +1100,13 @@ int launch_render_forward(const float *vertices, const float *transforms, const 
                           const float *diffuse, const int32_t *tris, const float *light_pos,
                           const float *light_col, const float *ambient, int B, int V, int T, int W, int H,
                           int L, float *clip, int32_t *ids, float *bary, float *z, int want_z, float *rgba,
-                          void *corner_records, void *ws, hipStream_t s) {
+                          uint8_t *rgba_u8, void *corner_records, void *ws, hipStream_t s) {
   const int rc = launch_vertex_transform(vertices, transforms, B, V, clip, s);
   if (rc != MR_OK) return rc;
   if ((size_t)B * W * H == 0) return MR_OK;
   CornerRec *corners = (CornerRec *)corner_records;
   return raster_forward(clip, tris, B, V, T, W, H, ids, bary, z,
-                        RasterShade{corners, Lights{light_pos, light_col, ambient, L}, rgba, want_z},
+                        RasterShade{corners, Lights{light_pos, light_col, ambient, L}, rgba, (uint32_t *)rgba_u8, want_z},
                         SetupAttributes{(const F3 *)normals, (const F3 *)vertices, (const F3 *)diffuse, corners}, ws,
                         s);
 }

@@ -108,11 +108,12 @@ class ImageGather:
             self._side.wait_stream(torch.cuda.current_stream(local.device))
         ctx = torch.cuda.stream(self._side) if on_gpu else _NullContext()
         with ctx:
-            send = local.detach()
             if transform is not None:
                 if on_gpu:
-                    send.record_stream(self._side)   # read by the side stream: keep it alive for it
-                send = transform(send)
+                    local.record_stream(self._side)   # read by the side stream: keep it alive for it
+                send = transform(local).detach()     # (the tensor itself: it may carry ready-made frames)
+            else:
+                send = local.detach()
             if send.shape[0] != max_count:
                 pad = torch.zeros((max_count - send.shape[0],) + tuple(send.shape[1:]),
                                   dtype=send.dtype, device=send.device)

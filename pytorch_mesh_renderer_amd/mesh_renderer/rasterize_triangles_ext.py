@@ -110,6 +110,11 @@ class FusedAttributeRasterizer(torch.autograd.Function):
 # FusedPhongRenderer's forward: True = one pass over the pixels (mr_render_forward: the shading is the
 # epilogue of the rasterizer's tile walk); False = k_raster, then k_shade_forward over the G-buffer.
 USE_SHADING_EPILOGUE = os.environ.get("MR_SHADING_EPILOGUE", "1") != "0"
+# True: the one-pass forward also writes the image as 8-bit frames (4 B/px of stores) and render()
+# attaches them to the image it returns; mesh_renderer.to_uint8(image) then hands them out instead
+# of converting the float image in a pass of its own.  For callers that export every frame (the
+# multi-GPU hand-over of bench.py).
+EMIT_UINT8_FRAMES = os.environ.get("MR_EMIT_UINT8_FRAMES", "0") != "0"
 
 
 class FusedPhongRenderer(torch.autograd.Function):
@@ -130,7 +135,12 @@ class FusedPhongRenderer(torch.autograd.Function):
         args = [t.detach().contiguous() for t in (normals, diffuse)]
         lp, li = light_positions.detach().contiguous(), light_intensities.detach().contiguous()
         amb = ambient.detach().contiguous() if ambient is not None else None
-        if USE_SHADING_EPILOGUE:
+        frames = None
+        if USE_SHADING_EPILOGUE and EMIT_UINT8_FRAMES:
+            clip, ids, bary, _, rgba, corner_records, frames = _native.render_forward(
+                verts, xf, args[0], args[1], triangles, lp, li, amb, int(image_width), int(image_height),
+                want_z=False, want_u8=True)
+        elif USE_SHADING_EPILOGUE:
             clip, ids, bary, _, rgba, corner_records = _native.render_forward(
                 verts, xf, args[0], args[1], triangles, lp, li, amb, int(image_width), int(image_height),
                 want_z=False)
@@ -147,7 +157,9 @@ class FusedPhongRenderer(torch.autograd.Function):
             saved.append(amb)
         ctx.save_for_backward(*saved)
         ctx.has_ambient = amb is not None
-        return rgba
+        if frames is not None:
+            ctx.mark_non_differentiable(frames)
+        return rgba, frames
 
     @staticmethod
     def _input_grads(saved, needs_transform_grad, upstream, l1_signs=None):
@@ -166,7 +178,7 @@ class FusedPhongRenderer(torch.autograd.Function):
         return dverts, dxf, dn, dd, None, dlp, dli, damb
 
     @staticmethod
-    def backward(ctx, drgba):
+    def backward(ctx, drgba, _dframes=None):
         grads = FusedPhongRenderer._input_grads(ctx.saved_tensors, ctx.needs_input_grad[1], drgba.contiguous())
         return grads + (None, None)
 

@@ -190,8 +190,10 @@ def _render_fused(vertices, triangles, normals, diffuse_colors, camera_position,
     lp, li = light_positions.to(device), light_intensities.to(device).to(torch.float32)
     amb = ambient_color.to(device) if ambient_color is not None else None
     transforms = clip_space_transforms.to(torch.float32)
-    image = FusedPhongRenderer.apply(vertices, transforms, normals, diffuse_colors, triangles, lp, li, amb,
-                                     image_width, image_height)
+    image, frames = FusedPhongRenderer.apply(vertices, transforms, normals, diffuse_colors, triangles, lp, li,
+                                             amb, image_width, image_height)
+    if frames is not None:  # rasterize_triangles_ext.EMIT_UINT8_FRAMES: see to_uint8
+        image._mr_frames_u8 = (frames, image._version)
     if image.grad_fn is not None:
         # lets losses.l1_loss differentiate straight to these inputs (FusedPhongL1Loss); the node
         # is compared by identity there, so a tensor derived from `image` never takes that path
@@ -285,4 +287,7 @@ def to_uint8(image):
     from .. import _native
     if image.dtype != torch.float32:
         raise ValueError("to_uint8 expects a float32 image")
+    ready = getattr(image, "_mr_frames_u8", None)   # written by render()'s forward kernel, if asked to
+    if ready is not None and ready[1] == image._version and ready[0].shape == image.shape:
+        return ready[0]
     return _native.export_u8(image.detach())

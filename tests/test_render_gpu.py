@@ -478,6 +478,40 @@ def test_fused_specular_shininess_gradient_matches_composed_path(device, kind):
         np.testing.assert_allclose(grads_f[k], grads_c[k], atol=ATOL, rtol=0, err_msg=k)
 
 
+def test_render_emits_uint8_frames_on_request(device):
+    """rasterize_triangles_ext.EMIT_UINT8_FRAMES: the forward kernel also writes the 8-bit frames;
+    to_uint8(image) hands them out (no conversion pass) and they equal mr_export_u8 of the float image;
+    an image modified in place falls back to the conversion."""
+    import importlib
+    ext = importlib.import_module("pytorch_mesh_renderer_amd.mesh_renderer.rasterize_triangles_ext")
+    job = synthetic.sphere_job(2, 130, 67, 10)
+    d = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in job.items()}
+    def render():
+        return mesh_renderer.render(d["vertices"].clone().requires_grad_(True), d["triangles"], d["normals"],
+                                    torch.rand(d["vertices"].shape, generator=torch.Generator().manual_seed(1)).to(device) * 1.5,
+                                    job["eyes"], torch.zeros(2, 3), torch.tensor([0.0, 1.0, 0.0]),
+                                    d["light_positions"], d["light_intensities"] * 1.3, 130, 67)
+    plain = render()
+    ext.EMIT_UINT8_FRAMES = True
+    try:
+        image = render()
+        with _CountCalls("export_u8") as counter:
+            frames = mesh_renderer.to_uint8(image)
+        assert counter.calls == 0 and frames.dtype == torch.uint8 and frames.shape == image.shape
+        assert torch.equal(image.detach(), plain.detach())
+        from pytorch_mesh_renderer_amd import _native
+        assert torch.equal(frames, _native.export_u8(image.detach()))
+        assert int(frames[..., :3].max()) == 255                  # over-exposed pixels saturate
+        torch.mean(image).backward()                             # the extra output does not disturb autograd
+        with torch.no_grad():
+            image.mul_(0.5)
+        with _CountCalls("export_u8") as counter:
+            again = mesh_renderer.to_uint8(image)
+        assert counter.calls == 1 and torch.equal(again, _native.export_u8(image.detach()))
+    finally:
+        ext.EMIT_UINT8_FRAMES = False
+
+
 def test_render_with_and_without_shading_epilogue(device):
     """render() + L1 loss + backward with FusedPhongRenderer's one-pass forward (mr_render_forward) and with
     its two-kernel forward (torch clip transform, k_raster, k_shade_forward): same image, same gradients --
