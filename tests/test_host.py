@@ -250,6 +250,14 @@ def test_native_wrappers_validate_dtypes_and_shapes_before_anything_reaches_the_
         (_native.soft_forward, (clip, p, n, kd, tris, lp, f(B, L + 1), W, H, 1e-4, 1e-2, 0.01), ValueError, "light_intensities"),
         (_native.l1_loss_forward, (rgba, rgba.double()), RuntimeError, "float32"),
         (_native.l1_loss_forward, (rgba, f(B, H, W, 3)), ValueError, "shape"),
+        # render()'s one-pass forward: world vertices + clip-space transforms
+        (_native.render_forward, (p, f(B, 4, 4), n, kd, tris.long(), lp, li, None, W, H), RuntimeError, "int32"),
+        (_native.render_forward, (p, f(B, 4, 4).double(), n, kd, tris, lp, li, None, W, H), RuntimeError, "float32"),
+        (_native.render_forward, (p, f(B + 1, 4, 4), n, kd, tris, lp, li, None, W, H), ValueError, "transforms"),
+        (_native.render_forward, (p, f(B, 4, 4), f(B, V + 2, 3), kd, tris, lp, li, None, W, H), ValueError, "normals"),
+        (_native.vertex_transform, (p, f(B, 3, 4)), ValueError, "transforms"),
+        (_native.shade_backward, (rgba, ids, bary, clip, n, p, kd, tris, lp, li, None, None, None, None, f(B, 4, 4)),
+         ValueError, "adjacency"),
     ]
     for fn, args, exc, word in cases:
         with pytest.raises(exc, match=word):
