@@ -2,11 +2,17 @@
 //
 // Replaces rasterize_triangles_forward
 // (reference: src/mesh_renderer/kernels/rasterize_triangles.cpp:302-419 and its
-// helpers :19-98) with three kernels on one stream:
+// helpers :19-98) with three kernels on one stream -- and, as mr_render_forward, the whole
+// forward of render() (src/mesh_renderer/render.py:183-228): a clip-space transform in front
+// (k_vertex_transform) and the Phong shading as the epilogue of k_raster's tile walk
+// (template parameter SHADE, see RasterShade):
 //
 //   k_setup   one thread per (image, triangle): sign-corrected adjugate, clip z/w,
 //             pixel bbox (binary64 projection as in cpp:361-366), packed into a
-//             64-byte record; plus the binary64 pixel-centre tables (cpp:376-377).
+//             64-byte record; plus the binary64 pixel-centre tables (cpp:376-377);
+//             for mr_render_forward also the shading's corner record (corner_rec.h).
+//   k_coarse  one workgroup per (image, 256x256-pixel cell): id-ordered list of the
+//             triangles whose bbox touches the cell, and the cell's depth split.
 //   k_raster  one 256-thread workgroup per 64x64-pixel region (32x32 for small launches), two stages:
 //     bin    each wavefront scans a quarter of the image's triangle list (no barrier
 //            in the loop): bbox-vs-region test, then an EXACT trivial reject -- the

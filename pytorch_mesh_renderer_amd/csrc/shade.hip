@@ -13,17 +13,23 @@
 // 1024^2 x 32); here the forward reads 16 B/px (id + barycentrics) and writes 16 B/px
 // (RGBA), and the backward reads 32 B/px (dRGBA + id + barycentrics).
 //
-//   k_shade_forward    one thread per pixel; vertex attributes are gathered from the
-//                      L2-resident [B,V,3] arrays (no concatenated attribute tensor).
-//   ShadeGradFn        per-pixel backward evaluated inside k_accumulate_runs
-//                      (run_accum.h): recomputes the pixel's shading, back-propagates
-//                      to the interpolated normal / position / diffuse colour, to the
-//                      barycentrics and -- through rasterize_triangles.cpp:202-269 -- to
-//                      the clip-space corners; 36 sums per triangle (27 attribute + 9
-//                      clip) ride the column runs, light / ambient gradients are
-//                      per-lane sums reduced once per wave.
-//   k_shade_scatter    one thread per touched (image, triangle): atomics into
-//                      dnormals / dpositions / ddiffuse [B,V,3] and dclip [B,V,4].
+//   k_shade_forward    one thread per pixel; the triangle's corner attributes come from one
+//                      128-byte record per (image, triangle) (corner_rec.h).  render() itself
+//                      no longer launches it: the same shading (shade_pixel.h) runs as the
+//                      epilogue of k_raster's tile walk (raster_forward.hip, mr_render_forward).
+//   ShadeGradFn        per-pixel backward evaluated inside k_accumulate_rows (run_accum.h):
+//                      recomputes the pixel's shading, back-propagates to the interpolated
+//                      normal / position / diffuse colour, to the barycentrics and -- through
+//                      rasterize_triangles.cpp:202-269 -- to the clip-space corners; the 36
+//                      sums per triangle (27 attribute + 9 clip) are products of 15 per-pixel
+//                      factors formed in the row reduction, light / ambient gradients are
+//                      per-lane sums reduced once per wave.  The upstream gradient is a dense
+//                      image or, for the L1 loss, its 1 B/px sign codes.
+//   k_shade_gather     sixteen lanes per (image, vertex): sums the rows of the incident
+//                      triangles over the CSR adjacency (no atomics) and, given the clip-space
+//                      transforms, pulls d clip back onto the world-space vertices.
+//   k_shade_scatter    without an adjacency: one thread per touched (image, triangle),
+//                      atomics into dnormals / dpositions / ddiffuse [B,V,3] and dclip [B,V,4].
 #include "shade_pixel.h"
 
 namespace mr {
