@@ -405,6 +405,9 @@ struct RasterShade {
                                           // written between the bin rounds of a crowded region (as state)
 };
 
+#ifndef MR_EPI_LDS_LIGHTS
+#define MR_EPI_LDS_LIGHTS 1
+#endif
 #ifndef MR_RASTER_STORE_AUX
 #define MR_RASTER_STORE_AUX 2  // cache policy of the G-buffer / RGBA stores: 2 = nontemporal (written once, read by a
                                 // later kernel from HBM anyway): kernel -5 %, step -2 % against 0 (same-box A/B)
@@ -545,8 +548,18 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : MR_RASTER
       SHADE ? shade.rgba + 4 * ((ptrdiff_t)img_px + ((ptrdiff_t)H - R - Y0) * W + X0) : nullptr, 0, 0x7fffffff,
       kRsrcWord3);
   const CornerRec *img_corners = SHADE ? shade.corners + (size_t)img * T : nullptr;
+#if MR_EPI_LDS_LIGHTS
+  const float *s_lights_ptr = nullptr;
+  if constexpr (SHADE) {  // (no LDS at all in the G-buffer-only instantiation: its 23040 B are exactly 18 granules)
+    __shared__ float s_lights[32];
+    LightsInLds::stage(shade.lights, img, s_lights, tid);  // (the bin stage's barriers come before any use)
+    s_lights_ptr = s_lights;
+  }
+  const LightsInLds lights{s_lights_ptr, shade.lights.L, shade.lights.amb != nullptr};
+#else
   LightsInRegisters lights;
   if (SHADE) lights.load(shade.lights, img);
+#endif
   typedef float v3f __attribute__((ext_vector_type(3)));
   typedef unsigned v3u __attribute__((ext_vector_type(3)));
   // Every wavefront of this kernel is fully populated (256-thread workgroups, padding workgroups

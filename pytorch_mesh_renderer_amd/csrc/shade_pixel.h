@@ -79,6 +79,30 @@ struct LightsInRegisters {
   __device__ __forceinline__ float color(int i, int k) const { return col[i][k]; }
 };
 
+// Staged once per workgroup in LDS ([0..2] ambient, then per light 3 position + 3 colour floats) and
+// read per tile with wave-uniform (broadcast) ds_reads: no scalar registers held across the tile
+// walk (they were spilled to VGPR lanes and read back with v_readlane), no per-tile memory latency.
+struct LightsInLds {
+  const float *s;  // LDS
+  int n;
+  bool amb_on;
+  static constexpr int kFloats = 3 + 6 * kMaxLights;
+  // all threads of the workgroup call this; the caller provides the barrier before the first use
+  __device__ __forceinline__ static void stage(const Lights &l, int img, float *lds, int tid) {
+    if (tid < 3) lds[tid] = l.amb ? ((ConstFloats)(uintptr_t)l.amb)[(size_t)img * 3 + tid] : 0.0f;
+    if (tid >= 3 && tid < 3 + 6 * l.L) {
+      const int i = (tid - 3) / 6, k = (tid - 3) % 6;
+      const float *src = k < 3 ? l.pos : l.col;
+      lds[tid] = ((ConstFloats)(uintptr_t)src)[((size_t)img * l.L + i) * 3 + (k % 3)];
+    }
+  }
+  __device__ __forceinline__ int count() const { return n; }
+  __device__ __forceinline__ bool has_ambient() const { return amb_on; }
+  __device__ __forceinline__ float ambient(int k) const { return s[k]; }
+  __device__ __forceinline__ float position(int i, int k) const { return s[3 + 6 * i + k]; }
+  __device__ __forceinline__ float color(int i, int k) const { return s[6 + 6 * i + k]; }
+};
+
 // Shading of one covered pixel from its blended attributes `at` (render.py:201-215, 298-323).
 template <class LightSet>
 __device__ __forceinline__ float4 shade_attributes(const float (&at)[9], const LightSet &lights) {
