@@ -478,6 +478,44 @@ def test_fused_specular_shininess_gradient_matches_composed_path(device, kind):
         np.testing.assert_allclose(grads_f[k], grads_c[k], atol=ATOL, rtol=0, err_msg=k)
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_render_forward_on_triangle_soup(device, seed):
+    """mr_render_forward vs mr_rasterize_forward + mr_shade_forward on random triangle soups under random
+    projective transforms: vertices behind the eye (w < 0, the full-screen bbox path), slivers,
+    interpenetrating and repeated triangles, out-of-range vertex indices, negative diffuse colours
+    (render()'s mask), several lights.  G-buffer bit for bit, RGBA within the shading budget."""
+    from pytorch_mesh_renderer_amd import _native
+    gen = torch.Generator().manual_seed(100 + seed)
+    B, V, T, W, H = 3, 70, 160, 97, 61
+    vertices = (torch.rand(B, V, 3, generator=gen) * 2 - 1).to(device)
+    tris = torch.randint(0, V, (T, 3), generator=gen, dtype=torch.int32)
+    tris[5] = tris[4]                    # a repeated triangle: the depth tie goes to the larger id
+    tris[9, 2] = V + 3                   # out of range: never drawn
+    tris[11, 1] = tris[11, 0]            # degenerate
+    tris = tris.to(device)
+    xf = torch.eye(4).repeat(B, 1, 1)
+    xf[:, 3, 2] = torch.rand(B, generator=gen) * 2 - 1           # w = c z + d: some vertices get w < 0
+    xf[:, 3, 3] = torch.rand(B, generator=gen) * 0.8 + 0.2
+    xf[:, :3, 3] = (torch.rand(B, 3, generator=gen) - 0.5) * 0.3
+    xf = xf.to(device)
+    normals = torch.randn(B, V, 3, generator=gen).to(device)
+    diffuse = (torch.rand(B, V, 3, generator=gen) * 1.2 - 0.2).to(device)    # some negative: masked pixels
+    n_lights = 1 + seed % 4
+    lp = (torch.rand(B, n_lights, 3, generator=gen) * 6 - 3).to(device)
+    li = (torch.rand(B, n_lights, 3, generator=gen) + 0.1).to(device)
+    amb = (torch.rand(B, 3, generator=gen) * 0.3).to(device) if seed % 2 else None
+    clip = _native.vertex_transform(vertices, xf)
+    assert int((clip[..., 3] < 0).sum()) > 0
+    ids, bary, z = _native.rasterize_forward(clip, tris, W, H)
+    rgba = _native.shade_forward(ids, bary, normals, vertices, diffuse, tris, lp, li, amb)
+    covered = float((rgba[..., 3] > 0).float().mean())
+    assert covered > 0.05
+    clip2, ids2, bary2, z2, rgba2, _ = _native.render_forward(vertices, xf, normals, diffuse, tris, lp, li, amb, W, H)
+    assert torch.equal(clip2, clip) and torch.equal(ids2, ids) and torch.equal(bary2, bary) and torch.equal(z2, z)
+    assert torch.equal(rgba2[..., 3], rgba[..., 3])
+    np.testing.assert_allclose(rgba2.cpu().numpy(), rgba.cpu().numpy(), atol=2e-6, rtol=1e-6)
+
+
 def test_render_emits_uint8_frames_on_request(device):
     """rasterize_triangles_ext.EMIT_UINT8_FRAMES: the forward kernel also writes the 8-bit frames;
     to_uint8(image) hands them out (no conversion pass) and they equal mr_export_u8 of the float image;
