@@ -516,6 +516,43 @@ def test_render_forward_on_triangle_soup(device, seed):
     np.testing.assert_allclose(rgba2.cpu().numpy(), rgba.cpu().numpy(), atol=2e-6, rtol=1e-6)
 
 
+def test_fused_diffuse_render_matches_composed_path_including_the_camera(device):
+    """render() without a specular term: FusedPhongRenderer (clip transform, rasterizer, shading and their
+    backward inside the library; camera gradient through one batched product) vs the composed path (torch
+    clip transform and Phong over the HIP rasterizer / interpolation, torch autograd): image and the
+    gradients w.r.t. vertices, normals, colours, lights, ambient AND the eye."""
+    render_mod = sys.modules["pytorch_mesh_renderer_amd.mesh_renderer.render"]
+    job = synthetic.sphere_job(2, 112, 84, 12)
+    gen = torch.Generator().manual_seed(9)
+    target = torch.rand(2, 84, 112, 4, generator=gen).to(device)
+    results = {}
+    for fused in (True, False):
+        leaf = lambda t: t.clone().to(device).requires_grad_(True)
+        scene = {"vertices": leaf(job["vertices"]), "normals": leaf(job["normals"]),
+                 "diffuse": leaf(torch.rand(job["vertices"].shape, generator=torch.Generator().manual_seed(4))),
+                 "light_positions": leaf(torch.tensor([[[2.0, 3.0, 4.0], [-3.0, 1.0, 2.5]],
+                                                       [[0.5, -2.0, 3.0], [3.0, 3.0, -1.0]]])),
+                 "light_intensities": leaf(torch.rand(2, 2, 3, generator=torch.Generator().manual_seed(5)) + 0.2),
+                 "ambient": leaf(torch.rand(2, 3, generator=torch.Generator().manual_seed(6)) * 0.3),
+                 "eye": leaf(job["eyes"])}
+        render_mod.USE_FUSED_SHADING = fused
+        try:
+            with _CountCalls("render_forward") as counter:
+                img = mesh_renderer.render(scene["vertices"], job["triangles"].to(device), scene["normals"],
+                                           scene["diffuse"], scene["eye"], torch.zeros(2, 3, device=device),
+                                           torch.tensor([0.0, 1.0, 0.0], device=device), scene["light_positions"],
+                                           scene["light_intensities"], 112, 84, ambient_color=scene["ambient"])
+            (torch.mean(torch.abs(img - target)) * 10.0).backward()
+        finally:
+            render_mod.USE_FUSED_SHADING = True
+        assert counter.calls == (1 if fused else 0)
+        results[fused] = (img.detach().cpu().numpy(), {k: v.grad.cpu().numpy() for k, v in scene.items()})
+    np.testing.assert_allclose(results[True][0], results[False][0], atol=ATOL, rtol=0)
+    for k, want in results[False][1].items():
+        assert np.abs(want).max() > 1e-4, k
+        np.testing.assert_allclose(results[True][1][k], want, atol=ATOL, rtol=0, err_msg=k)
+
+
 def test_render_emits_uint8_frames_on_request(device):
     """rasterize_triangles_ext.EMIT_UINT8_FRAMES: the forward kernel also writes the 8-bit frames;
     to_uint8(image) hands them out (no conversion pass) and they equal mr_export_u8 of the float image;
