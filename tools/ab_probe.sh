@@ -4,8 +4,8 @@ set -e
 cd $GRAFT_REPO_ROOT
 for flags in "$@"; do
   make -C pytorch_mesh_renderer_amd/csrc clean >/dev/null
-  make -j8 -C pytorch_mesh_renderer_amd/csrc $flags all >/dev/null 2>&1
-  make -j8 -C pytorch_mesh_renderer_amd/csrc $flags probes >/dev/null 2>&1
+  make -j8 -C pytorch_mesh_renderer_amd/csrc "$flags" all >/dev/null 2>&1
+  make -j8 -C pytorch_mesh_renderer_amd/csrc "$flags" probes >/dev/null 2>&1
   echo "--- $flags"
   if [ "$AB_BENCH" = bench ]; then timeout -k 5 200 python bench.py --cpu-sample 0 --steps 100 2>/dev/null | grep -o "ms_per_step[^,]*\|avg_kernel_ms[^}]*" | tr '\n' ' '; echo
   elif [ "$AB_BENCH" = kernels ]; then timeout -k 5 100 python tools/shade_bench.py 2>/dev/null | grep shade; timeout -k 5 100 python tools/raster_bench.py --config c3 --backward 2>/dev/null | grep "bwd\|fwd"
