@@ -235,8 +235,8 @@ struct ShadeGradFn {
     const bool mask = (at[6] >= 0.0f) || (at[7] >= 0.0f) || (at[8] >= 0.0f);
     const float gs = SIGNS ? im.g_scale : 1.0f;
     const float g[3] = {mask ? p.g.x * gs : 0.f, mask ? p.g.y * gs : 0.f, mask ? p.g.z * gs : 0.f};
-    const float nn = fast_sqrt(at[0] * at[0] + at[1] * at[1] + at[2] * at[2]);
-    const float inv_nn = fast_rcp(fmaxf(nn, kNormEps));
+    const float nn2 = at[0] * at[0] + at[1] * at[1] + at[2] * at[2];
+    const float inv_nn = inv_norm(nn2);
     const float N[3] = {at[0] * inv_nn, at[1] * inv_nn, at[2] * inv_nn};
     float dN[3] = {0.f, 0.f, 0.f}, dP[3] = {0.f, 0.f, 0.f};
     float dKd[3] = {g[0] * im.amb[0], g[1] * im.amb[1], g[2] * im.amb[2]};
@@ -245,8 +245,8 @@ struct ShadeGradFn {
 #pragma unroll
     for (int l = 0; l < L; ++l) {
       const float v[3] = {im.lp[l][0] - at[3], im.lp[l][1] - at[4], im.lp[l][2] - at[5]};
-      const float vn = fast_sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-      const float inv_vn = fast_rcp(fmaxf(vn, kNormEps));
+      const float vn2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+      const float inv_vn = inv_norm(vn2);
       const float D[3] = {v[0] * inv_vn, v[1] * inv_vn, v[2] * inv_vn};
       const float pre_l = N[0] * D[0] + N[1] * D[1] + N[2] * D[2];
       const float ndl = fminf(fmaxf(pre_l, 0.0f), 1.0f);
@@ -268,7 +268,7 @@ struct ShadeGradFn {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           // backward of v / max(|v|, eps)
-          const float dv = (vn > kNormEps ? (dD[c] - D[c] * dd) : dD[c]) * inv_vn;
+          const float dv = (vn2 > kNormEpsSquared ? (dD[c] - D[c] * dd) : dD[c]) * inv_vn;
           im.dpos[l][c] += dv;
           dP[c] -= dv;
         }
@@ -279,7 +279,7 @@ struct ShadeGradFn {
       const float nd = N[0] * dN[0] + N[1] * dN[1] + N[2] * dN[2];
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        dat[c] = (nn > kNormEps ? (dN[c] - N[c] * nd) : dN[c]) * inv_nn;
+        dat[c] = (nn2 > kNormEpsSquared ? (dN[c] - N[c] * nd) : dN[c]) * inv_nn;
         dat[3 + c] = dP[c];
         dat[6 + c] = dKd[c];
       }

@@ -19,6 +19,11 @@ struct Lights {
 // are ~10 VALU ops each and these kernels are VALU-bound; the parity budget is 1e-4 absolute.
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+// 1 / max(sqrt(s), eps) of torch.nn.functional.normalize for a squared length s, as ONE transcendental
+// (v_rsq_f32, 1 ulp) instead of v_sqrt + v_rcp: they issue at a third of the plain vector rate.
+// s = 0 -> rsq = inf -> 1 / eps; s = inf -> 0; NaN propagates.  `norm > eps` is `s > eps^2`.
+constexpr float kInvNormEps = 1.0f / kNormEps, kNormEpsSquared = kNormEps * kNormEps;
+__device__ __forceinline__ float inv_norm(float s) { return fminf(__builtin_amdgcn_rsqf(s), kInvNormEps); }
 
 // alpha = clamp(sum(2*bary), 0, 1); attr = alpha * interp + (1 - alpha) * (-1)
 // (rasterize.py:137-150 with render.py:197's background of -1).
@@ -109,8 +114,7 @@ __device__ __forceinline__ float4 shade_attributes(const float (&at)[9], const L
 #pragma clang fp contract(fast)  // also inside raster_forward.hip, which is built with -ffp-contract=off
   const bool mask = (at[6] >= 0.0f) || (at[7] >= 0.0f) || (at[8] >= 0.0f);  // render.py:215
   if (!mask) return make_float4(0.f, 0.f, 0.f, 0.f);
-  const float nn = fast_sqrt(at[0] * at[0] + at[1] * at[1] + at[2] * at[2]);
-  const float inv_nn = fast_rcp(fmaxf(nn, kNormEps));
+  const float inv_nn = inv_norm(at[0] * at[0] + at[1] * at[1] + at[2] * at[2]);
   const float nx = at[0] * inv_nn, ny = at[1] * inv_nn, nz = at[2] * inv_nn;
   float r = 0.f, g = 0.f, bl = 0.f;
   if (lights.has_ambient()) {  // render.py:298-301
@@ -123,7 +127,7 @@ __device__ __forceinline__ float4 shade_attributes(const float (&at)[9], const L
     if (l >= lights.count()) break;
     const float vx = lights.position(l, 0) - at[3], vy = lights.position(l, 1) - at[4],
                 vz = lights.position(l, 2) - at[5];
-    const float inv_vn = fast_rcp(fmaxf(fast_sqrt(vx * vx + vy * vy + vz * vz), kNormEps));
+    const float inv_vn = inv_norm(vx * vx + vy * vy + vz * vz);
     const float ndl = fminf(fmaxf(nx * (vx * inv_vn) + ny * (vy * inv_vn) + nz * (vz * inv_vn), 0.0f), 1.0f);
     r += at[6] * ndl * lights.color(l, 0);
     g += at[7] * ndl * lights.color(l, 1);
