@@ -18,6 +18,9 @@
 #ifndef MR_L1_NT_STORE
 #define MR_L1_NT_STORE 1
 #endif
+#ifndef MR_L1_BLOCKS
+#define MR_L1_BLOCKS 2048  // = MR_L1_PARTIALS
+#endif
 #ifndef MR_L1_UNROLL
 #define MR_L1_UNROLL 2  // measured alone at 1024^2 x 32: 1 -> 0.216, 2 -> 0.211, 4 -> 0.248, 8 -> 0.241 ms
 #endif
@@ -205,7 +208,7 @@ __global__ __launch_bounds__(kThreads) void k_tone_map(const float *__restrict__
 
 inline unsigned blocks_for(size_t n4) {
   const size_t want = (n4 + kThreads - 1) / kThreads;
-  return (unsigned)(want < 2048 ? (want ? want : 1) : 2048);
+  return (unsigned)(want < MR_L1_BLOCKS ? (want ? want : 1) : MR_L1_BLOCKS);
 }
 
 }  // namespace
