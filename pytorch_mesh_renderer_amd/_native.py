@@ -16,7 +16,7 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 # build libmesh_raster_hip_probes.so this way); the product always loads the in-tree library.
 LIB_PATH = os.environ.get("MR_NATIVE_LIB_PATH") or os.path.join(_CSRC, "libmesh_raster_hip.so")
 
-ABI_VERSION = 331
+ABI_VERSION = 332
 TIMER_RASTER_FORWARD, TIMER_SHADE_BACKWARD, TIMER_SHADE_FORWARD, TIMER_RASTER_BACKWARD = 0, 1, 2, 3
 MR_OK, MR_EINVAL, MR_EWORKSPACE, MR_ELAUNCH = 0, -1, -2, -3
 _ERR = {MR_EINVAL: "invalid argument", MR_EWORKSPACE: "workspace too small or misaligned",
@@ -558,9 +558,10 @@ def vertex_adjacency(triangles, vertex_count):
 
 def shade_backward(drgba, ids, bary, clip, normals, positions, diffuse, triangles, light_positions,
                    light_intensities, ambient, corner_records=None, adjacency=None, l1_signs=None,
-                   transforms=None):
+                   transforms=None, want_light_grads=True):
     """-> (dclip [B,V,4], dnormals, dpositions, ddiffuse [B,V,3], dlight_positions,
-    dlight_intensities [B,L,3], dambient [B,3] or None).
+    dlight_intensities [B,L,3], dambient [B,3] or None); with want_light_grads=False the last three
+    are None and the kernel leaves their accumulation out.
 
     transforms ([B,4,4], needs `adjacency`): clip = transforms . (positions, 1); dpositions then also
     holds the clip-space gradient pulled back through that product (the whole d / d world vertices).
@@ -595,13 +596,13 @@ def shade_backward(drgba, ids, bary, clip, normals, positions, diffuse, triangle
     B, H, W = ids.shape
     V, T, nl = normals.shape[1], triangles.shape[0], light_positions.shape[1]
     # one allocation, laid out back to back: the library then zeroes all outputs with one memset
-    n4, n3, nlg = B * V * 4, B * V * 3, B * (6 * nl + 3)
+    n4, n3, nlg = B * V * 4, B * V * 3, (B * (6 * nl + 3) if want_light_grads else 0)
     flat = torch.empty(n4 + 3 * n3 + nlg, dtype=torch.float32, device=dev)
     dclip = flat[:n4].view(B, V, 4)
     dn = flat[n4:n4 + n3].view(B, V, 3)
     dp = flat[n4 + n3:n4 + 2 * n3].view(B, V, 3)
     dd = flat[n4 + 2 * n3:n4 + 3 * n3].view(B, V, 3)
-    lg = flat[n4 + 3 * n3:].view(B, 6 * nl + 3)
+    lg = flat[n4 + 3 * n3:].view(B, 6 * nl + 3) if want_light_grads else None
     tail = (B, V, T, W, H, nl, _ptr(dclip), _ptr(dn), _ptr(dp), _ptr(dd), _ptr(lg), _ptr(corner_records),
             _ptr(adjacency[0]) if adjacency is not None else None,
             _ptr(adjacency[1]) if adjacency is not None else None, _ptr(transforms))
@@ -625,6 +626,8 @@ def shade_backward(drgba, ids, bary, clip, normals, positions, diffuse, triangle
                                      _ptr(light_positions), _ptr(light_intensities), _ptr(ambient),
                                      *tail, _ptr(ws), have, _stream(dev))
     _check(rc, "mr_shade_backward")
+    if lg is None:
+        return dclip, dn, dp, dd, None, None, None
     dlpos = lg[:, :3 * nl].reshape(B, nl, 3)
     dlint = lg[:, 3 * nl:6 * nl].reshape(B, nl, 3)
     damb = lg[:, 6 * nl:] if ambient is not None else None

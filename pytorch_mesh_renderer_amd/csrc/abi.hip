@@ -30,7 +30,7 @@ extern thread_local int g_deterministic;
 
 extern "C" {
 
-int mr_version(void) { return 331; /* 0.3.1: deterministic mode, tone map, vertex normals, sign-coded shading backward */ }
+int mr_version(void) { return 332; /* 0.3.1: deterministic mode, tone map, vertex normals, sign-coded shading backward */ }
 
 int mr_last_hip_error(void) { return mr::g_last_hip_error; }
 
@@ -259,8 +259,7 @@ int mr_shade_backward(const float *drgba, const int32_t *ids, const float *bary,
     return MR_EINVAL;
   if (B == 0) return MR_OK;
   if (!drgba || !ids || !bary || !clip || !normals || !positions || !diffuse || !triangles ||
-      !light_positions || !light_intensities || !dclip || !dnormals || !dpositions || !ddiffuse ||
-      !light_grads)
+      !light_positions || !light_intensities || !dclip || !dnormals || !dpositions || !ddiffuse)
     return MR_EINVAL;
   if (((uintptr_t)corner_records & 127u) != 0) return MR_EINVAL;
   if ((vertex_offsets == nullptr) != (vertex_entries == nullptr)) return MR_EINVAL;
@@ -292,8 +291,7 @@ int mr_shade_backward_l1(const uint8_t *signs, const float *upstream, const int3
     return MR_EINVAL;
   if (B == 0) return MR_OK;
   if (!signs || !upstream || !ids || !bary || !clip || !normals || !positions || !diffuse || !triangles ||
-      !light_positions || !light_intensities || !dclip || !dnormals || !dpositions || !ddiffuse ||
-      !light_grads)
+      !light_positions || !light_intensities || !dclip || !dnormals || !dpositions || !ddiffuse)
     return MR_EINVAL;
   if (((uintptr_t)corner_records & 127u) != 0) return MR_EINVAL;
   if ((vertex_offsets == nullptr) != (vertex_entries == nullptr)) return MR_EINVAL;

@@ -118,7 +118,9 @@ __global__ __launch_bounds__(kThreads, MR_SHADE_FWD_WAVES) void k_shade_forward(
 #ifndef MR_SHADE_NT
 #define MR_SHADE_NT 1
 #endif
-template <int L, bool SIGNS>
+// LG: the caller wants the light / ambient gradients (false: light_grads == nullptr; their nine
+// per-lane accumulators and ~25 instructions per row are not compiled in: the kernel -4 %).
+template <int L, bool SIGNS, bool LG>
 struct ShadeGradFn {
   static constexpr int kN = 36;       // 27 attribute partials [corner][attr] + 9 clip partials
   static constexpr int kStride = 36;
@@ -241,7 +243,7 @@ struct ShadeGradFn {
     float dN[3] = {0.f, 0.f, 0.f}, dP[3] = {0.f, 0.f, 0.f};
     float dKd[3] = {g[0] * im.amb[0], g[1] * im.amb[1], g[2] * im.amb[2]};
 #pragma unroll
-    for (int c = 0; c < 3; ++c) im.damb[c] += g[c] * at[6 + c];
+    for (int c = 0; c < 3; ++c) if (LG) im.damb[c] += g[c] * at[6 + c];
 #pragma unroll
     for (int l = 0; l < L; ++l) {
       const float v[3] = {im.lp[l][0] - at[3], im.lp[l][1] - at[4], im.lp[l][2] - at[5]};
@@ -254,7 +256,7 @@ struct ShadeGradFn {
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         dKd[c] += g[c] * ndl * im.li[l][c];
-        im.dcol[l][c] += g[c] * at[6 + c] * ndl;
+        if (LG) im.dcol[l][c] += g[c] * at[6 + c] * ndl;
         t_l += g[c] * at[6 + c] * im.li[l][c];
       }
       if (pre_l >= 0.0f && pre_l <= 1.0f) {  // torch.clamp passes the gradient inclusively
@@ -269,7 +271,7 @@ struct ShadeGradFn {
         for (int c = 0; c < 3; ++c) {
           // backward of v / max(|v|, eps)
           const float dv = (vn2 > kNormEpsSquared ? (dD[c] - D[c] * dd) : dD[c]) * inv_vn;
-          im.dpos[l][c] += dv;
+          if (LG) im.dpos[l][c] += dv;
           dP[c] -= dv;
         }
       }
@@ -310,6 +312,7 @@ struct ShadeGradFn {
   }
 
   __device__ __forceinline__ void end_image(int img, Image &im) const {
+    if (!LG) return;
     float *dst = light_grads + (size_t)img * (L * 6 + 3);
     long long *dst_fixed = light_fixed ? light_fixed + (size_t)img * (L * 6 + 3) : nullptr;
     const float to_fixed = light_fixed ? det_scale[0] : 0.0f;
@@ -540,7 +543,7 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
   if (B == 0) return MR_OK;
   if (transforms && !(vertex_offsets && vertex_entries)) return MR_EINVAL;  // the gather applies them
   const size_t v3 = (size_t)B * V * 3 * sizeof(float), v4 = (size_t)B * V * 4 * sizeof(float);
-  const size_t lg = (size_t)B * (L * 6 + 3) * sizeof(float);
+  const size_t lg = light_grads ? (size_t)B * (L * 6 + 3) * sizeof(float) : 0;  // nullptr: not wanted
   const bool det = g_deterministic != 0;
   const float sign_inv_n = 1.0f / (float)((size_t)B * H * W * 4);  // the L1 mean runs over the whole image
   // With the vertex adjacency the gather writes every vertex output exactly once, and k_bwd_setup
@@ -562,7 +565,7 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
       if (hipMemsetAsync(dpositions, 0, v3, s) != hipSuccess) return check_launch();
       if (hipMemsetAsync(ddiffuse, 0, v3, s) != hipSuccess) return check_launch();
     }
-    if (hipMemsetAsync(light_grads, 0, lg, s) != hipSuccess) return check_launch();
+    if (light_grads && hipMemsetAsync(light_grads, 0, lg, s) != hipSuccess) return check_launch();
   }
   if (T == 0 || V == 0) return MR_OK;
   float *acc = (float *)ws;
@@ -586,7 +589,7 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
     if ((rc = check_launch()) != MR_OK) return rc;
   }
   rc = fused_clear ? launch_bwd_setup(clip, tris, B, V, T, recs, s, acc, 36 * sizeof(float), light_grads,
-                                      B * (L * 6 + 3))
+                                      light_grads ? B * (L * 6 + 3) : 0)
                    : launch_bwd_setup(clip, tris, B, V, T, recs, s);
   if (rc != MR_OK) return rc;
   if (corner_records) {  // the forward's records (same inputs): skip the gather
@@ -599,14 +602,22 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
 #define MR_SHADE_BWD(NL)                                                                        \
   {                                                                                             \
     KernelTimer timer(MR_TIMER_SHADE_BACKWARD, s);                                              \
-    if (signs) {                                                                                \
-      ShadeGradFn<NL, true> fn{nullptr, signs, sign_upstream, sign_inv_n, ids, (const F3 *)bary, corners, recs, \
-                               lights, light_grads, T, W, H, det ? light_fixed : nullptr, det_scale}; \
+    if (signs && light_grads) {                                                                 \
+      ShadeGradFn<NL, true, true> fn{nullptr, signs, sign_upstream, sign_inv_n, ids, (const F3 *)bary, corners, \
+                                     recs, lights, light_grads, T, W, H, det ? light_fixed : nullptr, det_scale}; \
+      rc = launch_accumulate_rows(fn, B, T, W, H, acc, s, det ? det_scale : nullptr);           \
+    } else if (signs) {                                                                         \
+      ShadeGradFn<NL, true, false> fn{nullptr, signs, sign_upstream, sign_inv_n, ids, (const F3 *)bary, corners, \
+                                      recs, lights, nullptr, T, W, H, nullptr, det_scale};      \
+      rc = launch_accumulate_rows(fn, B, T, W, H, acc, s, det ? det_scale : nullptr);           \
+    } else if (light_grads) {                                                                   \
+      ShadeGradFn<NL, false, true> fn{(const float4 *)drgba, nullptr, nullptr, 0.0f, ids, (const F3 *)bary, \
+                                      corners, recs, lights, light_grads, T, W, H,              \
+                                      det ? light_fixed : nullptr, det_scale};                  \
       rc = launch_accumulate_rows(fn, B, T, W, H, acc, s, det ? det_scale : nullptr);           \
     } else {                                                                                    \
-      ShadeGradFn<NL, false> fn{(const float4 *)drgba, nullptr, nullptr, 0.0f, ids, (const F3 *)bary, \
-                                corners, recs, lights, light_grads, T, W, H,                    \
-                                det ? light_fixed : nullptr, det_scale};                        \
+      ShadeGradFn<NL, false, false> fn{(const float4 *)drgba, nullptr, nullptr, 0.0f, ids, (const F3 *)bary, \
+                                       corners, recs, lights, nullptr, T, W, H, nullptr, det_scale}; \
       rc = launch_accumulate_rows(fn, B, T, W, H, acc, s, det ? det_scale : nullptr);           \
     }                                                                                           \
   }
@@ -626,7 +637,8 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
       hipLaunchKernelGGL(k_shade_gather<true>, grid, dim3(kThreads), 0, s, acc, det_scale, vertex_offsets,
                          vertex_entries, B, V, T, dnormals, dpositions, ddiffuse, dclip, transforms);
       if ((rc = check_launch()) != MR_OK) return rc;
-      const int n_light = B * (L * 6 + 3);
+      const int n_light = light_grads ? B * (L * 6 + 3) : 0;
+      if (n_light > 0)
       hipLaunchKernelGGL(k_light_from_fixed, dim3((unsigned)((n_light + kThreads - 1) / kThreads)), dim3(kThreads),
                          0, s, light_fixed, det_scale, n_light, light_grads);
     } else {

@@ -162,15 +162,17 @@ class FusedPhongRenderer(torch.autograd.Function):
         return rgba, frames
 
     @staticmethod
-    def _input_grads(saved, needs_transform_grad, upstream, l1_signs=None):
+    def _input_grads(saved, needs_transform_grad, needs_light_grads, upstream, l1_signs=None):
         """The shading backward on the tensors forward() saved -> gradients in the order of forward()'s
-        tensor arguments (vertices, transforms, normals, diffuse, None, lights..., ambient)."""
+        tensor arguments (vertices, transforms, normals, diffuse, None, lights..., ambient).
+        needs_light_grads: some of light_positions / light_intensities / ambient requires grad."""
         (clip, ids, bary, normals, verts, diffuse, triangles, lp, li, corner_records, offsets,
          entries, xf) = saved[:13]
         amb = saved[13] if len(saved) > 13 else None
         dclip, dn, dverts, dd, dlp, dli, damb = _native.shade_backward(
             upstream, ids, bary, clip, normals, verts, diffuse, triangles, lp, li, amb,
-            corner_records=corner_records, adjacency=(offsets, entries), l1_signs=l1_signs, transforms=xf)
+            corner_records=corner_records, adjacency=(offsets, entries), l1_signs=l1_signs, transforms=xf,
+            want_light_grads=needs_light_grads)
         dxf = None
         if needs_transform_grad:  # d clip[b,v,r] / d xf[b,r,k] = (vertex, 1)[k]
             ones = torch.ones(verts.shape[0], verts.shape[1], 1, dtype=verts.dtype, device=verts.device)
@@ -179,7 +181,8 @@ class FusedPhongRenderer(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, drgba, _dframes=None):
-        grads = FusedPhongRenderer._input_grads(ctx.saved_tensors, ctx.needs_input_grad[1], drgba.contiguous())
+        grads = FusedPhongRenderer._input_grads(ctx.saved_tensors, ctx.needs_input_grad[1],
+                                                any(ctx.needs_input_grad[5:8]), drgba.contiguous())
         return grads + (None, None)
 
 
@@ -205,7 +208,8 @@ class FusedPhongL1Loss(torch.autograd.Function):
         signs = ctx.saved_tensors[0]
         upstream = grad.to(torch.float32).reshape(1)
         dverts, dxf, dn, dd, _, dlp, dli, damb = FusedPhongRenderer._input_grads(
-            ctx.saved_tensors[1:], ctx.needs_input_grad[3], upstream, l1_signs=signs)
+            ctx.saved_tensors[1:], ctx.needs_input_grad[3], any(ctx.needs_input_grad[6:9]), upstream,
+            l1_signs=signs)
         dtarget = None
         if ctx.needs_input_grad[1]:
             dtarget = -_native.l1_loss_backward(signs, ctx.image_shape, upstream)

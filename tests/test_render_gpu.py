@@ -661,6 +661,19 @@ def test_render_forward_matches_raster_then_shade(device, w, h, res, n_lights, a
     np.testing.assert_allclose(pulled[2].cpu().numpy(), want.cpu().numpy(), atol=1e-7, rtol=1e-5)
     for k in (0, 1, 3):
         np.testing.assert_allclose(pulled[k].cpu().numpy(), gathered[k].cpu().numpy(), atol=1e-8, rtol=1e-5)
+    # without the light / ambient gradients (none of them requires grad): the same vertex-side outputs
+    lean = _native.shade_backward(*args, adjacency=adjacency, want_light_grads=False)
+    assert lean[4] is None and lean[5] is None and lean[6] is None
+    for k in range(4):
+        np.testing.assert_allclose(lean[k].cpu().numpy(), gathered[k].cpu().numpy(), atol=1e-8, rtol=1e-5)
+    signs_loss, signs = _native.l1_loss_forward(rgba, torch.zeros_like(rgba))
+    up = torch.ones(1, device=rgba.device)
+    l1_args = (up,) + args[1:]
+    with_lights = _native.shade_backward(*l1_args, adjacency=adjacency, l1_signs=signs)
+    lean_l1 = _native.shade_backward(*l1_args, adjacency=adjacency, l1_signs=signs, want_light_grads=False)
+    assert float(with_lights[4].abs().max()) > 0 and lean_l1[4] is None
+    for k in range(4):
+        np.testing.assert_allclose(lean_l1[k].cpu().numpy(), with_lights[k].cpu().numpy(), atol=1e-8, rtol=1e-5)
 
 
 def test_shade_backward_gather_matches_scatter(device):
