@@ -109,6 +109,7 @@ template <int AP>
 struct AttrRowsFn {
   static constexpr int kN = 3 * AP + 9;          // [corner][attribute] partials + 9 clip partials
   static constexpr int kStride = (kN + 3) & ~3;  // floats per acc row
+  static constexpr int kRowsPerWave = MR_ROWS_PER_WAVE;  // see run_accum.h
   static constexpr int kSlots = 256;
   static constexpr int kMinWavesPerSimd = AP <= 8 ? 4 : 3;
   static constexpr bool kCountBackground = false;

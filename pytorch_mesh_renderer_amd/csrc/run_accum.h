@@ -41,7 +41,10 @@
 namespace mr {
 
 constexpr int kRunThreads = 256;
-constexpr int kRunRowsPerWave = 32;                                  // pixels each lane walks
+#ifndef MR_RUN_ROWS_PER_WAVE
+#define MR_RUN_ROWS_PER_WAVE 32
+#endif
+constexpr int kRunRowsPerWave = MR_RUN_ROWS_PER_WAVE;                 // pixels each lane walks (k_accumulate_runs)
 constexpr int kRunRegionH = kRunRowsPerWave * (kRunThreads / kWave);  // 128 rows / workgroup
 constexpr int kRunMaxProbe = 16;
 
@@ -209,6 +212,15 @@ __device__ __forceinline__ void lds_read_pairs4(unsigned addr_a, unsigned addr_b
       : "v"(addr_a), "v"(addr_b) : "memory");
 }
 
+// Fn::kRowsPerWave: rows a wavefront of k_accumulate_rows walks down its 64-pixel-wide strip.  Short
+// strips balance the load (background rows cost almost nothing, silhouette strips a lot) better than
+// long ones amortise the merge table: measured at 1024^2 x 32, shading backward: 4 -> 0.417,
+// 8 -> 0.405, 16 -> 0.412, 32 -> 0.440, 64 -> 0.502 ms; the specular backward (2 waves per SIMD, a
+// per-image epilogue per wavefront): 8 -> 4.39, 16 -> 3.89, 32 -> 4.01 ms per step.
+#ifndef MR_ROWS_PER_WAVE
+#define MR_ROWS_PER_WAVE 8
+#endif
+
 template <class Fn, bool DET>
 __global__ __launch_bounds__(kRunThreads, Fn::kMinWavesPerSimd) void k_accumulate_rows(
     Fn fn, int T, int W, int H, int regions_x, int regions_per_image, int n_regions,
@@ -248,8 +260,9 @@ __global__ __launch_bounds__(kRunThreads, Fn::kMinWavesPerSimd) void k_accumulat
   const int x = rx * kWave + lane;
   const bool in_range = x < W;
   const int xc = in_range ? x : W - 1;
-  const int y_begin = ry * kRunRegionH + wave * kRunRowsPerWave;
-  const int y_end = min(y_begin + kRunRowsPerWave, H);
+  constexpr int kRowsPerWave = Fn::kRowsPerWave, kRowsRegionH = kRowsPerWave * (kRunThreads / kWave);
+  const int y_begin = ry * kRowsRegionH + wave * kRowsPerWave;
+  const int y_end = min(y_begin + kRowsPerWave, H);
   float *acc_img = acc + (size_t)img * T * STRIDE;
   long long *acc_fixed = (long long *)acc + (size_t)img * T * STRIDE;  // DET: 8-byte elements
   const float to_fixed = DET ? det_scale[0] : 0.0f;
@@ -397,7 +410,8 @@ template <class Fn>
 inline int launch_accumulate_rows(const Fn &fn, int B, int T, int W, int H, float *acc,
                                   hipStream_t s, const float *det_scale = nullptr) {
   const int regions_x = (W + kWave - 1) / kWave;
-  const int regions_y = (H + kRunRegionH - 1) / kRunRegionH;
+  constexpr int kRowsRegionH = Fn::kRowsPerWave * (kRunThreads / kWave);
+  const int regions_y = (H + kRowsRegionH - 1) / kRowsRegionH;
   const int per_image = regions_x * regions_y;
   const int n_regions = per_image * B;
   const int per_xcd = (n_regions + kXcds - 1) / kXcds;

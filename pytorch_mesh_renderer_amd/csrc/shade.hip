@@ -124,6 +124,7 @@ template <int L, bool SIGNS, bool LG>
 struct ShadeGradFn {
   static constexpr int kN = 36;       // 27 attribute partials [corner][attr] + 9 clip partials
   static constexpr int kStride = 36;
+  static constexpr int kRowsPerWave = MR_ROWS_PER_WAVE;  // see run_accum.h
   // per-pixel factors parked in LDS: b[3] | y[9] = alpha * d/d attr | q[3] = clip brackets
   static constexpr int kFactors = 15;
   static constexpr int kFactorStride = 20;

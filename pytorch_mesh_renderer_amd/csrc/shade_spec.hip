@@ -324,6 +324,7 @@ struct SpecGradFn {
   static constexpr int kA = attr_count(PV);
   static constexpr int kN = 3 * kA + 9;  // attribute partials [corner][attr] + 9 clip partials: 45 / 48
   static constexpr int kStride = 48;
+  static constexpr int kRowsPerWave = 16;  // see run_accum.h
   static constexpr int kSlots = 256;
   static constexpr int kMinWavesPerSimd = 2;
   static constexpr bool kCountBackground = true;
