@@ -220,9 +220,16 @@ __device__ __forceinline__ void lds_read_pairs4(unsigned addr_a, unsigned addr_b
 #ifndef MR_ROWS_PER_WAVE
 #define MR_ROWS_PER_WAVE 8
 #endif
+// One wavefront per workgroup: the wavefronts of k_accumulate_rows share nothing (each has its own
+// staging rows and merge table), and single-wave workgroups are placed and retired one by one --
+// 256 threads -> 0.405, 128 -> 0.391, 64 -> 0.382 ms (shading backward, 1024^2 x 32).
+#ifndef MR_ROWS_THREADS
+#define MR_ROWS_THREADS 64
+#endif
+constexpr int kRowsThreads = MR_ROWS_THREADS;
 
 template <class Fn, bool DET>
-__global__ __launch_bounds__(kRunThreads, Fn::kMinWavesPerSimd) void k_accumulate_rows(
+__global__ __launch_bounds__(kRowsThreads, Fn::kMinWavesPerSimd) void k_accumulate_rows(
     Fn fn, int T, int W, int H, int regions_x, int regions_per_image, int n_regions,
     int regions_per_xcd, float *__restrict__ acc, const float *__restrict__ det_scale) {
   constexpr int N = Fn::kN, STRIDE = Fn::kStride, F = Fn::kFactorStride;
@@ -234,7 +241,7 @@ __global__ __launch_bounds__(kRunThreads, Fn::kMinWavesPerSimd) void k_accumulat
   // collide; 6 spare columns behind a row absorb the last batch's over-read.
   constexpr int kRowStride = 74;
   static_assert(Fn::kFactors <= 32, "bank layout of the parked rows: 32 distinct even bank offsets");
-  __shared__ __attribute__((aligned(16))) float s_stage[kRunThreads / kWave][Fn::kFactors * kRowStride];
+  __shared__ __attribute__((aligned(16))) float s_stage[kRowsThreads / kWave][Fn::kFactors * kRowStride];
   // Per-wavefront merge table: a triangle's segments of consecutive rows are summed here, in LDS,
   // and leave as ONE N-lane global atomic per (wavefront, triangle) instead of one per (row,
   // segment).  Global float atomics run at one wave-instruction per ~50 ns per CU whatever their
@@ -245,7 +252,7 @@ __global__ __launch_bounds__(kRunThreads, Fn::kMinWavesPerSimd) void k_accumulat
   // A slot is a whole 64-float row (lanes >= N carry along a copy of lane N-1's sum): reads and
   // writes of a slot then need no lane mask.
   constexpr int kMergeSlots = MR_ROWS_MERGE_SLOTS;
-  __shared__ float s_merge[kRunThreads / kWave][kMergeSlots > 0 ? kMergeSlots * kWave : 1];
+  __shared__ float s_merge[kRowsThreads / kWave][kMergeSlots > 0 ? kMergeSlots * kWave : 1];
 
   const int region = xcd_contiguous_block((int)blockIdx.x, n_regions, regions_per_xcd);
   if (region < 0) return;
@@ -260,7 +267,7 @@ __global__ __launch_bounds__(kRunThreads, Fn::kMinWavesPerSimd) void k_accumulat
   const int x = rx * kWave + lane;
   const bool in_range = x < W;
   const int xc = in_range ? x : W - 1;
-  constexpr int kRowsPerWave = Fn::kRowsPerWave, kRowsRegionH = kRowsPerWave * (kRunThreads / kWave);
+  constexpr int kRowsPerWave = Fn::kRowsPerWave, kRowsRegionH = kRowsPerWave * (kRowsThreads / kWave);
   const int y_begin = ry * kRowsRegionH + wave * kRowsPerWave;
   const int y_end = min(y_begin + kRowsPerWave, H);
   float *acc_img = acc + (size_t)img * T * STRIDE;
@@ -410,18 +417,18 @@ template <class Fn>
 inline int launch_accumulate_rows(const Fn &fn, int B, int T, int W, int H, float *acc,
                                   hipStream_t s, const float *det_scale = nullptr) {
   const int regions_x = (W + kWave - 1) / kWave;
-  constexpr int kRowsRegionH = Fn::kRowsPerWave * (kRunThreads / kWave);
+  constexpr int kRowsRegionH = Fn::kRowsPerWave * (kRowsThreads / kWave);
   const int regions_y = (H + kRowsRegionH - 1) / kRowsRegionH;
   const int per_image = regions_x * regions_y;
   const int n_regions = per_image * B;
   const int per_xcd = (n_regions + kXcds - 1) / kXcds;
   if (det_scale)
     hipLaunchKernelGGL((k_accumulate_rows<Fn, true>), dim3((unsigned)(per_xcd * kXcds)),
-                       dim3(kRunThreads), 0, s, fn, T, W, H, regions_x, per_image, n_regions,
+                       dim3(kRowsThreads), 0, s, fn, T, W, H, regions_x, per_image, n_regions,
                        per_xcd, acc, det_scale);
   else
     hipLaunchKernelGGL((k_accumulate_rows<Fn, false>), dim3((unsigned)(per_xcd * kXcds)),
-                       dim3(kRunThreads), 0, s, fn, T, W, H, regions_x, per_image, n_regions,
+                       dim3(kRowsThreads), 0, s, fn, T, W, H, regions_x, per_image, n_regions,
                        per_xcd, acc, det_scale);
   return check_launch();
 }
