@@ -124,7 +124,10 @@ template <int L, bool SIGNS, bool LG>
 struct ShadeGradFn {
   static constexpr int kN = 36;       // 27 attribute partials [corner][attr] + 9 clip partials
   static constexpr int kStride = 36;
-  static constexpr int kRowsPerWave = MR_ROWS_PER_WAVE;  // see run_accum.h
+  // see run_accum.h.  With the light gradients every strip ends in 6L + 3 atomics on the image's
+  // one set of sums: 8-row strips put four times as many of them on the same addresses (dense
+  // upstream, 1024^2 x 32: 8 -> 0.84, 16 -> 0.56, 32 -> 0.56 ms)
+  static constexpr int kRowsPerWave = LG ? 16 : MR_ROWS_PER_WAVE;
   // per-pixel factors parked in LDS: b[3] | y[9] = alpha * d/d attr | q[3] = clip brackets
   static constexpr int kFactors = 15;
   static constexpr int kFactorStride = 20;
