@@ -13,6 +13,7 @@ for flags in "$@"; do
   elif [ "$AB_BENCH" = rasterize ]; then timeout -k 5 200 python tools/rasterize_bench.py 2>/dev/null | grep rasterize
   elif [ "$AB_BENCH" = c4 ]; then timeout -k 5 300 python bench.py --config c4 --cpu-sample 0 --steps 60 2>/dev/null | grep -o "ms_per_step[^,]*\|avg_kernel_ms\": [0-9.]*" | tr '\n' ' '; echo
   elif [ "$AB_BENCH" = rows ]; then timeout -k 5 200 python tools/rasterize_bench.py 2>/dev/null | grep rasterize; timeout -k 5 200 python tools/specular_bench.py 2>/dev/null | grep "specular"; timeout -k 5 300 python bench.py --config c4 --cpu-sample 0 --steps 60 2>/dev/null | grep -o "ms_per_step[^,]*"; timeout -k 5 300 python bench.py --cpu-sample 0 --steps 100 2>/dev/null | grep -o "ms_per_step[^,]*"
+  elif [ "$AB_BENCH" = rbwd ]; then timeout -k 5 200 python tools/raster_bench.py --config c3 --backward 2>/dev/null | grep bwd; timeout -k 5 200 python tools/raster_bench.py --config c4 --backward 2>/dev/null | grep bwd
   elif [ "$AB_BENCH" = gather ]; then bash tools/gather_time.sh
   elif [ "$AB_BENCH" = l1 ]; then timeout -k 5 100 python tools/l1_bench.py 2>/dev/null | grep -v amdgpu
   elif [ "$AB_BENCH" = soft ]; then timeout -k 5 200 python tools/soft_bench.py 2>/dev/null | grep config5
