@@ -206,14 +206,28 @@ __global__ __launch_bounds__(kThreads) void k_setup(
 // triangle-id order, the ids whose bbox touches the cell.  The raster kernel's regions
 // (4x4 per cell) then scan ~T * ((256 + d) / W)^2 ids instead of all T (d = triangle size).
 // ---------------------------------------------------------------------------------------
-constexpr int kCellRegions = 4;                       // regions per cell edge (cell = 4 x 4 regions)
+#ifndef MR_CELL_REGIONS
+#define MR_CELL_REGIONS 4
+#endif
+constexpr int kCellRegions = MR_CELL_REGIONS;         // regions per cell edge (cell = 4 x 4 regions)
 constexpr int kCoarseThreads = 1024;
+// Second level: per raster REGION, the ids of its cell's list whose bbox touches the region (~60-100 of
+// the cell's ~400 at 1024^2 / 5k triangles), still in triangle-id order.  k_raster's bin stage then
+// scans one or two 64-id chunks per region instead of seven (0.225 -> 0.187 ms for the G-buffer
+// kernel at 1024^2 x 32).  A region whose list would not fit kRegionListCap ids keeps reading its
+// cell's list (count = -1).
+constexpr int kRegionListCap = 512;
+constexpr int kCellStash = 1024;  // hits of a cell kept in LDS between k_coarse's two levels
 
 __global__ __launch_bounds__(kCoarseThreads) void k_coarse(
     const TriBox *__restrict__ bbs, int T, int W, int H, int cells_x, int cells_per_image, int cell_size,
-    int32_t *__restrict__ cell_ids, int32_t *__restrict__ cell_count, float *__restrict__ cell_split) {
+    int32_t *__restrict__ cell_ids, int32_t *__restrict__ cell_count, float *__restrict__ cell_split,
+    int regions_x, int regions_y, int32_t *__restrict__ region_ids, int32_t *__restrict__ region_count) {
+  static_assert(kCoarseThreads / kWave == kCellRegions * kCellRegions, "one wavefront per region of the cell");
   __shared__ int s_wave_count[kCoarseThreads / kWave];
   __shared__ float s_wave_lo[kCoarseThreads / kWave], s_wave_hi[kCoarseThreads / kWave];
+  __shared__ uint2 s_hit_box[kCellStash];  // (lr, bt) of the cell's first kCellStash hits, for the second level
+  __shared__ int32_t s_hit_id[kCellStash];
   const int img = (int)blockIdx.x / cells_per_image;
   const int cell = (int)blockIdx.x - img * cells_per_image;
   const int cy = cell / cells_x, cx = cell - cy * cells_x;
@@ -252,9 +266,15 @@ __global__ __launch_bounds__(kCoarseThreads) void k_coarse(
         if (w < wave) offset += c;
         total += c;
       }
-      if (hit)
-        out[offset + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
-                                                    __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = t;
+      if (hit) {
+        const int pos = offset + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
+                                                                __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        out[pos] = t;
+        if (pos < kCellStash) {
+          s_hit_box[pos] = make_uint2(bb[u].lr, bb[u].bt);
+          s_hit_id[pos] = t;
+        }
+      }
       n += total;
       __syncthreads();
     }
@@ -280,6 +300,44 @@ __global__ __launch_bounds__(kCoarseThreads) void k_coarse(
     }
     cell_count[(size_t)img * cells_per_image + cell] = n;
     cell_split[(size_t)img * cells_per_image + cell] = (n > 0 && lo > -INFINITY) ? 0.5f * lo + 0.5f * hi : NAN;
+  }
+  // Second level: wavefront w compacts the cell's list (just written; the barriers above order it)
+  // for region (w % 4, w / 4) of the cell -- wave-local ballots, no further barriers.
+  {
+    const int edge = cell_size / kCellRegions;
+    const int rx = cx * kCellRegions + wave % kCellRegions, ry = cy * kCellRegions + wave / kCellRegions;
+    if (rx < regions_x && ry < regions_y) {  // wave-uniform
+      const int RX0 = rx * edge, RY0 = ry * edge;
+      const int RX1 = min(RX0 + edge, W), RY1 = min(RY0 + edge, H);
+      const size_t region = ((size_t)img * regions_y + ry) * regions_x + rx;
+      int32_t *rout = region_ids + region * kRegionListCap;
+      int count = 0;
+      for (int base = 0; base < n; base += kWave) {
+        const int k = base + lane;
+        int t = -1;
+        uint2 box = make_uint2(0u, 0u);
+        if (k < n) {
+          if (k < kCellStash) {
+            t = s_hit_id[k];
+            box = s_hit_box[k];
+          } else {
+            t = out[k];
+            const TriBox bb = img_bbs[t];
+            box = make_uint2(bb.lr, bb.bt);
+          }
+        }
+        const int l = (int)(box.x & 0xffffu), r = (int)(box.x >> 16);
+        const int bt = (int)(box.y & 0xffffu), tp = (int)(box.y >> 16);
+        const bool hit = (l < RX1) && (r > RX0) && (bt < RY1) && (tp > RY0);  // t < 0: the all-zero box misses
+        const unsigned long long m = __ballot(hit);
+        if (hit) {
+          const int pos = count + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+          if (pos < kRegionListCap) rout[pos] = t;
+        }
+        count += __builtin_popcountll(m);
+      }
+      if (lane == 0) region_count[region] = count <= kRegionListCap ? count : -1;
+    }
   }
 }
 
@@ -422,7 +480,8 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : MR_RASTER
     int regions_x, int regions_per_image, int n_regions, int regions_per_xcd,
     const int32_t *__restrict__ cell_ids, const int32_t *__restrict__ cell_count,
     const float *__restrict__ cell_split, int cells_x,
-    int cells_per_image, int32_t *__restrict__ ids, float *__restrict__ bary,
+    int cells_per_image, const int32_t *__restrict__ region_ids,
+    const int32_t *__restrict__ region_count, int32_t *__restrict__ ids, float *__restrict__ bary,
     float *__restrict__ zbuf, const RasterShade shade) {
   static_assert(R == 64 || R == 32, "region edge");
   static_assert(!SHADE || PROBE == 0, "the shading epilogue has no timing probes");
@@ -469,8 +528,11 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : MR_RASTER
   const size_t img_px = (size_t)img * H * W;
   // this region's coarse cell: the id-ordered list of triangles whose bbox touches it
   const int cell = (ry / kCellRegions) * cells_x + (rx / kCellRegions);
-  const int32_t *cand = cell_ids + ((size_t)img * cells_per_image + cell) * T;
-  const int n_cand = cell_count[(size_t)img * cells_per_image + cell];
+  // ... or, where k_coarse_regions could fit it, the shorter list of those that touch this region
+  const int region_n = region_count[region];  // workgroup-uniform
+  const int32_t *cand = region_n >= 0 ? region_ids + (size_t)region * kRegionListCap
+                                      : cell_ids + ((size_t)img * cells_per_image + cell) * T;
+  const int n_cand = region_n >= 0 ? region_n : cell_count[(size_t)img * cells_per_image + cell];
   // Front-to-back classes (see depth_lower_bound): when every triangle of the cell is tame, the
   // bin holds the candidates whose depth bound lies below the cell's split first ("near"), in id
   // order, then the others ("far"), in id order.  A tile whose pixels all hold a depth below the
@@ -997,9 +1059,12 @@ size_t raster_forward_ws(int B, int V, int T, int W, int H) {
   const size_t nbt = (size_t)B * T;
   const int cell = kCellRegions * region_edge(B, W, H);
   const size_t cells = (size_t)((W + cell - 1) / cell) * ((H + cell - 1) / cell) * B;
+  const int edge = region_edge(B, W, H);
+  const size_t regions = (size_t)((W + edge - 1) / edge) * ((H + edge - 1) / edge) * B;
   return align_up(nbt * sizeof(TriRec), 256) + align_up(nbt * sizeof(TriBox), 256) +
          align_up((size_t)W * sizeof(float), 256) + align_up((size_t)H * sizeof(float), 256) +
-         align_up(cells * T * sizeof(int32_t), 256) + 2 * align_up(cells * sizeof(int32_t), 256);
+         align_up(cells * T * sizeof(int32_t), 256) + 2 * align_up(cells * sizeof(int32_t), 256) +
+         align_up(regions * kRegionListCap * sizeof(int32_t), 256) + align_up(regions * sizeof(int32_t), 256);
 }
 
 #ifdef MR_PROBES
@@ -1013,6 +1078,7 @@ struct RasterArgs {
   const int32_t *cell_ids, *cell_count;
   const float *cell_split;
   int cells_x, cells_per_image;
+  const int32_t *region_ids, *region_count;
   int32_t *ids; float *bary, *z;
   RasterShade shade;  // rgba == nullptr: G-buffer only
 };
@@ -1021,7 +1087,8 @@ template <int R, int PROBE, bool SHADE = false>
 void launch_k_raster(const RasterArgs &a, dim3 grid, hipStream_t s) {
   hipLaunchKernelGGL((k_raster<R, PROBE, SHADE>), grid, dim3(kThreads), 0, s, a.recs, a.bbs, a.pxtab, a.pytab, a.T,
                      a.W, a.H, a.regions_x, a.per_image, a.n_regions, a.per_xcd, a.cell_ids, a.cell_count,
-                     a.cell_split, a.cells_x, a.cells_per_image, a.ids, a.bary, a.z, a.shade);
+                     a.cell_split, a.cells_x, a.cells_per_image, a.region_ids, a.region_count, a.ids, a.bary, a.z,
+                     a.shade);
 }
 
 template <int R>
@@ -1065,6 +1132,14 @@ int raster_forward(const float *clip, const int32_t *tris, int B, int V, int T, 
   int32_t *cell_count = (int32_t *)p;
   p += align_up((size_t)cells_per_image * B * sizeof(int32_t), 256);
   float *cell_split = (float *)p;
+  p += align_up((size_t)cells_per_image * B * sizeof(int32_t), 256);
+  const int regions_x = (W + edge - 1) / edge;
+  const int regions_y = (H + edge - 1) / edge;
+  const int per_image = regions_x * regions_y;
+  const int n_regions = per_image * B;
+  int32_t *region_ids = (int32_t *)p;
+  p += align_up((size_t)n_regions * kRegionListCap * sizeof(int32_t), 256);
+  int32_t *region_count = (int32_t *)p;
 
   const long setup_threads = (long)nbt + W + H;
   const unsigned setup_blocks = (unsigned)((setup_threads + kThreads - 1) / kThreads);
@@ -1074,18 +1149,16 @@ int raster_forward(const float *clip, const int32_t *tris, int B, int V, int T, 
   if (rc != MR_OK) return rc;
   if (B == 0) return MR_OK;
   hipLaunchKernelGGL(k_coarse, dim3((unsigned)(cells_per_image * B)), dim3(kCoarseThreads), 0, s, bbs, T,
-                     W, H, cells_x, cells_per_image, cell, cell_ids, cell_count, cell_split);
+                     W, H, cells_x, cells_per_image, cell, cell_ids, cell_count, cell_split, regions_x, regions_y,
+                     region_ids, region_count);
   rc = check_launch();
   if (rc != MR_OK) return rc;
 
-  const int regions_x = (W + edge - 1) / edge;
-  const int regions_y = (H + edge - 1) / edge;
-  const int per_image = regions_x * regions_y;
-  const int n_regions = per_image * B;
   const int per_xcd = (n_regions + kXcds - 1) / kXcds;
   const dim3 grid((unsigned)(per_xcd * kXcds));
   const RasterArgs args{recs, bbs, pxtab, pytab, T, W, H, regions_x, per_image, n_regions, per_xcd,
-                        cell_ids, cell_count, cell_split, cells_x, cells_per_image, ids, bary, z, shade};
+                        cell_ids, cell_count, cell_split, cells_x, cells_per_image, region_ids, region_count,
+                        ids, bary, z, shade};
   {
     KernelTimer timer(MR_TIMER_RASTER_FORWARD, s);  // records only when a caller armed it
     if (edge == 32) launch_k_raster_probe<32>(args, grid, s);

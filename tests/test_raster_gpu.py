@@ -255,6 +255,24 @@ def test_bin_overflow_many_triangles_one_region(device):
     assert (want[1].sum(-1) > 0.5).mean() > 0.9
 
 
+def test_region_lists_past_the_cell_stash(device):
+    """6000 small triangles over one 256x256 cell: the cell's list is far longer than k_coarse's LDS stash
+    (1024 hits) while most 64x64 regions keep a list of their own (<= 512 ids) and the crowded ones
+    fall back to the cell's -- all three paths of the second binning level, bit-exact."""
+    rng = np.random.default_rng(11)
+    T = 6000
+    centers = rng.uniform(-1.0, 1.0, size=(T, 1, 2)).astype(np.float32)
+    centers[: T // 4] *= 0.25          # a crowd in the middle four regions
+    offs = rng.uniform(-0.04, 0.04, size=(T, 3, 2)).astype(np.float32)
+    xy = (centers + offs).reshape(-1, 2)
+    zz = rng.uniform(-0.9, 0.9, size=(T * 3, 1)).astype(np.float32)
+    clip = np.concatenate([xy, zz, np.ones((T * 3, 1), np.float32)], 1)
+    tris = np.arange(T * 3, dtype=np.int32).reshape(T, 3)
+    want = oracle.forward(clip, tris, 256, 256)
+    got = hip_forward(clip, tris, 256, 256, device)
+    assert_forward_bitwise(got, want)
+
+
 def test_empty_inputs(device):
     clip = torch.zeros(2, 5, 4, device=device)
     tris = torch.zeros(0, 3, dtype=torch.int32, device=device)
