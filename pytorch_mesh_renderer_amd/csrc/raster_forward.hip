@@ -217,14 +217,13 @@ constexpr int kCoarseThreads = 1024;
 // kernel at 1024^2 x 32).  A region whose list would not fit kRegionListCap ids keeps reading its
 // cell's list (count = -1).
 constexpr int kRegionListCap = 512;
-constexpr int kCellStash = 1024;  // hits of a cell kept in LDS between k_coarse's two levels
+constexpr int kCellStash = 2048;  // hits of a cell kept in LDS between k_coarse's two levels (24 KB)
 
 __global__ __launch_bounds__(kCoarseThreads) void k_coarse(
     const TriBox *__restrict__ bbs, int T, int W, int H, int cells_x, int cells_per_image, int cell_size,
     int32_t *__restrict__ cell_ids, int32_t *__restrict__ cell_count, float *__restrict__ cell_split,
     int regions_x, int regions_y, int32_t *__restrict__ region_ids, int32_t *__restrict__ region_count) {
   static_assert(kCoarseThreads / kWave == kCellRegions * kCellRegions, "one wavefront per region of the cell");
-  __shared__ int s_wave_count[kCoarseThreads / kWave];
   __shared__ float s_wave_lo[kCoarseThreads / kWave], s_wave_hi[kCoarseThreads / kWave];
   __shared__ uint2 s_hit_box[kCellStash];  // (lr, bt) of the cell's first kCellStash hits, for the second level
   __shared__ int32_t s_hit_id[kCellStash];
@@ -239,16 +238,26 @@ __global__ __launch_bounds__(kCoarseThreads) void k_coarse(
   int n = 0;  // workgroup-uniform
   float lo = INFINITY, hi = -INFINITY;  // range of the depth bounds of this thread's hits
   constexpr int kUnroll = 4;
-  for (int base = 0; base < T; base += kUnroll * kCoarseThreads) {
+  static_assert(kUnroll * (kCoarseThreads / kWave) == kWave, "one lane per (sub-chunk, wavefront) count");
+  // One barrier per kUnroll x 1024 triangles: every wavefront posts the hit counts of its kUnroll
+  // sub-chunks, and after the barrier EVERY wavefront scans the 64 counts itself (lane = sub-chunk x 16
+  // + wavefront, the id order of the hits) with six shuffles.  The counts are double-buffered: a
+  // wavefront can only overwrite a buffer two trips later, i.e. after a barrier that everyone reached
+  // after reading it.  (Two barriers per 1024 triangles before: 100 us at 50k triangles, 2048^2.)
+  __shared__ int s_counts[2][kWave];
+  int trip = 0;
+  // (Requesting the next trip's boxes a trip ahead changes nothing: at 50k triangles the kernel is bound
+  // by the L2 -> CU traffic of every cell reading every box, 64 cells x 50k x 16 B per image.)
+  for (int base = 0; base < T; base += kUnroll * kCoarseThreads, trip ^= 1) {
     TriBox bb[kUnroll];
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
       const int t = base + u * kCoarseThreads + tid;
       bb[u] = (t < T) ? img_bbs[t] : TriBox{0u, 0u, 0.0f, 0u};
     }
+    unsigned long long m[kUnroll];
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
-      const int t = base + u * kCoarseThreads + tid;
       const int l = (int)(bb[u].lr & 0xffffu), r = (int)(bb[u].lr >> 16);
       const int bt = (int)(bb[u].bt & 0xffffu), tp = (int)(bb[u].bt >> 16);
       const bool hit = (l < X1) && (r > X0) && (bt < Y1) && (tp > Y0);  // empty bbox = all zeros
@@ -256,29 +265,35 @@ __global__ __launch_bounds__(kCoarseThreads) void k_coarse(
         lo = fminf(lo, bb[u].zlo);  // -inf (a triangle that is not tame) sticks
         hi = fmaxf(hi, bb[u].zlo);
       }
-      const unsigned long long m = __ballot(hit);
-      if (lane == 0) s_wave_count[wave] = __builtin_popcountll(m);
-      __syncthreads();
-      int offset = n, total = 0;
+      m[u] = __ballot(hit);
+      if (lane == 0) s_counts[trip][u * (kCoarseThreads / kWave) + wave] = __builtin_popcountll(m[u]);
+    }
+    __syncthreads();
+    int incl = s_counts[trip][lane];
+    const int own = incl;
 #pragma unroll
-      for (int w = 0; w < kCoarseThreads / kWave; ++w) {
-        const int c = s_wave_count[w];
-        if (w < wave) offset += c;
-        total += c;
-      }
-      if (hit) {
-        const int pos = offset + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
-                                                                __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+    for (int off = 1; off < kWave; off <<= 1) {
+      const int up = __shfl_up(incl, off);
+      if (lane >= off) incl += up;
+    }
+    const int excl = incl - own;
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int offset = n + __shfl(excl, u * (kCoarseThreads / kWave) + wave);
+      if ((m[u] >> lane) & 1ull) {
+        const int t = base + u * kCoarseThreads + tid;
+        const int pos = offset + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m[u] >> 32),
+                                                                __builtin_amdgcn_mbcnt_lo((unsigned)m[u], 0u));
         out[pos] = t;
         if (pos < kCellStash) {
           s_hit_box[pos] = make_uint2(bb[u].lr, bb[u].bt);
           s_hit_id[pos] = t;
         }
       }
-      n += total;
-      __syncthreads();
     }
+    n += __shfl(incl, kWave - 1);
   }
+  __syncthreads();  // the stash and the list are complete
   // The cell's depth split: midway between the smallest and the largest depth bound of its
   // triangles.  k_raster draws the triangles whose bound lies below it first ("near" class).
   // NaN = some triangle of the cell is not tame: its regions keep strict triangle-id order.
