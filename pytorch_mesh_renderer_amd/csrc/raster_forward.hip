@@ -206,10 +206,7 @@ __global__ __launch_bounds__(kThreads) void k_setup(
 // triangle-id order, the ids whose bbox touches the cell.  The raster kernel's regions
 // (4x4 per cell) then scan ~T * ((256 + d) / W)^2 ids instead of all T (d = triangle size).
 // ---------------------------------------------------------------------------------------
-#ifndef MR_CELL_REGIONS
-#define MR_CELL_REGIONS 4
-#endif
-constexpr int kCellRegions = MR_CELL_REGIONS;         // regions per cell edge (cell = 4 x 4 regions)
+constexpr int kCellRegions = 4;         // regions per cell edge (cell = 4 x 4 regions)
 constexpr int kCoarseThreads = 1024;
 // Second level: per raster REGION, the ids of its cell's list whose bbox touches the region (~60-100 of
 // the cell's ~400 at 1024^2 / 5k triangles), still in triangle-id order.  k_raster's bin stage then

@@ -197,10 +197,6 @@ typedef float lds_v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned lds_address(const float *p) {
   return (unsigned)(size_t)(const __attribute__((address_space(3))) float *)p;
 }
-__device__ __forceinline__ void lds_read_pair(unsigned addr_a, unsigned addr_b, lds_v2f &a, lds_v2f &b) {
-  asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %3\n\ts_waitcnt lgkmcnt(0)"
-               : "=&v"(a), "=&v"(b) : "v"(addr_a), "v"(addr_b) : "memory");
-}
 __device__ __forceinline__ void lds_read_pairs4(unsigned addr_a, unsigned addr_b, lds_v2f (&a)[4], lds_v2f (&b)[4]) {
   asm volatile(
       "ds_read_b64 %0, %8\n\tds_read_b64 %4, %9\n\t"
