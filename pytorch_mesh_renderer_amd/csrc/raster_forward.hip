@@ -12,9 +12,10 @@
 //             64-byte record; plus the binary64 pixel-centre tables (cpp:376-377);
 //             for mr_render_forward also the shading's corner record (corner_rec.h).
 //   k_coarse  one workgroup per (image, 256x256-pixel cell): id-ordered list of the
-//             triangles whose bbox touches the cell, and the cell's depth split.
+//             triangles whose bbox touches the cell, the cell's depth split, and -- second
+//             level -- the same list cut down once more for each of the cell's 4 x 4 regions.
 //   k_raster  one 256-thread workgroup per 64x64-pixel region (32x32 for small launches), two stages:
-//     bin    each wavefront scans a quarter of the image's triangle list (no barrier
+//     bin    each wavefront scans a quarter of the region's candidate list (no barrier
 //            in the loop): bbox-vs-region test, then an EXACT trivial reject -- the
 //            reference's own edge function evaluated at the region's most favourable
 //            pixel centre; fp32 multiply/add are monotone, so a negative value there
@@ -540,7 +541,7 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : MR_RASTER
   const size_t img_px = (size_t)img * H * W;
   // this region's coarse cell: the id-ordered list of triangles whose bbox touches it
   const int cell = (ry / kCellRegions) * cells_x + (rx / kCellRegions);
-  // ... or, where k_coarse_regions could fit it, the shorter list of those that touch this region
+  // ... or, where k_coarse's second level could fit it, the shorter list of those that touch this region
   const int region_n = region_count[region];  // workgroup-uniform
   const int32_t *cand = region_n >= 0 ? region_ids + (size_t)region * kRegionListCap
                                       : cell_ids + ((size_t)img * cells_per_image + cell) * T;
