@@ -149,7 +149,7 @@ struct AttrRowsFn {
   };
 
   __device__ __forceinline__ void begin_image(int, Image &) const {}
-  __device__ __forceinline__ void end_image(int, Image &) const {}
+  __device__ __forceinline__ void end_strip(int, int, Image &) const {}
   __device__ __forceinline__ void fetch(int, int, int, size_t pix, Raw &r) const {
     r.b = bary[pix];
     r.t = ids[pix];

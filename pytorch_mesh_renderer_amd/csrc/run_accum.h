@@ -27,7 +27,8 @@
 //     __device__ bool prepare(const Raw &, int T, int &tri, Pixel &) const;    // false: skip
 //     __device__ void load_triangle(int img, int tri, Triangle &) const;   // on run change
 //     __device__ void accumulate(const Pixel &, const Triangle &, float (&a)[kN], Image &) const;
-//     __device__ void end_image(int img, Image &) const;   // per-lane image-wide sums
+//     __device__ void end_image(int img, Image &) const;   // per-lane image-wide sums (k_accumulate_runs)
+//     __device__ void end_strip(int img, int strip, Image &) const;   // the same for k_accumulate_rows
 //   };
 // fetch() must not branch on loaded data: the kernel issues the NEXT pixel's fetch before
 // it evaluates the current one, so two pixels' loads are in flight per lane.
@@ -404,7 +405,55 @@ __global__ __launch_bounds__(kRowsThreads, Fn::kMinWavesPerSimd) void k_accumula
     __builtin_amdgcn_wave_barrier();
   }
   flush_merge_table();
-  fn.end_image(img, image_sums);
+  fn.end_strip(img, region, image_sums);
+}
+
+// Image-wide sums of the rows kernel's functors (light / camera gradients): every strip -- one per
+// workgroup, `region` above -- leaves ONE row of them, and this kernel adds an image's rows in a fixed
+// order.  (They used to be float atomics on the image's one row: every strip of an image queued up
+// on the same cache line; and the deterministic mode needed a fixed-point copy of the row.)
+// One workgroup per image; thread = (slot, part): 32 slots x 32 parts, eight loads in flight per thread
+// (with 8 parts and one load at a time this was a 128-deep chain of load latencies, 100 us).
+constexpr int kSumRowSlots = 32, kSumRowThreads = 1024;
+static __global__ __launch_bounds__(kSumRowThreads) void k_sum_strip_rows(const float *__restrict__ rows, int per_image,
+                                                                          int row, float *__restrict__ out) {
+  constexpr int kParts = kSumRowThreads / kSumRowSlots;
+  __shared__ float s_part[kParts][kSumRowSlots + 1];
+  const int img = (int)blockIdx.x, slot = (int)threadIdx.x % kSumRowSlots, part = (int)threadIdx.x / kSumRowSlots;
+  const float *mine = rows + (size_t)img * per_image * row;
+  float v = 0.0f;
+  if (slot < row) {
+    constexpr int kInFlight = 8;
+    for (int i = part; i < per_image; i += kParts * kInFlight) {
+      float x[kInFlight];
+#pragma unroll
+      for (int u = 0; u < kInFlight; ++u) {
+        const int k = i + u * kParts;
+        x[u] = k < per_image ? mine[(size_t)k * row + slot] : 0.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < kInFlight; ++u) v += x[u];
+    }
+  }
+  s_part[part][slot] = v;
+  __syncthreads();
+  if (part == 0 && slot < row) {
+    float t = 0.0f;
+    for (int k = 0; k < kParts; ++k) t += s_part[k][slot];
+    out[(size_t)img * row + slot] = t;
+  }
+}
+
+// strips (= workgroups = `region`s) of k_accumulate_rows<Fn> per image
+template <class Fn>
+inline int strips_per_image(int W, int H) {
+  constexpr int kRowsRegionH = Fn::kRowsPerWave * (kRowsThreads / kWave);
+  return ((W + kWave - 1) / kWave) * ((H + kRowsRegionH - 1) / kRowsRegionH);
+}
+inline int launch_sum_strip_rows(const float *rows, int B, int per_image, int row, float *out, hipStream_t s) {
+  if (row > kSumRowSlots) return MR_EINVAL;
+  hipLaunchKernelGGL(k_sum_strip_rows, dim3((unsigned)B), dim3(kSumRowThreads), 0, s, rows, per_image, row, out);
+  return check_launch();
 }
 
 // det_scale: nullptr = float atomics; else the device pair (2^k, 2^-k) of the deterministic mode and

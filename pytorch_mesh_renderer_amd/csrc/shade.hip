@@ -152,10 +152,8 @@ struct ShadeGradFn {
   const CornerRec *__restrict__ corners;
   const BwdRec *__restrict__ recs;
   Lights lights;
-  float *__restrict__ light_grads;    // [B][L*6 + 3]: dpos (L x 3), dcol (L x 3), dambient (3)
+  float *__restrict__ light_rows;     // LG: [strips][L*6 + 3] per strip: dpos (L x 3), dcol (L x 3), dambient (3)
   int T_, W, H;
-  long long *__restrict__ light_fixed;   // deterministic mode: the same sums in fixed point, else nullptr
-  const float *__restrict__ det_scale;   // deterministic mode: (2^k, 2^-k), see run_accum.h
 
   struct Pixel {
     F3 b, g;
@@ -315,19 +313,16 @@ struct ShadeGradFn {
     for (int k = kFactors; k < kFactorStride; ++k) f[k] = 0.f;
   }
 
-  __device__ __forceinline__ void end_image(int img, Image &im) const {
+  // the strip's row of light sums (k_sum_strip_rows adds an image's rows up, in a fixed order)
+  __device__ __forceinline__ void end_strip(int img, int strip, Image &im) const {
+    (void)img;
     if (!LG) return;
-    float *dst = light_grads + (size_t)img * (L * 6 + 3);
-    long long *dst_fixed = light_fixed ? light_fixed + (size_t)img * (L * 6 + 3) : nullptr;
-    const float to_fixed = light_fixed ? det_scale[0] : 0.0f;
+    float *dst = light_rows + (size_t)strip * (L * 6 + 3);
     const int lane = lane_id();
     auto reduce_add = [&](float v, int slot) {
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);  // fixed tree: deterministic
-      if (lane == 0 && v != 0.0f) {
-        if (dst_fixed) atomic_add_fixed(&dst_fixed[slot], v, to_fixed);
-        else atomicAdd(&dst[slot], v);
-      }
+      if (lane == 0) dst[slot] = v;
     };
 #pragma unroll
     for (int l = 0; l < L; ++l) {
@@ -337,10 +332,8 @@ struct ShadeGradFn {
         reduce_add(im.dcol[l][c], L * 3 + l * 3 + c);
       }
     }
-    if (lights.amb) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) reduce_add(im.damb[c], L * 6 + c);
-    }
+    for (int c = 0; c < 3; ++c) reduce_add(lights.amb ? im.damb[c] : 0.0f, L * 6 + c);
   }
 };
 
@@ -454,7 +447,10 @@ inline unsigned capped_blocks(size_t n) {
 // 8 bytes per element: room for the deterministic mode's fixed-point accumulators
 inline size_t shade_acc_bytes(int B, int T) { return align_up((size_t)B * T * 36 * sizeof(long long), 256); }
 constexpr size_t kDetMiscBytes = 512;  // det_scale (2 floats), max bits (1 int)
-inline size_t light_fixed_bytes(int B) { return align_up((size_t)B * (kMaxLights * 6 + 3) * sizeof(long long), 256); }
+// one row of light sums per strip of the pixel pass (the variant with light gradients walks 16-row strips)
+inline size_t light_rows_bytes(int B, int W, int H) {
+  return align_up((size_t)B * strips_per_image<ShadeGradFn<1, true, true>>(W, H) * (kMaxLights * 6 + 3) * sizeof(float), 256);
+}
 
 // ---- deterministic mode helpers -------------------------------------------------------------
 // largest |x| of an array as float bits (non-negative floats order like integers; a NaN sorts on top)
@@ -478,13 +474,6 @@ __global__ void k_det_scale(const int *__restrict__ max_bits, const float *__res
   const int k = min(max(41 - e, -100), 100);
   det_scale[0] = ldexpf(1.0f, k);
   det_scale[1] = ldexpf(1.0f, -k);
-}
-
-__global__ __launch_bounds__(kThreads) void k_light_from_fixed(const long long *__restrict__ fixed,
-                                                               const float *__restrict__ det_scale, int n,
-                                                               float *__restrict__ out) {
-  const int i = (int)(blockIdx.x * kThreads + threadIdx.x);
-  if (i < n) out[i] = (float)fixed[i] * det_scale[1];
 }
 
 inline size_t corner_bytes(int B, int T) { return align_up((size_t)B * T * sizeof(CornerRec), 256); }
@@ -530,7 +519,7 @@ int launch_shade_forward(const int32_t *ids, const float *bary, const float *nor
 size_t shade_backward_ws(int B, int V, int T, int W, int H) {
   (void)V; (void)W; (void)H;
   return shade_acc_bytes(B, T) + align_up((size_t)B * T * sizeof(BwdRec), 256) + corner_bytes(B, T) +
-         light_fixed_bytes(B) + kDetMiscBytes;
+         kDetMiscBytes + light_rows_bytes(B, W, H);
 }
 
 thread_local int g_deterministic = 0;  // mr_set_deterministic
@@ -575,15 +564,15 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
   float *acc = (float *)ws;
   BwdRec *recs = (BwdRec *)((char *)ws + shade_acc_bytes(B, T));
   CornerRec *corners = (CornerRec *)((char *)recs + align_up((size_t)B * T * sizeof(BwdRec), 256));
-  long long *light_fixed = (long long *)((char *)corners + corner_bytes(B, T));
-  float *det_scale = (float *)((char *)light_fixed + light_fixed_bytes(B));
+  float *det_scale = (float *)((char *)corners + corner_bytes(B, T));
   int *max_bits = (int *)(det_scale + 4);
+  float *light_rows = (float *)((char *)det_scale + kDetMiscBytes);
   if (det && !(vertex_offsets && vertex_entries)) return MR_EINVAL;  // the scatter path is atomics only
   const size_t acc_bytes = (size_t)B * T * 36 * (det ? sizeof(long long) : sizeof(float));
   if (!fused_clear && hipMemsetAsync(acc, 0, acc_bytes, s) != hipSuccess) return check_launch();
   int rc = MR_OK;
   if (det) {
-    if (hipMemsetAsync(light_fixed, 0, light_fixed_bytes(B) + kDetMiscBytes, s) != hipSuccess) return check_launch();
+    if (hipMemsetAsync(det_scale, 0, kDetMiscBytes, s) != hipSuccess) return check_launch();
     if (!signs) {
       const size_t n4 = (size_t)B * H * W;
       hipLaunchKernelGGL(k_abs_max, dim3(capped_blocks(n4)), dim3(kThreads), 0, s, (const float4 *)drgba, n4, max_bits);
@@ -608,20 +597,19 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
     KernelTimer timer(MR_TIMER_SHADE_BACKWARD, s);                                              \
     if (signs && light_grads) {                                                                 \
       ShadeGradFn<NL, true, true> fn{nullptr, signs, sign_upstream, sign_inv_n, ids, (const F3 *)bary, corners, \
-                                     recs, lights, light_grads, T, W, H, det ? light_fixed : nullptr, det_scale}; \
+                                     recs, lights, light_rows, T, W, H};                        \
       rc = launch_accumulate_rows(fn, B, T, W, H, acc, s, det ? det_scale : nullptr);           \
     } else if (signs) {                                                                         \
       ShadeGradFn<NL, true, false> fn{nullptr, signs, sign_upstream, sign_inv_n, ids, (const F3 *)bary, corners, \
-                                      recs, lights, nullptr, T, W, H, nullptr, det_scale};      \
+                                      recs, lights, nullptr, T, W, H};                          \
       rc = launch_accumulate_rows(fn, B, T, W, H, acc, s, det ? det_scale : nullptr);           \
     } else if (light_grads) {                                                                   \
       ShadeGradFn<NL, false, true> fn{(const float4 *)drgba, nullptr, nullptr, 0.0f, ids, (const F3 *)bary, \
-                                      corners, recs, lights, light_grads, T, W, H,              \
-                                      det ? light_fixed : nullptr, det_scale};                  \
+                                      corners, recs, lights, light_rows, T, W, H};              \
       rc = launch_accumulate_rows(fn, B, T, W, H, acc, s, det ? det_scale : nullptr);           \
     } else {                                                                                    \
       ShadeGradFn<NL, false, false> fn{(const float4 *)drgba, nullptr, nullptr, 0.0f, ids, (const F3 *)bary, \
-                                       corners, recs, lights, nullptr, T, W, H, nullptr, det_scale}; \
+                                       corners, recs, lights, nullptr, T, W, H};                \
       rc = launch_accumulate_rows(fn, B, T, W, H, acc, s, det ? det_scale : nullptr);           \
     }                                                                                           \
   }
@@ -634,17 +622,17 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
   }
 #undef MR_SHADE_BWD
   if (rc != MR_OK) return rc;
+  if (light_grads) {  // the strips' rows of light sums -> [B][6L + 3], fixed order (every element is written)
+    rc = launch_sum_strip_rows(light_rows, B, strips_per_image<ShadeGradFn<1, true, true>>(W, H), L * 6 + 3,
+                               light_grads, s);
+    if (rc != MR_OK) return rc;
+  }
   if (vertex_offsets && vertex_entries) {
     const long nbv = (long)B * V * 16;  // sixteen lanes per vertex
     const dim3 grid((unsigned)((nbv + kThreads - 1) / kThreads));
     if (det) {
       hipLaunchKernelGGL(k_shade_gather<true>, grid, dim3(kThreads), 0, s, acc, det_scale, vertex_offsets,
                          vertex_entries, B, V, T, dnormals, dpositions, ddiffuse, dclip, transforms);
-      if ((rc = check_launch()) != MR_OK) return rc;
-      const int n_light = light_grads ? B * (L * 6 + 3) : 0;
-      if (n_light > 0)
-      hipLaunchKernelGGL(k_light_from_fixed, dim3((unsigned)((n_light + kThreads - 1) / kThreads)), dim3(kThreads),
-                         0, s, light_fixed, det_scale, n_light, light_grads);
     } else {
       hipLaunchKernelGGL(k_shade_gather<false>, grid, dim3(kThreads), 0, s, acc, det_scale, vertex_offsets,
                          vertex_entries, B, V, T, dnormals, dpositions, ddiffuse, dclip, transforms);
