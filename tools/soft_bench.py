@@ -10,9 +10,9 @@ dev = torch.device("cuda:0")
 job = synthetic.sphere_job(B, W, H, 50)
 v = job["vertices"].to(dev).requires_grad_(True)
 tri, kd = job["triangles"].to(dev), job["diffuse"].to(dev)
-eyes, lp = job["eyes"].to(dev), job["light_positions"].to(dev)
+eyes, lp = job["eyes"], job["light_positions"].to(dev)   # cameras stay host tensors, as in the reference's usage (and bench.py)
 li = torch.ones(B, 1, device=dev)
-zero, up = torch.zeros(B, 3, device=dev), torch.tensor([0.0, 1.0, 0.0], device=dev)
+zero, up = torch.zeros(B, 3), torch.tensor([0.0, 1.0, 0.0])
 def step():
     v.grad = None
     img = soft_mesh_renderer.render(v, tri, kd, eyes, zero, up, lp, li, W, H)
