@@ -173,35 +173,74 @@ __global__ __launch_bounds__(kThreads) void k_export_u8(const float4 *__restrict
 // top: one integer atomicMax per workgroup also reproduces torch.max's NaN propagation; (2) the
 // powers are recomputed (cheaper than 4 B/element of scratch traffic), scaled with an IEEE
 // division as torch does, clamped, and stored as fp32 or straight as 8-bit frames.
+// FAST: gamma is finite.  For a finite positive base the power is exp2(gamma * log2(v)) on the 1-ulp
+// hardware v_log_f32 / v_exp_f32 (relative error <= (0.69 |gamma log2 v| + 1) 2^-23: below 4e-7 for the
+// values that survive the division by the image's maximum); zero with a positive exponent is zero;
+// everything else (negative, infinite, NaN bases; zero with gamma <= 0) takes powf and its special
+// cases, which is torch.pow's table.  (powf for every element made both passes instruction-bound:
+// 0.78 + 0.60 ms for 32 x 1024^2 x 4 where the data moves in 0.1 + 0.22.)
+template <bool FAST>
 __device__ __forceinline__ float tone_power(float v, float gamma) {
-  const float p = powf(v, gamma);
+  float p;
+  if (FAST && v > 0.0f && v < INFINITY) p = __builtin_amdgcn_exp2f(gamma * __builtin_amdgcn_logf(v));
+  else if (FAST && v == 0.0f && gamma > 0.0f) p = 0.0f;
+  else p = powf(v, gamma);
   return p != p ? __int_as_float(0x7fc00000) : p;  // canonical NaN: positive as an integer
 }
 
+// VEC: the image's element count is a multiple of four (every image then starts 16-byte aligned):
+// 16-byte accesses.  One integer atomicMax per WORKGROUP, ~2048 workgroups in all: with one per
+// wavefront of a 512-workgroup grid, 65k atomics queued up on the one cache line that holds all the
+// images' maxima.
+constexpr int kToneBlocks = 64;
+template <bool FAST, bool VEC>
 __global__ __launch_bounds__(kThreads) void k_tone_max(const float *__restrict__ image, size_t per_image,
                                                        float gamma, int *__restrict__ max_bits) {
   const float *img = image + (size_t)blockIdx.y * per_image;
   int best = 0;  // bits of +0.0
-  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < per_image; i += (size_t)gridDim.x * kThreads)
-    best = max(best, __float_as_int(tone_power(img[i], gamma)) & 0x7fffffff);  // (-0.0 -> +0.0)
+  auto take = [&](float v) { best = max(best, __float_as_int(tone_power<FAST>(v, gamma)) & 0x7fffffff); };  // (-0.0 -> +0.0)
+  if (VEC) {
+    const float4 *img4 = (const float4 *)img;
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < per_image / 4; i += (size_t)gridDim.x * kThreads) {
+      const float4 v = img4[i];
+      take(v.x); take(v.y); take(v.z); take(v.w);
+    }
+  } else {
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < per_image; i += (size_t)gridDim.x * kThreads)
+      take(img[i]);
+  }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) best = max(best, __shfl_down(best, off));
-  if ((threadIdx.x & (kWave - 1)) == 0 && best != 0) atomicMax(&max_bits[blockIdx.y], best);
+  __shared__ int s_best[kThreads / kWave];
+  if ((threadIdx.x & (kWave - 1)) == 0) s_best[threadIdx.x >> 6] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kThreads / kWave; ++w) best = max(best, s_best[w]);
+    if (best != 0) atomicMax(&max_bits[blockIdx.y], best);
+  }
 }
 
-template <bool U8>
+template <bool U8, bool FAST, bool VEC>
 __global__ __launch_bounds__(kThreads) void k_tone_map(const float *__restrict__ image, size_t per_image,
                                                        float gamma, const int *__restrict__ max_bits,
                                                        float *__restrict__ out, uint8_t *__restrict__ out_u8) {
   const size_t base = (size_t)blockIdx.y * per_image;
   const float image_max = __int_as_float(max_bits[blockIdx.y]);
-  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < per_image; i += (size_t)gridDim.x * kThreads) {
-    const float scaled = tone_power(image[base + i], gamma) / image_max;
-    if (U8) {
-      out_u8[base + i] = (uint8_t)to_u8(scaled);
-    } else {
-      // torch.clamp: NaN stays NaN
-      out[base + i] = scaled != scaled ? scaled : fminf(fmaxf(scaled, 0.0f), 1.0f);
+  auto scaled = [&](float v) { return tone_power<FAST>(v, gamma) / image_max; };  // IEEE division, as torch does
+  auto clamped = [](float x) { return x != x ? x : fminf(fmaxf(x, 0.0f), 1.0f); };  // torch.clamp: NaN stays NaN
+  if (VEC) {
+    const float4 *in4 = (const float4 *)(image + base);
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < per_image / 4; i += (size_t)gridDim.x * kThreads) {
+      const float4 v = in4[i];
+      const float a = scaled(v.x), b = scaled(v.y), c = scaled(v.z), d = scaled(v.w);
+      if (U8) ((uint32_t *)(out_u8 + base))[i] = to_u8(a) | (to_u8(b) << 8) | (to_u8(c) << 16) | (to_u8(d) << 24);
+      else ((float4 *)(out + base))[i] = make_float4(clamped(a), clamped(b), clamped(c), clamped(d));
+    }
+  } else {
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < per_image; i += (size_t)gridDim.x * kThreads) {
+      const float x = scaled(image[base + i]);
+      if (U8) out_u8[base + i] = (uint8_t)to_u8(x);
+      else out[base + i] = clamped(x);
     }
   }
 }
@@ -242,13 +281,28 @@ int launch_tone_map(const float *image, int B, size_t per_image, float gamma, in
                     uint8_t *out_u8, hipStream_t s) {
   if (B == 0 || per_image == 0) return MR_OK;
   if (hipMemsetAsync(max_bits, 0, (size_t)B * sizeof(int), s) != hipSuccess) return check_launch();
-  const size_t want = (per_image + kThreads - 1) / kThreads;
-  const dim3 grid((unsigned)(want < 512 ? want : 512), (unsigned)B);
-  hipLaunchKernelGGL(k_tone_max, grid, dim3(kThreads), 0, s, image, per_image, gamma, max_bits);
-  int rc = check_launch();
-  if (rc != MR_OK) return rc;
-  if (out_u8) hipLaunchKernelGGL(k_tone_map<true>, grid, dim3(kThreads), 0, s, image, per_image, gamma, max_bits, out, out_u8);
-  else hipLaunchKernelGGL(k_tone_map<false>, grid, dim3(kThreads), 0, s, image, per_image, gamma, max_bits, out, out_u8);
+  const bool vec = per_image % 4 == 0 && ((uintptr_t)image & 15u) == 0 && ((uintptr_t)out & 15u) == 0 &&
+                   ((uintptr_t)out_u8 & 3u) == 0;
+  const bool fast = gamma == gamma && gamma - gamma == 0.0f;  // finite
+  const size_t want = ((vec ? per_image / 4 : per_image) + kThreads - 1) / kThreads;
+  // ~2048 workgroups in all (a full chip of 256-thread workgroups), at least 8 and at most 512 per image
+  const size_t per = B >= 256 ? 8 : (size_t)(kToneBlocks * 32 / B < 512 ? kToneBlocks * 32 / B : 512);
+  const dim3 grid((unsigned)(want < per ? want : per), (unsigned)B);
+#define MR_TONE(FAST, VEC)                                                                                 \
+  {                                                                                                        \
+    hipLaunchKernelGGL((k_tone_max<FAST, VEC>), grid, dim3(kThreads), 0, s, image, per_image, gamma, max_bits); \
+    const int rc = check_launch();                                                                         \
+    if (rc != MR_OK) return rc;                                                                            \
+    if (out_u8) hipLaunchKernelGGL((k_tone_map<true, FAST, VEC>), grid, dim3(kThreads), 0, s, image, per_image, gamma, \
+                                   max_bits, out, out_u8);                                                 \
+    else hipLaunchKernelGGL((k_tone_map<false, FAST, VEC>), grid, dim3(kThreads), 0, s, image, per_image, gamma,      \
+                            max_bits, out, out_u8);                                                        \
+  }
+  if (fast && vec) MR_TONE(true, true)
+  else if (fast) MR_TONE(true, false)
+  else if (vec) MR_TONE(false, true)
+  else MR_TONE(false, false)
+#undef MR_TONE
   return check_launch();
 }
 
