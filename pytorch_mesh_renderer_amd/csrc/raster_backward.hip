@@ -180,7 +180,14 @@ __global__ __launch_bounds__(kThreads) void k_abs_max_f(const float *__restrict_
     best = max(best, __float_as_int(fabsf(x[i])));
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) best = max(best, __shfl_down(best, off));
-  if ((threadIdx.x & (kWave - 1)) == 0 && best != 0) atomicMax(max_bits, best);
+  // one atomic per WORKGROUP (thousands of wavefronts on one address queue up behind each other)
+  __shared__ int s_best[kThreads / kWave];
+  if ((threadIdx.x & (kWave - 1)) == 0) s_best[threadIdx.x >> 6] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kThreads / kWave; ++w) best = max(best, s_best[w]);
+    if (best != 0) atomicMax(max_bits, best);
+  }
 }
 
 __global__ void k_det_scale_from_max(const int *__restrict__ max_bits, float *__restrict__ det_scale) {
@@ -256,7 +263,7 @@ int launch_raster_backward(const float *dbary, const float *clip, const int32_t 
     if (hipMemsetAsync(dclip_fixed, 0, dclip_fixed_bytes(B, V) + 256, s) != hipSuccess) return check_launch();
     const size_t n = (size_t)B * H * W * 3;
     const size_t want = (n + kThreads - 1) / kThreads;
-    hipLaunchKernelGGL(k_abs_max_f, dim3((unsigned)(want < 8192 ? want : 8192)), dim3(kThreads), 0, s, dbary, n, max_bits);
+    hipLaunchKernelGGL(k_abs_max_f, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(kThreads), 0, s, dbary, n, max_bits);
     if ((rc = check_launch()) != MR_OK) return rc;
     hipLaunchKernelGGL(k_det_scale_from_max, dim3(1), dim3(1), 0, s, max_bits, det_scale);
     if ((rc = check_launch()) != MR_OK) return rc;

@@ -462,7 +462,14 @@ __global__ __launch_bounds__(kThreads) void k_abs_max(const float4 *__restrict__
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) best = max(best, __shfl_down(best, off));
-  if ((threadIdx.x & (kWave - 1)) == 0 && best != 0) atomicMax(max_bits, best);
+  // one atomic per WORKGROUP (thousands of wavefronts on one address queue up behind each other)
+  __shared__ int s_best[kThreads / kWave];
+  if ((threadIdx.x & (kWave - 1)) == 0) s_best[threadIdx.x >> 6] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kThreads / kWave; ++w) best = max(best, s_best[w]);
+    if (best != 0) atomicMax(max_bits, best);
+  }
 }
 
 // (2^k, 2^-k) with k such that the largest upstream gradient maps to about 2^41
@@ -575,7 +582,8 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
     if (hipMemsetAsync(det_scale, 0, kDetMiscBytes, s) != hipSuccess) return check_launch();
     if (!signs) {
       const size_t n4 = (size_t)B * H * W;
-      hipLaunchKernelGGL(k_abs_max, dim3(capped_blocks(n4)), dim3(kThreads), 0, s, (const float4 *)drgba, n4, max_bits);
+      const unsigned blocks = capped_blocks(n4) < 2048u ? capped_blocks(n4) : 2048u;
+      hipLaunchKernelGGL(k_abs_max, dim3(blocks), dim3(kThreads), 0, s, (const float4 *)drgba, n4, max_bits);
       if ((rc = check_launch()) != MR_OK) return rc;
     }
     hipLaunchKernelGGL(k_det_scale, dim3(1), dim3(1), 0, s, max_bits, sign_upstream, sign_inv_n, det_scale);
