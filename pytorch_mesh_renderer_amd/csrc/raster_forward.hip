@@ -244,8 +244,8 @@ __global__ __launch_bounds__(kCoarseThreads) void k_coarse(
   // after reading it.  (Two barriers per 1024 triangles before: 100 us at 50k triangles, 2048^2.)
   __shared__ int s_counts[2][kWave];
   int trip = 0;
-  // (Requesting the next trip's boxes a trip ahead changes nothing: at 50k triangles the kernel is bound
-  // by the L2 -> CU traffic of every cell reading every box, 64 cells x 50k x 16 B per image.)
+  // (Measured, no gain: requesting the next trip's boxes a trip ahead; keeping the hits in LDS and
+  // copying the list out at the end; skipping 64-triangle chunks by a union box -- see DESIGN.md 4.1.)
   for (int base = 0; base < T; base += kUnroll * kCoarseThreads, trip ^= 1) {
     TriBox bb[kUnroll];
 #pragma unroll
