@@ -483,6 +483,12 @@ struct RasterShade {
 #define MR_RASTER_STORE_AUX 2  // cache policy of the G-buffer / RGBA stores: 2 = nontemporal (written once, read by a
                                 // later kernel from HBM anyway): kernel -5 %, step -2 % against 0 (same-box A/B)
 #endif
+#ifndef MR_RASTER_STORE_AUX_IDS
+#define MR_RASTER_STORE_AUX_IDS 0  // the id plane alone through the caches: its 64-byte runs are the shortest of the tile's
+                                   // stores.  Same-box A/B, two boxes: fused kernel 0.261 -> 0.250 / 0.2496 -> 0.2483 ms,
+                                   // G-buffer kernel 0.189 -> 0.164 / 0.161 -> 0.160 (never slower; barycentrics or the
+                                   // depth plane cached: slower or equal)
+#endif
 #ifndef MR_RASTER_SHADE_WAVES
 #define MR_RASTER_SHADE_WAVES 6  // measured against 7 (more spills) and 5: 0.336 / 0.352 / 0.347 ms at 1024^2 x 32
 #endif
@@ -873,7 +879,7 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : MR_RASTER
         }
       }
       if (in_image && !((PROBE & 32) && st.z != 123.0f)) {  // 32: timing probe, no stores
-        __builtin_amdgcn_raw_buffer_store_b32((unsigned)max(st.id, 0), rs_ids, lane_pix * 4u, tile_pix * 4, MR_RASTER_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b32((unsigned)max(st.id, 0), rs_ids, lane_pix * 4u, tile_pix * 4, MR_RASTER_STORE_AUX_IDS);
         if (!SHADE || !last_round || shade.keep_z)  // workgroup-uniform
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, st.z), rs_z, lane_pix * 4u, tile_pix * 4, MR_RASTER_STORE_AUX);
         __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(v3u, v3f{st.b0, st.b1, st.b2}), rs_bary, lane_pix * 12u,
