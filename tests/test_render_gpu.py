@@ -441,6 +441,37 @@ def test_fused_specular_matches_composed_path(device, n_lights, ambient):
         np.testing.assert_allclose(grads_f[k], grads_c[k], atol=ATOL, rtol=0, err_msg=k)
 
 
+def test_image_wide_sums_are_bit_reproducible(device):
+    """The sums that run over a whole image -- the specular term's across-pixels norm, and the light,
+    ambient, camera and per-image shininess gradients -- are fixed-order sums of per-workgroup partials
+    (no float atomics): two runs give the same bits, in the default mode, with 4 lights and ambient."""
+    # light, ambient and shininess gradients; the image (through the norm)
+    shininess = torch.tensor([1.0, 2.5], device=device)
+    gen = torch.Generator().manual_seed(5)
+    target = torch.rand(2, 80, 96, 4, generator=gen).to(device)
+    runs = []
+    for _ in range(2):
+        job, scene = _specular_scene(device, 4, True)
+        shin = shininess.clone().requires_grad_(True)
+        img = _render_specular(job, scene, device, shin)
+        (torch.mean(torch.abs(img - target)) * 50.0).backward()
+        # (not the eye: its gradient also runs through the clip-space transform, i.e. through the
+        # per-triangle sums, which are float atomics outside the deterministic mode)
+        runs.append((img.detach(), [scene[k].grad for k in ("light_positions", "light_intensities", "ambient")]
+                     + [shin.grad]))
+        # ... and the diffuse path's light gradients (dense upstream)
+        job, scene = _specular_scene(device, 4, True)
+        img = mesh_renderer.render(
+            scene["vertices"], job["triangles"].to(device), scene["normals"], scene["diffuse"], scene["eye"],
+            torch.zeros(2, 3, device=device), torch.tensor([0.0, 1.0, 0.0], device=device),
+            scene["light_positions"], scene["light_intensities"], 96, 80, ambient_color=scene["ambient"])
+        torch.mean(torch.abs(img - target)).backward()
+        runs[-1][1].extend(scene[k].grad for k in ("light_positions", "light_intensities", "ambient"))
+    assert torch.equal(runs[0][0], runs[1][0])          # the image depends on the norm
+    for a, b in zip(runs[0][1], runs[1][1]):
+        assert a is not None and float(a.abs().max()) > 0 and torch.equal(a, b)
+
+
 @pytest.mark.parametrize("kind", ["vertex", "image", "scalar"])
 def test_fused_specular_shininess_gradient_matches_composed_path(device, kind):
     """A shininess that requires grad -- [B,V], [B] or 0-D -- through the fused kernels vs torch autograd
