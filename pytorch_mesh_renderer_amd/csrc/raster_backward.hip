@@ -143,6 +143,57 @@ struct RasterGradFn {
   }
 };
 
+// The same sums through the row kernel (run_accum.h, k_accumulate_rows): acc[j * 3 + c] = sum over the
+// triangle's pixels of b_j q_c is a product of two per-pixel factors, so the lanes park b[3] and q[3]
+// and nine reduction lanes form the products -- the structure the fused shading backward uses, with
+// its 8-row strips, per-wavefront merge table and one contiguous atomic per (strip, triangle).
+#ifndef MR_RASTER_BWD_ROWS
+#define MR_RASTER_BWD_ROWS 1
+#endif
+struct RasterRowsFn {
+  static constexpr int kN = 9;
+  static constexpr int kStride = mr::kStride;
+  static constexpr int kRowsPerWave = MR_ROWS_PER_WAVE;
+  static constexpr int kFactors = 6, kFactorStride = 8;
+  static constexpr int kMinWavesPerSimd = 6;
+  static constexpr bool kCountBackground = false;
+  __device__ static void factor_pair(int o, int &ia, int &ib) { ia = o / 3; ib = 3 + o % 3; }
+  const F3 *__restrict__ dbary;
+  const int32_t *__restrict__ ids;
+  const F3 *__restrict__ bary;
+  const BwdRec *__restrict__ recs;
+  int T_;
+  struct Pixel { F3 b, g; };
+  struct Raw { F3 b, g; int t; };
+  using Triangle = BwdTriangle;
+  struct Image { int n_bg; };
+  __device__ __forceinline__ void begin_image(int, Image &) const {}
+  __device__ __forceinline__ void end_strip(int, int, Image &) const {}
+  __device__ __forceinline__ void fetch(int, int, int, size_t pix, Raw &r) const {
+    r.t = __builtin_nontemporal_load(&ids[pix]);
+    r.b = load_streamed(&bary[pix]);
+    r.g = load_streamed(&dbary[pix]);
+  }
+  __device__ __forceinline__ bool prepare(const Raw &r, int T, int &tri, Pixel &p) const {
+    if ((unsigned)r.t >= (unsigned)T) return false;                             // foreign id
+    if (r.t == 0 && (r.b.x + r.b.y) + r.b.z < kDegenerateCutoff) return false;  // cpp:162
+    p.b = r.b;
+    p.g = r.g;
+    tri = r.t;
+    return true;
+  }
+  __device__ __forceinline__ void load_triangle(int img, int tri, Triangle &t) const {
+    load_bwd_triangle(recs + (size_t)img * T_ + tri, t);
+  }
+  __device__ __forceinline__ void factors(const Pixel &p, const Triangle &t, float (&f)[kFactorStride], Image &) const {
+    float q[3];
+    raster_pixel_q(p.b, p.g, t, t.inv, q);
+    f[0] = p.b.x; f[1] = p.b.y; f[2] = p.b.z;
+    f[3] = q[0]; f[4] = q[1]; f[5] = q[2];
+    f[6] = 0.f; f[7] = 0.f;
+  }
+};
+
 __global__ __launch_bounds__(kThreads) void k_bwd_scatter(
     const float *__restrict__ acc, const int32_t *__restrict__ tris, int B, int V, int T,
     float *__restrict__ dclip) {
@@ -282,7 +333,12 @@ int launch_raster_backward(const float *dbary, const float *clip, const int32_t 
   }
   {
     KernelTimer timer(MR_TIMER_RASTER_BACKWARD, s);
+#if MR_RASTER_BWD_ROWS
+    RasterRowsFn rows{(const F3 *)dbary, ids, (const F3 *)bary, recs, T};
+    rc = launch_accumulate_rows(rows, B, T, W, H, acc, s);
+#else
     rc = launch_accumulate_runs(fn, B, T, W, H, acc, s);
+#endif
   }
   if (rc != MR_OK) return rc;
   const long nbt = (long)B * T;
