@@ -28,6 +28,8 @@ Extra objects in the line:
                            measured with HIP events recorded around that kernel on its stream.
   roofline_shade_backward  same for the pixel pass of the fused shading backward, the kernel that
                            takes the largest share of the step (32 B/px read).
+  roofline_l1_forward      same for the loss's streaming pass (33 B/px): with the two above, the three
+                           kernels that make up 92 % of the step.
   cpu_baseline             the same step on the host cores for a bounded sample of the batch (torch-CPU
                            eager restatement of the reference's render path, oracle/shading.py, over the
                            reference's own compiled C++ kernel oracle/_ref when present), plus the
@@ -277,12 +279,14 @@ def main():
     n_ev = min(args.steps, 64)             # kernel timers on the first n_ev timed steps
     ev_raster = KernelEvents(n_ev, _native.TIMER_RASTER_FORWARD)
     ev_shade = KernelEvents(n_ev, _native.TIMER_SHADE_BACKWARD)
+    ev_l1 = KernelEvents(n_ev, _native.TIMER_L1_FORWARD)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         if i < n_ev:
             ev_raster.arm(i)
             ev_shade.arm(i)
+            ev_l1.arm(i)
         step()
     if gather is not None:
         gather.wait()                    # the last step's hand-over belongs to the timed region
@@ -344,6 +348,10 @@ def main():
             "roofline_shade_backward": roofline(
                 "k_accumulate_rows<ShadeGradFn> (fused shading backward, pixel pass)",
                 px * 17 + batch * T * (128 + 64), ev_shade.mean_ms(n_ev), "shade_backward", args.config),
+            # the loss: image and target read (2 x 16 B/px), the sign codes written (1 B/px)
+            "roofline_l1_forward": roofline(
+                "k_l1_forward (mean |image - target| and its sign codes, one streaming pass)",
+                px * 33, ev_l1.mean_ms(n_ev), "l1_forward", args.config),
         }
         if world == 1 and args.cpu_sample > 0:
             line["cpu_baseline"] = cpu_baseline(batch, width, height, sphere_k, args.cpu_sample)

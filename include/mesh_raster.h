@@ -394,7 +394,8 @@ int mr_set_deterministic(int on);
 #define MR_TIMER_SHADE_BACKWARD 1  /* the pixel pass of mr_shade_backward (fused shading backward)    */
 #define MR_TIMER_SHADE_FORWARD 2   /* the pixel pass of mr_shade_forward                              */
 #define MR_TIMER_RASTER_BACKWARD 3 /* the pixel pass of mr_rasterize_backward                         */
-#define MR_TIMER_COUNT 4
+#define MR_TIMER_L1_FORWARD 4      /* the streaming pass of mr_l1_loss_forward                        */
+#define MR_TIMER_COUNT 5
 int mr_time_next_kernel(int which, void *start_event, void *stop_event);
 
 #ifdef __cplusplus

@@ -17,7 +17,7 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.environ.get("MR_NATIVE_LIB_PATH") or os.path.join(_CSRC, "libmesh_raster_hip.so")
 
 ABI_VERSION = 332
-TIMER_RASTER_FORWARD, TIMER_SHADE_BACKWARD, TIMER_SHADE_FORWARD, TIMER_RASTER_BACKWARD = 0, 1, 2, 3
+TIMER_RASTER_FORWARD, TIMER_SHADE_BACKWARD, TIMER_SHADE_FORWARD, TIMER_RASTER_BACKWARD, TIMER_L1_FORWARD = 0, 1, 2, 3, 4
 MR_OK, MR_EINVAL, MR_EWORKSPACE, MR_ELAUNCH = 0, -1, -2, -3
 _ERR = {MR_EINVAL: "invalid argument", MR_EWORKSPACE: "workspace too small or misaligned",
         MR_ELAUNCH: "HIP launch failed"}
@@ -804,6 +804,7 @@ def l1_loss_forward(a, b, want_signs=True):
     signs = torch.empty((a.numel() + 3) // 4, dtype=torch.uint8, device=dev) if want_signs else None
     partials = torch.empty(2048, dtype=torch.float32, device=dev)   # MR_L1_PARTIALS
     with torch.cuda.device(dev):
+        _arm_timer(TIMER_L1_FORWARD)
         rc = lib().mr_l1_loss_forward(_ptr(a), _ptr(b), a.numel(), _ptr(out),
                                       _ptr(signs) if want_signs else None, _ptr(partials), _stream(dev))
     _check(rc, "mr_l1_loss_forward")

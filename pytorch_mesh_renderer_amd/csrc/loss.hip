@@ -260,9 +260,12 @@ int launch_l1_forward(const float *a, const float *b, size_t n, float *out, uint
   }
   const size_t n4 = n / 4;
   const unsigned blocks = blocks_for(n4);
-  hipLaunchKernelGGL(k_l1_forward, dim3(blocks), dim3(kThreads), 0, s, (const float4 *)a,
-                     (const float4 *)b, n4, a + 4 * n4, b + 4 * n4, (int)(n - 4 * n4), 1.0f / (float)n, partials,
-                     signs);
+  {
+    KernelTimer timer(MR_TIMER_L1_FORWARD, s);  // records only when a caller armed it
+    hipLaunchKernelGGL(k_l1_forward, dim3(blocks), dim3(kThreads), 0, s, (const float4 *)a,
+                       (const float4 *)b, n4, a + 4 * n4, b + 4 * n4, (int)(n - 4 * n4), 1.0f / (float)n, partials,
+                       signs);
+  }
   int rc = check_launch();
   if (rc != MR_OK) return rc;
   hipLaunchKernelGGL(k_l1_finish, dim3(1), dim3(kFinishThreads), 0, s, partials, (int)blocks, out);

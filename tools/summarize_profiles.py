@@ -79,6 +79,8 @@ out = {
                      "algorithmic_bytes": bench.get("roofline_gbuffer", {}).get("algorithmic_bytes")},
         "shade_backward": {"bytes_per_launch": traffic(raw["ShadeGradFn"]),
                            "algorithmic_bytes": bench.get("roofline_shade_backward", {}).get("algorithmic_bytes")},
+        "l1_forward": {"bytes_per_launch": traffic(raw["k_l1_forward"]),
+                       "algorithmic_bytes": bench.get("roofline_l1_forward", {}).get("algorithmic_bytes")},
     },
     "raw": raw,
 }
