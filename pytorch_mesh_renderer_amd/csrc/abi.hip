@@ -30,7 +30,7 @@ extern thread_local int g_deterministic;
 
 extern "C" {
 
-int mr_version(void) { return 332; /* 0.3.1: deterministic mode, tone map, vertex normals, sign-coded shading backward */ }
+int mr_version(void) { return 333; /* 0.3.3: deterministic mode, tone map, vertex normals, sign-coded shading backward, L1 timer */ }
 
 int mr_last_hip_error(void) { return mr::g_last_hip_error; }
 
