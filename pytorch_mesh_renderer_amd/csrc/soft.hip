@@ -288,7 +288,7 @@ __global__ __launch_bounds__(kCoarseThreads) void k_soft_coarse(
 }
 
 struct TileGeom {
-  int img, x, y, cell;
+  int img, x, y, cell, tile;  // tile: logical tile index over the whole batch
   bool in_image;
   float px, py, tx0, tx1, ty0, ty1;
 };
@@ -297,6 +297,7 @@ __device__ __forceinline__ bool tile_geometry(int W, int H, int tiles_x, int til
                                               int tiles_per_xcd, TileGeom &g) {
   const int tile = xcd_contiguous_block((int)blockIdx.x, n_tiles, tiles_per_xcd);
   if (tile < 0) return false;
+  g.tile = tile;
   g.img = tile / tiles_per_image;
   const int rr = tile - g.img * tiles_per_image;
   const int ty = rr / tiles_x, tx = rr - ty * tiles_x;
@@ -376,6 +377,7 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+constexpr int kLightRow = 16;  // floats per wavefront row of light sums (4 x kMaxLights)
 #ifndef MR_SOFT_BWD_WAVES
 #define MR_SOFT_BWD_WAVES 1
 #endif
@@ -386,8 +388,7 @@ __global__ __launch_bounds__(kThreads, MR_SOFT_BWD_WAVES) void k_soft_backward(
     int tiles_per_xcd, const int32_t *__restrict__ cell_ids, const int32_t *__restrict__ cell_count,
     int cells_per_image, const float4 *__restrict__ drgba, const float4 *__restrict__ rgba,
     const float4 *__restrict__ aux, float *__restrict__ dclip, float *__restrict__ dnormals,
-    float *__restrict__ dpositions, float *__restrict__ ddiffuse, float *__restrict__ dlpos,
-    float *__restrict__ dlint) {
+    float *__restrict__ dpositions, float *__restrict__ ddiffuse, float *__restrict__ light_rows) {
   __shared__ int s_list[kListCap];
   __shared__ int s_wave_count[kThreads / 64];
   TileGeom g;
@@ -627,16 +628,53 @@ __global__ __launch_bounds__(kThreads, MR_SOFT_BWD_WAVES) void k_soft_backward(
       __syncthreads();
     }
   }
+  // The light gradients leave as ONE row per wavefront -- [3L position sums | L intensity sums] -- and
+  // k_soft_light_sum adds an image's rows in a fixed order.  (As float atomics on the image's 4L
+  // addresses they were 0.7 ms of this kernel's 1.26 at 512^2 x 16: 4096 wavefronts per image queued
+  // up on one cache line.)
+  float *row = light_rows + ((size_t)g.tile * (kThreads / 64) + wave) * kLightRow;
 #pragma unroll
   for (int l = 0; l < kMaxLights; ++l) {
     if (l >= L) break;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const float s = wave_sum(g_lp[l][c]);
-      if (lane == 0 && s != 0.0f) atomicAdd(&dlpos[((size_t)g.img * L + l) * 3 + c], s);
+      if (lane == 0) row[l * 3 + c] = s;
     }
     const float s = wave_sum(g_li[l]);
-    if (lane == 0 && s != 0.0f) atomicAdd(&dlint[(size_t)g.img * L + l], s);
+    if (lane == 0) row[3 * L + l] = s;
+  }
+}
+
+// One workgroup per image: the fixed-order sum of its wavefronts' rows -> dlpos [B,L,3], dlint [B,L].
+constexpr int kLightSumThreads = 1024;
+__global__ __launch_bounds__(kLightSumThreads) void k_soft_light_sum(const float *__restrict__ rows, int per_image, int L,
+                                                                     float *__restrict__ dlpos, float *__restrict__ dlint) {
+  constexpr int kParts = kLightSumThreads / kLightRow;
+  __shared__ float s_part[kParts][kLightRow + 1];
+  const int img = (int)blockIdx.x, slot = (int)threadIdx.x % kLightRow, part = (int)threadIdx.x / kLightRow;
+  const float *mine = rows + (size_t)img * per_image * kLightRow;
+  float v = 0.0f;
+  if (slot < 4 * L) {
+    constexpr int kInFlight = 8;
+    for (int i = part; i < per_image; i += kParts * kInFlight) {
+      float x[kInFlight];
+#pragma unroll
+      for (int u = 0; u < kInFlight; ++u) {
+        const int k = i + u * kParts;
+        x[u] = k < per_image ? mine[(size_t)k * kLightRow + slot] : 0.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < kInFlight; ++u) v += x[u];
+    }
+  }
+  s_part[part][slot] = v;
+  __syncthreads();
+  if (part == 0 && slot < 4 * L) {
+    float t = 0.0f;
+    for (int k = 0; k < kParts; ++k) t += s_part[k][slot];
+    if (slot < 3 * L) dlpos[(size_t)img * 3 * L + slot] = t;
+    else dlint[(size_t)img * L + (slot - 3 * L)] = t;
   }
 }
 
@@ -675,10 +713,14 @@ inline size_t cell_count_bytes(int B, int W, int H) {
   return align_up((size_t)B * cell_grid(W, H).per_image * sizeof(int32_t), 256);
 }
 
+static size_t soft_light_rows_bytes(int B, int W, int H) {
+  return align_up((size_t)tile_grid(B, W, H).n_tiles * (kThreads / 64) * kLightRow * sizeof(float), 256);
+}
+
 size_t soft_ws(int B, int V, int T, int W, int H) {
   (void)V;
   return soft_rec_bytes(B, T) + align_up((size_t)B * T * sizeof(CornerRec), 256) + cell_ids_bytes(B, T, W, H) +
-         cell_count_bytes(B, W, H);
+         cell_count_bytes(B, W, H) + soft_light_rows_bytes(B, W, H);
 }
 
 // records, corner attributes and the coarse cell lists: the part the forward and the backward share
@@ -753,10 +795,15 @@ int launch_soft_backward(const float *drgba, const float *rgba, const float *aux
   if (rc != MR_OK) return rc;
   const TileGrid tg = tile_grid(B, W, H);
   const SoftParams pr{sigma, gamma, blur};
+  float *light_rows = (float *)((char *)cell_count + cell_count_bytes(B, W, H));
   hipLaunchKernelGGL(k_soft_backward, dim3((unsigned)(tg.per_xcd * kXcds)), dim3(kThreads), 0, s, recs,
                      corners, lpos, lint, tris, V, T, W, H, L, pr, tg.tiles_x, tg.per_image, tg.n_tiles,
                      tg.per_xcd, cell_ids, cell_count, cell_grid(W, H).per_image, (const float4 *)drgba, (const float4 *)rgba, (const float4 *)aux, dclip,
-                     dnormals, dpositions, ddiffuse, dlpos, dlint);
+                     dnormals, dpositions, ddiffuse, light_rows);
+  const int rc2 = check_launch();
+  if (rc2 != MR_OK) return rc2;
+  hipLaunchKernelGGL(k_soft_light_sum, dim3((unsigned)B), dim3(kLightSumThreads), 0, s, light_rows,
+                     tg.per_image * (kThreads / 64), L, dlpos, dlint);
   return check_launch();
 }
 
