@@ -193,7 +193,12 @@ int mr_render_forward(const float *vertices, const float *transforms, const floa
  *   drgba        [B,H,W,4] f32  dL/d(rgba); the alpha channel's gradient is ignored
  *   clip         [B,V,4]   f32  the clip-space vertices the G-buffer was made from
  *   dclip        [B,V,4]   f32 out  through the barycentrics (column z stays 0)
- *   dnormals, dpositions, ddiffuse [B,V,3] f32 out  through the interpolated attributes
+ *   dnormals, dpositions, ddiffuse [B,V,3] f32 out  through the interpolated attributes.
+ *                               dnormals and / or ddiffuse may be NULL (with the vertex adjacency):
+ *                               that gradient is not wanted -- autograd's needs_input_grad -- and its
+ *                               nine sums per triangle are not formed; without light_grads the pixel
+ *                               pass then keeps the 18 or 27 remaining products in registers down each
+ *                               lane's vertical run (k_accumulate_lanes) instead of reducing 36 per row
  *   light_grads  [B, 6L+3] f32 out  per image: d light_positions (L x 3),
  *                               d light_intensities (L x 3), d ambient (3; 0 if NULL).
  *                               NULL: not wanted -- an instantiation without the nine per-lane

@@ -21,6 +21,13 @@ extern "C" {
  * either way; the workspace query follows the setting, so set it before querying. */
 int mr_debug_set_raster_region_edge(int edge);
 
+/* Pixel kernel of mr_shade_backward / mr_shade_backward_l1 for the calling thread's next launches:
+ * 0 = automatic (default: the lane-accumulating kernel when dnormals or ddiffuse is NULL, no
+ * light_grads and not the deterministic mode; the rows kernel otherwise), 1 = always the rows kernel
+ * (all 36 sums are formed, unwanted outputs are just not written), 2 = the lane-accumulating kernel
+ * wherever it is instantiated.  For the parity tests, which compare the two on the same inputs. */
+int mr_debug_set_shade_backward_kernel(int which);
+
 /* Stage-timing probes of k_raster.  Only a library built with -DMR_PROBES (make probes ->
  * libmesh_raster_hip_probes.so) contains the probe instantiations; the production library
  * returns MR_EINVAL for every value but 0, its kernel has no probe code at all.

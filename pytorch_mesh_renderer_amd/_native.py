@@ -46,6 +46,19 @@ def _sync_deterministic():
     lib().mr_set_deterministic(1 if _deterministic else 0)
 
 
+# Test / measurement hook (include/mesh_raster_debug.h): pixel kernel of the shading backward --
+# 0 automatic, 1 the rows kernel, 2 the lane-accumulating kernel wherever it exists.  Like the
+# deterministic flag it is handed over by the launching thread.
+_shade_backward_kernel = int(os.environ.get("MR_SHADE_BACKWARD_KERNEL", "0"))
+
+
+def debug_set_shade_backward_kernel(which):
+    global _shade_backward_kernel
+    before = _shade_backward_kernel
+    _shade_backward_kernel = int(which)
+    return before
+
+
 def time_next_kernel(which, start_event, stop_event):
     """Measurement (bench.py): HIP events (ctypes.c_void_p) to record around the NEXT launch of
     kernel `which` (TIMER_*) made through this module, from whatever thread makes it -- autograd runs
@@ -99,6 +112,8 @@ def lib():
         L.mr_debug_set_raster_probe.restype = ci
         L.mr_debug_set_raster_region_edge.argtypes = [ci]
         L.mr_debug_set_raster_region_edge.restype = ci
+        L.mr_debug_set_shade_backward_kernel.argtypes = [ci]
+        L.mr_debug_set_shade_backward_kernel.restype = ci
         L.mr_rasterize_forward_workspace_bytes.argtypes = [ci] * 5
         L.mr_rasterize_forward_workspace_bytes.restype = sz
         L.mr_rasterize_forward.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, sz, vp]
@@ -558,10 +573,12 @@ def vertex_adjacency(triangles, vertex_count):
 
 def shade_backward(drgba, ids, bary, clip, normals, positions, diffuse, triangles, light_positions,
                    light_intensities, ambient, corner_records=None, adjacency=None, l1_signs=None,
-                   transforms=None, want_light_grads=True):
+                   transforms=None, want_light_grads=True, want_normal_grads=True, want_diffuse_grads=True):
     """-> (dclip [B,V,4], dnormals, dpositions, ddiffuse [B,V,3], dlight_positions,
     dlight_intensities [B,L,3], dambient [B,3] or None); with want_light_grads=False the last three
-    are None and the kernel leaves their accumulation out.
+    are None and the kernel leaves their accumulation out; want_normal_grads / want_diffuse_grads=False
+    (needs `adjacency`) return None for that gradient and its sums are not formed either -- the
+    backward then runs the lane-accumulating kernel (18 or 27 sums per triangle instead of 36).
 
     transforms ([B,4,4], needs `adjacency`): clip = transforms . (positions, 1); dpositions then also
     holds the clip-space gradient pulled back through that product (the whole d / d world vertices).
@@ -603,12 +620,19 @@ def shade_backward(drgba, ids, bary, clip, normals, positions, diffuse, triangle
     dp = flat[n4 + n3:n4 + 2 * n3].view(B, V, 3)
     dd = flat[n4 + 2 * n3:n4 + 3 * n3].view(B, V, 3)
     lg = flat[n4 + 3 * n3:].view(B, 6 * nl + 3) if want_light_grads else None
+    if adjacency is None and not (want_normal_grads and want_diffuse_grads):
+        raise ValueError("leaving a gradient out needs the per-vertex gather: pass the adjacency")
+    if not want_normal_grads:
+        dn = None
+    if not want_diffuse_grads:
+        dd = None
     tail = (B, V, T, W, H, nl, _ptr(dclip), _ptr(dn), _ptr(dp), _ptr(dd), _ptr(lg), _ptr(corner_records),
             _ptr(adjacency[0]) if adjacency is not None else None,
             _ptr(adjacency[1]) if adjacency is not None else None, _ptr(transforms))
     with torch.cuda.device(dev):
         _arm_timer(TIMER_SHADE_BACKWARD)
         _sync_deterministic()
+        L.mr_debug_set_shade_backward_kernel(_shade_backward_kernel)
         if l1_signs is not None:
             if l1_signs.dtype != torch.uint8 or l1_signs.numel() != B * H * W or drgba.numel() != 1:
                 raise ValueError("l1_signs must hold one byte per pixel and drgba the scalar upstream gradient")

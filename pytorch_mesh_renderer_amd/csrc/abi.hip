@@ -26,6 +26,7 @@ extern thread_local int g_raster_probe;
 #endif
 thread_local KernelTimerSlot g_kernel_timers[MR_TIMER_COUNT];
 extern thread_local int g_deterministic;
+extern thread_local int g_shade_backward_kernel;
 }
 
 extern "C" {
@@ -52,6 +53,12 @@ int mr_time_next_kernel(int which, void *start_event, void *stop_event) {
 int mr_debug_set_raster_region_edge(int edge) {
   if (edge != 0 && edge != 32 && edge != 64) return MR_EINVAL;
   mr::g_raster_region_edge = edge;
+  return MR_OK;
+}
+
+int mr_debug_set_shade_backward_kernel(int which) {
+  if (which < 0 || which > 2) return MR_EINVAL;
+  mr::g_shade_backward_kernel = which;
   return MR_OK;
 }
 
@@ -259,8 +266,9 @@ int mr_shade_backward(const float *drgba, const int32_t *ids, const float *bary,
     return MR_EINVAL;
   if (B == 0) return MR_OK;
   if (!drgba || !ids || !bary || !clip || !normals || !positions || !diffuse || !triangles ||
-      !light_positions || !light_intensities || !dclip || !dnormals || !dpositions || !ddiffuse)
+      !light_positions || !light_intensities || !dclip || !dpositions)
     return MR_EINVAL;
+  if ((!dnormals || !ddiffuse) && !vertex_offsets) return MR_EINVAL;  /* only the per-vertex gather can leave outputs out */
   if (((uintptr_t)corner_records & 127u) != 0) return MR_EINVAL;
   if ((vertex_offsets == nullptr) != (vertex_entries == nullptr)) return MR_EINVAL;
   if (vertex_offsets && ((uintptr_t)dclip & 15u) != 0) return MR_EINVAL;
@@ -291,8 +299,9 @@ int mr_shade_backward_l1(const uint8_t *signs, const float *upstream, const int3
     return MR_EINVAL;
   if (B == 0) return MR_OK;
   if (!signs || !upstream || !ids || !bary || !clip || !normals || !positions || !diffuse || !triangles ||
-      !light_positions || !light_intensities || !dclip || !dnormals || !dpositions || !ddiffuse)
+      !light_positions || !light_intensities || !dclip || !dpositions)
     return MR_EINVAL;
+  if ((!dnormals || !ddiffuse) && !vertex_offsets) return MR_EINVAL;  /* only the per-vertex gather can leave outputs out */
   if (((uintptr_t)corner_records & 127u) != 0) return MR_EINVAL;
   if ((vertex_offsets == nullptr) != (vertex_entries == nullptr)) return MR_EINVAL;
   if (vertex_offsets && ((uintptr_t)dclip & 15u) != 0) return MR_EINVAL;

@@ -209,6 +209,18 @@ __device__ __forceinline__ void lds_read_pairs4(unsigned addr_a, unsigned addr_b
       : "v"(addr_a), "v"(addr_b) : "memory");
 }
 
+// Round 3: the reduction's inner loop used to be "8 reads, s_waitcnt lgkmcnt(0), 8 dependent
+// FMAs" (lds_read_pairs4 above): at four wavefronts per SIMD nothing hid the LDS round trip of a
+// group and the loop ran at ~4.8 clocks per instruction.  It is software-pipelined now -- the next
+// group's reads are in flight while this group is summed -- with reads the COMPILER can count
+// (hand-issued reads in inline assembly made the register allocator copy registers whose loads
+// were still in flight): 16-byte reads, which it cannot pair into ds_read2 (rows are 16-byte
+// aligned for that: stride 76 floats).
+__device__ __forceinline__ float4 lds_read4(const float *p) { return *(const float4 *)p; }
+#ifndef MR_ROWS_PIPELINE
+#define MR_ROWS_PIPELINE 1
+#endif
+
 // Fn::kRowsPerWave: rows a wavefront of k_accumulate_rows walks down its 64-pixel-wide strip.  Short
 // strips balance the load (background rows cost almost nothing, silhouette strips a lot) better than
 // long ones amortise the merge table: measured at 1024^2 x 32, shading backward: 4 -> 0.417,
@@ -235,8 +247,12 @@ __global__ __launch_bounds__(kRowsThreads, Fn::kMinWavesPerSimd) void k_accumula
   // reducing lane fetches TWO consecutive pixels of its factor with one ds_read_b64 (256 B/clk
   // instead of the 128 B/clk of ds_read_b32: the reduction is bound by LDS reads).  Row stride 74
   // floats: consecutive rows start 10 banks apart (mod 64: 32 distinct even offsets), pairs never
-  // collide; 6 spare columns behind a row absorb the last batch's over-read.
-  constexpr int kRowStride = 74;
+  // collide; the spare columns behind a row absorb the over-read of one group behind the last.
+  // Stride 76 (round 3, 16-byte reads): rows start 12 banks apart; in every 16-lane group of a
+  // ds_read_b128 the lanes address at most 11 distinct rows whose 4-bank windows are disjoint, and
+  // lanes on the same row read the same address (broadcast): conflict-free (checked per lane group
+  // for the factor pairs of all three functors' layouts: rows 0..2 and 3..15).
+  constexpr int kRowStride = MR_ROWS_PIPELINE ? 76 : 74;
   static_assert(Fn::kFactors <= 32, "bank layout of the parked rows: 32 distinct even bank offsets");
   __shared__ __attribute__((aligned(16))) float s_stage[kRowsThreads / kWave][Fn::kFactors * kRowStride];
   // Per-wavefront merge table: a triangle's segments of consecutive rows are summed here, in LDS,
@@ -343,13 +359,13 @@ __global__ __launch_bounds__(kRowsThreads, Fn::kMinWavesPerSimd) void k_accumula
     int cur_t = -1;           // triangle of the running segment, wave-uniform
     int cur_slot = -1;        // its merge-table slot, claimed when the segment starts (-1: none) ...
     float merged = 0.0f;      // ... and that slot's value so far, requested at the same time
-    float sum = 0.0f;
+    float sum = 0.0f, sum2 = 0.0f;  // two chains (even / odd pixels): a dependent FMA issues every ~6.6 clocks, an independent one every 4
     auto close_segment = [&]() {
 #if MR_PROBE_ROWS == 1  // timing probe: reduction but no global atomics
-      if (cur_t >= 0 && lane < N && sum == 123.456f) atomicAdd(&acc_img[(size_t)cur_t * STRIDE + lane], sum);
+      if (cur_t >= 0 && lane < N && sum + sum2 == 123.456f) atomicAdd(&acc_img[(size_t)cur_t * STRIDE + lane], sum);
 #else
-      if (cur_slot >= 0) merge[cur_slot * kWave + lane] = merged + sum;
-      else if (cur_t >= 0) commit(cur_t, sum);  // no table, or more segments in one row than it has slots
+      if (cur_slot >= 0) merge[cur_slot * kWave + lane] = merged + (sum + sum2);
+      else if (cur_t >= 0) commit(cur_t, sum + sum2);  // no table, or more segments in one row than it has slots
 #endif
     };
     auto open_segment = [&](const int pixel) {
@@ -360,6 +376,11 @@ __global__ __launch_bounds__(kRowsThreads, Fn::kMinWavesPerSimd) void k_accumula
       if (hit) {
         cur_slot = __builtin_ctz(hit);
         merged = merge[cur_slot * kWave + lane];
+#if MR_ROWS_PIPELINE
+        // land it here: carried in flight, the compiler waits for it -- with lgkmcnt(0), draining
+        // the rolling reads -- at the loop-carried copies of EVERY later group
+        asm volatile("" : "+v"(merged));
+#endif
       } else if (merge_count < kMergeSlots) {  // (the table was emptied before the pass if it was short of room)
         cur_slot = merge_count;
         if (lane == merge_count) merge_keys = cur_t;
@@ -368,42 +389,267 @@ __global__ __launch_bounds__(kRowsThreads, Fn::kMinWavesPerSimd) void k_accumula
         cur_slot = -1;
       }
       sum = 0.0f;
+      sum2 = 0.0f;
     };
     // each head may claim a slot of the merge table: if they might not all fit, everything in the
     // table leaves now (once per row at most, instead of a check per segment)
     if (kMergeSlots > 0 && merge_count + (int)__builtin_popcountll(heads) > kMergeSlots) flush_merge_table();
     const int first_group = heads ? (int)(__builtin_ctzll(heads) >> 3) : 8;
     const int last_group = valids ? (63 - (int)__builtin_clzll(valids)) >> 3 : -1;
-    // Runs of head-free groups go through a loop of their own (8 reads, 8 FMAs, two address
-    // increments: as one loop with the head handling, the compiler spent 14 scalar and 12 vector
-    // instructions per group on loop-carried copies of the segment state).
-    for (int g = first_group; g <= last_group;) {
-      const unsigned long long rest = heads >> (8 * g);  // heads at or after group g
-      const int plain = min(rest ? (int)(__builtin_ctzll(rest) >> 3) : 8, last_group + 1 - g);
-      unsigned addr_a = row_a + 32u * g, addr_b = row_b + 32u * g;
-      for (int k = 0; k < plain; ++k, addr_a += 32u, addr_b += 32u) {
-        v2f ra[4], rb[4];
-        lds_read_pairs4(addr_a, addr_b, ra, rb);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) sum = fmaf(ra[j].y, rb[j].y, fmaf(ra[j].x, rb[j].x, sum));
+#if MR_ROWS_PIPELINE
+    // ONE pass over the row's pixels in groups of eight with ROLLING reads: as soon as four pixels
+    // of both factors are summed, the same registers are requested again for the pixels eight
+    // further on, so two of the four 16-byte reads of a group are always in flight under the FMAs
+    // (one loop body, no unrolling: nothing is copied between register sets).  The reads behind
+    // the last group land in the row's spare columns.
+    static_assert(kRowStride >= 72 && kRowStride % 4 == 0, "over-read of one group behind the row; 16-byte rows");
+    if (first_group <= last_group) {
+      const float *pa = stage + ia * kRowStride + 8 * first_group, *pb = stage + ib * kRowStride + 8 * first_group;
+      float4 a0 = lds_read4(pa), b0 = lds_read4(pb), a1 = lds_read4(pa + 4), b1 = lds_read4(pb + 4);
+      for (int g = first_group; g <= last_group; ++g, pa += 8, pb += 8) {
+        const unsigned hg = (unsigned)(heads >> (8 * g)) & 0xffu;
+        if (hg == 0u) {  // no segment starts in this group: eight FMAs straight
+          sum = fmaf(a0.x, b0.x, sum); sum2 = fmaf(a0.y, b0.y, sum2);
+          sum = fmaf(a0.z, b0.z, sum); sum2 = fmaf(a0.w, b0.w, sum2);
+          a0 = lds_read4(pa + 8); b0 = lds_read4(pb + 8);
+          sum = fmaf(a1.x, b1.x, sum); sum2 = fmaf(a1.y, b1.y, sum2);
+          sum = fmaf(a1.z, b1.z, sum); sum2 = fmaf(a1.w, b1.w, sum2);
+          a1 = lds_read4(pa + 12); b1 = lds_read4(pb + 12);
+        } else {
+          if (hg & 1u) open_segment(8 * g);
+          sum = fmaf(a0.x, b0.x, sum);
+          if (hg & 2u) open_segment(8 * g + 1);
+          sum2 = fmaf(a0.y, b0.y, sum2);
+          if (hg & 4u) open_segment(8 * g + 2);
+          sum = fmaf(a0.z, b0.z, sum);
+          if (hg & 8u) open_segment(8 * g + 3);
+          sum2 = fmaf(a0.w, b0.w, sum2);
+          a0 = lds_read4(pa + 8); b0 = lds_read4(pb + 8);
+          if (hg & 16u) open_segment(8 * g + 4);
+          sum = fmaf(a1.x, b1.x, sum);
+          if (hg & 32u) open_segment(8 * g + 5);
+          sum2 = fmaf(a1.y, b1.y, sum2);
+          if (hg & 64u) open_segment(8 * g + 6);
+          sum = fmaf(a1.z, b1.z, sum);
+          if (hg & 128u) open_segment(8 * g + 7);
+          sum2 = fmaf(a1.w, b1.w, sum2);
+          a1 = lds_read4(pa + 12); b1 = lds_read4(pb + 12);
+        }
       }
-      g += plain;
-      if (g > last_group) break;
-      v2f ra[4], rb[4];  // group g holds a head
-      lds_read_pairs4(addr_a, addr_b, ra, rb);
+    }
+#else
+    for (int g = first_group; g <= last_group; ++g) {
+      v2f ra[4], rb[4];
+      lds_read_pairs4(row_a + 32u * g, row_b + 32u * g, ra, rb);
       const unsigned hg = (unsigned)(heads >> (8 * g)) & 0xffu;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         if (hg & (1u << (2 * j))) open_segment(8 * g + 2 * j);
         sum = fmaf(ra[j].x, rb[j].x, sum);
         if (hg & (2u << (2 * j))) open_segment(8 * g + 2 * j + 1);
-        sum = fmaf(ra[j].y, rb[j].y, sum);
+        sum2 = fmaf(ra[j].y, rb[j].y, sum2);
       }
-      ++g;
     }
+#endif
     close_segment();
     __builtin_amdgcn_wave_barrier();
   }
+  flush_merge_table();
+  fn.end_strip(img, region, image_sums);
+}
+
+// ---------------------------------------------------------------------------------------
+// Lane-accumulating variant (round 3) for functors with few sums per triangle (N <= ~27).
+//
+// The rows kernel above spends one reduction step per PIXEL (64 per row: ~230 issued instructions
+// and eight exposed LDS round trips per 64-pixel row, as much as the pixel math itself).  Here every
+// lane adds its pixel's N products to N REGISTER accumulators for as long as it stays on one
+// triangle walking down its column -- N FMAs per row -- and only a FINISHED vertical run (the
+// triangle under the lane changed, or the strip ended) goes through LDS: the lane parks its N sums,
+// and lanes 0..N-1 walk the finished lanes of this row -- one add per finished lane, ~7 per row at
+// 1024^2 / 5k triangles instead of 64 -- merging neighbours that finished the same triangle and
+// committing through the same per-wavefront merge table as the rows kernel.
+//
+// Functor interface as for k_accumulate_runs (accumulate() adds the pixel's N products to a[]) plus
+//   static int column(int o);          // float of the triangle's acc row that sum o belongs to
+//   static constexpr int kLaneRowsPerWave;
+#ifndef MR_PROBE_LANES
+#define MR_PROBE_LANES 0
+#endif
+#ifndef MR_LANES_LOAD_FIRST
+#define MR_LANES_LOAD_FIRST 1
+#endif
+#ifndef MR_LANES_MERGE_SLOTS
+#define MR_LANES_MERGE_SLOTS 16
+#endif
+constexpr int lanes_park_stride(int n) {  // multiple of 4 with an odd number of quads: per-lane b128 accesses are conflict-free
+  int s = (n + 3) / 4;
+  if (s % 2 == 0) s += 1;
+  return s * 4;
+}
+
+template <class Fn, bool DET>
+__global__ __launch_bounds__(kWave, Fn::kMinWavesPerSimd) void k_accumulate_lanes(
+    Fn fn, int T, int W, int H, int regions_x, int regions_per_image, int n_regions,
+    int regions_per_xcd, float *__restrict__ acc, const float *__restrict__ det_scale) {
+  constexpr int N = Fn::kN, STRIDE = Fn::kStride, P = lanes_park_stride(N);
+  static_assert(N <= kWave && N <= STRIDE, "one reduction lane per sum");
+  __shared__ __attribute__((aligned(16))) float s_park[kWave * P];
+  constexpr int kMergeSlots = MR_LANES_MERGE_SLOTS;
+  static_assert(kMergeSlots >= 1 && kMergeSlots <= kWave, "lane i of merge_keys holds slot i's triangle");
+  __shared__ float s_merge[kMergeSlots * kWave];
+
+  const int region = xcd_contiguous_block((int)blockIdx.x, n_regions, regions_per_xcd);
+  if (region < 0) return;
+  const int img = region / regions_per_image;
+  const int rr = region - img * regions_per_image;
+  const int ry = rr / regions_x;
+  const int rx = rr - ry * regions_x;
+
+  const int lane = (int)threadIdx.x;
+  const int x = rx * kWave + lane;
+  const bool in_range = x < W;
+  const int xc = in_range ? x : W - 1;
+  constexpr int kRowsPerWave = Fn::kLaneRowsPerWave;
+  const int y_begin = ry * kRowsPerWave;
+  const int y_end = min(y_begin + kRowsPerWave, H);
+  float *acc_img = acc + (size_t)img * T * STRIDE;
+  long long *acc_fixed = (long long *)acc + (size_t)img * T * STRIDE;  // DET: 8-byte elements
+  const float to_fixed = DET ? det_scale[0] : 0.0f;
+  const int red = min(lane, N - 1);     // the sum this lane reduces (lanes >= N idle along on a copy)
+  const int col = Fn::column(red);      // ... and its float inside the triangle's acc row
+
+  int merge_keys = -1;   // lane i < kMergeSlots: triangle id held by slot i (-1: free)
+  int merge_count = 0;   // slots in use, wave-uniform
+  auto commit = [&](const int t, const float v) {
+    if (lane < N) {
+      if (DET) atomic_add_fixed(&acc_fixed[(size_t)t * STRIDE + col], v, to_fixed);
+      else atomicAdd(&acc_img[(size_t)t * STRIDE + col], v);
+    }
+  };
+  auto flush_merge_table = [&]() {
+#pragma unroll 1
+    for (int slot = 0; slot < merge_count; ++slot)
+      commit(__builtin_amdgcn_readlane(merge_keys, slot), s_merge[slot * kWave + lane]);
+    merge_count = 0;
+    merge_keys = -1;
+  };
+
+  typename Fn::Image image_sums;
+  fn.begin_image(img, image_sums);
+  float a[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) a[k] = 0.0f;
+  int run_tri = -1;    // triangle the lane's sums belong to (-1: the sums are zero)
+  int data_tri = -1;   // triangle whose records the lane holds
+  typename Fn::Triangle tri_data;
+
+  // Finished runs: park, reduce over the finished lanes, restart.
+  auto flush = [&](const bool fin) {
+    const unsigned long long finm = __ballot(fin);
+    if (!finm) return;
+    if (fin) {
+      float4 *dst = (float4 *)(s_park + lane * P);
+#pragma unroll
+      for (int q = 0; q < (N + 3) / 4; ++q)
+        dst[q] = make_float4(a[4 * q], 4 * q + 1 < N ? a[4 * q + 1] : 0.f, 4 * q + 2 < N ? a[4 * q + 2] : 0.f,
+                             4 * q + 3 < N ? a[4 * q + 3] : 0.f);
+#pragma unroll
+      for (int k = 0; k < N; ++k) a[k] = 0.0f;
+    }
+    const int old = run_tri;
+    if (fin) run_tri = -1;
+    __builtin_amdgcn_wave_barrier();  // LDS executes one wavefront's operations in order
+    int cur_t = -1, cur_slot = -1;    // triangle of the running segment and its merge-table slot
+    float merged = 0.0f, sum = 0.0f;
+    auto close_segment = [&]() {
+      if (cur_t >= 0) s_merge[cur_slot * kWave + lane] = merged + sum;
+    };
+    auto open_segment = [&](const int t) {
+      close_segment();
+      cur_t = t;
+      const unsigned hit = (unsigned)__ballot(merge_keys == t);
+      if (hit) {
+        cur_slot = __builtin_ctz(hit);
+        merged = s_merge[cur_slot * kWave + lane];
+      } else {
+        if (merge_count == kMergeSlots) flush_merge_table();  // full: everything leaves, then slot 0
+        cur_slot = merge_count;
+        if (lane == merge_count) merge_keys = t;
+        merge_count += 1;
+        merged = 0.0f;
+      }
+      sum = 0.0f;
+    };
+    const float *src = s_park + red;
+    unsigned long long m = finm;
+#if MR_PROBE_LANES == 1  // timing probe: finished runs are parked and dropped
+    m = 0;
+#endif
+    while (m) {  // four finished lanes per trip: their reads are in flight together
+      int l[4], t[4], cnt = 0;
+      float v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (m) { l[i] = (int)__builtin_ctzll(m); m &= m - 1; cnt = i + 1; }
+        else l[i] = l[0];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = src[l[i] * P];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) t[i] = __builtin_amdgcn_readlane(old, l[i]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (i < cnt) {
+          if (t[i] != cur_t) open_segment(t[i]);
+          sum += v[i];
+        }
+      }
+    }
+    close_segment();
+    __builtin_amdgcn_wave_barrier();
+  };
+
+  size_t pix = ((size_t)img * H + y_begin) * W + xc;
+  typename Fn::Raw raw_next;
+  if (y_begin < y_end) fn.fetch(img, xc, y_begin, pix, raw_next);
+  for (int y = y_begin; y < y_end; ++y, pix += W) {  // wave-uniform trip count
+    const typename Fn::Raw raw = raw_next;
+    if (y + 1 < y_end) fn.fetch(img, xc, y + 1, pix + W, raw_next);  // software prefetch
+    int tri = -1;
+    typename Fn::Pixel p;
+    const bool valid = fn.prepare(raw, T, tri, p) && in_range;
+    if (Fn::kCountBackground && in_range && !valid) image_sums.n_bg += 1;
+    if (!__ballot(valid)) continue;  // nothing in this row segment (background); open runs stay open
+    // the new triangles' records are requested BEFORE the finished runs are reduced: the flush does
+    // not touch them, so their L2 round trip (11 loads per lane) flies under its LDS work
+#if MR_LANES_LOAD_FIRST
+#if MR_PROBE_LANES == 3  // timing probe: records are loaded once per strip (results are garbage)
+    if (valid && data_tri < 0) {
+#else
+    if (valid && tri != data_tri) {
+#endif
+      data_tri = tri;
+      fn.load_triangle(img, tri, tri_data);
+    }
+#endif
+#if MR_PROBE_LANES == 2  // timing probe: runs never finish before the strip ends
+    flush(false);
+#else
+    flush(valid && run_tri >= 0 && tri != run_tri);
+#endif
+#if !MR_LANES_LOAD_FIRST
+    if (valid && tri != data_tri) {
+      data_tri = tri;
+      fn.load_triangle(img, tri, tri_data);
+    }
+#endif
+    if (valid) {
+      run_tri = tri;
+      fn.accumulate(p, tri_data, a, image_sums);
+    }
+  }
+  flush(run_tri >= 0);
   flush_merge_table();
   fn.end_strip(img, region, image_sums);
 }
@@ -475,6 +721,24 @@ inline int launch_accumulate_rows(const Fn &fn, int B, int T, int W, int H, floa
     hipLaunchKernelGGL((k_accumulate_rows<Fn, false>), dim3((unsigned)(per_xcd * kXcds)),
                        dim3(kRowsThreads), 0, s, fn, T, W, H, regions_x, per_image, n_regions,
                        per_xcd, acc, det_scale);
+  return check_launch();
+}
+
+template <class Fn>
+inline int lanes_strips_per_image(int W, int H) {
+  return ((W + kWave - 1) / kWave) * ((H + Fn::kLaneRowsPerWave - 1) / Fn::kLaneRowsPerWave);
+}
+template <class Fn>
+inline int launch_accumulate_lanes(const Fn &fn, int B, int T, int W, int H, float *acc,
+                                   hipStream_t s, const float *det_scale = nullptr) {
+  const int regions_x = (W + kWave - 1) / kWave;
+  const int regions_y = (H + Fn::kLaneRowsPerWave - 1) / Fn::kLaneRowsPerWave;
+  const int per_image = regions_x * regions_y;
+  const int n_regions = per_image * B;
+  const int per_xcd = (n_regions + kXcds - 1) / kXcds;
+  if (det_scale) return MR_EINVAL;  // the deterministic mode stays on the rows / runs kernels (not instantiated here)
+  hipLaunchKernelGGL((k_accumulate_lanes<Fn, false>), dim3((unsigned)(per_xcd * kXcds)), dim3(kWave), 0, s,
+                     fn, T, W, H, regions_x, per_image, n_regions, per_xcd, acc, det_scale);
   return check_launch();
 }
 

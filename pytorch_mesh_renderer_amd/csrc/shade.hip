@@ -337,6 +337,66 @@ struct ShadeGradFn {
   }
 };
 
+// The same backward for k_accumulate_lanes (run_accum.h): the lane multiplies its pixel's factors out
+// and keeps the products in registers down its vertical run.  GROUPS selects the attribute gradients
+// the caller wants (bit 0 normals, bit 1 positions, bit 2 diffuse colours; the nine clip-space sums
+// always): render() differentiates to whatever requires grad -- in the optimisation loops of the
+// reference's tests and examples the vertices alone (9 + 9 sums) or vertices and normals (27).
+// Factors nobody multiplies are dead code to the compiler.
+#ifndef MR_LANE_ROWS
+#define MR_LANE_ROWS 16
+#endif
+#ifndef MR_SHADE_LANES_ALL
+#define MR_SHADE_LANES_ALL 0   // 1: also instantiate the 36-sum variant (every attribute gradient wanted)
+#endif
+#ifndef MR_LANE_WAVES
+#define MR_LANE_WAVES 4
+#endif
+template <int L, bool SIGNS, bool LG, int GROUPS>
+struct ShadeLaneFn : ShadeGradFn<L, SIGNS, LG> {
+  using Base = ShadeGradFn<L, SIGNS, LG>;
+  static_assert(GROUPS >= 0 && GROUPS < 8, "attribute groups: normals | positions | diffuse");
+  static constexpr int kGroups = (GROUPS & 1) + ((GROUPS >> 1) & 1) + ((GROUPS >> 2) & 1);
+  static constexpr int kN = 9 * kGroups + 9;
+  static constexpr int kStride = 36;  // the rows of acc keep ShadeGradFn's layout: the gather reads it
+  static constexpr int kLaneRowsPerWave = LG ? 32 : MR_LANE_ROWS;
+  static constexpr int kMinWavesPerSimd = MR_LANE_WAVES;
+  // the gi-th selected group
+  __host__ __device__ static constexpr int group(int gi) {
+    int g = 0;
+    for (int seen = 0; g < 3; ++g) {
+      if ((GROUPS >> g) & 1) {
+        if (seen == gi) break;
+        ++seen;
+      }
+    }
+    return g;
+  }
+  // sum o = (gi * 3 + corner) * 3 + c  -> b[corner] * y[group * 3 + c],  acc column corner * 9 + group * 3 + c
+  //     o = 9 * kGroups + corner * 3 + c -> b[corner] * q[c],            acc column 27 + corner * 3 + c
+  __device__ static int column(int o) {
+    if (o >= 9 * kGroups) return 27 + (o - 9 * kGroups);
+    const int gi = o / 9, k = (o % 9) / 3, c = o % 3;
+    const int g = gi == 0 ? group(0) : gi == 1 ? group(1) : group(2);
+    return k * 9 + g * 3 + c;
+  }
+  __device__ __forceinline__ void accumulate(const typename Base::Pixel &p, const typename Base::Triangle &t,
+                                             float (&a)[kN], typename Base::Image &im) const {
+    float f[Base::kFactorStride];
+    Base::factors(p, t, f, im);
+#pragma unroll
+    for (int gi = 0; gi < kGroups; ++gi)
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a[(gi * 3 + k) * 3 + c] = fmaf(f[k], f[3 + group(gi) * 3 + c], a[(gi * 3 + k) * 3 + c]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) a[9 * kGroups + k * 3 + c] = fmaf(f[k], f[12 + c], a[9 * kGroups + k * 3 + c]);
+  }
+};
+
 __global__ __launch_bounds__(kThreads) void k_shade_scatter(
     const float *__restrict__ acc, const int32_t *__restrict__ tris, int B, int V, int T,
     float *__restrict__ dnormals, float *__restrict__ dpositions, float *__restrict__ ddiffuse,
@@ -396,6 +456,8 @@ __global__ __launch_bounds__(kThreads) void k_shade_gather(
   if (gid >= (long)B * V || j > 12) return;
   const int b = (int)(gid / V);
   const int v = (int)(gid - (long)b * V);
+  // outputs the caller does not want (nullptr): their sums were not formed either
+  if ((j < 3 && !dnormals) || (j >= 6 && j < 9 && !ddiffuse)) return;
   float sum = 0.f;
   if (j < 12) {
     const int e1 = offsets[v + 1];
@@ -530,6 +592,10 @@ size_t shade_backward_ws(int B, int V, int T, int W, int H) {
 }
 
 thread_local int g_deterministic = 0;  // mr_set_deterministic
+// mr_debug_set_shade_backward_kernel: 0 = automatic (lane-accumulating kernel where it exists: no
+// light gradients, not every attribute gradient wanted, not deterministic), 1 = always the rows
+// kernel, 2 = the lane-accumulating kernel wherever it is instantiated
+thread_local int g_shade_backward_kernel = 0;
 
 int launch_shade_backward(const float *drgba, const uint8_t *signs, const float *sign_upstream,
                           const int32_t *ids, const float *bary,
@@ -555,15 +621,15 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
   // dnormals, dpositions, ddiffuse, light_grads -- _native.py does) gets ONE memset instead of five
   // launch-bound ones.
   if (fused_clear) {
-  } else if ((char *)dnormals == (char *)dclip + v4 && (char *)dpositions == (char *)dnormals + v3 &&
+  } else if (dnormals && ddiffuse && (char *)dnormals == (char *)dclip + v4 && (char *)dpositions == (char *)dnormals + v3 &&
              (char *)ddiffuse == (char *)dpositions + v3 && (char *)light_grads == (char *)ddiffuse + v3) {
     if (hipMemsetAsync(dclip, 0, v4 + 3 * v3 + lg, s) != hipSuccess) return check_launch();
   } else {
     if (V > 0) {
       if (hipMemsetAsync(dclip, 0, v4, s) != hipSuccess) return check_launch();
-      if (hipMemsetAsync(dnormals, 0, v3, s) != hipSuccess) return check_launch();
+      if (dnormals && hipMemsetAsync(dnormals, 0, v3, s) != hipSuccess) return check_launch();
       if (hipMemsetAsync(dpositions, 0, v3, s) != hipSuccess) return check_launch();
-      if (hipMemsetAsync(ddiffuse, 0, v3, s) != hipSuccess) return check_launch();
+      if (ddiffuse && hipMemsetAsync(ddiffuse, 0, v3, s) != hipSuccess) return check_launch();
     }
     if (light_grads && hipMemsetAsync(light_grads, 0, lg, s) != hipSuccess) return check_launch();
   }
@@ -600,6 +666,41 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
     if (rc != MR_OK) return rc;
   }
   Lights lights{light_pos, light_col, ambient, L};
+  // Attribute gradients the caller wants (nullptr: not wanted).  The scatter path (no adjacency)
+  // writes all of them.
+  if ((!dnormals || !ddiffuse) && !(vertex_offsets && vertex_entries)) return MR_EINVAL;
+  const int groups = (dnormals ? 1 : 0) | 2 | (ddiffuse ? 4 : 0);
+  const bool lanes_exist = !light_grads && !det && groups != 6 && (groups != 7 || MR_SHADE_LANES_ALL);
+  const bool use_lanes = lanes_exist && (g_shade_backward_kernel == 2 || (g_shade_backward_kernel == 0 && groups != 7));
+#define MR_SHADE_LANES(NL, G)                                                                   \
+  {                                                                                             \
+    KernelTimer timer(MR_TIMER_SHADE_BACKWARD, s);                                              \
+    if (signs) {                                                                                \
+      ShadeLaneFn<NL, true, false, G> fn{{nullptr, signs, sign_upstream, sign_inv_n, ids, (const F3 *)bary, \
+                                          corners, recs, lights, nullptr, T, W, H}};            \
+      rc = launch_accumulate_lanes(fn, B, T, W, H, acc, s);                                     \
+    } else {                                                                                    \
+      ShadeLaneFn<NL, false, false, G> fn{{(const float4 *)drgba, nullptr, nullptr, 0.0f, ids, (const F3 *)bary, \
+                                           corners, recs, lights, nullptr, T, W, H}};           \
+      rc = launch_accumulate_lanes(fn, B, T, W, H, acc, s);                                     \
+    }                                                                                           \
+  }
+#if MR_SHADE_LANES_ALL
+#define MR_SHADE_LANES_G(NL)                                                                    \
+  if (groups == 2) MR_SHADE_LANES(NL, 2) else if (groups == 3) MR_SHADE_LANES(NL, 3) else MR_SHADE_LANES(NL, 7)
+#else
+#define MR_SHADE_LANES_G(NL)                                                                    \
+  if (groups == 2) MR_SHADE_LANES(NL, 2) else MR_SHADE_LANES(NL, 3)
+#endif
+  if (use_lanes) {
+    switch (L) {
+      case 1: MR_SHADE_LANES_G(1); break;
+      case 2: MR_SHADE_LANES_G(2); break;
+      case 3: MR_SHADE_LANES_G(3); break;
+      case 4: MR_SHADE_LANES_G(4); break;
+      default: return MR_EINVAL;
+    }
+  } else {
 #define MR_SHADE_BWD(NL)                                                                        \
   {                                                                                             \
     KernelTimer timer(MR_TIMER_SHADE_BACKWARD, s);                                              \
@@ -628,7 +729,10 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
     case 4: MR_SHADE_BWD(4); break;
     default: return MR_EINVAL;
   }
+  }
 #undef MR_SHADE_BWD
+#undef MR_SHADE_LANES_G
+#undef MR_SHADE_LANES
   if (rc != MR_OK) return rc;
   if (light_grads) {  // the strips' rows of light sums -> [B][6L + 3], fixed order (every element is written)
     rc = launch_sum_strip_rows(light_rows, B, strips_per_image<ShadeGradFn<1, true, true>>(W, H), L * 6 + 3,

@@ -162,17 +162,20 @@ class FusedPhongRenderer(torch.autograd.Function):
         return rgba, frames
 
     @staticmethod
-    def _input_grads(saved, needs_transform_grad, needs_light_grads, upstream, l1_signs=None):
+    def _input_grads(saved, needs_transform_grad, needs_light_grads, upstream, l1_signs=None,
+                     needs_normal_grad=True, needs_diffuse_grad=True):
         """The shading backward on the tensors forward() saved -> gradients in the order of forward()'s
         tensor arguments (vertices, transforms, normals, diffuse, None, lights..., ambient).
-        needs_light_grads: some of light_positions / light_intensities / ambient requires grad."""
+        needs_light_grads: some of light_positions / light_intensities / ambient requires grad;
+        needs_normal_grad / needs_diffuse_grad: False leaves that gradient (None) and its sums out."""
         (clip, ids, bary, normals, verts, diffuse, triangles, lp, li, corner_records, offsets,
          entries, xf) = saved[:13]
         amb = saved[13] if len(saved) > 13 else None
         dclip, dn, dverts, dd, dlp, dli, damb = _native.shade_backward(
             upstream, ids, bary, clip, normals, verts, diffuse, triangles, lp, li, amb,
             corner_records=corner_records, adjacency=(offsets, entries), l1_signs=l1_signs, transforms=xf,
-            want_light_grads=needs_light_grads)
+            want_light_grads=needs_light_grads, want_normal_grads=needs_normal_grad,
+            want_diffuse_grads=needs_diffuse_grad)
         dxf = None
         if needs_transform_grad:  # d clip[b,v,r] / d xf[b,r,k] = (vertex, 1)[k]
             ones = torch.ones(verts.shape[0], verts.shape[1], 1, dtype=verts.dtype, device=verts.device)
@@ -182,7 +185,9 @@ class FusedPhongRenderer(torch.autograd.Function):
     @staticmethod
     def backward(ctx, drgba, _dframes=None):
         grads = FusedPhongRenderer._input_grads(ctx.saved_tensors, ctx.needs_input_grad[1],
-                                                any(ctx.needs_input_grad[5:8]), drgba.contiguous())
+                                                any(ctx.needs_input_grad[5:8]), drgba.contiguous(),
+                                                needs_normal_grad=ctx.needs_input_grad[2],
+                                                needs_diffuse_grad=ctx.needs_input_grad[3])
         return grads + (None, None)
 
 
@@ -209,7 +214,7 @@ class FusedPhongL1Loss(torch.autograd.Function):
         upstream = grad.to(torch.float32).reshape(1)
         dverts, dxf, dn, dd, _, dlp, dli, damb = FusedPhongRenderer._input_grads(
             ctx.saved_tensors[1:], ctx.needs_input_grad[3], any(ctx.needs_input_grad[6:9]), upstream,
-            l1_signs=signs)
+            l1_signs=signs, needs_normal_grad=ctx.needs_input_grad[4], needs_diffuse_grad=ctx.needs_input_grad[5])
         dtarget = None
         if ctx.needs_input_grad[1]:
             dtarget = -_native.l1_loss_backward(signs, ctx.image_shape, upstream)

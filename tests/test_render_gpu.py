@@ -707,6 +707,54 @@ def test_render_forward_matches_raster_then_shade(device, w, h, res, n_lights, a
         np.testing.assert_allclose(lean_l1[k].cpu().numpy(), with_lights[k].cpu().numpy(), atol=1e-8, rtol=1e-5)
 
 
+@pytest.mark.parametrize("w,h,res,n_lights,ambient", [(96, 80, 12, 1, False), (130, 67, 10, 3, True),
+                                                        (64, 64, 120, 2, True), (33, 31, 6, 4, False),
+                                                        (200, 150, 50, 1, False)])
+def test_shade_backward_lane_kernel_matches_rows_kernel(device, w, h, res, n_lights, ambient):
+    """Round 3: when the caller does not want d normals and / or d diffuse (autograd's needs_input_grad),
+    mr_shade_backward runs k_accumulate_lanes -- the remaining 18 / 27 products stay in registers down
+    each lane's vertical run -- instead of the rows kernel's 36 sums per row.  Same outputs as the rows
+    kernel (forced through the debug hook) for both upstream forms; the outputs left out are None.
+    The 120-subdivision sphere at 64x64 has thousands of one-pixel runs per strip (merge-table
+    overflow), (200, 150) spans several strips and a ragged last column block."""
+    from pytorch_mesh_renderer_amd import _native
+    job = synthetic.sphere_job(2, w, h, res)
+    d = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in job.items()}
+    gen = torch.Generator().manual_seed(5)
+    diffuse = torch.rand(d["vertices"].shape, generator=gen).to(device)
+    lp = (torch.rand(2, n_lights, 3, generator=gen) * 6 - 3).to(device)
+    li = (torch.rand(2, n_lights, 3, generator=gen) + 0.2).to(device)
+    amb = (torch.rand(2, 3, generator=gen) * 0.3).to(device) if ambient else None
+    xf = synthetic.clip_transforms(job["eyes"], w, h).to(device)
+    clip, ids, bary, _, rgba, records = _native.render_forward(
+        d["vertices"], xf, d["normals"], diffuse, d["triangles"], lp, li, amb, w, h, want_z=False)
+    adjacency = _native.vertex_adjacency(d["triangles"], d["vertices"].shape[1])
+    g = torch.randn(2, h, w, 4, generator=torch.Generator().manual_seed(1)).to(device) / (h * w)
+    _, signs = _native.l1_loss_forward(rgba, torch.zeros_like(rgba))
+    up = torch.full((1,), 0.7, device=rgba.device)
+    tail = (ids, bary, clip, d["normals"], d["vertices"], diffuse, d["triangles"], lp, li, amb)
+    kw = dict(corner_records=records, adjacency=adjacency, transforms=xf, want_light_grads=False)
+    try:
+        for upstream, extra in ((g, {}), (up, {"l1_signs": signs})):
+            _native.debug_set_shade_backward_kernel(1)
+            full = _native.shade_backward(upstream, *tail, **kw, **extra)
+            assert all(float(full[k].abs().max()) > 0 for k in range(4))
+            for want_n, want_d in ((False, False), (True, False)):
+                for which in (1, 2):
+                    _native.debug_set_shade_backward_kernel(which)
+                    lean = _native.shade_backward(upstream, *tail, **kw, **extra, want_normal_grads=want_n,
+                                                  want_diffuse_grads=want_d)
+                    assert lean[3] is None and (lean[1] is None) == (not want_n)
+                    for k in (0, 1, 2):
+                        if lean[k] is None:
+                            continue
+                        scale = float(full[k].abs().max())
+                        np.testing.assert_allclose(lean[k].cpu().numpy(), full[k].cpu().numpy(), rtol=2e-4,
+                                                   atol=2e-6 * scale, err_msg="output %d kernel %d" % (k, which))
+    finally:
+        _native.debug_set_shade_backward_kernel(0)
+
+
 def test_shade_backward_gather_matches_scatter(device):
     """mr_shade_backward with the CSR vertex adjacency (per-vertex gather, what render() uses) vs
     without it (float-atomic scatter), incl. a triangle with a repeated and an out-of-range vertex."""
