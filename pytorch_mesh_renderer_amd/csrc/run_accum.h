@@ -209,18 +209,11 @@ __device__ __forceinline__ void lds_read_pairs4(unsigned addr_a, unsigned addr_b
       : "v"(addr_a), "v"(addr_b) : "memory");
 }
 
-// Round 3: the reduction's inner loop used to be "8 reads, s_waitcnt lgkmcnt(0), 8 dependent
-// FMAs" (lds_read_pairs4 above): at four wavefronts per SIMD nothing hid the LDS round trip of a
-// group and the loop ran at ~4.8 clocks per instruction.  It is software-pipelined now -- the next
-// group's reads are in flight while this group is summed -- with reads the COMPILER can count
-// (hand-issued reads in inline assembly made the register allocator copy registers whose loads
-// were still in flight): 16-byte reads, which it cannot pair into ds_read2 (rows are 16-byte
-// aligned for that: stride 76 floats).
-__device__ __forceinline__ float4 lds_read4(const float *p) { return *(const float4 *)p; }
-#ifndef MR_ROWS_PIPELINE
-#define MR_ROWS_PIPELINE 1
-#endif
-
+// (Round 3, measured and dropped: software-pipelining this loop.  Hand-issued reads in inline assembly
+// -- the next group's reads in flight under the FMAs -- made the register allocator copy registers
+// whose loads were still in flight; the same with compiler-visible 16-byte reads, rolling or
+// double-buffered, came out with eight v_mov per group and an lgkmcnt(0) at the loop-carried copies:
+// 0.381 -> 0.416 ms.  What did help is not reducing per pixel at all: k_accumulate_lanes below.)
 // Fn::kRowsPerWave: rows a wavefront of k_accumulate_rows walks down its 64-pixel-wide strip.  Short
 // strips balance the load (background rows cost almost nothing, silhouette strips a lot) better than
 // long ones amortise the merge table: measured at 1024^2 x 32, shading backward: 4 -> 0.417,
@@ -247,12 +240,8 @@ __global__ __launch_bounds__(kRowsThreads, Fn::kMinWavesPerSimd) void k_accumula
   // reducing lane fetches TWO consecutive pixels of its factor with one ds_read_b64 (256 B/clk
   // instead of the 128 B/clk of ds_read_b32: the reduction is bound by LDS reads).  Row stride 74
   // floats: consecutive rows start 10 banks apart (mod 64: 32 distinct even offsets), pairs never
-  // collide; the spare columns behind a row absorb the over-read of one group behind the last.
-  // Stride 76 (round 3, 16-byte reads): rows start 12 banks apart; in every 16-lane group of a
-  // ds_read_b128 the lanes address at most 11 distinct rows whose 4-bank windows are disjoint, and
-  // lanes on the same row read the same address (broadcast): conflict-free (checked per lane group
-  // for the factor pairs of all three functors' layouts: rows 0..2 and 3..15).
-  constexpr int kRowStride = MR_ROWS_PIPELINE ? 76 : 74;
+  // collide; 6 spare columns behind a row absorb the last batch's over-read.
+  constexpr int kRowStride = 74;
   static_assert(Fn::kFactors <= 32, "bank layout of the parked rows: 32 distinct even bank offsets");
   __shared__ __attribute__((aligned(16))) float s_stage[kRowsThreads / kWave][Fn::kFactors * kRowStride];
   // Per-wavefront merge table: a triangle's segments of consecutive rows are summed here, in LDS,
@@ -376,11 +365,6 @@ __global__ __launch_bounds__(kRowsThreads, Fn::kMinWavesPerSimd) void k_accumula
       if (hit) {
         cur_slot = __builtin_ctz(hit);
         merged = merge[cur_slot * kWave + lane];
-#if MR_ROWS_PIPELINE
-        // land it here: carried in flight, the compiler waits for it -- with lgkmcnt(0), draining
-        // the rolling reads -- at the loop-carried copies of EVERY later group
-        asm volatile("" : "+v"(merged));
-#endif
       } else if (merge_count < kMergeSlots) {  // (the table was emptied before the pass if it was short of room)
         cur_slot = merge_count;
         if (lane == merge_count) merge_keys = cur_t;
@@ -396,48 +380,6 @@ __global__ __launch_bounds__(kRowsThreads, Fn::kMinWavesPerSimd) void k_accumula
     if (kMergeSlots > 0 && merge_count + (int)__builtin_popcountll(heads) > kMergeSlots) flush_merge_table();
     const int first_group = heads ? (int)(__builtin_ctzll(heads) >> 3) : 8;
     const int last_group = valids ? (63 - (int)__builtin_clzll(valids)) >> 3 : -1;
-#if MR_ROWS_PIPELINE
-    // ONE pass over the row's pixels in groups of eight with ROLLING reads: as soon as four pixels
-    // of both factors are summed, the same registers are requested again for the pixels eight
-    // further on, so two of the four 16-byte reads of a group are always in flight under the FMAs
-    // (one loop body, no unrolling: nothing is copied between register sets).  The reads behind
-    // the last group land in the row's spare columns.
-    static_assert(kRowStride >= 72 && kRowStride % 4 == 0, "over-read of one group behind the row; 16-byte rows");
-    if (first_group <= last_group) {
-      const float *pa = stage + ia * kRowStride + 8 * first_group, *pb = stage + ib * kRowStride + 8 * first_group;
-      float4 a0 = lds_read4(pa), b0 = lds_read4(pb), a1 = lds_read4(pa + 4), b1 = lds_read4(pb + 4);
-      for (int g = first_group; g <= last_group; ++g, pa += 8, pb += 8) {
-        const unsigned hg = (unsigned)(heads >> (8 * g)) & 0xffu;
-        if (hg == 0u) {  // no segment starts in this group: eight FMAs straight
-          sum = fmaf(a0.x, b0.x, sum); sum2 = fmaf(a0.y, b0.y, sum2);
-          sum = fmaf(a0.z, b0.z, sum); sum2 = fmaf(a0.w, b0.w, sum2);
-          a0 = lds_read4(pa + 8); b0 = lds_read4(pb + 8);
-          sum = fmaf(a1.x, b1.x, sum); sum2 = fmaf(a1.y, b1.y, sum2);
-          sum = fmaf(a1.z, b1.z, sum); sum2 = fmaf(a1.w, b1.w, sum2);
-          a1 = lds_read4(pa + 12); b1 = lds_read4(pb + 12);
-        } else {
-          if (hg & 1u) open_segment(8 * g);
-          sum = fmaf(a0.x, b0.x, sum);
-          if (hg & 2u) open_segment(8 * g + 1);
-          sum2 = fmaf(a0.y, b0.y, sum2);
-          if (hg & 4u) open_segment(8 * g + 2);
-          sum = fmaf(a0.z, b0.z, sum);
-          if (hg & 8u) open_segment(8 * g + 3);
-          sum2 = fmaf(a0.w, b0.w, sum2);
-          a0 = lds_read4(pa + 8); b0 = lds_read4(pb + 8);
-          if (hg & 16u) open_segment(8 * g + 4);
-          sum = fmaf(a1.x, b1.x, sum);
-          if (hg & 32u) open_segment(8 * g + 5);
-          sum2 = fmaf(a1.y, b1.y, sum2);
-          if (hg & 64u) open_segment(8 * g + 6);
-          sum = fmaf(a1.z, b1.z, sum);
-          if (hg & 128u) open_segment(8 * g + 7);
-          sum2 = fmaf(a1.w, b1.w, sum2);
-          a1 = lds_read4(pa + 12); b1 = lds_read4(pb + 12);
-        }
-      }
-    }
-#else
     for (int g = first_group; g <= last_group; ++g) {
       v2f ra[4], rb[4];
       lds_read_pairs4(row_a + 32u * g, row_b + 32u * g, ra, rb);
@@ -450,7 +392,6 @@ __global__ __launch_bounds__(kRowsThreads, Fn::kMinWavesPerSimd) void k_accumula
         sum2 = fmaf(ra[j].y, rb[j].y, sum2);
       }
     }
-#endif
     close_segment();
     __builtin_amdgcn_wave_barrier();
   }
@@ -469,12 +410,27 @@ __global__ __launch_bounds__(kRowsThreads, Fn::kMinWavesPerSimd) void k_accumula
 // and lanes 0..N-1 walk the finished lanes of this row -- one add per finished lane, ~7 per row at
 // 1024^2 / 5k triangles instead of 64 -- merging neighbours that finished the same triangle and
 // committing through the same per-wavefront merge table as the rows kernel.
+// Measured at 1024^2 x 32, 5k triangles, shading backward with 18 sums (vertex gradients only):
+// rows kernel 0.381 ms -> 0.275 ms; per launch 179.5 -> ~150 M vector, 87 -> 52 M scalar, 34 -> 16 M
+// branch and 32.6 -> 6.8 M LDS instructions.  What was measured on the way: requesting the new
+// triangles' records BEFORE the flush instead of after it -0.02 ms (their L2 round trip flies under
+// the flush's LDS work); a dense pass for flushes of 20 or more lanes (the strip's end) -0.005; strips
+// of 16 rows (8: +0.004, 32: +0.02, 64: +0.03 ms); 16 merge slots (8: +0.005, 32: +0.07 -- LDS per
+// wavefront); merging with ds_add_f32 instead of read + add + store: +0.08 ms (an LDS float atomic
+// costs ~26 LDS cycles whatever it does); restarting the accumulators with in-place selects
+// instead of a branch (the compiler copied all of them out and back: 75 v_mov per row) -0.01.
 //
 // Functor interface as for k_accumulate_runs (accumulate() adds the pixel's N products to a[]) plus
 //   static int column(int o);          // float of the triangle's acc row that sum o belongs to
 //   static constexpr int kLaneRowsPerWave;
 #ifndef MR_PROBE_LANES
 #define MR_PROBE_LANES 0
+#endif
+#ifndef MR_LANES_DENSE
+#define MR_LANES_DENSE 20   // finished lanes from which a flush walks all 64 parked rows (65: never)
+#endif
+#ifndef MR_LANES_DS_ADD
+#define MR_LANES_DS_ADD 0
 #endif
 #ifndef MR_LANES_LOAD_FIRST
 #define MR_LANES_LOAD_FIRST 1
@@ -545,67 +501,123 @@ __global__ __launch_bounds__(kWave, Fn::kMinWavesPerSimd) void k_accumulate_lane
   typename Fn::Triangle tri_data;
 
   // Finished runs: park, reduce over the finished lanes, restart.
+  //   sparse (a few lanes finished, the usual row): lanes 0..N-1 visit the finished lanes four at a
+  //          time -- their four reads in flight together --, one add each;
+  //   dense  (kDense or more, e.g. the end of the strip, where every lane finishes): every lane parks
+  //          -- the unfinished ones zeros -- and the pass walks all 64 rows in groups of eight, opening
+  //          a segment where the triangle changes (a ballot tells where), like the rows kernel.
+  // A segment's sum goes into its triangle's merge-table slot with ONE LDS operation that returns
+  // nothing (ds_add_f32, or a plain store into a slot claimed by this segment): nothing to wait for.
+  constexpr int kDense = MR_LANES_DENSE;
   auto flush = [&](const bool fin) {
     const unsigned long long finm = __ballot(fin);
     if (!finm) return;
-    if (fin) {
+    const bool dense = (int)__builtin_popcountll(finm) >= kDense;  // wave-uniform
+    {
       float4 *dst = (float4 *)(s_park + lane * P);
+      auto quad = [&](const int q) {
+        return make_float4(a[4 * q], 4 * q + 1 < N ? a[4 * q + 1] : 0.f, 4 * q + 2 < N ? a[4 * q + 2] : 0.f,
+                           4 * q + 3 < N ? a[4 * q + 3] : 0.f);
+      };
+      if (dense) {  // wave-uniform: every lane parks
 #pragma unroll
-      for (int q = 0; q < (N + 3) / 4; ++q)
-        dst[q] = make_float4(a[4 * q], 4 * q + 1 < N ? a[4 * q + 1] : 0.f, 4 * q + 2 < N ? a[4 * q + 2] : 0.f,
-                             4 * q + 3 < N ? a[4 * q + 3] : 0.f);
+        for (int q = 0; q < (N + 3) / 4; ++q) {
+          const float4 v = quad(q);
+          dst[q] = make_float4(fin ? v.x : 0.f, fin ? v.y : 0.f, fin ? v.z : 0.f, fin ? v.w : 0.f);
+        }
+      } else if (fin) {
 #pragma unroll
-      for (int k = 0; k < N; ++k) a[k] = 0.0f;
+        for (int q = 0; q < (N + 3) / 4; ++q) dst[q] = quad(q);
+      }
+      // restart as selects on the accumulators in place (inside the branch above the compiler
+      // copied all N of them out and back: 75 vector instructions per row)
+#pragma unroll
+      for (int k = 0; k < N; ++k) a[k] = fin ? 0.0f : a[k];
     }
-    const int old = run_tri;
+    const int old = fin ? run_tri : -1;
     if (fin) run_tri = -1;
     __builtin_amdgcn_wave_barrier();  // LDS executes one wavefront's operations in order
     int cur_t = -1, cur_slot = -1;    // triangle of the running segment and its merge-table slot
-    float merged = 0.0f, sum = 0.0f;
+    bool cur_fresh = false;           // the slot was claimed by this segment: it holds nothing yet
+    float sum = 0.0f, sum2 = 0.0f, merged = 0.0f;
     auto close_segment = [&]() {
-      if (cur_t >= 0) s_merge[cur_slot * kWave + lane] = merged + sum;
+      if (cur_t < 0) return;
+      float *slot = &s_merge[cur_slot * kWave + lane];
+#if MR_LANES_DS_ADD   // measured: ds_add_f32 costs more than it saves (0.305 -> 0.368 ms): ~26 LDS cycles each
+      if (cur_fresh) *slot = sum + sum2;
+      else atomicAdd(slot, sum + sum2);
+#else
+      *slot = merged + (sum + sum2);
+#endif
     };
     auto open_segment = [&](const int t) {
       close_segment();
       cur_t = t;
       const unsigned hit = (unsigned)__ballot(merge_keys == t);
+      cur_fresh = hit == 0u;
+      merged = 0.0f;
       if (hit) {
         cur_slot = __builtin_ctz(hit);
-        merged = s_merge[cur_slot * kWave + lane];
+        if (!MR_LANES_DS_ADD) merged = s_merge[cur_slot * kWave + lane];
       } else {
         if (merge_count == kMergeSlots) flush_merge_table();  // full: everything leaves, then slot 0
         cur_slot = merge_count;
         if (lane == merge_count) merge_keys = t;
         merge_count += 1;
-        merged = 0.0f;
       }
       sum = 0.0f;
+      sum2 = 0.0f;
     };
     const float *src = s_park + red;
-    unsigned long long m = finm;
-#if MR_PROBE_LANES == 1  // timing probe: finished runs are parked and dropped
-    m = 0;
-#endif
-    while (m) {  // four finished lanes per trip: their reads are in flight together
-      int l[4], t[4], cnt = 0;
-      float v[4];
+#if MR_PROBE_LANES == 1  // timing probe: finished runs are parked and dropped (the park is kept alive)
+    if (src[(lane & 7) * P] == 123.456f) open_segment(0);
+#else
+    if (dense) {
+      const int left = __shfl_up(old, 1);
+      const unsigned long long heads = __ballot(fin && (lane == 0 || left != old));
+      const int g0 = (int)(__builtin_ctzll(finm) >> 3), g1 = (63 - (int)__builtin_clzll(finm)) >> 3;
+      for (int g = g0; g <= g1; ++g) {
+        float v[8];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (m) { l[i] = (int)__builtin_ctzll(m); m &= m - 1; cnt = i + 1; }
-        else l[i] = l[0];
-      }
+        for (int j = 0; j < 8; ++j) v[j] = src[(8 * g + j) * P];
+        const unsigned hg = (unsigned)(heads >> (8 * g)) & 0xffu;
+        if (hg == 0u) {
+          sum += (v[0] + v[1]) + (v[2] + v[3]);
+          sum2 += (v[4] + v[5]) + (v[6] + v[7]);
+        } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] = src[l[i] * P];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) t[i] = __builtin_amdgcn_readlane(old, l[i]);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (i < cnt) {
-          if (t[i] != cur_t) open_segment(t[i]);
-          sum += v[i];
+          for (int j = 0; j < 8; ++j) {
+            if (hg & (1u << j)) open_segment(__builtin_amdgcn_readlane(old, 8 * g + j));
+            sum += v[j];
+          }
         }
       }
+    } else {
+      unsigned long long m = finm;
+      int left = (int)__builtin_popcountll(finm);
+      while (left > 0) {  // four finished lanes per trip: their reads are in flight together
+        int l[4], t[4];
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {  // (behind the last one: ffs(0) - 1 = -1 -> lane 63, read and ignored)
+          l[i] = (__builtin_ffsll((long long)m) - 1) & 63;
+          m &= ~(1ull << l[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = src[l[i] * P];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t[i] = __builtin_amdgcn_readlane(old, l[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (i < left) {
+            if (t[i] != cur_t) open_segment(t[i]);
+            sum += v[i];
+          }
+        }
+        left -= 4;
+      }
     }
+#endif
     close_segment();
     __builtin_amdgcn_wave_barrier();
   };

@@ -1,5 +1,7 @@
 # SQ activity counters of the bench step's kernels, four --pmc passes over `bench.py --steps 3`.
 #   gpurun -- 'bash tools/pmc_step.sh'   -> gpurun_out/pmc_step/summary.txt
+# (copy the summary to profiles/rNN_pmc_step_summary.txt; MR_SHADE_BACKWARD_KERNEL=1 in the environment
+#  profiles the rows kernel instead of the lane-accumulating one)
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/pmc_step
@@ -17,7 +19,7 @@ done
 python3 - <<'PY' | tee gpurun_out/pmc_step/summary.txt
 import csv, glob, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-keys = ("k_accumulate_rows", "k_raster<64, 0, true>", "k_raster<64, 0, false>", "k_l1_forward", "k_shade_gather")
+keys = ("k_accumulate_lanes", "k_accumulate_rows", "k_raster<64, 0, true>", "k_raster<64, 0, false>", "k_l1_forward", "k_shade_gather")
 for f in glob.glob("gpurun_out/pmc_step/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         for key in keys:
