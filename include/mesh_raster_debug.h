@@ -32,7 +32,8 @@ int mr_debug_set_shade_backward_kernel(int which);
  * libmesh_raster_hip_probes.so) contains the probe instantiations; the production library
  * returns MR_EINVAL for every value but 0, its kernel has no probe code at all.
  *   0 normal | 1 bin only | 2 empty tile walk + stores | 3 bin + tile masks | 8 no depth loop |
- *   16 no coverage loop | 32 no stores | 40 no depth loop and no stores
+ *   16 no coverage loop | 32 no stores | 40 no depth loop and no stores |
+ *   64 row-shaped store addresses (each store instruction one contiguous run; scrambled image)
  * The G-buffer is UNDEFINED while a probe is selected. */
 int mr_debug_set_raster_probe(int probe);
 

@@ -879,11 +879,17 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : MR_RASTER
         }
       }
       if (in_image && !((PROBE & 32) && st.z != 123.0f)) {  // 32: timing probe, no stores
-        __builtin_amdgcn_raw_buffer_store_b32((unsigned)max(st.id, 0), rs_ids, lane_pix * 4u, tile_pix * 4, MR_RASTER_STORE_AUX_IDS);
+        // 64: timing probe (R = 64 only) -- the same bytes, but tile (tx, ty) writes ROW ty * 4 + tx of the
+        // region, lane = x: every store instruction covers one contiguous run (256 B of ids / depths,
+        // 768 B of barycentrics) instead of four 64- / 192-byte runs.  The image comes out scrambled.
+        const unsigned st_lane = ((PROBE & 64) && R == 64) ? (unsigned)lane : lane_pix;
+        const int st_tile = ((PROBE & 64) && R == 64) ? (ty * kTileH + tx) * W : tile_pix;
+        __builtin_amdgcn_raw_buffer_store_b32((unsigned)max(st.id, 0), rs_ids, st_lane * 4u, st_tile * 4,
+                                              (PROBE & 64) ? MR_RASTER_STORE_AUX : MR_RASTER_STORE_AUX_IDS);
         if (!SHADE || !last_round || shade.keep_z)  // workgroup-uniform
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, st.z), rs_z, lane_pix * 4u, tile_pix * 4, MR_RASTER_STORE_AUX);
-        __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(v3u, v3f{st.b0, st.b1, st.b2}), rs_bary, lane_pix * 12u,
-                                              tile_pix * 12, MR_RASTER_STORE_AUX);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, st.z), rs_z, st_lane * 4u, st_tile * 4, MR_RASTER_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(v3u, v3f{st.b0, st.b1, st.b2}), rs_bary, st_lane * 12u,
+                                              st_tile * 12, MR_RASTER_STORE_AUX);
       }
       // Later rounds re-LOAD the pixel state.  vmcnt is in order on gfx950, so the compiler's wait
       // for such a load also drains the G-buffer stores behind it; draining explicitly here -- on
@@ -1122,6 +1128,7 @@ void launch_k_raster_probe(const RasterArgs &a, dim3 grid, hipStream_t s) {
     case 16: return launch_k_raster<R, 16>(a, grid, s);
     case 32: return launch_k_raster<R, 32>(a, grid, s);
     case 40: return launch_k_raster<R, 40>(a, grid, s);
+    case 64: return launch_k_raster<R, 64>(a, grid, s);
     default: break;
   }
 #endif
