@@ -147,9 +147,6 @@ struct RasterGradFn {
 // triangle's pixels of b_j q_c is a product of two per-pixel factors, so the lanes park b[3] and q[3]
 // and nine reduction lanes form the products -- the structure the fused shading backward uses, with
 // its 8-row strips, per-wavefront merge table and one contiguous atomic per (strip, triangle).
-#ifndef MR_RASTER_BWD_ROWS
-#define MR_RASTER_BWD_ROWS 1
-#endif
 struct RasterRowsFn {
   static constexpr int kN = 9;
   static constexpr int kStride = mr::kStride;
@@ -191,6 +188,27 @@ struct RasterRowsFn {
     f[0] = p.b.x; f[1] = p.b.y; f[2] = p.b.z;
     f[3] = q[0]; f[4] = q[1]; f[5] = q[2];
     f[6] = 0.f; f[7] = 0.f;
+  }
+};
+
+// Round 3: the same nine sums through k_accumulate_lanes (run_accum.h) -- each lane keeps them in
+// registers down its vertical run (RasterGradFn's accumulate()), only finished runs go through LDS.
+// MR_RASTER_BWD_KERNEL: 0 = column runs + LDS hash table, 1 = rows kernel, 2 = lane-accumulating.
+#ifndef MR_RASTER_BWD_KERNEL
+#define MR_RASTER_BWD_KERNEL 2
+#endif
+#ifndef MR_RASTER_LANE_ROWS
+#define MR_RASTER_LANE_ROWS 16
+#endif
+struct RasterLanesFn : RasterGradFn {
+  static constexpr int kLaneRowsPerWave = MR_RASTER_LANE_ROWS;
+  static constexpr bool kCountBackground = false;
+  __device__ static int column(int o) { return o; }
+  struct Image { int n_bg; };
+  __device__ __forceinline__ void begin_image(int, Image &) const {}
+  __device__ __forceinline__ void end_strip(int, int, Image &) const {}
+  __device__ __forceinline__ void accumulate(const Pixel &p, const Triangle &t, float (&acc)[kN], Image &) const {
+    raster_pixel_partials(p.b, p.g, t, acc);
   }
 };
 
@@ -333,7 +351,10 @@ int launch_raster_backward(const float *dbary, const float *clip, const int32_t 
   }
   {
     KernelTimer timer(MR_TIMER_RASTER_BACKWARD, s);
-#if MR_RASTER_BWD_ROWS
+#if MR_RASTER_BWD_KERNEL == 2
+    RasterLanesFn lanes{{(const F3 *)dbary, ids, (const F3 *)bary, recs, T}};
+    rc = launch_accumulate_lanes(lanes, B, T, W, H, acc, s);
+#elif MR_RASTER_BWD_KERNEL == 1
     RasterRowsFn rows{(const F3 *)dbary, ids, (const F3 *)bary, recs, T};
     rc = launch_accumulate_rows(rows, B, T, W, H, acc, s);
 #else

@@ -447,7 +447,7 @@ constexpr int lanes_park_stride(int n) {  // multiple of 4 with an odd number of
 template <class Fn, bool DET>
 __global__ __launch_bounds__(kWave, Fn::kMinWavesPerSimd) void k_accumulate_lanes(
     Fn fn, int T, int W, int H, int regions_x, int regions_per_image, int n_regions,
-    int regions_per_xcd, float *__restrict__ acc, const float *__restrict__ det_scale) {
+    int regions_per_xcd, int rows_per_wave, float *__restrict__ acc, const float *__restrict__ det_scale) {
   constexpr int N = Fn::kN, STRIDE = Fn::kStride, P = lanes_park_stride(N);
   static_assert(N <= kWave && N <= STRIDE, "one reduction lane per sum");
   __shared__ __attribute__((aligned(16))) float s_park[kWave * P];
@@ -466,9 +466,8 @@ __global__ __launch_bounds__(kWave, Fn::kMinWavesPerSimd) void k_accumulate_lane
   const int x = rx * kWave + lane;
   const bool in_range = x < W;
   const int xc = in_range ? x : W - 1;
-  constexpr int kRowsPerWave = Fn::kLaneRowsPerWave;
-  const int y_begin = ry * kRowsPerWave;
-  const int y_end = min(y_begin + kRowsPerWave, H);
+  const int y_begin = ry * rows_per_wave;
+  const int y_end = min(y_begin + rows_per_wave, H);
   float *acc_img = acc + (size_t)img * T * STRIDE;
   long long *acc_fixed = (long long *)acc + (size_t)img * T * STRIDE;  // DET: 8-byte elements
   const float to_fixed = DET ? det_scale[0] : 0.0f;
@@ -736,21 +735,34 @@ inline int launch_accumulate_rows(const Fn &fn, int B, int T, int W, int H, floa
   return check_launch();
 }
 
+// Rows a wavefront of k_accumulate_lanes walks down its 64-pixel-wide strip: Fn::kLaneRowsPerWave
+// (16 at 1024^2 x 32: 8 -> +1 %, 32 -> +7 %), halved while the launch would leave wavefront slots of
+// the chip empty (256^2 x 8 in 16-row strips is 512 wavefronts for 4096 slots: the rasterizer
+// backward took 0.082 ms there against the rows kernel's 0.054).
 template <class Fn>
-inline int lanes_strips_per_image(int W, int H) {
-  return ((W + kWave - 1) / kWave) * ((H + Fn::kLaneRowsPerWave - 1) / Fn::kLaneRowsPerWave);
+inline int lanes_rows_per_wave(int B, int W, int H) {
+  int rows = Fn::kLaneRowsPerWave;
+  const long columns = (long)B * ((W + kWave - 1) / kWave);
+  while (rows > 4 && columns * ((H + rows - 1) / rows) < 8192) rows /= 2;
+  return rows;
+}
+template <class Fn>
+inline int lanes_strips_per_image(int B, int W, int H) {
+  const int rows = lanes_rows_per_wave<Fn>(B, W, H);
+  return ((W + kWave - 1) / kWave) * ((H + rows - 1) / rows);
 }
 template <class Fn>
 inline int launch_accumulate_lanes(const Fn &fn, int B, int T, int W, int H, float *acc,
                                    hipStream_t s, const float *det_scale = nullptr) {
+  const int rows = lanes_rows_per_wave<Fn>(B, W, H);
   const int regions_x = (W + kWave - 1) / kWave;
-  const int regions_y = (H + Fn::kLaneRowsPerWave - 1) / Fn::kLaneRowsPerWave;
+  const int regions_y = (H + rows - 1) / rows;
   const int per_image = regions_x * regions_y;
   const int n_regions = per_image * B;
   const int per_xcd = (n_regions + kXcds - 1) / kXcds;
   if (det_scale) return MR_EINVAL;  // the deterministic mode stays on the rows / runs kernels (not instantiated here)
   hipLaunchKernelGGL((k_accumulate_lanes<Fn, false>), dim3((unsigned)(per_xcd * kXcds)), dim3(kWave), 0, s,
-                     fn, T, W, H, regions_x, per_image, n_regions, per_xcd, acc, det_scale);
+                     fn, T, W, H, regions_x, per_image, n_regions, per_xcd, rows, acc, det_scale);
   return check_launch();
 }
 
