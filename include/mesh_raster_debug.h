@@ -22,10 +22,10 @@ extern "C" {
 int mr_debug_set_raster_region_edge(int edge);
 
 /* Pixel kernel of mr_shade_backward / mr_shade_backward_l1 for the calling thread's next launches:
- * 0 = automatic (default: the lane-accumulating kernel when dnormals or ddiffuse is NULL, no
- * light_grads and not the deterministic mode; the rows kernel otherwise), 1 = always the rows kernel
- * (all 36 sums are formed, unwanted outputs are just not written), 2 = the lane-accumulating kernel
- * wherever it is instantiated.  For the parity tests, which compare the two on the same inputs. */
+ * 0 = automatic (default: the lane-accumulating kernel without light_grads and outside the
+ * deterministic mode; the rows kernel otherwise), 1 = always the rows kernel (all 36 sums are
+ * formed, unwanted outputs are just not written), 2 = as 0.  For the parity tests, which compare
+ * the two kernels on the same inputs. */
 int mr_debug_set_shade_backward_kernel(int which);
 
 /* Stage-timing probes of k_raster.  Only a library built with -DMR_PROBES (make probes ->

@@ -711,10 +711,11 @@ def test_render_forward_matches_raster_then_shade(device, w, h, res, n_lights, a
                                                         (64, 64, 120, 2, True), (33, 31, 6, 4, False),
                                                         (200, 150, 50, 1, False)])
 def test_shade_backward_lane_kernel_matches_rows_kernel(device, w, h, res, n_lights, ambient):
-    """Round 3: when the caller does not want d normals and / or d diffuse (autograd's needs_input_grad),
-    mr_shade_backward runs k_accumulate_lanes -- the remaining 18 / 27 products stay in registers down
-    each lane's vertical run -- instead of the rows kernel's 36 sums per row.  Same outputs as the rows
-    kernel (forced through the debug hook) for both upstream forms; the outputs left out are None.
+    """Round 3: without light gradients mr_shade_backward runs k_accumulate_lanes -- the 18 / 27 / 36
+    products the caller wants (autograd's needs_input_grad: d normals and / or d diffuse may be left
+    out) stay in registers down each lane's vertical run -- instead of the rows kernel's 36 sums per
+    row.  Same outputs as the rows kernel (forced through the debug hook) for both upstream forms; the
+    outputs left out are None.
     The 120-subdivision sphere at 64x64 has thousands of one-pixel runs per strip (merge-table
     overflow), (200, 150) spans several strips and a ragged last column block."""
     from pytorch_mesh_renderer_amd import _native
@@ -739,13 +740,13 @@ def test_shade_backward_lane_kernel_matches_rows_kernel(device, w, h, res, n_lig
             _native.debug_set_shade_backward_kernel(1)
             full = _native.shade_backward(upstream, *tail, **kw, **extra)
             assert all(float(full[k].abs().max()) > 0 for k in range(4))
-            for want_n, want_d in ((False, False), (True, False)):
+            for want_n, want_d in ((False, False), (True, False), (True, True)):
                 for which in (1, 2):
                     _native.debug_set_shade_backward_kernel(which)
                     lean = _native.shade_backward(upstream, *tail, **kw, **extra, want_normal_grads=want_n,
                                                   want_diffuse_grads=want_d)
-                    assert lean[3] is None and (lean[1] is None) == (not want_n)
-                    for k in (0, 1, 2):
+                    assert (lean[3] is None) == (not want_d) and (lean[1] is None) == (not want_n)
+                    for k in (0, 1, 2, 3):
                         if lean[k] is None:
                             continue
                         scale = float(full[k].abs().max())
