@@ -125,15 +125,15 @@ def make_step(job, device, gather, handover="u8"):
     up = torch.tensor([0.0, 1.0, 0.0])
     lpos, lint = job["light_positions"].to(device), job["light_intensities"].to(device)
     transform = mesh_renderer.to_uint8 if handover == "u8" else None
-    if gather is not None and handover == "u8":
-        # every frame is handed over: let the forward kernel write the 8-bit frames itself (4 B/px)
-        # instead of converting the float image in a pass of its own on the side stream
-        from pytorch_mesh_renderer_amd.mesh_renderer import rasterize_triangles_ext
-        rasterize_triangles_ext.EMIT_UINT8_FRAMES = True
+    from pytorch_mesh_renderer_amd.mesh_renderer import rasterize_triangles_ext
+    # every frame is handed over: the forward kernel then writes the 8-bit frames itself (4 B/px)
+    # instead of a conversion pass over the float image on the side stream
+    emit_frames = gather is not None and handover == "u8"
 
     def forward():
-        return mesh_renderer.render(vertices, tri, normals, diffuse, eyes, center, up, lpos, lint,
-                                    width, height)
+        with rasterize_triangles_ext.emit_uint8_frames(emit_frames):
+            return mesh_renderer.render(vertices, tri, normals, diffuse, eyes, center, up, lpos, lint,
+                                        width, height)
 
     # fixed target: the same scene with the mesh slightly rotated (mirrors the reference's
     # optimisation tests), rendered once outside the timed region
@@ -305,15 +305,11 @@ def main():
     n_gb = 20
     ev_gbuffer = KernelEvents(n_gb, _native.TIMER_RASTER_FORWARD)
     from pytorch_mesh_renderer_amd.mesh_renderer import rasterize_triangles_ext as ext
-    epilogue_was = ext.USE_SHADING_EPILOGUE
-    ext.USE_SHADING_EPILOGUE = False
-    try:
+    with ext.shading_epilogue(False):
         for i in range(n_gb + 2):
             if i >= 2:
                 ev_gbuffer.arm(i - 2)
             step()
-    finally:
-        ext.USE_SHADING_EPILOGUE = epilogue_was
     if gather is not None:
         gather.wait()
     torch.cuda.synchronize(device)

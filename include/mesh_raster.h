@@ -334,6 +334,7 @@ int mr_soft_backward(const float *drgba, const float *rgba, const float *aux,
  * partials: MR_L1_PARTIALS floats of scratch: the workgroups' partial sums, added in a fixed
  * order by one wavefront -- the loss value is bit-identical from run to run. */
 #define MR_L1_PARTIALS 2048
+int mr_l1_loss_partials(void); /* MR_L1_PARTIALS of the library that was loaded (a binding without the header asks) */
 int mr_l1_loss_forward(const float *a, const float *b, size_t n, float *loss, uint8_t *signs,
                        float *partials, void *stream);
 int mr_l1_loss_backward(const uint8_t *signs, size_t n, const float *upstream, float *da,

@@ -150,6 +150,8 @@ def lib():
         L.mr_soft_forward.restype = ci
         L.mr_soft_backward.argtypes = [vp] * 10 + [ci] * 6 + [cf] * 3 + [vp] * 6 + [vp, sz, vp]
         L.mr_soft_backward.restype = ci
+        L.mr_l1_loss_partials.argtypes = []
+        L.mr_l1_loss_partials.restype = ci
         L.mr_l1_loss_forward.argtypes = [vp, vp, sz, vp, vp, vp, vp]
         L.mr_l1_loss_forward.restype = ci
         L.mr_l1_loss_backward.argtypes = [vp, sz, vp, vp, vp]
@@ -826,7 +828,7 @@ def l1_loss_forward(a, b, want_signs=True):
     a, b = a.contiguous(), b.contiguous()
     out = torch.empty((), dtype=torch.float32, device=dev)
     signs = torch.empty((a.numel() + 3) // 4, dtype=torch.uint8, device=dev) if want_signs else None
-    partials = torch.empty(2048, dtype=torch.float32, device=dev)   # MR_L1_PARTIALS
+    partials = torch.empty(lib().mr_l1_loss_partials(), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         _arm_timer(TIMER_L1_FORWARD)
         rc = lib().mr_l1_loss_forward(_ptr(a), _ptr(b), a.numel(), _ptr(out),
@@ -878,14 +880,15 @@ def tone_map(image, gamma, as_uint8=False):
     return out
 
 
-def vertex_normals_forward(vertices, triangles):
-    """-> (normals [B,V,3], sums [B,V,3]); compute_vertex_normals of the reference as a per-vertex gather."""
+def vertex_normals_forward(vertices, triangles, adjacency=None):
+    """-> (normals [B,V,3], sums [B,V,3]); compute_vertex_normals of the reference as a per-vertex gather.
+    adjacency: vertex_adjacency(triangles, V) if the caller already holds it."""
     _chk("vertices", vertices, _F32, None, None, 3)
     _chk("triangles", triangles, _I32, None, 3)
     dev = _require_device(vertices, triangles)
     vertices, triangles = vertices.contiguous(), triangles.contiguous()
     B, V, _ = vertices.shape
-    offsets, entries = vertex_adjacency(triangles, V)
+    offsets, entries = adjacency if adjacency is not None else vertex_adjacency(triangles, V)
     sums, normals = torch.empty_like(vertices), torch.empty_like(vertices)
     with torch.cuda.device(dev):
         rc = lib().mr_vertex_normals_forward(_ptr(vertices), _ptr(triangles), _ptr(offsets), _ptr(entries), B, V,
@@ -894,7 +897,7 @@ def vertex_normals_forward(vertices, triangles):
     return normals, sums
 
 
-def vertex_normals_backward(dnormals, vertices, sums, triangles):
+def vertex_normals_backward(dnormals, vertices, sums, triangles, adjacency=None):
     """-> dvertices [B,V,3]."""
     _chk("vertices", vertices, _F32, None, None, 3)
     B, V, _ = vertices.shape
@@ -903,7 +906,7 @@ def vertex_normals_backward(dnormals, vertices, sums, triangles):
     _chk("triangles", triangles, _I32, None, 3)
     dev = _require_device(dnormals, vertices, sums, triangles)
     dnormals, vertices, sums, triangles = [t.contiguous() for t in (dnormals, vertices, sums, triangles)]
-    offsets, entries = vertex_adjacency(triangles, V)
+    offsets, entries = adjacency if adjacency is not None else vertex_adjacency(triangles, V)
     dsums, dvertices = torch.empty_like(vertices), torch.empty_like(vertices)
     with torch.cuda.device(dev):
         rc = lib().mr_vertex_normals_backward(_ptr(dnormals), _ptr(vertices), _ptr(sums), _ptr(triangles),

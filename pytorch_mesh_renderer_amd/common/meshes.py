@@ -15,23 +15,33 @@ class _VertexNormals(torch.autograd.Function):
     def forward(ctx, vertices, triangles):
         from .. import _native
         v = vertices.detach().contiguous()
-        normals, sums = _native.vertex_normals_forward(v, triangles)
-        ctx.save_for_backward(v, sums, triangles)
+        offsets, entries = _native.vertex_adjacency(triangles, v.shape[1])
+        normals, sums = _native.vertex_normals_forward(v, triangles, adjacency=(offsets, entries))
+        # the adjacency travels with the node: the backward does not rebuild it (an argsort) when the
+        # cache on the caller's tensor object is gone
+        ctx.save_for_backward(v, sums, triangles, offsets, entries)
         return normals
 
     @staticmethod
     def backward(ctx, dnormals):
         from .. import _native
-        v, sums, triangles = ctx.saved_tensors
-        return _native.vertex_normals_backward(dnormals.contiguous(), v, sums, triangles), None
+        v, sums, triangles, offsets, entries = ctx.saved_tensors
+        return _native.vertex_normals_backward(dnormals.contiguous(), v, sums, triangles,
+                                               adjacency=(offsets, entries)), None
 
 
 def compute_vertex_normals(vertices, triangles):
-    """vertices [B,V,3], triangles [T,3] -> unit vertex normals [B,V,3]."""
+    """vertices [B,V,3], triangles [T,3] (any integer dtype, as the reference's triangles.long()
+    accepts: src/common/meshes.py:18) -> unit vertex normals [B,V,3]."""
     if vertices.is_cuda and vertices.dtype == torch.float32:
-        if triangles.dtype != torch.int32:
-            raise RuntimeError("triangles must be int32")
-        return _VertexNormals.apply(vertices, triangles.to(vertices.device))
+        if triangles.dtype in (torch.float16, torch.float32, torch.float64, torch.bfloat16, torch.bool):
+            raise RuntimeError("triangles must hold integer vertex indices")
+        # the kernels index with int32 (a vertex count beyond 2^31 does not fit a GPU anyway); the
+        # conversion keeps the caller's tensor object -- and the adjacency cached on it -- when it
+        # already is int32 on the right device
+        tri = triangles if triangles.dtype == torch.int32 and triangles.device == vertices.device else \
+            triangles.to(device=vertices.device, dtype=torch.int32)
+        return _VertexNormals.apply(vertices, tri)
     tri = triangles.long()
     corner_index = tri.t().reshape(-1)                                   # [3T]: all first corners, then ...
     corners = vertices.index_select(1, corner_index).reshape(vertices.shape[0], 3, -1, 3)

@@ -424,6 +424,8 @@ int mr_soft_backward(const float *drgba, const float *rgba, const float *aux, co
                                   dlight_intensities, workspace, (hipStream_t)stream);
 }
 
+int mr_l1_loss_partials(void) { return MR_L1_PARTIALS; }
+
 int mr_l1_loss_forward(const float *a, const float *b, size_t n, float *loss, uint8_t *signs,
                        float *partials, void *stream) {
   if (!loss || (n > 0 && (!a || !b || !partials))) return MR_EINVAL;

@@ -19,8 +19,9 @@
 #define MR_L1_NT_STORE 1
 #endif
 #ifndef MR_L1_BLOCKS
-#define MR_L1_BLOCKS 2048  // = MR_L1_PARTIALS
+#define MR_L1_BLOCKS MR_L1_PARTIALS
 #endif
+static_assert(MR_L1_BLOCKS <= MR_L1_PARTIALS, "one partial sum per workgroup: the caller's scratch holds MR_L1_PARTIALS floats");
 #ifndef MR_L1_UNROLL
 #define MR_L1_UNROLL 2  // measured alone at 1024^2 x 32: 1 -> 0.216, 2 -> 0.211, 4 -> 0.248, 8 -> 0.241 ms
 #endif
@@ -169,8 +170,8 @@ __global__ __launch_bounds__(kThreads) void k_export_u8(const float4 *__restrict
 
 // ---- tone_mapper (src/mesh_renderer/render.py:389-419): out = clamp(image^gamma / max, 0, 1) with
 // max taken per image over image^gamma.  Two streaming passes: (1) per-image maximum of the powers
-// -- they are non-negative or NaN, so their bit patterns order like signed integers with NaN on
-// top: one integer atomicMax per workgroup also reproduces torch.max's NaN propagation; (2) the
+// as order-preserving integer keys (tone_key below): one integer atomicMax per workgroup, which
+// also reproduces torch.max's NaN propagation; (2) the
 // powers are recomputed (cheaper than 4 B/element of scratch traffic), scaled with an IEEE
 // division as torch does, clamped, and stored as fp32 or straight as 8-bit frames.
 // FAST: gamma is finite.  For a finite positive base the power is exp2(gamma * log2(v)) on the 1-ulp
@@ -188,6 +189,17 @@ __device__ __forceinline__ float tone_power(float v, float gamma) {
   return p != p ? __int_as_float(0x7fc00000) : p;  // canonical NaN: positive as an integer
 }
 
+// The maximum is taken on integer keys that order like the floats they stand for: non-negative
+// values and NaN (canonical, positive) keep their bit pattern -- NaN sorts on top, which is
+// torch.max's propagation --, negative values (a negative base with an odd integer gamma: (-2)^3 =
+// -8) map below all of them in their own order, -0.0 counts as +0.0.  (Round 2 masked the sign bit
+// off instead: -8 became +8 and could win the maximum.)
+__device__ __forceinline__ int tone_key(float p) {
+  const int u = __float_as_int(p);
+  return u >= 0 ? u : (u == INT_MIN ? 0 : u ^ 0x7fffffff);
+}
+__device__ __forceinline__ float tone_value(int key) { return __int_as_float(key >= 0 ? key : key ^ 0x7fffffff); }
+
 // VEC: the image's element count is a multiple of four (every image then starts 16-byte aligned):
 // 16-byte accesses.  One integer atomicMax per WORKGROUP, ~2048 workgroups in all: with one per
 // wavefront of a 512-workgroup grid, 65k atomics queued up on the one cache line that holds all the
@@ -197,8 +209,8 @@ template <bool FAST, bool VEC>
 __global__ __launch_bounds__(kThreads) void k_tone_max(const float *__restrict__ image, size_t per_image,
                                                        float gamma, int *__restrict__ max_bits) {
   const float *img = image + (size_t)blockIdx.y * per_image;
-  int best = 0;  // bits of +0.0
-  auto take = [&](float v) { best = max(best, __float_as_int(tone_power<FAST>(v, gamma)) & 0x7fffffff); };  // (-0.0 -> +0.0)
+  int best = INT_MIN;  // below every key
+  auto take = [&](float v) { best = max(best, tone_key(tone_power<FAST>(v, gamma))); };
   if (VEC) {
     const float4 *img4 = (const float4 *)img;
     for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < per_image / 4; i += (size_t)gridDim.x * kThreads) {
@@ -216,7 +228,7 @@ __global__ __launch_bounds__(kThreads) void k_tone_max(const float *__restrict__
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int w = 1; w < kThreads / kWave; ++w) best = max(best, s_best[w]);
-    if (best != 0) atomicMax(&max_bits[blockIdx.y], best);
+    if (best != INT_MIN) atomicMax(&max_bits[blockIdx.y], best);
   }
 }
 
@@ -225,7 +237,7 @@ __global__ __launch_bounds__(kThreads) void k_tone_map(const float *__restrict__
                                                        float gamma, const int *__restrict__ max_bits,
                                                        float *__restrict__ out, uint8_t *__restrict__ out_u8) {
   const size_t base = (size_t)blockIdx.y * per_image;
-  const float image_max = __int_as_float(max_bits[blockIdx.y]);
+  const float image_max = tone_value(max_bits[blockIdx.y]);
   auto scaled = [&](float v) { return tone_power<FAST>(v, gamma) / image_max; };  // IEEE division, as torch does
   auto clamped = [](float x) { return x != x ? x : fminf(fmaxf(x, 0.0f), 1.0f); };  // torch.clamp: NaN stays NaN
   if (VEC) {
@@ -283,7 +295,7 @@ int launch_l1_backward(const uint8_t *signs, size_t n, const float *upstream, fl
 int launch_tone_map(const float *image, int B, size_t per_image, float gamma, int *max_bits, float *out,
                     uint8_t *out_u8, hipStream_t s) {
   if (B == 0 || per_image == 0) return MR_OK;
-  if (hipMemsetAsync(max_bits, 0, (size_t)B * sizeof(int), s) != hipSuccess) return check_launch();
+  if (hipMemsetD32Async((hipDeviceptr_t)max_bits, INT_MIN, (size_t)B, s) != hipSuccess) return check_launch();  // below every key
   const bool vec = per_image % 4 == 0 && ((uintptr_t)image & 15u) == 0 && ((uintptr_t)out & 15u) == 0 &&
                    ((uintptr_t)out_u8 & 3u) == 0;
   const bool fast = gamma == gamma && gamma - gamma == 0.0f;  // finite

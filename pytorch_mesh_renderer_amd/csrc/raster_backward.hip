@@ -143,6 +143,11 @@ struct RasterGradFn {
   }
 };
 
+// MR_RASTER_BWD_KERNEL: 0 = column runs + LDS hash table, 1 = rows kernel, 2 = lane-accumulating (round 3).
+#ifndef MR_RASTER_BWD_KERNEL
+#define MR_RASTER_BWD_KERNEL 2
+#endif
+#if MR_RASTER_BWD_KERNEL == 1
 // The same sums through the row kernel (run_accum.h, k_accumulate_rows): acc[j * 3 + c] = sum over the
 // triangle's pixels of b_j q_c is a product of two per-pixel factors, so the lanes park b[3] and q[3]
 // and nine reduction lanes form the products -- the structure the fused shading backward uses, with
@@ -190,13 +195,12 @@ struct RasterRowsFn {
     f[6] = 0.f; f[7] = 0.f;
   }
 };
+#endif
 
 // Round 3: the same nine sums through k_accumulate_lanes (run_accum.h) -- each lane keeps them in
 // registers down its vertical run (RasterGradFn's accumulate()), only finished runs go through LDS.
-// MR_RASTER_BWD_KERNEL: 0 = column runs + LDS hash table, 1 = rows kernel, 2 = lane-accumulating.
-#ifndef MR_RASTER_BWD_KERNEL
-#define MR_RASTER_BWD_KERNEL 2
-#endif
+// Measured, whole mr_rasterize_backward call: 1024^2 x 32 / 5k triangles 0.310 -> 0.288 ms, 2048^2 x 8 /
+// 50k 0.364 -> 0.366, 256^2 x 8 0.054 -> (with the launch-size-dependent strip height) see DESIGN.
 #ifndef MR_RASTER_LANE_ROWS
 #define MR_RASTER_LANE_ROWS 16
 #endif
@@ -299,7 +303,8 @@ __global__ __launch_bounds__(kThreads) void k_from_fixed(const long long *__rest
                                                          const float *__restrict__ det_scale, long n,
                                                          float *__restrict__ out) {
   const long i = (long)blockIdx.x * kThreads + threadIdx.x;
-  if (i < n) out[i] = (float)fixed[i] * det_scale[1];
+  // a contribution did not fit the fixed-point range (run_accum.h, atomic_add_fixed): NaN, not garbage
+  if (i < n) out[i] = *det_overflow_flag(det_scale) ? __int_as_float(0x7fc00000) : (float)fixed[i] * det_scale[1];
 }
 
 }  // namespace

@@ -56,8 +56,21 @@ constexpr int kRunMaxProbe = 16;
 // fixed point (a power of two: exact), det_scale[1] = 2^-k back; k is derived on the device from the
 // largest upstream gradient g so that g maps to about 2^41: values down to g * 2^-42 are resolved and
 // a triangle's total may reach g * 2^21 before the 64-bit range ends.
-__device__ __forceinline__ void atomic_add_fixed(long long *p, float v, float to_fixed) {
-  atomicAdd((unsigned long long *)p, (unsigned long long)__float2ll_rn(v * to_fixed));
+// A contribution that does not fit -- NaN, infinite, or beyond +-2^63 after scaling (1 / det of a
+// sliver triangle times a large upstream gradient) -- is not converted (the conversion of an
+// out-of-range float is garbage of arbitrary sign): it raises the launch's overflow flag instead,
+// det_overflow_flag(det_scale), and the pass that converts the sums back to float writes NaN
+// everywhere when the flag is set -- the float path's answer to such inputs, spread over the whole
+// output, instead of a finite wrong number.  (Sums of many in-range contributions still wrap
+// silently beyond 2^63: the scale leaves 2^21 of headroom over the largest upstream gradient.)
+__device__ __forceinline__ int *det_overflow_flag(const float *det_scale) { return (int *)det_scale + 8; }
+__device__ __forceinline__ void atomic_add_fixed(long long *p, float v, float to_fixed, int *overflow) {
+  const float x = v * to_fixed;
+  if (!(fabsf(x) < 9.0e18f)) {
+    atomicOr(overflow, 1);
+    return;
+  }
+  atomicAdd((unsigned long long *)p, (unsigned long long)__float2ll_rn(x));
 }
 
 template <int SLOTS>
@@ -75,13 +88,13 @@ __device__ __forceinline__ int run_find_slot(int *keys, int tri) {
 // VAL = float (float atomics) or long long (deterministic mode: fixed point, `scale` = 2^k)
 template <int N, int STRIDE, int SLOTS, class VAL>
 __device__ __forceinline__ void run_flush(int *keys, VAL *vals, VAL *acc_img, int tri,
-                                          float (&a)[N], float scale) {
+                                          float (&a)[N], float scale, int *overflow) {
   if (tri < 0) return;
   const int slot = run_find_slot<SLOTS>(keys, tri);
   VAL *dst = slot >= 0 ? &vals[slot * N] : &acc_img[(size_t)tri * STRIDE];  // saturated table: straight to HBM
 #pragma unroll
   for (int k = 0; k < N; ++k) {
-    if constexpr (sizeof(VAL) == 8) atomic_add_fixed((long long *)&dst[k], a[k], scale);
+    if constexpr (sizeof(VAL) == 8) atomic_add_fixed((long long *)&dst[k], a[k], scale, overflow);
     else atomicAdd(&dst[k], a[k]);
   }
 #pragma unroll
@@ -98,6 +111,7 @@ __global__ __launch_bounds__(kRunThreads, DET ? 1 : Fn::kMinWavesPerSimd) void k
   __shared__ int s_keys[SLOTS];
   __shared__ VAL s_vals[SLOTS * N];
   const float scale = DET ? det_scale[0] : 0.0f;
+  int *overflow = DET ? det_overflow_flag(det_scale) : nullptr;
 
   const int region = xcd_contiguous_block((int)blockIdx.x, n_regions, regions_per_xcd);
   if (region < 0) return;
@@ -136,13 +150,13 @@ __global__ __launch_bounds__(kRunThreads, DET ? 1 : Fn::kMinWavesPerSimd) void k
       typename Fn::Pixel p;
       if (!fn.prepare(raw, T, tri, p)) continue;
       if (tri != run_tri) {
-        run_flush<N, STRIDE, SLOTS, VAL>(s_keys, s_vals, acc_img, run_tri, a, scale);
+        run_flush<N, STRIDE, SLOTS, VAL>(s_keys, s_vals, acc_img, run_tri, a, scale, overflow);
         run_tri = tri;
         fn.load_triangle(img, tri, tri_data);
       }
       fn.accumulate(p, tri_data, a, image_sums);
     }
-    run_flush<N, STRIDE, SLOTS, VAL>(s_keys, s_vals, acc_img, run_tri, a, scale);
+    run_flush<N, STRIDE, SLOTS, VAL>(s_keys, s_vals, acc_img, run_tri, a, scale, overflow);
   }
   fn.end_image(img, image_sums);  // every lane takes part (wave-level reduction inside)
   __syncthreads();
@@ -286,7 +300,7 @@ __global__ __launch_bounds__(kRowsThreads, Fn::kMinWavesPerSimd) void k_accumula
   int merge_count = 0;   // slots in use, wave-uniform
   auto commit = [&](const int t, const float v) {  // one contiguous N-lane atomic into the triangle's row
     if (lane < N) {
-      if (DET) atomic_add_fixed(&acc_fixed[(size_t)t * STRIDE + lane], v, to_fixed);
+      if (DET) atomic_add_fixed(&acc_fixed[(size_t)t * STRIDE + lane], v, to_fixed, det_overflow_flag(det_scale));
       else atomicAdd(&acc_img[(size_t)t * STRIDE + lane], v);
     }
   };
@@ -478,7 +492,7 @@ __global__ __launch_bounds__(kWave, Fn::kMinWavesPerSimd) void k_accumulate_lane
   int merge_count = 0;   // slots in use, wave-uniform
   auto commit = [&](const int t, const float v) {
     if (lane < N) {
-      if (DET) atomic_add_fixed(&acc_fixed[(size_t)t * STRIDE + col], v, to_fixed);
+      if (DET) atomic_add_fixed(&acc_fixed[(size_t)t * STRIDE + col], v, to_fixed, det_overflow_flag(det_scale));
       else atomicAdd(&acc_img[(size_t)t * STRIDE + col], v);
     }
   };

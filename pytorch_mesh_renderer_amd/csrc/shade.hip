@@ -361,7 +361,7 @@ struct ShadeLaneFn : ShadeGradFn<L, SIGNS, LG> {
   static constexpr int kN = 9 * kGroups + 9;
   static constexpr int kStride = 36;  // the rows of acc keep ShadeGradFn's layout: the gather reads it
   static constexpr int kLaneRowsPerWave = LG ? 32 : MR_LANE_ROWS;
-  static constexpr int kMinWavesPerSimd = MR_LANE_WAVES;
+  static constexpr int kMinWavesPerSimd = kN > 27 ? 3 : MR_LANE_WAVES;  // 36 accumulators: 137-145 VGPRs
   // the gi-th selected group
   __host__ __device__ static constexpr int group(int gi) {
     int g = 0;
@@ -493,6 +493,7 @@ __global__ __launch_bounds__(kThreads) void k_shade_gather(
       sum += (m[0] * dx + m[4] * dy) + m[12] * dw;
     }
   }
+  if (DET && *det_overflow_flag(det_scale)) sum = __int_as_float(0x7fc00000);  // see atomic_add_fixed
   float *out = j < 3 ? dnormals + gid * 3 + j
              : j < 6 ? dpositions + gid * 3 + (j - 3)
              : j < 9 ? ddiffuse + gid * 3 + (j - 6)

@@ -39,16 +39,19 @@ def l1_loss(image, target):
 
     When `image` is the direct output of render()'s fused diffuse path, the backward skips the
     dense gradient image: the loss's sign codes go straight into the shading backward
-    (rasterize_triangles_ext.FusedPhongL1Loss)."""
+    (rasterize_triangles_ext.FusedPhongL1Loss).  That route never forms d loss / d image, so it is
+    taken only while nothing observes that gradient -- no image.retain_grad(), no hook on the image
+    -- and once per rendered image; torch.autograd.grad(loss, image) needs the generic op
+    (USE_FUSED_RENDER_LOSS = False, or any op between render() and the loss)."""
     if image.shape != target.shape:
         raise ValueError("image and target must have the same shape")
     if image.dtype != torch.float32 or target.dtype != torch.float32:
         raise ValueError("l1_loss expects float32 tensors")
-    record = getattr(image, "_mr_fused_render", None)
-    if (USE_FUSED_RENDER_LOSS and record is not None and image.grad_fn is record["node"] and
-            torch.is_grad_enabled() and image.requires_grad):
-        from .rasterize_triangles_ext import FusedPhongL1Loss
-        # image.detach(): the renderer's own node must not be part of this loss's graph (autograd
-        # would run it on a materialised all-zero gradient image)
-        return FusedPhongL1Loss.apply(image.detach(), target, *record["inputs"], record["saved"])
+    if USE_FUSED_RENDER_LOSS and torch.is_grad_enabled() and image.requires_grad:
+        from .rasterize_triangles_ext import FusedPhongL1Loss, take_fused_render
+        record = take_fused_render(image)
+        if record is not None:
+            # image.detach(): the renderer's own node must not be part of this loss's graph (autograd
+            # would run it on a materialised all-zero gradient image)
+            return FusedPhongL1Loss.apply(image.detach(), target, *record["inputs"], record["saved"])
     return _MeanAbsError.apply(image, target)

@@ -6,7 +6,10 @@ rasterizes ONE image per call; this one also accepts a batch ([B,V,4]) so that
 rasterize_clip_space does not need a Python loop over images
 (src/mesh_renderer/rasterize.py:112-121) -- on MI355X the batch is the grid.
 """
+import contextlib
 import os
+import threading
+import weakref
 
 import torch
 
@@ -107,14 +110,47 @@ class FusedAttributeRasterizer(torch.autograd.Function):
         return dclip, dattrs, None, dbackground, None, None
 
 
-# FusedPhongRenderer's forward: True = one pass over the pixels (mr_render_forward: the shading is the
-# epilogue of the rasterizer's tile walk); False = k_raster, then k_shade_forward over the G-buffer.
-USE_SHADING_EPILOGUE = os.environ.get("MR_SHADING_EPILOGUE", "1") != "0"
-# True: the one-pass forward also writes the image as 8-bit frames (4 B/px of stores) and render()
-# attaches them to the image it returns; mesh_renderer.to_uint8(image) then hands them out instead
-# of converting the float image in a pass of its own.  For callers that export every frame (the
-# multi-GPU hand-over of bench.py).
-EMIT_UINT8_FRAMES = os.environ.get("MR_EMIT_UINT8_FRAMES", "0") != "0"
+# Switches of FusedPhongRenderer's forward.  They are scoped to a `with` block of the calling thread
+# (round 2 flipped module globals from the benchmark: whichever thread set them last won):
+#   shading_epilogue(False)  k_raster, then k_shade_forward over the G-buffer, instead of one pass over
+#                            the pixels (mr_render_forward: the shading is the epilogue of the
+#                            rasterizer's tile walk).  For measurements and the parity tests.
+#   emit_uint8_frames(True)  the one-pass forward also writes the image as 8-bit frames (4 B/px of
+#                            stores) and render() attaches them to the image it returns;
+#                            mesh_renderer.to_uint8(image) then hands them out instead of converting
+#                            the float image in a pass of its own.  For callers that export every frame
+#                            (the multi-GPU hand-over of bench.py).
+# Defaults come from the environment (MR_SHADING_EPILOGUE, MR_EMIT_UINT8_FRAMES) once, at import.
+_DEFAULTS = {"shading_epilogue": os.environ.get("MR_SHADING_EPILOGUE", "1") != "0",
+             "emit_uint8_frames": os.environ.get("MR_EMIT_UINT8_FRAMES", "0") != "0"}
+_scoped = threading.local()
+
+
+def _switch(name):
+    return getattr(_scoped, name, _DEFAULTS[name])
+
+
+@contextlib.contextmanager
+def _scoped_switch(name, value):
+    had, before = hasattr(_scoped, name), getattr(_scoped, name, None)
+    setattr(_scoped, name, bool(value))
+    try:
+        yield
+    finally:
+        if had:
+            setattr(_scoped, name, before)
+        else:
+            delattr(_scoped, name)
+
+
+def shading_epilogue(on):
+    """with shading_epilogue(False): render(...) -- see the comment above."""
+    return _scoped_switch("shading_epilogue", on)
+
+
+def emit_uint8_frames(on):
+    """with emit_uint8_frames(True): image = render(...); frames = to_uint8(image)."""
+    return _scoped_switch("emit_uint8_frames", on)
 
 
 class FusedPhongRenderer(torch.autograd.Function):
@@ -136,11 +172,12 @@ class FusedPhongRenderer(torch.autograd.Function):
         lp, li = light_positions.detach().contiguous(), light_intensities.detach().contiguous()
         amb = ambient.detach().contiguous() if ambient is not None else None
         frames = None
-        if USE_SHADING_EPILOGUE and EMIT_UINT8_FRAMES:
+        epilogue, want_frames = _switch("shading_epilogue"), _switch("emit_uint8_frames")
+        if epilogue and want_frames:
             clip, ids, bary, _, rgba, corner_records, frames = _native.render_forward(
                 verts, xf, args[0], args[1], triangles, lp, li, amb, int(image_width), int(image_height),
                 want_z=False, want_u8=True)
-        elif USE_SHADING_EPILOGUE:
+        elif epilogue:
             clip, ids, bary, _, rgba, corner_records = _native.render_forward(
                 verts, xf, args[0], args[1], triangles, lp, li, amb, int(image_width), int(image_height),
                 want_z=False)
@@ -189,6 +226,31 @@ class FusedPhongRenderer(torch.autograd.Function):
                                                 needs_normal_grad=ctx.needs_input_grad[2],
                                                 needs_diffuse_grad=ctx.needs_input_grad[3])
         return grads + (None, None)
+
+
+# render()'s fused diffuse outputs, by autograd node: what FusedPhongL1Loss needs to differentiate a
+# loss on that image straight to the renderer's inputs.  Weak keys: an entry lives as long as its
+# node does, and holds only tensors the node holds anyway.
+_fused_renders = weakref.WeakKeyDictionary()
+
+
+def remember_fused_render(node, inputs):
+    _fused_renders[node] = {"saved": tuple(node.saved_tensors), "inputs": inputs}
+
+
+def take_fused_render(image):
+    """The record of render()'s node behind `image` -- once: the caller (losses.l1_loss) hands the saved
+    tensors to FusedPhongL1Loss, which keeps them itself; a second loss on the same image goes
+    through the renderer's own node like any other op.  None when `image` is not such an output, or
+    when something observes the image's own gradient (retain_grad(), a tensor hook): the fused
+    route never forms that gradient."""
+    node = image.grad_fn
+    if node is None or image.retains_grad or image._backward_hooks:
+        return None
+    try:
+        return _fused_renders.pop(node, None)
+    except TypeError:   # a built-in node (MulBackward0, ...) cannot even be weakly referenced: not ours
+        return None
 
 
 class FusedPhongL1Loss(torch.autograd.Function):

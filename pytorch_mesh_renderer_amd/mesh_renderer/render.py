@@ -192,13 +192,15 @@ def _render_fused(vertices, triangles, normals, diffuse_colors, camera_position,
     transforms = clip_space_transforms.to(torch.float32)
     image, frames = FusedPhongRenderer.apply(vertices, transforms, normals, diffuse_colors, triangles, lp, li,
                                              amb, image_width, image_height)
-    if frames is not None:  # rasterize_triangles_ext.EMIT_UINT8_FRAMES: see to_uint8
+    if frames is not None:  # rasterize_triangles_ext.emit_uint8_frames: see to_uint8
         image._mr_frames_u8 = (frames, image._version)
     if image.grad_fn is not None:
-        # lets losses.l1_loss differentiate straight to these inputs (FusedPhongL1Loss); the node
-        # is compared by identity there, so a tensor derived from `image` never takes that path
-        image._mr_fused_render = {"node": image.grad_fn, "saved": tuple(image.grad_fn.saved_tensors),
-                                  "inputs": (vertices, transforms, normals, diffuse_colors, lp, li, amb)}
+        # lets losses.l1_loss differentiate straight to these inputs (FusedPhongL1Loss).  The record
+        # is keyed by the autograd node in a weak map -- nothing is stored on the tensor (it stays
+        # picklable / deep-copyable), a tensor derived from `image` has another node and never takes
+        # that path, and the record dies with the node.
+        from .rasterize_triangles_ext import remember_fused_render
+        remember_fused_render(image.grad_fn, (vertices, transforms, normals, diffuse_colors, lp, li, amb))
     return image
 
 

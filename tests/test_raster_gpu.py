@@ -421,8 +421,54 @@ def test_vertex_normals_kernel_matches_reference(device):
     bad = tris.clone()
     bad[0, 1] = v.shape[1] + 3
     assert bool(torch.isfinite(meshes.compute_vertex_normals(v.detach(), bad)).all())
+    # any integer dtype, as the reference's triangles.long() takes (meshes.py:18); floats are an error
+    assert torch.equal(meshes.compute_vertex_normals(v.detach(), tris.long()), n.detach())
+    assert torch.equal(meshes.compute_vertex_normals(v.detach(), tris.cpu().to(torch.int16)), n.detach())
     with pytest.raises(RuntimeError):
-        meshes.compute_vertex_normals(v.detach(), tris.long())
+        meshes.compute_vertex_normals(v.detach(), tris.float())
+    # the backward reuses the adjacency its forward saved (no argsort when the cache on the tensor is gone)
+    from pytorch_mesh_renderer_amd import _native
+    v3 = torch.tensor(g["vertices"], device=device, requires_grad=True)
+    n3 = meshes.compute_vertex_normals(v3, tris.long())
+    calls = []
+    real = _native.vertex_adjacency
+    _native.vertex_adjacency = lambda *a, **k: calls.append(1) or real(*a, **k)
+    try:
+        (n3 * torch.tensor(g["weights"], device=device)).sum().backward()
+    finally:
+        _native.vertex_adjacency = real
+    assert not calls and torch.equal(v3.grad, v.grad)
+
+
+def test_deterministic_mode_flags_contributions_outside_its_fixed_point_range(device):
+    """the deterministic mode converts every contribution to 64-bit fixed point; one that
+    does not fit -- here an infinite upstream gradient on one pixel, and a NaN -- used to come back
+    as a finite number of arbitrary sign.  Now the launch is flagged and the outputs are NaN; inputs
+    in range still give the float path's values."""
+    from pytorch_mesh_renderer_amd import _native
+    g = golden_npz("raster_cube64.npz")
+    clip, tris = torch.tensor(g["clip"], device=device), torch.tensor(g["triangles"], device=device)
+    if clip.dim() == 2:
+        clip = clip.unsqueeze(0)
+    ids, bary, _ = _native.rasterize_forward(clip, tris, 64, 64)
+    dbary = seeded_dbary((64, 64, 3), seed=2).unsqueeze(0).to(device)
+    covered = (bary.sum(-1) > 0.5).nonzero()
+    _, y, x = [int(t) for t in covered[len(covered) // 2]]
+    want = _native.rasterize_backward(dbary, clip, tris, ids, bary)
+    before = _native.set_deterministic(True)
+    try:
+        fine = _native.rasterize_backward(dbary, clip, tris, ids, bary)
+        np.testing.assert_allclose(fine.cpu().numpy(), want.cpu().numpy(), atol=1e-7, rtol=1e-4)
+        for poison in (float("inf"), float("nan")):
+            bad = dbary.clone()
+            bad[0, y, x, 1] = poison
+            got = _native.rasterize_backward(bad, clip, tris, ids, bary)
+            assert not bool(torch.isfinite(got).any()), "a contribution outside the range must poison the result"
+    finally:
+        _native.set_deterministic(before)
+    floaty = dbary.clone()
+    floaty[0, y, x, 1] = float("inf")
+    assert not bool(torch.isfinite(_native.rasterize_backward(floaty, clip, tris, ids, bary)).all())
 
 
 def test_rasterize_triangles_cpp_shim_is_a_drop_in(device):

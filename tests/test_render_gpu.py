@@ -585,7 +585,7 @@ def test_fused_diffuse_render_matches_composed_path_including_the_camera(device)
 
 
 def test_render_emits_uint8_frames_on_request(device):
-    """rasterize_triangles_ext.EMIT_UINT8_FRAMES: the forward kernel also writes the 8-bit frames;
+    """rasterize_triangles_ext.emit_uint8_frames(True): the forward kernel also writes the 8-bit frames;
     to_uint8(image) hands them out (no conversion pass) and they equal mr_export_u8 of the float image;
     an image modified in place falls back to the conversion."""
     import importlib
@@ -598,24 +598,22 @@ def test_render_emits_uint8_frames_on_request(device):
                                     job["eyes"], torch.zeros(2, 3), torch.tensor([0.0, 1.0, 0.0]),
                                     d["light_positions"], d["light_intensities"] * 1.3, 130, 67)
     plain = render()
-    ext.EMIT_UINT8_FRAMES = True
-    try:
+    with ext.emit_uint8_frames(True):
         image = render()
-        with _CountCalls("export_u8") as counter:
-            frames = mesh_renderer.to_uint8(image)
-        assert counter.calls == 0 and frames.dtype == torch.uint8 and frames.shape == image.shape
-        assert torch.equal(image.detach(), plain.detach())
-        from pytorch_mesh_renderer_amd import _native
-        assert torch.equal(frames, _native.export_u8(image.detach()))
-        assert int(frames[..., :3].max()) == 255                  # over-exposed pixels saturate
-        torch.mean(image).backward()                             # the extra output does not disturb autograd
-        with torch.no_grad():
-            image.mul_(0.5)
-        with _CountCalls("export_u8") as counter:
-            again = mesh_renderer.to_uint8(image)
-        assert counter.calls == 1 and torch.equal(again, _native.export_u8(image.detach()))
-    finally:
-        ext.EMIT_UINT8_FRAMES = False
+    assert getattr(render(), "_mr_frames_u8", None) is None     # the switch ended with its block
+    with _CountCalls("export_u8") as counter:
+        frames = mesh_renderer.to_uint8(image)
+    assert counter.calls == 0 and frames.dtype == torch.uint8 and frames.shape == image.shape
+    assert torch.equal(image.detach(), plain.detach())
+    from pytorch_mesh_renderer_amd import _native
+    assert torch.equal(frames, _native.export_u8(image.detach()))
+    assert int(frames[..., :3].max()) == 255                  # over-exposed pixels saturate
+    torch.mean(image).backward()                             # the extra output does not disturb autograd
+    with torch.no_grad():
+        image.mul_(0.5)
+    with _CountCalls("export_u8") as counter:
+        again = mesh_renderer.to_uint8(image)
+    assert counter.calls == 1 and torch.equal(again, _native.export_u8(image.detach()))
 
 
 def test_render_with_and_without_shading_epilogue(device):
@@ -630,16 +628,13 @@ def test_render_with_and_without_shading_epilogue(device):
     for epilogue in (True, False):
         leaves = {k: job[k].clone().to(device).requires_grad_(True)
                   for k in ("vertices", "normals", "diffuse", "light_positions", "eyes")}
-        ext.USE_SHADING_EPILOGUE = epilogue
-        try:
+        with ext.shading_epilogue(epilogue):
             with _CountCalls("render_forward") as counter:
                 img = mesh_renderer.render(leaves["vertices"], job["triangles"].to(device), leaves["normals"],
                                            leaves["diffuse"], leaves["eyes"], torch.zeros(2, 3, device=device),
                                            torch.tensor([0.0, 1.0, 0.0], device=device), leaves["light_positions"],
                                            job["light_intensities"].to(device), 120, 90)
                 mesh_renderer.losses.l1_loss(img, target).backward()
-        finally:
-            ext.USE_SHADING_EPILOGUE = True
         assert counter.calls == (1 if epilogue else 0)
         results[epilogue] = (img.detach().cpu().numpy(), {k: v.grad.cpu().numpy() for k, v in leaves.items()})
     np.testing.assert_allclose(results[True][0], results[False][0], atol=ATOL, rtol=0)
@@ -894,12 +889,80 @@ def test_l1_loss_on_a_derived_image_takes_the_generic_path(device):
     img = mesh_renderer.render(v, job["triangles"].to(device), job["normals"].to(device), job["diffuse"].to(device),
                                job["eyes"], torch.zeros(1, 3), torch.tensor([0.0, 1.0, 0.0]),
                                job["light_positions"].to(device), job["light_intensities"].to(device), 64, 48)
-    assert getattr(img, "_mr_fused_render", None) is not None
+    from pytorch_mesh_renderer_amd.mesh_renderer import rasterize_triangles_ext as ext
+    assert img.grad_fn in ext._fused_renders and "_mr_fused_render" not in img.__dict__
     derived = img * 1.0
-    assert getattr(derived, "_mr_fused_render", None) is None
+    assert ext.take_fused_render(derived) is None
     with _CountCalls("l1_loss_backward") as dense:
         mesh_renderer.losses.l1_loss(derived, torch.zeros_like(derived)).backward()
     assert dense.calls == 1 and float(v.grad.abs().max()) > 0
+
+
+def test_fused_render_loss_keeps_autograd_semantics_of_the_image(device):
+    """the fused render-loss route differentiates from image.detach() straight to the
+    renderer's inputs, so it must step aside whenever the image's own gradient is observed
+    (retain_grad, a tensor hook), must not leave Python state on the tensor (torch.save / deepcopy
+    work), is taken once per rendered image, and its record dies with the autograd node."""
+    import copy
+    import gc
+    import io
+    from pytorch_mesh_renderer_amd.mesh_renderer import rasterize_triangles_ext as ext
+    job = synthetic.sphere_job(1, 64, 48, 8)
+    tri, normals, diffuse = job["triangles"].to(device), job["normals"].to(device), job["diffuse"].to(device)
+    target = torch.rand(1, 48, 64, 4, generator=torch.Generator().manual_seed(4)).to(device)
+
+    def render(v):
+        return mesh_renderer.render(v, tri, normals, diffuse, job["eyes"], torch.zeros(1, 3),
+                                    torch.tensor([0.0, 1.0, 0.0]), job["light_positions"].to(device),
+                                    job["light_intensities"].to(device), 64, 48)
+
+    def leaf():
+        return job["vertices"].clone().to(device).requires_grad_(True)
+
+    # reference gradient: the fused route
+    v0 = leaf()
+    with _CountCalls("l1_loss_backward") as dense:
+        mesh_renderer.losses.l1_loss(render(v0), target).backward()
+    assert dense.calls == 0
+    # retain_grad: the image receives its gradient, the vertices the same one as before
+    v1 = leaf()
+    img = render(v1)
+    img.retain_grad()
+    with _CountCalls("l1_loss_backward") as dense:
+        mesh_renderer.losses.l1_loss(img, target).backward()
+    assert dense.calls == 1 and img.grad is not None and float(img.grad.abs().max()) > 0
+    np.testing.assert_allclose(v1.grad.cpu().numpy(), v0.grad.cpu().numpy(), rtol=2e-4, atol=1e-9)
+    # a hook on the image fires
+    v2 = leaf()
+    img = render(v2)
+    seen = []
+    img.register_hook(lambda g: seen.append(float(g.abs().sum())))
+    mesh_renderer.losses.l1_loss(img, target).backward()
+    assert len(seen) == 1 and seen[0] > 0
+    np.testing.assert_allclose(v2.grad.cpu().numpy(), v0.grad.cpu().numpy(), rtol=2e-4, atol=1e-9)
+    # torch.autograd.grad w.r.t. the image: generic route on request
+    v3 = leaf()
+    img = render(v3)
+    img.retain_grad()
+    (dimg,) = torch.autograd.grad(mesh_renderer.losses.l1_loss(img, target), img)
+    assert dimg.shape == img.shape
+    # nothing on the tensor: it pickles and deep-copies; two losses on one image add up
+    v4 = leaf()
+    img = render(v4)
+    assert not [k for k in img.__dict__ if k.startswith("_mr_fused")]
+    buf = io.BytesIO()
+    torch.save(img.detach(), buf)
+    torch.save(img, buf)
+    assert torch.equal(copy.deepcopy(img.detach()), img.detach())
+    (mesh_renderer.losses.l1_loss(img, target) + mesh_renderer.losses.l1_loss(img, target)).backward()
+    np.testing.assert_allclose(v4.grad.cpu().numpy(), 2.0 * v0.grad.cpu().numpy(), rtol=2e-4, atol=1e-9)
+    # the record lives exactly as long as the renderer's node
+    n_before = len(ext._fused_renders)
+    img = render(leaf())
+    assert len(ext._fused_renders) == n_before + 1
+    del img
+    gc.collect()
+    assert len(ext._fused_renders) == n_before
 
 
 def test_tone_mapper_hip_matches_reference_golden_and_torch(device):
@@ -926,6 +989,16 @@ def test_tone_mapper_hip_matches_reference_golden_and_torch(device):
         frames = mesh_renderer.tone_mapper_uint8(x.to(device), gamma).cpu().numpy()
         ref = (np.clip(np.nan_to_num(got, nan=0.0), 0.0, 1.0) * np.float32(255.0)).astype(np.uint8)
         assert frames.dtype == np.uint8 and np.abs(frames.astype(int) - ref.astype(int)).max() <= 0
+    # negative bases with an odd integer exponent give NEGATIVE powers ((-2)^3 = -8): they must lose the
+    # maximum to every non-negative power, and win it -- as the largest value -- in an all-negative image
+    y = torch.rand(3, 16, 16, 4, generator=gen) + 0.5
+    y[0, 2, 3, 1] = -2.0                       # |power| = 8 > every positive power (< 3.4)
+    y[1] = -(torch.rand(16, 16, 4, generator=gen) + 0.5)   # all negative: max = the one closest to zero
+    y[2, 0, 0, 0] = -0.0
+    p3 = torch.pow(y, 3.0)
+    want = torch.clamp(p3 / p3.reshape(3, -1).max(dim=1).values.reshape(3, 1, 1, 1), 0.0, 1.0).numpy()
+    got = mesh_renderer.tone_mapper(y.to(device), 3.0).cpu().numpy()
+    np.testing.assert_allclose(got, want, atol=2e-6, rtol=0)
     # a gradient request takes the torch expression (the reference's op is differentiable)
     xg = (torch.rand(2, 8, 8, 3, generator=gen) + 0.1).to(device).requires_grad_(True)
     mesh_renderer.tone_mapper(xg, 0.7).sum().backward()
