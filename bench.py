@@ -23,11 +23,17 @@ the conversion the reference's examples apply before writing a frame) or as the 
 (--handover f32, 4x the bytes).
 
 Extra objects in the line:
-  roofline                 the forward G-buffer kernel (k_raster): algorithmic bytes per launch
-                           (20 B/px written + clip and triangle reads) / its average duration,
-                           measured with HIP events recorded around that kernel on its stream.
-  roofline_shade_backward  same for the pixel pass of the fused shading backward, the kernel that
-                           takes the largest share of the step (32 B/px read).
+  roofline                 the step's forward kernel (k_raster with the shading epilogue: ids +
+                           barycentrics + RGBA, 32 B/px written): algorithmic bytes per launch / its
+                           average duration, measured with HIP events recorded around that kernel on
+                           its stream.
+  roofline_gbuffer         SURVEY.md 8(d)'s figure: the G-buffer kernel alone (20 B/px), timed in extra steps
+                           AFTER the timed region with the shading epilogue switched off.
+  roofline_shade_backward  same for the pixel pass of the fused shading backward (17 B/px read with the
+                           sign-coded upstream).
+  rccl, ms_per_step_render_only   (N > 1) what torch.distributed reports about the group, and the same
+                           loop with the hand-over off, run after the timed region: rendering alone
+                           next to `ms_per_step`, which includes the hand-over.
   roofline_l1_forward      same for the loss's streaming pass (33 B/px): with the two above, the three
                            kernels that make up 92 % of the step.
   cpu_baseline             the same step on the host cores for a bounded sample of the batch (torch-CPU
@@ -142,13 +148,13 @@ def make_step(job, device, gather, handover="u8"):
         rot = torch.tensor([[c, 0.0, s], [0.0, 1.0, 0.0], [-s, 0.0, c]], device=device)
         target = mesh_renderer.render(vertices @ rot.T, tri, normals @ rot.T, diffuse, eyes, center, up,
                                       lpos, lint, width, height)
-    state = {"target": target, "image": None}
+    state = {"target": target, "image": None, "handover": True}
 
     def step():
         vertices.grad = None
         image = forward()
         state["image"] = image
-        if gather is not None:
+        if gather is not None and state["handover"]:
             gather.wait()                # the previous step's hand-over (no-op the first time) ...
             # ... then this one; conversion (u8) and transfer both run on the side stream,
             # overlapping the loss, the backward and the next step's forward
@@ -266,11 +272,22 @@ def main():
                for k, v in job.items()}
     # images are handed over to rank 0 (RCCL gather): the root receives its N-1 shards over N-1
     # xGMI links at once; an all-gather would move N times the bytes for nothing
-    gather = distributed.ImageGather(batch * world, mode="root") if world > 1 else None
-    step, vertices, _ = make_step(job, device, gather, args.handover)
+    # MR_BENCH_FORCE_GROUP=1 (tests): a single rank still forms a 1-rank group and hands its frames over
+    # through RCCL, so that the N > 1 code path -- frames from the forward's epilogue, side stream,
+    # gather.wait() inside the timed loop -- meets the real backend on a one-GPU box.
+    forced = world == 1 and os.environ.get("MR_BENCH_FORCE_GROUP") == "1"
+    if forced:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        backend = os.environ.get("MR_DIST_BACKEND", "nccl")
+        torch.distributed.init_process_group(backend=backend, rank=0, world_size=1,
+                                             **({"device_id": device} if backend == "nccl" else {}))
+    grouped = world > 1 or forced
+    gather = distributed.ImageGather(batch * world, mode="root", force_collective=forced) if grouped else None
+    step, vertices, step_state = make_step(job, device, gather, args.handover)
 
     def barrier():
-        if world > 1:
+        if grouped:
             torch.distributed.barrier()
         torch.cuda.synchronize(device)
 
@@ -293,7 +310,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
 
-    if world > 1:
+    if grouped:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -313,6 +330,22 @@ def main():
     if gather is not None:
         gather.wait()
     torch.cuda.synchronize(device)
+
+    # N > 1, also outside the timed region: the same loop with the hand-over switched off, so that the
+    # first scaling run separates how the rendering scales from what the root's inbound links cost.
+    render_only_ms = None
+    if grouped:
+        step_state["handover"] = False
+        n_ro = min(args.steps, 50)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(n_ro):
+            step()
+        barrier()
+        t = torch.tensor([time.perf_counter() - t1], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        render_only_ms = float(t.item()) / n_ro * 1e3
+        step_state["handover"] = True
 
     if rank == 0:
         V, T = job["vertices"].shape[1], job["triangles"].shape[0]
@@ -336,24 +369,35 @@ def main():
             "roofline": roofline("k_raster<shade> (forward: ids + barycentrics + shaded RGBA write)",
                                  px * 32 + batch * V * 16 + T * 12 + batch * T * 128,
                                  ev_raster.mean_ms(n_ev), "k_raster_shade", args.config),
-            "roofline_gbuffer": roofline("k_raster (G-buffer write alone: %d steps with the shading epilogue off, after the timed region)" % n_gb,
-                                         px * 20 + batch * V * 16 + T * 12, ev_gbuffer.mean_ms(n_gb), "k_raster",
-                                         args.config),
+            "roofline_gbuffer": dict(
+                roofline("k_raster (G-buffer write alone: %d steps with the shading epilogue off)" % n_gb,
+                         px * 20 + batch * V * 16 + T * 12, ev_gbuffer.mean_ms(n_gb), "k_raster", args.config),
+                timed="OUTSIDE the timed region: %d extra steps run after it with the shading epilogue switched "
+                      "off (rasterize_triangles_ext.shading_epilogue(False)); `value` / `ms_per_step` do not "
+                      "contain them" % (n_gb + 2)),
             # ids + barycentrics (16 B/px) and the loss's sign codes (1 B/px) read, the triangles'
             # attribute and adjugate records (128 + 64 B) read
             "roofline_shade_backward": roofline(
-                "k_accumulate_rows<ShadeGradFn> (fused shading backward, pixel pass)",
+                "k_accumulate_lanes<ShadeLaneFn> (fused shading backward, pixel pass: vertex gradients only, "
+                "18 sums per triangle kept in registers down each lane's vertical run)",
                 px * 17 + batch * T * (128 + 64), ev_shade.mean_ms(n_ev), "shade_backward", args.config),
             # the loss: image and target read (2 x 16 B/px), the sign codes written (1 B/px)
             "roofline_l1_forward": roofline(
                 "k_l1_forward (mean |image - target| and its sign codes, one streaming pass)",
                 px * 33, ev_l1.mean_ms(n_ev), "l1_forward", args.config),
         }
+        if grouped:
+            line["rccl"] = {"backend": torch.distributed.get_backend(), "ranks": torch.distributed.get_world_size(),
+                            "device_per_rank": "cuda:%d of %d visible" % (device.index, torch.cuda.device_count()),
+                            "handover_bytes_per_rank_per_step": px * (4 if args.handover == "u8" else 16)}
+            # the same step with the hand-over off (after the timed region): rendering alone, max over ranks
+            line["ms_per_step_render_only"] = round(render_only_ms, 4)
+            line["ms_per_step_with_handover"] = line["ms_per_step"]
         if world == 1 and args.cpu_sample > 0:
             line["cpu_baseline"] = cpu_baseline(batch, width, height, sphere_k, args.cpu_sample)
         print(json.dumps(line), flush=True)
 
-    if world > 1:
+    if grouped:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

@@ -32,9 +32,11 @@ def _nearest_on_segment(p, a, b):
 
 
 def rasterize_batch(clip, triangles, world, normals, diffuse, light_positions, light_intensities,
-                    width, height, sigma_val, gamma_val, blur_radius=0.01):
+                    width, height, sigma_val, gamma_val, blur_radius=0.01, window=None):
     """One image: clip [V,4], triangles [T,3], world/normals/diffuse [V,3], lights [L,3]/[L]
-    -> [H,W,4]."""
+    -> [H,W,4].  window = (x0, y0, w, h): only those pixels of the width x height image are
+    evaluated (-> [h,w,4]) -- the dense [pixels x triangles] evaluation then fits a crop of a
+    full-size image (tests/test_full_size_gpu.py); every pixel is independent of the others."""
     T = triangles.shape[0]
     tri = triangles.long()
     cv = clip[tri]                                   # [T,3,4]
@@ -60,9 +62,10 @@ def rasterize_batch(clip, triangles, world, normals, diffuse, light_positions, l
     lo = torch.stack([xs.min(1).values - blur_radius, ys.min(1).values - blur_radius], -1)
     hi = torch.stack([xs.max(1).values + blur_radius, ys.max(1).values + blur_radius], -1)
 
-    yy, xx = torch.meshgrid(torch.arange(height), torch.arange(width), indexing="ij")
-    px = torch.tensor([2.0 * ((x + 0.5) / width) - 1.0 for x in range(width)], dtype=torch.float32)
-    py = torch.tensor([-2.0 * ((y + 0.5) / height) + 1.0 for y in range(height)], dtype=torch.float32)
+    x0, y0, out_w, out_h = window if window is not None else (0, 0, width, height)
+    yy, xx = torch.meshgrid(torch.arange(out_h), torch.arange(out_w), indexing="ij")
+    px = torch.tensor([2.0 * ((x + 0.5) / width) - 1.0 for x in range(x0, x0 + out_w)], dtype=torch.float32)
+    py = torch.tensor([-2.0 * ((y + 0.5) / height) + 1.0 for y in range(y0, y0 + out_h)], dtype=torch.float32)
     p2 = torch.stack([px[xx.reshape(-1)], py[yy.reshape(-1)]], -1)         # [P,2], row 0 = top
     P = p2.shape[0]
     p3 = torch.cat([p2, torch.ones(P, 1)], -1)
@@ -105,15 +108,15 @@ def rasterize_batch(clip, triangles, world, normals, diffuse, light_positions, l
     wts = wts / (wts.sum(-1) + bg).unsqueeze(-1)
     rgb = torch.einsum("pt,ptc->pc", wts, color)
     alpha = 1.0 - torch.prod(1.0 - frag, dim=-1)
-    return torch.cat([rgb, alpha.unsqueeze(-1)], -1).reshape(height, width, 4)
+    return torch.cat([rgb, alpha.unsqueeze(-1)], -1).reshape(out_h, out_w, 4)
 
 
 def rasterize(world, triangles, normals, diffuse, light_positions, light_intensities,
-              camera_matrices, width, height, sigma_val, gamma_val):
+              camera_matrices, width, height, sigma_val, gamma_val, window=None):
     clip = shading.transform_homogeneous(camera_matrices, world)
     return torch.stack([
         rasterize_batch(clip[b], triangles, world[b], normals[b], diffuse[b], light_positions[b],
-                        light_intensities[b], width, height, sigma_val, gamma_val)
+                        light_intensities[b], width, height, sigma_val, gamma_val, window=window)
         for b in range(world.shape[0])], 0)
 
 
@@ -133,11 +136,11 @@ def compute_vertex_normals(vertices, triangles):
 
 def render(vertices, triangles, diffuse, camera_position, camera_lookat, camera_up, light_positions,
            light_intensities, width, height, sigma_val=1e-5, gamma_val=1e-4, fov_y=40.0,
-           near_clip=0.01, far_clip=10.0):
+           near_clip=0.01, far_clip=10.0, window=None):
     batch = vertices.shape[0]
     full = lambda v: torch.full((batch,), float(v))
     proj = shading.perspective(width / height, full(fov_y), full(near_clip), full(far_clip))
     transforms = torch.matmul(proj, shading.look_at(camera_position, camera_lookat, camera_up))
     normals = compute_vertex_normals(vertices, triangles)
     return rasterize(vertices, triangles, normals, diffuse, light_positions, light_intensities,
-                     transforms, width, height, sigma_val, gamma_val)
+                     transforms, width, height, sigma_val, gamma_val, window=window)

@@ -66,7 +66,8 @@ class ImageGather:
     start(local) enqueues the collective on a side stream (GPU) and returns at once;
     wait() makes the current stream wait for it and returns the [B_total, H, W, C]
     tensor (mode "all": on every rank; mode "root": on rank `dst`, None elsewhere).
-    Shards may be uneven (they are padded to the largest one).
+    Shards may be uneven (they are padded to the largest one).  The returned tensor is one of two
+    receive buffers used alternately: it is overwritten by the second start() after the wait().
 
     mode "all"  = all_gather: every rank ends up with every image.
     mode "root" = gather to one rank (RCCL point-to-point under the hood): on a fully
@@ -89,6 +90,13 @@ class ImageGather:
         self._side = None
         self._out = None
         self._work = None
+        # receive buffers (two, used alternately) and the padded send buffer are allocated once per
+        # (shape, dtype, device): a step's hand-over allocates nothing (round 2 allocated `gathered`
+        # and its chunk list every step).  The tensor wait() returns stays valid until the second
+        # start() after it.
+        self._recv = {}
+        self._turn = 0
+        self._send_pad = {}
 
     def start(self, local, transform=None):
         """transform: optional callable applied to `local` ON THE SIDE STREAM before the
@@ -114,31 +122,38 @@ class ImageGather:
                 send = transform(local).detach()     # (the tensor itself: it may carry ready-made frames)
             else:
                 send = local.detach()
-            if send.shape[0] != max_count:
-                pad = torch.zeros((max_count - send.shape[0],) + tuple(send.shape[1:]),
-                                  dtype=send.dtype, device=send.device)
-                send = torch.cat([send, pad], 0)
+            key = (tuple(send.shape[1:]), send.dtype, send.device)
+            if send.shape[0] != max_count:   # an uneven shard: padded to the largest one, in a buffer kept for that
+                padded = self._send_pad.get(key)
+                if padded is None:
+                    padded = self._send_pad[key] = torch.zeros((max_count,) + key[0], dtype=send.dtype,
+                                                               device=send.device)
+                padded[:send.shape[0]].copy_(send)
+                send = padded
             send = send.contiguous()
             if on_gpu:
                 send.record_stream(self._side)
             self._max_count = max_count
+            gathered, chunks = None, None
+            if self.mode == "all" or self.rank == self.dst:
+                pair = self._recv.get(key)
+                if pair is None:
+                    pair = self._recv[key] = []
+                    for _ in range(2):
+                        buf = torch.empty((self.world * max_count,) + key[0], dtype=send.dtype, device=send.device)
+                        pair.append((buf, list(buf.chunk(self.world, 0))))
+                gathered, chunks = pair[self._turn]
+                self._turn ^= 1
             if self.mode == "root":
-                gathered = None
-                if self.rank == self.dst:
-                    gathered = torch.empty((self.world * max_count,) + tuple(send.shape[1:]),
-                                           dtype=send.dtype, device=send.device)
-                dist.gather(send, list(gathered.chunk(self.world, 0)) if gathered is not None else None,
-                            dst=self.dst, group=self.group)
+                dist.gather(send, chunks, dst=self.dst, group=self.group)
                 self._keep = send          # the send buffer must outlive the collective
                 self._out = gathered
                 return
-            gathered = torch.empty((self.world * max_count,) + tuple(send.shape[1:]),
-                                   dtype=send.dtype, device=send.device)
             if dist.get_backend(self.group) == "gloo":
-                chunks = list(gathered.chunk(self.world, 0))
                 dist.all_gather(chunks, send, group=self.group)
             else:
                 dist.all_gather_into_tensor(gathered, send, group=self.group)
+            self._keep = send
             self._out = gathered
 
     def wait(self):

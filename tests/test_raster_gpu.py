@@ -375,6 +375,32 @@ def test_rccl_image_gather_single_rank(device):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("handover", ["u8", "f32"])
+def test_bench_rank_path_meets_rccl_on_one_gpu(device, handover):
+    """bench.py's N > 1 path -- 8-bit frames written by the forward's epilogue (or the fp32 image), the
+    side-stream hand-over, gather.wait() inside the timed loop, the render-only loop after it -- under
+    a 1-rank RCCL group (MR_BENCH_FORCE_GROUP=1): the line names the backend and the rank count that
+    torch.distributed reports, and carries both per-step figures."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MR_BENCH_FORCE_GROUP="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT="29541" if handover == "u8" else "29542")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    proc = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "1",
+                           "--cpu-sample", "0", "--handover", handover], env=env, capture_output=True, text=True,
+                          timeout=600)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    line = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["rccl"]["backend"] == "nccl" and line["rccl"]["ranks"] == 1
+    assert line["rccl"]["handover_bytes_per_rank_per_step"] == 32 * 1024 * 1024 * (4 if handover == "u8" else 16)
+    assert 0 < line["ms_per_step_render_only"] and line["ms_per_step_with_handover"] == line["ms_per_step"]
+    assert line["config"]["handover"] == handover and line["n_gpus"] == 1
+
+
 def test_external_triangle_matches_reference_png_and_golden(device):
     """A triangle with one vertex behind the eye: the reference's own (unused) fixture
     test_data/External_Triangle.png under its own comparison, plus the float golden."""
