@@ -135,11 +135,19 @@ int mr_interpolate_raster_backward(const float *dout, const int32_t *ids, const 
  *   ids, bary                 the G-buffer of mr_rasterize_forward
  *   normals, positions, diffuse  [B,V,3] f32 per-vertex attributes (positions =
  *                             world-space vertices)
- *   light_positions, light_intensities [B,L,3] f32, 1 <= L <= mr_shade_max_lights()
+ *   light_positions, light_intensities [B,L,3] f32, 1 <= L <= mr_shade_max_lights() (32: the
+ *                             reference takes any count, render.py:304-323; up to mr_shade_fast_lights()
+ *                             = 4 of them are kept in registers, further ones go through a run-time
+ *                             loop).  Two things stay at mr_shade_fast_lights() per call: the specular
+ *                             entry points, and light_grads of mr_shade_backward[_l1] -- a caller
+ *                             with more lights asks for the light gradients four lights at a time
+ *                             (each light's gradient depends on that light alone; see
+ *                             pytorch_mesh_renderer_amd/_native.py, shade_backward)
  *   ambient                   [B,3] f32 or NULL
  *   rgba                      [B,H,W,4] f32 out; row 0 is the TOP scanline; alpha is
  *                             1 on covered pixels with a non-negative diffuse colour */
 int mr_shade_max_lights(void);
+int mr_shade_fast_lights(void);
 size_t mr_shade_forward_workspace_bytes(int B, int V, int T, int W, int H);
 int mr_shade_forward(const int32_t *ids, const float *bary, const float *normals,
                      const float *positions, const float *diffuse,

@@ -130,6 +130,8 @@ def lib():
                                               vp, vp, vp, sz, vp]
         L.mr_interpolate_backward.restype = ci
         L.mr_shade_max_lights.restype = ci
+        L.mr_shade_fast_lights.argtypes = []
+        L.mr_shade_fast_lights.restype = ci
         L.mr_shade_forward_workspace_bytes.argtypes = [ci] * 5
         L.mr_shade_forward_workspace_bytes.restype = sz
         L.mr_shade_forward.argtypes = [vp] * 9 + [ci] * 6 + [vp, vp, sz, vp]
@@ -391,6 +393,11 @@ def shade_max_lights():
     return int(lib().mr_shade_max_lights())
 
 
+def shade_fast_lights():
+    """Lights per call of the specular kernels and of the light gradients (kept in registers)."""
+    return int(lib().mr_shade_fast_lights())
+
+
 def _aligned_bytes(nbytes, dev):
     """A fresh uint8 tensor of `nbytes` whose data pointer is 256-byte aligned."""
     raw = torch.empty(max(int(nbytes), 1) + 256, dtype=torch.uint8, device=dev)
@@ -576,6 +583,40 @@ def vertex_adjacency(triangles, vertex_count):
 def shade_backward(drgba, ids, bary, clip, normals, positions, diffuse, triangles, light_positions,
                    light_intensities, ambient, corner_records=None, adjacency=None, l1_signs=None,
                    transforms=None, want_light_grads=True, want_normal_grads=True, want_diffuse_grads=True):
+    """_shade_backward_call for any light count up to shade_max_lights().  The kernels keep the light
+    gradients' 6 L sums in registers, four lights per call; with more lights the vertex-side gradients
+    come from one call over all lights (a run-time loop, no light gradients) and each group of four
+    lights gets a call of its own for d light_positions / d light_intensities -- a light's gradient
+    depends on that light, the upstream gradient and the pixel's attributes, not on the other lights.
+    (1 + ceil(L / 4) passes over the G-buffer: more than four lights WITH light gradients is the rare
+    case -- the reference's tests and examples use one to three.)"""
+    nl = light_positions.shape[1]
+    kw = dict(corner_records=corner_records, adjacency=adjacency, l1_signs=l1_signs, transforms=transforms,
+              want_normal_grads=want_normal_grads, want_diffuse_grads=want_diffuse_grads)
+    fast = shade_fast_lights() if nl > 4 else nl
+    if nl <= fast or not want_light_grads:
+        return _shade_backward_call(drgba, ids, bary, clip, normals, positions, diffuse, triangles,
+                                    light_positions, light_intensities, ambient, want_light_grads=want_light_grads,
+                                    **kw)
+    out = _shade_backward_call(drgba, ids, bary, clip, normals, positions, diffuse, triangles, light_positions,
+                               light_intensities, ambient, want_light_grads=False, **kw)
+    chunk_kw = dict(kw, want_normal_grads=False, want_diffuse_grads=False) if adjacency is not None else kw
+    dlpos, dlint, damb = [], [], None
+    for first in range(0, nl, fast):
+        part = _shade_backward_call(drgba, ids, bary, clip, normals, positions, diffuse, triangles,
+                                    light_positions[:, first:first + fast].contiguous(),
+                                    light_intensities[:, first:first + fast].contiguous(),
+                                    ambient if first == 0 else None, want_light_grads=True, **chunk_kw)
+        dlpos.append(part[4])
+        dlint.append(part[5])
+        if first == 0:
+            damb = part[6]
+    return out[:4] + (torch.cat(dlpos, 1), torch.cat(dlint, 1), damb)
+
+
+def _shade_backward_call(drgba, ids, bary, clip, normals, positions, diffuse, triangles, light_positions,
+                         light_intensities, ambient, corner_records=None, adjacency=None, l1_signs=None,
+                         transforms=None, want_light_grads=True, want_normal_grads=True, want_diffuse_grads=True):
     """-> (dclip [B,V,4], dnormals, dpositions, ddiffuse [B,V,3], dlight_positions,
     dlight_intensities [B,L,3], dambient [B,3] or None); with want_light_grads=False the last three
     are None and the kernel leaves their accumulation out; want_normal_grads / want_diffuse_grads=False
@@ -672,7 +713,7 @@ def shade_specular_forward(ids, bary, normals, positions, diffuse, specular, tri
     for name, t in (("normals", normals), ("diffuse colors", diffuse), ("specular colors", specular)):
         _chk(name, t, _F32, B, V, 3)
     _chk_gbuffer(ids, bary, B)
-    _chk_lights(light_positions, light_intensities, ambient, B, shade_max_lights())
+    _chk_lights(light_positions, light_intensities, ambient, B, shade_fast_lights())
     _chk("camera_position", camera_position, _F32, B, 3)
     per_vertex = _chk_shininess(shininess, B, V)
     dev = _require_device(*(tensors + ([ambient] if ambient is not None else [])))
@@ -709,7 +750,7 @@ def shade_specular_backward(drgba, ids, bary, clip, normals, positions, diffuse,
                     ("specular colors", specular)):
         _chk(name, t, _F32, B, V, 3)
     h, w = _chk_gbuffer(ids, bary, B)
-    nl_ = _chk_lights(light_positions, light_intensities, ambient, B, shade_max_lights())
+    nl_ = _chk_lights(light_positions, light_intensities, ambient, B, shade_fast_lights())
     _chk("upstream gradient", drgba, _F32, B, h, w, 4)
     _chk("camera_position", camera_position, _F32, B, 3)
     per_vertex = _chk_shininess(shininess, B, V)

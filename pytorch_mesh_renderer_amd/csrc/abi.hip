@@ -195,6 +195,7 @@ int mr_interpolate_raster_backward(const float *dout, const int32_t *ids, const 
 }
 
 int mr_shade_max_lights(void) { return mr::shade_max_lights(); }
+int mr_shade_fast_lights(void) { return mr::shade_light_gradient_max_lights(); }
 
 int mr_shade_forward(const int32_t *ids, const float *bary, const float *normals,
                      const float *positions, const float *diffuse, const int32_t *triangles,
@@ -327,7 +328,7 @@ int mr_shade_specular_forward(const int32_t *ids, const float *bary, const float
                               int shininess_per_vertex, int B, int V, int T, int W, int H, int L,
                               float *rgba, float *norms2, void *workspace, size_t workspace_bytes,
                               void *stream) {
-  if (bad_dims(B, V, T, W, H) || T < 1 || V < 1 || L < 1 || L > mr::shade_max_lights())
+  if (bad_dims(B, V, T, W, H) || T < 1 || V < 1 || L < 1 || L > mr::shade_light_gradient_max_lights())
     return MR_EINVAL;
   if (B == 0) return MR_OK;
   if (!ids || !bary || !normals || !positions || !diffuse || !specular || !triangles ||
@@ -358,7 +359,7 @@ int mr_shade_specular_backward(const float *drgba, const int32_t *ids, const flo
                                float *ddiffuse, float *dspecular, float *dshininess,
                                float *light_grads, void *workspace, size_t workspace_bytes,
                                void *stream) {
-  if (bad_dims(B, V, T, W, H) || T < 1 || V < 1 || L < 1 || L > mr::shade_max_lights())
+  if (bad_dims(B, V, T, W, H) || T < 1 || V < 1 || L < 1 || L > mr::shade_light_gradient_max_lights())
     return MR_EINVAL;
   if (B == 0) return MR_OK;
   if (!drgba || !ids || !bary || !clip || !normals || !positions || !diffuse || !specular ||

@@ -109,6 +109,7 @@ int launch_interp_backward(const float *dout, const int32_t *ids, const float *b
                            void *ws, hipStream_t s);
 size_t interp_backward_ws(int B, int V, int T, int W, int H, int A);
 int shade_max_lights();
+int shade_light_gradient_max_lights();
 int launch_shade_forward(const int32_t *ids, const float *bary, const float *normals,
                          const float *positions, const float *diffuse, const int32_t *tris,
                          const float *light_pos, const float *light_col, const float *ambient,

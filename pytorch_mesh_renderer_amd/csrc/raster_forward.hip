@@ -632,7 +632,7 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : MR_RASTER
 #if MR_EPI_LDS_LIGHTS
   const float *s_lights_ptr = nullptr;
   if constexpr (SHADE) {  // (no LDS at all in the G-buffer-only instantiation: its 23040 B are exactly 18 granules)
-    __shared__ float s_lights[32];
+    __shared__ float s_lights[(LightsInLds::kFloats + 31) / 32 * 32];  // 3 + 6 x 32 lights: 780 B, inside the 19th LDS granule
     LightsInLds::stage(shade.lights, img, s_lights, tid);  // (the bin stage's barriers come before any use)
     s_lights_ptr = s_lights;
   }

@@ -120,8 +120,14 @@ __global__ __launch_bounds__(kThreads, MR_SHADE_FWD_WAVES) void k_shade_forward(
 #endif
 // LG: the caller wants the light / ambient gradients (false: light_grads == nullptr; their nine
 // per-lane accumulators and ~25 instructions per row are not compiled in: the kernel -4 %).
+// L = 1..4: that many lights, kept in registers and unrolled.  L = 0 (round 3): any count up to
+// kMaxLightsAny through a run-time loop, each light read through the scalar cache per pixel row (no
+// per-lane copies); without the light gradients (LG) -- their 6 L per-lane sums do not scale: the
+// caller forms them four lights at a time (pytorch_mesh_renderer_amd/_native.py, shade_backward).
 template <int L, bool SIGNS, bool LG>
 struct ShadeGradFn {
+  static_assert(L >= 0 && L <= kMaxLights && (L > 0 || !LG), "lights in registers: 1..4; L = 0 = run-time count, no light gradients");
+  static constexpr int LA = L > 0 ? L : 1;  // array extents
   static constexpr int kN = 36;       // 27 attribute partials [corner][attr] + 9 clip partials
   static constexpr int kStride = 36;
   // see run_accum.h.  With the light gradients every strip ends in 6L + 3 atomics on the image's
@@ -171,13 +177,15 @@ struct ShadeGradFn {
   };
   struct Image {
     int n_bg;                              // unused (kCountBackground = false)
+    int img;                               // L = 0: where this image's lights start
     float g_scale;                         // SIGNS: upstream * 1 / n
-    float lp[L][3], li[L][3], amb[3];      // this image's lights (loaded once per lane)
-    float dpos[L][3], dcol[L][3], damb[3];  // per-lane partial sums
+    float lp[LA][3], li[LA][3], amb[3];    // this image's lights (loaded once per lane; L > 0)
+    float dpos[LA][3], dcol[LA][3], damb[3];  // per-lane partial sums
   };
 
   __device__ __forceinline__ void begin_image(int img, Image &im) const {
     im.g_scale = SIGNS ? sign_upstream[0] * sign_inv_n : 0.f;
+    im.img = img;
 #pragma unroll
     for (int l = 0; l < L; ++l) {
 #pragma unroll
@@ -246,9 +254,18 @@ struct ShadeGradFn {
     float dKd[3] = {g[0] * im.amb[0], g[1] * im.amb[1], g[2] * im.amb[2]};
 #pragma unroll
     for (int c = 0; c < 3; ++c) if (LG) im.damb[c] += g[c] * at[6 + c];
+    const int n_lights = L > 0 ? L : lights.L;  // (L > 0: a constant, the loop unrolls)
+    ConstFloats all_pos = (ConstFloats)(uintptr_t)(lights.pos + (size_t)im.img * lights.L * 3);
+    ConstFloats all_col = (ConstFloats)(uintptr_t)(lights.col + (size_t)im.img * lights.L * 3);
 #pragma unroll
-    for (int l = 0; l < L; ++l) {
-      const float v[3] = {im.lp[l][0] - at[3], im.lp[l][1] - at[4], im.lp[l][2] - at[5]};
+    for (int l = 0; l < n_lights; ++l) {
+      float lpos[3], lcol[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        lpos[c] = L > 0 ? im.lp[L > 0 ? l : 0][c] : all_pos[3 * l + c];   // L = 0: wave-uniform scalar loads
+        lcol[c] = L > 0 ? im.li[L > 0 ? l : 0][c] : all_col[3 * l + c];
+      }
+      const float v[3] = {lpos[0] - at[3], lpos[1] - at[4], lpos[2] - at[5]};
       const float vn2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
       const float inv_vn = inv_norm(vn2);
       const float D[3] = {v[0] * inv_vn, v[1] * inv_vn, v[2] * inv_vn};
@@ -257,9 +274,9 @@ struct ShadeGradFn {
       float t_l = 0.f;  // d/d ndl
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        dKd[c] += g[c] * ndl * im.li[l][c];
-        if (LG) im.dcol[l][c] += g[c] * at[6 + c] * ndl;
-        t_l += g[c] * at[6 + c] * im.li[l][c];
+        dKd[c] += g[c] * ndl * lcol[c];
+        if (LG) im.dcol[L > 0 ? l : 0][c] += g[c] * at[6 + c] * ndl;
+        t_l += g[c] * at[6 + c] * lcol[c];
       }
       if (pre_l >= 0.0f && pre_l <= 1.0f) {  // torch.clamp passes the gradient inclusively
         float dD[3], dd = 0.f;
@@ -273,7 +290,7 @@ struct ShadeGradFn {
         for (int c = 0; c < 3; ++c) {
           // backward of v / max(|v|, eps)
           const float dv = (vn2 > kNormEpsSquared ? (dD[c] - D[c] * dd) : dD[c]) * inv_vn;
-          if (LG) im.dpos[l][c] += dv;
+          if (LG) im.dpos[L > 0 ? l : 0][c] += dv;
           dP[c] -= dv;
         }
       }
@@ -551,7 +568,8 @@ inline size_t corner_bytes(int B, int T) { return align_up((size_t)B * T * sizeo
 
 }  // namespace
 
-int shade_max_lights() { return kMaxLights; }
+int shade_max_lights() { return kMaxLightsAny; }
+int shade_light_gradient_max_lights() { return kMaxLights; }
 
 size_t shade_forward_ws(int B, int V, int T, int W, int H) {
   (void)V; (void)W; (void)H;
@@ -668,6 +686,7 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
     if (rc != MR_OK) return rc;
   }
   Lights lights{light_pos, light_col, ambient, L};
+  if (L > kMaxLights && light_grads) return MR_EINVAL;  // light gradients: four lights per call (see ShadeGradFn)
   // Attribute gradients the caller wants (nullptr: not wanted).  The scatter path (no adjacency)
   // writes all of them.
   if ((!dnormals || !ddiffuse) && !(vertex_offsets && vertex_entries)) return MR_EINVAL;
@@ -700,7 +719,7 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
       case 2: MR_SHADE_LANES_G(2); break;
       case 3: MR_SHADE_LANES_G(3); break;
       case 4: MR_SHADE_LANES_G(4); break;
-      default: return MR_EINVAL;
+      default: MR_SHADE_LANES_G(0); break;  // 5..kMaxLightsAny lights: run-time loop
     }
   } else {
 #define MR_SHADE_BWD(NL)                                                                        \
@@ -729,7 +748,18 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
     case 2: MR_SHADE_BWD(2); break;
     case 3: MR_SHADE_BWD(3); break;
     case 4: MR_SHADE_BWD(4); break;
-    default: return MR_EINVAL;
+    default: {  // 5..kMaxLightsAny lights: run-time loop, no light gradients (rejected above)
+      KernelTimer timer(MR_TIMER_SHADE_BACKWARD, s);
+      if (signs) {
+        ShadeGradFn<0, true, false> fn{nullptr, signs, sign_upstream, sign_inv_n, ids, (const F3 *)bary, corners,
+                                       recs, lights, nullptr, T, W, H};
+        rc = launch_accumulate_rows(fn, B, T, W, H, acc, s, det ? det_scale : nullptr);
+      } else {
+        ShadeGradFn<0, false, false> fn{(const float4 *)drgba, nullptr, nullptr, 0.0f, ids, (const F3 *)bary,
+                                        corners, recs, lights, nullptr, T, W, H};
+        rc = launch_accumulate_rows(fn, B, T, W, H, acc, s, det ? det_scale : nullptr);
+      }
+    } break;
   }
   }
 #undef MR_SHADE_BWD

@@ -40,7 +40,9 @@ __device__ __forceinline__ void interpolate9(const Corners &cr, const F3 b, floa
   }
 }
 
-constexpr int kMaxLights = 4;  // fused shading paths; more lights use the composed path
+constexpr int kMaxLights = 4;      // lights the kernels keep in registers / unrolled instantiations (1..4)
+constexpr int kMaxLightsAny = 32;  // round 3: up to this many through a run-time loop (the reference takes any
+                                   // count, src/mesh_renderer/render.py:304-323); LDS stage of the forward epilogue
 
 // Wave-uniform read-only data read through the constant address space: scalar loads (lgkmcnt).
 typedef const __attribute__((address_space(4))) float *ConstFloats;
@@ -91,8 +93,9 @@ struct LightsInLds {
   const float *s;  // LDS
   int n;
   bool amb_on;
-  static constexpr int kFloats = 3 + 6 * kMaxLights;
-  // all threads of the workgroup call this; the caller provides the barrier before the first use
+  static constexpr int kFloats = 3 + 6 * kMaxLightsAny;
+  // all threads of the workgroup call this (at least 3 + 6 L of them: 195 for 32 lights); the caller
+  // provides the barrier before the first use
   __device__ __forceinline__ static void stage(const Lights &l, int img, float *lds, int tid) {
     if (tid < 3) lds[tid] = l.amb ? ((ConstFloats)(uintptr_t)l.amb)[(size_t)img * 3 + tid] : 0.0f;
     if (tid >= 3 && tid < 3 + 6 * l.L) {
@@ -122,9 +125,7 @@ __device__ __forceinline__ float4 shade_attributes(const float (&at)[9], const L
     g = lights.ambient(1) * at[7];
     bl = lights.ambient(2) * at[8];
   }
-#pragma unroll
-  for (int l = 0; l < kMaxLights; ++l) {  // render.py:304-323
-    if (l >= lights.count()) break;
+  auto add_light = [&](const int l) {  // render.py:304-323
     const float vx = lights.position(l, 0) - at[3], vy = lights.position(l, 1) - at[4],
                 vz = lights.position(l, 2) - at[5];
     const float inv_vn = inv_norm(vx * vx + vy * vy + vz * vz);
@@ -132,7 +133,14 @@ __device__ __forceinline__ float4 shade_attributes(const float (&at)[9], const L
     r += at[6] * ndl * lights.color(l, 0);
     g += at[7] * ndl * lights.color(l, 1);
     bl += at[8] * ndl * lights.color(l, 2);
+  };
+#pragma unroll
+  for (int l = 0; l < kMaxLights; ++l) {  // the first four unrolled, as before
+    if (l >= lights.count()) break;
+    add_light(l);
   }
+#pragma unroll 1
+  for (int l = kMaxLights; l < lights.count(); ++l) add_light(l);  // any further ones (round 3), same order
   return make_float4(r, g, bl, 1.0f);
 }
 

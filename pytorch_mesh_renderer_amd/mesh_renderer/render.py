@@ -83,7 +83,7 @@ def render(vertices, triangles, normals, diffuse_colors, camera_position, camera
     if shininess_coefficients is not None and specular_colors is None:
         raise ValueError("Shininess coefficients were supplied without specular colors.")
 
-    if _fused_path_applies(vertices, normals, diffuse_colors, light_positions):
+    if _fused_path_applies(vertices, normals, diffuse_colors, light_positions, specular_colors is not None):
         if specular_colors is None:
             return _render_fused(vertices, triangles, normals, diffuse_colors, camera_position,
                                  camera_lookat, camera_up, light_positions, light_intensities,
@@ -144,14 +144,14 @@ def render(vertices, triangles, normals, diffuse_colors, camera_position, camera
         ambient_color=ambient_color.to(device) if ambient_color is not None else None)
 
 
-def _fused_path_applies(vertices, normals, diffuse_colors, light_positions):
-    """The fused HIP shading kernels cover Phong shading (ambient, diffuse, and specular with
-    per-image or per-vertex shininess) with 1..4 lights on float32 inputs of matching [B,V,3]
-    shape; everything else takes the composed path."""
+def _fused_path_applies(vertices, normals, diffuse_colors, light_positions, specular):
+    """The fused HIP shading kernels cover Phong shading on float32 inputs of matching [B,V,3] shape:
+    ambient + diffuse with 1..32 lights, and the specular term (per-image or per-vertex shininess)
+    with 1..4; everything else takes the composed path."""
     from .. import _native
+    limit = _native.shade_fast_lights() if specular else _native.shade_max_lights()
     return (USE_FUSED_SHADING and vertices.dtype == torch.float32 and normals.shape == vertices.shape and
-            diffuse_colors.shape == vertices.shape and
-            1 <= light_positions.shape[1] <= _native.shade_max_lights())
+            diffuse_colors.shape == vertices.shape and 1 <= light_positions.shape[1] <= limit)
 
 
 def _fused_shininess(shininess_coefficients, batch_size, vertex_count, device):

@@ -241,7 +241,7 @@ def test_native_wrappers_validate_dtypes_and_shapes_before_anything_reaches_the_
         (_native.shade_forward, (ids, bary, n, p, f(B, V + 1, 3), tris, lp, li, None), ValueError, "diffuse"),
         (_native.shade_forward, (ids, bary, n, p, kd, tris, f(B + 1, L, 3), li, None), ValueError, "light_positions"),
         (_native.shade_forward, (ids, bary, n, p, kd, tris, lp, f(B, L + 1, 3), None), ValueError, "light_intensities"),
-        (_native.shade_forward, (ids, bary, n, p, kd, tris, f(B, 9, 3), f(B, 9, 3), None), ValueError, "lights"),
+        (_native.shade_forward, (ids, bary, n, p, kd, tris, f(B, 33, 3), f(B, 33, 3), None), ValueError, "lights"),
         (_native.shade_forward, (ids, bary, n, p, kd, tris, lp, li, f(B + 1, 3)), ValueError, "ambient"),
         (_native.shade_backward, (rgba.double(), ids, bary, clip, n, p, kd, tris, lp, li, None), RuntimeError, "float32"),
         (_native.shade_backward, (rgba, ids, bary, f(B, V + 2, 4), n, p, kd, tris, lp, li, None), ValueError, "shape"),

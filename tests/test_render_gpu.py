@@ -96,6 +96,61 @@ def test_render_diffuse_goldens(device, name):
     _render_golden(name, device)
 
 
+def test_render_six_lights_golden_takes_the_fused_path(device):
+    """Round 3: more than four lights no longer fall back to HIP interpolation + ~40 eager torch ops (a
+    10x cliff): the forward loops over them from LDS, the backward over a run-time count, the light
+    gradients come four lights at a time.  The reference's capture with SIX lights + ambient, image and
+    every gradient, and the fused entry points must have been the ones that ran."""
+    from pytorch_mesh_renderer_amd import _native
+    assert _native.shade_max_lights() >= 6 and _native.shade_fast_lights() == 4
+    with _CountCalls("render_forward") as fwd, _CountCalls("_shade_backward_call") as bwd, \
+            _CountCalls("interpolate_forward") as composed:
+        _render_golden("render_six_lights_64x48.npz", device)
+    assert fwd.calls == 1 and composed.calls == 0
+    assert bwd.calls == 3, "one pass for the vertex-side gradients, two for the light gradients (4 + 2 lights)"
+
+
+@pytest.mark.parametrize("n_lights,light_grads", [(5, True), (9, True), (7, False), (32, False)])
+def test_fused_render_with_many_lights_matches_composed_path(device, n_lights, light_grads):
+    """5 / 7 / 9 / 32 lights through the fused kernels vs the composed path (HIP interpolation + torch
+    Phong + autograd), image and gradients -- with and without the lights requiring grad, sign-coded
+    loss route included (losses.l1_loss on render()'s own output)."""
+    import importlib
+    render_mod = importlib.import_module("pytorch_mesh_renderer_amd.mesh_renderer.render")
+    job = synthetic.sphere_job(2, 96, 72, 10)
+    gen = torch.Generator().manual_seed(n_lights)
+    target = torch.rand(2, 72, 96, 4, generator=gen).to(device)
+    base = {"vertices": job["vertices"], "normals": job["normals"],
+            "diffuse": torch.rand(job["vertices"].shape, generator=gen),
+            "light_positions": torch.rand(2, n_lights, 3, generator=gen) * 8.0 - 4.0,
+            "light_intensities": torch.rand(2, n_lights, 3, generator=gen) * (1.5 / n_lights),
+            "ambient": torch.rand(2, 3, generator=gen) * 0.2}
+    results = {}
+    for fused in (True, False):
+        scene = {k: v.clone().to(device) for k, v in base.items()}
+        for k in scene:
+            if light_grads or k in ("vertices", "normals", "diffuse"):
+                scene[k].requires_grad_(True)
+        render_mod.USE_FUSED_SHADING = fused
+        try:
+            with _CountCalls("render_forward") as counter:
+                img = mesh_renderer.render(scene["vertices"], job["triangles"].to(device), scene["normals"],
+                                           scene["diffuse"], job["eyes"], torch.zeros(2, 3), torch.tensor([0.0, 1.0, 0.0]),
+                                           scene["light_positions"], scene["light_intensities"], 96, 72,
+                                           ambient_color=scene["ambient"])
+            (mesh_renderer.losses.l1_loss(img, target) * 10.0).backward()
+        finally:
+            render_mod.USE_FUSED_SHADING = True
+        assert counter.calls == (1 if fused else 0)
+        results[fused] = (img.detach().cpu().numpy(),
+                          {k: v.grad.cpu().numpy() for k, v in scene.items() if v.requires_grad})
+    np.testing.assert_allclose(results[True][0], results[False][0], atol=ATOL, rtol=0)
+    assert set(results[True][1]) == set(results[False][1])
+    for k, want in results[False][1].items():
+        assert np.abs(want).max() > 1e-5, k
+        np.testing.assert_allclose(results[True][1][k], want, atol=ATOL, rtol=2e-3, err_msg=k)
+
+
 class _CountCalls:
     """Counts the calls of a _native entry point (which path did render() take?)."""
 
