@@ -373,6 +373,25 @@ int mr_vertex_normals_backward(const float *dnormals, const float *vertices, con
                                const int32_t *vertex_entries, int B, int V, int T, float *dsums,
                                float *dvertices, void *stream);
 
+/* ---- clip-space transforms --------------------------------------------------------------
+ * perspective(aspect, fov_y, near, far) . look_at(eye, center, up) per image, the product render() and
+ * rasterize() apply to the vertices (src/common/camera_utils.py:45-139; src/mesh_renderer/render.py
+ * :187-193), as one launch on cameras that live on the device, and its backward to eye / center / up
+ * (one launch; fov_y, near, far are not differentiated).
+ *   eye, center, up [B,3] f32; fov_y (degrees), near_clip, far_clip [B] f32; aspect = width / height
+ *   transforms [B,4,4] f32 out, row-major
+ *   degenerate  1 int32 out (device): bit 0 = some |center - eye| <= 1e-6, bit 1 = some
+ *               |forward x up| <= 1e-6 -- the two conditions the reference asserts on
+ *               (camera_utils.py:68-69, 74-76); the caller decides when to read it back
+ *   dtransforms [B,4,4] f32; deye, dcenter, dup [B,3] f32 out */
+int mr_camera_transforms(const float *eye, const float *center, const float *up, const float *fov_y,
+                         const float *near_clip, const float *far_clip, float aspect, int B, float *transforms,
+                         int32_t *degenerate, void *stream);
+int mr_camera_transforms_backward(const float *dtransforms, const float *eye, const float *center,
+                                  const float *up, const float *fov_y, const float *near_clip,
+                                  const float *far_clip, float aspect, int B, float *deye, float *dcenter,
+                                  float *dup, void *stream);
+
 /* ---- tone_mapper ------------------------------------------------------------------------
  * Replaces tone_mapper (src/mesh_renderer/render.py:389-419): per image,
  *   out = clamp(image^gamma / max(image^gamma), 0, 1)     (torch.pow / torch.max / torch.clamp

@@ -152,6 +152,11 @@ def lib():
         L.mr_soft_forward.restype = ci
         L.mr_soft_backward.argtypes = [vp] * 10 + [ci] * 6 + [cf] * 3 + [vp] * 6 + [vp, sz, vp]
         L.mr_soft_backward.restype = ci
+        fp = vp
+        L.mr_camera_transforms.argtypes = [fp, fp, fp, fp, fp, fp, ctypes.c_float, ci, fp, vp, vp]
+        L.mr_camera_transforms.restype = ci
+        L.mr_camera_transforms_backward.argtypes = [fp, fp, fp, fp, fp, fp, fp, ctypes.c_float, ci, fp, fp, fp, vp]
+        L.mr_camera_transforms_backward.restype = ci
         L.mr_l1_loss_partials.argtypes = []
         L.mr_l1_loss_partials.restype = ci
         L.mr_l1_loss_forward.argtypes = [vp, vp, sz, vp, vp, vp, vp]
@@ -955,3 +960,42 @@ def vertex_normals_backward(dnormals, vertices, sums, triangles, adjacency=None)
                                               _ptr(dvertices), _stream(dev))
     _check(rc, "mr_vertex_normals_backward")
     return dvertices
+
+
+def _chk_cameras(eye, center, up, fov_y, near_clip, far_clip):
+    _chk("camera position", eye, _F32, None, 3)
+    B = eye.shape[0]
+    _chk("camera lookat", center, _F32, B, 3)
+    _chk("camera up", up, _F32, B, 3)
+    for name, t in (("fov_y", fov_y), ("near_clip", near_clip), ("far_clip", far_clip)):
+        _chk(name, t, _F32, B)
+    return B
+
+
+def camera_transforms(eye, center, up, fov_y, near_clip, far_clip, aspect_ratio):
+    """perspective . look_at per image as ONE launch -> (transforms [B,4,4], degenerate flags: a 1-element
+    int32 device tensor, bit 0 = eye ~ center, bit 1 = up ~ gaze for some image)."""
+    B = _chk_cameras(eye, center, up, fov_y, near_clip, far_clip)
+    tensors = [t.contiguous() for t in (eye, center, up, fov_y, near_clip, far_clip)]
+    dev = _require_device(*tensors)
+    out = torch.empty(B, 4, 4, dtype=torch.float32, device=dev)
+    flags = torch.empty(1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib().mr_camera_transforms(*[_ptr(t) for t in tensors], float(aspect_ratio), B, _ptr(out), _ptr(flags),
+                                        _stream(dev))
+    _check(rc, "mr_camera_transforms")
+    return out, flags
+
+
+def camera_transforms_backward(dtransforms, eye, center, up, fov_y, near_clip, far_clip, aspect_ratio):
+    """-> (deye, dcenter, dup) [B,3]."""
+    B = _chk_cameras(eye, center, up, fov_y, near_clip, far_clip)
+    _chk("gradient of the transforms", dtransforms, _F32, B, 4, 4)
+    tensors = [t.contiguous() for t in (dtransforms, eye, center, up, fov_y, near_clip, far_clip)]
+    dev = _require_device(*tensors)
+    outs = [torch.empty(B, 3, dtype=torch.float32, device=dev) for _ in range(3)]
+    with torch.cuda.device(dev):
+        rc = lib().mr_camera_transforms_backward(*[_ptr(t) for t in tensors], float(aspect_ratio), B,
+                                                 *[_ptr(t) for t in outs], _stream(dev))
+    _check(rc, "mr_camera_transforms_backward")
+    return tuple(outs)

@@ -440,6 +440,28 @@ int mr_l1_loss_backward(const uint8_t *signs, size_t n, const float *upstream, f
   return mr::launch_l1_backward(signs, n, upstream, da, (hipStream_t)stream);
 }
 
+int mr_camera_transforms(const float *eye, const float *center, const float *up, const float *fov_y,
+                         const float *near_clip, const float *far_clip, float aspect, int B, float *transforms,
+                         int32_t *degenerate, void *stream) {
+  if (B < 0 || !(aspect > 0.0f)) return MR_EINVAL;
+  if (B == 0) return MR_OK;
+  if (!eye || !center || !up || !fov_y || !near_clip || !far_clip || !transforms || !degenerate) return MR_EINVAL;
+  return mr::launch_camera_transforms(eye, center, up, fov_y, near_clip, far_clip, aspect, B, transforms,
+                                      (int *)degenerate, (hipStream_t)stream);
+}
+
+int mr_camera_transforms_backward(const float *dtransforms, const float *eye, const float *center,
+                                  const float *up, const float *fov_y, const float *near_clip,
+                                  const float *far_clip, float aspect, int B, float *deye, float *dcenter,
+                                  float *dup, void *stream) {
+  if (B < 0 || !(aspect > 0.0f)) return MR_EINVAL;
+  if (B == 0) return MR_OK;
+  if (!dtransforms || !eye || !center || !up || !fov_y || !near_clip || !far_clip || !deye || !dcenter || !dup)
+    return MR_EINVAL;
+  return mr::launch_camera_transforms_backward(dtransforms, eye, center, up, fov_y, near_clip, far_clip, aspect, B,
+                                               deye, dcenter, dup, (hipStream_t)stream);
+}
+
 int mr_vertex_normals_forward(const float *vertices, const int32_t *triangles,
                               const int32_t *vertex_offsets, const int32_t *vertex_entries, int B, int V,
                               int T, float *sums, float *normals, void *stream) {

@@ -172,6 +172,13 @@ int launch_vertex_normals(const float *vertices, const int32_t *tris, const int3
 int launch_vertex_normals_backward(const float *dnormals, const float *vertices, const float *sums,
                                    const int32_t *tris, const int32_t *offsets, const int32_t *entries,
                                    int B, int V, float *dsums, float *dvertices, hipStream_t s);
+int launch_camera_transforms(const float *eye, const float *center, const float *up, const float *fov_y,
+                             const float *near_clip, const float *far_clip, float aspect, int B, float *transforms,
+                             int *degenerate, hipStream_t s);
+int launch_camera_transforms_backward(const float *dtransforms, const float *eye, const float *center,
+                                      const float *up, const float *fov_y, const float *near_clip,
+                                      const float *far_clip, float aspect, int B, float *deye, float *dcenter,
+                                      float *dup, hipStream_t s);
 int launch_tone_map(const float *image, int B, size_t per_image, float gamma, int *max_bits, float *out,
                     uint8_t *out_u8, hipStream_t s);
 int soft_max_lights();

@@ -1020,6 +1020,65 @@ def test_fused_render_loss_keeps_autograd_semantics_of_the_image(device):
     assert len(ext._fused_renders) == n_before
 
 
+def test_camera_transform_kernel_matches_reference_golden_and_torch_autograd(device):
+    """Round 3: perspective . look_at on device-resident cameras as ONE launch each way
+    (mr_camera_transforms[_backward]) instead of ~30 tiny torch kernels: the reference's captured
+    look_at / perspective matrices, torch autograd of the same expressions for the gradients w.r.t. eye,
+    center and up, the reference's two degeneracy assertions, and render() end to end."""
+    from pytorch_mesh_renderer_amd import _native
+    g = golden_npz("camera_utils.npz")
+    eyes = torch.tensor(g["eyes"], device=device)
+    n = eyes.shape[0]
+    zeros, up = torch.zeros(n, 3, device=device), torch.tensor([[0.0, 1.0, 0.0]], device=device).repeat(n, 1)
+    full = lambda v: torch.full((n,), float(v), device=device)
+    got, flags = _native.camera_transforms(eyes, zeros, up, full(40.0), full(0.01), full(10.0), 1.25)
+    want = np.matmul(g["perspective"][0], g["look_at"])           # perspective(1.25, 40, 0.01, 10) . look_at
+    np.testing.assert_allclose(got.cpu().numpy(), want, atol=2e-6, rtol=1e-6)
+    assert int(flags.item()) == 0
+    # gradients: the kernel vs torch autograd through camera_utils' own expressions
+    gen = torch.Generator().manual_seed(12)
+    base = {"eye": torch.randn(7, 3, generator=gen) * 3.0, "center": torch.randn(7, 3, generator=gen) * 0.5,
+            "up": torch.nn.functional.normalize(torch.randn(7, 3, generator=gen) + torch.tensor([0.0, 2.0, 0.0]), dim=1)}
+    fov = torch.tensor([20.0, 40.0, 60.0, 35.0, 50.0, 75.0, 10.0], device=device)
+    near, far = torch.full((7,), 0.05, device=device), torch.tensor([10.0, 20.0, 5.0, 8.0, 100.0, 9.0, 30.0], device=device)
+    weights = torch.randn(7, 4, 4, generator=gen).to(device)
+    results = {}
+    for use_kernel in (True, False):
+        leaves = {k: v.clone().to(device).requires_grad_(True) for k, v in base.items()}
+        camera_utils.USE_CAMERA_KERNEL = use_kernel
+        try:
+            with _CountCalls("camera_transforms") as counter:
+                m = camera_utils.clip_space_transforms(leaves["eye"], leaves["center"], leaves["up"], fov, near, far,
+                                                       1.5, device)
+        finally:
+            camera_utils.USE_CAMERA_KERNEL = True
+        assert counter.calls == (1 if use_kernel else 0)
+        (m * weights).sum().backward()
+        results[use_kernel] = (m.detach().cpu().numpy(), {k: v.grad.cpu().numpy() for k, v in leaves.items()})
+    np.testing.assert_allclose(results[True][0], results[False][0], atol=1e-5, rtol=1e-5)
+    for k, want_grad in results[False][1].items():
+        assert np.abs(want_grad).max() > 1e-3, k
+        np.testing.assert_allclose(results[True][1][k], want_grad, atol=2e-5, rtol=2e-4, err_msg=k)
+    # the reference's assertions (camera_utils.py:68-69, 74-76)
+    one = lambda *v: torch.tensor([list(v)], dtype=torch.float32, device=device)
+    f1 = lambda v: torch.full((1,), float(v), device=device)
+    with pytest.raises(AssertionError, match="eye and center are close"):
+        camera_utils.clip_space_transforms(one(0, 0, 0), one(0, 0, 0), one(0, 1, 0), f1(40), f1(0.01), f1(10), 1.0, device)
+    with pytest.raises(AssertionError, match="up and gaze are too close"):
+        camera_utils.clip_space_transforms(one(0, 0, 0), one(0, 1, 0), one(0, 1, 0), f1(40), f1(0.01), f1(10), 1.0, device)
+    # render() with the camera on the device: one launch, and the eye receives a gradient
+    job = synthetic.sphere_job(2, 64, 48, 8)
+    eye = job["eyes"].clone().to(device).requires_grad_(True)
+    with _CountCalls("camera_transforms") as counter:
+        img = mesh_renderer.render(job["vertices"].to(device), job["triangles"].to(device), job["normals"].to(device),
+                                   job["diffuse"].to(device), eye, torch.zeros(2, 3, device=device),
+                                   torch.tensor([0.0, 1.0, 0.0], device=device), job["light_positions"].to(device),
+                                   job["light_intensities"].to(device), 64, 48)
+    assert counter.calls == 1
+    img[..., :3].mean().backward()
+    assert eye.grad is not None and float(eye.grad.abs().max()) > 0
+
+
 def test_tone_mapper_hip_matches_reference_golden_and_torch(device):
     """tone_mapper (render.py:389-419) as HIP passes: the reference's captured output, then torch's
     own pow / max / clamp semantics on images with zeros, values > 1, a negative entry (NaN power ->
