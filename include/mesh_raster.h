@@ -276,6 +276,11 @@ int mr_shade_backward_l1(const uint8_t *signs, const float *upstream, const int3
  *   light_grads      [B, 6L+7] f32 out  per image: d light_positions (L x 3), d light_intensities
  *                                 (L x 3), d ambient (3; 0 if NULL), d camera_position (3),
  *                                 d per-image shininess (1; 0 with per-vertex exponents)
+ *   vertex_offsets, vertex_entries (backward)  both NULL, or the CSR vertex adjacency of `triangles`
+ *                                 exactly as for mr_shade_backward: the per-triangle sums are then
+ *                                 gathered per vertex (no atomics, every output written once, fixed
+ *                                 order) instead of scattered with float atomics; required in the
+ *                                 deterministic mode
  * Only pixels that pass render()'s mask (render.py:215) evaluate the power; the reference's
  * autograd multiplies the masked pixels' zero gradient by pow(0, -1) = inf of the background
  * exponent -1 and returns NaN for every per-vertex-shininess call with a background pixel. */
@@ -298,7 +303,8 @@ int mr_shade_specular_backward(const float *drgba, const int32_t *ids, const flo
                                int shininess_per_vertex, const float *norms2, int B, int V, int T,
                                int W, int H, int L, float *dclip, float *dnormals, float *dpositions,
                                float *ddiffuse, float *dspecular, float *dshininess,
-                               float *light_grads, void *workspace, size_t workspace_bytes,
+                               float *light_grads, const int32_t *vertex_offsets,
+                               const int32_t *vertex_entries, void *workspace, size_t workspace_bytes,
                                void *stream);
 
 /* ---- SoftRas renderer ---------------------------------------------------------------
@@ -412,9 +418,12 @@ int mr_tone_map(const float *image, int B, size_t elements_per_image, float gamm
  * fixed-point scale is a power of two derived on the device from the largest upstream gradient g:
  * contributions below g * 2^-42 are rounded away, a per-triangle total may reach g * 2^21.  About
  * 10 % slower (8-byte atomics, one extra pass to find g when the upstream is a dense image).
- * mr_shade_backward needs the vertex adjacency in this mode (MR_EINVAL without).  The other
- * entry points (interpolation, specular and soft-renderer backward passes) are not covered and keep
- * float atomics.  mr_l1_loss_forward is always deterministic.  Returns the previous setting. */
+ * mr_shade_backward needs the vertex adjacency in this mode (MR_EINVAL without).  Round 3 extends the
+ * mode to mr_interpolate_raster_backward and mr_shade_specular_backward (the latter needs the
+ * adjacency too).  A contribution that does not fit the fixed-point range (NaN, infinite, beyond
+ * 2^63 after scaling) raises a flag and the outputs of that call are NaN instead of a finite wrong
+ * number.  Not covered, float atomics remain: the composed interpolation backward
+ * (mr_interpolate_backward) and the soft renderer's backward.  mr_l1_loss_forward is always deterministic.  Returns the previous setting. */
 int mr_set_deterministic(int on);
 
 /* ---- kernel timing (measurement, no reference counterpart) ----------------------------

@@ -16,7 +16,7 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 # build libmesh_raster_hip_probes.so this way); the product always loads the in-tree library.
 LIB_PATH = os.environ.get("MR_NATIVE_LIB_PATH") or os.path.join(_CSRC, "libmesh_raster_hip.so")
 
-ABI_VERSION = 333
+ABI_VERSION = 340
 TIMER_RASTER_FORWARD, TIMER_SHADE_BACKWARD, TIMER_SHADE_FORWARD, TIMER_RASTER_BACKWARD, TIMER_L1_FORWARD = 0, 1, 2, 3, 4
 MR_OK, MR_EINVAL, MR_EWORKSPACE, MR_ELAUNCH = 0, -1, -2, -3
 _ERR = {MR_EINVAL: "invalid argument", MR_EWORKSPACE: "workspace too small or misaligned",
@@ -182,7 +182,7 @@ def lib():
         L.mr_shade_specular_forward.restype = ci
         L.mr_shade_specular_backward_workspace_bytes.argtypes = [ci] * 5
         L.mr_shade_specular_backward_workspace_bytes.restype = sz
-        L.mr_shade_specular_backward.argtypes = [vp] * 14 + [ci, vp] + [ci] * 6 + [vp] * 7 + [vp, sz, vp]
+        L.mr_shade_specular_backward.argtypes = [vp] * 14 + [ci, vp] + [ci] * 6 + [vp] * 7 + [vp, vp] + [vp, sz, vp]
         L.mr_shade_specular_backward.restype = ci
         L.mr_export_u8.argtypes = [vp, sz, vp, vp]
         L.mr_export_u8.restype = ci
@@ -550,6 +550,7 @@ def interpolate_raster_backward(dout, ids, bary, clip, attrs, triangles, backgro
     dattrs = torch.empty(B, V, A, dtype=torch.float32, device=dev)
     dclip = torch.empty(B, V, 4, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
+        _sync_deterministic()
         need = L.mr_interpolate_raster_backward_workspace_bytes(B, V, T, W, H, A)
         ws, have = _workspace(dev, need)
         rc = L.mr_interpolate_raster_backward(
@@ -744,10 +745,11 @@ def shade_specular_forward(ids, bary, normals, positions, diffuse, specular, tri
 
 def shade_specular_backward(drgba, ids, bary, clip, normals, positions, diffuse, specular, triangles,
                             light_positions, light_intensities, ambient, camera_position, shininess,
-                            norms2):
+                            norms2, adjacency=None):
     """-> (dclip [B,V,4], dnormals, dpositions, ddiffuse, dspecular [B,V,3], dlight_positions,
     dlight_intensities [B,L,3], dambient [B,3] or None, dcamera_position [B,3], dshininess shaped
-    like shininess ([B] or [B,V]))."""
+    like shininess ([B] or [B,V])).  adjacency: vertex_adjacency(triangles, V) -- the per-triangle
+    sums are then gathered per vertex (no atomics; required by the deterministic mode)."""
     tensors = [drgba, ids, bary, clip, normals, positions, diffuse, specular, triangles,
                light_positions, light_intensities, camera_position, shininess, norms2]
     B, V, _ = _chk_mesh(clip, triangles)
@@ -771,7 +773,11 @@ def shade_specular_backward(drgba, ids, bary, clip, normals, positions, diffuse,
     dn, dp, dd, dsp = [torch.empty(B, V, 3, dtype=torch.float32, device=dev) for _ in range(4)]
     lg = torch.empty(B, 6 * nl + 7, dtype=torch.float32, device=dev)
     dshin_v = torch.empty(B, V, dtype=torch.float32, device=dev) if per_vertex else None
+    if adjacency is not None:
+        _chk("adjacency offsets", adjacency[0], _I32, V + 1)
+        _chk("adjacency entries", adjacency[1], _I32, None)
     with torch.cuda.device(dev):
+        _sync_deterministic()
         need = L.mr_shade_specular_backward_workspace_bytes(B, V, T, W, H)
         ws, have = _workspace(dev, need)
         rc = L.mr_shade_specular_backward(
@@ -779,7 +785,8 @@ def shade_specular_backward(drgba, ids, bary, clip, normals, positions, diffuse,
             _ptr(diffuse), _ptr(specular), _ptr(triangles), _ptr(light_positions),
             _ptr(light_intensities), _ptr(ambient), _ptr(camera_position), _ptr(shininess),
             int(per_vertex), _ptr(norms2), B, V, T, W, H, nl, _ptr(dclip), _ptr(dn), _ptr(dp), _ptr(dd),
-            _ptr(dsp), _ptr(dshin_v), _ptr(lg), _ptr(ws), have, _stream(dev))
+            _ptr(dsp), _ptr(dshin_v), _ptr(lg), _ptr(adjacency[0]) if adjacency is not None else None,
+            _ptr(adjacency[1]) if adjacency is not None else None, _ptr(ws), have, _stream(dev))
     _check(rc, "mr_shade_specular_backward")
     dlpos = lg[:, :3 * nl].reshape(B, nl, 3)
     dlint = lg[:, 3 * nl:6 * nl].reshape(B, nl, 3)

@@ -31,7 +31,7 @@ extern thread_local int g_shade_backward_kernel;
 
 extern "C" {
 
-int mr_version(void) { return 333; /* 0.3.3: deterministic mode, tone map, vertex normals, sign-coded shading backward, L1 timer */ }
+int mr_version(void) { return 340; /* 0.4.0: NULL attribute gradients, many lights, camera transforms, adjacency for the specular backward, wider deterministic mode */ }
 
 int mr_last_hip_error(void) { return mr::g_last_hip_error; }
 
@@ -357,10 +357,13 @@ int mr_shade_specular_backward(const float *drgba, const int32_t *ids, const flo
                                int shininess_per_vertex, const float *norms2, int B, int V, int T,
                                int W, int H, int L, float *dclip, float *dnormals, float *dpositions,
                                float *ddiffuse, float *dspecular, float *dshininess,
-                               float *light_grads, void *workspace, size_t workspace_bytes,
+                               float *light_grads, const int32_t *vertex_offsets,
+                               const int32_t *vertex_entries, void *workspace, size_t workspace_bytes,
                                void *stream) {
   if (bad_dims(B, V, T, W, H) || T < 1 || V < 1 || L < 1 || L > mr::shade_light_gradient_max_lights())
     return MR_EINVAL;
+  if ((vertex_offsets == nullptr) != (vertex_entries == nullptr)) return MR_EINVAL;
+  if (vertex_offsets && ((uintptr_t)dclip & 15u) != 0) return MR_EINVAL;
   if (B == 0) return MR_OK;
   if (!drgba || !ids || !bary || !clip || !normals || !positions || !diffuse || !specular ||
       !triangles || !light_positions || !light_intensities || !camera_position || !shininess ||
@@ -373,8 +376,8 @@ int mr_shade_specular_backward(const float *drgba, const int32_t *ids, const flo
                                             specular, triangles, light_positions, light_intensities,
                                             ambient, camera_position, shininess, shininess_per_vertex,
                                             norms2, B, V, T, W, H, L, dclip, dnormals, dpositions,
-                                            ddiffuse, dspecular, dshininess, light_grads, workspace,
-                                            (hipStream_t)stream);
+                                            ddiffuse, dspecular, dshininess, light_grads, vertex_offsets,
+                                            vertex_entries, workspace, (hipStream_t)stream);
 }
 
 int mr_soft_max_lights(void) { return mr::soft_max_lights(); }

@@ -20,6 +20,7 @@
 #include "run_accum.h"
 
 namespace mr {
+extern thread_local int g_deterministic;  // mr_set_deterministic (shade.hip)
 namespace {
 
 constexpr int kThreads = 256;
@@ -214,10 +215,12 @@ struct AttrRowsFn {
 
 // One thread per (image, vertex): sums the rows of the triangles incident to its vertex (CSR
 // adjacency: entry = 3 * triangle + corner).  Every output is written exactly once, no atomics.
-template <int AP>
+// DET (mr_set_deterministic): the rows hold 64-bit fixed-point sums (run_accum.h), converted here.
+template <int AP, bool DET>
 __global__ __launch_bounds__(kThreads) void k_attr_gather(
-    const float *__restrict__ acc, const int32_t *__restrict__ offsets, const int32_t *__restrict__ entries,
-    int B, int V, int T, int A, float *__restrict__ dattrs, float *__restrict__ dclip) {
+    const float *__restrict__ acc, const float *__restrict__ det_scale, const int32_t *__restrict__ offsets,
+    const int32_t *__restrict__ entries, int B, int V, int T, int A, float *__restrict__ dattrs,
+    float *__restrict__ dclip) {
   constexpr int STRIDE = AttrRowsFn<AP>::kStride;
   const long gid = (long)blockIdx.x * kThreads + threadIdx.x;
   if (gid >= (long)B * V) return;
@@ -231,10 +234,16 @@ __global__ __launch_bounds__(kThreads) void k_attr_gather(
     const int e = entries[i];
     const int t = e / 3, k = e - 3 * t;
     const float *row = acc + ((size_t)b * T + t) * STRIDE;
+    const long long *row_x = (const long long *)acc + ((size_t)b * T + t) * STRIDE;
 #pragma unroll
-    for (int j = 0; j < AP; ++j) a[j] += row[k * AP + j];
+    for (int j = 0; j < AP; ++j) a[j] += DET ? (float)row_x[k * AP + j] * det_scale[1] : row[k * AP + j];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) c[j] += row[3 * AP + k * 3 + j];
+    for (int j = 0; j < 3; ++j) c[j] += DET ? (float)row_x[3 * AP + k * 3 + j] * det_scale[1] : row[3 * AP + k * 3 + j];
+  }
+  if (DET && *det_overflow_flag(det_scale)) {  // a contribution outside the fixed-point range: NaN, not garbage
+#pragma unroll
+    for (int j = 0; j < AP; ++j) a[j] = __int_as_float(0x7fc00000);
+    c[0] = c[1] = c[2] = __int_as_float(0x7fc00000);
   }
   float *dst = dattrs + (size_t)gid * A;
 #pragma unroll
@@ -244,9 +253,9 @@ __global__ __launch_bounds__(kThreads) void k_attr_gather(
 }
 
 inline int padded_attrs(int A) { return A <= 4 ? 4 : (A <= 8 ? 8 : (A <= 12 ? 12 : 16)); }
-inline size_t acc_bytes(int B, int T, int AP) {
+inline size_t acc_bytes(int B, int T, int AP) {  // 8 bytes per element: room for the deterministic mode's fixed point
   const int stride = (3 * AP + 9 + 3) & ~3;
-  return align_up((size_t)B * T * stride * sizeof(float), 256);
+  return align_up((size_t)B * T * stride * sizeof(long long), 256);
 }
 inline size_t corner_bytes(int B, int T, int AP) { return align_up((size_t)B * T * 3 * AP * sizeof(float), 256); }
 
@@ -282,9 +291,15 @@ int run(const float *dout, const int32_t *ids, const float *bary, const float *c
   BwdRec *recs = (BwdRec *)p;
   p += align_up((size_t)B * T * sizeof(BwdRec), 256);
   float *corners = (float *)p;
-  if (hipMemsetAsync(acc, 0, (size_t)B * T * AttrRowsFn<AP>::kStride * sizeof(float), s) != hipSuccess)
+  p += corner_bytes(B, T, AP);
+  float *det_block = (float *)p;
+  const bool det = g_deterministic != 0;
+  if (hipMemsetAsync(acc, 0, (size_t)B * T * AttrRowsFn<AP>::kStride * (det ? sizeof(long long) : sizeof(float)), s) !=
+      hipSuccess)
     return check_launch();
-  int rc = launch_bwd_setup(clip, tris, B, V, T, recs, s);
+  int rc = MR_OK;
+  if (det && (rc = launch_det_scale(dout, (size_t)B * H * W * A, 1.0f, det_block, s)) != MR_OK) return rc;
+  rc = launch_bwd_setup(clip, tris, B, V, T, recs, s);
   if (rc != MR_OK) return rc;
   if (corner_records) {  // the forward's records (same inputs): skip the gather
     corners = const_cast<float *>(corner_records);
@@ -293,11 +308,16 @@ int run(const float *dout, const int32_t *ids, const float *bary, const float *c
     if (rc != MR_OK) return rc;
   }
   AttrRowsFn<AP> fn{dout, ids, (const F3 *)bary, corners, recs, bg, A, T};
-  rc = launch_accumulate_rows(fn, B, T, W, H, acc, s);
+  rc = launch_accumulate_rows(fn, B, T, W, H, acc, s, det ? det_block : nullptr);
   if (rc != MR_OK) return rc;
   const long nbv = (long)B * V;
-  hipLaunchKernelGGL(k_attr_gather<AP>, dim3((unsigned)((nbv + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
-                     acc, offsets, entries, B, V, T, A, dattrs, dclip);
+  const dim3 grid((unsigned)((nbv + kThreads - 1) / kThreads));
+  if (det)
+    hipLaunchKernelGGL((k_attr_gather<AP, true>), grid, dim3(kThreads), 0, s, acc, det_block, offsets, entries, B, V,
+                       T, A, dattrs, dclip);
+  else
+    hipLaunchKernelGGL((k_attr_gather<AP, false>), grid, dim3(kThreads), 0, s, acc, det_block, offsets, entries, B, V,
+                       T, A, dattrs, dclip);
   return check_launch();
 }
 
@@ -308,7 +328,7 @@ int interp_raster_max_attrs() { return 16; }
 size_t interp_raster_backward_ws(int B, int V, int T, int W, int H, int A) {
   (void)V; (void)W; (void)H;
   const int AP = padded_attrs(A);
-  return acc_bytes(B, T, AP) + align_up((size_t)B * T * sizeof(BwdRec), 256) + corner_bytes(B, T, AP);
+  return acc_bytes(B, T, AP) + align_up((size_t)B * T * sizeof(BwdRec), 256) + corner_bytes(B, T, AP) + kDetBlockBytes;
 }
 
 size_t interp_records_bytes(int B, int T, int A) { return corner_bytes(B, T, padded_attrs(A)); }

@@ -73,6 +73,46 @@ __device__ __forceinline__ void atomic_add_fixed(long long *p, float v, float to
   atomicAdd((unsigned long long *)p, (unsigned long long)__float2ll_rn(x));
 }
 
+// The deterministic mode's 512-byte side block (zeroed per launch): float [0] = 2^k, [1] = 2^-k,
+// int [4] = bits of the largest |upstream gradient|, int [8] = overflow flag (above).
+constexpr size_t kDetBlockBytes = 512;
+static __global__ __launch_bounds__(256) void k_det_abs_max(const float *__restrict__ x, size_t n, int *__restrict__ max_bits) {
+  int best = 0;  // non-negative floats order like integers; a NaN sorts on top
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    best = max(best, __float_as_int(fabsf(x[i])));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) best = max(best, __shfl_down(best, off));
+  __shared__ int s_best[4];  // one atomic per WORKGROUP (thousands on one address queue up)
+  if ((threadIdx.x & 63) == 0) s_best[threadIdx.x >> 6] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) best = max(best, s_best[w]);
+    if (best != 0) atomicMax(max_bits, best);
+  }
+}
+// (2^k, 2^-k) with k such that `gain` times the largest upstream gradient maps to about 2^41
+static __global__ void k_det_scale_from_bits(const int *__restrict__ max_bits, float gain, float *__restrict__ det_scale) {
+  const float g = __int_as_float(max_bits[0]) * gain;
+  int e = 0;
+  if (g > 0.0f && g < INFINITY) (void)frexpf(g, &e);  // g = m * 2^e, m in [0.5, 1)
+  const int k = min(max(41 - e, -100), 100);
+  det_scale[0] = ldexpf(1.0f, k);
+  det_scale[1] = ldexpf(1.0f, -k);
+}
+// Zeroes the block and fills its scale pair from the n floats at x (the upstream gradient image).
+// gain: the largest factor a contribution may carry over the upstream gradient beyond the 2^21 of
+// headroom the scale leaves (1 for the rasterizer / shading passes; 1 / min(sigma, gamma) for SoftRas).
+inline int launch_det_scale(const float *x, size_t n, float gain, float *det_block, hipStream_t s) {
+  if (hipMemsetAsync(det_block, 0, kDetBlockBytes, s) != hipSuccess) return check_launch();
+  const size_t want = (n + 255) / 256;
+  hipLaunchKernelGGL(k_det_abs_max, dim3((unsigned)(want < 2048 ? (want ? want : 1) : 2048)), dim3(256), 0, s, x, n,
+                     (int *)det_block + 4);
+  int rc = check_launch();
+  if (rc != MR_OK) return rc;
+  hipLaunchKernelGGL(k_det_scale_from_bits, dim3(1), dim3(1), 0, s, (const int *)det_block + 4, gain, det_block);
+  return check_launch();
+}
+
 template <int SLOTS>
 __device__ __forceinline__ int run_find_slot(int *keys, int tri) {
   static_assert((SLOTS & (SLOTS - 1)) == 0, "power of two");

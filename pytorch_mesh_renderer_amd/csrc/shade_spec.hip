@@ -40,6 +40,7 @@
 #endif
 
 namespace mr {
+extern thread_local int g_deterministic;  // mr_set_deterministic (shade.hip)
 namespace {
 
 constexpr int kThreads = 256;
@@ -625,10 +626,62 @@ __global__ __launch_bounds__(kThreads) void k_spec_scatter(
   }
 }
 
+// Vertex-centric alternative (round 3; the diffuse path has had it since round 2): sixteen lanes per
+// (image, vertex), one per output float -- A attribute gradients, then the three clip gradients -- sum the
+// rows of the incident triangles over the CSR adjacency (entry = 3 * triangle + corner).  No atomics,
+// every output written exactly once, fixed order; DET: the rows hold 64-bit fixed point (run_accum.h).
+template <int A, bool DET>
+__global__ __launch_bounds__(kThreads) void k_spec_gather(
+    const float *__restrict__ acc, const float *__restrict__ det_scale, const int32_t *__restrict__ offsets,
+    const int32_t *__restrict__ entries, int B, int V, int T, float *__restrict__ dnormals,
+    float *__restrict__ dpositions, float *__restrict__ ddiffuse, float *__restrict__ dspecular,
+    float *__restrict__ dshininess, float *__restrict__ dclip) {
+  static_assert(A + 3 <= 16, "one lane per output float");
+  const long tid = (long)blockIdx.x * kThreads + threadIdx.x;
+  const long gid = tid >> 4;   // (image, vertex)
+  const int j = (int)(tid & 15);
+  if (gid >= (long)B * V || j > A + 2) return;
+  const int b = (int)(gid / V);
+  const int v = (int)(gid - (long)b * V);
+  float sum = 0.f;
+  {
+    const unsigned col0 = j < A ? (unsigned)j : 3u * A + (unsigned)(j - A), colk = j < A ? (unsigned)A : 3u;
+    const float *acc_f = acc + (size_t)b * T * 48;
+    const long long *acc_x = (const long long *)acc + (size_t)b * T * 48;
+    const int e1 = offsets[v + 1];
+    constexpr int kChunk = 8;
+    for (int i = offsets[v]; i < e1; i += kChunk) {
+      int e[kChunk];
+      float val[kChunk];
+#pragma unroll
+      for (int u = 0; u < kChunk; ++u) e[u] = i + u < e1 ? entries[i + u] : -1;
+#pragma unroll
+      for (int u = 0; u < kChunk; ++u) {
+        const unsigned t = (unsigned)e[u] / 3u, k = (unsigned)e[u] - 3u * t;
+        const unsigned at = t * 48u + col0 + k * colk;
+        val[u] = e[u] < 0 ? 0.f : DET ? (float)acc_x[at] * det_scale[1] : acc_f[at];
+      }
+#pragma unroll
+      for (int u = 0; u < kChunk; ++u) sum += val[u];
+    }
+  }
+  if (DET && *det_overflow_flag(det_scale)) sum = __int_as_float(0x7fc00000);  // see atomic_add_fixed
+  float *out = j < 3 ? dnormals + gid * 3 + j
+             : j < 6 ? dpositions + gid * 3 + (j - 3)
+             : j < 9 ? ddiffuse + gid * 3 + (j - 6)
+             : j < 12 ? dspecular + gid * 3 + (j - 9)
+             : j < A ? dshininess + gid
+             : j < A + 2 ? dclip + gid * 4 + (j - A)
+             : dclip + gid * 4 + 3;
+  *out = sum;
+  if (j == A + 2) dclip[gid * 4 + 2] = 0.0f;  // the clip z column receives no gradient (with 13 attributes all 16 lanes are taken)
+}
+
 inline size_t spec_corner_bytes(int B, int T) {
   return align_up((size_t)B * T * sizeof(SpecCornerRec<kAttrMax>), 256);
 }
-inline size_t spec_acc_bytes(int B, int T) { return align_up((size_t)B * T * 48 * sizeof(float), 256); }
+// 8 bytes per element: room for the deterministic mode's fixed-point accumulators
+inline size_t spec_acc_bytes(int B, int T) { return align_up((size_t)B * T * 48 * sizeof(long long), 256); }
 inline size_t spec_sums_bytes(int B) { return align_up((size_t)B * 4 * sizeof(float), 256); }
 // k_spec_pixels' per-workgroup partial sums (kNorms, kGsum): [workgroups][L <= 4]
 inline int spec_blocks_per_image(int W, int H) { return ((W + kThreads - 1) / kThreads) * H; }
@@ -690,14 +743,22 @@ int spec_forward(const int32_t *ids, const float *bary, const float *normals, co
   return launch_spec_pixels<kShade, PV>(L, ids, bary, ws, scene, B, T, W, H, nullptr, rgba, nullptr, nullptr, s);
 }
 
+// one row of light / camera / shininess sums per strip of the backward's pixel pass
+inline size_t spec_light_rows_bytes(int B, int W, int H) {
+  return align_up((size_t)B * strips_per_image<SpecGradFn<1, false>>(W, H) * kSumRowSlots * sizeof(float), 256);
+}
+
 template <bool PV>
 int spec_backward(const float *drgba, const int32_t *ids, const float *bary, const float *clip,
                   const float *normals, const float *positions, const float *diffuse, const float *specular,
                   const int32_t *tris, const float *light_pos, const float *light_col, const float *ambient,
                   const float *camera, const float *shininess, const float *norms2, int B, int V, int T, int W,
                   int H, int L, float *dclip, float *dnormals, float *dpositions, float *ddiffuse,
-                  float *dspecular, float *dshininess, float *light_grads, void *ws, hipStream_t s) {
+                  float *dspecular, float *dshininess, float *light_grads, const int32_t *vertex_offsets,
+                  const int32_t *vertex_entries, void *ws, hipStream_t s) {
   constexpr int A = attr_count(PV);
+  const bool det = g_deterministic != 0;
+  if (det && !(vertex_offsets && vertex_entries)) return MR_EINVAL;  // the scatter path is float atomics only
   char *p = (char *)ws;
   float *acc = (float *)p;
   p += spec_acc_bytes(B, T);
@@ -710,8 +771,13 @@ int spec_backward(const float *drgba, const int32_t *ids, const float *bary, con
   float *partials = (float *)p;
   p += spec_partials_bytes(B, W, H);
   float *light_rows = (float *)p;
-  if (hipMemsetAsync(acc, 0, (size_t)B * T * 48 * sizeof(float), s) != hipSuccess) return check_launch();
-  int rc = launch_bwd_setup(clip, tris, B, V, T, recs, s);
+  p += spec_light_rows_bytes(B, W, H);
+  float *det_block = (float *)p;
+  if (hipMemsetAsync(acc, 0, (size_t)B * T * 48 * (det ? sizeof(long long) : sizeof(float)), s) != hipSuccess)
+    return check_launch();
+  int rc = MR_OK;
+  if (det && (rc = launch_det_scale(drgba, (size_t)B * H * W * 4, 1.0f, det_block, s)) != MR_OK) return rc;
+  rc = launch_bwd_setup(clip, tris, B, V, T, recs, s);
   if (rc != MR_OK) return rc;
   rc = launch_spec_corner_setup<PV>(normals, positions, diffuse, specular, PV ? shininess : nullptr, tris, B, V, T,
                                     corners, s);
@@ -724,7 +790,7 @@ int spec_backward(const float *drgba, const int32_t *ids, const float *bary, con
   {                                                                                                   \
     SpecGradFn<NL, PV> fn{(const float4 *)drgba, ids, (const F3 *)bary, (const SpecCornerRec<A> *)corners, \
                           recs, scene, light_rows, T, W, H};                                          \
-    rc = launch_accumulate_rows(fn, B, T, W, H, acc, s);                                              \
+    rc = launch_accumulate_rows(fn, B, T, W, H, acc, s, det ? det_block : nullptr);                   \
   }
   switch (L) {
     case 1: MR_SPEC_BWD(1); break;
@@ -737,6 +803,17 @@ int spec_backward(const float *drgba, const int32_t *ids, const float *bary, con
   if (rc != MR_OK) return rc;
   rc = launch_sum_strip_rows(light_rows, B, strips_per_image<SpecGradFn<1, PV>>(W, H), L * 6 + 7, light_grads, s);
   if (rc != MR_OK) return rc;
+  if (vertex_offsets && vertex_entries) {
+    const long nbv = (long)B * V * 16;  // sixteen lanes per vertex
+    const dim3 grid((unsigned)((nbv + kThreads - 1) / kThreads));
+    if (det)
+      hipLaunchKernelGGL((k_spec_gather<A, true>), grid, dim3(kThreads), 0, s, acc, det_block, vertex_offsets,
+                         vertex_entries, B, V, T, dnormals, dpositions, ddiffuse, dspecular, dshininess, dclip);
+    else
+      hipLaunchKernelGGL((k_spec_gather<A, false>), grid, dim3(kThreads), 0, s, acc, det_block, vertex_offsets,
+                         vertex_entries, B, V, T, dnormals, dpositions, ddiffuse, dspecular, dshininess, dclip);
+    return check_launch();
+  }
   const long nbt = (long)B * T;
   hipLaunchKernelGGL((k_spec_scatter<A>), dim3((unsigned)((nbt + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
                      acc, tris, B, V, T, dnormals, dpositions, ddiffuse, dspecular, dshininess, dclip);
@@ -745,10 +822,6 @@ int spec_backward(const float *drgba, const int32_t *ids, const float *bary, con
 
 }  // namespace
 
-// one row of light / camera / shininess sums per strip of the backward's pixel pass
-static size_t spec_light_rows_bytes(int B, int W, int H) {
-  return align_up((size_t)B * strips_per_image<SpecGradFn<1, false>>(W, H) * kSumRowSlots * sizeof(float), 256);
-}
 
 size_t shade_specular_forward_ws(int B, int V, int T, int W, int H) {
   (void)V;
@@ -772,7 +845,7 @@ int launch_shade_specular_forward(const int32_t *ids, const float *bary, const f
 size_t shade_specular_backward_ws(int B, int V, int T, int W, int H) {
   (void)V;
   return spec_acc_bytes(B, T) + align_up((size_t)B * T * sizeof(BwdRec), 256) + spec_corner_bytes(B, T) +
-         spec_sums_bytes(B) + spec_partials_bytes(B, W, H) + spec_light_rows_bytes(B, W, H);
+         spec_sums_bytes(B) + spec_partials_bytes(B, W, H) + spec_light_rows_bytes(B, W, H) + kDetBlockBytes;
 }
 
 int launch_shade_specular_backward(const float *drgba, const int32_t *ids, const float *bary,
@@ -782,10 +855,12 @@ int launch_shade_specular_backward(const float *drgba, const int32_t *ids, const
                                    const float *camera, const float *shininess, int shininess_per_vertex,
                                    const float *norms2, int B, int V, int T, int W, int H, int L, float *dclip,
                                    float *dnormals, float *dpositions, float *ddiffuse, float *dspecular,
-                                   float *dshininess, float *light_grads, void *ws, hipStream_t s) {
+                                   float *dshininess, float *light_grads, const int32_t *vertex_offsets,
+                                   const int32_t *vertex_entries, void *ws, hipStream_t s) {
   if (B == 0) return MR_OK;
   const size_t v3 = (size_t)B * V * 3 * sizeof(float);
-  if (V > 0) {
+  const bool gathered = vertex_offsets && vertex_entries && T > 0 && (size_t)W * H > 0;  // every output written once
+  if (V > 0 && !gathered) {
     if (hipMemsetAsync(dclip, 0, (size_t)B * V * 4 * sizeof(float), s) != hipSuccess) return check_launch();
     if (hipMemsetAsync(dnormals, 0, v3, s) != hipSuccess) return check_launch();
     if (hipMemsetAsync(dpositions, 0, v3, s) != hipSuccess) return check_launch();
@@ -801,10 +876,12 @@ int launch_shade_specular_backward(const float *drgba, const int32_t *ids, const
   return shininess_per_vertex
              ? spec_backward<true>(drgba, ids, bary, clip, normals, positions, diffuse, specular, tris, light_pos,
                                    light_col, ambient, camera, shininess, norms2, B, V, T, W, H, L, dclip,
-                                   dnormals, dpositions, ddiffuse, dspecular, dshininess, light_grads, ws, s)
+                                   dnormals, dpositions, ddiffuse, dspecular, dshininess, light_grads,
+                                   vertex_offsets, vertex_entries, ws, s)
              : spec_backward<false>(drgba, ids, bary, clip, normals, positions, diffuse, specular, tris, light_pos,
                                     light_col, ambient, camera, shininess, norms2, B, V, T, W, H, L, dclip,
-                                    dnormals, dpositions, ddiffuse, dspecular, dshininess, light_grads, ws, s);
+                                    dnormals, dpositions, ddiffuse, dspecular, dshininess, light_grads,
+                                    vertex_offsets, vertex_entries, ws, s);
 }
 
 }  // namespace mr

@@ -301,7 +301,8 @@ class FusedSpecularPhongRenderer(torch.autograd.Function):
         cam, shin = camera_position.detach().contiguous(), shininess.detach().contiguous()
         rgba, norms2 = _native.shade_specular_forward(ids, bary, attrs[0], attrs[1], attrs[2], attrs[3],
                                                       triangles, lp, li, amb, cam, shin)
-        saved = [clip_d, ids, bary] + attrs + [triangles, lp, li, cam, shin, norms2]
+        offsets, entries = _native.vertex_adjacency(triangles, positions.shape[1])   # cached per mesh
+        saved = [clip_d, ids, bary] + attrs + [triangles, lp, li, cam, shin, norms2, offsets, entries]
         if amb is not None:
             saved.append(amb)
         ctx.save_for_backward(*saved)
@@ -312,8 +313,10 @@ class FusedSpecularPhongRenderer(torch.autograd.Function):
     def backward(ctx, drgba):
         saved = ctx.saved_tensors
         clip, ids, bary, normals, positions, diffuse, specular, triangles, lp, li, cam, shin, norms2 = saved[:13]
-        amb = saved[13] if ctx.has_ambient else None
+        offsets, entries = saved[13:15]
+        amb = saved[15] if ctx.has_ambient else None
+        # per-vertex gather over the adjacency (round 3): no atomics, every output written once
         dclip, dn, dp, dd, dsp, dlp, dli, damb, dcam, dshin = _native.shade_specular_backward(
             drgba.contiguous(), ids, bary, clip, normals, positions, diffuse, specular, triangles, lp, li,
-            amb, cam, shin, norms2)
+            amb, cam, shin, norms2, adjacency=(offsets, entries))
         return dclip, dp, dn, dd, dsp, None, dlp, dli, damb, dcam, dshin, None, None

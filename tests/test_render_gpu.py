@@ -527,6 +527,82 @@ def test_image_wide_sums_are_bit_reproducible(device):
         assert a is not None and float(a.abs().max()) > 0 and torch.equal(a, b)
 
 
+def test_deterministic_mode_covers_specular_and_rasterize_backward(device):
+    """Round 3: mr_set_deterministic also covers the specular backward (fixed-point rows + per-vertex
+    gather over the adjacency instead of k_spec_scatter's float atomics) and the fused interpolation
+    backward of rasterize(): every gradient is bit-identical between two runs, and equals the default
+    float-atomic kernels within the parity tolerance.  Sizes with thousands of merge-table flushes per
+    image (a 50-subdivision sphere at 320x240)."""
+    from pytorch_mesh_renderer_amd import _native
+    job = synthetic.sphere_job(2, 320, 240, 50)
+    gen = torch.Generator().manual_seed(17)
+    target = torch.rand(2, 240, 320, 4, generator=gen).to(device)
+    base = {"vertices": job["vertices"], "normals": job["normals"],
+            "diffuse": torch.rand(job["vertices"].shape, generator=gen),
+            "specular": torch.rand(job["vertices"].shape, generator=gen),
+            "shininess": 0.3 + torch.rand(2, job["vertices"].shape[1], generator=gen)}
+    attrs = torch.rand(2, job["vertices"].shape[1], 7, generator=gen)
+    weights = torch.randn(2, 240, 320, 7, generator=gen).to(device) / (240 * 320)
+
+    def run():
+        leaves = {k: v.clone().to(device).requires_grad_(True) for k, v in base.items()}
+        img = mesh_renderer.render(leaves["vertices"], job["triangles"].to(device), leaves["normals"], leaves["diffuse"],
+                                   job["eyes"], torch.zeros(2, 3), torch.tensor([0.0, 1.0, 0.0]),
+                                   job["light_positions"].to(device), job["light_intensities"].to(device), 320, 240,
+                                   specular_colors=leaves["specular"], shininess_coefficients=leaves["shininess"])
+        (torch.mean(torch.abs(img - target)) * 20.0).backward()
+        grads = [leaves[k].grad.clone() for k in sorted(leaves)]
+        clip = job["clip"].clone().to(device).requires_grad_(True)
+        a = attrs.clone().to(device).requires_grad_(True)
+        from pytorch_mesh_renderer_amd.mesh_renderer.rasterize import rasterize_clip_space
+        out = rasterize_clip_space(clip, a, job["triangles"].to(device), 320, 240,
+                                   torch.zeros(7, device=device))
+        (out * weights).sum().backward()
+        return grads + [clip.grad.clone(), a.grad.clone()]
+
+    default = run()
+    before = _native.set_deterministic(True)
+    try:
+        first, second = run(), run()
+    finally:
+        _native.set_deterministic(before)
+    for i, (a, b, d) in enumerate(zip(first, second, default)):
+        assert float(a.abs().max()) > 0, i
+        assert torch.equal(a, b), "output %d differs between two deterministic runs" % i
+        scale = float(d.abs().max())
+        np.testing.assert_allclose(a.cpu().numpy(), d.cpu().numpy(), atol=max(1e-4 * scale, 1e-9), rtol=1e-3,
+                                   err_msg="deterministic vs default, output %d" % i)
+
+
+def test_specular_backward_gather_matches_scatter(device):
+    """mr_shade_specular_backward with the CSR vertex adjacency (per-vertex gather, what render() uses
+    since round 3) vs without it (float-atomic scatter), per-vertex shininess included."""
+    from pytorch_mesh_renderer_amd import _native
+    job = synthetic.sphere_job(2, 120, 90, 10)
+    d = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in job.items()}
+    gen = torch.Generator().manual_seed(3)
+    V = d["vertices"].shape[1]
+    spec = torch.rand(2, V, 3, generator=gen).to(device)
+    ids, bary, _ = _native.rasterize_forward(d["clip"], d["triangles"], 120, 90)
+    cam = job["eyes"].to(device)
+    g = torch.randn(2, 90, 120, 4, generator=gen).to(device) / (90 * 120)
+    for shin in (torch.tensor([1.5, 0.7], device=device), (0.3 + torch.rand(2, V, generator=gen)).to(device)):
+        rgba, norms2 = _native.shade_specular_forward(ids, bary, d["normals"], d["vertices"], d["diffuse"], spec,
+                                                      d["triangles"], d["light_positions"], d["light_intensities"],
+                                                      None, cam, shin)
+        args = (g, ids, bary, d["clip"], d["normals"], d["vertices"], d["diffuse"], spec, d["triangles"],
+                d["light_positions"], d["light_intensities"], None, cam, shin, norms2)
+        scatter = _native.shade_specular_backward(*args)
+        gather = _native.shade_specular_backward(*args, adjacency=_native.vertex_adjacency(d["triangles"], V))
+        for i, (a, b) in enumerate(zip(scatter, gather)):
+            if a is None:
+                assert b is None
+                continue
+            assert float(a.abs().max()) > 0, i
+            np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), atol=1e-7 * max(1.0, float(a.abs().max()) * 1e3),
+                                       rtol=1e-4, err_msg="output %d" % i)
+
+
 @pytest.mark.parametrize("kind", ["vertex", "image", "scalar"])
 def test_fused_specular_shininess_gradient_matches_composed_path(device, kind):
     """A shininess that requires grad -- [B,V], [B] or 0-D -- through the fused kernels vs torch autograd
