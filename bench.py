@@ -233,8 +233,9 @@ def roofline(kernel, algorithmic, avg_ms, traffic_key, config="c3"):
     pmc_path = os.path.join(ROOT, "profiles", "kernel_traffic.json")
     if os.path.exists(pmc_path):   # written from separate rocprofv3 --pmc passes over this command
         pmc = json.load(open(pmc_path))
-        # (the counters were collected on the default configuration only)
-        if config == "c3" and traffic_key in pmc.get("kernels", {}):
+        if config != "c3":   # the default configuration sits at the top level, the others under "configs"
+            pmc = pmc.get("configs", {}).get(config, {})
+        if traffic_key in pmc.get("kernels", {}) and pmc["kernels"][traffic_key]["bytes_per_launch"]:
             out["traffic"] = pmc["kernels"][traffic_key]["bytes_per_launch"]
             out["traffic_source"] = ("profiles/kernel_traffic.json: rocprofv3 --pmc passes over `%s` at %s, NOT "
                                      "this run" % (pmc.get("command", "bench.py"), pmc.get("tag", "?")))

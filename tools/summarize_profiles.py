@@ -1,6 +1,6 @@
 """Condense gpurun_out/prof_final (tools/collect_profiles.sh) into the files under profiles/.
 
-    python tools/summarize_profiles.py <tag>      # e.g. r01_h
+    python tools/summarize_profiles.py <tag> [config]     # e.g. r03_b, r03_b c4
 
 Writes profiles/<tag>_bench_kernel_stats.csv (rocprofv3 --stats, top kernels),
 profiles/<tag>_bench.json (the bench lines of the same box) and rewrites
@@ -12,6 +12,9 @@ import csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof_final")
 tag = sys.argv[1]
+config = sys.argv[2] if len(sys.argv) > 2 else "c3"   # bench.py --config the passes ran with
+if config != "c3":
+    SRC = SRC + "_" + config
 prof = os.path.join(ROOT, "profiles")
 
 
@@ -24,7 +27,8 @@ def one(pattern):
 
 # 1. kernel statistics
 rows = list(csv.DictReader(open(one("stats/**/*kernel_stats.csv"))))
-with open(os.path.join(prof, tag + "_bench_kernel_stats.csv"), "w", newline="") as f:
+suffix = "" if config == "c3" else "_" + config
+with open(os.path.join(prof, tag + suffix + "_bench_kernel_stats.csv"), "w", newline="") as f:
     w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
     w.writeheader()
     for r in rows[:24]:
@@ -36,13 +40,13 @@ for name in ("bench.log", "bench_under_rocprof.log"):
     for line in open(os.path.join(SRC, name)):
         if line.startswith('{"metric"'):
             lines[name[:-4]] = json.loads(line)
-json.dump(lines, open(os.path.join(prof, tag + "_bench.json"), "w"), indent=1)
+json.dump(lines, open(os.path.join(prof, tag + suffix + "_bench.json"), "w"), indent=1)
 
 # 3. HBM traffic of the kernels of interest, per launch
 # k_raster<R, PROBE, SHADE>: "true>" = with the shading epilogue (the step's forward), "false>" = the
 # G-buffer kernel alone (bench.py runs 22 such steps after its timed region)
 wanted = {"k_raster_shade": "k_raster<64, 0, true>", "k_raster": "k_raster<64, 0, false>",
-          "k_shade_forward": "k_shade_forward(", "ShadeGradFn": "ShadeGradFn",
+          "k_shade_forward": "k_shade_forward(", "ShadeGradFn": ("ShadeLaneFn", "ShadeGradFn"),
           "k_l1_forward": "k_l1_forward(", "k_l1_backward": "k_l1_backward("}
 raw = {k: {} for k in wanted}
 for counter in ("WRITE_SIZE", "FETCH_SIZE"):
@@ -51,7 +55,8 @@ for counter in ("WRITE_SIZE", "FETCH_SIZE"):
         if r["Counter_Name"] != counter:
             continue
         for k, needle in wanted.items():
-            if needle in r["Kernel_Name"]:
+            needles = needle if isinstance(needle, tuple) else (needle,)
+            if any(n in r["Kernel_Name"] for n in needles):
                 acc[k].append(float(r["Counter_Value"]))
     for k, v in acc.items():
         if v:
@@ -65,8 +70,9 @@ def traffic(entry):
     return int(round((entry.get("WRITE_SIZE", 0.0) + 2.0 * entry.get("FETCH_SIZE", 0.0)) * 1024))
 
 
+cmd = "python3 bench.py --steps 3 --warmup 1 --cpu-sample 0" + ("" if config == "c3" else " --config " + config)
 out = {
-    "command": "python3 bench.py --steps 3 --warmup 1 --cpu-sample 0",
+    "command": cmd,
     "tag": tag,
     "how": "rocprofv3 --kernel-trace --pmc WRITE_SIZE and --pmc FETCH_SIZE in separate passes over the command "
            "(tools/collect_profiles.sh), averaged over each kernel's dispatches; bytes = (WRITE_SIZE + "
@@ -84,5 +90,15 @@ out = {
     },
     "raw": raw,
 }
-json.dump(out, open(os.path.join(prof, "kernel_traffic.json"), "w"), indent=1)
+# one file for every configuration: the default (configs[2]) at the top level, as bench.py has read it
+# since round 1, the others under "configs"
+path = os.path.join(prof, "kernel_traffic.json")
+if config == "c3":
+    merged = dict(out)
+    if os.path.exists(path):
+        merged["configs"] = json.load(open(path)).get("configs", {})
+else:
+    merged = json.load(open(path)) if os.path.exists(path) else {}
+    merged.setdefault("configs", {})[config] = out
+json.dump(merged, open(path, "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k != "how"}, indent=1))
