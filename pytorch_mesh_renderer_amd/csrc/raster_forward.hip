@@ -581,8 +581,18 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : MR_RASTER
     // pixel-centre extents of tile column t: s_pxy[0][t kTileW] .. s_pxy[0][min(t kTileW + kTileW - 1, last)]
     const int last_x = X1 - 1 - X0, last_y = Y1 - 1 - Y0;
     __syncthreads();
-    if (tid < n_near || (tid >= far_base && tid < far_base + n_far)) {
-      const float *p = s_ent + tid * kEntryDw;
+    // Round 3: SEVERAL threads per entry.  A region's bin holds ~40 entries at 1024^2 / 5k triangles:
+    // with one thread each, one wavefront of the four walked up to 64 tiles per entry serially while
+    // the other three waited at the barrier -- 24 us of the kernel's 150 (stage probes, profiles/
+    // r03_raster_stage_times.txt).  `per` threads (a power of two, as many as fit the workgroup, at
+    // most one per tile row) now share an entry's tile rows.
+    const int total = n_near + n_far;
+    int per_log = 0;
+    while (per_log < 4 && (total << (per_log + 1)) <= kThreads) ++per_log;   // workgroup-uniform
+    const int idx = tid >> per_log, sub = tid & ((1 << per_log) - 1), per = 1 << per_log;
+    if (idx < total) {
+      const int e = idx < n_near ? idx : far_base + (idx - n_near);
+      const float *p = s_ent + e * kEntryDw;
       const uint2 box = *(const uint2 *)(p + 16);
       const float4 q0 = *(const float4 *)(p), q1 = *(const float4 *)(p + 4);
       const float m8 = p[8];
@@ -590,9 +600,9 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : MR_RASTER
       const int bl = (int)(box.x & 0xffffu), bb = (int)(box.x >> 16);
       const int tx0 = bl / kTileW, tx1 = (bl + (int)(box.y & 0xffffu)) / kTileW;
       const int ty0 = bb / kTileH, ty1 = (bb + (int)(box.y >> 16)) / kTileH;
-      const unsigned bit = 1u << (tid & 31);
-      const int word = tid >> 5;
-      for (int ty = ty0; ty <= ty1; ++ty) {
+      const unsigned bit = 1u << (e & 31);
+      const int word = e >> 5;
+      for (int ty = ty0 + sub; ty <= ty1; ty += per) {
         const float ylo = s_pxy[1][ty * kTileH], yhi = s_pxy[1][min(ty * kTileH + kTileH - 1, last_y)];
         for (int tx = tx0; tx <= tx1; ++tx) {
           if (!rect_outside_triangle(q0, q1, m8, s_pxy[0][tx * kTileW],

@@ -7,7 +7,7 @@ for flags in "$@"; do
   make -j8 -C pytorch_mesh_renderer_amd/csrc "$flags" all >/dev/null 2>&1
   make -j8 -C pytorch_mesh_renderer_amd/csrc "$flags" probes >/dev/null 2>&1
   echo "--- $flags"
-  if [ "$AB_BENCH" = step ]; then timeout -k 5 200 python bench.py --cpu-sample 0 --steps 100 2>/dev/null | grep -o "ms_per_step[^,]*\|avg_kernel_ms\": [0-9.]*" | sed 's/avg_kernel_ms": //' | tr '\n' ' '; echo " (step | fused fwd, gbuffer, shade bwd, l1 fwd)"
+  if [ "$AB_BENCH" = step ]; then timeout -k 5 200 python bench.py --cpu-sample 0 --steps 100 2>/dev/null | grep -o "\"ms_per_step\": [0-9.]*\|avg_kernel_ms\": [0-9.]*" | sed 's/avg_kernel_ms": //; s/"ms_per_step": //' | tr '\n' ' '; echo " (step | fused fwd, gbuffer, shade bwd, l1 fwd)"
   elif [ "$AB_BENCH" = bench ]; then timeout -k 5 200 python bench.py --cpu-sample 0 --steps 100 2>/dev/null | grep -o "ms_per_step[^,]*\|avg_kernel_ms[^}]*" | tr '\n' ' '; echo
   elif [ "$AB_BENCH" = kernels ]; then timeout -k 5 100 python tools/shade_bench.py 2>/dev/null | grep shade; timeout -k 5 100 python tools/raster_bench.py --config c3 --backward 2>/dev/null | grep "bwd\|fwd"
   elif [ "$AB_BENCH" = spec ]; then timeout -k 5 200 python tools/specular_bench.py 2>/dev/null | grep "specular=True"
