@@ -924,11 +924,16 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : MR_RASTER
     s_chunk_count[tid] = 0;  // kRoundChunks == kThreads
     __syncthreads();
     int count = 0, stop = round_chunks;  // stop: first chunk this wavefront could not take
-    constexpr int kUnroll = 2;  // chunks per trip: their loads are issued together
+    // One chunk per trip, and a candidate's RECORD is requested together with its box (round 3): a
+    // region's list holds ~80 ids -- one chunk for each of two wavefronts -- and nearly all of them pass
+    // the box test (the list was made by it, at region granularity), so the stage was a chain of three
+    // dependent L2 round trips (id -> box -> record); now two.
+    constexpr int kUnroll = 1;
     for (int c0 = wave; c0 < round_chunks && stop == round_chunks; c0 += kUnroll * kWaves) {
       TriBox bb[kUnroll];
       int tri[kUnroll];
       bool near[kUnroll];
+      float4 rec_a[kUnroll], rec_b[kUnroll], rec_c[kUnroll], rec_d[kUnroll];
 #pragma unroll
       for (int u = 0; u < kUnroll; ++u) {
         const int c = c0 + u * kWaves;
@@ -937,7 +942,11 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : MR_RASTER
       }
 #pragma unroll
       for (int u = 0; u < kUnroll; ++u) {
-        bb[u] = (tri[u] >= 0) ? img_bbs[tri[u]] : TriBox{0u, 0u, 0.0f, 0u};
+        const int t = max(tri[u], 0);   // (lanes without a candidate read triangle 0 and ignore it)
+        bb[u] = img_bbs[t];
+        const TriRec *rp = img_recs + t;
+        rec_a[u] = rp->a; rec_b[u] = rp->b; rec_c[u] = rp->c; rec_d[u] = rp->d;
+        if (tri[u] < 0) bb[u] = TriBox{0u, 0u, 0.0f, 0u};
       }
 #pragma unroll
       for (int u = 0; u < kUnroll; ++u) {
@@ -951,10 +960,7 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : MR_RASTER
         if (c >= round_chunks || stop != round_chunks) continue;  // wave-uniform
         const int t = tri[u];
         bool pass = false;
-        if (near[u]) {
-          const TriRec *rp = img_recs + t;
-          pass = !rect_outside_triangle(rp->a, rp->b, rp->c.x, rpxlo, rpxhi, rpylo, rpyhi);
-        }
+        if (near[u]) pass = !rect_outside_triangle(rec_a[u], rec_b[u], rec_c[u].x, rpxlo, rpxhi, rpylo, rpyhi);
         const unsigned long long m = __ballot(pass);
         const int cnt = __builtin_popcountll(m);
         if (count + cnt > kSubCap) {  // this wavefront's sub-bin is full
@@ -973,12 +979,11 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : MR_RASTER
                                                                 __builtin_amdgcn_mbcnt_lo((unsigned)m_class, 0u)) |
                                       (far ? 0x80000000u : 0u);
           float *p = s_ent + (wave * kSubCap + count + rank) * kEntryDw;
-          const TriRec *rp = img_recs + t;  // L1/L2-hot: just read by the reject test
-          const float4 q2 = rp->c;
-          *(float4 *)(p) = rp->a;
-          *(float4 *)(p + 4) = rp->b;
+          const float4 q2 = rec_c[u];
+          *(float4 *)(p) = rec_a[u];
+          *(float4 *)(p + 4) = rec_b[u];
           *(float4 *)(p + 8) = make_float4(q2.x, __builtin_bit_cast(float, t), q2.z, q2.w);
-          *(float4 *)(p + 12) = rp->d;
+          *(float4 *)(p + 12) = rec_d[u];
           const int l = (int)(bb[u].lr & 0xffffu), r = (int)(bb[u].lr >> 16);
           const int bt = (int)(bb[u].bt & 0xffffu), tp = (int)(bb[u].bt >> 16);
           // bbox clipped to the region, region-relative: (l | b << 16), (w - 1 | h - 1 << 16)
