@@ -422,8 +422,10 @@ int mr_tone_map(const float *image, int B, size_t elements_per_image, float gamm
  * mode to mr_interpolate_raster_backward and mr_shade_specular_backward (the latter needs the
  * adjacency too).  A contribution that does not fit the fixed-point range (NaN, infinite, beyond
  * 2^63 after scaling) raises a flag and the outputs of that call are NaN instead of a finite wrong
- * number.  Not covered, float atomics remain: the composed interpolation backward
- * (mr_interpolate_backward) and the soft renderer's backward.  mr_l1_loss_forward is always deterministic.  Returns the previous setting. */
+ * number.  mr_soft_backward is covered as well (fixed-point integer atomics into 64-bit copies of its
+ * four vertex outputs, scaled for the 1 / sigma and 1 / gamma its contributions carry; its light
+ * gradients are fixed-order sums in either mode).  Not covered, float atomics remain: the composed
+ * interpolation backward (mr_interpolate_backward, the path for more than 16 attributes).  mr_l1_loss_forward is always deterministic.  Returns the previous setting. */
 int mr_set_deterministic(int on);
 
 /* ---- kernel timing (measurement, no reference counterpart) ----------------------------

@@ -858,6 +858,7 @@ def soft_backward(drgba, rgba, aux, clip, positions, normals, diffuse, triangles
     dlp = torch.empty(B, nl, 3, dtype=torch.float32, device=dev)
     dli = torch.empty(B, nl, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
+        _sync_deterministic()
         need = L.mr_soft_workspace_bytes(B, V, T, W, H)
         ws, have = _workspace(dev, need)
         rc = L.mr_soft_backward(_ptr(drgba), _ptr(rgba), _ptr(aux), _ptr(clip), _ptr(positions),

@@ -32,6 +32,7 @@
 #include "corner_rec.h"
 
 namespace mr {
+extern thread_local int g_deterministic;  // mr_set_deterministic (shade.hip)
 namespace {
 
 constexpr int kThreads = 256;
@@ -381,6 +382,10 @@ constexpr int kLightRow = 16;  // floats per wavefront row of light sums (4 x kM
 #ifndef MR_SOFT_BWD_WAVES
 #define MR_SOFT_BWD_WAVES 1
 #endif
+// DET (mr_set_deterministic, round 3): the 39 sums of a (wavefront, triangle) leave as 64-bit fixed-point
+// integer atomics into int64 copies of the four outputs (det_fixed: dclip [B,V,4], then dnormals,
+// dpositions, ddiffuse [B,V,3] each) instead of float atomics into the outputs; k_soft_from_fixed converts.
+template <bool DET>
 __global__ __launch_bounds__(kThreads, MR_SOFT_BWD_WAVES) void k_soft_backward(
     const SoftRec *__restrict__ recs, const CornerRec *__restrict__ corners,
     const float *__restrict__ lpos, const float *__restrict__ lint, const int32_t *__restrict__ tris,
@@ -388,7 +393,8 @@ __global__ __launch_bounds__(kThreads, MR_SOFT_BWD_WAVES) void k_soft_backward(
     int tiles_per_xcd, const int32_t *__restrict__ cell_ids, const int32_t *__restrict__ cell_count,
     int cells_per_image, const float4 *__restrict__ drgba, const float4 *__restrict__ rgba,
     const float4 *__restrict__ aux, float *__restrict__ dclip, float *__restrict__ dnormals,
-    float *__restrict__ dpositions, float *__restrict__ ddiffuse, float *__restrict__ light_rows) {
+    float *__restrict__ dpositions, float *__restrict__ ddiffuse, float *__restrict__ light_rows,
+    long long *__restrict__ det_fixed, const float *__restrict__ det_scale, int B) {
   __shared__ int s_list[kListCap];
   __shared__ int s_wave_count[kThreads / 64];
   TileGeom g;
@@ -417,6 +423,11 @@ __global__ __launch_bounds__(kThreads, MR_SOFT_BWD_WAVES) void k_soft_backward(
   float *out_base = o_comp < 4 ? dclip : (o_comp < 7 ? dnormals : (o_comp < 10 ? dpositions : ddiffuse));
   const int out_stride = o_comp < 4 ? 4 : 3;
   const int out_off = o_comp < 4 ? o_comp : (o_comp - 4) % 3;
+  // DET: the same element inside the int64 copy (the four arrays back to back)
+  const size_t bv = (size_t)B * V;
+  long long *fixed_base = !DET ? nullptr
+                        : o_comp < 4 ? det_fixed : det_fixed + bv * 4 + (size_t)(o_comp < 7 ? 0 : (o_comp < 10 ? 1 : 2)) * bv * 3;
+  const float to_fixed = DET ? det_scale[0] : 0.0f;
 
   float4 go = make_float4(0.f, 0.f, 0.f, 0.f), out = go, ax = make_float4(0.f, 1.f, 1.f, 0.f);
   if (g.in_image) {
@@ -621,8 +632,11 @@ __global__ __launch_bounds__(kThreads, MR_SOFT_BWD_WAVES) void k_soft_backward(
           for (int j = 0; j < 8; ++j) sum = fmaf(ra[j], rb[j], sum);
         }
         __builtin_amdgcn_wave_barrier();  // the next candidate overwrites the rows
-        if (lane < 39 && sum != 0.0f && (unsigned)my_vertex < (unsigned)V)
-          atomicAdd(out_base + ((size_t)g.img * V + my_vertex) * out_stride + out_off, sum);
+        if (lane < 39 && sum != 0.0f && (unsigned)my_vertex < (unsigned)V) {
+          const size_t at = ((size_t)g.img * V + my_vertex) * out_stride + out_off;
+          if (DET) atomic_add_fixed(fixed_base + at, sum, to_fixed, det_overflow_flag(det_scale));
+          else atomicAdd(out_base + at, sum);
+        }
       }
       n = 0;
       __syncthreads();
@@ -678,6 +692,21 @@ __global__ __launch_bounds__(kLightSumThreads) void k_soft_light_sum(const float
   }
 }
 
+// DET: the int64 sums back to float, array by array (dclip [B,V,4] | dnormals | dpositions | ddiffuse [B,V,3])
+__global__ __launch_bounds__(kThreads) void k_soft_from_fixed(const long long *__restrict__ fixed,
+                                                             const float *__restrict__ det_scale, size_t bv,
+                                                             float *__restrict__ dclip, float *__restrict__ dnormals,
+                                                             float *__restrict__ dpositions, float *__restrict__ ddiffuse) {
+  const size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= bv * 13) return;
+  const float v = *det_overflow_flag(det_scale) ? __int_as_float(0x7fc00000) : (float)fixed[i] * det_scale[1];
+  if (i < bv * 4) dclip[i] = v;
+  else if (i < bv * 7) dnormals[i - bv * 4] = v;
+  else if (i < bv * 10) dpositions[i - bv * 7] = v;
+  else ddiffuse[i - bv * 10] = v;
+}
+inline size_t soft_fixed_bytes(int B, int V) { return align_up((size_t)B * V * 13 * sizeof(long long), 256); }
+
 inline size_t soft_rec_bytes(int B, int T) { return align_up((size_t)B * T * sizeof(SoftRec), 256); }
 
 struct TileGrid {
@@ -718,9 +747,8 @@ static size_t soft_light_rows_bytes(int B, int W, int H) {
 }
 
 size_t soft_ws(int B, int V, int T, int W, int H) {
-  (void)V;
   return soft_rec_bytes(B, T) + align_up((size_t)B * T * sizeof(CornerRec), 256) + cell_ids_bytes(B, T, W, H) +
-         cell_count_bytes(B, W, H) + soft_light_rows_bytes(B, W, H);
+         cell_count_bytes(B, W, H) + soft_light_rows_bytes(B, W, H) + soft_fixed_bytes(B, V) + kDetBlockBytes;
 }
 
 // records, corner attributes and the coarse cell lists: the part the forward and the backward share
@@ -796,12 +824,37 @@ int launch_soft_backward(const float *drgba, const float *rgba, const float *aux
   const TileGrid tg = tile_grid(B, W, H);
   const SoftParams pr{sigma, gamma, blur};
   float *light_rows = (float *)((char *)cell_count + cell_count_bytes(B, W, H));
-  hipLaunchKernelGGL(k_soft_backward, dim3((unsigned)(tg.per_xcd * kXcds)), dim3(kThreads), 0, s, recs,
-                     corners, lpos, lint, tris, V, T, W, H, L, pr, tg.tiles_x, tg.per_image, tg.n_tiles,
-                     tg.per_xcd, cell_ids, cell_count, cell_grid(W, H).per_image, (const float4 *)drgba, (const float4 *)rgba, (const float4 *)aux, dclip,
-                     dnormals, dpositions, ddiffuse, light_rows);
+  long long *det_fixed = (long long *)((char *)light_rows + soft_light_rows_bytes(B, W, H));
+  float *det_block = (float *)((char *)det_fixed + soft_fixed_bytes(B, V));
+  const bool det = g_deterministic != 0;
+  if (det) {
+    // the scale: a contribution carries up to 1 / sigma (or 1 / gamma) over the upstream gradient before the
+    // geometry factors; the fixed point's 2^21 of headroom takes those
+    if (hipMemsetAsync(det_fixed, 0, (size_t)B * V * 13 * sizeof(long long), s) != hipSuccess) return check_launch();
+    const float gain = 1.0f / fminf(fminf(sigma, gamma), 1.0f);
+    const int rcd = launch_det_scale(drgba, (size_t)B * H * W * 4, gain, det_block, s);
+    if (rcd != MR_OK) return rcd;
+    hipLaunchKernelGGL(k_soft_backward<true>, dim3((unsigned)(tg.per_xcd * kXcds)), dim3(kThreads), 0, s, recs,
+                       corners, lpos, lint, tris, V, T, W, H, L, pr, tg.tiles_x, tg.per_image, tg.n_tiles,
+                       tg.per_xcd, cell_ids, cell_count, cell_grid(W, H).per_image, (const float4 *)drgba,
+                       (const float4 *)rgba, (const float4 *)aux, dclip, dnormals, dpositions, ddiffuse, light_rows,
+                       det_fixed, det_block, B);
+  } else {
+    hipLaunchKernelGGL(k_soft_backward<false>, dim3((unsigned)(tg.per_xcd * kXcds)), dim3(kThreads), 0, s, recs,
+                       corners, lpos, lint, tris, V, T, W, H, L, pr, tg.tiles_x, tg.per_image, tg.n_tiles,
+                       tg.per_xcd, cell_ids, cell_count, cell_grid(W, H).per_image, (const float4 *)drgba,
+                       (const float4 *)rgba, (const float4 *)aux, dclip, dnormals, dpositions, ddiffuse, light_rows,
+                       det_fixed, det_block, B);
+  }
   const int rc2 = check_launch();
   if (rc2 != MR_OK) return rc2;
+  if (det) {
+    const size_t n = (size_t)B * V * 13;
+    hipLaunchKernelGGL(k_soft_from_fixed, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
+                       det_fixed, det_block, (size_t)B * V, dclip, dnormals, dpositions, ddiffuse);
+    const int rc3 = check_launch();
+    if (rc3 != MR_OK) return rc3;
+  }
   hipLaunchKernelGGL(k_soft_light_sum, dim3((unsigned)B), dim3(kLightSumThreads), 0, s, light_rows,
                      tg.per_image * (kThreads / 64), L, dlpos, dlint);
   return check_launch();
