@@ -299,8 +299,22 @@ class FusedSpecularPhongRenderer(torch.autograd.Function):
         lp, li = light_positions.detach().contiguous(), light_intensities.detach().contiguous()
         amb = ambient.detach().contiguous() if ambient is not None else None
         cam, shin = camera_position.detach().contiguous(), shininess.detach().contiguous()
-        rgba, norms2 = _native.shade_specular_forward(ids, bary, attrs[0], attrs[1], attrs[2], attrs[3],
-                                                      triangles, lp, li, amb, cam, shin)
+        # The kernels keep four lights in registers.  More (round 3): every light's term -- diffuse and
+        # specular, with its own across-pixels norm -- depends on that light alone, so the image is the
+        # sum of the images of groups of four lights (ambient in the first group), and the gradients
+        # add up the same way in the backward.
+        rgba, norms2 = None, []
+        for first in range(0, lp.shape[1], _native.shade_fast_lights()):
+            last = first + _native.shade_fast_lights()
+            part, part_norms = _native.shade_specular_forward(
+                ids, bary, attrs[0], attrs[1], attrs[2], attrs[3], triangles, lp[:, first:last].contiguous(),
+                li[:, first:last].contiguous(), amb if first == 0 else None, cam, shin)
+            norms2.append(part_norms)
+            if rgba is None:
+                rgba = part
+            else:
+                rgba[..., :3] += part[..., :3]
+        norms2 = norms2[0] if len(norms2) == 1 else torch.cat(norms2, 1)
         offsets, entries = _native.vertex_adjacency(triangles, positions.shape[1])   # cached per mesh
         saved = [clip_d, ids, bary] + attrs + [triangles, lp, li, cam, shin, norms2, offsets, entries]
         if amb is not None:
@@ -316,7 +330,21 @@ class FusedSpecularPhongRenderer(torch.autograd.Function):
         offsets, entries = saved[13:15]
         amb = saved[15] if ctx.has_ambient else None
         # per-vertex gather over the adjacency (round 3): no atomics, every output written once
-        dclip, dn, dp, dd, dsp, dlp, dli, damb, dcam, dshin = _native.shade_specular_backward(
-            drgba.contiguous(), ids, bary, clip, normals, positions, diffuse, specular, triangles, lp, li,
-            amb, cam, shin, norms2, adjacency=(offsets, entries))
+        drgba = drgba.contiguous()
+        step = _native.shade_fast_lights()
+        total = None
+        for first in range(0, lp.shape[1], step):    # groups of four lights: see forward()
+            part = _native.shade_specular_backward(
+                drgba, ids, bary, clip, normals, positions, diffuse, specular, triangles,
+                lp[:, first:first + step].contiguous(), li[:, first:first + step].contiguous(),
+                amb if first == 0 else None, cam, shin, norms2[:, first:first + step].contiguous(),
+                adjacency=(offsets, entries))
+            if total is None:
+                total = list(part)
+                continue
+            for k in (0, 1, 2, 3, 4, 8, 9):          # dclip, dn, dp, dd, dsp, dcam, dshin add up
+                total[k] = total[k] + part[k]
+            total[5] = torch.cat([total[5], part[5]], 1)   # d light_positions / d light_intensities: per light
+            total[6] = torch.cat([total[6], part[6]], 1)
+        dclip, dn, dp, dd, dsp, dlp, dli, damb, dcam, dshin = total
         return dclip, dp, dn, dd, dsp, None, dlp, dli, damb, dcam, dshin, None, None

@@ -145,11 +145,12 @@ def render(vertices, triangles, normals, diffuse_colors, camera_position, camera
 
 
 def _fused_path_applies(vertices, normals, diffuse_colors, light_positions, specular):
-    """The fused HIP shading kernels cover Phong shading on float32 inputs of matching [B,V,3] shape:
-    ambient + diffuse with 1..32 lights, and the specular term (per-image or per-vertex shininess)
-    with 1..4; everything else takes the composed path."""
+    """The fused HIP shading kernels cover Phong shading on float32 inputs of matching [B,V,3] shape
+    with 1..32 lights: ambient + diffuse, and the specular term (per-image or per-vertex shininess;
+    four lights per pass, rasterize_triangles_ext.FusedSpecularPhongRenderer); everything else takes
+    the composed path."""
     from .. import _native
-    limit = _native.shade_fast_lights() if specular else _native.shade_max_lights()
+    limit = _native.shade_max_lights()
     return (USE_FUSED_SHADING and vertices.dtype == torch.float32 and normals.shape == vertices.shape and
             diffuse_colors.shape == vertices.shape and 1 <= light_positions.shape[1] <= limit)
 
