@@ -121,11 +121,25 @@ struct SetupAttributes {
   CornerRec *__restrict__ corners;
 };
 
+// Heaviest regions first (round 3).  k_raster's workgroups cost anything between ~5 us (background)
+// and ~30 us (sphere interior); dispatched in image order, the launch ended with a tail of heavy
+// regions at falling occupancy.  k_coarse files every region of an XCD's range under a weight class
+// -- by the length of its candidate list -- and k_raster's workgroups take the classes heaviest first,
+// so the launch drains on the cheap ones.  Placement only: results do not depend on it.
+constexpr int kWeightClasses = 8;
+__device__ __forceinline__ int region_weight_class(int count) {  // 0 = heaviest; count < 0: the list overflowed
+  if (count < 0 || count >= 256) return 0;
+  if (count == 0) return kWeightClasses - 1;
+  return min(kWeightClasses - 2, 8 - (32 - __builtin_clz((unsigned)count)));  // 128.. -> 1, 64.. -> 2, ..., 1..7 -> 6
+}
+
 __global__ __launch_bounds__(kThreads) void k_setup(
     const float4 *__restrict__ clip, const int32_t *__restrict__ tris, int B, int V, int T,
     int W, int H, TriRec *__restrict__ recs, TriBox *__restrict__ bbs,
-    float *__restrict__ pxtab, float *__restrict__ pytab, const SetupAttributes attrs) {
+    float *__restrict__ pxtab, float *__restrict__ pytab, const SetupAttributes attrs,
+    int32_t *__restrict__ order_count) {
   const long gid = (long)blockIdx.x * kThreads + threadIdx.x;
+  if (gid < kXcds * kWeightClasses) order_count[gid] = 0;  // k_coarse counts into it (a later kernel on the stream)
   const long nbt = (long)B * T;
   const float hw = (float)(0.5 * (double)W);  // cpp:309
   const float hh = (float)(0.5 * (double)H);  // cpp:310
@@ -220,11 +234,13 @@ constexpr int kCellStash = 2048;  // hits of a cell kept in LDS between k_coarse
 __global__ __launch_bounds__(kCoarseThreads) void k_coarse(
     const TriBox *__restrict__ bbs, int T, int W, int H, int cells_x, int cells_per_image, int cell_size,
     int32_t *__restrict__ cell_ids, int32_t *__restrict__ cell_count, float *__restrict__ cell_split,
-    int regions_x, int regions_y, int32_t *__restrict__ region_ids, int32_t *__restrict__ region_count) {
+    int regions_x, int regions_y, int32_t *__restrict__ region_ids, int32_t *__restrict__ region_count,
+    int regions_per_xcd, int32_t *__restrict__ order_count, int32_t *__restrict__ order_list) {
   static_assert(kCoarseThreads / kWave == kCellRegions * kCellRegions, "one wavefront per region of the cell");
   __shared__ float s_wave_lo[kCoarseThreads / kWave], s_wave_hi[kCoarseThreads / kWave];
   __shared__ uint2 s_hit_box[kCellStash];  // (lr, bt) of the cell's first kCellStash hits, for the second level
   __shared__ int32_t s_hit_id[kCellStash];
+  __shared__ int s_order_slot[kCellRegions * kCellRegions], s_order_region[kCellRegions * kCellRegions];
   const int img = (int)blockIdx.x / cells_per_image;
   const int cell = (int)blockIdx.x - img * cells_per_image;
   const int cy = cell / cells_x, cx = cell - cy * cells_x;
@@ -349,8 +365,34 @@ __global__ __launch_bounds__(kCoarseThreads) void k_coarse(
         }
         count += __builtin_popcountll(m);
       }
-      if (lane == 0) region_count[region] = count <= kRegionListCap ? count : -1;
+      if (lane == 0) {
+        region_count[region] = count <= kRegionListCap ? count : -1;
+        // the region's (XCD, weight class) slot, see region_weight_class
+        const int xcd = (int)(region / (size_t)regions_per_xcd);
+        s_order_slot[wave] = xcd * kWeightClasses + region_weight_class(count <= kRegionListCap ? count : -1);
+        s_order_region[wave] = (int)region;
+      }
+    } else if (lane == 0) {
+      s_order_slot[wave] = -1;
     }
+  }
+  // File the cell's regions under their slots with ONE atomic per (cell, slot): one per region put up to
+  // ~700 same-address atomics in a row on an XCD's busiest class (k_coarse 13 -> 50 us).
+  __syncthreads();
+  if (tid < kCellRegions * kCellRegions) {
+    const int slot = s_order_slot[tid];
+    int leader = tid, n = 0, rank = 0;
+    for (int w = 0; w < kCellRegions * kCellRegions; ++w) {
+      if (slot >= 0 && s_order_slot[w] == slot) {
+        leader = min(leader, w);
+        rank += w < tid ? 1 : 0;
+        n += 1;
+      }
+    }
+    int base = 0;
+    if (slot >= 0 && leader == tid) base = atomicAdd(&order_count[slot], n);
+    base = __shfl(base, leader);   // (lanes 0..15 of the first wavefront)
+    if (slot >= 0) order_list[(size_t)slot * regions_per_xcd + base + rank] = s_order_region[tid];
   }
 }
 
@@ -500,7 +542,8 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : MR_RASTER
     const int32_t *__restrict__ cell_ids, const int32_t *__restrict__ cell_count,
     const float *__restrict__ cell_split, int cells_x,
     int cells_per_image, const int32_t *__restrict__ region_ids,
-    const int32_t *__restrict__ region_count, int32_t *__restrict__ ids, float *__restrict__ bary,
+    const int32_t *__restrict__ region_count, const int32_t *__restrict__ order_count,
+    const int32_t *__restrict__ order_list, int32_t *__restrict__ ids, float *__restrict__ bary,
     float *__restrict__ zbuf, const RasterShade shade) {
   static_assert(R == 64 || R == 32, "region edge");
   static_assert(!SHADE || PROBE == 0, "the shading epilogue has no timing probes");
@@ -530,8 +573,22 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : MR_RASTER
   int *s_chunk_count = (int *)s_shared;   // [kRoundChunks]
   int *s_count = s_chunk_count + kRoundChunks, *s_stop = s_count + kWaves, *s_wave_total = s_stop + kWaves;
 
-  const int region = xcd_contiguous_block((int)blockIdx.x, n_regions, regions_per_xcd);
-  if (region < 0) return;  // padding block (whole workgroup)
+  // Hardware block b runs on XCD b % 8 (round-robin dispatch) and is the (b / 8)-th workgroup there:
+  // it takes the (b / 8)-th region of that XCD's range in weight-class order, heaviest class first.
+  int region;
+  {
+    const int xcd = (int)blockIdx.x % kXcds;
+    int pos = (int)blockIdx.x / kXcds;
+    if (xcd * regions_per_xcd + pos >= n_regions || pos >= regions_per_xcd) return;  // padding block (whole workgroup)
+    const int32_t *counts = order_count + xcd * kWeightClasses;
+    int cls = 0;
+#pragma unroll
+    for (int c = 0; c < kWeightClasses - 1; ++c) {
+      const int n = counts[c];   // wave-uniform scalar loads
+      if (cls == c && pos >= n) { pos -= n; cls = c + 1; }
+    }
+    region = order_list[(size_t)(xcd * kWeightClasses + cls) * regions_per_xcd + pos];
+  }
   const int img = region / regions_per_image;
   const int rr = region - img * regions_per_image;
   const int ry = rr / regions_x;
@@ -1104,7 +1161,8 @@ size_t raster_forward_ws(int B, int V, int T, int W, int H) {
   return align_up(nbt * sizeof(TriRec), 256) + align_up(nbt * sizeof(TriBox), 256) +
          align_up((size_t)W * sizeof(float), 256) + align_up((size_t)H * sizeof(float), 256) +
          align_up(cells * T * sizeof(int32_t), 256) + 2 * align_up(cells * sizeof(int32_t), 256) +
-         align_up(regions * kRegionListCap * sizeof(int32_t), 256) + align_up(regions * sizeof(int32_t), 256);
+         align_up(regions * kRegionListCap * sizeof(int32_t), 256) + align_up(regions * sizeof(int32_t), 256) +
+         256 + align_up((size_t)kXcds * kWeightClasses * ((regions + kXcds - 1) / kXcds) * sizeof(int32_t), 256);
 }
 
 #ifdef MR_PROBES
@@ -1118,7 +1176,7 @@ struct RasterArgs {
   const int32_t *cell_ids, *cell_count;
   const float *cell_split;
   int cells_x, cells_per_image;
-  const int32_t *region_ids, *region_count;
+  const int32_t *region_ids, *region_count, *order_count, *order_list;
   int32_t *ids; float *bary, *z;
   RasterShade shade;  // rgba == nullptr: G-buffer only
 };
@@ -1127,8 +1185,8 @@ template <int R, int PROBE, bool SHADE = false>
 void launch_k_raster(const RasterArgs &a, dim3 grid, hipStream_t s) {
   hipLaunchKernelGGL((k_raster<R, PROBE, SHADE>), grid, dim3(kThreads), 0, s, a.recs, a.bbs, a.pxtab, a.pytab, a.T,
                      a.W, a.H, a.regions_x, a.per_image, a.n_regions, a.per_xcd, a.cell_ids, a.cell_count,
-                     a.cell_split, a.cells_x, a.cells_per_image, a.region_ids, a.region_count, a.ids, a.bary, a.z,
-                     a.shade);
+                     a.cell_split, a.cells_x, a.cells_per_image, a.region_ids, a.region_count, a.order_count,
+                     a.order_list, a.ids, a.bary, a.z, a.shade);
 }
 
 template <int R>
@@ -1181,25 +1239,29 @@ int raster_forward(const float *clip, const int32_t *tris, int B, int V, int T, 
   int32_t *region_ids = (int32_t *)p;
   p += align_up((size_t)n_regions * kRegionListCap * sizeof(int32_t), 256);
   int32_t *region_count = (int32_t *)p;
+  p += align_up((size_t)n_regions * sizeof(int32_t), 256);
+  const int per_xcd = (n_regions + kXcds - 1) / kXcds;
+  int32_t *order_count = (int32_t *)p;   // [kXcds][kWeightClasses]
+  p += 256;
+  int32_t *order_list = (int32_t *)p;    // [kXcds][kWeightClasses][per_xcd]
 
   const long setup_threads = (long)nbt + W + H;
   const unsigned setup_blocks = (unsigned)((setup_threads + kThreads - 1) / kThreads);
   hipLaunchKernelGGL(k_setup, dim3(setup_blocks), dim3(kThreads), 0, s, (const float4 *)clip, tris,
-                     B, V, T, W, H, recs, bbs, pxtab, pytab, attrs);
+                     B, V, T, W, H, recs, bbs, pxtab, pytab, attrs, order_count);
   int rc = check_launch();
   if (rc != MR_OK) return rc;
   if (B == 0) return MR_OK;
   hipLaunchKernelGGL(k_coarse, dim3((unsigned)(cells_per_image * B)), dim3(kCoarseThreads), 0, s, bbs, T,
                      W, H, cells_x, cells_per_image, cell, cell_ids, cell_count, cell_split, regions_x, regions_y,
-                     region_ids, region_count);
+                     region_ids, region_count, per_xcd, order_count, order_list);
   rc = check_launch();
   if (rc != MR_OK) return rc;
 
-  const int per_xcd = (n_regions + kXcds - 1) / kXcds;
   const dim3 grid((unsigned)(per_xcd * kXcds));
   const RasterArgs args{recs, bbs, pxtab, pytab, T, W, H, regions_x, per_image, n_regions, per_xcd,
                         cell_ids, cell_count, cell_split, cells_x, cells_per_image, region_ids, region_count,
-                        ids, bary, z, shade};
+                        order_count, order_list, ids, bary, z, shade};
   {
     KernelTimer timer(MR_TIMER_RASTER_FORWARD, s);  // records only when a caller armed it
     if (edge == 32) launch_k_raster_probe<32>(args, grid, s);
