@@ -851,12 +851,16 @@ def soft_backward(drgba, rgba, aux, clip, positions, normals, diffuse, triangles
     B, V, _ = clip.shape
     T, nl = triangles.shape[0], light_positions.shape[1]
     _, H, W, _ = rgba.shape
-    dclip = torch.empty(B, V, 4, dtype=torch.float32, device=dev)
-    dp = torch.empty(B, V, 3, dtype=torch.float32, device=dev)
-    dn = torch.empty(B, V, 3, dtype=torch.float32, device=dev)
-    dd = torch.empty(B, V, 3, dtype=torch.float32, device=dev)
-    dlp = torch.empty(B, nl, 3, dtype=torch.float32, device=dev)
-    dli = torch.empty(B, nl, dtype=torch.float32, device=dev)
+    # one allocation, laid out back to back (dclip, dpositions, dnormals, ddiffuse, dlight_positions,
+    # dlight_intensities): the library then zeroes all six with one memset instead of six launches
+    n4, n3, nl3 = B * V * 4, B * V * 3, B * nl * 3
+    flat = torch.empty(n4 + 3 * n3 + nl3 + B * nl, dtype=torch.float32, device=dev)
+    dclip = flat[:n4].view(B, V, 4)
+    dp = flat[n4:n4 + n3].view(B, V, 3)
+    dn = flat[n4 + n3:n4 + 2 * n3].view(B, V, 3)
+    dd = flat[n4 + 2 * n3:n4 + 3 * n3].view(B, V, 3)
+    dlp = flat[n4 + 3 * n3:n4 + 3 * n3 + nl3].view(B, nl, 3)
+    dli = flat[n4 + 3 * n3 + nl3:].view(B, nl)
     with torch.cuda.device(dev):
         _sync_deterministic()
         need = L.mr_soft_workspace_bytes(B, V, T, W, H)
