@@ -325,6 +325,12 @@ int mr_soft_forward(const float *clip, const float *positions, const float *norm
                     int B, int V, int T, int W, int H, int L,
                     float sigma, float gamma, float blur, float *rgba, float *aux,
                     void *workspace, size_t workspace_bytes, void *stream);
+/* mr_soft_forward leaves its per-triangle records and candidate lists in the first
+ * mr_soft_prepared_bytes() of its workspace.  A caller that keeps that workspace untouched until the
+ * backward pass of the SAME inputs and sizes hands it over as `prepared` and the backward does not
+ * rebuild them (three launches); prepared = NULL rebuilds them in `workspace`.  The forward itself is
+ * content with a workspace of mr_soft_prepared_bytes(); the backward wants mr_soft_workspace_bytes(). */
+size_t mr_soft_prepared_bytes(int B, int V, int T, int W, int H);
 /* All gradient outputs are zeroed here.  drgba [B,H,W,4]; dclip [B,V,4];
  * dpositions / dnormals / ddiffuse [B,V,3]; dlight_positions [B,L,3]; dlight_intensities [B,L]. */
 int mr_soft_backward(const float *drgba, const float *rgba, const float *aux,
@@ -334,7 +340,7 @@ int mr_soft_backward(const float *drgba, const float *rgba, const float *aux,
                      int B, int V, int T, int W, int H, int L,
                      float sigma, float gamma, float blur,
                      float *dclip, float *dpositions, float *dnormals, float *ddiffuse,
-                     float *dlight_positions, float *dlight_intensities,
+                     float *dlight_positions, float *dlight_intensities, const void *prepared,
                      void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- mean-absolute-error image loss --------------------------------------------------

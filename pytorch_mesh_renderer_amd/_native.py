@@ -16,7 +16,7 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 # build libmesh_raster_hip_probes.so this way); the product always loads the in-tree library.
 LIB_PATH = os.environ.get("MR_NATIVE_LIB_PATH") or os.path.join(_CSRC, "libmesh_raster_hip.so")
 
-ABI_VERSION = 340
+ABI_VERSION = 341
 TIMER_RASTER_FORWARD, TIMER_SHADE_BACKWARD, TIMER_SHADE_FORWARD, TIMER_RASTER_BACKWARD, TIMER_L1_FORWARD = 0, 1, 2, 3, 4
 MR_OK, MR_EINVAL, MR_EWORKSPACE, MR_ELAUNCH = 0, -1, -2, -3
 _ERR = {MR_EINVAL: "invalid argument", MR_EWORKSPACE: "workspace too small or misaligned",
@@ -150,7 +150,9 @@ def lib():
         cf = ctypes.c_float
         L.mr_soft_forward.argtypes = [vp] * 7 + [ci] * 6 + [cf] * 3 + [vp, vp, vp, sz, vp]
         L.mr_soft_forward.restype = ci
-        L.mr_soft_backward.argtypes = [vp] * 10 + [ci] * 6 + [cf] * 3 + [vp] * 6 + [vp, sz, vp]
+        L.mr_soft_prepared_bytes.argtypes = [ci] * 5
+        L.mr_soft_prepared_bytes.restype = sz
+        L.mr_soft_backward.argtypes = [vp] * 10 + [ci] * 6 + [cf] * 3 + [vp] * 6 + [vp, vp, sz, vp]
         L.mr_soft_backward.restype = ci
         fp = vp
         L.mr_camera_transforms.argtypes = [fp, fp, fp, fp, fp, fp, ctypes.c_float, ci, fp, vp, vp]
@@ -801,8 +803,12 @@ def soft_max_lights():
 
 
 def soft_forward(clip, positions, normals, diffuse, triangles, light_positions, light_intensities,
-                 width, height, sigma, gamma, blur):
-    """SoftRas forward: -> (rgba [B,H,W,4] with row 0 = top, aux [B,H,W,4] for the backward)."""
+                 width, height, sigma, gamma, blur, keep_prepared=False):
+    """SoftRas forward: -> (rgba [B,H,W,4] with row 0 = top, aux [B,H,W,4] for the backward).
+
+    keep_prepared=True runs in a workspace of its own and returns it as a third value: handed to
+    soft_backward(prepared=...) for the same inputs, the per-triangle records and candidate lists the
+    forward built there are not built again."""
     tensors = [clip, positions, normals, diffuse, triangles, light_positions, light_intensities]
     B, V, _ = _chk_mesh(clip, triangles)
     for name, t in (("positions", positions), ("normals", normals), ("diffuse colors", diffuse)):
@@ -821,19 +827,27 @@ def soft_forward(clip, positions, normals, diffuse, triangles, light_positions, 
     aux = torch.empty(B, height, width, 4, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         need = L.mr_soft_workspace_bytes(B, V, T, width, height)
-        ws, have = _workspace(dev, need)
+        if keep_prepared:
+            ws = torch.empty(max(int(L.mr_soft_prepared_bytes(B, V, T, width, height)), 256),
+                             dtype=torch.uint8, device=dev)
+            have = ws.numel()
+        else:
+            ws, have = _workspace(dev, need)
         rc = L.mr_soft_forward(_ptr(clip), _ptr(positions), _ptr(normals), _ptr(diffuse), _ptr(triangles),
                                _ptr(light_positions), _ptr(light_intensities), B, V, T, width, height, nl,
                                float(sigma), float(gamma), float(blur), _ptr(rgba), _ptr(aux), _ptr(ws),
                                have, _stream(dev))
     _check(rc, "mr_soft_forward")
+    if keep_prepared:
+        return rgba, aux, ws
     return rgba, aux
 
 
 def soft_backward(drgba, rgba, aux, clip, positions, normals, diffuse, triangles, light_positions,
-                  light_intensities, sigma, gamma, blur):
+                  light_intensities, sigma, gamma, blur, prepared=None):
     """-> (dclip [B,V,4], dpositions, dnormals, ddiffuse [B,V,3], dlight_positions [B,L,3],
-    dlight_intensities [B,L])."""
+    dlight_intensities [B,L]).  prepared: the third value of soft_forward(keep_prepared=True) for the
+    same inputs, or None."""
     tensors = [drgba, rgba, aux, clip, positions, normals, diffuse, triangles, light_positions,
                light_intensities]
     B, V, _ = _chk_mesh(clip, triangles)
@@ -863,13 +877,18 @@ def soft_backward(drgba, rgba, aux, clip, positions, normals, diffuse, triangles
     dli = flat[n4 + 3 * n3 + nl3:].view(B, nl)
     with torch.cuda.device(dev):
         _sync_deterministic()
+        if prepared is not None and (prepared.device != dev or prepared.dtype != torch.uint8 or
+                                     prepared.numel() < L.mr_soft_prepared_bytes(B, V, T, W, H)):
+            raise ValueError("prepared must be the workspace soft_forward(keep_prepared=True) returned "
+                             "for these sizes")
         need = L.mr_soft_workspace_bytes(B, V, T, W, H)
         ws, have = _workspace(dev, need)
         rc = L.mr_soft_backward(_ptr(drgba), _ptr(rgba), _ptr(aux), _ptr(clip), _ptr(positions),
                                 _ptr(normals), _ptr(diffuse), _ptr(triangles), _ptr(light_positions),
                                 _ptr(light_intensities), B, V, T, W, H, nl, float(sigma), float(gamma),
                                 float(blur), _ptr(dclip), _ptr(dp), _ptr(dn), _ptr(dd), _ptr(dlp),
-                                _ptr(dli), _ptr(ws), have, _stream(dev))
+                                _ptr(dli), _ptr(prepared) if prepared is not None else None, _ptr(ws), have,
+                                _stream(dev))
     _check(rc, "mr_soft_backward")
     return dclip, dp, dn, dd, dlp, dli
 

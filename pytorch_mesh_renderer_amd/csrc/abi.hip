@@ -31,7 +31,7 @@ extern thread_local int g_shade_backward_kernel;
 
 extern "C" {
 
-int mr_version(void) { return 340; /* 0.4.0: NULL attribute gradients, many lights, camera transforms, adjacency for the specular backward, wider deterministic mode */ }
+int mr_version(void) { return 341; /* 0.4.0: NULL attribute gradients, many lights, camera transforms, adjacency for the specular backward, wider deterministic mode */ }
 
 int mr_last_hip_error(void) { return mr::g_last_hip_error; }
 
@@ -387,6 +387,11 @@ size_t mr_soft_workspace_bytes(int B, int V, int T, int W, int H) {
   return mr::soft_ws(B, V, T, W, H);
 }
 
+size_t mr_soft_prepared_bytes(int B, int V, int T, int W, int H) {
+  if (bad_dims(B, V, T, W, H)) return 0;
+  return mr::soft_prepared_bytes(B, V, T, W, H);
+}
+
 int mr_soft_forward(const float *clip, const float *positions, const float *normals,
                     const float *diffuse, const int32_t *triangles, const float *light_positions,
                     const float *light_intensities, int B, int V, int T, int W, int H, int L,
@@ -397,7 +402,7 @@ int mr_soft_forward(const float *clip, const float *positions, const float *norm
   if (B == 0) return MR_OK;
   if (!rgba || !aux || !light_positions || !light_intensities) return MR_EINVAL;
   if (T > 0 && (!clip || !positions || !normals || !diffuse || !triangles)) return MR_EINVAL;
-  const int rc = check_ws(workspace, workspace_bytes, mr::soft_ws(B, V, T, W, H));
+  const int rc = check_ws(workspace, workspace_bytes, mr::soft_prepared_bytes(B, V, T, W, H));  // the head is all it uses
   if (rc != MR_OK) return rc;
   return mr::launch_soft_forward(clip, positions, normals, diffuse, triangles, light_positions,
                                  light_intensities, B, V, T, W, H, L, sigma, gamma, blur, rgba, aux,
@@ -410,7 +415,8 @@ int mr_soft_backward(const float *drgba, const float *rgba, const float *aux, co
                      const float *light_intensities, int B, int V, int T, int W, int H, int L,
                      float sigma, float gamma, float blur, float *dclip, float *dpositions,
                      float *dnormals, float *ddiffuse, float *dlight_positions,
-                     float *dlight_intensities, void *workspace, size_t workspace_bytes, void *stream) {
+                     float *dlight_intensities, const void *prepared, void *workspace, size_t workspace_bytes,
+                     void *stream) {
   if (bad_dims(B, V, T, W, H) || L < 1 || L > mr::soft_max_lights() || !(sigma > 0.f) || !(gamma > 0.f))
     return MR_EINVAL;
   if (B == 0) return MR_OK;
@@ -425,7 +431,7 @@ int mr_soft_backward(const float *drgba, const float *rgba, const float *aux, co
   return mr::launch_soft_backward(drgba, rgba, aux, clip, positions, normals, diffuse, triangles,
                                   light_positions, light_intensities, B, V, T, W, H, L, sigma, gamma,
                                   blur, dclip, dpositions, dnormals, ddiffuse, dlight_positions,
-                                  dlight_intensities, workspace, (hipStream_t)stream);
+                                  dlight_intensities, prepared, workspace, (hipStream_t)stream);
 }
 
 int mr_l1_loss_partials(void) { return MR_L1_PARTIALS; }

@@ -183,6 +183,7 @@ int launch_tone_map(const float *image, int B, size_t per_image, float gamma, in
                     uint8_t *out_u8, hipStream_t s);
 int soft_max_lights();
 size_t soft_ws(int B, int V, int T, int W, int H);
+size_t soft_prepared_bytes(int B, int V, int T, int W, int H);
 int launch_soft_forward(const float *clip, const float *positions, const float *normals,
                         const float *diffuse, const int32_t *tris, const float *lpos,
                         const float *lint, int B, int V, int T, int W, int H, int L, float sigma,
@@ -192,6 +193,6 @@ int launch_soft_backward(const float *drgba, const float *rgba, const float *aux
                          const int32_t *tris, const float *lpos, const float *lint, int B, int V, int T,
                          int W, int H, int L, float sigma, float gamma, float blur, float *dclip,
                          float *dpositions, float *dnormals, float *ddiffuse, float *dlpos, float *dlint,
-                         void *ws, hipStream_t s);
+                         const void *prepared, void *ws, hipStream_t s);
 
 }  // namespace mr

@@ -751,12 +751,16 @@ size_t soft_ws(int B, int V, int T, int W, int H) {
          cell_count_bytes(B, W, H) + soft_light_rows_bytes(B, W, H) + soft_fixed_bytes(B, V) + kDetBlockBytes;
 }
 
-// records, corner attributes and the coarse cell lists: the part the forward and the backward share
-static int soft_prepare(const float *clip, const float *positions, const float *normals, const float *diffuse,
-                        const int32_t *tris, int B, int V, int T, int W, int H, float blur, void *ws,
-                        SoftRec *&recs, CornerRec *&corners, int32_t *&cell_ids, int32_t *&cell_count,
-                        hipStream_t s) {
-  char *p = (char *)ws;
+// the head of the workspace: what soft_prepare() leaves there and both passes read
+size_t soft_prepared_bytes(int B, int V, int T, int W, int H) {
+  (void)V;
+  return soft_rec_bytes(B, T) + align_up((size_t)B * T * sizeof(CornerRec), 256) + cell_ids_bytes(B, T, W, H) +
+         cell_count_bytes(B, W, H);
+}
+
+static void soft_prepared_layout(void *head, int B, int T, int W, int H, SoftRec *&recs, CornerRec *&corners,
+                                 int32_t *&cell_ids, int32_t *&cell_count) {
+  char *p = (char *)head;
   recs = (SoftRec *)p;
   p += soft_rec_bytes(B, T);
   corners = (CornerRec *)p;
@@ -764,6 +768,14 @@ static int soft_prepare(const float *clip, const float *positions, const float *
   cell_ids = (int32_t *)p;
   p += cell_ids_bytes(B, T, W, H);
   cell_count = (int32_t *)p;
+}
+
+// records, corner attributes and the coarse cell lists: the part the forward and the backward share
+static int soft_prepare(const float *clip, const float *positions, const float *normals, const float *diffuse,
+                        const int32_t *tris, int B, int V, int T, int W, int H, float blur, void *ws,
+                        SoftRec *&recs, CornerRec *&corners, int32_t *&cell_ids, int32_t *&cell_count,
+                        hipStream_t s) {
+  soft_prepared_layout(ws, B, T, W, H, recs, corners, cell_ids, cell_count);
   const CellGrid cg = cell_grid(W, H);
   const long nbt = (long)B * T;
   if (nbt > 0) {
@@ -803,7 +815,7 @@ int launch_soft_backward(const float *drgba, const float *rgba, const float *aux
                          const int32_t *tris, const float *lpos, const float *lint, int B, int V, int T,
                          int W, int H, int L, float sigma, float gamma, float blur, float *dclip,
                          float *dpositions, float *dnormals, float *ddiffuse, float *dlpos, float *dlint,
-                         void *ws, hipStream_t s) {
+                         const void *prepared, void *ws, hipStream_t s) {
   if (B == 0) return MR_OK;
   const size_t v3 = (size_t)B * V * 3 * sizeof(float), v4 = (size_t)B * V * 4 * sizeof(float);
   const size_t l3 = (size_t)B * L * 3 * sizeof(float), l1 = (size_t)B * L * sizeof(float);
@@ -827,12 +839,18 @@ int launch_soft_backward(const float *drgba, const float *rgba, const float *aux
   SoftRec *recs;
   CornerRec *corners;
   int32_t *cell_ids, *cell_count;
-  const int rc = soft_prepare(clip, positions, normals, diffuse, tris, B, V, T, W, H, blur, ws, recs, corners,
-                              cell_ids, cell_count, s);
-  if (rc != MR_OK) return rc;
+  if (prepared) {
+    // the forward pass of the same inputs left these (mr_soft_prepared_bytes at the head of ITS workspace):
+    // three launches (~30 us of a 1 ms step) are not repeated
+    soft_prepared_layout(const_cast<void *>(prepared), B, T, W, H, recs, corners, cell_ids, cell_count);
+  } else {
+    const int rc = soft_prepare(clip, positions, normals, diffuse, tris, B, V, T, W, H, blur, ws, recs, corners,
+                                cell_ids, cell_count, s);
+    if (rc != MR_OK) return rc;
+  }
   const TileGrid tg = tile_grid(B, W, H);
   const SoftParams pr{sigma, gamma, blur};
-  float *light_rows = (float *)((char *)cell_count + cell_count_bytes(B, W, H));
+  float *light_rows = (float *)((char *)ws + soft_prepared_bytes(B, V, T, W, H));
   long long *det_fixed = (long long *)((char *)light_rows + soft_light_rows_bytes(B, W, H));
   float *det_block = (float *)((char *)det_fixed + soft_fixed_bytes(B, V));
   const bool det = g_deterministic != 0;

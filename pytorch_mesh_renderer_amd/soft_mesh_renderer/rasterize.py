@@ -17,9 +17,13 @@ class SoftRasterizer(torch.autograd.Function):
                 image_width, image_height, sigma_val, gamma_val, blur_radius):
         args = [t.detach().contiguous() for t in (clip, positions, normals, diffuse)]
         lp, li = light_positions.detach().contiguous(), light_intensities.detach().contiguous()
-        rgba, aux = _native.soft_forward(args[0], args[1], args[2], args[3], triangles, lp, li,
-                                         int(image_width), int(image_height), float(sigma_val),
-                                         float(gamma_val), float(blur_radius))
+        # with a backward pass to come the forward keeps its records and candidate lists for it
+        keep = any(ctx.needs_input_grad)
+        out = _native.soft_forward(args[0], args[1], args[2], args[3], triangles, lp, li,
+                                   int(image_width), int(image_height), float(sigma_val),
+                                   float(gamma_val), float(blur_radius), keep_prepared=keep)
+        rgba, aux = out[0], out[1]
+        ctx.prepared = out[2] if keep else None
         ctx.save_for_backward(rgba, aux, args[0], args[1], args[2], args[3], triangles, lp, li)
         ctx.params = (float(sigma_val), float(gamma_val), float(blur_radius))
         return rgba
@@ -30,7 +34,7 @@ class SoftRasterizer(torch.autograd.Function):
         sigma, gamma, blur = ctx.params
         dclip, dp, dn, dd, dlp, dli = _native.soft_backward(
             drgba.contiguous(), rgba, aux, clip, positions, normals, diffuse, triangles, lp, li,
-            sigma, gamma, blur)
+            sigma, gamma, blur, prepared=ctx.prepared)
         return dclip, dp, dn, dd, None, dlp, dli, None, None, None, None, None
 
 

@@ -141,3 +141,40 @@ def test_soft_backward_deterministic_mode_is_bit_reproducible(device):
         assert torch.equal(a, b), "output %d differs between two deterministic runs" % i
         scale = float(d.abs().max())
         np.testing.assert_allclose(a.cpu().numpy(), d.cpu().numpy(), atol=1e-4 * scale, rtol=1e-3, err_msg=str(i))
+
+
+def test_soft_backward_with_the_forward_pass_s_prepared_records(device):
+    """Round 3: the autograd path hands the forward's records / candidate lists to the backward
+    (mr_soft_prepared_bytes, `prepared`).  In deterministic mode the gradients are bit-identical to the
+    ones of a backward that rebuilds them (prepared = NULL), also after other SoftRas calls have run in
+    between (the kept workspace is private to the forward call)."""
+    from pytorch_mesh_renderer_amd import _native
+    from pytorch_mesh_renderer_amd.common import synthetic
+    g = torch.Generator().manual_seed(11)
+    job = synthetic.sphere_job(2, 96, 80, 20)
+    V = job["vertices"].shape[1]
+    pos = job["vertices"].to(device)
+    clip = torch.cat([pos[..., :2] * 0.8, pos[..., 2:] * 0.1 + 0.5, torch.ones(2, V, 1, device=device) * 1.1], -1).contiguous()
+    nrm = torch.nn.functional.normalize(pos, dim=-1).contiguous()
+    dif = torch.rand(2, V, 3, generator=g).to(device)
+    tris = job["triangles"].to(device)
+    lp = torch.tensor([[[0.0, 3.0, 3.0]], [[2.0, 1.0, 3.0]]], device=device)
+    li = torch.ones(2, 1, device=device)
+    args = (clip, pos, nrm, dif, tris, lp, li)
+    before = _native.set_deterministic(True)
+    try:
+        rgba, aux, kept = _native.soft_forward(*args, 96, 80, 1e-3, 1e-2, 0.02, keep_prepared=True)
+        rgba2, aux2 = _native.soft_forward(*args, 96, 80, 1e-3, 1e-2, 0.02)
+        assert torch.equal(rgba, rgba2) and torch.equal(aux, aux2)
+        drgba = torch.rand(2, 80, 96, 4, generator=g).to(device)
+        # another size in between: the shared workspace is rewritten, the kept one is not
+        _native.soft_forward(clip[:1], pos[:1], nrm[:1], dif[:1], tris, lp[:1], li[:1], 64, 64, 1e-3, 1e-2, 0.05)
+        with_kept = _native.soft_backward(drgba, rgba, aux, *args, 1e-3, 1e-2, 0.02, prepared=kept)
+        rebuilt = _native.soft_backward(drgba, rgba, aux, *args, 1e-3, 1e-2, 0.02)
+    finally:
+        _native.set_deterministic(before)
+    for i, (a, b) in enumerate(zip(with_kept, rebuilt)):
+        assert float(a.abs().max()) > 0, i
+        assert torch.equal(a, b), i
+    with pytest.raises(ValueError):
+        _native.soft_backward(drgba, rgba, aux, *args, 1e-3, 1e-2, 0.02, prepared=kept[:1000])
