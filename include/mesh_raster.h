@@ -376,14 +376,14 @@ int mr_export_u8(const float *image, size_t n, uint8_t *out, void *stream);
  * see mr_shade_backward): no atomics, fixed summation order.  Triangles with a vertex id outside
  * [0, V) are skipped.
  *   vertices [B,V,3] f32;  sums [B,V,3] f32 out (the un-normalised sums, input of the backward);
- *   normals [B,V,3] f32 out;  backward: dnormals in, dsums [B,V,3] scratch, dvertices [B,V,3] out. */
+ *   normals [B,V,3] f32 out;  backward: dnormals in, dvertices [B,V,3] out. */
 int mr_vertex_normals_forward(const float *vertices, const int32_t *triangles,
                               const int32_t *vertex_offsets, const int32_t *vertex_entries, int B, int V,
                               int T, float *sums, float *normals, void *stream);
 int mr_vertex_normals_backward(const float *dnormals, const float *vertices, const float *sums,
                                const int32_t *triangles, const int32_t *vertex_offsets,
-                               const int32_t *vertex_entries, int B, int V, int T, float *dsums,
-                               float *dvertices, void *stream);
+                               const int32_t *vertex_entries, int B, int V, int T, float *dvertices,
+                               void *stream);
 
 /* ---- clip-space transforms --------------------------------------------------------------
  * perspective(aspect, fov_y, near, far) . look_at(eye, center, up) per image, the product render() and

@@ -192,7 +192,7 @@ def lib():
         L.mr_tone_map.restype = ci
         L.mr_vertex_normals_forward.argtypes = [vp] * 4 + [ci] * 3 + [vp, vp, vp]
         L.mr_vertex_normals_forward.restype = ci
-        L.mr_vertex_normals_backward.argtypes = [vp] * 6 + [ci] * 3 + [vp, vp, vp]
+        L.mr_vertex_normals_backward.argtypes = [vp] * 6 + [ci] * 3 + [vp, vp]
         L.mr_vertex_normals_backward.restype = ci
         _lib = L
     return _lib
@@ -984,10 +984,10 @@ def vertex_normals_backward(dnormals, vertices, sums, triangles, adjacency=None)
     dev = _require_device(dnormals, vertices, sums, triangles)
     dnormals, vertices, sums, triangles = [t.contiguous() for t in (dnormals, vertices, sums, triangles)]
     offsets, entries = adjacency if adjacency is not None else vertex_adjacency(triangles, V)
-    dsums, dvertices = torch.empty_like(vertices), torch.empty_like(vertices)
+    dvertices = torch.empty_like(vertices)
     with torch.cuda.device(dev):
         rc = lib().mr_vertex_normals_backward(_ptr(dnormals), _ptr(vertices), _ptr(sums), _ptr(triangles),
-                                              _ptr(offsets), _ptr(entries), B, V, triangles.shape[0], _ptr(dsums),
+                                              _ptr(offsets), _ptr(entries), B, V, triangles.shape[0],
                                               _ptr(dvertices), _stream(dev))
     _check(rc, "mr_vertex_normals_backward")
     return dvertices

@@ -484,15 +484,15 @@ int mr_vertex_normals_forward(const float *vertices, const int32_t *triangles,
 
 int mr_vertex_normals_backward(const float *dnormals, const float *vertices, const float *sums,
                                const int32_t *triangles, const int32_t *vertex_offsets,
-                               const int32_t *vertex_entries, int B, int V, int T, float *dsums,
-                               float *dvertices, void *stream) {
+                               const int32_t *vertex_entries, int B, int V, int T, float *dvertices,
+                               void *stream) {
   if (B < 0 || V < 0 || T < 0) return MR_EINVAL;
   if (B == 0 || V == 0) return MR_OK;
-  if (!dnormals || !vertices || !sums || !vertex_offsets || !dsums || !dvertices ||
+  if (!dnormals || !vertices || !sums || !vertex_offsets || !dvertices ||
       (T > 0 && (!triangles || !vertex_entries)))
     return MR_EINVAL;
   return mr::launch_vertex_normals_backward(dnormals, vertices, sums, triangles, vertex_offsets,
-                                            vertex_entries, B, V, dsums, dvertices, (hipStream_t)stream);
+                                            vertex_entries, B, V, dvertices, (hipStream_t)stream);
 }
 
 int mr_tone_map(const float *image, int B, size_t elements_per_image, float gamma, int32_t *max_scratch,

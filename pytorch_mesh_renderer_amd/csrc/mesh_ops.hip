@@ -3,10 +3,10 @@
 //
 // The reference adds, for every triangle and each of its corners o (with a, b the next two
 // corners), the area-weighted face normal (a - o) x (b - o) to vertex o with index_add_ and
-// normalises the sums (eps 1e-6).  Here one thread owns one (image, vertex): it walks the
+// normalises the sums (eps 1e-6).  Here eight lanes own one (image, vertex): they walk the
 // vertex's incident (triangle, corner) pairs in the CSR adjacency that the renderer already keeps
-// per triangle array, evaluates the corner's own cross product (the reference's three expressions
-// differ in rounding; each corner uses its own) and sums in adjacency order: no atomics, every
+// per triangle array, evaluate each corner's own cross product (the reference's three expressions
+// differ in rounding; each corner uses its own) and sum in a fixed order: no atomics, every
 // output written once, bitwise reproducible.  The backward is the same walk with the three
 // cross products' derivatives gathered at the vertex.
 #include "mr_internal.h"
@@ -34,67 +34,90 @@ __device__ __forceinline__ bool load_triangle(const int32_t *tris, int t, int V,
   return (unsigned)idx[0] < (unsigned)V && (unsigned)idx[1] < (unsigned)V && (unsigned)idx[2] < (unsigned)V;
 }
 
+// Eight lanes per (image, vertex), one incident (triangle, corner) pair each (a second trip for valence
+// > 8): the walk is three dependent loads per pair (entry -> triangle -> corners), and with one thread per
+// vertex those chains ran one after the other at under one wavefront per SIMD -- 21 + 5 + 29 us for 41k
+// vertices (SoftRas config 5), all of it latency.  The partial sums meet in a fixed butterfly over the
+// eight lanes: still no atomics, every output written once, bitwise reproducible.
+constexpr int kLanesPerVertex = 8;
+
+__device__ __forceinline__ V3 sum_over_vertex_lanes(V3 s) {
+#pragma unroll
+  for (int m = 1; m < kLanesPerVertex; m <<= 1) {
+    s.x += __shfl_xor(s.x, m, kLanesPerVertex);
+    s.y += __shfl_xor(s.y, m, kLanesPerVertex);
+    s.z += __shfl_xor(s.z, m, kLanesPerVertex);
+  }
+  return s;
+}
+
 __global__ __launch_bounds__(kThreads) void k_vertex_normals(
     const V3 *__restrict__ vertices, const int32_t *__restrict__ tris, const int32_t *__restrict__ offsets,
     const int32_t *__restrict__ entries, int B, int V, V3 *__restrict__ sums, V3 *__restrict__ normals) {
-  const long gid = (long)blockIdx.x * kThreads + threadIdx.x;
-  if (gid >= (long)B * V) return;
-  const int b = (int)(gid / V), v = (int)(gid - (long)b * V);
+  const long tid = (long)blockIdx.x * kThreads + threadIdx.x;
+  const long gid = tid / kLanesPerVertex;
+  const int sub = (int)(tid % kLanesPerVertex);
+  const bool have = gid < (long)B * V;   // (whole groups of eight: the butterfly below stays inside one)
+  const long g = have ? gid : 0;
+  const int b = (int)(g / V), v = (int)(g - (long)b * V);
   const V3 *vb = vertices + (size_t)b * V;
   V3 s{0.f, 0.f, 0.f};
-  const int e1 = offsets[v + 1];
-  for (int i = offsets[v]; i < e1; ++i) {
+  const int e1 = have ? offsets[v + 1] : 0;
+  for (int i = offsets[v] + sub; i < e1; i += kLanesPerVertex) {
     const int e = entries[i], t = e / 3, k = e - 3 * t;
     int idx[3];
     if (!load_triangle(tris, t, V, idx)) continue;  // the reference would index out of bounds
     const V3 o = vb[idx[k]], a = vb[idx[(k + 1) % 3]], c = vb[idx[(k + 2) % 3]];
     s = s + cross(a - o, c - o);  // meshes.py:24-33, corner k's expression
   }
+  s = sum_over_vertex_lanes(s);
+  if (!have || sub != 0) return;
   sums[gid] = s;
   const float inv = 1.0f / fmaxf(sqrtf(dot(s, s)), kNormalEps);
   normals[gid] = {s.x * inv, s.y * inv, s.z * inv};
 }
 
 // d normalize(s) / d s applied to dn:  (dn - n (n . dn)) / |s|   (|s| > eps), dn / eps otherwise.
-__global__ __launch_bounds__(kThreads) void k_vertex_normals_dsums(const V3 *__restrict__ dnormals,
-                                                                   const V3 *__restrict__ sums, long n,
-                                                                   V3 *__restrict__ dsums) {
-  const long gid = (long)blockIdx.x * kThreads + threadIdx.x;
-  if (gid >= n) return;
-  const V3 s = sums[gid], dn = dnormals[gid];
+__device__ __forceinline__ V3 normalize_backward(V3 s, V3 dn) {
   const float len = sqrtf(dot(s, s));
   if (len > kNormalEps) {
     const float inv = 1.0f / len;
     const V3 nrm{s.x * inv, s.y * inv, s.z * inv};
     const float nd = dot(nrm, dn);
-    dsums[gid] = {(dn.x - nrm.x * nd) * inv, (dn.y - nrm.y * nd) * inv, (dn.z - nrm.z * nd) * inv};
-  } else {
-    const float inv = 1.0f / kNormalEps;
-    dsums[gid] = {dn.x * inv, dn.y * inv, dn.z * inv};
+    return {(dn.x - nrm.x * nd) * inv, (dn.y - nrm.y * nd) * inv, (dn.z - nrm.z * nd) * inv};
   }
+  const float inv = 1.0f / kNormalEps;
+  return {dn.x * inv, dn.y * inv, dn.z * inv};
 }
 
 // For c_j = (v_{j+1} - v_j) x (v_{j+2} - v_j) with upstream g_j (the gradient of the sum at v_j):
 //   d/d v_{j+1} = (v_{j+2} - v_j) x g_j,   d/d v_{j+2} = g_j x (v_{j+1} - v_j),   d/d v_j = -(both).
-// The vertex at corner k of a triangle collects its share of all three c_j.
+// The vertex at corner k of a triangle collects its share of all three c_j.  g_j is formed on the spot
+// from the corner's dnormal and sum (a launch of its own before: 5 us for 40 flops per vertex).
 __global__ __launch_bounds__(kThreads) void k_vertex_normals_backward(
-    const V3 *__restrict__ vertices, const V3 *__restrict__ dsums, const int32_t *__restrict__ tris,
-    const int32_t *__restrict__ offsets, const int32_t *__restrict__ entries, int B, int V,
-    V3 *__restrict__ dvertices) {
-  const long gid = (long)blockIdx.x * kThreads + threadIdx.x;
-  if (gid >= (long)B * V) return;
-  const int b = (int)(gid / V), v = (int)(gid - (long)b * V);
+    const V3 *__restrict__ vertices, const V3 *__restrict__ dnormals, const V3 *__restrict__ sums,
+    const int32_t *__restrict__ tris, const int32_t *__restrict__ offsets, const int32_t *__restrict__ entries,
+    int B, int V, V3 *__restrict__ dvertices) {
+  const long tid = (long)blockIdx.x * kThreads + threadIdx.x;
+  const long gid = tid / kLanesPerVertex;
+  const int sub = (int)(tid % kLanesPerVertex);
+  const bool have = gid < (long)B * V;
+  const long g = have ? gid : 0;
+  const int b = (int)(g / V), v = (int)(g - (long)b * V);
   const V3 *vb = vertices + (size_t)b * V;
-  const V3 *gb = dsums + (size_t)b * V;
+  const V3 *nb = dnormals + (size_t)b * V;
+  const V3 *sb = sums + (size_t)b * V;
   V3 d{0.f, 0.f, 0.f};
-  const int e1 = offsets[v + 1];
-  for (int i = offsets[v]; i < e1; ++i) {
+  const int e1 = have ? offsets[v + 1] : 0;
+  for (int i = offsets[v] + sub; i < e1; i += kLanesPerVertex) {
     const int e = entries[i], t = e / 3, k = e - 3 * t;
     int idx[3];
     if (!load_triangle(tris, t, V, idx)) continue;
     const int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
     const V3 p0 = vb[idx[k]], p1 = vb[idx[k1]], p2 = vb[idx[k2]];
-    const V3 g0 = gb[idx[k]], g1 = gb[idx[k1]], g2 = gb[idx[k2]];
+    const V3 g0 = normalize_backward(sb[idx[k]], nb[idx[k]]);
+    const V3 g1 = normalize_backward(sb[idx[k1]], nb[idx[k1]]);
+    const V3 g2 = normalize_backward(sb[idx[k2]], nb[idx[k2]]);
     // j = k: this vertex is the cross product's origin
     const V3 da = cross(p2 - p0, g0), db = cross(g0, p1 - p0);
     d = d - (da + db);
@@ -103,7 +126,8 @@ __global__ __launch_bounds__(kThreads) void k_vertex_normals_backward(
     // j = k1 (its "next-next" corner is k): d/d v_{j+2} = g_j x (v_{j+1} - v_j) with j+1 = k2
     d = d + cross(g1, p2 - p1);
   }
-  dvertices[gid] = d;
+  d = sum_over_vertex_lanes(d);
+  if (have && sub == 0) dvertices[gid] = d;
 }
 
 }  // namespace
@@ -112,23 +136,19 @@ int launch_vertex_normals(const float *vertices, const int32_t *tris, const int3
                           const int32_t *entries, int B, int V, float *sums, float *normals, hipStream_t s) {
   const long n = (long)B * V;
   if (n == 0) return MR_OK;
-  hipLaunchKernelGGL(k_vertex_normals, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
+  hipLaunchKernelGGL(k_vertex_normals, dim3((unsigned)((n * kLanesPerVertex + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
                      (const V3 *)vertices, tris, offsets, entries, B, V, (V3 *)sums, (V3 *)normals);
   return check_launch();
 }
 
 int launch_vertex_normals_backward(const float *dnormals, const float *vertices, const float *sums,
                                    const int32_t *tris, const int32_t *offsets, const int32_t *entries,
-                                   int B, int V, float *dsums, float *dvertices, hipStream_t s) {
+                                   int B, int V, float *dvertices, hipStream_t s) {
   const long n = (long)B * V;
   if (n == 0) return MR_OK;
-  const dim3 grid((unsigned)((n + kThreads - 1) / kThreads));
-  hipLaunchKernelGGL(k_vertex_normals_dsums, grid, dim3(kThreads), 0, s, (const V3 *)dnormals, (const V3 *)sums, n,
-                     (V3 *)dsums);
-  int rc = check_launch();
-  if (rc != MR_OK) return rc;
+  const dim3 grid((unsigned)((n * kLanesPerVertex + kThreads - 1) / kThreads));
   hipLaunchKernelGGL(k_vertex_normals_backward, grid, dim3(kThreads), 0, s, (const V3 *)vertices,
-                     (const V3 *)dsums, tris, offsets, entries, B, V, (V3 *)dvertices);
+                     (const V3 *)dnormals, (const V3 *)sums, tris, offsets, entries, B, V, (V3 *)dvertices);
   return check_launch();
 }
 

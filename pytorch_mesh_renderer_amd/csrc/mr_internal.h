@@ -171,7 +171,7 @@ int launch_vertex_normals(const float *vertices, const int32_t *tris, const int3
                           const int32_t *entries, int B, int V, float *sums, float *normals, hipStream_t s);
 int launch_vertex_normals_backward(const float *dnormals, const float *vertices, const float *sums,
                                    const int32_t *tris, const int32_t *offsets, const int32_t *entries,
-                                   int B, int V, float *dsums, float *dvertices, hipStream_t s);
+                                   int B, int V, float *dvertices, hipStream_t s);
 int launch_camera_transforms(const float *eye, const float *center, const float *up, const float *fov_y,
                              const float *near_clip, const float *far_clip, float aspect, int B, float *transforms,
                              int *degenerate, hipStream_t s);

@@ -591,7 +591,7 @@ __global__ __launch_bounds__(kWave, Fn::kMinWavesPerSimd) void k_accumulate_lane
     if (fin) run_tri = -1;
     __builtin_amdgcn_wave_barrier();  // LDS executes one wavefront's operations in order
     int cur_t = -1, cur_slot = -1;    // triangle of the running segment and its merge-table slot
-    bool cur_fresh = false;           // the slot was claimed by this segment: it holds nothing yet
+    [[maybe_unused]] bool cur_fresh = false;  // the slot was claimed by this segment: it holds nothing yet
     float sum = 0.0f, sum2 = 0.0f, merged = 0.0f;
     auto close_segment = [&]() {
       if (cur_t < 0) return;

@@ -466,6 +466,38 @@ def test_vertex_normals_kernel_matches_reference(device):
     assert not calls and torch.equal(v3.grad, v.grad)
 
 
+def test_vertex_normals_high_valence_and_odd_vertex_counts(device):
+    """Round 3: eight lanes per vertex, a second trip for valence > 8.  A 21-triangle fan (hub valence 21,
+    V = 23: the last group of eight lanes is partly past the end) in two images against the reference's
+    scatter formulation (meshes.py:18-35) written with torch ops, both ways."""
+    from pytorch_mesh_renderer_amd.common import meshes
+    g = torch.Generator().manual_seed(5)
+    n_rim = 22
+    ang = torch.linspace(0, 5.5, n_rim)
+    rim = torch.stack([torch.cos(ang), torch.sin(ang), 0.2 * torch.rand(n_rim, generator=g)], 1)
+    verts = torch.cat([torch.tensor([[0.0, 0.0, 0.5]]), rim]).unsqueeze(0).repeat(2, 1, 1)
+    verts[1] += 0.1 * torch.rand(23, 3, generator=g)
+    tris = torch.tensor([[0, i, i + 1] for i in range(1, n_rim)], dtype=torch.int32)
+    w = torch.rand(2, 23, 3, generator=g)
+
+    def reference(v):
+        t = tris.long()
+        a, b, c = v[:, t[:, 0]], v[:, t[:, 1]], v[:, t[:, 2]]
+        sums = torch.zeros_like(v)
+        sums = sums.index_add(1, t[:, 0], torch.cross(b - a, c - a, dim=-1))
+        sums = sums.index_add(1, t[:, 1], torch.cross(c - b, a - b, dim=-1))
+        sums = sums.index_add(1, t[:, 2], torch.cross(a - c, b - c, dim=-1))
+        return torch.nn.functional.normalize(sums, dim=2, eps=1e-6)
+
+    vr = verts.clone().double().requires_grad_(True)
+    (reference(vr) * w.double()).sum().backward()
+    vd = verts.clone().to(device).requires_grad_(True)
+    n = meshes.compute_vertex_normals(vd, tris.to(device))
+    (n * w.to(device)).sum().backward()
+    np.testing.assert_allclose(n.detach().cpu().numpy(), reference(verts.double()).numpy(), atol=2e-6, rtol=0)
+    np.testing.assert_allclose(vd.grad.cpu().numpy(), vr.grad.numpy(), atol=2e-5, rtol=1e-4)
+
+
 def test_deterministic_mode_flags_contributions_outside_its_fixed_point_range(device):
     """the deterministic mode converts every contribution to 64-bit fixed point; one that
     does not fit -- here an infinite upstream gradient on one pixel, and a NaN -- used to come back

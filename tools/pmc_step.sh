@@ -1,10 +1,13 @@
 # SQ activity counters of the bench step's kernels, four --pmc passes over `bench.py --steps 3`.
 #   gpurun -- 'bash tools/pmc_step.sh'   -> gpurun_out/pmc_step/summary.txt
 # (copy the summary to profiles/rNN_pmc_step_summary.txt; MR_SHADE_BACKWARD_KERNEL=1 in the environment
-#  profiles the rows kernel instead of the lane-accumulating one)
+#  profiles the rows kernel instead of the lane-accumulating one; PMC_CMD="python3 tools/soft_bench.py 3"
+#  PMC_KEYS="k_soft_backward,k_soft_forward" PMC_OUT=gpurun_out/pmc_soft profiles another command's kernels)
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-OUT=gpurun_out/pmc_step
+OUT=${PMC_OUT:-gpurun_out/pmc_step}
+CMD=${PMC_CMD:-python3 bench.py --steps 3 --warmup 1 --cpu-sample 0}
+export PMC_OUT=$OUT
 rm -rf "$OUT" && mkdir -p "$OUT"
 i=0
 for set in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" \
@@ -14,13 +17,13 @@ for set in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA
            "SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_ANY"; do
   i=$((i + 1))
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$OUT/p$i" -o run -- \
-      python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 > "$OUT/p$i.log" 2>&1
+      $CMD > "$OUT/p$i.log" 2>&1
 done
-python3 - <<'PY' | tee gpurun_out/pmc_step/summary.txt
-import csv, glob, collections
+python3 - <<'PY' | tee "$OUT/summary.txt"
+import csv, glob, collections, os
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-keys = ("k_accumulate_lanes", "k_accumulate_rows", "k_raster<64, 0, true>", "k_raster<64, 0, false>", "k_l1_forward", "k_shade_gather")
-for f in glob.glob("gpurun_out/pmc_step/**/*counter_collection.csv", recursive=True):
+keys = tuple(os.environ["PMC_KEYS"].split(",")) if os.environ.get("PMC_KEYS") else ("k_accumulate_lanes", "k_accumulate_rows", "k_raster<64, 0, true>", "k_raster<64, 0, false>", "k_l1_forward", "k_shade_gather")
+for f in glob.glob(os.environ["PMC_OUT"] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         for key in keys:
             if key in r["Kernel_Name"]:

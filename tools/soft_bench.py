@@ -17,9 +17,9 @@ def step():
     v.grad = None
     img = soft_mesh_renderer.render(v, tri, kd, eyes, zero, up, lp, li, W, H)
     img.mean().backward()
-for _ in range(10): step()
+for _ in range(10 if len(sys.argv) < 2 else 1): step()
 torch.cuda.synchronize(); t0 = time.perf_counter()
-n = 100
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 for _ in range(n): step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
 print(f"config5 soft render fwd+bwd: {dt*1e3:.2f} ms/step -> {B*W*H/dt/1e6:.1f} Mpix/s (reference CPU: ~165 px/s)")
