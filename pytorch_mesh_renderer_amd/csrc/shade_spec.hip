@@ -235,15 +235,26 @@ enum SpecPass { kNorms = 0, kShade = 1, kGsum = 2 };
 // order.  (They used to be float atomics on the image's L addresses: 4096 workgroups per image queued
 // up on the same cache line, 1.45 ms for the norm pass at 1024^2 x 32 against 0.26 ms for the shading
 // pass that does more arithmetic.)
+#ifndef MR_SPEC_ROWS
+#define MR_SPEC_ROWS 4   // rows per workgroup, in batches whose G-buffer loads are all in flight before the first pixel's math
+#endif
+#ifndef MR_SPEC_CACHE_RECORD
+#define MR_SPEC_CACHE_RECORD 0
+#endif
+#ifndef MR_SPEC_BATCH
+#define MR_SPEC_BATCH 4
+#endif
+constexpr int kSpecRows = MR_SPEC_ROWS, kSpecBatch = MR_SPEC_BATCH;
+static_assert(kSpecRows % kSpecBatch == 0, "whole batches");
 template <int L, int PASS, bool PV>
 __global__ __launch_bounds__(kThreads) void k_spec_pixels(
     const int32_t *__restrict__ ids, const F3 *__restrict__ bary,
     const SpecCornerRec<attr_count(PV)> *__restrict__ corners, SpecSceneIn scene_in, int T, int W, int H, int x_blocks,
-    const float4 *__restrict__ drgba, float4 *__restrict__ rgba_out, float *__restrict__ sums_out) {
+    int y_blocks, const float4 *__restrict__ drgba, float4 *__restrict__ rgba_out, float *__restrict__ sums_out) {
   const int blk = (int)blockIdx.x;
-  const int img = blk / (x_blocks * H);
-  const int rem = blk - img * (x_blocks * H);
-  const int y = rem / x_blocks, xb = rem - y * x_blocks;
+  const int img = blk / (x_blocks * y_blocks);
+  const int rem = blk - img * (x_blocks * y_blocks);
+  const int yb = rem / x_blocks, xb = rem - yb * x_blocks;
   const int x = xb * kThreads + (int)threadIdx.x;
   constexpr int A = attr_count(PV);
   SpecScene<L> sc;
@@ -251,15 +262,48 @@ __global__ __launch_bounds__(kThreads) void k_spec_pixels(
   float part[L];
 #pragma unroll
   for (int l = 0; l < L; ++l) part[l] = 0.0f;
-  if (x < W) {
-    const size_t pix = ((size_t)img * H + y) * W + x;
-    const F3 b = MR_SPEC_NT ? load_streamed(&bary[pix]) : bary[pix];
-    int t = MR_SPEC_NT ? __builtin_nontemporal_load(&ids[pix]) : ids[pix];
+  // One thread per pixel and workgroup launched 1.3 dependent round trips (G-buffer -> corner record) per
+  // 256 pixels with nothing else in flight: 3.1 TB/s for the read-only norm pass.  All rows' G-buffer loads go
+  // out first.
+  // (MR_SPEC_CACHE_RECORD: the thread keeps its triangle's 144-byte corner record while it stays on that
+  // triangle going down a 16-row column instead of gathering it per pixel.  Measured slower -- norm pass 153
+  // -> 195 us, the other two +5..20 -- the gather is not what binds these passes.)
+  SpecCorners<A> cr;
+  int cached_t = -1;
+#pragma unroll 1
+  for (int r0 = 0; r0 < kSpecRows; r0 += kSpecBatch) {
+  F3 b_row[kSpecBatch];
+  int t_row[kSpecBatch];
+  float4 g_row[kSpecBatch];
+#pragma unroll
+  for (int r = 0; r < kSpecBatch; ++r) {
+    const int y = yb * kSpecRows + r0 + r;
+    b_row[r] = F3{0.f, 0.f, 0.f};
+    t_row[r] = -1;
+    g_row[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (x < W && y < H) {
+      const size_t pix = ((size_t)img * H + y) * W + x;
+      b_row[r] = MR_SPEC_NT ? load_streamed(&bary[pix]) : bary[pix];
+      t_row[r] = MR_SPEC_NT ? __builtin_nontemporal_load(&ids[pix]) : ids[pix];
+      if (PASS == kGsum) {
+        const size_t out_pix = ((size_t)img * H + (H - 1 - y)) * W + x;
+        g_row[r] = MR_SPEC_NT ? load_streamed(&drgba[out_pix]) : drgba[out_pix];
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < kSpecBatch; ++r) {
+    const int y = yb * kSpecRows + r0 + r;
+    if (!(x < W && y < H)) continue;
+    const F3 b = b_row[r];
+    const int t = t_row[r];
     float at[A], pre = 0.0f, alpha = 0.0f;
     const bool live = ((2.0f * b.x + 2.0f * b.y) + 2.0f * b.z) > 0.0f && (unsigned)t < (unsigned)T;
     if (live) {
-      SpecCorners<A> cr;
-      load_spec_corners(corners + (size_t)img * T + t, cr);
+      if (!MR_SPEC_CACHE_RECORD || t != cached_t) {
+        load_spec_corners(corners + (size_t)img * T + t, cr);
+        cached_t = t;
+      }
       interpolate_attrs(cr, b, pre, alpha, at);
     } else {
 #pragma unroll
@@ -271,17 +315,13 @@ __global__ __launch_bounds__(kThreads) void k_spec_pixels(
       PixelFrame f;
       pixel_frame(at, sc.cam, f);
       float rgb[3] = {sc.amb[0] * at[6], sc.amb[1] * at[7], sc.amb[2] * at[8]};
-      float g[3] = {0.f, 0.f, 0.f};
-      if (PASS == kGsum) {
-        const float4 gg = MR_SPEC_NT ? load_streamed(&drgba[out_pix]) : drgba[out_pix];
-        g[0] = gg.x; g[1] = gg.y; g[2] = gg.z;
-      }
+      const float g[3] = {g_row[r].x, g_row[r].y, g_row[r].z};
 #pragma unroll
       for (int l = 0; l < L; ++l) {
         LightTerm lt;
         light_term(at, f, sc.lp[l], lt);
         if (PASS == kNorms) {
-          part[l] = lt.rdc * lt.rdc;
+          part[l] += lt.rdc * lt.rdc;
         } else {
           SpecTerm st;  // only masked-in pixels get here
           specularity(lt.rdc, sc.inv_norm[l], lt.ndl, PV ? at[A - 1] : sc.shin, st);
@@ -290,7 +330,7 @@ __global__ __launch_bounds__(kThreads) void k_spec_pixels(
             for (int c = 0; c < 3; ++c) rgb[c] += (at[6 + c] * lt.ndl + at[9 + c] * st.spec) * sc.li[l][c];
           } else {
             const float dspec = (g[0] * at[9] * sc.li[l][0] + g[1] * at[10] * sc.li[l][1]) + g[2] * at[11] * sc.li[l][2];
-            part[l] = dspec * st.dspec_drn * lt.rdc;
+            part[l] += dspec * st.dspec_drn * lt.rdc;
           }
         }
       }
@@ -302,6 +342,7 @@ __global__ __launch_bounds__(kThreads) void k_spec_pixels(
       if (MR_SPEC_NT) store_streamed(&rgba_out[out_pix], make_float4(0.f, 0.f, 0.f, 0.f));
       else rgba_out[out_pix] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+  }
   }
   if (PASS != kShade) {  // workgroup-uniform
     __shared__ float s_part[kThreads / kWave][L];
@@ -684,7 +725,9 @@ inline size_t spec_corner_bytes(int B, int T) {
 inline size_t spec_acc_bytes(int B, int T) { return align_up((size_t)B * T * 48 * sizeof(long long), 256); }
 inline size_t spec_sums_bytes(int B) { return align_up((size_t)B * 4 * sizeof(float), 256); }
 // k_spec_pixels' per-workgroup partial sums (kNorms, kGsum): [workgroups][L <= 4]
-inline int spec_blocks_per_image(int W, int H) { return ((W + kThreads - 1) / kThreads) * H; }
+inline int spec_blocks_per_image(int W, int H) {
+  return ((W + kThreads - 1) / kThreads) * ((H + kSpecRows - 1) / kSpecRows);
+}
 inline size_t spec_partials_bytes(int B, int W, int H) {
   return align_up((size_t)B * spec_blocks_per_image(W, H) * 4 * sizeof(float), 256);
 }
@@ -707,11 +750,12 @@ int launch_spec_pixels(int L, const int32_t *ids, const float *bary, const void 
                        const SpecSceneIn &scene, int B, int T, int W, int H, const float *drgba, float *rgba,
                        float *sums, float *partials, hipStream_t s) {
   const int x_blocks = (W + kThreads - 1) / kThreads;
-  const dim3 grid((unsigned)((size_t)x_blocks * H * B)), block(kThreads);
+  const int y_blocks = (H + kSpecRows - 1) / kSpecRows;
+  const dim3 grid((unsigned)((size_t)x_blocks * y_blocks * B)), block(kThreads);
 #define MR_SPEC_PIXELS(NL)                                                                        \
   hipLaunchKernelGGL((k_spec_pixels<NL, PASS, PV>), grid, block, 0, s, ids, (const F3 *)bary,     \
                      (const SpecCornerRec<attr_count(PV)> *)corners, scene, T, W, H, x_blocks,    \
-                     (const float4 *)drgba, (float4 *)rgba, partials)
+                     y_blocks, (const float4 *)drgba, (float4 *)rgba, partials)
   switch (L) {
     case 1: MR_SPEC_PIXELS(1); break;
     case 2: MR_SPEC_PIXELS(2); break;
