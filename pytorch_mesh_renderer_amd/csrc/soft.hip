@@ -43,14 +43,20 @@ constexpr int kMaxLights = 4;
 constexpr float kEps = 1e-10f;     // rasterize.py:211
 constexpr float kNormEps = 1e-12f;
 
-struct alignas(128) SoftRec {
+// gfx950 has no scalar floating-point ALU: whatever a kernel computes from a record's fields alone -- the same
+// value in all 64 lanes -- costs a vector instruction per wavefront and candidate.  The edges' unit
+// directions and inverse lengths (a sqrt and two reciprocals per edge at a quarter of the vector rate) and the
+// reciprocals of w are therefore formed once per triangle here, with the expressions the pixel kernels used.
+struct alignas(64) SoftRec {
   float x[3], y[3], zn[3], w[3];   // NDC corners and clip w
   float minv[9];                   // rows = barycentric coefficients (a, b, c): bc_i = a x + b y + c
   float lo[2], hi[2];              // blur-inflated NDC bbox
   float valid;                     // 1 = front-facing, non-degenerate
-  float pad[6];
+  float nx[3], ny[3], ilen[3];     // edges 01, 12, 20: unit direction (rasterize.py:169-172) and 1 / length
+  float iw[3];                     // 1 / w
+  float pad[10];
 };
-static_assert(sizeof(SoftRec) == 128, "one cache line");
+static_assert(sizeof(SoftRec) == 192, "three 64-byte scalar loads");
 
 struct SoftParams {
   float sigma, gamma, blur;
@@ -65,7 +71,7 @@ __global__ __launch_bounds__(kThreads) void k_soft_setup(
   const int t = (int)(gid - (long)b * T);
   SoftRec r;
   r.valid = 0.f;
-  for (int k = 0; k < 6; ++k) r.pad[k] = 0.f;
+  for (int k = 0; k < 10; ++k) r.pad[k] = 0.f;
   const int vi[3] = {tris[3 * t], tris[3 * t + 1], tris[3 * t + 2]};
   bool ok = true;
 #pragma unroll
@@ -90,6 +96,17 @@ __global__ __launch_bounds__(kThreads) void k_soft_setup(
   r.lo[1] = fminf(fminf(r.y[0], r.y[1]), r.y[2]) - blur;
   r.hi[0] = fmaxf(fmaxf(r.x[0], r.x[1]), r.x[2]) + blur;
   r.hi[1] = fmaxf(fmaxf(r.y[0], r.y[1]), r.y[2]) + blur;
+#pragma unroll
+  for (int e = 0; e < 3; ++e) {
+    const int a = e, b2 = (e + 1) % 3;
+    const float abx = r.x[b2] - r.x[a], aby = r.y[b2] - r.y[a];
+    const float len = sqrtf(abx * abx + aby * aby);
+    const float il = 1.0f / fmaxf(len, kNormEps);
+    r.nx[e] = abx * il;
+    r.ny[e] = aby * il;
+    r.ilen[e] = 1.0f / len;
+    r.iw[e] = 1.0f / r.w[e];
+  }
   // rasterize.py:331-336: area > 0 back-facing, == 0 degenerate; a singular matrix leaves area 0
   r.valid = (ok && !(area >= 0.0f) && det != 0.0f) ? 1.f : 0.f;
   recs[gid] = r;
@@ -115,15 +132,12 @@ struct LightSet {
   int L;
 };
 
-__device__ __forceinline__ void edge_nearest(float px, float py, float ax, float ay, float bx, float by,
-                                             float &t, float &d2) {  // rasterize.py:169-176
+__device__ __forceinline__ void edge_nearest(float px, float py, float ax, float ay, float bx, float by, float nx,
+                                             float ny, float ilen, float &t, float &d2) {  // rasterize.py:169-176
   const float abx = bx - ax, aby = by - ay;
-  const float len = sqrtf(abx * abx + aby * aby);
-  const float il = 1.0f / fmaxf(len, kNormEps);
-  const float nx = abx * il, ny = aby * il;
   const float dpn = (px - ax) * nx + (py - ay) * ny;
   const float prx = dpn * nx, pry = dpn * ny;
-  t = fminf(fmaxf((prx * nx + pry * ny) / len, 0.0f), 1.0f);
+  t = fminf(fmaxf((prx * nx + pry * ny) * ilen, 0.0f), 1.0f);
   const float qx = ax + t * abx - px, qy = ay + t * aby - py;
   d2 = qx * qx + qy * qy;
 }
@@ -134,9 +148,9 @@ __device__ __forceinline__ bool eval_pair(const SoftRec &r, const Corners &cr, c
   if (!(px <= r.hi[0] && px >= r.lo[0] && py <= r.hi[1] && py >= r.lo[1])) return false;  // quadtree.py:18-31
 #pragma unroll
   for (int i = 0; i < 3; ++i) o.bc[i] = r.minv[3 * i] * px + r.minv[3 * i + 1] * py + r.minv[3 * i + 2];
-  edge_nearest(px, py, r.x[0], r.y[0], r.x[1], r.y[1], o.t[0], o.d2[0]);
-  edge_nearest(px, py, r.x[1], r.y[1], r.x[2], r.y[2], o.t[1], o.d2[1]);
-  edge_nearest(px, py, r.x[2], r.y[2], r.x[0], r.y[0], o.t[2], o.d2[2]);
+  edge_nearest(px, py, r.x[0], r.y[0], r.x[1], r.y[1], r.nx[0], r.ny[0], r.ilen[0], o.t[0], o.d2[0]);
+  edge_nearest(px, py, r.x[1], r.y[1], r.x[2], r.y[2], r.nx[1], r.ny[1], r.ilen[1], o.t[1], o.d2[1]);
+  edge_nearest(px, py, r.x[2], r.y[2], r.x[0], r.y[0], r.nx[2], r.ny[2], r.ilen[2], o.t[2], o.d2[2]);
   o.edge = 0;
   o.dist2 = o.d2[0];
   if (o.d2[1] < o.dist2) { o.edge = 1; o.dist2 = o.d2[1]; }
@@ -155,7 +169,7 @@ __device__ __forceinline__ bool eval_pair(const SoftRec &r, const Corners &cr, c
   o.s1 = 0.f;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    o.q[k] = o.u[k] / r.w[k];
+    o.q[k] = o.u[k] * r.iw[k];
     o.s1 += fabsf(o.q[k]);
   }
   const float is1 = 1.0f / fmaxf(o.s1, kNormEps);  // F.normalize(p=1), rasterize.py:359-365
@@ -552,8 +566,8 @@ __global__ __launch_bounds__(kThreads, MR_SOFT_BWD_WAVES) void k_soft_backward(
             for (int a = 0; a < 3; ++a) {
               const float sgn = p.q[a] > 0.f ? 1.f : (p.q[a] < 0.f ? -1.f : 0.f);
               const float g_q = p.s1 > kNormEps ? (g_sb[a] - sgn * dot) * is1 : g_sb[a] * is1;
-              g_u[a] = g_q / r.w[a];
-              g_w4[a] = -g_q * p.q[a] / r.w[a];
+              g_u[a] = g_q * r.iw[a];
+              g_w4[a] = -g_q * p.q[a] * r.iw[a];
             }
           }
           // ---- u -> screen geometry ----
@@ -614,7 +628,7 @@ __global__ __launch_bounds__(kThreads, MR_SOFT_BWD_WAVES) void k_soft_backward(
           // ---- NDC -> clip: x = cx / w, y = cy / w, zn = cz / w ----
 #pragma unroll
           for (int a = 0; a < 3; ++a) {
-            const float iw = 1.0f / r.w[a];
+            const float iw = r.iw[a];
             f[12 + 4 * a + 0] = g_x2[a] * iw;
             f[12 + 4 * a + 1] = g_y2[a] * iw;
             f[12 + 4 * a + 2] = g_zn[a] * iw;
