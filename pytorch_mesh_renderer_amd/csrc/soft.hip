@@ -47,6 +47,9 @@ constexpr float kNormEps = 1e-12f;
 // value in all 64 lanes -- costs a vector instruction per wavefront and candidate.  The edges' unit
 // directions and inverse lengths (a sqrt and two reciprocals per edge at a quarter of the vector rate) and the
 // reciprocals of w are therefore formed once per triangle here, with the expressions the pixel kernels used.
+#ifndef MR_SOFT_EDGE_VECTORS
+#define MR_SOFT_EDGE_VECTORS 0   // 1: +9 wave-uniform values held in scalar registers, which the backward is out of
+#endif                           //    (109 spilled to vector lanes either way): configs[4] step 0.80 -> 0.825 ms
 struct alignas(64) SoftRec {
   float x[3], y[3], zn[3], w[3];   // NDC corners and clip w
   float minv[9];                   // rows = barycentric coefficients (a, b, c): bc_i = a x + b y + c
@@ -54,13 +57,22 @@ struct alignas(64) SoftRec {
   float valid;                     // 1 = front-facing, non-degenerate
   float nx[3], ny[3], ilen[3];     // edges 01, 12, 20: unit direction (rasterize.py:169-172) and 1 / length
   float iw[3];                     // 1 / w
+#if MR_SOFT_EDGE_VECTORS
+  float ex[3], ey[3], il2[3];      // edge vectors b - a and 1 / |b - a|^2
+  float pad[1];
+#else
   float pad[10];
+#endif
 };
 static_assert(sizeof(SoftRec) == 192, "three 64-byte scalar loads");
 
 struct SoftParams {
   float sigma, gamma, blur;
+  float inv_sigma, inv_gamma, blur2;  // formed on the host: a uniform division inside a kernel is vector work per pair
 };
+inline SoftParams soft_params(float sigma, float gamma, float blur) {
+  return SoftParams{sigma, gamma, blur, 1.0f / sigma, 1.0f / gamma, blur * blur};
+}
 
 __global__ __launch_bounds__(kThreads) void k_soft_setup(
     const float4 *__restrict__ clip, const int32_t *__restrict__ tris, int B, int V, int T,
@@ -71,7 +83,7 @@ __global__ __launch_bounds__(kThreads) void k_soft_setup(
   const int t = (int)(gid - (long)b * T);
   SoftRec r;
   r.valid = 0.f;
-  for (int k = 0; k < 10; ++k) r.pad[k] = 0.f;
+  for (int k = 0; k < (int)(sizeof(r.pad) / sizeof(float)); ++k) r.pad[k] = 0.f;
   const int vi[3] = {tris[3 * t], tris[3 * t + 1], tris[3 * t + 2]};
   bool ok = true;
 #pragma unroll
@@ -105,6 +117,11 @@ __global__ __launch_bounds__(kThreads) void k_soft_setup(
     r.nx[e] = abx * il;
     r.ny[e] = aby * il;
     r.ilen[e] = 1.0f / len;
+#if MR_SOFT_EDGE_VECTORS
+    r.ex[e] = abx;
+    r.ey[e] = aby;
+    r.il2[e] = 1.0f / (abx * abx + aby * aby);
+#endif
     r.iw[e] = 1.0f / r.w[e];
   }
   // rasterize.py:331-336: area > 0 back-facing, == 0 degenerate; a singular matrix leaves area 0
@@ -126,15 +143,18 @@ struct Pair {
   float c[3];
 };
 
+// ML: the light count the kernel is compiled for (1, or kMaxLights for 2..4): the lights are wave-uniform,
+// i.e. scalar registers, and those are what the pair math runs out of (k_soft_backward spilled 109 of them
+// to vector lanes with four lights' worth held).
+template <int ML>
 struct LightSet {
-  float pos[kMaxLights][3];
-  float inten[kMaxLights];
+  float pos[ML][3];
+  float inten[ML];
   int L;
 };
 
-__device__ __forceinline__ void edge_nearest(float px, float py, float ax, float ay, float bx, float by, float nx,
+__device__ __forceinline__ void edge_nearest(float px, float py, float ax, float ay, float abx, float aby, float nx,
                                              float ny, float ilen, float &t, float &d2) {  // rasterize.py:169-176
-  const float abx = bx - ax, aby = by - ay;
   const float dpn = (px - ax) * nx + (py - ay) * ny;
   const float prx = dpn * nx, pry = dpn * ny;
   t = fminf(fmaxf((prx * nx + pry * ny) * ilen, 0.0f), 1.0f);
@@ -143,20 +163,27 @@ __device__ __forceinline__ void edge_nearest(float px, float py, float ax, float
 }
 
 // Returns false when the pair is culled (bbox, blur radius, depth range).
-__device__ __forceinline__ bool eval_pair(const SoftRec &r, const Corners &cr, const LightSet &ls,
+template <int ML>
+__device__ __forceinline__ bool eval_pair(const SoftRec &r, const Corners &cr, const LightSet<ML> &ls,
                                           const SoftParams &pr, float px, float py, Pair &o) {
   if (!(px <= r.hi[0] && px >= r.lo[0] && py <= r.hi[1] && py >= r.lo[1])) return false;  // quadtree.py:18-31
 #pragma unroll
   for (int i = 0; i < 3; ++i) o.bc[i] = r.minv[3 * i] * px + r.minv[3 * i + 1] * py + r.minv[3 * i + 2];
-  edge_nearest(px, py, r.x[0], r.y[0], r.x[1], r.y[1], r.nx[0], r.ny[0], r.ilen[0], o.t[0], o.d2[0]);
-  edge_nearest(px, py, r.x[1], r.y[1], r.x[2], r.y[2], r.nx[1], r.ny[1], r.ilen[1], o.t[1], o.d2[1]);
-  edge_nearest(px, py, r.x[2], r.y[2], r.x[0], r.y[0], r.nx[2], r.ny[2], r.ilen[2], o.t[2], o.d2[2]);
+#if MR_SOFT_EDGE_VECTORS
+  edge_nearest(px, py, r.x[0], r.y[0], r.ex[0], r.ey[0], r.nx[0], r.ny[0], r.ilen[0], o.t[0], o.d2[0]);
+  edge_nearest(px, py, r.x[1], r.y[1], r.ex[1], r.ey[1], r.nx[1], r.ny[1], r.ilen[1], o.t[1], o.d2[1]);
+  edge_nearest(px, py, r.x[2], r.y[2], r.ex[2], r.ey[2], r.nx[2], r.ny[2], r.ilen[2], o.t[2], o.d2[2]);
+#else
+  edge_nearest(px, py, r.x[0], r.y[0], r.x[1] - r.x[0], r.y[1] - r.y[0], r.nx[0], r.ny[0], r.ilen[0], o.t[0], o.d2[0]);
+  edge_nearest(px, py, r.x[1], r.y[1], r.x[2] - r.x[1], r.y[2] - r.y[1], r.nx[1], r.ny[1], r.ilen[1], o.t[1], o.d2[1]);
+  edge_nearest(px, py, r.x[2], r.y[2], r.x[0] - r.x[2], r.y[0] - r.y[2], r.nx[2], r.ny[2], r.ilen[2], o.t[2], o.d2[2]);
+#endif
   o.edge = 0;
   o.dist2 = o.d2[0];
   if (o.d2[1] < o.dist2) { o.edge = 1; o.dist2 = o.d2[1]; }
   if (o.d2[2] < o.dist2) { o.edge = 2; o.dist2 = o.d2[2]; }
   o.inside = !(o.bc[0] < 0.f || o.bc[1] < 0.f || o.bc[2] < 0.f);
-  if (!o.inside && o.dist2 > pr.blur * pr.blur) return false;  // rasterize.py:354
+  if (!o.inside && o.dist2 > pr.blur2) return false;  // rasterize.py:354
   if (o.inside) {
     o.u[0] = o.bc[0]; o.u[1] = o.bc[1]; o.u[2] = o.bc[2];
   } else if (o.edge == 0) {
@@ -190,8 +217,8 @@ __device__ __forceinline__ bool eval_pair(const SoftRec &r, const Corners &cr, c
   for (int c = 0; c < 3; ++c) o.N[c] = o.nraw[c] * inn;
   o.lum = 0.f;
 #pragma unroll
-  for (int l = 0; l < kMaxLights; ++l) {  // rasterize.py:197-206 (unrolled: static register indices)
-    if (l >= ls.L) break;
+  for (int l = 0; l < ML; ++l) {  // rasterize.py:197-206 (unrolled: static register indices)
+    if (ML > 1 && l >= ls.L) break;
     const float vx = ls.pos[l][0] - o.pos[0], vy = ls.pos[l][1] - o.pos[1], vz = ls.pos[l][2] - o.pos[2];
     const float ivn = 1.0f / fmaxf(sqrtf(vx * vx + vy * vy + vz * vz), kNormEps);
     const float ndl = fminf(fmaxf((vx * o.N[0] + vy * o.N[1] + vz * o.N[2]) * ivn, 0.0f), 1.0f);
@@ -199,15 +226,16 @@ __device__ __forceinline__ bool eval_pair(const SoftRec &r, const Corners &cr, c
   }
 #pragma unroll
   for (int c = 0; c < 3; ++c) o.c[c] = o.kd[c] * o.lum;
-  const float xarg = (o.inside ? o.dist2 : -o.dist2) / pr.sigma;  // rasterize.py:388-389
+  const float xarg = (o.inside ? o.dist2 : -o.dist2) * pr.inv_sigma;  // rasterize.py:388-389
   o.D = 1.0f / (1.0f + expf(-xarg));
-  o.logit = o.z / pr.gamma;  // rasterize.py:394
+  o.logit = o.z * pr.inv_gamma;  // rasterize.py:394
   return true;
 }
 
-__device__ __forceinline__ void load_lights(const float *lpos, const float *lint, int img, int L, LightSet &ls) {
+template <int ML>
+__device__ __forceinline__ void load_lights(const float *lpos, const float *lint, int img, int L, LightSet<ML> &ls) {
   ls.L = L;
-  for (int l = 0; l < kMaxLights; ++l) {
+  for (int l = 0; l < ML; ++l) {
     const bool have = l < L;
     ls.inten[l] = have ? lint[(size_t)img * L + l] : 0.f;
     for (int c = 0; c < 3; ++c) ls.pos[l][c] = have ? lpos[((size_t)img * L + l) * 3 + c] : 0.f;
@@ -343,6 +371,7 @@ __device__ __forceinline__ bool tile_geometry(int W, int H, int tiles_x, int til
   return true;
 }
 
+template <int ML>
 __global__ __launch_bounds__(kThreads) void k_soft_forward(
     const SoftRec *__restrict__ recs, const CornerRec *__restrict__ corners,
     const float *__restrict__ lpos, const float *__restrict__ lint, int T, int W, int H, int L,
@@ -355,10 +384,10 @@ __global__ __launch_bounds__(kThreads) void k_soft_forward(
   if (!tile_geometry(W, H, tiles_x, tiles_per_image, n_tiles, tiles_per_xcd, g)) return;
   const SoftRec *img_recs = recs + (size_t)g.img * T;
   const CornerRec *img_corners = corners + (size_t)g.img * T;
-  LightSet ls;
+  LightSet<ML> ls;
   load_lights(lpos, lint, g.img, L, ls);
 
-  float m = kEps / pr.gamma;  // running max logit; the reference's floor (rasterize.py:397)
+  float m = kEps * pr.inv_gamma;  // running max logit; the reference's floor (rasterize.py:397)
   float sw = 0.f, acc[3] = {0.f, 0.f, 0.f}, prod = 1.f;
   int n = 0;
   const int32_t *cand = cell_ids + ((size_t)g.img * cells_per_image + g.cell) * T;
@@ -389,7 +418,7 @@ __global__ __launch_bounds__(kThreads) void k_soft_forward(
     }
   }
   if (g.in_image) {
-    const float bg = fmaxf(expf(kEps / pr.gamma - m), kEps);  // rasterize.py:401
+    const float bg = fmaxf(expf(kEps * pr.inv_gamma - m), kEps);  // rasterize.py:401
     const float S = sw + bg;
     const size_t pix = ((size_t)g.img * H + g.y) * W + g.x;
     rgba[pix] = make_float4(acc[0] / S, acc[1] / S, acc[2] / S, 1.0f - prod);
@@ -410,7 +439,7 @@ constexpr int kLightRow = 16;  // floats per wavefront row of light sums (4 x kM
 // DET (mr_set_deterministic, round 3): the 39 sums of a (wavefront, triangle) leave as 64-bit fixed-point
 // integer atomics into int64 copies of the four outputs (det_fixed: dclip [B,V,4], then dnormals,
 // dpositions, ddiffuse [B,V,3] each) instead of float atomics into the outputs; k_soft_from_fixed converts.
-template <bool DET>
+template <bool DET, int ML>
 __global__ __launch_bounds__(kThreads, MR_SOFT_BWD_WAVES) void k_soft_backward(
     const SoftRec *__restrict__ recs, const CornerRec *__restrict__ corners,
     const float *__restrict__ lpos, const float *__restrict__ lint, const int32_t *__restrict__ tris,
@@ -426,7 +455,7 @@ __global__ __launch_bounds__(kThreads, MR_SOFT_BWD_WAVES) void k_soft_backward(
   if (!tile_geometry(W, H, tiles_x, tiles_per_image, n_tiles, tiles_per_xcd, g)) return;
   const SoftRec *img_recs = recs + (size_t)g.img * T;
   const CornerRec *img_corners = corners + (size_t)g.img * T;
-  LightSet ls;
+  LightSet<ML> ls;
   load_lights(lpos, lint, g.img, L, ls);
   const int lane = (int)threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -461,9 +490,9 @@ __global__ __launch_bounds__(kThreads, MR_SOFT_BWD_WAVES) void k_soft_backward(
     out = rgba[pix];
     ax = aux[pix];
   }
-  const float m = ax.x, S = ax.y, prod = ax.z;
-  float g_lp[kMaxLights][3], g_li[kMaxLights];
-  for (int l = 0; l < kMaxLights; ++l) { g_li[l] = 0.f; g_lp[l][0] = g_lp[l][1] = g_lp[l][2] = 0.f; }
+  const float m = ax.x, inv_S = 1.0f / ax.y, prod = ax.z;
+  float g_lp[ML][3], g_li[ML];
+  for (int l = 0; l < ML; ++l) { g_li[l] = 0.f; g_lp[l][0] = g_lp[l][1] = g_lp[l][2] = 0.f; }
 
   int n = 0;
   const int32_t *cand = cell_ids + ((size_t)g.img * cells_per_image + g.cell) * T;
@@ -492,12 +521,12 @@ __global__ __launch_bounds__(kThreads, MR_SOFT_BWD_WAVES) void k_soft_backward(
           const float e = expf(p.logit - m);
           const float wgt = p.D * e;
           // rgb = sum_i w_i c_i / S with S = sum_i w_i + bg  (rasterize.py:397-410)
-          const float g_w = (go.x * (p.c[0] - out.x) + go.y * (p.c[1] - out.y) + go.z * (p.c[2] - out.z)) / S;
-          const float g_c[3] = {go.x * wgt / S, go.y * wgt / S, go.z * wgt / S};
+          const float g_w = (go.x * (p.c[0] - out.x) + go.y * (p.c[1] - out.y) + go.z * (p.c[2] - out.z)) * inv_S;
+          const float g_c[3] = {go.x * wgt * inv_S, go.y * wgt * inv_S, go.z * wgt * inv_S};
           // alpha = 1 - prod(1 - D): d alpha / d x_i = prod * D_i  (x = +-d2/sigma, D = sigmoid(x))
           const float g_x = g_w * e * p.D * (1.0f - p.D) + go.w * prod * p.D;
-          const float g_d2 = (p.inside ? g_x : -g_x) / pr.sigma;
-          const float g_z = g_w * wgt / pr.gamma;
+          const float g_d2 = (p.inside ? g_x : -g_x) * pr.inv_sigma;
+          const float g_z = g_w * wgt * pr.inv_gamma;
           // ---- colour (rasterize.py:183-208) ----
           float g_sb[3] = {0.f, 0.f, 0.f};
           float g_kd[3], g_pos[3] = {0.f, 0.f, 0.f}, g_N[3] = {0.f, 0.f, 0.f};
@@ -508,8 +537,8 @@ __global__ __launch_bounds__(kThreads, MR_SOFT_BWD_WAVES) void k_soft_backward(
             g_lum += g_c[c] * p.kd[c];
           }
 #pragma unroll
-          for (int l = 0; l < kMaxLights; ++l) {
-            if (l >= ls.L) break;
+          for (int l = 0; l < ML; ++l) {
+            if (ML > 1 && l >= ls.L) break;
             const float v[3] = {ls.pos[l][0] - p.pos[0], ls.pos[l][1] - p.pos[1], ls.pos[l][2] - p.pos[2]};
             const float vn = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
             const float ivn = 1.0f / fmaxf(vn, kNormEps);
@@ -597,10 +626,16 @@ __global__ __launch_bounds__(kThreads, MR_SOFT_BWD_WAVES) void k_soft_backward(
             const int ia = p.edge, ib = (ia == 0) ? 1 : (ia == 1 ? 2 : 0);
             const float ax2 = ia == 0 ? r.x[0] : (ia == 1 ? r.x[1] : r.x[2]);
             const float ay2 = ia == 0 ? r.y[0] : (ia == 1 ? r.y[1] : r.y[2]);
+#if MR_SOFT_EDGE_VECTORS
+            const float abx = ia == 0 ? r.ex[0] : (ia == 1 ? r.ex[1] : r.ex[2]);
+            const float aby = ia == 0 ? r.ey[0] : (ia == 1 ? r.ey[1] : r.ey[2]);
+            const float iL2 = ia == 0 ? r.il2[0] : (ia == 1 ? r.il2[1] : r.il2[2]);
+#else
             const float bx = ia == 0 ? r.x[1] : (ia == 1 ? r.x[2] : r.x[0]);
             const float by = ia == 0 ? r.y[1] : (ia == 1 ? r.y[2] : r.y[0]);
             const float abx = bx - ax2, aby = by - ay2;
-            const float L2 = abx * abx + aby * aby;
+            const float iL2 = 1.0f / (abx * abx + aby * aby);
+#endif
             const float tt = ia == 0 ? p.t[0] : (ia == 1 ? p.t[1] : p.t[2]);
             const float dvx = ax2 + tt * abx - g.px, dvy = ay2 + tt * aby - g.py;
             const float gxx = 2.0f * dvx * g_d2, gxy = 2.0f * dvy * g_d2;  // d/d nearest point
@@ -609,10 +644,10 @@ __global__ __launch_bounds__(kThreads, MR_SOFT_BWD_WAVES) void k_soft_backward(
             const float g_tt_total = g_t + gxx * abx + gxy * aby;
             // unclamped t = ((p - a) . ab) / |ab|^2; the clamp passes the gradient on [0, 1]
             const float num = (g.px - ax2) * abx + (g.py - ay2) * aby;
-            const float traw = num / L2;
+            const float traw = num * iL2;
             if (traw >= 0.0f && traw <= 1.0f) {
-              const float g_num = g_tt_total / L2;
-              const float g_L2 = -g_tt_total * traw / L2;
+              const float g_num = g_tt_total * iL2;
+              const float g_L2 = -g_tt_total * traw * iL2;
               gax -= g_num * abx; gay -= g_num * aby;
               gabx += g_num * (g.px - ax2) + 2.0f * g_L2 * abx;
               gaby += g_num * (g.py - ay2) + 2.0f * g_L2 * aby;
@@ -673,7 +708,7 @@ __global__ __launch_bounds__(kThreads, MR_SOFT_BWD_WAVES) void k_soft_backward(
   // up on one cache line.)
   float *row = light_rows + ((size_t)g.tile * (kThreads / 64) + wave) * kLightRow;
 #pragma unroll
-  for (int l = 0; l < kMaxLights; ++l) {
+  for (int l = 0; l < ML; ++l) {
     if (l >= L) break;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -828,10 +863,15 @@ int launch_soft_forward(const float *clip, const float *positions, const float *
                                cell_ids, cell_count, s);
   if (rc0 != MR_OK) return rc0;
   const TileGrid tg = tile_grid(B, W, H);
-  const SoftParams pr{sigma, gamma, blur};
-  hipLaunchKernelGGL(k_soft_forward, dim3((unsigned)(tg.per_xcd * kXcds)), dim3(kThreads), 0, s, recs,
-                     corners, lpos, lint, T, W, H, L, pr, tg.tiles_x, tg.per_image, tg.n_tiles, tg.per_xcd,
-                     cell_ids, cell_count, cell_grid(W, H).per_image, (float4 *)rgba, (float4 *)aux);
+  const SoftParams pr = soft_params(sigma, gamma, blur);
+  if (L == 1)
+    hipLaunchKernelGGL(k_soft_forward<1>, dim3((unsigned)(tg.per_xcd * kXcds)), dim3(kThreads), 0, s, recs,
+                       corners, lpos, lint, T, W, H, L, pr, tg.tiles_x, tg.per_image, tg.n_tiles, tg.per_xcd,
+                       cell_ids, cell_count, cell_grid(W, H).per_image, (float4 *)rgba, (float4 *)aux);
+  else
+    hipLaunchKernelGGL(k_soft_forward<kMaxLights>, dim3((unsigned)(tg.per_xcd * kXcds)), dim3(kThreads), 0, s, recs,
+                       corners, lpos, lint, T, W, H, L, pr, tg.tiles_x, tg.per_image, tg.n_tiles, tg.per_xcd,
+                       cell_ids, cell_count, cell_grid(W, H).per_image, (float4 *)rgba, (float4 *)aux);
   return check_launch();
 }
 
@@ -874,10 +914,16 @@ int launch_soft_backward(const float *drgba, const float *rgba, const float *aux
     if (rc != MR_OK) return rc;
   }
   const TileGrid tg = tile_grid(B, W, H);
-  const SoftParams pr{sigma, gamma, blur};
+  const SoftParams pr = soft_params(sigma, gamma, blur);
   float *light_rows = (float *)((char *)ws + soft_prepared_bytes(B, V, T, W, H));
   long long *det_fixed = (long long *)((char *)light_rows + soft_light_rows_bytes(B, W, H));
   float *det_block = (float *)((char *)det_fixed + soft_fixed_bytes(B, V));
+#define MR_SOFT_BWD(DET_, ML_)                                                                              \
+  hipLaunchKernelGGL((k_soft_backward<DET_, ML_>), dim3((unsigned)(tg.per_xcd * kXcds)), dim3(kThreads), 0, s, \
+                     recs, corners, lpos, lint, tris, V, T, W, H, L, pr, tg.tiles_x, tg.per_image, tg.n_tiles,  \
+                     tg.per_xcd, cell_ids, cell_count, cell_grid(W, H).per_image, (const float4 *)drgba,       \
+                     (const float4 *)rgba, (const float4 *)aux, dclip, dnormals, dpositions, ddiffuse,         \
+                     light_rows, det_fixed, det_block, B)
   const bool det = g_deterministic != 0;
   if (det) {
     // the scale: a contribution carries up to 1 / sigma (or 1 / gamma) over the upstream gradient before the
@@ -886,18 +932,13 @@ int launch_soft_backward(const float *drgba, const float *rgba, const float *aux
     const float gain = 1.0f / fminf(fminf(sigma, gamma), 1.0f);
     const int rcd = launch_det_scale(drgba, (size_t)B * H * W * 4, gain, det_block, s);
     if (rcd != MR_OK) return rcd;
-    hipLaunchKernelGGL(k_soft_backward<true>, dim3((unsigned)(tg.per_xcd * kXcds)), dim3(kThreads), 0, s, recs,
-                       corners, lpos, lint, tris, V, T, W, H, L, pr, tg.tiles_x, tg.per_image, tg.n_tiles,
-                       tg.per_xcd, cell_ids, cell_count, cell_grid(W, H).per_image, (const float4 *)drgba,
-                       (const float4 *)rgba, (const float4 *)aux, dclip, dnormals, dpositions, ddiffuse, light_rows,
-                       det_fixed, det_block, B);
+    if (L == 1) MR_SOFT_BWD(true, 1);
+    else MR_SOFT_BWD(true, kMaxLights);
   } else {
-    hipLaunchKernelGGL(k_soft_backward<false>, dim3((unsigned)(tg.per_xcd * kXcds)), dim3(kThreads), 0, s, recs,
-                       corners, lpos, lint, tris, V, T, W, H, L, pr, tg.tiles_x, tg.per_image, tg.n_tiles,
-                       tg.per_xcd, cell_ids, cell_count, cell_grid(W, H).per_image, (const float4 *)drgba,
-                       (const float4 *)rgba, (const float4 *)aux, dclip, dnormals, dpositions, ddiffuse, light_rows,
-                       det_fixed, det_block, B);
+    if (L == 1) MR_SOFT_BWD(false, 1);
+    else MR_SOFT_BWD(false, kMaxLights);
   }
+#undef MR_SOFT_BWD
   const int rc2 = check_launch();
   if (rc2 != MR_OK) return rc2;
   if (det) {
