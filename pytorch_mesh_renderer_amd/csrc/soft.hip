@@ -47,6 +47,9 @@ constexpr float kNormEps = 1e-12f;
 // value in all 64 lanes -- costs a vector instruction per wavefront and candidate.  The edges' unit
 // directions and inverse lengths (a sqrt and two reciprocals per edge at a quarter of the vector rate) and the
 // reciprocals of w are therefore formed once per triangle here, with the expressions the pixel kernels used.
+#ifndef MR_SOFT_LATE_CORNERS
+#define MR_SOFT_LATE_CORNERS 0   // 1: measured 0.765 -> 0.83-0.88 ms/step (scalar spills 43 -> 24, but the load's latency sits on the live path)
+#endif
 #ifndef MR_SOFT_EDGE_VECTORS
 #define MR_SOFT_EDGE_VECTORS 0   // 1: +9 wave-uniform values held in scalar registers, which the backward is out of
 #endif                           //    (109 spilled to vector lanes either way): configs[4] step 0.80 -> 0.825 ms
@@ -164,7 +167,8 @@ __device__ __forceinline__ void edge_nearest(float px, float py, float ax, float
 
 // Returns false when the pair is culled (bbox, blur radius, depth range).
 template <int ML>
-__device__ __forceinline__ bool eval_pair(const SoftRec &r, const Corners &cr, const LightSet<ML> &ls,
+__device__ __forceinline__ bool eval_pair(const SoftRec &r, const CornerRec *__restrict__ corner_rec, Corners &cr,
+                                          const LightSet<ML> &ls,
                                           const SoftParams &pr, float px, float py, Pair &o) {
   if (!(px <= r.hi[0] && px >= r.lo[0] && py <= r.hi[1] && py >= r.lo[1])) return false;  // quadtree.py:18-31
 #pragma unroll
@@ -205,6 +209,13 @@ __device__ __forceinline__ bool eval_pair(const SoftRec &r, const Corners &cr, c
   const float zz = o.sb[0] * r.zn[0] + o.sb[1] * r.zn[1] + o.sb[2] * r.zn[2];
   o.z = 0.5f - zz / 2.0f;  // rasterize.py:368-370
   if (o.z < 0.0f || o.z > 1.0f) return false;
+#if MR_SOFT_LATE_CORNERS
+  // the corners' attributes (27 wave-uniform floats = scalar registers) are requested only now, by the
+  // wavefronts that have a pixel left after the culls: loaded with the record they were live through all of
+  // the geometry above, in a kernel that spills scalar registers to vector lanes
+  asm volatile("" ::: "memory");
+  load_corners(corner_rec, cr);
+#endif
 #pragma unroll
   for (int c = 0; c < 3; ++c) {  // rasterize.py:194-196; corner record rows: normal, position, diffuse
     o.nraw[c] = o.sb[0] * cr.c[0][c] + o.sb[1] * cr.c[1][c] + o.sb[2] * cr.c[2][c];
@@ -399,9 +410,11 @@ __global__ __launch_bounds__(kThreads) void k_soft_forward(
         const int t = __builtin_amdgcn_readfirstlane(s_list[k]);  // workgroup-uniform
         const SoftRec r = img_recs[t];
         Corners cr;
+#if !MR_SOFT_LATE_CORNERS
         load_corners(img_corners + t, cr);
+#endif
         Pair p;
-        if (g.in_image && eval_pair(r, cr, ls, pr, g.px, g.py, p)) {
+        if (g.in_image && eval_pair(r, img_corners + t, cr, ls, pr, g.px, g.py, p)) {
           if (p.logit > m) {  // online softmax: rescale what has been summed so far
             const float sc = expf(m - p.logit);
             sw *= sc; acc[0] *= sc; acc[1] *= sc; acc[2] *= sc;
@@ -504,9 +517,11 @@ __global__ __launch_bounds__(kThreads, MR_SOFT_BWD_WAVES) void k_soft_backward(
         const int t = __builtin_amdgcn_readfirstlane(s_list[k]);  // workgroup-uniform
         const SoftRec r = img_recs[t];
         Corners cr;
+#if !MR_SOFT_LATE_CORNERS
         load_corners(img_corners + t, cr);
+#endif
         Pair p;
-        const bool live = g.in_image && eval_pair(r, cr, ls, pr, g.px, g.py, p);
+        const bool live = g.in_image && eval_pair(r, img_corners + t, cr, ls, pr, g.px, g.py, p);
         if (!__ballot(live)) continue;  // no pixel of this wavefront touches the triangle
         // this lane's corner vertex id for the commit at the end (latency hidden by the math)
         const int my_vertex = (lane < 39) ? tris[3 * t + o_corner] : 0;
