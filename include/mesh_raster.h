@@ -237,7 +237,15 @@ int mr_shade_backward(const float *drgba, const int32_t *ids, const float *bary,
                       float *dclip, float *dnormals, float *dpositions,
                       float *ddiffuse, float *light_grads, const void *corner_records,
                       const int32_t *vertex_offsets, const int32_t *vertex_entries,
-                      const float *transforms, void *workspace, size_t workspace_bytes, void *stream);
+                      const float *transforms, int gbuffer_flags, void *workspace, size_t workspace_bytes,
+                      void *stream);
+/* gbuffer_flags, bit 0 = MR_GBUFFER_NORMALISED: the caller vouches that ids / bary are what
+ * mr_rasterize_forward (or mr_render_forward) wrote for these very vertices -- every covered pixel's
+ * barycentrics sum to 1 within rounding.  The coverage alpha = clamp(2 * sum) (rasterize.py:137-150) is then
+ * exactly 1 and outside the clamp's pass band, and the pixel pass leaves out the blend with the background
+ * and the d / d alpha terms: the same bits with ~20 % fewer vector instructions per pixel.  0 = any
+ * G-buffer (e.g. one the caller edited). */
+#define MR_GBUFFER_NORMALISED 1
 
 /* mr_shade_backward for an upstream gradient that is the backward of mr_l1_loss_forward(rgba,
  * target): instead of the [B,H,W,4] float image mr_l1_loss_backward would write (16 B/px) it takes
@@ -254,8 +262,8 @@ int mr_shade_backward_l1(const uint8_t *signs, const float *upstream, const int3
                          float *dclip, float *dnormals, float *dpositions, float *ddiffuse,
                          float *light_grads, const void *corner_records,
                          const int32_t *vertex_offsets, const int32_t *vertex_entries,
-                         const float *transforms, void *workspace, size_t workspace_bytes,
-                         void *stream);
+                         const float *transforms, int gbuffer_flags, void *workspace,
+                         size_t workspace_bytes, void *stream);
 
 /* ---- fused deferred shading with the specular term --------------------------------
  * The same replacement as mr_shade_forward / mr_shade_backward for render() calls that pass

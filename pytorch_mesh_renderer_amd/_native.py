@@ -16,7 +16,8 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 # build libmesh_raster_hip_probes.so this way); the product always loads the in-tree library.
 LIB_PATH = os.environ.get("MR_NATIVE_LIB_PATH") or os.path.join(_CSRC, "libmesh_raster_hip.so")
 
-ABI_VERSION = 341
+ABI_VERSION = 342
+GBUFFER_NORMALISED = 1   # mesh_raster.h, MR_GBUFFER_NORMALISED
 TIMER_RASTER_FORWARD, TIMER_SHADE_BACKWARD, TIMER_SHADE_FORWARD, TIMER_RASTER_BACKWARD, TIMER_L1_FORWARD = 0, 1, 2, 3, 4
 MR_OK, MR_EINVAL, MR_EWORKSPACE, MR_ELAUNCH = 0, -1, -2, -3
 _ERR = {MR_EINVAL: "invalid argument", MR_EWORKSPACE: "workspace too small or misaligned",
@@ -138,11 +139,11 @@ def lib():
         L.mr_shade_forward.restype = ci
         L.mr_shade_backward_workspace_bytes.argtypes = [ci] * 5
         L.mr_shade_backward_workspace_bytes.restype = sz
-        L.mr_shade_backward.argtypes = [vp] * 11 + [ci] * 6 + [vp] * 10 + [sz, vp]
+        L.mr_shade_backward.argtypes = [vp] * 11 + [ci] * 6 + [vp] * 9 + [ci, vp, sz, vp]
         L.mr_shade_backward.restype = ci
         L.mr_shade_backward_l1_workspace_bytes.argtypes = [ci] * 5
         L.mr_shade_backward_l1_workspace_bytes.restype = sz
-        L.mr_shade_backward_l1.argtypes = [vp] * 12 + [ci] * 6 + [vp] * 10 + [sz, vp]
+        L.mr_shade_backward_l1.argtypes = [vp] * 12 + [ci] * 6 + [vp] * 9 + [ci, vp, sz, vp]
         L.mr_shade_backward_l1.restype = ci
         L.mr_soft_max_lights.restype = ci
         L.mr_soft_workspace_bytes.argtypes = [ci] * 5
@@ -590,7 +591,8 @@ def vertex_adjacency(triangles, vertex_count):
 
 def shade_backward(drgba, ids, bary, clip, normals, positions, diffuse, triangles, light_positions,
                    light_intensities, ambient, corner_records=None, adjacency=None, l1_signs=None,
-                   transforms=None, want_light_grads=True, want_normal_grads=True, want_diffuse_grads=True):
+                   transforms=None, want_light_grads=True, want_normal_grads=True, want_diffuse_grads=True,
+                   normalised_gbuffer=False):
     """_shade_backward_call for any light count up to shade_max_lights().  The kernels keep the light
     gradients' 6 L sums in registers, four lights per call; with more lights the vertex-side gradients
     come from one call over all lights (a run-time loop, no light gradients) and each group of four
@@ -600,7 +602,8 @@ def shade_backward(drgba, ids, bary, clip, normals, positions, diffuse, triangle
     case -- the reference's tests and examples use one to three.)"""
     nl = light_positions.shape[1]
     kw = dict(corner_records=corner_records, adjacency=adjacency, l1_signs=l1_signs, transforms=transforms,
-              want_normal_grads=want_normal_grads, want_diffuse_grads=want_diffuse_grads)
+              want_normal_grads=want_normal_grads, want_diffuse_grads=want_diffuse_grads,
+              normalised_gbuffer=normalised_gbuffer)
     fast = shade_fast_lights() if nl > 4 else nl
     if nl <= fast or not want_light_grads:
         return _shade_backward_call(drgba, ids, bary, clip, normals, positions, diffuse, triangles,
@@ -624,7 +627,8 @@ def shade_backward(drgba, ids, bary, clip, normals, positions, diffuse, triangle
 
 def _shade_backward_call(drgba, ids, bary, clip, normals, positions, diffuse, triangles, light_positions,
                          light_intensities, ambient, corner_records=None, adjacency=None, l1_signs=None,
-                         transforms=None, want_light_grads=True, want_normal_grads=True, want_diffuse_grads=True):
+                         transforms=None, want_light_grads=True, want_normal_grads=True, want_diffuse_grads=True,
+                         normalised_gbuffer=False):
     """-> (dclip [B,V,4], dnormals, dpositions, ddiffuse [B,V,3], dlight_positions,
     dlight_intensities [B,L,3], dambient [B,3] or None); with want_light_grads=False the last three
     are None and the kernel leaves their accumulation out; want_normal_grads / want_diffuse_grads=False
@@ -635,7 +639,10 @@ def _shade_backward_call(drgba, ids, bary, clip, normals, positions, diffuse, tr
     holds the clip-space gradient pulled back through that product (the whole d / d world vertices).
 
     l1_signs: the packed sign codes of l1_loss_forward(rgba, target); `drgba` is then the 1-element
-    upstream gradient of that loss and the [B,H,W,4] gradient image is never materialised."""
+    upstream gradient of that loss and the [B,H,W,4] gradient image is never materialised.
+
+    normalised_gbuffer: ids / bary are what rasterize_forward / render_forward wrote for these vertices
+    (MR_GBUFFER_NORMALISED): the pixel pass leaves the alpha terms out, same bits."""
     tensors = [drgba, ids, bary, clip, normals, positions, diffuse, triangles, light_positions,
                light_intensities]
     B, V, _ = _chk_mesh(clip, triangles)
@@ -679,7 +686,8 @@ def _shade_backward_call(drgba, ids, bary, clip, normals, positions, diffuse, tr
         dd = None
     tail = (B, V, T, W, H, nl, _ptr(dclip), _ptr(dn), _ptr(dp), _ptr(dd), _ptr(lg), _ptr(corner_records),
             _ptr(adjacency[0]) if adjacency is not None else None,
-            _ptr(adjacency[1]) if adjacency is not None else None, _ptr(transforms))
+            _ptr(adjacency[1]) if adjacency is not None else None, _ptr(transforms),
+            GBUFFER_NORMALISED if normalised_gbuffer else 0)
     with torch.cuda.device(dev):
         _arm_timer(TIMER_SHADE_BACKWARD)
         _sync_deterministic()

@@ -31,7 +31,7 @@ extern thread_local int g_shade_backward_kernel;
 
 extern "C" {
 
-int mr_version(void) { return 341; /* 0.4.0: NULL attribute gradients, many lights, camera transforms, adjacency for the specular backward, wider deterministic mode */ }
+int mr_version(void) { return 342; /* 0.4.0: NULL attribute gradients, many lights, camera transforms, adjacency for the specular backward, wider deterministic mode */ }
 
 int mr_last_hip_error(void) { return mr::g_last_hip_error; }
 
@@ -262,8 +262,10 @@ int mr_shade_backward(const float *drgba, const int32_t *ids, const float *bary,
                       int W, int H, int L, float *dclip, float *dnormals, float *dpositions,
                       float *ddiffuse, float *light_grads, const void *corner_records,
                       const int32_t *vertex_offsets, const int32_t *vertex_entries,
-                      const float *transforms, void *workspace, size_t workspace_bytes, void *stream) {
-  if (bad_dims(B, V, T, W, H) || T < 1 || V < 1 || L < 1 || L > mr::shade_max_lights())
+                      const float *transforms, int gbuffer_flags, void *workspace, size_t workspace_bytes,
+                      void *stream) {
+  if (bad_dims(B, V, T, W, H) || T < 1 || V < 1 || L < 1 || L > mr::shade_max_lights() ||
+      (gbuffer_flags & ~MR_GBUFFER_NORMALISED))
     return MR_EINVAL;
   if (B == 0) return MR_OK;
   if (!drgba || !ids || !bary || !clip || !normals || !positions || !diffuse || !triangles ||
@@ -279,7 +281,8 @@ int mr_shade_backward(const float *drgba, const int32_t *ids, const float *bary,
   return mr::launch_shade_backward(drgba, nullptr, nullptr, ids, bary, clip, normals, positions, diffuse,
                                    triangles, light_positions, light_intensities, ambient, B, V, T, W, H, L,
                                    dclip, dnormals, dpositions, ddiffuse, light_grads, corner_records,
-                                   vertex_offsets, vertex_entries, transforms, workspace, (hipStream_t)stream);
+                                   vertex_offsets, vertex_entries, transforms, gbuffer_flags, workspace,
+                                   (hipStream_t)stream);
 }
 
 size_t mr_shade_backward_l1_workspace_bytes(int B, int V, int T, int W, int H) {
@@ -294,9 +297,10 @@ int mr_shade_backward_l1(const uint8_t *signs, const float *upstream, const int3
                          const float *ambient, int B, int V, int T, int W, int H, int L, float *dclip,
                          float *dnormals, float *dpositions, float *ddiffuse, float *light_grads,
                          const void *corner_records, const int32_t *vertex_offsets,
-                         const int32_t *vertex_entries, const float *transforms, void *workspace,
-                         size_t workspace_bytes, void *stream) {
-  if (bad_dims(B, V, T, W, H) || T < 1 || V < 1 || L < 1 || L > mr::shade_max_lights())
+                         const int32_t *vertex_entries, const float *transforms, int gbuffer_flags,
+                         void *workspace, size_t workspace_bytes, void *stream) {
+  if (bad_dims(B, V, T, W, H) || T < 1 || V < 1 || L < 1 || L > mr::shade_max_lights() ||
+      (gbuffer_flags & ~MR_GBUFFER_NORMALISED))
     return MR_EINVAL;
   if (B == 0) return MR_OK;
   if (!signs || !upstream || !ids || !bary || !clip || !normals || !positions || !diffuse || !triangles ||
@@ -312,7 +316,8 @@ int mr_shade_backward_l1(const uint8_t *signs, const float *upstream, const int3
   return mr::launch_shade_backward(nullptr, signs, upstream, ids, bary, clip, normals, positions, diffuse,
                                    triangles, light_positions, light_intensities, ambient, B, V, T, W, H, L,
                                    dclip, dnormals, dpositions, ddiffuse, light_grads, corner_records,
-                                   vertex_offsets, vertex_entries, transforms, workspace, (hipStream_t)stream);
+                                   vertex_offsets, vertex_entries, transforms, gbuffer_flags, workspace,
+                                   (hipStream_t)stream);
 }
 
 size_t mr_shade_specular_forward_workspace_bytes(int B, int V, int T, int W, int H) {

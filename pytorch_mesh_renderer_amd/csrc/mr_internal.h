@@ -125,7 +125,7 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
                           int H, int L, float *dclip, float *dnormals, float *dpositions,
                           float *ddiffuse, float *light_grads, const void *corner_records,
                           const int32_t *vertex_offsets, const int32_t *vertex_entries,
-                          const float *transforms, void *ws, hipStream_t s);
+                          const float *transforms, int gbuffer_flags, void *ws, hipStream_t s);
 
 int interp_raster_max_attrs();
 size_t interp_raster_backward_ws(int B, int V, int T, int W, int H, int A);

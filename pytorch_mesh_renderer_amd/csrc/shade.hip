@@ -240,8 +240,25 @@ struct ShadeGradFn {
 
   __device__ __forceinline__ void factors(const Pixel &p, const Triangle &t, float (&f)[kFactorStride],
                                           Image &im) const {
+    factors_of<false>(p, t, f, im);
+  }
+  // OPAQUE: the caller vouches that every covered pixel's barycentrics sum to more than 1/2, as those
+  // mr_rasterize_forward writes do (they are normalised: the sum is 1 to a few ulp).  Then alpha = clamp(2 sum)
+  // is exactly 1 and sits outside the clamp's pass band: attr = 1 * interp + 0 * (-1) = interp, d/d attr =
+  // 1 * dat, and nothing flows through alpha -- the same bits as the general path with ~45 of its ~235 vector
+  // instructions per pixel gone (the blend, the d/d alpha dot product, its reciprocal).
+  template <bool OPAQUE>
+  __device__ __forceinline__ void factors_of(const Pixel &p, const Triangle &t, float (&f)[kFactorStride],
+                                             Image &im) const {
     float pre, alpha, interp[9], at[9];
-    interpolate9(t.cr, p.b, pre, alpha, interp, at);
+    if (OPAQUE) {
+      pre = 2.0f;
+      alpha = 1.0f;
+#pragma unroll
+      for (int a = 0; a < 9; ++a) at[a] = (t.cr.c[0][a] * p.b.x + t.cr.c[1][a] * p.b.y) + t.cr.c[2][a] * p.b.z;
+    } else {
+      interpolate9(t.cr, p.b, pre, alpha, interp, at);
+    }
     // render.py:215 mask: where() sends no gradient to a masked pixel.  All 36 outputs are
     // linear in g, so a masked pixel simply runs with g = 0 (every output must be assigned).
     const bool mask = (at[6] >= 0.0f) || (at[7] >= 0.0f) || (at[8] >= 0.0f);
@@ -312,13 +329,13 @@ struct ShadeGradFn {
     f[0] = p.b.x; f[1] = p.b.y; f[2] = p.b.z;
 #pragma unroll
     for (int a = 0; a < 9; ++a) {
-      const float di = alpha * dat[a];
-      dalpha_a += dat[a] * (at[a] + 1.0f);  // background is -1
+      const float di = OPAQUE ? dat[a] : alpha * dat[a];
+      if (!OPAQUE) dalpha_a += dat[a] * (at[a] + 1.0f);  // background is -1
 #pragma unroll
       for (int k = 0; k < 3; ++k) db[k] += di * t.cr.c[k][a];
       f[3 + a] = di;  // d/d attr[corner k][a] = b_k * di: the product is formed in the reduction
     }
-    const float dpre = (pre >= 0.0f && pre <= 1.0f) ? 2.0f * dalpha_a * fast_rcp(alpha) : 0.0f;
+    const float dpre = (!OPAQUE && pre >= 0.0f && pre <= 1.0f) ? 2.0f * dalpha_a * fast_rcp(alpha) : 0.0f;
     F3 dbary;
     dbary.x = db[0] + dpre; dbary.y = db[1] + dpre; dbary.z = db[2] + dpre;
     // rasterizer backward (cpp:162 skip rule, then cpp:202-269)
@@ -370,7 +387,7 @@ struct ShadeGradFn {
 #ifndef MR_LANE_WAVES
 #define MR_LANE_WAVES 4
 #endif
-template <int L, bool SIGNS, bool LG, int GROUPS>
+template <int L, bool SIGNS, bool LG, int GROUPS, bool OPAQUE = false>
 struct ShadeLaneFn : ShadeGradFn<L, SIGNS, LG> {
   using Base = ShadeGradFn<L, SIGNS, LG>;
   static_assert(GROUPS >= 0 && GROUPS < 8, "attribute groups: normals | positions | diffuse");
@@ -401,7 +418,7 @@ struct ShadeLaneFn : ShadeGradFn<L, SIGNS, LG> {
   __device__ __forceinline__ void accumulate(const typename Base::Pixel &p, const typename Base::Triangle &t,
                                              float (&a)[kN], typename Base::Image &im) const {
     float f[Base::kFactorStride];
-    Base::factors(p, t, f, im);
+    Base::template factors_of<OPAQUE>(p, t, f, im);
 #pragma unroll
     for (int gi = 0; gi < kGroups; ++gi)
 #pragma unroll
@@ -625,7 +642,7 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
                           int H, int L, float *dclip, float *dnormals, float *dpositions,
                           float *ddiffuse, float *light_grads, const void *corner_records,
                           const int32_t *vertex_offsets, const int32_t *vertex_entries,
-                          const float *transforms, void *ws, hipStream_t s) {
+                          const float *transforms, int gbuffer_flags, void *ws, hipStream_t s) {
   if (B == 0) return MR_OK;
   if (transforms && !(vertex_offsets && vertex_entries)) return MR_EINVAL;  // the gather applies them
   const size_t v3 = (size_t)B * V * 3 * sizeof(float), v4 = (size_t)B * V * 4 * sizeof(float);
@@ -693,19 +710,22 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
   const int groups = (dnormals ? 1 : 0) | 2 | (ddiffuse ? 4 : 0);
   const bool lanes_exist = !light_grads && !det && groups != 6 && (groups != 7 || MR_SHADE_LANES_ALL);
   const bool use_lanes = lanes_exist && g_shade_backward_kernel != 1;
-#define MR_SHADE_LANES(NL, G)                                                                   \
+  const bool opaque = (gbuffer_flags & MR_GBUFFER_NORMALISED) != 0;  // (the lane kernels only)
+#define MR_SHADE_LANES_O(NL, G, OPQ)                                                            \
   {                                                                                             \
     KernelTimer timer(MR_TIMER_SHADE_BACKWARD, s);                                              \
     if (signs) {                                                                                \
-      ShadeLaneFn<NL, true, false, G> fn{{nullptr, signs, sign_upstream, sign_inv_n, ids, (const F3 *)bary, \
-                                          corners, recs, lights, nullptr, T, W, H}};            \
+      ShadeLaneFn<NL, true, false, G, OPQ> fn{{nullptr, signs, sign_upstream, sign_inv_n, ids, (const F3 *)bary, \
+                                               corners, recs, lights, nullptr, T, W, H}};       \
       rc = launch_accumulate_lanes(fn, B, T, W, H, acc, s);                                     \
     } else {                                                                                    \
-      ShadeLaneFn<NL, false, false, G> fn{{(const float4 *)drgba, nullptr, nullptr, 0.0f, ids, (const F3 *)bary, \
-                                           corners, recs, lights, nullptr, T, W, H}};           \
+      ShadeLaneFn<NL, false, false, G, OPQ> fn{{(const float4 *)drgba, nullptr, nullptr, 0.0f, ids, (const F3 *)bary, \
+                                                corners, recs, lights, nullptr, T, W, H}};      \
       rc = launch_accumulate_lanes(fn, B, T, W, H, acc, s);                                     \
     }                                                                                           \
   }
+#define MR_SHADE_LANES(NL, G)                                                                   \
+  if (opaque) MR_SHADE_LANES_O(NL, G, true) else MR_SHADE_LANES_O(NL, G, false)
 #if MR_SHADE_LANES_ALL
 #define MR_SHADE_LANES_G(NL)                                                                    \
   if (groups == 2) MR_SHADE_LANES(NL, 2) else if (groups == 3) MR_SHADE_LANES(NL, 3) else MR_SHADE_LANES(NL, 7)

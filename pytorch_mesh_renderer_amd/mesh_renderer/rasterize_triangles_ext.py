@@ -212,7 +212,8 @@ class FusedPhongRenderer(torch.autograd.Function):
             upstream, ids, bary, clip, normals, verts, diffuse, triangles, lp, li, amb,
             corner_records=corner_records, adjacency=(offsets, entries), l1_signs=l1_signs, transforms=xf,
             want_light_grads=needs_light_grads, want_normal_grads=needs_normal_grad,
-            want_diffuse_grads=needs_diffuse_grad)
+            want_diffuse_grads=needs_diffuse_grad,
+            normalised_gbuffer=True)   # this function's own forward wrote ids / bary
         dxf = None
         if needs_transform_grad:  # d clip[b,v,r] / d xf[b,r,k] = (vertex, 1)[k]
             ones = torch.ones(verts.shape[0], verts.shape[1], 1, dtype=verts.dtype, device=verts.device)

@@ -843,7 +843,7 @@ def test_shade_backward_lane_kernel_matches_rows_kernel(device, w, h, res, n_lig
     products the caller wants (autograd's needs_input_grad: d normals and / or d diffuse may be left
     out) stay in registers down each lane's vertical run -- instead of the rows kernel's 36 sums per
     row.  Same outputs as the rows kernel (forced through the debug hook) for both upstream forms; the
-    outputs left out are None.
+    outputs left out are None; and the same again with the G-buffer declared normalised.
     The 120-subdivision sphere at 64x64 has thousands of one-pixel runs per strip (merge-table
     overflow), (200, 150) spans several strips and a ragged last column block."""
     from pytorch_mesh_renderer_amd import _native
@@ -869,10 +869,12 @@ def test_shade_backward_lane_kernel_matches_rows_kernel(device, w, h, res, n_lig
             full = _native.shade_backward(upstream, *tail, **kw, **extra)
             assert all(float(full[k].abs().max()) > 0 for k in range(4))
             for want_n, want_d in ((False, False), (True, False), (True, True)):
-                for which in (1, 2):
-                    _native.debug_set_shade_backward_kernel(which)
+                # which = 3: the lane kernel told that the G-buffer is the rasterizer's own
+                # (MR_GBUFFER_NORMALISED: alpha = 1 exactly, its terms are left out) -- same outputs
+                for which in (1, 2, 3):
+                    _native.debug_set_shade_backward_kernel(min(which, 2))
                     lean = _native.shade_backward(upstream, *tail, **kw, **extra, want_normal_grads=want_n,
-                                                  want_diffuse_grads=want_d)
+                                                  want_diffuse_grads=want_d, normalised_gbuffer=which == 3)
                     assert (lean[3] is None) == (not want_d) and (lean[1] is None) == (not want_n)
                     for k in (0, 1, 2, 3):
                         if lean[k] is None:
