@@ -554,6 +554,7 @@ def interpolate_raster_backward(dout, ids, bary, clip, attrs, triangles, backgro
     dclip = torch.empty(B, V, 4, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         _sync_deterministic()
+        L.mr_debug_set_shade_backward_kernel(_shade_backward_kernel)
         need = L.mr_interpolate_raster_backward_workspace_bytes(B, V, T, W, H, A)
         ws, have = _workspace(dev, need)
         rc = L.mr_interpolate_raster_backward(

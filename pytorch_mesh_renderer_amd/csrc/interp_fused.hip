@@ -21,6 +21,7 @@
 
 namespace mr {
 extern thread_local int g_deterministic;  // mr_set_deterministic (shade.hip)
+extern thread_local int g_shade_backward_kernel;  // mr_debug_set_shade_backward_kernel (shade.hip): 1 = rows kernels
 namespace {
 
 constexpr int kThreads = 256;
@@ -213,6 +214,36 @@ struct AttrRowsFn {
   }
 };
 
+// The same pass through k_accumulate_lanes (run_accum.h, round 3): the 3 AP + 9 sums stay in registers for as
+// long as a lane stays on one triangle going down its column; only finished vertical runs go through LDS.
+// Measured at 1024^2 x 32, 5k triangles: A = 4 392 -> 348 us, A = 8 ~-4 %.  (Less than the shading backward
+// gained: SQ counters show this pass 53 % vector-busy at 3 waves per SIMD with ~40 branches and ~100 scalar
+// instructions per row -- it is bound by the row loop's control flow and the triangle records' round trip,
+// not by the reduction that the lane kernel removes.)
+#ifndef MR_ATTR_LANES_MAX_AP
+#define MR_ATTR_LANES_MAX_AP 8    // wider records stay on the rows kernel (AP = 12: 45 sums, 161 VGPRs, 17 KB of LDS
+                                  // per wavefront: 601 us against the rows kernel's 612 at 1024^2 x 32 -- no gain)
+#endif
+template <int AP>
+struct AttrLaneFn : AttrRowsFn<AP> {
+  using Base = AttrRowsFn<AP>;
+  static constexpr int kLaneRowsPerWave = 16;
+  static constexpr int kMinWavesPerSimd = AP <= 4 ? 4 : 3;   // 94 / 126 / 161 VGPRs for AP = 4 / 8 / 12 (LDS: 11 / 13 / 17 KB per wavefront)
+  __device__ static int column(int o) { return o; }
+  __device__ __forceinline__ void accumulate(const typename Base::Pixel &p, const typename Base::Triangle &t,
+                                             float (&a)[Base::kN], typename Base::Image &im) const {
+    float f[Base::kFactorStride];
+    Base::factors(p, t, f, im);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+      for (int c = 0; c < AP; ++c) a[k * AP + c] = fmaf(f[k], f[3 + c], a[k * AP + c]);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) a[3 * AP + k * 3 + c] = fmaf(f[k], f[3 + AP + c], a[3 * AP + k * 3 + c]);
+    }
+  }
+};
+
 // One thread per (image, vertex): sums the rows of the triangles incident to its vertex (CSR
 // adjacency: entry = 3 * triangle + corner).  Every output is written exactly once, no atomics.
 // DET (mr_set_deterministic): the rows hold 64-bit fixed-point sums (run_accum.h), converted here.
@@ -307,8 +338,18 @@ int run(const float *dout, const int32_t *ids, const float *bary, const float *c
     rc = setup_records<AP>(attrs, tris, B, V, T, A, corners, s);
     if (rc != MR_OK) return rc;
   }
-  AttrRowsFn<AP> fn{dout, ids, (const F3 *)bary, corners, recs, bg, A, T};
-  rc = launch_accumulate_rows(fn, B, T, W, H, acc, s, det ? det_block : nullptr);
+  if constexpr (AP <= MR_ATTR_LANES_MAX_AP) {
+    if (!det && g_shade_backward_kernel != 1) {   // (debug switch: 1 = rows kernel)
+      AttrLaneFn<AP> fn{{dout, ids, (const F3 *)bary, corners, recs, bg, A, T}};
+      rc = launch_accumulate_lanes(fn, B, T, W, H, acc, s);
+    } else {
+      AttrRowsFn<AP> fn{dout, ids, (const F3 *)bary, corners, recs, bg, A, T};
+      rc = launch_accumulate_rows(fn, B, T, W, H, acc, s, det ? det_block : nullptr);
+    }
+  } else {
+    AttrRowsFn<AP> fn{dout, ids, (const F3 *)bary, corners, recs, bg, A, T};
+    rc = launch_accumulate_rows(fn, B, T, W, H, acc, s, det ? det_block : nullptr);
+  }
   if (rc != MR_OK) return rc;
   const long nbv = (long)B * V;
   const dim3 grid((unsigned)((nbv + kThreads - 1) / kThreads));

@@ -951,6 +951,21 @@ def test_fused_rasterize_backward_matches_composed_ops(device, n_attrs):
     for name, got, want in zip(("out", "dvertices", "dattributes", "dbackground"), results[True], results[False]):
         assert np.abs(want).max() > 0, name
         np.testing.assert_allclose(got, want, atol=ATOL * 1e-2, rtol=1e-4, err_msg=name)
+    if n_attrs <= 8:
+        # round 3: up to 8 attributes the fused backward is the lane-accumulating kernel (AttrLaneFn);
+        # the rows kernel, forced through the debug switch, gives the same gradients
+        from pytorch_mesh_renderer_amd import _native
+        before = _native.debug_set_shade_backward_kernel(1)
+        try:
+            v = job["vertices"].clone().to(device).requires_grad_(True)
+            a = torch.rand(2, v.shape[1], n_attrs, generator=torch.Generator().manual_seed(7)).to(device).requires_grad_(True)
+            bg = torch.linspace(-1.0, 0.5, n_attrs).to(device).requires_grad_(True)
+            out = mesh_renderer.rasterize(v, a, job["triangles"].to(device), proj, 121, 87, bg)
+            torch.mean(torch.abs(out - target)).backward()
+        finally:
+            _native.debug_set_shade_backward_kernel(before)
+        for name, got, want in zip(("dvertices", "dattributes"), results[True][1:3], (v.grad, a.grad)):
+            np.testing.assert_allclose(got, want.cpu().numpy(), atol=ATOL * 1e-2, rtol=1e-4, err_msg="rows kernel " + name)
 
 
 @pytest.mark.parametrize("w,h", [(1, 1), (7, 3), (65, 2), (63, 65)])
