@@ -123,8 +123,9 @@ static void run(int32_t *ids, float *z, float *bary, int B, int W, int H) {
          kNames[MODE], bytes, total / reps, best, bytes / (total / reps * 1e-3) / 1e12, bytes / (best * 1e-3) / 1e12);
 }
 
-int main() {
-  const int B = 32, W = 1024, H = 1024;
+int main(int argc, char **argv) {
+  // default: configs[2]'s planes (32 x 1024^2); `store_patterns 8 2048 2048`: configs[3]'s per-GPU share, same pixels
+  const int B = argc > 3 ? atoi(argv[1]) : 32, W = argc > 3 ? atoi(argv[2]) : 1024, H = argc > 3 ? atoi(argv[3]) : 1024;
   const size_t px = (size_t)B * W * H;
   int32_t *ids;
   float *z, *bary;
