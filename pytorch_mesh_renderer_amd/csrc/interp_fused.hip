@@ -220,6 +220,9 @@ struct AttrRowsFn {
 // gained: SQ counters show this pass 53 % vector-busy at 3 waves per SIMD with ~40 branches and ~100 scalar
 // instructions per row -- it is bound by the row loop's control flow and the triangle records' round trip,
 // not by the reduction that the lane kernel removes.)
+#ifndef MR_ATTR_LANES_PIPELINED
+#define MR_ATTR_LANES_PIPELINED 0   // the two-rows-ahead row loop (run_accum.h): A = 4 1.11 -> 1.12 ms, A = 8 1.70 -> 1.78 (VGPRs 94 -> 102, 126 -> 140)
+#endif
 #ifndef MR_ATTR_LANES_MAX_AP
 #define MR_ATTR_LANES_MAX_AP 8    // wider records stay on the rows kernel (AP = 12: 45 sums, 161 VGPRs, 17 KB of LDS
                                   // per wavefront: 601 us against the rows kernel's 612 at 1024^2 x 32 -- no gain)
@@ -228,6 +231,7 @@ template <int AP>
 struct AttrLaneFn : AttrRowsFn<AP> {
   using Base = AttrRowsFn<AP>;
   static constexpr int kLaneRowsPerWave = 16;
+  static constexpr bool kPipelinedRows = MR_ATTR_LANES_PIPELINED != 0;
   static constexpr int kMinWavesPerSimd = AP <= 4 ? 4 : 3;   // 94 / 126 / 161 VGPRs for AP = 4 / 8 / 12 (LDS: 11 / 13 / 17 KB per wavefront)
   __device__ static int column(int o) { return o; }
   __device__ __forceinline__ void accumulate(const typename Base::Pixel &p, const typename Base::Triangle &t,

@@ -201,12 +201,18 @@ struct RasterRowsFn {
 // registers down its vertical run (RasterGradFn's accumulate()), only finished runs go through LDS.
 // Measured, whole mr_rasterize_backward call: 1024^2 x 32 / 5k triangles 0.310 -> 0.288 ms, 2048^2 x 8 /
 // 50k 0.364 -> 0.366, 256^2 x 8 0.054 -> (with the launch-size-dependent strip height) see DESIGN.
+// MR_RASTER_BWD_PIPELINED (second half of round 3): the row loop with the streamed planes two rows ahead and
+// unconditional record loads (run_accum.h, kPipelinedRows): 0.282 -> 0.267 ms, 0.366 -> 0.343.
+#ifndef MR_RASTER_BWD_PIPELINED
+#define MR_RASTER_BWD_PIPELINED 1
+#endif
 #ifndef MR_RASTER_LANE_ROWS
 #define MR_RASTER_LANE_ROWS 16
 #endif
 struct RasterLanesFn : RasterGradFn {
   static constexpr int kLaneRowsPerWave = MR_RASTER_LANE_ROWS;
   static constexpr bool kCountBackground = false;
+  static constexpr bool kPipelinedRows = MR_RASTER_BWD_PIPELINED != 0;
   __device__ static int column(int o) { return o; }
   struct Image { int n_bg; };
   __device__ __forceinline__ void begin_image(int, Image &) const {}

@@ -498,6 +498,14 @@ constexpr int lanes_park_stride(int n) {  // multiple of 4 with an odd number of
   return s * 4;
 }
 
+// Fn::kPipelinedRows (optional member, default false): see the pipelined row loop in k_accumulate_lanes
+template <class Fn, class = void>
+struct LanesPipelined { static constexpr bool value = false; };
+template <class Fn>
+struct LanesPipelined<Fn, decltype((void)Fn::kPipelinedRows)> { static constexpr bool value = Fn::kPipelinedRows; };
+template <class Fn>
+constexpr bool lanes_pipelined() { return LanesPipelined<Fn>::value; }
+
 template <class Fn, bool DET>
 __global__ __launch_bounds__(kWave, Fn::kMinWavesPerSimd) void k_accumulate_lanes(
     Fn fn, int T, int W, int H, int regions_x, int regions_per_image, int n_regions,
@@ -562,7 +570,7 @@ __global__ __launch_bounds__(kWave, Fn::kMinWavesPerSimd) void k_accumulate_lane
   // A segment's sum goes into its triangle's merge-table slot with ONE LDS operation that returns
   // nothing (ds_add_f32, or a plain store into a slot claimed by this segment): nothing to wait for.
   constexpr int kDense = MR_LANES_DENSE;
-  auto flush = [&](const bool fin) {
+  auto flush = [&](const bool fin) __attribute__((always_inline)) {
     const unsigned long long finm = __ballot(fin);
     if (!finm) return;
     const bool dense = (int)__builtin_popcountll(finm) >= kDense;  // wave-uniform
@@ -676,6 +684,48 @@ __global__ __launch_bounds__(kWave, Fn::kMinWavesPerSimd) void k_accumulate_lane
   };
 
   size_t pix = ((size_t)img * H + y_begin) * W + xc;
+  if constexpr (lanes_pipelined<Fn>()) {
+    // Streamed planes TWO rows ahead (functors whose pixel math is light).  vmcnt retires loads in issue
+    // order: in the plain loop below the wait for a row's triangle records (an L2 round trip) also drains the
+    // next row's G-buffer / upstream loads issued just before them (an HBM round trip), so every row costs
+    // one HBM latency (~1.9 us per row and wavefront at 1024^2 x 32, 66 % of the wave-cycles waiting).
+    // Here a row's streamed values are requested two iterations before they are used, AFTER that
+    // iteration's record loads, into the register set whose row has just been unpacked by prepare():
+    // two sets used alternately by an iteration pair -- copying a pending load's destination would make
+    // the compiler wait for it.
+    typename Fn::Raw raw_a, raw_b;   // raw_a: rows y_begin, + 2, ...; raw_b: rows y_begin + 1, + 3, ...
+    if (y_begin < y_end) fn.fetch(img, xc, y_begin, pix, raw_a);
+    if (y_begin + 1 < y_end) fn.fetch(img, xc, y_begin + 1, pix + W, raw_b);
+    auto row = [&](const int y, typename Fn::Raw &raw) __attribute__((always_inline)) {
+      int tri = -1;
+      typename Fn::Pixel p;
+      const bool valid = fn.prepare(raw, T, tri, p) && in_range;
+      if (Fn::kCountBackground && in_range && !valid) image_sums.n_bg += 1;
+      const bool any = __ballot(valid) != 0ull;
+      // EVERY lane (re)loads its row's records, with no branch around the loads: behind `if (tri !=
+      // data_tri)` hipcc loads into temporaries and copies them into tri_data inside the branch -- an
+      // s_waitcnt right behind the loads, the whole L2 round trip exposed.  Unconditional loads land in
+      // tri_data's registers and are waited for where accumulate() first uses them, after the refill below
+      // has been issued and the flush has run.  (Lanes without a pixel re-read the record they hold.)
+      data_tri = valid ? tri : max(data_tri, 0);
+      fn.load_triangle(img, data_tri, tri_data);
+      if (y + 2 < y_end) fn.fetch(img, xc, y + 2, pix + 2 * (size_t)W, raw);  // refill: row y + 2
+      pix += W;
+      if (!any) return;  // nothing in this row segment (background); open runs stay open
+      // (requesting the refill after the flush instead -- straight-line code away from accumulate()'s wait --
+      //  measured slower: 0.268 -> 0.275 ms; hipcc's vmcnt placement around the flush's branches and atomics
+      //  is conservative either way)
+      flush(valid && run_tri >= 0 && tri != run_tri);
+      if (valid) {
+        run_tri = tri;
+        fn.accumulate(p, tri_data, a, image_sums);
+      }
+    };
+    for (int y = y_begin; y < y_end; y += 2) {  // wave-uniform trip count
+      row(y, raw_a);
+      if (y + 1 < y_end) row(y + 1, raw_b);
+    }
+  } else {
   typename Fn::Raw raw_next;
   if (y_begin < y_end) fn.fetch(img, xc, y_begin, pix, raw_next);
   for (int y = y_begin; y < y_end; ++y, pix += W) {  // wave-uniform trip count
@@ -713,6 +763,7 @@ __global__ __launch_bounds__(kWave, Fn::kMinWavesPerSimd) void k_accumulate_lane
       run_tri = tri;
       fn.accumulate(p, tri_data, a, image_sums);
     }
+  }
   }
   flush(run_tri >= 0);
   flush_merge_table();
