@@ -265,6 +265,10 @@ def main():
     device = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(device)
 
+    # the timed step computes its camera matrices every time, as the reference would: the library's memo for
+    # unchanged host-side cameras (camera_utils.CACHE_HOST_CAMERAS) stays out of the measurement
+    from pytorch_mesh_renderer_amd.common import camera_utils
+    camera_utils.CACHE_HOST_CAMERAS = False
     entry, batch, width, height, sphere_k = CONFIGS[args.config]
     job = synthetic.sphere_job(batch, width, height, sphere_k)
     if world > 1:  # every rank renders its own `batch` jobs: rotate the orbit per rank

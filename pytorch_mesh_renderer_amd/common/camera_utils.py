@@ -8,6 +8,7 @@ HBM.  All functions are plain differentiable torch ops (the examples optimise
 camera position and Euler angles through them).
 """
 import math
+import threading
 
 import torch
 
@@ -156,6 +157,12 @@ def clip_space_transforms(camera_position, camera_lookat, camera_up, fov_y, near
     device synchronisation in the middle of a render.  Cameras that live on the GPU (e.g. when
     they are being optimised there) stay on the GPU and remain differentiable either way."""
     cam_device = camera_position.device
+    host_key = _host_camera_key(camera_position, camera_lookat, camera_up, fov_y, near_clip, far_clip,
+                                aspect_ratio, device)
+    if host_key is not None:
+        hit = _host_camera_lookup(host_key)
+        if hit is not None:
+            return hit
     if cam_device.type == "cuda" and USE_CAMERA_KERNEL:
         # round 3: ~30 tiny launches (+0.45 ms on a 1.2 ms SoftRas step) become one each way
         transforms = _device_cameras(camera_position, camera_lookat, camera_up, fov_y, near_clip, far_clip,
@@ -165,4 +172,46 @@ def clip_space_transforms(camera_position, camera_lookat, camera_up, fov_y, near
     to_cam = lambda t: t.to(cam_device)
     view = look_at(camera_position, to_cam(camera_lookat), to_cam(camera_up))
     proj = perspective(aspect_ratio, to_cam(fov_y), to_cam(near_clip), to_cam(far_clip))
-    return torch.matmul(proj, view).to(device, non_blocking=True)
+    out = torch.matmul(proj, view).to(device, non_blocking=True)
+    if host_key is not None:
+        _host_camera_store(host_key, out)
+    return out
+
+
+# Host-side cameras that do not change between calls (the usual optimisation loop moves the mesh, not the
+# cameras): ~30 tiny CPU tensor ops and an upload per render() -- 0.12 of a launch-bound step's 0.32 ms on a
+# 64^2 scene.  The last result is kept per thread and returned when ALL camera inputs compare equal BY VALUE
+# (a few microseconds for [B,3] tensors; identity or version counters would miss writes through `.data`).
+# Never used for cameras that require gradients or live on a device.  CACHE_HOST_CAMERAS = False turns it
+# off (bench.py does: its timed step recomputes the cameras like the reference would).
+CACHE_HOST_CAMERAS = True
+_host_cache = threading.local()
+
+
+def _host_camera_key(camera_position, camera_lookat, camera_up, fov_y, near_clip, far_clip, aspect_ratio, device):
+    if not CACHE_HOST_CAMERAS or not isinstance(aspect_ratio, (int, float)):
+        return None
+    tensors = (camera_position, camera_lookat, camera_up, fov_y, near_clip, far_clip)
+    for t in tensors:
+        if not torch.is_tensor(t) or t.device.type != "cpu" or t.requires_grad:
+            return None
+    return tensors, float(aspect_ratio), torch.device(device)
+
+
+def _host_camera_lookup(key):
+    entry = getattr(_host_cache, "entry", None)
+    if entry is None:
+        return None
+    tensors, aspect, device = key
+    kept, kept_aspect, kept_device, out = entry
+    if aspect != kept_aspect or device != kept_device:
+        return None
+    for a, b in zip(tensors, kept):
+        if a.shape != b.shape or a.dtype != b.dtype or not torch.equal(a, b):
+            return None
+    return out
+
+
+def _host_camera_store(key, out):
+    tensors, aspect, device = key
+    _host_cache.entry = (tuple(t.detach().clone() for t in tensors), aspect, device, out)

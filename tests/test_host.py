@@ -277,3 +277,32 @@ def test_render_refuses_mismatched_inputs_on_the_host():
         mesh_renderer.render(v, tris, n, kd, eye, center, up, lp, li, 8, 8)
     with pytest.raises(ValueError):
         mesh_renderer.render(v, tris.int()[:, :2], n, kd, eye, center, up, lp, li, 8, 8)
+
+
+def test_host_camera_transforms_are_memoised_by_value():
+    """Round 3: clip_space_transforms keeps the last result for host-side cameras and returns it while all
+    camera inputs compare equal by value -- a write through `.data` (no version bump) is seen, cameras that
+    require gradients are never served from it, CACHE_HOST_CAMERAS = False switches it off."""
+    from pytorch_mesh_renderer_amd.common import camera_utils as cu
+    eye = torch.tensor([[0.0, 0.0, 3.0], [1.0, 0.0, 3.0]])
+    center, up = torch.zeros(2, 3), torch.tensor([[0.0, 1.0, 0.0]]).repeat(2, 1)
+    fov, near, far = torch.tensor([40.0, 40.0]), torch.tensor([0.01, 0.01]), torch.tensor([10.0, 10.0])
+    cpu = torch.device("cpu")
+    before = cu.CACHE_HOST_CAMERAS
+    cu.CACHE_HOST_CAMERAS = True
+    try:
+        first = cu.clip_space_transforms(eye, center, up, fov, near, far, 1.5, cpu)
+        assert cu.clip_space_transforms(eye.clone(), center, up, fov, near, far, 1.5, cpu) is first
+        assert cu.clip_space_transforms(eye, center, up, fov, near, far, 1.25, cpu) is not first   # other aspect
+        cu.clip_space_transforms(eye, center, up, fov, near, far, 1.5, cpu)
+        eye.data[0, 0] = 0.5
+        moved = cu.clip_space_transforms(eye, center, up, fov, near, far, 1.5, cpu)
+        want = torch.matmul(cu.perspective(1.5, fov, near, far), cu.look_at(eye, center, up))
+        assert torch.equal(moved, want) and not torch.equal(moved, first)
+        grad_eye = eye.clone().requires_grad_(True)
+        live = cu.clip_space_transforms(grad_eye, center, up, fov, near, far, 1.5, cpu)
+        assert live.requires_grad and live is not moved
+        cu.CACHE_HOST_CAMERAS = False
+        assert cu.clip_space_transforms(eye, center, up, fov, near, far, 1.5, cpu) is not moved
+    finally:
+        cu.CACHE_HOST_CAMERAS = before
