@@ -837,7 +837,7 @@ def test_render_forward_matches_raster_then_shade(device, w, h, res, n_lights, a
 
 @pytest.mark.parametrize("w,h,res,n_lights,ambient", [(96, 80, 12, 1, False), (130, 67, 10, 3, True),
                                                         (64, 64, 120, 2, True), (33, 31, 6, 4, False),
-                                                        (200, 150, 50, 1, False)])
+                                                        (200, 150, 50, 1, False), (80, 56, 10, 6, True)])
 def test_shade_backward_lane_kernel_matches_rows_kernel(device, w, h, res, n_lights, ambient):
     """Round 3: without light gradients mr_shade_backward runs k_accumulate_lanes -- the 18 / 27 / 36
     products the caller wants (autograd's needs_input_grad: d normals and / or d diffuse may be left
