@@ -384,6 +384,12 @@ struct ShadeGradFn {
 #define MR_SHADE_LANES_ALL 1   // the 36-sum variant too (every attribute gradient wanted; three waves per SIMD):
                                // 0.405 -> 0.385 ms sign-coded, 0.430 -> 0.399 dense upstream (whole call, 1024^2 x 32)
 #endif
+#ifndef MR_LANE_ROWS_LG
+#define MR_LANE_ROWS_LG 16
+#endif
+#ifndef MR_SHADE_LANES_LG
+#define MR_SHADE_LANES_LG 1
+#endif
 #ifndef MR_LANE_WAVES
 #define MR_LANE_WAVES 4
 #endif
@@ -394,8 +400,9 @@ struct ShadeLaneFn : ShadeGradFn<L, SIGNS, LG> {
   static constexpr int kGroups = (GROUPS & 1) + ((GROUPS >> 1) & 1) + ((GROUPS >> 2) & 1);
   static constexpr int kN = 9 * kGroups + 9;
   static constexpr int kStride = 36;  // the rows of acc keep ShadeGradFn's layout: the gather reads it
-  static constexpr int kLaneRowsPerWave = LG ? 32 : MR_LANE_ROWS;
-  static constexpr int kMinWavesPerSimd = kN > 27 ? 3 : MR_LANE_WAVES;  // 36 accumulators: 137-145 VGPRs
+  static constexpr int kLaneRowsPerWave = LG ? MR_LANE_ROWS_LG : MR_LANE_ROWS;
+  // 36 accumulators: 137-145 VGPRs; with light gradients 6 L + 3 more per-lane sums ride along
+  static constexpr int kMinWavesPerSimd = LG ? 3 : (kN > 27 ? 3 : MR_LANE_WAVES);   // LG: 134-161 VGPRs
   // the gi-th selected group
   __host__ __device__ static constexpr int group(int gi) {
     int g = 0;
@@ -546,8 +553,13 @@ inline unsigned capped_blocks(size_t n) {
 inline size_t shade_acc_bytes(int B, int T) { return align_up((size_t)B * T * 36 * sizeof(long long), 256); }
 constexpr size_t kDetMiscBytes = 512;  // det_scale (2 floats), max bits (1 int)
 // one row of light sums per strip of the pixel pass (the variant with light gradients walks 16-row strips)
+struct LightGradLaneGeometry { static constexpr int kLaneRowsPerWave = MR_LANE_ROWS_LG; };  // = ShadeLaneFn<..., LG = true, ...>'s strips
+inline int light_strips_per_image(int B, int W, int H, bool lanes) {
+  return lanes ? lanes_strips_per_image<LightGradLaneGeometry>(B, W, H) : strips_per_image<ShadeGradFn<1, true, true>>(W, H);
+}
 inline size_t light_rows_bytes(int B, int W, int H) {
-  return align_up((size_t)B * strips_per_image<ShadeGradFn<1, true, true>>(W, H) * (kMaxLights * 6 + 3) * sizeof(float), 256);
+  const int strips = max(light_strips_per_image(B, W, H, true), light_strips_per_image(B, W, H, false));
+  return align_up((size_t)B * strips * (kMaxLights * 6 + 3) * sizeof(float), 256);
 }
 
 // ---- deterministic mode helpers -------------------------------------------------------------
@@ -708,7 +720,9 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
   // writes all of them.
   if ((!dnormals || !ddiffuse) && !(vertex_offsets && vertex_entries)) return MR_EINVAL;
   const int groups = (dnormals ? 1 : 0) | 2 | (ddiffuse ? 4 : 0);
-  const bool lanes_exist = !light_grads && !det && groups != 6 && (groups != 7 || MR_SHADE_LANES_ALL);
+  // with light gradients: one or two lights (6 L + 3 more per-lane sums; three and four stay on the rows kernel)
+  const bool lanes_exist = (!light_grads || (MR_SHADE_LANES_LG && L <= 2)) && !det && groups != 6 &&
+                           (groups != 7 || MR_SHADE_LANES_ALL);
   const bool use_lanes = lanes_exist && g_shade_backward_kernel != 1;
   const bool opaque = (gbuffer_flags & MR_GBUFFER_NORMALISED) != 0;  // (the lane kernels only)
 #define MR_SHADE_LANES_O(NL, G, OPQ)                                                            \
@@ -724,19 +738,38 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
       rc = launch_accumulate_lanes(fn, B, T, W, H, acc, s);                                     \
     }                                                                                           \
   }
+#define MR_SHADE_LANES_LGV(NL, G)                                                               \
+  {                                                                                             \
+    KernelTimer timer(MR_TIMER_SHADE_BACKWARD, s);                                              \
+    if (signs) {                                                                                \
+      ShadeLaneFn<NL, true, true, G, false> fn{{nullptr, signs, sign_upstream, sign_inv_n, ids, (const F3 *)bary, \
+                                                corners, recs, lights, light_rows, T, W, H}};   \
+      rc = launch_accumulate_lanes(fn, B, T, W, H, acc, s);                                     \
+    } else {                                                                                    \
+      ShadeLaneFn<NL, false, true, G, false> fn{{(const float4 *)drgba, nullptr, nullptr, 0.0f, ids, (const F3 *)bary, \
+                                                 corners, recs, lights, light_rows, T, W, H}};  \
+      rc = launch_accumulate_lanes(fn, B, T, W, H, acc, s);                                     \
+    }                                                                                           \
+  }
 #define MR_SHADE_LANES(NL, G)                                                                   \
   if (opaque) MR_SHADE_LANES_O(NL, G, true) else MR_SHADE_LANES_O(NL, G, false)
+#define MR_SHADE_LANES_LIGHTS(NL, G)   /* one or two lights: the variant with light gradients exists */ \
+  if (light_grads) MR_SHADE_LANES_LGV(NL, G) else MR_SHADE_LANES(NL, G)
 #if MR_SHADE_LANES_ALL
 #define MR_SHADE_LANES_G(NL)                                                                    \
   if (groups == 2) MR_SHADE_LANES(NL, 2) else if (groups == 3) MR_SHADE_LANES(NL, 3) else MR_SHADE_LANES(NL, 7)
+#define MR_SHADE_LANES_GL(NL)                                                                   \
+  if (groups == 2) MR_SHADE_LANES_LIGHTS(NL, 2) else if (groups == 3) MR_SHADE_LANES_LIGHTS(NL, 3) else MR_SHADE_LANES_LIGHTS(NL, 7)
 #else
 #define MR_SHADE_LANES_G(NL)                                                                    \
   if (groups == 2) MR_SHADE_LANES(NL, 2) else MR_SHADE_LANES(NL, 3)
+#define MR_SHADE_LANES_GL(NL)                                                                   \
+  if (groups == 2) MR_SHADE_LANES_LIGHTS(NL, 2) else MR_SHADE_LANES_LIGHTS(NL, 3)
 #endif
   if (use_lanes) {
     switch (L) {
-      case 1: MR_SHADE_LANES_G(1); break;
-      case 2: MR_SHADE_LANES_G(2); break;
+      case 1: MR_SHADE_LANES_GL(1); break;
+      case 2: MR_SHADE_LANES_GL(2); break;
       case 3: MR_SHADE_LANES_G(3); break;
       case 4: MR_SHADE_LANES_G(4); break;
       default: MR_SHADE_LANES_G(0); break;  // 5..kMaxLightsAny lights: run-time loop
@@ -787,8 +820,7 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
 #undef MR_SHADE_LANES
   if (rc != MR_OK) return rc;
   if (light_grads) {  // the strips' rows of light sums -> [B][6L + 3], fixed order (every element is written)
-    rc = launch_sum_strip_rows(light_rows, B, strips_per_image<ShadeGradFn<1, true, true>>(W, H), L * 6 + 3,
-                               light_grads, s);
+    rc = launch_sum_strip_rows(light_rows, B, light_strips_per_image(B, W, H, use_lanes), L * 6 + 3, light_grads, s);
     if (rc != MR_OK) return rc;
   }
   if (vertex_offsets && vertex_entries) {

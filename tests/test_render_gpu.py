@@ -882,6 +882,22 @@ def test_shade_backward_lane_kernel_matches_rows_kernel(device, w, h, res, n_lig
                         scale = float(full[k].abs().max())
                         np.testing.assert_allclose(lean[k].cpu().numpy(), full[k].cpu().numpy(), rtol=2e-4,
                                                    atol=2e-6 * scale, err_msg="output %d kernel %d" % (k, which))
+            if n_lights <= 2:
+                # second half of round 3: with one or two lights the lane kernel also carries the light
+                # gradients (6 L + 3 per-lane sums, one row per strip) -- against the rows kernel
+                kw_l = dict(kw, want_light_grads=True)
+                _native.debug_set_shade_backward_kernel(1)
+                rows = _native.shade_backward(upstream, *tail, **kw_l, **extra)
+                _native.debug_set_shade_backward_kernel(2)
+                lanes = _native.shade_backward(upstream, *tail, **kw_l, **extra)
+                for k, (a, b) in enumerate(zip(lanes, rows)):
+                    if b is None:
+                        assert a is None
+                        continue
+                    scale = float(b.abs().max())
+                    assert scale > 0 or k >= 4, k
+                    np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-4, atol=2e-6 * scale + 1e-12,
+                                               err_msg="light-gradient variant, output %d" % k)
     finally:
         _native.debug_set_shade_backward_kernel(0)
 
