@@ -188,6 +188,15 @@ CACHE_HOST_CAMERAS = True
 _host_cache = threading.local()
 
 
+def _resolved_device(device):
+    """`device` with an explicit index: an index-less 'cuda' means the CURRENT device, which changes
+    with torch.cuda.set_device() -- a key without the index would hand out a tensor on the old GPU."""
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    return device
+
+
 def _host_camera_key(camera_position, camera_lookat, camera_up, fov_y, near_clip, far_clip, aspect_ratio, device):
     if not CACHE_HOST_CAMERAS or not isinstance(aspect_ratio, (int, float)):
         return None
@@ -195,7 +204,13 @@ def _host_camera_key(camera_position, camera_lookat, camera_up, fov_y, near_clip
     for t in tensors:
         if not torch.is_tensor(t) or t.device.type != "cpu" or t.requires_grad:
             return None
-    return tensors, float(aspect_ratio), torch.device(device)
+    device = _resolved_device(device)
+    # A stream capture must not see the memo at all: a graph would bake in the kept tensor's
+    # address, and the next eager call with other cameras frees that tensor under the graph's replays.
+    # (Without the memo a capture with host cameras fails loudly at the upload, as it always did.)
+    if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+        return None
+    return tensors, float(aspect_ratio), device
 
 
 def _host_camera_lookup(key):
@@ -203,15 +218,26 @@ def _host_camera_lookup(key):
     if entry is None:
         return None
     tensors, aspect, device = key
-    kept, kept_aspect, kept_device, out = entry
+    kept, kept_aspect, kept_device, out, version, ready = entry
     if aspect != kept_aspect or device != kept_device:
+        return None
+    if out._version != version:   # somebody edited the kept result in place: it is no longer the cameras' matrix
+        _host_cache.entry = None
         return None
     for a, b in zip(tensors, kept):
         if a.shape != b.shape or a.dtype != b.dtype or not torch.equal(a, b):
             return None
+    if ready is not None:
+        # the upload ran on the stream of the call that stored it; a hit on any other stream (a user
+        # stream, ImageGather's side stream) must be ordered behind it
+        torch.cuda.current_stream(device).wait_event(ready)
     return out
 
 
 def _host_camera_store(key, out):
     tensors, aspect, device = key
-    _host_cache.entry = (tuple(t.detach().clone() for t in tensors), aspect, device, out)
+    ready = None
+    if device.type == "cuda":
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(device))
+    _host_cache.entry = (tuple(t.detach().clone() for t in tensors), aspect, device, out, out._version, ready)

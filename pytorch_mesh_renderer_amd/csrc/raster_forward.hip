@@ -531,6 +531,20 @@ struct RasterShade {
                                    // G-buffer kernel 0.189 -> 0.164 / 0.161 -> 0.160 (never slower; barycentrics or the
                                    // depth plane cached: slower or equal)
 #endif
+#ifndef MR_BARY_STAGE
+#define MR_BARY_STAGE 0  // round 4 (measured, OFF: WRITE_SIZE unchanged at 1.19x, kernel +3 %): the barycentric plane leaves as 16-byte-per-lane stores after a transpose through
+                         // LDS (see "staged barycentric store" in k_raster) instead of one 12-byte store per lane
+#endif
+#ifndef MR_INTERLEAVE_EMPTY
+#define MR_INTERLEAVE_EMPTY 0  // measured, OFF: empty regions spread evenly over the order instead of closing it --
+                               // G-buffer kernel 0.1586 -> 0.1635 ms, fused forward 0.2366 -> 0.2421 (same box)
+#endif
+#ifndef MR_EMPTY_FAST
+#define MR_EMPTY_FAST 1        // see "empty regions" in k_raster: 0.1589 -> 0.1573 ms (same box)
+#endif
+#ifndef MR_RASTER_STORE_AUX_Z
+#define MR_RASTER_STORE_AUX_Z MR_RASTER_STORE_AUX
+#endif
 #ifndef MR_RASTER_SHADE_WAVES
 #define MR_RASTER_SHADE_WAVES 6  // measured against 7 (more spills) and 5: 0.336 / 0.352 / 0.347 ms at 1024^2 x 32
 #endif
@@ -552,7 +566,7 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : MR_RASTER
   // barycentric triples); with 8 x 8 tiles two wavefronts shared each sector and the L2 had to
   // merge their halves (measured: the kernel ran FASTER with fewer workgroups in flight).
   constexpr int kTileW = MR_TILE_W, kTileH = kWave / kTileW;
-  static_assert(kTileW == 8 || kTileW == 16, "tile width");
+  static_assert(kTileW == 8 || kTileW == 16 || kTileW == 32, "tile width");
   constexpr int kTilesX = R / kTileW, kTilesY = R / kTileH;
   constexpr int kTiles = kTilesX * kTilesY;  // tiles per region: 64 or 16
   constexpr int kMaskWords = kBin2Cap / 32;
@@ -582,6 +596,23 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : MR_RASTER
     if (xcd * regions_per_xcd + pos >= n_regions || pos >= regions_per_xcd) return;  // padding block (whole workgroup)
     const int32_t *counts = order_count + xcd * kWeightClasses;
     int cls = 0;
+#if MR_INTERLEAVE_EMPTY
+    // Round 4: the EMPTY regions (last class: no candidate at all -- pure stores of the cleared G-buffer, a
+    // quarter of the benchmark's pixels) are spread evenly over the XCD's order instead of closing it: taken
+    // last, the launch ended in a phase that only stored while the vector units idled, after a phase that
+    // computed with the memory pipeline half empty.  Slot p of N is an empty one iff floor((p+1) E / N) >
+    // floor(p E / N); the other slots keep the heaviest-first order.
+    {
+      const int n_here = min(regions_per_xcd, n_regions - xcd * regions_per_xcd);
+      const int n_empty = counts[kWeightClasses - 1];
+      if (n_empty > 0 && n_empty < n_here) {
+        const int before = (int)((long)pos * n_empty / n_here), through = (int)((long)(pos + 1) * n_empty / n_here);
+        if (through > before) { cls = kWeightClasses - 1; pos = before; }
+        else pos -= before;
+      }
+    }
+    if (cls == 0)
+#endif
 #pragma unroll
     for (int c = 0; c < kWeightClasses - 1; ++c) {
       const int n = counts[c];   // wave-uniform scalar loads
@@ -710,6 +741,31 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : MR_RASTER
 #endif
   typedef float v3f __attribute__((ext_vector_type(3)));
   typedef unsigned v3u __attribute__((ext_vector_type(3)));
+#if MR_EMPTY_FAST
+  // Empty regions (round 4): no candidate at all -- the cleared G-buffer (id 0, depth 1, barycentrics 0;
+  // cpp:313-321) and, with the shading epilogue, transparent black.  The values do not depend on the lane,
+  // so the lanes are laid along the region's ROWS: every store instruction covers 64 / R whole rows of the
+  // region, one contiguous run each (256 B of ids / depths, 768 B of barycentrics, 1 KB of RGBA at R = 64)
+  // instead of a tile's 64- / 192-byte pieces, and none of the bin / mask / walk machinery runs.
+  if (PROBE == 0 && n_cand == 0 && X1 - X0 == R && Y1 - Y0 == R) {  // workgroup-uniform
+    constexpr int kRowsPerInst = kWave / R;
+    const int x = lane % R;
+    for (int y = wave * kRowsPerInst + lane / R; y < R; y += kWaves * kRowsPerInst) {
+      const unsigned pix = (unsigned)(y * W + x);
+      __builtin_amdgcn_raw_buffer_store_b32(0u, rs_ids, pix * 4u, 0, MR_RASTER_STORE_AUX_IDS);
+      if (!SHADE || shade.keep_z)
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, 1.0f), rs_z, pix * 4u, 0, MR_RASTER_STORE_AUX_Z);
+      __builtin_amdgcn_raw_buffer_store_b96(v3u{0u, 0u, 0u}, rs_bary, pix * 12u, 0, MR_RASTER_STORE_AUX);
+      if constexpr (SHADE) {
+        typedef unsigned v4u __attribute__((ext_vector_type(4)));
+        __builtin_amdgcn_raw_buffer_store_b128(v4u{0u, 0u, 0u, 0u}, rs_rgba, (unsigned)((R - 1 - y) * W + x) * 16u, 0,
+                                               MR_RASTER_STORE_AUX);
+        if (shade.rgba8) __builtin_nontemporal_store(0u, &shade.rgba8[img_px + (size_t)(H - 1 - (Y0 + y)) * W + X0 + x]);
+      }
+    }
+    return;
+  }
+#endif
   // Every wavefront of this kernel is fully populated (256-thread workgroups, padding workgroups
   // leave as a whole), so EXEC is all ones in wave-uniform code: the coverage loop restores it
   // with a constant after its v_cmpx chain.
@@ -722,8 +778,23 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : MR_RASTER
   const unsigned *lane_word = (const unsigned *)lane_px + 2 * R;  // &s_tmask[0][lx]
   // `full`: the region lies wholly inside the image (all but the last column / row of regions of
   // an image whose size is not a multiple of R): no per-tile or per-lane bounds tests at all.
-  auto raster_pass = [&](auto fresh_tag, auto full_tag, const int far_word, const bool last_round) {
+  // Staged barycentric store (round 4).  One 12-byte store per lane puts lane boundaries inside 32-byte
+  // sectors (lane 2 covers bytes 24..35, ...): the memory pipeline forwards the nontemporal store in groups
+  // of lanes, a sector shared by two groups goes to memory twice as two partial writes, and WRITE_SIZE
+  // showed 796 MB leaving for a 671 MB G-buffer (profiles/kernel_traffic.json, r03: +1/3 of the 403 MB
+  // barycentric plane) -- in a kernel that an empty, store-only walk already takes 134 of its 148 us.
+  // A tile's 64 x 3 floats are four rows of 192 contiguous bytes: each lane parks its triple at
+  // 12 * lane of a 768-byte LDS slot private to its wavefront (stride 3 dwords: conflict-free) and lanes
+  // with lx < 12 read 16 bytes back at 192 ly + 16 lx = 12 * lane + 4 lx and store them at the same
+  // offset of the tile: 48 lanes x 16 bytes, every lane inside one sector, every sector written whole.
+  // The slots are the top 3 KB of the entry bin (no LDS beyond the 18 granules the seven workgroups per
+  // CU leave): `stage` is set while the bin's entries end below them (~40 of 256 used at 1024^2 / 5k
+  // triangles), a crowded bin keeps the per-lane store.  Only whole-region (`full`) walks stage.
+  constexpr int kStageDw = 3 * kWave;                                   // per wavefront
+  constexpr int kStageEntries = (kWaves * kStageDw + kEntryDw - 1) / kEntryDw;  // bin entries the slots overlay
+  auto raster_pass = [&](auto fresh_tag, auto full_tag, auto stage_tag, const int far_word, const bool last_round) {
     constexpr bool fresh = decltype(fresh_tag)::value, full = decltype(full_tag)::value;
+    constexpr bool stage = MR_BARY_STAGE && decltype(stage_tag)::value && full && !(PROBE & 64);
     const unsigned near_words = (1u << far_word) - 1u;  // far_word == kMaskWords: every word
     // wavefront w walks tiles w, w + 4, ... (row-major tile numbering).  (Walking pairs of
     // horizontally adjacent tiles back to back, so that both halves of a 128-byte line come from
@@ -954,9 +1025,21 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : MR_RASTER
         __builtin_amdgcn_raw_buffer_store_b32((unsigned)max(st.id, 0), rs_ids, st_lane * 4u, st_tile * 4,
                                               (PROBE & 64) ? MR_RASTER_STORE_AUX : MR_RASTER_STORE_AUX_IDS);
         if (!SHADE || !last_round || shade.keep_z)  // workgroup-uniform
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, st.z), rs_z, st_lane * 4u, st_tile * 4, MR_RASTER_STORE_AUX);
-        __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(v3u, v3f{st.b0, st.b1, st.b2}), rs_bary, st_lane * 12u,
-                                              st_tile * 12, MR_RASTER_STORE_AUX);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, st.z), rs_z, st_lane * 4u, st_tile * 4, MR_RASTER_STORE_AUX_Z);
+        if constexpr (stage) {
+          typedef float v4f __attribute__((ext_vector_type(4)));
+          typedef unsigned v4u __attribute__((ext_vector_type(4)));
+          float *slot = s_ent + (kBin2Cap * kEntryDw - kWaves * kStageDw) + wave * kStageDw + 3 * lane;
+          slot[0] = st.b0; slot[1] = st.b1; slot[2] = st.b2;
+          // (same wavefront, LDS operations complete in order: no barrier between the two)
+          const v4f run = *(const v4f *)(slot + lx);
+          if (lx < kTileW * 3 / 4)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, run), rs_bary, lane_pix * 12u + (unsigned)lx * 4u,
+                                                   tile_pix * 12, MR_RASTER_STORE_AUX);
+        } else {
+          __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(v3u, v3f{st.b0, st.b1, st.b2}), rs_bary, st_lane * 12u,
+                                                st_tile * 12, MR_RASTER_STORE_AUX);
+        }
       }
       // Later rounds re-LOAD the pixel state.  vmcnt is in order on gfx950, so the compiler's wait
       // for such a load also drains the G-buffer stores behind it; draining explicitly here -- on
@@ -1118,10 +1201,14 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : MR_RASTER
     // mask word that starts the far class (kMaskWords: no clean cut, the walk never skips)
     const int far_word = (ordered && n_far > 0 && (far_base & 31) == 0) ? far_base >> 5 : kMaskWords;
     const bool last_round = next_base >= n_cand;
+    // the staging slots overlay the last kStageEntries entries of the bin (see "staged barycentric store")
+    const bool stage = max(n_near, far_base + n_far) <= kBin2Cap - kStageEntries;
     auto walk = [&]() {
-      if (!first_pass) raster_pass(std::false_type{}, std::false_type{}, far_word, last_round);
-      else if (X1 - X0 == R && Y1 - Y0 == R) raster_pass(std::true_type{}, std::true_type{}, far_word, last_round);
-      else raster_pass(std::true_type{}, std::false_type{}, far_word, last_round);
+      if (!first_pass) raster_pass(std::false_type{}, std::false_type{}, std::false_type{}, far_word, last_round);
+      else if (X1 - X0 == R && Y1 - Y0 == R) {
+        if (MR_BARY_STAGE && stage) raster_pass(std::true_type{}, std::true_type{}, std::true_type{}, far_word, last_round);
+        else raster_pass(std::true_type{}, std::true_type{}, std::false_type{}, far_word, last_round);
+      } else raster_pass(std::true_type{}, std::false_type{}, std::false_type{}, far_word, last_round);
     };
     if constexpr (PROBE == 0 || PROBE >= 8) {
       build_tile_masks(n_near, far_base, n_far);

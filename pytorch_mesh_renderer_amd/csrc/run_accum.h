@@ -308,6 +308,7 @@ __global__ __launch_bounds__(kRowsThreads, Fn::kMinWavesPerSimd) void k_accumula
   // A slot is a whole 64-float row (lanes >= N carry along a copy of lane N-1's sum): reads and
   // writes of a slot then need no lane mask.
   constexpr int kMergeSlots = MR_ROWS_MERGE_SLOTS;
+  static_assert(kMergeSlots <= 32, "slot lookups keep the low 32 bits of the ballot");
   __shared__ float s_merge[kRowsThreads / kWave][kMergeSlots > 0 ? kMergeSlots * kWave : 1];
 
   const int region = xcd_contiguous_block((int)blockIdx.x, n_regions, regions_per_xcd);
@@ -514,7 +515,7 @@ __global__ __launch_bounds__(kWave, Fn::kMinWavesPerSimd) void k_accumulate_lane
   static_assert(N <= kWave && N <= STRIDE, "one reduction lane per sum");
   __shared__ __attribute__((aligned(16))) float s_park[kWave * P];
   constexpr int kMergeSlots = MR_LANES_MERGE_SLOTS;
-  static_assert(kMergeSlots >= 1 && kMergeSlots <= kWave, "lane i of merge_keys holds slot i's triangle");
+  static_assert(kMergeSlots >= 1 && kMergeSlots <= 32, "lane i of merge_keys holds slot i's triangle; slot lookups keep the low 32 bits of the ballot");
   __shared__ float s_merge[kMergeSlots * kWave];
 
   const int region = xcd_contiguous_block((int)blockIdx.x, n_regions, regions_per_xcd);

@@ -302,6 +302,12 @@ def test_host_camera_transforms_are_memoised_by_value():
         grad_eye = eye.clone().requires_grad_(True)
         live = cu.clip_space_transforms(grad_eye, center, up, fov, near, far, 1.5, cpu)
         assert live.requires_grad and live is not moved
+        # round 4: a kept result that somebody edited in place is dropped, not handed out again
+        kept = cu.clip_space_transforms(eye, center, up, fov, near, far, 1.5, cpu)
+        assert cu.clip_space_transforms(eye, center, up, fov, near, far, 1.5, cpu) is kept
+        kept.mul_(2.0)
+        fresh = cu.clip_space_transforms(eye, center, up, fov, near, far, 1.5, cpu)
+        assert fresh is not kept and torch.equal(fresh, want)
         cu.CACHE_HOST_CAMERAS = False
         assert cu.clip_space_transforms(eye, center, up, fov, near, far, 1.5, cpu) is not moved
     finally:

@@ -941,6 +941,44 @@ def test_step_is_capturable_into_a_hip_graph(device):
     assert float(got_grad.abs().max()) > 0
 
 
+def test_host_camera_memo_stays_out_of_graph_captures_and_orders_streams(device):
+    """(1) the host-camera memo is neither read nor written while a stream is capturing -- a
+    warm-up render() must not make a capture with host cameras succeed by baking the kept tensor's address
+    into the graph (the next eager call with other cameras would free it under the replays); (2) a hit on
+    another stream is ordered behind the upload of the call that stored the entry; (3) the key carries
+    the resolved device index."""
+    from pytorch_mesh_renderer_amd.common import camera_utils as cu
+    eye = torch.tensor([[0.0, 0.0, 3.0], [1.0, 0.5, 3.0]])
+    center, up = torch.zeros(2, 3), torch.tensor([[0.0, 1.0, 0.0]]).repeat(2, 1)
+    fov, near, far = torch.tensor([40.0, 40.0]), torch.tensor([0.01, 0.01]), torch.tensor([10.0, 10.0])
+    want = torch.matmul(cu.perspective(1.0, fov, near, far), cu.look_at(eye, center, up))
+    before = cu.CACHE_HOST_CAMERAS
+    cu.CACHE_HOST_CAMERAS = True
+    try:
+        kept = cu.clip_space_transforms(eye, center, up, fov, near, far, 1.0, "cuda")     # index-less device
+        assert cu.clip_space_transforms(eye, center, up, fov, near, far, 1.0, device) is kept
+        assert cu._host_cache.entry[2] == torch.device("cuda", torch.cuda.current_device())
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            hit = cu.clip_space_transforms(eye, center, up, fov, near, far, 1.0, device)
+            got = hit.clone()
+        side.synchronize()
+        assert hit is kept and torch.equal(got.cpu(), want)
+        # a capture neither looks the memo up nor stores into it
+        graph = torch.cuda.CUDAGraph()
+        captured = None
+        with torch.cuda.graph(graph):
+            assert cu._host_camera_key(eye, center, up, fov, near, far, 1.0, device) is None
+            captured = cu._host_cache.entry
+        assert captured is cu._host_cache.entry and captured[3] is kept
+        # other cameras eagerly: the entry is replaced, the earlier tensor object is untouched
+        eye2 = eye + 0.25
+        other = cu.clip_space_transforms(eye2, center, up, fov, near, far, 1.0, device)
+        assert other is not kept and torch.equal(kept.cpu(), want)
+    finally:
+        cu.CACHE_HOST_CAMERAS = before
+
+
 @pytest.mark.parametrize("n_attrs", [1, 4, 7, 9, 13, 16, 17])
 def test_fused_rasterize_backward_matches_composed_ops(device, n_attrs):
     """rasterize(): the one-pass fused backward (<= 16 attributes) vs the composed
