@@ -37,6 +37,15 @@ int mr_debug_set_shade_backward_kernel(int which);
  * The G-buffer is UNDEFINED while a probe is selected. */
 int mr_debug_set_raster_probe(int probe);
 
+/* The SoftRas kernels' nearest-point-on-a-segment evaluation on caller-given data: for i < n,
+ * out[4 i .. 4 i + 3] = (nearest.x, nearest.y, t, squared distance) of device point points[2 i .. ] against
+ * the segment seg_a[2 i ..] -> seg_b[2 i ..], computed by the same two device functions k_soft_setup /
+ * k_soft_forward / k_soft_backward call (edge_setup, edge_nearest in soft.hip).  Exists so that the
+ * vectors the reference's own test holds for point_to_segment_nearest
+ * (src/soft_mesh_renderer/test_rasterize.py:9-44, rasterize.py:169-176) can be checked on the device.
+ * Device pointers, asynchronous on `stream`. */
+int mr_debug_soft_nearest(const float *points, const float *seg_a, const float *seg_b, int n, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

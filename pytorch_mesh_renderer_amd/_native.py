@@ -16,7 +16,7 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 # build libmesh_raster_hip_probes.so this way); the product always loads the in-tree library.
 LIB_PATH = os.environ.get("MR_NATIVE_LIB_PATH") or os.path.join(_CSRC, "libmesh_raster_hip.so")
 
-ABI_VERSION = 342
+ABI_VERSION = 343
 GBUFFER_NORMALISED = 1   # mesh_raster.h, MR_GBUFFER_NORMALISED
 TIMER_RASTER_FORWARD, TIMER_SHADE_BACKWARD, TIMER_SHADE_FORWARD, TIMER_RASTER_BACKWARD, TIMER_L1_FORWARD = 0, 1, 2, 3, 4
 MR_OK, MR_EINVAL, MR_EWORKSPACE, MR_ELAUNCH = 0, -1, -2, -3
@@ -58,6 +58,22 @@ def debug_set_shade_backward_kernel(which):
     before = _shade_backward_kernel
     _shade_backward_kernel = int(which)
     return before
+
+
+def debug_soft_nearest(points, seg_a, seg_b):
+    """Tests only (include/mesh_raster_debug.h): the SoftRas kernels' nearest-point-on-a-segment
+    evaluation for [n,2] device points / segment ends -> [n,4] = (nearest x, y, t, squared distance)."""
+    for name, t in (("points", points), ("seg_a", seg_a), ("seg_b", seg_b)):
+        _chk(name, t, _F32, None, 2)
+    if not (points.shape == seg_a.shape == seg_b.shape):
+        raise ValueError("points, seg_a and seg_b must have the same [n,2] shape")
+    dev = _require_device(points, seg_a, seg_b)
+    out = torch.empty(points.shape[0], 4, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib().mr_debug_soft_nearest(_ptr(points.contiguous()), _ptr(seg_a.contiguous()), _ptr(seg_b.contiguous()),
+                                         points.shape[0], _ptr(out), _stream(dev))
+    _check(rc, "mr_debug_soft_nearest")
+    return out
 
 
 def time_next_kernel(which, start_event, stop_event):
@@ -115,6 +131,8 @@ def lib():
         L.mr_debug_set_raster_region_edge.restype = ci
         L.mr_debug_set_shade_backward_kernel.argtypes = [ci]
         L.mr_debug_set_shade_backward_kernel.restype = ci
+        L.mr_debug_soft_nearest.argtypes = [vp, vp, vp, ci, vp, vp]
+        L.mr_debug_soft_nearest.restype = ci
         L.mr_rasterize_forward_workspace_bytes.argtypes = [ci] * 5
         L.mr_rasterize_forward_workspace_bytes.restype = sz
         L.mr_rasterize_forward.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, sz, vp]

@@ -31,7 +31,7 @@ extern thread_local int g_shade_backward_kernel;
 
 extern "C" {
 
-int mr_version(void) { return 342; /* 0.4.0: NULL attribute gradients, many lights, camera transforms, adjacency for the specular backward, wider deterministic mode */ }
+int mr_version(void) { return 343; /* 0.4.1: + mr_debug_soft_nearest */ }
 
 int mr_last_hip_error(void) { return mr::g_last_hip_error; }
 
@@ -75,6 +75,11 @@ int mr_debug_set_raster_probe(int probe) {
 #else
   return probe == 0 ? MR_OK : MR_EINVAL;  // production build: no probe code in the kernel
 #endif
+}
+
+int mr_debug_soft_nearest(const float *points, const float *seg_a, const float *seg_b, int n, float *out, void *stream) {
+  if (n < 0 || (n > 0 && (!points || !seg_a || !seg_b || !out))) return MR_EINVAL;
+  return mr::launch_debug_soft_nearest(points, seg_a, seg_b, n, out, (hipStream_t)stream);
 }
 
 size_t mr_rasterize_forward_workspace_bytes(int B, int V, int T, int W, int H) {

@@ -182,6 +182,7 @@ int launch_camera_transforms_backward(const float *dtransforms, const float *eye
 int launch_tone_map(const float *image, int B, size_t per_image, float gamma, int *max_bits, float *out,
                     uint8_t *out_u8, hipStream_t s);
 int soft_max_lights();
+int launch_debug_soft_nearest(const float *p, const float *a, const float *b, int n, float *out, hipStream_t s);
 size_t soft_ws(int B, int V, int T, int W, int H);
 size_t soft_prepared_bytes(int B, int V, int T, int W, int H);
 int launch_soft_forward(const float *clip, const float *positions, const float *normals,

@@ -77,6 +77,16 @@ inline SoftParams soft_params(float sigma, float gamma, float blur) {
   return SoftParams{sigma, gamma, blur, 1.0f / sigma, 1.0f / gamma, blur * blur};
 }
 
+// Wave-uniform part of point_to_segment_nearest (rasterize.py:169-172) for one edge a -> b: the unit
+// direction n = ab / max(|ab|, 1e-12) and 1 / |ab|; formed once per (image, triangle) by k_soft_setup.
+__device__ __forceinline__ void edge_setup(float abx, float aby, float &nx, float &ny, float &ilen) {
+  const float len = sqrtf(abx * abx + aby * aby);
+  const float il = 1.0f / fmaxf(len, kNormEps);
+  nx = abx * il;
+  ny = aby * il;
+  ilen = 1.0f / len;
+}
+
 __global__ __launch_bounds__(kThreads) void k_soft_setup(
     const float4 *__restrict__ clip, const int32_t *__restrict__ tris, int B, int V, int T,
     float blur, SoftRec *__restrict__ recs) {
@@ -115,11 +125,7 @@ __global__ __launch_bounds__(kThreads) void k_soft_setup(
   for (int e = 0; e < 3; ++e) {
     const int a = e, b2 = (e + 1) % 3;
     const float abx = r.x[b2] - r.x[a], aby = r.y[b2] - r.y[a];
-    const float len = sqrtf(abx * abx + aby * aby);
-    const float il = 1.0f / fmaxf(len, kNormEps);
-    r.nx[e] = abx * il;
-    r.ny[e] = aby * il;
-    r.ilen[e] = 1.0f / len;
+    edge_setup(abx, aby, r.nx[e], r.ny[e], r.ilen[e]);
 #if MR_SOFT_EDGE_VECTORS
     r.ex[e] = abx;
     r.ey[e] = aby;
@@ -163,6 +169,21 @@ __device__ __forceinline__ void edge_nearest(float px, float py, float ax, float
   t = fminf(fmaxf((prx * nx + pry * ny) * ilen, 0.0f), 1.0f);
   const float qx = ax + t * abx - px, qy = ay + t * aby - py;
   d2 = qx * qx + qy * qy;
+}
+
+// mr_debug_soft_nearest (mesh_raster_debug.h): the two device functions above on caller-given points and
+// segments, so that the reference's own vectors for point_to_segment_nearest (test_rasterize.py:9-44) can be
+// checked against what the SoftRas kernels evaluate.  out[i] = (nearest x, nearest y, t, squared distance).
+__global__ __launch_bounds__(kThreads) void k_debug_soft_nearest(const float2 *__restrict__ p, const float2 *__restrict__ a,
+                                                                 const float2 *__restrict__ b, int n,
+                                                                 float4 *__restrict__ out) {
+  const int i = (int)(blockIdx.x * kThreads + threadIdx.x);
+  if (i >= n) return;
+  const float abx = b[i].x - a[i].x, aby = b[i].y - a[i].y;
+  float nx, ny, ilen, t, d2;
+  edge_setup(abx, aby, nx, ny, ilen);
+  edge_nearest(p[i].x, p[i].y, a[i].x, a[i].y, abx, aby, nx, ny, ilen, t, d2);
+  out[i] = make_float4(a[i].x + t * abx, a[i].y + t * aby, t, d2);
 }
 
 // Returns false when the pair is culled (bbox, blur radius, depth range).
@@ -863,6 +884,13 @@ static int soft_prepare(const float *clip, const float *positions, const float *
   }
   hipLaunchKernelGGL(k_soft_coarse, dim3((unsigned)(cg.per_image * B)), dim3(kCoarseThreads), 0, s, recs, T, W, H,
                      cg.cells_x, cg.per_image, cell_ids, cell_count);
+  return check_launch();
+}
+
+int launch_debug_soft_nearest(const float *p, const float *a, const float *b, int n, float *out, hipStream_t s) {
+  if (n <= 0) return MR_OK;
+  hipLaunchKernelGGL(k_debug_soft_nearest, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
+                     (const float2 *)p, (const float2 *)a, (const float2 *)b, n, (float4 *)out);
   return check_launch();
 }
 

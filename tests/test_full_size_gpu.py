@@ -131,6 +131,57 @@ def test_bench_step_from_world_space_inputs_records_the_conditioning_bound(devic
         assert worst["max"] <= 5e-4, worst
 
 
+def test_device_clip_transform_against_float64(device):
+    """"conditioning" as a checked fact.  The two sides of the test above differ in
+    how they form clip = M (v, 1): the device evaluates each row as ((m0 x + m1 y) + m2 z) + m3 per vertex,
+    un-fused (k_vertex_transform), the oracle -- like the reference -- through a batched GEMM on the host
+    (fused multiply-adds, another order).  Both are compared here with the same product evaluated in
+    float64 from the SAME float32 matrices and vertices, for all 32 x 2502 x 4 components of configs[2],
+    in units of one rounding step -- an ulp of the largest of the component's four products (x and y pass
+    through 0 where the products cancel; an ulp of the result itself would be meaningless there):
+      * the device stays within 3 such steps everywhere (four products and three sums, half a step each:
+        3.5 at most; recorded 2.3, mean 0.32) and equals the correctly rounded value in > 70 % of the
+        components; the host GEMM: recorded max 2.0, mean 0.29, 81 % -- fused, hence slightly closer,
+      * and the two float32 sides are never more than 5 steps apart.
+    So neither transform is defective and neither is off by more than its own rounding: the handful of
+    silhouette pixels that move between the two sides in the test above follow from WHICH last bit each
+    side rounded to, amplified by triangles seen edge-on."""
+    sys.path.insert(0, ROOT)
+    import bench
+    _, batch, width, height, k = bench.CONFIGS["c3"]
+    job = synthetic.sphere_job(batch, width, height, k)
+    b = batch
+    full = lambda v: torch.full((b,), float(v))
+    transforms = camera_utils.clip_space_transforms(
+        job["eyes"], torch.zeros(b, 3), torch.tensor([[0.0, 1.0, 0.0]]).repeat(b, 1), full(40.0), full(0.01),
+        full(10.0), width / height, torch.device("cpu")).to(torch.float32)
+    dev_clip = _native.vertex_transform(job["vertices"].to(device), transforms.to(device)).cpu().numpy()
+    host_clip = camera_utils.transform_homogeneous(transforms, job["vertices"]).numpy()
+    m64 = transforms.numpy().astype(np.float64)                       # [B,4,4]
+    v64 = np.concatenate([job["vertices"].numpy().astype(np.float64),
+                          np.ones((b, job["vertices"].shape[1], 1))], axis=2)   # [B,V,4]
+    exact = np.einsum("brk,bvk->bvr", m64, v64)
+    rounded = exact.astype(np.float32)
+    terms = np.abs(m64[:, None, :, :] * v64[:, :, None, :]).max(-1)   # [B,V,4]: largest product per component
+    step = np.spacing(np.maximum(terms, np.abs(exact)).astype(np.float32)).astype(np.float64)
+    dev_err = np.abs(dev_clip.astype(np.float64) - exact) / step
+    host_err = np.abs(host_clip.astype(np.float64) - exact) / step
+    print("clip transform vs float64, in rounding steps of the largest product: device max %.2f mean %.3f | host GEMM "
+          "max %.2f mean %.3f | correctly rounded: device %.1f %%, host %.1f %% of the components" % (
+              dev_err.max(), dev_err.mean(), host_err.max(), host_err.mean(),
+              100.0 * (dev_clip == rounded).mean(), 100.0 * (host_clip == rounded).mean()))
+    assert dev_err.max() <= 3.0, dev_err.max()
+    assert host_err.max() <= 3.0, host_err.max()
+    assert (dev_clip == rounded).mean() >= 0.7
+    assert abs(dev_err.mean() - host_err.mean()) <= 0.1, (dev_err.mean(), host_err.mean())
+    assert (np.abs(dev_clip.astype(np.float64) - host_clip.astype(np.float64)) / step).max() <= 5.0
+    # the emulation of the device's own expression in numpy float32 gives the device's bits exactly
+    m, v = transforms.numpy(), job["vertices"].numpy()
+    for r in range(4):
+        want = ((m[:, None, r, 0] * v[..., 0] + m[:, None, r, 1] * v[..., 1]) + m[:, None, r, 2] * v[..., 2]) + m[:, None, r, 3]
+        np.testing.assert_array_equal(dev_clip[..., r], want)
+
+
 def test_config5_soft_renderer_default_parameters_crop_against_oracle(device):
     """configs[4] at the DEFAULT sigma / gamma (1e-5 / 1e-4), 5k triangles, 512x512, B = 16 (VERDICT r2,
     weak 2): a 64x64 crop of image 9 of the full-size launch -- across the sphere's silhouette, where

@@ -192,6 +192,41 @@ def test_shading_oracle_shininess_gradient(name):
     assert np.abs(np.nan_to_num(g["d_shininess"])).max() > 1e-4
 
 
+def test_shading_oracle_nine_lights_with_specular():
+    """Round 4: nine lights, diffuse AND specular, ambient, a scalar shininess per image, every input
+    differentiated (the reference takes any light count, render.py:304-372; the fused HIP kernels take
+    them in groups of four -- nine crosses two group boundaries)."""
+    g = golden_npz("render_nine_lights_64x48.npz")
+    keys = ("vertices", "normals", "diffuse", "specular", "light_positions", "light_intensities", "ambient",
+            "shininess")
+    leaves = {k: _t(g[k], True) for k in keys}
+    img = shading.render(leaves["vertices"], _t(g["triangles"]), leaves["normals"], leaves["diffuse"],
+                         _t(g["eye"]), _t(g["center"]), _t(g["up"]), leaves["light_positions"],
+                         leaves["light_intensities"], 64, 48, specular_colors=leaves["specular"],
+                         shininess_coefficients=leaves["shininess"], ambient_color=leaves["ambient"])
+    assert g["light_positions"].shape[1] == 9
+    np.testing.assert_allclose(img.detach().numpy(), g["image"], atol=2e-6, rtol=0)
+    (float(g["loss_weight"]) * torch.mean(torch.abs(img - _t(g["target"])))).backward()
+    for k, t in leaves.items():
+        assert np.abs(g["d_" + k]).max() > 1e-5, k
+        np.testing.assert_allclose(t.grad.numpy(), g["d_" + k], atol=1e-5, rtol=0, err_msg=k)
+
+
+def test_shading_oracle_rasterize_seventeen_attributes():
+    """Round 4: rasterize() on a random triangle soup with 17 attributes and a per-attribute background
+    (rasterize.py:27-152), gradients to vertices, attributes and background."""
+    g = golden_npz("rasterize_soup_a17_40x30.npz")
+    v, a, bg = _t(g["vertices"], True), _t(g["attributes"], True), _t(g["background"], True)
+    out = shading.rasterize(v, a, _t(g["triangles"]), _t(g["transforms"]), 40, 30, bg)
+    assert out.shape[-1] == 17
+    np.testing.assert_allclose(out.detach().numpy(), g["image"], atol=1e-6, rtol=0)
+    torch.mean(torch.abs(out - _t(g["target"]))).backward()
+    np.testing.assert_allclose(v.grad.numpy(), g["d_vertices"], atol=1e-6, rtol=0)
+    np.testing.assert_allclose(a.grad.numpy(), g["d_attributes"], atol=1e-7, rtol=0)
+    np.testing.assert_allclose(bg.grad.numpy(), g["d_background"], atol=1e-6, rtol=0)
+    assert np.abs(g["d_vertices"]).max() > 1e-4
+
+
 # ---- SoftRas oracle (torch CPU restatement of src/soft_mesh_renderer) -----------------------------
 
 def test_soft_oracle_single_triangle_known_answers():
@@ -208,6 +243,28 @@ def test_soft_oracle_single_triangle_known_answers():
     red = g["image_a"][..., 0]
     assert red[0, 9] == 1.0 and red[9, 0] == 1.0 and red[0, 0] == 0.0
     np.testing.assert_allclose(np.diag(np.fliplr(g["image_a"][..., 3])), 0.5, atol=1e-6)
+
+
+def test_soft_oracle_point_to_segment_nearest():
+    """The vectors the reference's own test holds for point_to_segment_nearest (test_rasterize.py:9-44:
+    the first three cases, with the answers written there) and 256 more through the reference function
+    (rasterize.py:169-176): nearest point, parameter t and squared distance of oracle/soft.py's
+    vectorised restatement."""
+    from oracle import soft
+    g = golden_npz("soft_point_to_segment_nearest.npz")
+    p, a, b = _t(g["p"]), _t(g["a"]), _t(g["b"])
+    n = p.shape[0]
+    # one (pixel, triangle) pair per case: p [n,1,2] against a / b [1,n,2], the diagonal is the case itself
+    d2, t = soft._nearest_on_segment(p.reshape(n, 1, 2), a.reshape(1, n, 2), b.reshape(1, n, 2))
+    d2, t = torch.diagonal(d2).numpy(), torch.diagonal(t).numpy()
+    np.testing.assert_allclose(t[:3], g["held_t"], atol=1e-6, rtol=0)   # the reference test's own answers (its assert_close)
+    x = g["a"] + t[:, None] * (g["b"] - g["a"])
+    np.testing.assert_allclose(x[:3], g["held_nearest"], atol=1e-6, rtol=0)
+    np.testing.assert_allclose(t, g["t"], atol=1e-6, rtol=0)
+    np.testing.assert_allclose(x, g["nearest"], atol=1e-6, rtol=0)
+    want_d2 = ((g["nearest"] - g["p"]) ** 2).sum(-1)
+    np.testing.assert_allclose(d2, want_d2, atol=1e-6, rtol=1e-5)
+    assert (g["t"] == 0).sum() > 20 and (g["t"] == 1).sum() > 20 and ((g["t"] > 0) & (g["t"] < 1)).sum() > 20
 
 
 @pytest.mark.parametrize("name", ["soft_sphere_k6_32.npz", "soft_sphere_k10_32.npz"])

@@ -151,6 +151,120 @@ def test_fused_render_with_many_lights_matches_composed_path(device, n_lights, l
         np.testing.assert_allclose(results[True][1][k], want, atol=ATOL, rtol=2e-3, err_msg=k)
 
 
+def test_render_nine_lights_specular_golden(device):
+    """Round 4: the reference's capture with NINE lights, diffuse + specular (scalar shininess per image),
+    ambient, every input differentiated -- shininess included -- through the fused specular kernels (groups
+    of four lights: 4 + 4 + 1)."""
+    g = golden_npz("render_nine_lights_64x48.npz")
+    keys = ("vertices", "normals", "diffuse", "specular", "shininess", "light_positions", "light_intensities",
+            "ambient")
+    leaves = {k: _leaf(g, k, device) for k in keys}
+    dev = lambda k: torch.tensor(g[k], device=device)
+    with _CountCalls("shade_specular_forward") as fwd, _CountCalls("interpolate_forward") as composed:
+        img = mesh_renderer.render(leaves["vertices"], dev("triangles"), leaves["normals"], leaves["diffuse"],
+                                   dev("eye"), dev("center"), dev("up"), leaves["light_positions"],
+                                   leaves["light_intensities"], 64, 48, specular_colors=leaves["specular"],
+                                   shininess_coefficients=leaves["shininess"], ambient_color=leaves["ambient"])
+    assert fwd.calls == 3 and composed.calls == 0
+    np.testing.assert_allclose(img.detach().cpu().numpy(), g["image"], atol=ATOL, rtol=0)
+    (float(g["loss_weight"]) * torch.mean(torch.abs(img - dev("target")))).backward()
+    for k, t in leaves.items():
+        assert np.abs(g["d_" + k]).max() > 1e-5, k
+        np.testing.assert_allclose(t.grad.cpu().numpy(), g["d_" + k], atol=ATOL, rtol=0, err_msg=k)
+
+
+@pytest.mark.parametrize("n_lights,specular", [(9, False), (32, False), (9, True), (32, True), (7, "vertex")])
+def test_wide_light_paths_match_the_oracle(device, n_lights, specular):
+    """the many-light paths (run-time light loop of the diffuse kernels, groups of four in
+    the specular kernels, light gradients 1 + ceil(L / 4) passes) against the CPU restatement of the
+    reference (oracle/shading.render; render.py:304-372) instead of against the composed HIP path: image
+    and every gradient -- lights, ambient, specular colours, shininess (per image, or per vertex for
+    `specular == "vertex"`) -- within 1e-4 on a 64 x 48 sphere."""
+    job = synthetic.sphere_job(2, 64, 48, 8)
+    gen = torch.Generator().manual_seed(100 + n_lights)
+    V = job["vertices"].shape[1]
+    base = {"vertices": job["vertices"], "normals": job["normals"],
+            "diffuse": torch.rand(2, V, 3, generator=gen),
+            "light_positions": torch.rand(2, n_lights, 3, generator=gen) * 8.0 - 4.0,
+            "light_intensities": torch.rand(2, n_lights, 3, generator=gen) * (2.0 / n_lights),
+            "ambient": torch.rand(2, 3, generator=gen) * 0.2}
+    if specular:
+        base["specular"] = torch.rand(2, V, 3, generator=gen)
+        base["shininess"] = (0.3 + torch.rand(2, V, generator=gen)) if specular == "vertex" else torch.tensor([0.5, 0.9])
+    target = torch.rand(2, 48, 64, 4, generator=gen)
+    center, up = torch.zeros(2, 3), torch.tensor([[0.0, 1.0, 0.0]]).repeat(2, 1)
+    results = {}
+    for where in ("hip", "oracle"):
+        dev_ = device if where == "hip" else torch.device("cpu")
+        scene = {k: v.clone().to(dev_).requires_grad_(True) for k, v in base.items()}
+        kwargs = {"ambient_color": scene["ambient"]}
+        if specular:
+            kwargs.update(specular_colors=scene["specular"], shininess_coefficients=scene["shininess"])
+        if where == "hip":
+            img = mesh_renderer.render(scene["vertices"], job["triangles"].to(dev_), scene["normals"], scene["diffuse"],
+                                       job["eyes"], center, up, scene["light_positions"], scene["light_intensities"],
+                                       64, 48, **kwargs)
+        else:
+            # (the power inside the mask only: per-vertex shininess with background pixels, see shade_spec.hip)
+            img = shading.render(scene["vertices"], job["triangles"], scene["normals"], scene["diffuse"], job["eyes"],
+                                 center, up, scene["light_positions"], scene["light_intensities"], 64, 48,
+                                 power_inside_mask_only=specular == "vertex", **kwargs)
+        (20.0 * torch.mean(torch.abs(img - target.to(dev_)))).backward()
+        results[where] = (img.detach().cpu().numpy(), {k: v.grad.cpu().numpy() for k, v in scene.items()})
+    np.testing.assert_allclose(results["hip"][0], results["oracle"][0], atol=ATOL, rtol=0)
+    assert 0.2 < (results["oracle"][0][..., 3] > 0.5).mean() < 0.95
+    for k, want in results["oracle"][1].items():
+        assert np.isfinite(want).all() and np.abs(want).max() > 1e-6, k
+        np.testing.assert_allclose(results["hip"][1][k], want, atol=ATOL, rtol=0, err_msg=k)
+
+
+def _random_soup(seed, n_attrs, device=None):
+    gen = torch.Generator().manual_seed(seed)
+    V, T = 80, 60
+    soup = {"vertices": torch.rand(2, V, 3, generator=gen) * 2.0 - 1.0,
+            "attributes": torch.rand(2, V, n_attrs, generator=gen),
+            "background": torch.linspace(-1.0, 0.5, n_attrs)}
+    tris = torch.randint(0, V, (T, 3), generator=gen, dtype=torch.int32)
+    eye = torch.tensor([[0.0, 0.0, 4.0], [1.0, 1.0, 4.0]])
+    proj = torch.matmul(camera_utils.perspective(57 / 41, torch.tensor([40.0, 40.0]), torch.tensor([0.01, 0.01]),
+                                                 torch.tensor([10.0, 10.0])),
+                        camera_utils.look_at(eye, torch.zeros(2, 3), torch.tensor(2 * [[0.0, 1.0, 0.0]])))
+    return soup, tris, proj
+
+
+@pytest.mark.parametrize("n_attrs", [1, 4, 9, 16, 17])
+def test_rasterize_matches_oracle_on_random_soups(device, n_attrs):
+    """rasterize() (rasterize.py:27-152) against oracle/shading.rasterize on random
+    triangle soups -- values, dL/dattributes, dL/dvertices and dL/dbackground within 1e-4 -- for attribute
+    counts on both sides of the fused path's limit of 16 and both of its backward kernels (<= 8: lanes)."""
+    soup, tris, proj = _random_soup(300 + n_attrs, n_attrs)
+    target = torch.rand(2, 41, 57, n_attrs, generator=torch.Generator().manual_seed(n_attrs))
+    results = {}
+    for where in ("hip", "oracle"):
+        dev_ = device if where == "hip" else torch.device("cpu")
+        leaves = {k: v.clone().to(dev_).requires_grad_(True) for k, v in soup.items()}
+        fn = mesh_renderer.rasterize if where == "hip" else shading.rasterize
+        out = fn(leaves["vertices"], leaves["attributes"], tris.to(dev_), proj.to(dev_), 57, 41, leaves["background"])
+        torch.mean(torch.abs(out - target.to(dev_))).backward()
+        results[where] = (out.detach().cpu().numpy(), {k: v.grad.cpu().numpy() for k, v in leaves.items()})
+    np.testing.assert_allclose(results["hip"][0], results["oracle"][0], atol=ATOL, rtol=0)
+    for k, want in results["oracle"][1].items():
+        assert np.abs(want).max() > 1e-6, k
+        np.testing.assert_allclose(results["hip"][1][k], want, atol=ATOL, rtol=0, err_msg=k)
+
+
+def test_rasterize_seventeen_attributes_golden(device):
+    """The reference's own rasterize() on a random soup with 17 attributes (tools/make_goldens_r4.py attrs)."""
+    g = golden_npz("rasterize_soup_a17_40x30.npz")
+    leaves = {k: _leaf(g, k, device) for k in ("vertices", "attributes", "background")}
+    out = mesh_renderer.rasterize(leaves["vertices"], leaves["attributes"], torch.tensor(g["triangles"], device=device),
+                                  torch.tensor(g["transforms"], device=device), 40, 30, leaves["background"])
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g["image"], atol=ATOL, rtol=0)
+    torch.mean(torch.abs(out - torch.tensor(g["target"], device=device))).backward()
+    for k, t in leaves.items():
+        np.testing.assert_allclose(t.grad.cpu().numpy(), g["d_" + k], atol=ATOL, rtol=0, err_msg=k)
+
+
 class _CountCalls:
     """Counts the calls of a _native entry point (which path did render() take?)."""
 

@@ -25,6 +25,24 @@ def test_single_triangle_known_answers(device):
         np.testing.assert_allclose(img.cpu().numpy(), g["image_" + tag], atol=ATOL, rtol=0)
 
 
+def test_point_to_segment_nearest_vectors_on_the_device(device):
+    """Counterpart of the reference's test_point_to_segment_nearest (test_rasterize.py:9-44): its three
+    cases with the answers written there, and 256 more through the reference function, against the two
+    device functions every SoftRas kernel evaluates (edge_setup + edge_nearest in soft.hip, reached through
+    mr_debug_soft_nearest): nearest point, t and squared distance."""
+    from pytorch_mesh_renderer_amd import _native
+    g = golden_npz("soft_point_to_segment_nearest.npz")
+    out = _native.debug_soft_nearest(torch.tensor(g["p"], device=device), torch.tensor(g["a"], device=device),
+                                     torch.tensor(g["b"], device=device)).cpu().numpy()
+    np.testing.assert_allclose(out[:3, :2], g["held_nearest"], atol=1e-6, rtol=0)     # the reference test's own
+    np.testing.assert_allclose(out[:3, 2], g["held_t"], atol=1e-6, rtol=0)            # expected values
+    np.testing.assert_allclose(out[:, 2], g["t"], atol=2e-6, rtol=0)
+    np.testing.assert_allclose(out[:, :2], g["nearest"], atol=2e-6, rtol=0)
+    np.testing.assert_allclose(out[:, 3], ((g["nearest"] - g["p"]) ** 2).sum(-1), atol=1e-6, rtol=1e-4)
+    # t is clamped exactly: points beyond an end get exactly 0 or 1, as in the reference
+    assert np.array_equal(out[:, 2] == 0.0, g["t"] == 0.0) and np.array_equal(out[:, 2] == 1.0, g["t"] == 1.0)
+
+
 @pytest.mark.parametrize("name", ["soft_sphere_k6_32.npz", "soft_sphere_k10_32.npz"])
 def test_render_sphere_goldens(device, name):
     g = golden_npz(name)
