@@ -141,7 +141,8 @@ def test_device_clip_transform_against_float64(device):
     through 0 where the products cancel; an ulp of the result itself would be meaningless there):
       * the device stays within 3 such steps everywhere (four products and three sums, half a step each:
         3.5 at most; recorded 2.3, mean 0.32) and equals the correctly rounded value in > 70 % of the
-        components; the host GEMM: recorded max 2.0, mean 0.29, 81 % -- fused, hence slightly closer,
+        components; the host GEMM: recorded max 2.0, mean 0.29, 81 % in the build container (fused
+        multiply-adds: slightly closer) and exactly the device's figures on the GPU box's host,
       * and the two float32 sides are never more than 5 steps apart.
     So neither transform is defective and neither is off by more than its own rounding: the handful of
     silhouette pixels that move between the two sides in the test above follow from WHICH last bit each

@@ -243,8 +243,17 @@ def test_rasterize_matches_oracle_on_random_soups(device, n_attrs):
     for where in ("hip", "oracle"):
         dev_ = device if where == "hip" else torch.device("cpu")
         leaves = {k: v.clone().to(dev_).requires_grad_(True) for k, v in soup.items()}
-        fn = mesh_renderer.rasterize if where == "hip" else shading.rasterize
-        out = fn(leaves["vertices"], leaves["attributes"], tris.to(dev_), proj.to(dev_), 57, 41, leaves["background"])
+        if where == "hip":
+            out = mesh_renderer.rasterize(leaves["vertices"], leaves["attributes"], tris.to(dev_), proj.to(dev_), 57, 41,
+                                          leaves["background"])
+        else:
+            # a soup's triangles intersect each other: along those lines the winner of the depth test hangs on
+            # the last bit of the clip coordinates, so the oracle rasterizes the device's clip bits (its own
+            # matmul still carries the gradient; see oracle/shading.rasterize)
+            # (rasterize() forms them with transform_homogeneous -- a batched GEMM on the device)
+            clip_bits = camera_utils.transform_homogeneous(proj.to(device), soup["vertices"].to(device)).cpu()
+            out = shading.rasterize(leaves["vertices"], leaves["attributes"], tris, proj, 57, 41, leaves["background"],
+                                    clip_bits=clip_bits)
         torch.mean(torch.abs(out - target.to(dev_))).backward()
         results[where] = (out.detach().cpu().numpy(), {k: v.grad.cpu().numpy() for k, v in leaves.items()})
     np.testing.assert_allclose(results["hip"][0], results["oracle"][0], atol=ATOL, rtol=0)
