@@ -224,7 +224,12 @@ int mr_render_forward(const float *vertices, const float *transforms, const floa
  *                   also receives the clip-space gradient pulled back through that product, i.e.
  *                   it becomes the whole gradient w.r.t. the world-space vertices; dclip is still
  *                   written (a caller that differentiates the transforms needs it).  Requires the
- *                   vertex adjacency.
+ *                   vertex adjacency.  With transforms, dclip may be NULL: the clip-space gradient is
+ *                   not wanted on its own (the caller differentiates to the vertices, not to the
+ *                   cameras).  Where the lane kernel has the variant (no light_grads, dnormals and
+ *                   ddiffuse NULL, MR_GBUFFER_NORMALISED, not deterministic) the pull-back is then applied
+ *                   per pixel and the pixel pass keeps 9 sums per triangle instead of 18; elsewhere the
+ *                   clip gradient goes to the workspace.
  * dclip, dnormals, dpositions, ddiffuse, light_grads laid out back to back in that order are
  * zeroed with a single memset (none at all with the vertex adjacency: every output is written
  * exactly once). */
@@ -356,7 +361,7 @@ int mr_soft_backward(const float *drgba, const float *rgba, const float *aux,
  * torch.mean(torch.abs(render - target)) (src/mesh_renderer/mesh_renderer_test.py:250),
  * as one streaming pass each way.  a, b: n floats (16-byte aligned); loss: 1 float out;
  * signs: (n + 3) / 4 bytes out, or NULL when no gradient is wanted -- byte i holds
- * sign(a - b) of elements 4i .. 4i+3 as 2-bit codes (0: zero, 1: +1, 2: -1), so that the
+ * sign(a - b) of elements 4i .. 4i+3 as 2-bit two's-complement codes (0: zero, 1: +1, 3: -1), so that the
  * backward pass does not read the images again; upstream: 1 float (dL/dloss, read on the
  * device); da: n floats out (16-byte aligned) = upstream * sign(a - b) / n.
  * partials: MR_L1_PARTIALS floats of scratch: the workgroups' partial sums, added in a fixed

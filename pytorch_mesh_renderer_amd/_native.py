@@ -611,7 +611,7 @@ def vertex_adjacency(triangles, vertex_count):
 def shade_backward(drgba, ids, bary, clip, normals, positions, diffuse, triangles, light_positions,
                    light_intensities, ambient, corner_records=None, adjacency=None, l1_signs=None,
                    transforms=None, want_light_grads=True, want_normal_grads=True, want_diffuse_grads=True,
-                   normalised_gbuffer=False):
+                   normalised_gbuffer=False, want_clip_grads=True):
     """_shade_backward_call for any light count up to shade_max_lights().  The kernels keep the light
     gradients' 6 L sums in registers, four lights per call; with more lights the vertex-side gradients
     come from one call over all lights (a run-time loop, no light gradients) and each group of four
@@ -622,7 +622,7 @@ def shade_backward(drgba, ids, bary, clip, normals, positions, diffuse, triangle
     nl = light_positions.shape[1]
     kw = dict(corner_records=corner_records, adjacency=adjacency, l1_signs=l1_signs, transforms=transforms,
               want_normal_grads=want_normal_grads, want_diffuse_grads=want_diffuse_grads,
-              normalised_gbuffer=normalised_gbuffer)
+              normalised_gbuffer=normalised_gbuffer, want_clip_grads=want_clip_grads)
     fast = shade_fast_lights() if nl > 4 else nl
     if nl <= fast or not want_light_grads:
         return _shade_backward_call(drgba, ids, bary, clip, normals, positions, diffuse, triangles,
@@ -647,7 +647,7 @@ def shade_backward(drgba, ids, bary, clip, normals, positions, diffuse, triangle
 def _shade_backward_call(drgba, ids, bary, clip, normals, positions, diffuse, triangles, light_positions,
                          light_intensities, ambient, corner_records=None, adjacency=None, l1_signs=None,
                          transforms=None, want_light_grads=True, want_normal_grads=True, want_diffuse_grads=True,
-                         normalised_gbuffer=False):
+                         normalised_gbuffer=False, want_clip_grads=True):
     """-> (dclip [B,V,4], dnormals, dpositions, ddiffuse [B,V,3], dlight_positions,
     dlight_intensities [B,L,3], dambient [B,3] or None); with want_light_grads=False the last three
     are None and the kernel leaves their accumulation out; want_normal_grads / want_diffuse_grads=False
@@ -661,7 +661,13 @@ def _shade_backward_call(drgba, ids, bary, clip, normals, positions, diffuse, tr
     upstream gradient of that loss and the [B,H,W,4] gradient image is never materialised.
 
     normalised_gbuffer: ids / bary are what rasterize_forward / render_forward wrote for these vertices
-    (MR_GBUFFER_NORMALISED): the pixel pass leaves the alpha terms out, same bits."""
+    (MR_GBUFFER_NORMALISED): the pixel pass leaves the alpha terms out, same bits.
+
+    want_clip_grads=False (needs `transforms`): dclip is returned as None -- the caller differentiates to
+    the world-space vertices only; the pull-back through the transforms is then folded into the pixel
+    pass where the library has that variant (9 sums per triangle instead of 18)."""
+    if not want_clip_grads and transforms is None:
+        raise ValueError("without transforms the clip-space gradient is the vertex gradient: it cannot be left out")
     tensors = [drgba, ids, bary, clip, normals, positions, diffuse, triangles, light_positions,
                light_intensities]
     B, V, _ = _chk_mesh(clip, triangles)
@@ -703,6 +709,8 @@ def _shade_backward_call(drgba, ids, bary, clip, normals, positions, diffuse, tr
         dn = None
     if not want_diffuse_grads:
         dd = None
+    if not want_clip_grads:
+        dclip = None
     tail = (B, V, T, W, H, nl, _ptr(dclip), _ptr(dn), _ptr(dp), _ptr(dd), _ptr(lg), _ptr(corner_records),
             _ptr(adjacency[0]) if adjacency is not None else None,
             _ptr(adjacency[1]) if adjacency is not None else None, _ptr(transforms),

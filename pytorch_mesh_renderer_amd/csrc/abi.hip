@@ -274,7 +274,7 @@ int mr_shade_backward(const float *drgba, const int32_t *ids, const float *bary,
     return MR_EINVAL;
   if (B == 0) return MR_OK;
   if (!drgba || !ids || !bary || !clip || !normals || !positions || !diffuse || !triangles ||
-      !light_positions || !light_intensities || !dclip || !dpositions)
+      !light_positions || !light_intensities || (!dclip && !transforms) || !dpositions)
     return MR_EINVAL;
   if ((!dnormals || !ddiffuse) && !vertex_offsets) return MR_EINVAL;  /* only the per-vertex gather can leave outputs out */
   if (((uintptr_t)corner_records & 127u) != 0) return MR_EINVAL;
@@ -309,7 +309,7 @@ int mr_shade_backward_l1(const uint8_t *signs, const float *upstream, const int3
     return MR_EINVAL;
   if (B == 0) return MR_OK;
   if (!signs || !upstream || !ids || !bary || !clip || !normals || !positions || !diffuse || !triangles ||
-      !light_positions || !light_intensities || !dclip || !dpositions)
+      !light_positions || !light_intensities || (!dclip && !transforms) || !dpositions)
     return MR_EINVAL;
   if ((!dnormals || !ddiffuse) && !vertex_offsets) return MR_EINVAL;  /* only the per-vertex gather can leave outputs out */
   if (((uintptr_t)corner_records & 127u) != 0) return MR_EINVAL;

@@ -37,10 +37,11 @@ __device__ __forceinline__ float4 nt_load(const float4 *p) {
   return make_float4(v.x, v.y, v.z, v.w);
 }
 
-// 2-bit sign code of d: 0 -> 0, 1 -> +1, 2 -> -1 (NaN -> 0, like (0 < d) - (d < 0)).
-__device__ __forceinline__ unsigned sign_code(float d) { return d > 0.f ? 1u : (d < 0.f ? 2u : 0u); }
+// 2-bit sign code of d, two's complement: 0 -> 0, 1 -> +1, 3 -> -1 (NaN -> 0, like (0 < d) - (d < 0)); a
+// reader gets the value with one signed bit-field extract (v_bfe_i32) and a conversion.
+__device__ __forceinline__ unsigned sign_code(float d) { return d > 0.f ? 1u : (d < 0.f ? 3u : 0u); }
 __device__ __forceinline__ float sign_value(unsigned code) {
-  return (code & 1u) ? 1.f : ((code & 2u) ? -1.f : 0.f);
+  return (code & 2u) ? -1.f : ((code & 1u) ? 1.f : 0.f);
 }
 
 __global__ __launch_bounds__(kThreads) void k_l1_forward(const float4 *__restrict__ a,

@@ -493,6 +493,7 @@ __global__ __launch_bounds__(kRowsThreads, Fn::kMinWavesPerSimd) void k_accumula
 #ifndef MR_LANES_MERGE_SLOTS
 #define MR_LANES_MERGE_SLOTS 16
 #endif
+
 constexpr int lanes_park_stride(int n) {  // multiple of 4 with an odd number of quads: per-lane b128 accesses are conflict-free
   int s = (n + 3) / 4;
   if (s % 2 == 0) s += 1;
@@ -506,6 +507,15 @@ template <class Fn>
 struct LanesPipelined<Fn, decltype((void)Fn::kPipelinedRows)> { static constexpr bool value = Fn::kPipelinedRows; };
 template <class Fn>
 constexpr bool lanes_pipelined() { return LanesPipelined<Fn>::value; }
+// Fn::kPipelinedConditionalRecords (optional, default false): the pipelined loop (re)loads a lane's triangle
+// records only when its triangle changed -- for functors whose records are large (the shading's 11 x 16 bytes
+// per lane: unconditional loads would be 176 B per pixel of L2 traffic)
+template <class Fn, class = void>
+struct LanesPipelinedConditional { static constexpr bool value = false; };
+template <class Fn>
+struct LanesPipelinedConditional<Fn, decltype((void)Fn::kPipelinedConditionalRecords)> {
+  static constexpr bool value = Fn::kPipelinedConditionalRecords;
+};
 
 template <class Fn, bool DET>
 __global__ __launch_bounds__(kWave, Fn::kMinWavesPerSimd) void k_accumulate_lanes(
@@ -708,8 +718,15 @@ __global__ __launch_bounds__(kWave, Fn::kMinWavesPerSimd) void k_accumulate_lane
       // s_waitcnt right behind the loads, the whole L2 round trip exposed.  Unconditional loads land in
       // tri_data's registers and are waited for where accumulate() first uses them, after the refill below
       // has been issued and the flush has run.  (Lanes without a pixel re-read the record they hold.)
-      data_tri = valid ? tri : max(data_tri, 0);
-      fn.load_triangle(img, data_tri, tri_data);
+      if constexpr (LanesPipelinedConditional<Fn>::value) {
+        if (valid && tri != data_tri) {
+          data_tri = tri;
+          fn.load_triangle(img, tri, tri_data);
+        }
+      } else {
+        data_tri = valid ? tri : max(data_tri, 0);
+        fn.load_triangle(img, data_tri, tri_data);
+      }
       if (y + 2 < y_end) fn.fetch(img, xc, y + 2, pix + 2 * (size_t)W, raw);  // refill: row y + 2
       pix += W;
       if (!any) return;  // nothing in this row segment (background); open runs stay open
@@ -727,6 +744,9 @@ __global__ __launch_bounds__(kWave, Fn::kMinWavesPerSimd) void k_accumulate_lane
       if (y + 1 < y_end) row(y + 1, raw_b);
     }
   } else {
+  // (Measured in round 4 and dropped: requesting the next row into the SAME registers right after prepare() has
+  //  unpacked the current one -- it removes the 11 v_mov per row that copy `raw_next` into `raw`, but the loads then
+  //  issue behind the previous row's arrival: shading backward 0.263 -> 0.291 ms.)
   typename Fn::Raw raw_next;
   if (y_begin < y_end) fn.fetch(img, xc, y_begin, pix, raw_next);
   for (int y = y_begin; y < y_end; ++y, pix += W) {  // wave-uniform trip count

@@ -118,6 +118,9 @@ __global__ __launch_bounds__(kThreads, MR_SHADE_FWD_WAVES) void k_shade_forward(
 #ifndef MR_SHADE_NT
 #define MR_SHADE_NT 1
 #endif
+#ifndef MR_SHADE_OFFSET_FETCH
+#define MR_SHADE_OFFSET_FETCH 1  // see ShadeGradFn::fetch
+#endif
 // LG: the caller wants the light / ambient gradients (false: light_grads == nullptr; their nine
 // per-lane accumulators and ~25 instructions per row are not compiled in: the kernel -4 %).
 // L = 1..4: that many lights, kept in registers and unrolled.  L = 0 (round 3): any count up to
@@ -160,6 +163,7 @@ struct ShadeGradFn {
   Lights lights;
   float *__restrict__ light_rows;     // LG: [strips][L*6 + 3] per strip: dpos (L x 3), dcol (L x 3), dambient (3)
   int T_, W, H;
+  const float *__restrict__ transforms = nullptr;  // [B,4,4] clip = M (position, 1): ShadeLaneFn<..., FOLD> only
 
   struct Pixel {
     F3 b, g;
@@ -181,11 +185,17 @@ struct ShadeGradFn {
     float g_scale;                         // SIGNS: upstream * 1 / n
     float lp[LA][3], li[LA][3], amb[3];    // this image's lights (loaded once per lane; L > 0)
     float dpos[LA][3], dcol[LA][3], damb[3];  // per-lane partial sums
+    float pull[3][3];                      // FOLD: pull[r][c] = M[{0, 1, 3}[r]][c], the clip x / y / w rows' position columns
   };
 
   __device__ __forceinline__ void begin_image(int img, Image &im) const {
     im.g_scale = SIGNS ? sign_upstream[0] * sign_inv_n : 0.f;
     im.img = img;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c)   // (wave-uniform scalar loads; dead code unless a FOLD functor reads them)
+        im.pull[r][c] = transforms ? transforms[(size_t)img * 16 + (r == 2 ? 3 : r) * 4 + c] : 0.f;
 #pragma unroll
     for (int l = 0; l < L; ++l) {
 #pragma unroll
@@ -204,6 +214,21 @@ struct ShadeGradFn {
   }
 
   __device__ __forceinline__ void fetch(int img, int x, int y, size_t pix, Raw &r) const {
+#if MR_SHADE_OFFSET_FETCH
+    // Round 4: wave-uniform image bases (scalar registers) + 32-bit per-lane offsets inside the image --
+    // global_load's saddr form -- instead of a 64-bit address per plane and row (12 of the row loop's
+    // ~340 vector instructions were 64-bit multiply-adds forming them).  W * H < 2^27 pixels per image:
+    // the largest byte offset, 16 W H, stays below 2^31.
+    (void)pix;
+    const size_t img_px = (size_t)img * H * W;                         // wave-uniform
+    const unsigned gpix = (unsigned)(y * W) + (unsigned)x;             // G-buffer row y
+    const unsigned ipix = (unsigned)((H - 1 - y) * W) + (unsigned)x;   // image row (un-flipped)
+    const char *bary_img = (const char *)(bary + img_px), *ids_img = (const char *)(ids + img_px);
+    r.b = load_streamed((const F3 *)(bary_img + gpix * 12u));
+    r.t = __builtin_nontemporal_load((const int32_t *)(ids_img + gpix * 4u));
+    if (SIGNS) r.code = __builtin_nontemporal_load(signs + img_px + ipix);
+    else r.g = *(const float4 *)((const char *)(drgba + img_px) + ipix * 16u);
+#else
 #if MR_SHADE_NT
     // streamed once, never reused: nontemporal
     r.b = load_streamed(&bary[pix]);
@@ -215,16 +240,18 @@ struct ShadeGradFn {
     const size_t image_pix = ((size_t)img * H + (H - 1 - y)) * W + x;  // un-flip
     if (SIGNS) r.code = MR_SHADE_NT ? __builtin_nontemporal_load(&signs[image_pix]) : signs[image_pix];
     else r.g = drgba[image_pix];
+#endif
   }
   __device__ __forceinline__ bool prepare(const Raw &r, int T, int &tri, Pixel &p) const {
     const float pre = (2.0f * r.b.x + 2.0f * r.b.y) + 2.0f * r.b.z;
     if (!(pre > 0.0f)) return false;  // background: mask = 0, no gradient anywhere
     if ((unsigned)r.t >= (unsigned)T) return false;
     p.b = r.b;
-    if (SIGNS) {  // code 0 -> 0, 1 -> +1, 2 -> -1 (loss.hip), times the scale in factors()
-      p.g.x = (float)(int)(r.code & 1u) - (float)(int)((r.code >> 1) & 1u);
-      p.g.y = (float)(int)((r.code >> 2) & 1u) - (float)(int)((r.code >> 3) & 1u);
-      p.g.z = (float)(int)((r.code >> 4) & 1u) - (float)(int)((r.code >> 5) & 1u);
+    if (SIGNS) {  // 2-bit two's-complement codes 0, +1, -1 (loss.hip: sign_code), times the scale in factors():
+                  // one v_bfe_i32 and one conversion per channel
+      p.g.x = (float)(int)__builtin_amdgcn_sbfe(r.code, 0u, 2u);
+      p.g.y = (float)(int)__builtin_amdgcn_sbfe(r.code, 2u, 2u);
+      p.g.z = (float)(int)__builtin_amdgcn_sbfe(r.code, 4u, 2u);
     } else {
       p.g.x = r.g.x; p.g.y = r.g.y; p.g.z = r.g.z;  // d/d alpha is dropped: the mask is not differentiable
     }
@@ -384,6 +411,12 @@ struct ShadeGradFn {
 #define MR_SHADE_LANES_ALL 1   // the 36-sum variant too (every attribute gradient wanted; three waves per SIMD):
                                // 0.405 -> 0.385 ms sign-coded, 0.430 -> 0.399 dense upstream (whole call, 1024^2 x 32)
 #endif
+#ifndef MR_SHADE_LANES_PIPELINED
+#define MR_SHADE_LANES_PIPELINED 0   // 1: the pipelined row loop of k_accumulate_lanes, 2: with conditional record loads
+#endif
+#ifndef MR_SHADE_LANES_FOLD
+#define MR_SHADE_LANES_FOLD 1   // see ShadeLaneFn<..., FOLD>
+#endif
 #ifndef MR_LANE_ROWS_LG
 #define MR_LANE_ROWS_LG 16
 #endif
@@ -393,14 +426,25 @@ struct ShadeGradFn {
 #ifndef MR_LANE_WAVES
 #define MR_LANE_WAVES 4
 #endif
-template <int L, bool SIGNS, bool LG, int GROUPS, bool OPAQUE = false>
+// FOLD (round 4): the caller has the clip-space transforms M (clip = M (position, 1)) and does not want the
+// clip-space gradient on its own -- render() differentiated to the vertices, not to the cameras.  The pull-back
+// d position += M^T d clip is linear, so it is applied per PIXEL to the three clip brackets q and added to the
+// position attribute's gradient before the outer product with the barycentrics: 9 sums per triangle fewer to
+// keep in registers, to restart, to park, to merge and to commit (18 -> 9 for vertex gradients alone), for nine
+// multiply-adds with scalar operands; the gather then finds zeros in the clip columns.
+template <int L, bool SIGNS, bool LG, int GROUPS, bool OPAQUE = false, bool FOLD = false>
 struct ShadeLaneFn : ShadeGradFn<L, SIGNS, LG> {
   using Base = ShadeGradFn<L, SIGNS, LG>;
   static_assert(GROUPS >= 0 && GROUPS < 8, "attribute groups: normals | positions | diffuse");
+  static_assert(!FOLD || (GROUPS & 2), "folding the clip gradient needs the position group");
   static constexpr int kGroups = (GROUPS & 1) + ((GROUPS >> 1) & 1) + ((GROUPS >> 2) & 1);
-  static constexpr int kN = 9 * kGroups + 9;
+  static constexpr int kN = 9 * kGroups + (FOLD ? 0 : 9);
   static constexpr int kStride = 36;  // the rows of acc keep ShadeGradFn's layout: the gather reads it
   static constexpr int kLaneRowsPerWave = LG ? MR_LANE_ROWS_LG : MR_LANE_ROWS;
+#if MR_SHADE_LANES_PIPELINED
+  static constexpr bool kPipelinedRows = !LG;   // run_accum.h: streamed planes two rows ahead
+  static constexpr bool kPipelinedConditionalRecords = MR_SHADE_LANES_PIPELINED == 2;
+#endif
   // 36 accumulators: 137-145 VGPRs; with light gradients 6 L + 3 more per-lane sums ride along
   static constexpr int kMinWavesPerSimd = LG ? 3 : (kN > 27 ? 3 : MR_LANE_WAVES);   // LG: 134-161 VGPRs
   // the gi-th selected group
@@ -426,16 +470,23 @@ struct ShadeLaneFn : ShadeGradFn<L, SIGNS, LG> {
                                              float (&a)[kN], typename Base::Image &im) const {
     float f[Base::kFactorStride];
     Base::template factors_of<OPAQUE>(p, t, f, im);
+    if (FOLD) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        f[3 + 3 + c] += (im.pull[0][c] * f[12] + im.pull[1][c] * f[13]) + im.pull[2][c] * f[14];
+    }
 #pragma unroll
     for (int gi = 0; gi < kGroups; ++gi)
 #pragma unroll
       for (int k = 0; k < 3; ++k)
 #pragma unroll
         for (int c = 0; c < 3; ++c) a[(gi * 3 + k) * 3 + c] = fmaf(f[k], f[3 + group(gi) * 3 + c], a[(gi * 3 + k) * 3 + c]);
+    if (!FOLD) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
+      for (int k = 0; k < 3; ++k)
 #pragma unroll
-      for (int c = 0; c < 3; ++c) a[9 * kGroups + k * 3 + c] = fmaf(f[k], f[12 + c], a[9 * kGroups + k * 3 + c]);
+        for (int c = 0; c < 3; ++c) a[9 * kGroups + k * 3 + c] = fmaf(f[k], f[12 + c], a[9 * kGroups + k * 3 + c]);
+    }
   }
 };
 
@@ -501,7 +552,7 @@ __global__ __launch_bounds__(kThreads) void k_shade_gather(
   // outputs the caller does not want (nullptr): their sums were not formed either
   if ((j < 3 && !dnormals) || (j >= 6 && j < 9 && !ddiffuse)) return;
   float sum = 0.f;
-  if (j < 12) {
+  if (j < 12 && (dclip || j < 9)) {   // dclip == nullptr: not wanted (and its columns were not accumulated)
     const int e1 = offsets[v + 1];
     constexpr int kChunk = MR_GATHER_CHUNK;
     // this lane's float inside a triangle's 36-float row is  col0 + k * colk  for corner k
@@ -535,6 +586,7 @@ __global__ __launch_bounds__(kThreads) void k_shade_gather(
     }
   }
   if (DET && *det_overflow_flag(det_scale)) sum = __int_as_float(0x7fc00000);  // see atomic_add_fixed
+  if (!dclip && j >= 9) return;
   float *out = j < 3 ? dnormals + gid * 3 + j
              : j < 6 ? dpositions + gid * 3 + (j - 3)
              : j < 9 ? ddiffuse + gid * 3 + (j - 6)
@@ -635,9 +687,8 @@ int launch_shade_forward(const int32_t *ids, const float *bary, const float *nor
 }
 
 size_t shade_backward_ws(int B, int V, int T, int W, int H) {
-  (void)V; (void)W; (void)H;
   return shade_acc_bytes(B, T) + align_up((size_t)B * T * sizeof(BwdRec), 256) + corner_bytes(B, T) +
-         kDetMiscBytes + light_rows_bytes(B, W, H);
+         kDetMiscBytes + light_rows_bytes(B, W, H) + align_up((size_t)B * V * 4 * sizeof(float), 256);  // last: dclip scratch
 }
 
 thread_local int g_deterministic = 0;  // mr_set_deterministic
@@ -657,9 +708,17 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
                           const float *transforms, int gbuffer_flags, void *ws, hipStream_t s) {
   if (B == 0) return MR_OK;
   if (transforms && !(vertex_offsets && vertex_entries)) return MR_EINVAL;  // the gather applies them
+  if (!dclip && !transforms) return MR_EINVAL;  // without the pull-back the clip-space gradient IS the vertex gradient
   const size_t v3 = (size_t)B * V * 3 * sizeof(float), v4 = (size_t)B * V * 4 * sizeof(float);
   const size_t lg = light_grads ? (size_t)B * (L * 6 + 3) * sizeof(float) : 0;  // nullptr: not wanted
   const bool det = g_deterministic != 0;
+  // dclip == nullptr (with transforms): the caller wants the gradient of the world-space positions only.  Where
+  // the lane kernel has the variant, the pull-back through the transforms is folded into the pixel pass
+  // (ShadeLaneFn<..., FOLD>) and no clip-space sums exist at all; elsewhere the clip gradient goes to scratch.
+  const bool fold = !dclip && transforms && MR_SHADE_LANES_FOLD && !light_grads && !det && !dnormals && !ddiffuse &&
+                    (gbuffer_flags & MR_GBUFFER_NORMALISED) != 0 && g_shade_backward_kernel != 1 && T > 0 && V > 0;
+  if (!dclip && !fold)
+    dclip = (float *)((char *)ws + shade_backward_ws(B, V, T, W, H) - align_up((size_t)B * V * 4 * sizeof(float), 256));
   const float sign_inv_n = 1.0f / (float)((size_t)B * H * W * 4);  // the L1 mean runs over the whole image
   // With the vertex adjacency the gather writes every vertex output exactly once, and k_bwd_setup
   // clears the accumulator rows and light_grads on the side: no memset launches at all (two of
@@ -669,7 +728,7 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
   // Otherwise the outputs are zeroed here.  A caller that lays them out back to back (dclip,
   // dnormals, dpositions, ddiffuse, light_grads -- _native.py does) gets ONE memset instead of five
   // launch-bound ones.
-  if (fused_clear) {
+  if (fused_clear) {   // (always the case with `fold`: transforms imply the adjacency, and it excludes det)
   } else if (dnormals && ddiffuse && (char *)dnormals == (char *)dclip + v4 && (char *)dpositions == (char *)dnormals + v3 &&
              (char *)ddiffuse == (char *)dpositions + v3 && (char *)light_grads == (char *)ddiffuse + v3) {
     if (hipMemsetAsync(dclip, 0, v4 + 3 * v3 + lg, s) != hipSuccess) return check_launch();
@@ -751,8 +810,21 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
       rc = launch_accumulate_lanes(fn, B, T, W, H, acc, s);                                     \
     }                                                                                           \
   }
+#define MR_SHADE_LANES_FOLDED(NL)                                                               \
+  {                                                                                             \
+    KernelTimer timer(MR_TIMER_SHADE_BACKWARD, s);                                              \
+    if (signs) {                                                                                \
+      ShadeLaneFn<NL, true, false, 2, true, true> fn{{nullptr, signs, sign_upstream, sign_inv_n, ids, (const F3 *)bary, \
+                                                      corners, recs, lights, nullptr, T, W, H, transforms}};            \
+      rc = launch_accumulate_lanes(fn, B, T, W, H, acc, s);                                     \
+    } else {                                                                                    \
+      ShadeLaneFn<NL, false, false, 2, true, true> fn{{(const float4 *)drgba, nullptr, nullptr, 0.0f, ids, (const F3 *)bary, \
+                                                       corners, recs, lights, nullptr, T, W, H, transforms}};                \
+      rc = launch_accumulate_lanes(fn, B, T, W, H, acc, s);                                     \
+    }                                                                                           \
+  }
 #define MR_SHADE_LANES(NL, G)                                                                   \
-  if (opaque) MR_SHADE_LANES_O(NL, G, true) else MR_SHADE_LANES_O(NL, G, false)
+  if (fold) MR_SHADE_LANES_FOLDED(NL) else if (opaque) MR_SHADE_LANES_O(NL, G, true) else MR_SHADE_LANES_O(NL, G, false)
 #define MR_SHADE_LANES_LIGHTS(NL, G)   /* one or two lights: the variant with light gradients exists */ \
   if (light_grads) MR_SHADE_LANES_LGV(NL, G) else MR_SHADE_LANES(NL, G)
 #if MR_SHADE_LANES_ALL
@@ -818,6 +890,7 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
 #undef MR_SHADE_BWD
 #undef MR_SHADE_LANES_G
 #undef MR_SHADE_LANES
+#undef MR_SHADE_LANES_FOLDED
   if (rc != MR_OK) return rc;
   if (light_grads) {  // the strips' rows of light sums -> [B][6L + 3], fixed order (every element is written)
     rc = launch_sum_strip_rows(light_rows, B, light_strips_per_image(B, W, H, use_lanes), L * 6 + 3, light_grads, s);

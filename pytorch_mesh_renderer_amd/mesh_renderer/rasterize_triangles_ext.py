@@ -213,6 +213,7 @@ class FusedPhongRenderer(torch.autograd.Function):
             corner_records=corner_records, adjacency=(offsets, entries), l1_signs=l1_signs, transforms=xf,
             want_light_grads=needs_light_grads, want_normal_grads=needs_normal_grad,
             want_diffuse_grads=needs_diffuse_grad,
+            want_clip_grads=needs_transform_grad,   # d clip on its own only feeds d transforms below
             normalised_gbuffer=True)   # this function's own forward wrote ids / bary
         dxf = None
         if needs_transform_grad:  # d clip[b,v,r] / d xf[b,r,k] = (vertex, 1)[k]

@@ -1005,6 +1005,21 @@ def test_shade_backward_lane_kernel_matches_rows_kernel(device, w, h, res, n_lig
                         scale = float(full[k].abs().max())
                         np.testing.assert_allclose(lean[k].cpu().numpy(), full[k].cpu().numpy(), rtol=2e-4,
                                                    atol=2e-6 * scale, err_msg="output %d kernel %d" % (k, which))
+            # round 4: the clip-space gradient not wanted on its own (render() differentiated to the vertices
+            # only): the pull-back through the transforms is folded into the pixel pass -- 9 sums per triangle
+            # (ShadeLaneFn<..., FOLD>) -- and where that variant does not exist (rows kernel forced, G-buffer
+            # not declared normalised, normals wanted) the clip gradient goes to scratch: dclip is None and
+            # d positions is the same whole-vertex gradient every time
+            scale = float(full[2].abs().max())
+            for which, normalised, want_n in ((2, True, False), (1, True, False), (2, False, False), (2, True, True)):
+                _native.debug_set_shade_backward_kernel(which)
+                folded = _native.shade_backward(upstream, *tail, **kw, **extra, want_normal_grads=want_n,
+                                                want_diffuse_grads=False, normalised_gbuffer=normalised,
+                                                want_clip_grads=False)
+                assert folded[0] is None and folded[3] is None
+                np.testing.assert_allclose(folded[2].cpu().numpy(), full[2].cpu().numpy(), rtol=2e-4, atol=2e-6 * scale,
+                                           err_msg="d positions without d clip, kernel %d normalised %s normals %s" % (
+                                               which, normalised, want_n))
             if n_lights <= 2:
                 # second half of round 3: with one or two lights the lane kernel also carries the light
                 # gradients (6 L + 3 per-lane sums, one row per strip) -- against the rows kernel
