@@ -52,6 +52,34 @@ __device__ __forceinline__ void fill_corner_record(const F3 *__restrict__ normal
   for (int q = 0; q < 8; ++q) out->q[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
 }
 
+// Round 4: the record of the shading backward's folded lane kernel (ShadeFoldLaneFn, shade.hip), written by
+// k_bwd_setup from the CornerRec and the clip-space corners: the attributes in a DIFFERENCE basis --
+// e0 = c0 - c2, e1 = c1 - c2, c2 -- so that a pixel interpolates with 18 multiply-adds instead of 27
+// (at = c2 + b0 e0 + b1 e1: the rasterizer's barycentrics sum to 1) and the gradient through the
+// barycentrics needs two dot products with e0 / e1 instead of three with the corners (the rasterizer's
+// backward is invariant under a common shift of d L / d b: the brackets of cpp:202-269 sum to ~0 over the
+// corners), and of the adjugate only the rows of corners 0 and 1.  37 floats in 160 bytes.
+//   q[0..6]  e0[9] e1[9] c2[9] u0c[0] | q[7] u0c[1] u0c[2] u1c[0] u1c[1] | q[8] u1c[2] s[0] s[1] s[2] | q[9] 1/|det| - - -
+struct alignas(32) FoldRec {
+  float4 q[10];
+};
+struct FoldTriangle {
+  float e0[9], e1[9], c2[9], u0[3], u1[3], s[3], inv;
+};
+__device__ __forceinline__ void load_fold_triangle(const FoldRec *__restrict__ rec, FoldTriangle &t) {
+  float v[40];
+#pragma unroll
+  for (int q = 0; q < 10; ++q) {
+    const float4 f = rec->q[q];
+    v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w;
+  }
+#pragma unroll
+  for (int a = 0; a < 9; ++a) { t.e0[a] = v[a]; t.e1[a] = v[9 + a]; t.c2[a] = v[18 + a]; }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { t.u0[c] = v[27 + c]; t.u1[c] = v[30 + c]; t.s[c] = v[33 + c]; }
+  t.inv = v[36];
+}
+
 // Fills CornerRec[B*T] from the three [B,V,3] attribute arrays (defined in shade.hip).
 int launch_corner_setup(const float *normals, const float *positions, const float *diffuse,
                         const int32_t *tris, int B, int V, int T, CornerRec *out, hipStream_t s);

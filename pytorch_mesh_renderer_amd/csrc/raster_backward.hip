@@ -26,6 +26,7 @@
 // and the division by |det| is a multiplication by its fp32 reciprocal (<= 1.5 ulp
 // per partial).  Parity bar: 1e-4 abs.
 #include "run_accum.h"
+#include "corner_rec.h"
 
 namespace mr {
 
@@ -35,7 +36,8 @@ namespace mr {
 __global__ __launch_bounds__(256) void k_bwd_setup(
     const float4 *__restrict__ clip, const int32_t *__restrict__ tris, int B, int V, int T,
     BwdRec *__restrict__ recs, float4 *__restrict__ zero_rows, int zero_row_quads,
-    float *__restrict__ zero_tail, int zero_tail_count) {
+    float *__restrict__ zero_tail, int zero_tail_count, const CornerRec *__restrict__ corners,
+    FoldRec *__restrict__ fold_recs) {
   const long gid = (long)blockIdx.x * 256 + threadIdx.x;
   for (long i = gid; i < zero_tail_count; i += (long)gridDim.x * 256) zero_tail[i] = 0.0f;
   {  // the workgroup's 256 rows are one contiguous range: cleared with coalesced 16-byte stores
@@ -69,17 +71,40 @@ __global__ __launch_bounds__(256) void k_bwd_setup(
     r.d = make_float4(1.0f / fabsf(det), 0.f, 0.f, 0.f);
   }
   recs[gid] = r;
+  if (fold_recs) {  // (launch-uniform) the folded lane kernel's record, see corner_rec.h
+    float c[32];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float4 f = corners[gid].q[q];
+      c[4 * q] = f.x; c[4 * q + 1] = f.y; c[4 * q + 2] = f.z; c[4 * q + 3] = f.w;
+    }
+    float v[40];
+#pragma unroll
+    for (int a = 0; a < 9; ++a) {
+      v[a] = c[a] - c[18 + a];
+      v[9 + a] = c[9 + a] - c[18 + a];
+      v[18 + a] = c[18 + a];
+    }
+    // adjugate rows of corners 0 and 1 (u[3 i + c]: edge i, clip component c), the column sums, 1 / |det|
+    v[27] = r.a.x; v[28] = r.a.y; v[29] = r.a.z;
+    v[30] = r.a.w; v[31] = r.b.x; v[32] = r.b.y;
+    v[33] = r.c.y; v[34] = r.c.z; v[35] = r.c.w;
+    v[36] = r.d.x; v[37] = 0.f; v[38] = 0.f; v[39] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 10; ++q) fold_recs[gid].q[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+  }
 }
 
 int launch_bwd_setup(const float *clip, const int32_t *tris, int B, int V, int T, BwdRec *recs,
                      hipStream_t s, void *zero_rows, size_t zero_row_bytes, float *zero_tail,
-                     int zero_tail_count) {
+                     int zero_tail_count, const void *corners, void *fold_recs) {
   const long nbt = (long)B * T;
   if (nbt == 0) return MR_OK;
-  if (zero_row_bytes % 16 != 0) return MR_EINVAL;
+  if (zero_row_bytes % 16 != 0 || ((corners == nullptr) != (fold_recs == nullptr))) return MR_EINVAL;
   hipLaunchKernelGGL(k_bwd_setup, dim3((unsigned)((nbt + 255) / 256)), dim3(256), 0, s,
                      (const float4 *)clip, tris, B, V, T, recs, (float4 *)zero_rows,
-                     zero_rows ? (int)(zero_row_bytes / 16) : 0, zero_tail, zero_tail ? zero_tail_count : 0);
+                     zero_rows ? (int)(zero_row_bytes / 16) : 0, zero_tail, zero_tail ? zero_tail_count : 0,
+                     (const CornerRec *)corners, (FoldRec *)fold_recs);
   return check_launch();
 }
 

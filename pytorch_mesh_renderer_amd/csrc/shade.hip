@@ -265,32 +265,17 @@ struct ShadeGradFn {
     load_bwd_triangle(recs + (size_t)img * T_ + tri, t.bt);
   }
 
-  __device__ __forceinline__ void factors(const Pixel &p, const Triangle &t, float (&f)[kFactorStride],
-                                          Image &im) const {
-    factors_of<false>(p, t, f, im);
-  }
-  // OPAQUE: the caller vouches that every covered pixel's barycentrics sum to more than 1/2, as those
-  // mr_rasterize_forward writes do (they are normalised: the sum is 1 to a few ulp).  Then alpha = clamp(2 sum)
-  // is exactly 1 and sits outside the clamp's pass band: attr = 1 * interp + 0 * (-1) = interp, d/d attr =
-  // 1 * dat, and nothing flows through alpha -- the same bits as the general path with ~45 of its ~235 vector
-  // instructions per pixel gone (the blend, the d/d alpha dot product, its reciprocal).
-  template <bool OPAQUE>
-  __device__ __forceinline__ void factors_of(const Pixel &p, const Triangle &t, float (&f)[kFactorStride],
-                                             Image &im) const {
-    float pre, alpha, interp[9], at[9];
-    if (OPAQUE) {
-      pre = 2.0f;
-      alpha = 1.0f;
-#pragma unroll
-      for (int a = 0; a < 9; ++a) at[a] = (t.cr.c[0][a] * p.b.x + t.cr.c[1][a] * p.b.y) + t.cr.c[2][a] * p.b.z;
-    } else {
-      interpolate9(t.cr, p.b, pre, alpha, interp, at);
-    }
+  // The shading's backward at one pixel: from the interpolated attributes at[9] = (normal, position, diffuse
+  // colour) and the upstream gradient g of the pixel's RGB to dat[9] = d L / d at (render.py:199-228, 287-323
+  // differentiated by hand); the light / ambient gradients go to the per-lane sums of `im` (LG).
+  __device__ __forceinline__ void attribute_gradients(const float (&at)[9], const F3 &pg, Image &im,
+                                                      float (&dat_out)[9]) const {
     // render.py:215 mask: where() sends no gradient to a masked pixel.  All 36 outputs are
     // linear in g, so a masked pixel simply runs with g = 0 (every output must be assigned).
     const bool mask = (at[6] >= 0.0f) || (at[7] >= 0.0f) || (at[8] >= 0.0f);
+
     const float gs = SIGNS ? im.g_scale : 1.0f;
-    const float g[3] = {mask ? p.g.x * gs : 0.f, mask ? p.g.y * gs : 0.f, mask ? p.g.z * gs : 0.f};
+    const float g[3] = {mask ? pg.x * gs : 0.f, mask ? pg.y * gs : 0.f, mask ? pg.z * gs : 0.f};
     const float nn2 = at[0] * at[0] + at[1] * at[1] + at[2] * at[2];
     const float inv_nn = inv_norm(nn2);
     const float N[3] = {at[0] * inv_nn, at[1] * inv_nn, at[2] * inv_nn};
@@ -349,6 +334,33 @@ struct ShadeGradFn {
         dat[6 + c] = dKd[c];
       }
     }
+#pragma unroll
+    for (int a = 0; a < 9; ++a) dat_out[a] = dat[a];
+  }
+
+  __device__ __forceinline__ void factors(const Pixel &p, const Triangle &t, float (&f)[kFactorStride],
+                                          Image &im) const {
+    factors_of<false>(p, t, f, im);
+  }
+  // OPAQUE: the caller vouches that every covered pixel's barycentrics sum to more than 1/2, as those
+  // mr_rasterize_forward writes do (they are normalised: the sum is 1 to a few ulp).  Then alpha = clamp(2 sum)
+  // is exactly 1 and sits outside the clamp's pass band: attr = 1 * interp + 0 * (-1) = interp, d/d attr =
+  // 1 * dat, and nothing flows through alpha -- the same bits as the general path with ~45 of its ~235 vector
+  // instructions per pixel gone (the blend, the d/d alpha dot product, its reciprocal).
+  template <bool OPAQUE>
+  __device__ __forceinline__ void factors_of(const Pixel &p, const Triangle &t, float (&f)[kFactorStride],
+                                             Image &im) const {
+    float pre, alpha, interp[9], at[9];
+    if (OPAQUE) {
+      pre = 2.0f;
+      alpha = 1.0f;
+#pragma unroll
+      for (int a = 0; a < 9; ++a) at[a] = (t.cr.c[0][a] * p.b.x + t.cr.c[1][a] * p.b.y) + t.cr.c[2][a] * p.b.z;
+    } else {
+      interpolate9(t.cr, p.b, pre, alpha, interp, at);
+    }
+    float dat[9];
+    attribute_gradients(at, p.g, im, dat);
     // interpolation backward (rasterize.py:137-150)
     // d/d alpha = sum_a dat[a] * (interp[a] + 1) with interp[a] + 1 = (at[a] + 1) / alpha
     // (alpha > 0 on every valid pixel): `interp` need not stay live across the shading math.
@@ -487,6 +499,63 @@ struct ShadeLaneFn : ShadeGradFn<L, SIGNS, LG> {
 #pragma unroll
         for (int c = 0; c < 3; ++c) a[9 * kGroups + k * 3 + c] = fmaf(f[k], f[12 + c], a[9 * kGroups + k * 3 + c]);
     }
+  }
+};
+
+// The folded variant's functor proper (round 4): vertex gradients only, G-buffer normalised, no light
+// gradients -- the benchmark's and every vertex-optimisation loop's backward.  Per pixel and lane:
+//   at = c2 + b0 e0 + b1 e1                       (FoldRec's difference basis: 18 multiply-adds, not 27)
+//   dat = attribute_gradients(at, g)              (the shading's own backward, shared with every other variant)
+//   g0 = dat . e0, g1 = dat . e1                  (d L / d b0 - d L / d b2 and d L / d b1 - d L / d b2: 18, not 27)
+//   q_c = (g0 (s_c b0 - u_0c) + g1 (s_c b1 - u_1c)) / |det|     (cpp:202-269 with the common shift d L / d b2
+//                                                  taken out: its brackets sum to s_c (sum b - 1) ~ 0 over the corners)
+//   y_c = dat[3 + c] + (M^T q)_c                  (position attribute + clip-space pull-back, see FOLD above)
+//   a[k][c] += b_k y_c                            (9 sums per triangle)
+// ~50 vector instructions per pixel row fewer than ShadeLaneFn<L, SIGNS, false, 2, true, true>.
+#ifndef MR_SHADE_FOLD_DIFF
+#define MR_SHADE_FOLD_DIFF 1
+#endif
+template <int L, bool SIGNS>
+struct ShadeFoldLaneFn : ShadeGradFn<L, SIGNS, false> {
+  using Base = ShadeGradFn<L, SIGNS, false>;
+  static constexpr int kN = 9;
+  static constexpr int kStride = 36;  // the rows of acc keep ShadeGradFn's layout: the gather reads it
+  static constexpr int kLaneRowsPerWave = MR_LANE_ROWS;
+  static constexpr int kMinWavesPerSimd = MR_LANE_WAVES;
+  const FoldRec *__restrict__ fold_recs;
+  using Triangle = FoldTriangle;
+  __device__ static int column(int o) { return (o / 3) * 9 + 3 + o % 3; }  // sum o = corner * 3 + c -> position group
+  __device__ __forceinline__ void load_triangle(int img, int tri, Triangle &t) const {
+    load_fold_triangle(fold_recs + (size_t)img * this->T_ + tri, t);
+  }
+  __device__ __forceinline__ void accumulate(const typename Base::Pixel &p, const Triangle &t, float (&a)[kN],
+                                             typename Base::Image &im) const {
+    float at[9], dat[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) at[k] = fmaf(p.b.x, t.e0[k], fmaf(p.b.y, t.e1[k], t.c2[k]));
+    Base::attribute_gradients(at, p.g, im, dat);
+    float g0 = 0.f, g1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      g0 = fmaf(dat[k], t.e0[k], g0);
+      g1 = fmaf(dat[k], t.e1[k], g1);
+    }
+    float y[3];
+    float q[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float w0 = t.s[c] * p.b.x - t.u0[c];
+      const float w1 = t.s[c] * p.b.y - t.u1[c];
+      q[c] = (g0 * w0 + g1 * w1) * t.inv;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      y[c] = dat[3 + c] + ((im.pull[0][c] * q[0] + im.pull[1][c] * q[1]) + im.pull[2][c] * q[2]);
+    const float b[3] = {p.b.x, p.b.y, p.b.z};
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) a[k * 3 + c] = fmaf(b[k], y[c], a[k * 3 + c]);
   }
 };
 
@@ -688,7 +757,8 @@ int launch_shade_forward(const int32_t *ids, const float *bary, const float *nor
 
 size_t shade_backward_ws(int B, int V, int T, int W, int H) {
   return shade_acc_bytes(B, T) + align_up((size_t)B * T * sizeof(BwdRec), 256) + corner_bytes(B, T) +
-         kDetMiscBytes + light_rows_bytes(B, W, H) + align_up((size_t)B * V * 4 * sizeof(float), 256);  // last: dclip scratch
+         kDetMiscBytes + light_rows_bytes(B, W, H) + align_up((size_t)B * T * sizeof(FoldRec), 256) +
+         align_up((size_t)B * V * 4 * sizeof(float), 256);  // last two: the folded kernel's records, dclip scratch
 }
 
 thread_local int g_deterministic = 0;  // mr_set_deterministic
@@ -748,6 +818,8 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
   float *det_scale = (float *)((char *)corners + corner_bytes(B, T));
   int *max_bits = (int *)(det_scale + 4);
   float *light_rows = (float *)((char *)det_scale + kDetMiscBytes);
+  FoldRec *fold_recs = (FoldRec *)((char *)light_rows + light_rows_bytes(B, W, H));
+  const bool fold_diff = fold && MR_SHADE_FOLD_DIFF && corner_records != nullptr;   // (the records of the forward)
   if (det && !(vertex_offsets && vertex_entries)) return MR_EINVAL;  // the scatter path is atomics only
   const size_t acc_bytes = (size_t)B * T * 36 * (det ? sizeof(long long) : sizeof(float));
   if (!fused_clear && hipMemsetAsync(acc, 0, acc_bytes, s) != hipSuccess) return check_launch();
@@ -764,7 +836,8 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
     if ((rc = check_launch()) != MR_OK) return rc;
   }
   rc = fused_clear ? launch_bwd_setup(clip, tris, B, V, T, recs, s, acc, 36 * sizeof(float), light_grads,
-                                      light_grads ? B * (L * 6 + 3) : 0)
+                                      light_grads ? B * (L * 6 + 3) : 0, fold_diff ? corner_records : nullptr,
+                                      fold_diff ? fold_recs : nullptr)
                    : launch_bwd_setup(clip, tris, B, V, T, recs, s);
   if (rc != MR_OK) return rc;
   if (corner_records) {  // the forward's records (same inputs): skip the gather
@@ -811,7 +884,18 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
     }                                                                                           \
   }
 #define MR_SHADE_LANES_FOLDED(NL)                                                               \
-  {                                                                                             \
+  if (fold_diff) {                                                                              \
+    KernelTimer timer(MR_TIMER_SHADE_BACKWARD, s);                                              \
+    if (signs) {                                                                                \
+      ShadeFoldLaneFn<NL, true> fn{{nullptr, signs, sign_upstream, sign_inv_n, ids, (const F3 *)bary, corners, recs, \
+                                    lights, nullptr, T, W, H, transforms}, fold_recs};          \
+      rc = launch_accumulate_lanes(fn, B, T, W, H, acc, s);                                     \
+    } else {                                                                                    \
+      ShadeFoldLaneFn<NL, false> fn{{(const float4 *)drgba, nullptr, nullptr, 0.0f, ids, (const F3 *)bary, corners,  \
+                                     recs, lights, nullptr, T, W, H, transforms}, fold_recs};   \
+      rc = launch_accumulate_lanes(fn, B, T, W, H, acc, s);                                     \
+    }                                                                                           \
+  } else {                                                                                      \
     KernelTimer timer(MR_TIMER_SHADE_BACKWARD, s);                                              \
     if (signs) {                                                                                \
       ShadeLaneFn<NL, true, false, 2, true, true> fn{{nullptr, signs, sign_upstream, sign_inv_n, ids, (const F3 *)bary, \
