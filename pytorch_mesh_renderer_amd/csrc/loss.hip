@@ -114,6 +114,10 @@ __global__ __launch_bounds__(kThreads) void k_l1_forward(const float4 *__restric
   }
 }
 
+// (Round 4, measured and dropped: the workgroup that ARRIVES LAST adding the partial sums inside k_l1_forward --
+//  write-through partials, a drained store, one agent-scope add to an arrival counter per workgroup, agent-scope
+//  loads by the last one.  One launch less, but the pass's tail grows by more than the launch it saves: same-box
+//  A/B 0.190 + finish -> 0.2005 ms for the kernel, step 0.7241 -> 0.7322 ms.)
 // One workgroup adds the workgroups' partial sums in a fixed order (no float atomics: the loss
 // value is bit-identical from run to run).  1024 threads, two independent loads each: a single
 // wavefront looping over 2048 partials was 32 dependent load round trips (9 us).

@@ -515,16 +515,17 @@ struct ShadeLaneFn : ShadeGradFn<L, SIGNS, LG> {
 #ifndef MR_SHADE_FOLD_DIFF
 #define MR_SHADE_FOLD_DIFF 1
 #endif
+constexpr int kFoldAccStride = 12;  // floats per (image, triangle) accumulator row of the folded variant: 48 bytes
 template <int L, bool SIGNS>
 struct ShadeFoldLaneFn : ShadeGradFn<L, SIGNS, false> {
   using Base = ShadeGradFn<L, SIGNS, false>;
   static constexpr int kN = 9;
-  static constexpr int kStride = 36;  // the rows of acc keep ShadeGradFn's layout: the gather reads it
+  static constexpr int kStride = kFoldAccStride;  // COMPACT rows: [corner][c] + 3 of padding (k_shade_gather_fold reads them)
   static constexpr int kLaneRowsPerWave = MR_LANE_ROWS;
   static constexpr int kMinWavesPerSimd = MR_LANE_WAVES;
   const FoldRec *__restrict__ fold_recs;
   using Triangle = FoldTriangle;
-  __device__ static int column(int o) { return (o / 3) * 9 + 3 + o % 3; }  // sum o = corner * 3 + c -> position group
+  __device__ static int column(int o) { return o; }  // sum o = corner * 3 + c
   __device__ __forceinline__ void load_triangle(int img, int tri, Triangle &t) const {
     load_fold_triangle(fold_recs + (size_t)img * this->T_ + tri, t);
   }
@@ -662,6 +663,39 @@ __global__ __launch_bounds__(kThreads) void k_shade_gather(
              : j < 11 ? dclip + gid * 4 + (j - 9)
              : j == 11 ? dclip + gid * 4 + 3 : dclip + gid * 4 + 2;  // j == 12: column z stays 0
   *out = sum;
+}
+
+// The folded variant's per-vertex gather: its accumulator rows hold nine floats -- [corner][c], the whole
+// gradient of the corner's world-space position -- in 48 bytes, so a vertex needs three sums, not thirteen:
+// four lanes per (image, vertex) (the fourth idles), 320 k threads instead of 1.3 M at 32 x 2502 vertices, a third
+// of the bytes.  Same fixed summation order as k_shade_gather (the adjacency's).
+__global__ __launch_bounds__(kThreads) void k_shade_gather_fold(
+    const float *__restrict__ acc, const int32_t *__restrict__ offsets, const int32_t *__restrict__ entries, int B, int V,
+    int T, float *__restrict__ dpositions) {
+  const long tid = (long)blockIdx.x * kThreads + threadIdx.x;
+  const long gid = tid >> 2;   // (image, vertex)
+  const int c = (int)(tid & 3);
+  if (gid >= (long)B * V || c == 3) return;
+  const int b = (int)(gid / V);
+  const int v = (int)(gid - (long)b * V);
+  const float *acc_f = acc + (size_t)b * T * kFoldAccStride;
+  constexpr int kChunk = MR_GATHER_CHUNK;
+  float sum = 0.f;
+  const int e1 = offsets[v + 1];
+  for (int i = offsets[v]; i < e1; i += kChunk) {
+    int e[kChunk];
+    float val[kChunk];
+#pragma unroll
+    for (int u = 0; u < kChunk; ++u) e[u] = i + u < e1 ? entries[i + u] : -1;
+#pragma unroll
+    for (int u = 0; u < kChunk; ++u) {
+      const unsigned t = (unsigned)e[u] / 3u, k = (unsigned)e[u] - 3u * t;
+      val[u] = e[u] < 0 ? 0.f : acc_f[t * (unsigned)kFoldAccStride + k * 3u + (unsigned)c];
+    }
+#pragma unroll
+    for (int u = 0; u < kChunk; ++u) sum += val[u];
+  }
+  dpositions[gid * 3 + c] = sum;
 }
 
 inline unsigned capped_blocks(size_t n) {
@@ -835,7 +869,7 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
     hipLaunchKernelGGL(k_det_scale, dim3(1), dim3(1), 0, s, max_bits, sign_upstream, sign_inv_n, det_scale);
     if ((rc = check_launch()) != MR_OK) return rc;
   }
-  rc = fused_clear ? launch_bwd_setup(clip, tris, B, V, T, recs, s, acc, 36 * sizeof(float), light_grads,
+  rc = fused_clear ? launch_bwd_setup(clip, tris, B, V, T, recs, s, acc, (fold_diff ? kFoldAccStride : 36) * sizeof(float), light_grads,
                                       light_grads ? B * (L * 6 + 3) : 0, fold_diff ? corner_records : nullptr,
                                       fold_diff ? fold_recs : nullptr)
                    : launch_bwd_setup(clip, tris, B, V, T, recs, s);
@@ -979,6 +1013,12 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
   if (light_grads) {  // the strips' rows of light sums -> [B][6L + 3], fixed order (every element is written)
     rc = launch_sum_strip_rows(light_rows, B, light_strips_per_image(B, W, H, use_lanes), L * 6 + 3, light_grads, s);
     if (rc != MR_OK) return rc;
+  }
+  if (fold_diff) {  // compact rows, position gradient only
+    const long nbv = (long)B * V * 4;
+    hipLaunchKernelGGL(k_shade_gather_fold, dim3((unsigned)((nbv + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, acc,
+                       vertex_offsets, vertex_entries, B, V, T, dpositions);
+    return check_launch();
   }
   if (vertex_offsets && vertex_entries) {
     const long nbv = (long)B * V * 16;  // sixteen lanes per vertex
