@@ -187,14 +187,20 @@ int mr_vertex_transform(const float *vertices, const float *transforms, int B, i
  *                   and its contents after the call are undefined.
  *   corner_records  out, mr_shade_forward_workspace_bytes() bytes, 128-byte aligned: the gathered
  *                   per-triangle attribute records; may be handed to mr_shade_backward.
+ *   backward_prepared  NULL, or out: mr_shade_backward_prepared_bytes(B, T) bytes, 256-byte aligned.  For a
+ *                   caller that will differentiate the image to the world-space vertices ONLY (the usual
+ *                   optimisation loop): the per-triangle setup kernel -- which holds the corner attributes
+ *                   and the sign-corrected adjugate in registers anyway -- also writes the records of the
+ *                   folded shading backward and clears its accumulator rows.  Handed to
+ *                   mr_shade_backward[_l1] as `prepared`, the backward then needs no setup launch.
  *   workspace       mr_rasterize_forward_workspace_bytes() bytes */
 int mr_render_forward(const float *vertices, const float *transforms, const float *normals,
                       const float *diffuse, const int32_t *triangles,
                       const float *light_positions, const float *light_intensities,
                       const float *ambient, int B, int V, int T, int W, int H, int L,
                       float *clip, int32_t *ids, float *bary, float *z, int want_z, float *rgba,
-                      uint8_t *rgba_u8, void *corner_records, void *workspace, size_t workspace_bytes,
-                      void *stream);
+                      uint8_t *rgba_u8, void *corner_records, void *backward_prepared, void *workspace,
+                      size_t workspace_bytes, void *stream);
 
 /* Backward of mr_shade_forward AND of the rasterizer underneath it, in one pass
  * over the G-buffer (reads 32 B/px).  All outputs are zeroed here.
@@ -230,9 +236,16 @@ int mr_render_forward(const float *vertices, const float *transforms, const floa
  *                   ddiffuse NULL, MR_GBUFFER_NORMALISED, not deterministic) the pull-back is then applied
  *                   per pixel and the pixel pass keeps 9 sums per triangle instead of 18; elsewhere the
  *                   clip gradient goes to the workspace.
+ *   prepared        NULL, or the block mr_render_forward filled as `backward_prepared` for the SAME
+ *                   inputs (256-byte aligned).  Used -- the setup launch skipped -- when the call is one
+ *                   the folded kernel serves (dclip, dnormals, ddiffuse, light_grads NULL; transforms and
+ *                   the adjacency given; MR_GBUFFER_NORMALISED; not deterministic), ignored otherwise.  The
+ *                   block's accumulator rows are clear on entry and are left clear (the per-vertex gather
+ *                   zeroes what it reads): one block serves any number of backward calls, one at a time.
  * dclip, dnormals, dpositions, ddiffuse, light_grads laid out back to back in that order are
  * zeroed with a single memset (none at all with the vertex adjacency: every output is written
  * exactly once). */
+size_t mr_shade_backward_prepared_bytes(int B, int T);
 size_t mr_shade_backward_workspace_bytes(int B, int V, int T, int W, int H);
 int mr_shade_backward(const float *drgba, const int32_t *ids, const float *bary,
                       const float *clip, const float *normals, const float *positions,
@@ -242,7 +255,8 @@ int mr_shade_backward(const float *drgba, const int32_t *ids, const float *bary,
                       float *dclip, float *dnormals, float *dpositions,
                       float *ddiffuse, float *light_grads, const void *corner_records,
                       const int32_t *vertex_offsets, const int32_t *vertex_entries,
-                      const float *transforms, int gbuffer_flags, void *workspace, size_t workspace_bytes,
+                      const float *transforms, int gbuffer_flags, void *prepared, void *workspace,
+                      size_t workspace_bytes,
                       void *stream);
 /* gbuffer_flags, bit 0 = MR_GBUFFER_NORMALISED: the caller vouches that ids / bary are what
  * mr_rasterize_forward (or mr_render_forward) wrote for these very vertices -- every covered pixel's
@@ -267,7 +281,7 @@ int mr_shade_backward_l1(const uint8_t *signs, const float *upstream, const int3
                          float *dclip, float *dnormals, float *dpositions, float *ddiffuse,
                          float *light_grads, const void *corner_records,
                          const int32_t *vertex_offsets, const int32_t *vertex_entries,
-                         const float *transforms, int gbuffer_flags, void *workspace,
+                         const float *transforms, int gbuffer_flags, void *prepared, void *workspace,
                          size_t workspace_bytes, void *stream);
 
 /* ---- fused deferred shading with the specular term --------------------------------

@@ -16,7 +16,7 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 # build libmesh_raster_hip_probes.so this way); the product always loads the in-tree library.
 LIB_PATH = os.environ.get("MR_NATIVE_LIB_PATH") or os.path.join(_CSRC, "libmesh_raster_hip.so")
 
-ABI_VERSION = 343
+ABI_VERSION = 350
 GBUFFER_NORMALISED = 1   # mesh_raster.h, MR_GBUFFER_NORMALISED
 TIMER_RASTER_FORWARD, TIMER_SHADE_BACKWARD, TIMER_SHADE_FORWARD, TIMER_RASTER_BACKWARD, TIMER_L1_FORWARD = 0, 1, 2, 3, 4
 MR_OK, MR_EINVAL, MR_EWORKSPACE, MR_ELAUNCH = 0, -1, -2, -3
@@ -41,6 +41,11 @@ def set_deterministic(on):
     before = _deterministic
     _deterministic = bool(on)
     return before
+
+
+def deterministic():
+    """Whether set_deterministic(True) is in force."""
+    return _deterministic
 
 
 def _sync_deterministic():
@@ -157,11 +162,13 @@ def lib():
         L.mr_shade_forward.restype = ci
         L.mr_shade_backward_workspace_bytes.argtypes = [ci] * 5
         L.mr_shade_backward_workspace_bytes.restype = sz
-        L.mr_shade_backward.argtypes = [vp] * 11 + [ci] * 6 + [vp] * 9 + [ci, vp, sz, vp]
+        L.mr_shade_backward_prepared_bytes.argtypes = [ci] * 2
+        L.mr_shade_backward_prepared_bytes.restype = sz
+        L.mr_shade_backward.argtypes = [vp] * 11 + [ci] * 6 + [vp] * 9 + [ci, vp, vp, sz, vp]
         L.mr_shade_backward.restype = ci
         L.mr_shade_backward_l1_workspace_bytes.argtypes = [ci] * 5
         L.mr_shade_backward_l1_workspace_bytes.restype = sz
-        L.mr_shade_backward_l1.argtypes = [vp] * 12 + [ci] * 6 + [vp] * 9 + [ci, vp, sz, vp]
+        L.mr_shade_backward_l1.argtypes = [vp] * 12 + [ci] * 6 + [vp] * 9 + [ci, vp, vp, sz, vp]
         L.mr_shade_backward_l1.restype = ci
         L.mr_soft_max_lights.restype = ci
         L.mr_soft_workspace_bytes.argtypes = [ci] * 5
@@ -195,7 +202,7 @@ def lib():
         L.mr_interpolate_raster_backward.restype = ci
         L.mr_vertex_transform.argtypes = [vp, vp, ci, ci, vp, vp]
         L.mr_vertex_transform.restype = ci
-        L.mr_render_forward.argtypes = [vp] * 8 + [ci] * 6 + [vp, vp, vp, vp, ci] + [vp] * 4 + [sz, vp]
+        L.mr_render_forward.argtypes = [vp] * 8 + [ci] * 6 + [vp, vp, vp, vp, ci] + [vp] * 5 + [sz, vp]
         L.mr_render_forward.restype = ci
         L.mr_shade_specular_forward_workspace_bytes.argtypes = [ci] * 5
         L.mr_shade_specular_forward_workspace_bytes.restype = sz
@@ -481,12 +488,16 @@ def vertex_transform(vertices, transforms):
 
 
 def render_forward(vertices, transforms, normals, diffuse, triangles, light_positions, light_intensities,
-                   ambient, width, height, want_z=True, want_u8=False):
+                   ambient, width, height, want_z=True, want_u8=False, prepare_backward=False):
     """render()'s forward from world-space vertices: clip-space transform, rasterizer and shading
     (the shading is the epilogue of the rasterizer's tile walk: one pass over the pixels)
     -> (clip, ids, bary, z, rgba, corner_records); with want_z=False the depth plane is not written
     (z is returned as None); with want_u8=True a seventh value follows, the image as [B,H,W,4] uint8
-    frames (what export_u8(rgba) would return)."""
+    frames (what export_u8(rgba) would return).
+
+    prepare_backward=True (the caller will differentiate to the world-space vertices only): the setup kernel
+    also writes the folded shading backward's records and clears its accumulator rows; the block is returned as
+    the LAST value and goes to shade_backward(..., prepared=), which then launches no setup kernel."""
     tensors = [vertices, transforms, normals, diffuse, triangles, light_positions, light_intensities]
     _chk("vertices", vertices, _F32, None, None, 3)
     _chk("triangles", triangles, _I32, None, 3)
@@ -509,17 +520,17 @@ def render_forward(vertices, transforms, normals, diffuse, triangles, light_posi
     frames = torch.empty(B, height, width, 4, dtype=torch.uint8, device=dev) if want_u8 else None
     with torch.cuda.device(dev):
         records = _aligned_bytes(L.mr_shade_forward_workspace_bytes(B, V, T, width, height), dev)
+        prepared = _aligned_bytes(L.mr_shade_backward_prepared_bytes(B, T), dev) if prepare_backward else None
         need = L.mr_rasterize_forward_workspace_bytes(B, V, T, width, height)
         ws, have = _workspace(dev, need)
         _arm_timer(TIMER_RASTER_FORWARD)
         rc = L.mr_render_forward(_ptr(vertices), _ptr(transforms), _ptr(normals), _ptr(diffuse), _ptr(triangles),
                                  _ptr(light_positions), _ptr(light_intensities), _ptr(ambient), B, V, T,
                                  width, height, nl, _ptr(clip), _ptr(ids), _ptr(bary), _ptr(z), int(bool(want_z)),
-                                 _ptr(rgba), _ptr(frames), _ptr(records), _ptr(ws), have, _stream(dev))
+                                 _ptr(rgba), _ptr(frames), _ptr(records), _ptr(prepared), _ptr(ws), have, _stream(dev))
     _check(rc, "mr_render_forward")
-    if want_u8:
-        return clip, ids, bary, (z if want_z else None), rgba, records, frames
-    return clip, ids, bary, (z if want_z else None), rgba, records
+    out = (clip, ids, bary, (z if want_z else None), rgba, records) + ((frames,) if want_u8 else ())
+    return out + ((prepared,) if prepare_backward else ())
 
 
 def interpolate_raster_max_attributes():
@@ -611,7 +622,7 @@ def vertex_adjacency(triangles, vertex_count):
 def shade_backward(drgba, ids, bary, clip, normals, positions, diffuse, triangles, light_positions,
                    light_intensities, ambient, corner_records=None, adjacency=None, l1_signs=None,
                    transforms=None, want_light_grads=True, want_normal_grads=True, want_diffuse_grads=True,
-                   normalised_gbuffer=False, want_clip_grads=True):
+                   normalised_gbuffer=False, want_clip_grads=True, prepared=None):
     """_shade_backward_call for any light count up to shade_max_lights().  The kernels keep the light
     gradients' 6 L sums in registers, four lights per call; with more lights the vertex-side gradients
     come from one call over all lights (a run-time loop, no light gradients) and each group of four
@@ -622,7 +633,7 @@ def shade_backward(drgba, ids, bary, clip, normals, positions, diffuse, triangle
     nl = light_positions.shape[1]
     kw = dict(corner_records=corner_records, adjacency=adjacency, l1_signs=l1_signs, transforms=transforms,
               want_normal_grads=want_normal_grads, want_diffuse_grads=want_diffuse_grads,
-              normalised_gbuffer=normalised_gbuffer, want_clip_grads=want_clip_grads)
+              normalised_gbuffer=normalised_gbuffer, want_clip_grads=want_clip_grads, prepared=prepared)
     fast = shade_fast_lights() if nl > 4 else nl
     if nl <= fast or not want_light_grads:
         return _shade_backward_call(drgba, ids, bary, clip, normals, positions, diffuse, triangles,
@@ -647,7 +658,7 @@ def shade_backward(drgba, ids, bary, clip, normals, positions, diffuse, triangle
 def _shade_backward_call(drgba, ids, bary, clip, normals, positions, diffuse, triangles, light_positions,
                          light_intensities, ambient, corner_records=None, adjacency=None, l1_signs=None,
                          transforms=None, want_light_grads=True, want_normal_grads=True, want_diffuse_grads=True,
-                         normalised_gbuffer=False, want_clip_grads=True):
+                         normalised_gbuffer=False, want_clip_grads=True, prepared=None):
     """-> (dclip [B,V,4], dnormals, dpositions, ddiffuse [B,V,3], dlight_positions,
     dlight_intensities [B,L,3], dambient [B,3] or None); with want_light_grads=False the last three
     are None and the kernel leaves their accumulation out; want_normal_grads / want_diffuse_grads=False
@@ -665,7 +676,12 @@ def _shade_backward_call(drgba, ids, bary, clip, normals, positions, diffuse, tr
 
     want_clip_grads=False (needs `transforms`): dclip is returned as None -- the caller differentiates to
     the world-space vertices only; the pull-back through the transforms is then folded into the pixel
-    pass where the library has that variant (9 sums per triangle instead of 18)."""
+    pass where the library has that variant (9 sums per triangle instead of 18).
+
+    prepared: the block render_forward(..., prepare_backward=True) returned for these inputs (or None)."""
+    if prepared is not None and (prepared.dtype != torch.uint8 or
+                                 prepared.numel() < lib().mr_shade_backward_prepared_bytes(clip.shape[0], triangles.shape[0])):
+        raise ValueError("prepared must be the block render_forward(prepare_backward=True) returned for these inputs")
     if not want_clip_grads and transforms is None:
         raise ValueError("without transforms the clip-space gradient is the vertex gradient: it cannot be left out")
     tensors = [drgba, ids, bary, clip, normals, positions, diffuse, triangles, light_positions,
@@ -714,7 +730,7 @@ def _shade_backward_call(drgba, ids, bary, clip, normals, positions, diffuse, tr
     tail = (B, V, T, W, H, nl, _ptr(dclip), _ptr(dn), _ptr(dp), _ptr(dd), _ptr(lg), _ptr(corner_records),
             _ptr(adjacency[0]) if adjacency is not None else None,
             _ptr(adjacency[1]) if adjacency is not None else None, _ptr(transforms),
-            GBUFFER_NORMALISED if normalised_gbuffer else 0)
+            GBUFFER_NORMALISED if normalised_gbuffer else 0, _ptr(prepared))
     with torch.cuda.device(dev):
         _arm_timer(TIMER_SHADE_BACKWARD)
         _sync_deterministic()

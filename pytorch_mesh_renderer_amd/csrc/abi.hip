@@ -31,7 +31,7 @@ extern thread_local int g_shade_backward_kernel;
 
 extern "C" {
 
-int mr_version(void) { return 343; /* 0.4.1: + mr_debug_soft_nearest */ }
+int mr_version(void) { return 350; /* 0.5.0: dclip optional, backward_prepared / prepared, mr_debug_soft_nearest, two's-complement sign codes */ }
 
 int mr_last_hip_error(void) { return mr::g_last_hip_error; }
 
@@ -233,26 +233,32 @@ int mr_render_forward(const float *vertices, const float *transforms, const floa
                       const float *diffuse, const int32_t *triangles, const float *light_positions,
                       const float *light_intensities, const float *ambient, int B, int V, int T, int W,
                       int H, int L, float *clip, int32_t *ids, float *bary, float *z, int want_z,
-                      float *rgba, uint8_t *rgba_u8, void *corner_records, void *workspace,
-                      size_t workspace_bytes, void *stream) {
+                      float *rgba, uint8_t *rgba_u8, void *corner_records, void *backward_prepared,
+                      void *workspace, size_t workspace_bytes, void *stream) {
   if (bad_dims(B, V, T, W, H) || T < 1 || V < 1 || L < 1 || L > mr::shade_max_lights())
     return MR_EINVAL;
   if (B == 0) return MR_OK;
   if (!vertices || !transforms || !normals || !diffuse || !triangles || !light_positions ||
       !light_intensities || !clip || !ids || !bary || !z || !rgba || !corner_records ||
       ((uintptr_t)corner_records & 127u) || ((uintptr_t)clip & 15u) || ((uintptr_t)transforms & 15u) ||
-      ((uintptr_t)rgba_u8 & 3u))
+      ((uintptr_t)rgba_u8 & 3u) || ((uintptr_t)backward_prepared & 255u))
     return MR_EINVAL;
   const int rc = check_ws(workspace, workspace_bytes, mr::raster_forward_ws(B, V, T, W, H));
   if (rc != MR_OK) return rc;
   return mr::launch_render_forward(vertices, transforms, normals, diffuse, triangles, light_positions,
                                    light_intensities, ambient, B, V, T, W, H, L, clip, ids, bary, z,
-                                   want_z, rgba, rgba_u8, corner_records, workspace, (hipStream_t)stream);
+                                   want_z, rgba, rgba_u8, corner_records, backward_prepared, workspace,
+                                   (hipStream_t)stream);
 }
 
 size_t mr_shade_forward_workspace_bytes(int B, int V, int T, int W, int H) {
   if (bad_dims(B, V, T, W, H)) return 0;
   return mr::shade_forward_ws(B, V, T, W, H);
+}
+
+size_t mr_shade_backward_prepared_bytes(int B, int T) {
+  if (B < 0 || T < 0) return 0;
+  return mr::shade_backward_prepared_bytes(B, T);
 }
 
 size_t mr_shade_backward_workspace_bytes(int B, int V, int T, int W, int H) {
@@ -267,8 +273,8 @@ int mr_shade_backward(const float *drgba, const int32_t *ids, const float *bary,
                       int W, int H, int L, float *dclip, float *dnormals, float *dpositions,
                       float *ddiffuse, float *light_grads, const void *corner_records,
                       const int32_t *vertex_offsets, const int32_t *vertex_entries,
-                      const float *transforms, int gbuffer_flags, void *workspace, size_t workspace_bytes,
-                      void *stream) {
+                      const float *transforms, int gbuffer_flags, void *prepared, void *workspace,
+                      size_t workspace_bytes, void *stream) {
   if (bad_dims(B, V, T, W, H) || T < 1 || V < 1 || L < 1 || L > mr::shade_max_lights() ||
       (gbuffer_flags & ~MR_GBUFFER_NORMALISED))
     return MR_EINVAL;
@@ -281,12 +287,13 @@ int mr_shade_backward(const float *drgba, const int32_t *ids, const float *bary,
   if ((vertex_offsets == nullptr) != (vertex_entries == nullptr)) return MR_EINVAL;
   if (vertex_offsets && ((uintptr_t)dclip & 15u) != 0) return MR_EINVAL;
   if (transforms && (!vertex_offsets || ((uintptr_t)transforms & 3u) != 0)) return MR_EINVAL;
+  if (((uintptr_t)prepared & 255u) != 0) return MR_EINVAL;
   const int rc = check_ws(workspace, workspace_bytes, mr::shade_backward_ws(B, V, T, W, H));
   if (rc != MR_OK) return rc;
   return mr::launch_shade_backward(drgba, nullptr, nullptr, ids, bary, clip, normals, positions, diffuse,
                                    triangles, light_positions, light_intensities, ambient, B, V, T, W, H, L,
                                    dclip, dnormals, dpositions, ddiffuse, light_grads, corner_records,
-                                   vertex_offsets, vertex_entries, transforms, gbuffer_flags, workspace,
+                                   vertex_offsets, vertex_entries, transforms, gbuffer_flags, prepared, workspace,
                                    (hipStream_t)stream);
 }
 
@@ -303,7 +310,7 @@ int mr_shade_backward_l1(const uint8_t *signs, const float *upstream, const int3
                          float *dnormals, float *dpositions, float *ddiffuse, float *light_grads,
                          const void *corner_records, const int32_t *vertex_offsets,
                          const int32_t *vertex_entries, const float *transforms, int gbuffer_flags,
-                         void *workspace, size_t workspace_bytes, void *stream) {
+                         void *prepared, void *workspace, size_t workspace_bytes, void *stream) {
   if (bad_dims(B, V, T, W, H) || T < 1 || V < 1 || L < 1 || L > mr::shade_max_lights() ||
       (gbuffer_flags & ~MR_GBUFFER_NORMALISED))
     return MR_EINVAL;
@@ -316,12 +323,13 @@ int mr_shade_backward_l1(const uint8_t *signs, const float *upstream, const int3
   if ((vertex_offsets == nullptr) != (vertex_entries == nullptr)) return MR_EINVAL;
   if (vertex_offsets && ((uintptr_t)dclip & 15u) != 0) return MR_EINVAL;
   if (transforms && (!vertex_offsets || ((uintptr_t)transforms & 3u) != 0)) return MR_EINVAL;
+  if (((uintptr_t)prepared & 255u) != 0) return MR_EINVAL;
   const int rc = check_ws(workspace, workspace_bytes, mr::shade_backward_ws(B, V, T, W, H) + 256);
   if (rc != MR_OK) return rc;
   return mr::launch_shade_backward(nullptr, signs, upstream, ids, bary, clip, normals, positions, diffuse,
                                    triangles, light_positions, light_intensities, ambient, B, V, T, W, H, L,
                                    dclip, dnormals, dpositions, ddiffuse, light_grads, corner_records,
-                                   vertex_offsets, vertex_entries, transforms, gbuffer_flags, workspace,
+                                   vertex_offsets, vertex_entries, transforms, gbuffer_flags, prepared, workspace,
                                    (hipStream_t)stream);
 }
 

@@ -32,10 +32,9 @@ __device__ __forceinline__ void load_corners(const CornerRec *__restrict__ rec, 
 
 // The record of (image b, triangle t): its corners' (normal, position, diffuse), 27 floats + 5 of
 // padding.  A corner index outside [0, V) reads vertex 0 (such a triangle is never rasterized).
-__device__ __forceinline__ void fill_corner_record(const F3 *__restrict__ normals, const F3 *__restrict__ positions,
-                                                   const F3 *__restrict__ diffuse, const int32_t *__restrict__ tris,
-                                                   int b, int t, int V, CornerRec *__restrict__ out) {
-  float v[32];
+__device__ __forceinline__ void gather_corner_values(const F3 *__restrict__ normals, const F3 *__restrict__ positions,
+                                                     const F3 *__restrict__ diffuse, const int32_t *__restrict__ tris,
+                                                     int b, int t, int V, float (&v)[32]) {
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     int vi = tris[3 * t + k];
@@ -48,6 +47,12 @@ __device__ __forceinline__ void fill_corner_record(const F3 *__restrict__ normal
   }
 #pragma unroll
   for (int i = 27; i < 32; ++i) v[i] = 0.f;
+}
+__device__ __forceinline__ void fill_corner_record(const F3 *__restrict__ normals, const F3 *__restrict__ positions,
+                                                   const F3 *__restrict__ diffuse, const int32_t *__restrict__ tris,
+                                                   int b, int t, int V, CornerRec *__restrict__ out) {
+  float v[32];
+  gather_corner_values(normals, positions, diffuse, tris, b, t, V, v);
 #pragma unroll
   for (int q = 0; q < 8; ++q) out->q[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
 }
@@ -78,6 +83,34 @@ __device__ __forceinline__ void load_fold_triangle(const FoldRec *__restrict__ r
 #pragma unroll
   for (int c = 0; c < 3; ++c) { t.u0[c] = v[27 + c]; t.u1[c] = v[30 + c]; t.s[c] = v[33 + c]; }
   t.inv = v[36];
+}
+
+// FoldRec from a corner record's 27 values c[corner * 9 + attribute], the sign-corrected adjugate u[9] (row i =
+// edge i, column c = clip component x / y / w) and 1 / |det| (rasterize_triangles.cpp:180-198).
+__device__ __forceinline__ void store_fold_record(const float (&c)[32], const float (&u)[9], float inv_abs_det,
+                                                  FoldRec *__restrict__ out) {
+  float v[40];
+#pragma unroll
+  for (int a = 0; a < 9; ++a) {
+    v[a] = c[a] - c[18 + a];
+    v[9 + a] = c[9 + a] - c[18 + a];
+    v[18 + a] = c[18 + a];
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) v[27 + k] = u[k];
+#pragma unroll
+  for (int c3 = 0; c3 < 3; ++c3) v[33 + c3] = (u[c3] + u[3 + c3]) + u[6 + c3];  // cpp:187-198
+  v[36] = inv_abs_det; v[37] = 0.f; v[38] = 0.f; v[39] = 0.f;
+#pragma unroll
+  for (int q = 0; q < 10; ++q) out->q[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+}
+
+// The block mr_render_forward can prepare for the folded shading backward (include/mesh_raster.h,
+// `backward_prepared`): FoldRec[B*T], then the compact accumulator rows [B*T][kFoldAccStride] floats.
+constexpr int kFoldAccStride = 12;  // floats per (image, triangle) accumulator row of the folded variant: 48 bytes
+inline size_t fold_prepared_recs_bytes(int B, int T) { return align_up((size_t)B * T * sizeof(FoldRec), 256); }
+inline size_t fold_prepared_bytes(int B, int T) {
+  return fold_prepared_recs_bytes(B, T) + align_up((size_t)B * T * kFoldAccStride * sizeof(float), 256);
 }
 
 // Fills CornerRec[B*T] from the three [B,V,3] attribute arrays (defined in shade.hip).

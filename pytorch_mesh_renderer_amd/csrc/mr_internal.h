@@ -125,7 +125,8 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
                           int H, int L, float *dclip, float *dnormals, float *dpositions,
                           float *ddiffuse, float *light_grads, const void *corner_records,
                           const int32_t *vertex_offsets, const int32_t *vertex_entries,
-                          const float *transforms, int gbuffer_flags, void *ws, hipStream_t s);
+                          const float *transforms, int gbuffer_flags, void *prepared, void *ws, hipStream_t s);
+size_t shade_backward_prepared_bytes(int B, int T);
 
 int interp_raster_max_attrs();
 size_t interp_raster_backward_ws(int B, int V, int T, int W, int H, int A);
@@ -144,7 +145,7 @@ int launch_render_forward(const float *vertices, const float *transforms, const 
                           const float *diffuse, const int32_t *tris, const float *light_pos,
                           const float *light_col, const float *ambient, int B, int V, int T, int W, int H,
                           int L, float *clip, int32_t *ids, float *bary, float *z, int want_z, float *rgba,
-                          uint8_t *rgba_u8, void *corner_records, void *ws, hipStream_t s);
+                          uint8_t *rgba_u8, void *corner_records, void *backward_prepared, void *ws, hipStream_t s);
 size_t shade_specular_forward_ws(int B, int V, int T, int W, int H);
 int launch_shade_specular_forward(const int32_t *ids, const float *bary, const float *normals,
                                   const float *positions, const float *diffuse, const float *specular,

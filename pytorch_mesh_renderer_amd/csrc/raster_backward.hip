@@ -78,20 +78,8 @@ __global__ __launch_bounds__(256) void k_bwd_setup(
       const float4 f = corners[gid].q[q];
       c[4 * q] = f.x; c[4 * q + 1] = f.y; c[4 * q + 2] = f.z; c[4 * q + 3] = f.w;
     }
-    float v[40];
-#pragma unroll
-    for (int a = 0; a < 9; ++a) {
-      v[a] = c[a] - c[18 + a];
-      v[9 + a] = c[9 + a] - c[18 + a];
-      v[18 + a] = c[18 + a];
-    }
-    // adjugate rows of corners 0 and 1 (u[3 i + c]: edge i, clip component c), the column sums, 1 / |det|
-    v[27] = r.a.x; v[28] = r.a.y; v[29] = r.a.z;
-    v[30] = r.a.w; v[31] = r.b.x; v[32] = r.b.y;
-    v[33] = r.c.y; v[34] = r.c.z; v[35] = r.c.w;
-    v[36] = r.d.x; v[37] = 0.f; v[38] = 0.f; v[39] = 0.f;
-#pragma unroll
-    for (int q = 0; q < 10; ++q) fold_recs[gid].q[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    const float u[9] = {r.a.x, r.a.y, r.a.z, r.a.w, r.b.x, r.b.y, r.b.z, r.b.w, r.c.x};
+    store_fold_record(c, u, r.d.x, fold_recs + gid);
   }
 }
 

@@ -119,6 +119,12 @@ __global__ __launch_bounds__(kThreads) void k_vertex_transform(
 struct SetupAttributes {
   const F3 *__restrict__ normals, *__restrict__ positions, *__restrict__ diffuse;
   CornerRec *__restrict__ corners;
+  // Round 4 (with `corners`): the caller will run the folded shading backward on these inputs
+  // (mr_render_forward's `backward_prepared`): the thread also writes its triangle's FoldRec -- it has
+  // the corner attributes and the sign-corrected adjugate in registers anyway -- and clears the triangle's
+  // accumulator row, so that the backward needs no setup launch of its own (k_bwd_setup: 19 us at 1024^2 x 32).
+  FoldRec *__restrict__ fold_recs;
+  float4 *__restrict__ fold_acc;   // [B*T][kFoldAccStride / 4]
 };
 
 // Heaviest regions first (round 3).  k_raster's workgroups cost anything between ~5 us (background)
@@ -156,7 +162,18 @@ __global__ __launch_bounds__(kThreads) void k_setup(
   }
   const int b = (int)(gid / T);
   const int t = (int)(gid - (long)b * T);
-  if (attrs.corners) fill_corner_record(attrs.normals, attrs.positions, attrs.diffuse, tris, b, t, V, attrs.corners + gid);
+  float corner_values[32];
+  if (attrs.corners) {
+    gather_corner_values(attrs.normals, attrs.positions, attrs.diffuse, tris, b, t, V, corner_values);
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      attrs.corners[gid].q[q] = make_float4(corner_values[4 * q], corner_values[4 * q + 1], corner_values[4 * q + 2],
+                                            corner_values[4 * q + 3]);
+    if (attrs.fold_acc) {
+#pragma unroll
+      for (int q = 0; q < kFoldAccStride / 4; ++q) attrs.fold_acc[gid * (kFoldAccStride / 4) + q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
   const int i0 = tris[3 * t + 0], i1 = tris[3 * t + 1], i2 = tris[3 * t + 2];
   TriBox bb{0u, 0u, -INFINITY, 0u};
   if ((unsigned)i0 < (unsigned)V && (unsigned)i1 < (unsigned)V && (unsigned)i2 < (unsigned)V) {
@@ -210,6 +227,10 @@ __global__ __launch_bounds__(kThreads) void k_setup(
         rec.c = make_float4(m8, 0.0f, p0.z, w0);
         rec.d = make_float4(p1.z, w1, p2.z, w2);
         recs[gid] = rec;
+        if (attrs.fold_recs) {  // (only triangles that can be drawn are ever looked up by a pixel)
+          const float u[9] = {m0, m1, m2, m3, m4, m5, m6, m7, m8};
+          store_fold_record(corner_values, u, 1.0f / fabsf(det), attrs.fold_recs + gid);
+        }
       }
     }
   }
@@ -1362,7 +1383,7 @@ int launch_raster_forward(const float *clip, const int32_t *tris, int B, int V, 
                           int H, int32_t *ids, float *bary, float *z, void *ws, hipStream_t s) {
   return raster_forward(clip, tris, B, V, T, W, H, ids, bary, z,
                         RasterShade{nullptr, Lights{nullptr, nullptr, nullptr, 0}, nullptr, nullptr, 1},
-                        SetupAttributes{nullptr, nullptr, nullptr, nullptr}, ws, s);
+                        SetupAttributes{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, ws, s);
 }
 
 int launch_vertex_transform(const float *vertices, const float *transforms, int B, int V, float *clip,
@@ -1382,15 +1403,18 @@ int launch_render_forward(const float *vertices, const float *transforms, const 
                           const float *diffuse, const int32_t *tris, const float *light_pos,
                           const float *light_col, const float *ambient, int B, int V, int T, int W, int H,
                           int L, float *clip, int32_t *ids, float *bary, float *z, int want_z, float *rgba,
-                          uint8_t *rgba_u8, void *corner_records, void *ws, hipStream_t s) {
+                          uint8_t *rgba_u8, void *corner_records, void *backward_prepared, void *ws, hipStream_t s) {
   const int rc = launch_vertex_transform(vertices, transforms, B, V, clip, s);
   if (rc != MR_OK) return rc;
   if ((size_t)B * W * H == 0) return MR_OK;
   CornerRec *corners = (CornerRec *)corner_records;
   return raster_forward(clip, tris, B, V, T, W, H, ids, bary, z,
                         RasterShade{corners, Lights{light_pos, light_col, ambient, L}, rgba, (uint32_t *)rgba_u8, want_z},
-                        SetupAttributes{(const F3 *)normals, (const F3 *)vertices, (const F3 *)diffuse, corners}, ws,
-                        s);
+                        SetupAttributes{(const F3 *)normals, (const F3 *)vertices, (const F3 *)diffuse, corners,
+                                        (FoldRec *)backward_prepared,
+                                        backward_prepared ? (float4 *)((char *)backward_prepared + fold_prepared_recs_bytes(B, T))
+                                                          : nullptr},
+                        ws, s);
 }
 
 }  // namespace mr

@@ -515,7 +515,9 @@ struct ShadeLaneFn : ShadeGradFn<L, SIGNS, LG> {
 #ifndef MR_SHADE_FOLD_DIFF
 #define MR_SHADE_FOLD_DIFF 1
 #endif
-constexpr int kFoldAccStride = 12;  // floats per (image, triangle) accumulator row of the folded variant: 48 bytes
+#ifndef MR_SHADE_USE_PREPARED
+#define MR_SHADE_USE_PREPARED 1   // 0: ignore mr_render_forward's prepared block (A/B)
+#endif
 template <int L, bool SIGNS>
 struct ShadeFoldLaneFn : ShadeGradFn<L, SIGNS, false> {
   using Base = ShadeGradFn<L, SIGNS, false>;
@@ -669,8 +671,12 @@ __global__ __launch_bounds__(kThreads) void k_shade_gather(
 // gradient of the corner's world-space position -- in 48 bytes, so a vertex needs three sums, not thirteen:
 // four lanes per (image, vertex) (the fourth idles), 320 k threads instead of 1.3 M at 32 x 2502 vertices, a third
 // of the bytes.  Same fixed summation order as k_shade_gather (the adjacency's).
+// CLEAR: every accumulator float is read by exactly one lane of one vertex -- entry e = 3 t + k belongs to
+// vertex triangles[t][k] alone -- which stores a zero behind its read: the rows are clear again when the kernel
+// ends (a `prepared` block serves any number of backward calls; its first clearing is k_setup's).
+template <bool CLEAR>
 __global__ __launch_bounds__(kThreads) void k_shade_gather_fold(
-    const float *__restrict__ acc, const int32_t *__restrict__ offsets, const int32_t *__restrict__ entries, int B, int V,
+    float *__restrict__ acc, const int32_t *__restrict__ offsets, const int32_t *__restrict__ entries, int B, int V,
     int T, float *__restrict__ dpositions) {
   const long tid = (long)blockIdx.x * kThreads + threadIdx.x;
   const long gid = tid >> 2;   // (image, vertex)
@@ -678,7 +684,7 @@ __global__ __launch_bounds__(kThreads) void k_shade_gather_fold(
   if (gid >= (long)B * V || c == 3) return;
   const int b = (int)(gid / V);
   const int v = (int)(gid - (long)b * V);
-  const float *acc_f = acc + (size_t)b * T * kFoldAccStride;
+  float *acc_f = acc + (size_t)b * T * kFoldAccStride;
   constexpr int kChunk = MR_GATHER_CHUNK;
   float sum = 0.f;
   const int e1 = offsets[v + 1];
@@ -691,6 +697,13 @@ __global__ __launch_bounds__(kThreads) void k_shade_gather_fold(
     for (int u = 0; u < kChunk; ++u) {
       const unsigned t = (unsigned)e[u] / 3u, k = (unsigned)e[u] - 3u * t;
       val[u] = e[u] < 0 ? 0.f : acc_f[t * (unsigned)kFoldAccStride + k * 3u + (unsigned)c];
+    }
+    if (CLEAR) {
+#pragma unroll
+      for (int u = 0; u < kChunk; ++u) {
+        const unsigned t = (unsigned)e[u] / 3u, k = (unsigned)e[u] - 3u * t;
+        if (e[u] >= 0) acc_f[t * (unsigned)kFoldAccStride + k * 3u + (unsigned)c] = 0.f;
+      }
     }
 #pragma unroll
     for (int u = 0; u < kChunk; ++u) sum += val[u];
@@ -789,6 +802,8 @@ int launch_shade_forward(const int32_t *ids, const float *bary, const float *nor
   return check_launch();
 }
 
+size_t shade_backward_prepared_bytes(int B, int T) { return fold_prepared_bytes(B, T); }
+
 size_t shade_backward_ws(int B, int V, int T, int W, int H) {
   return shade_acc_bytes(B, T) + align_up((size_t)B * T * sizeof(BwdRec), 256) + corner_bytes(B, T) +
          kDetMiscBytes + light_rows_bytes(B, W, H) + align_up((size_t)B * T * sizeof(FoldRec), 256) +
@@ -809,7 +824,7 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
                           int H, int L, float *dclip, float *dnormals, float *dpositions,
                           float *ddiffuse, float *light_grads, const void *corner_records,
                           const int32_t *vertex_offsets, const int32_t *vertex_entries,
-                          const float *transforms, int gbuffer_flags, void *ws, hipStream_t s) {
+                          const float *transforms, int gbuffer_flags, void *prepared, void *ws, hipStream_t s) {
   if (B == 0) return MR_OK;
   if (transforms && !(vertex_offsets && vertex_entries)) return MR_EINVAL;  // the gather applies them
   if (!dclip && !transforms) return MR_EINVAL;  // without the pull-back the clip-space gradient IS the vertex gradient
@@ -853,7 +868,14 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
   int *max_bits = (int *)(det_scale + 4);
   float *light_rows = (float *)((char *)det_scale + kDetMiscBytes);
   FoldRec *fold_recs = (FoldRec *)((char *)light_rows + light_rows_bytes(B, W, H));
-  const bool fold_diff = fold && MR_SHADE_FOLD_DIFF && corner_records != nullptr;   // (the records of the forward)
+  const bool fold_diff = fold && MR_SHADE_FOLD_DIFF && (corner_records != nullptr || prepared != nullptr);
+  // `prepared` (mr_render_forward's backward_prepared: FoldRec[B*T] + cleared compact accumulator rows): the folded
+  // kernel's setup launch is skipped, and the gather leaves the rows cleared again for the next backward call
+  const bool use_prepared = fold_diff && prepared != nullptr && MR_SHADE_USE_PREPARED;
+  if (use_prepared) {
+    fold_recs = (FoldRec *)prepared;
+    acc = (float *)((char *)prepared + fold_prepared_recs_bytes(B, T));
+  }
   if (det && !(vertex_offsets && vertex_entries)) return MR_EINVAL;  // the scatter path is atomics only
   const size_t acc_bytes = (size_t)B * T * 36 * (det ? sizeof(long long) : sizeof(float));
   if (!fused_clear && hipMemsetAsync(acc, 0, acc_bytes, s) != hipSuccess) return check_launch();
@@ -869,6 +891,8 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
     hipLaunchKernelGGL(k_det_scale, dim3(1), dim3(1), 0, s, max_bits, sign_upstream, sign_inv_n, det_scale);
     if ((rc = check_launch()) != MR_OK) return rc;
   }
+  if (use_prepared) rc = MR_OK;
+  else
   rc = fused_clear ? launch_bwd_setup(clip, tris, B, V, T, recs, s, acc, (fold_diff ? kFoldAccStride : 36) * sizeof(float), light_grads,
                                       light_grads ? B * (L * 6 + 3) : 0, fold_diff ? corner_records : nullptr,
                                       fold_diff ? fold_recs : nullptr)
@@ -1016,8 +1040,12 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
   }
   if (fold_diff) {  // compact rows, position gradient only
     const long nbv = (long)B * V * 4;
-    hipLaunchKernelGGL(k_shade_gather_fold, dim3((unsigned)((nbv + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, acc,
-                       vertex_offsets, vertex_entries, B, V, T, dpositions);
+    if (use_prepared)
+      hipLaunchKernelGGL(k_shade_gather_fold<true>, dim3((unsigned)((nbv + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
+                         acc, vertex_offsets, vertex_entries, B, V, T, dpositions);
+    else
+      hipLaunchKernelGGL(k_shade_gather_fold<false>, dim3((unsigned)((nbv + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
+                         acc, vertex_offsets, vertex_entries, B, V, T, dpositions);
     return check_launch();
   }
   if (vertex_offsets && vertex_entries) {

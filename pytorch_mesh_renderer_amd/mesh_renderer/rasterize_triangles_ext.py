@@ -153,6 +153,9 @@ def emit_uint8_frames(on):
     return _scoped_switch("emit_uint8_frames", on)
 
 
+PREPARE_BACKWARD = True   # False: the backward always runs its own setup kernel (A/B, tests)
+
+
 class FusedPhongRenderer(torch.autograd.Function):
     """World-space vertices -> shaded image as ONE differentiable op: clip-space transform,
     G-buffer rasterization, attribute interpolation and diffuse/ambient Phong in four launches
@@ -173,14 +176,22 @@ class FusedPhongRenderer(torch.autograd.Function):
         amb = ambient.detach().contiguous() if ambient is not None else None
         frames = None
         epilogue, want_frames = _switch("shading_epilogue"), _switch("emit_uint8_frames")
-        if epilogue and want_frames:
-            clip, ids, bary, _, rgba, corner_records, frames = _native.render_forward(
+        # Round 4: when the image will be differentiated to the vertices ONLY (needs_input_grad: the usual
+        # optimisation loop), the forward's setup kernel also leaves the folded backward's records and cleared
+        # accumulators (`prepared`): the backward then has no setup launch.
+        needs = ctx.needs_input_grad
+        prepare = bool(epilogue and PREPARE_BACKWARD and needs[0] and not any(needs[i] for i in (1, 2, 3, 5, 6, 7))
+                       and not _native.deterministic())
+        prepared = None
+        if epilogue:
+            out = _native.render_forward(
                 verts, xf, args[0], args[1], triangles, lp, li, amb, int(image_width), int(image_height),
-                want_z=False, want_u8=True)
-        elif epilogue:
-            clip, ids, bary, _, rgba, corner_records = _native.render_forward(
-                verts, xf, args[0], args[1], triangles, lp, li, amb, int(image_width), int(image_height),
-                want_z=False)
+                want_z=False, want_u8=bool(want_frames), prepare_backward=prepare)
+            clip, ids, bary, _, rgba, corner_records = out[:6]
+            if want_frames:
+                frames = out[6]
+            if prepare:
+                prepared = out[-1]
         else:
             from ..common import camera_utils
             clip = camera_utils.transform_homogeneous(xf, verts).contiguous()
@@ -189,7 +200,8 @@ class FusedPhongRenderer(torch.autograd.Function):
                                                          li, amb, keep_corner_records=True)
         offsets, entries = _native.vertex_adjacency(triangles, vertices.shape[1])   # cached per mesh
         saved = [clip, ids, bary, args[0], verts, args[1], triangles, lp, li, corner_records,
-                 offsets, entries, xf]
+                 offsets, entries, xf,
+                 prepared if prepared is not None else torch.empty(0, dtype=torch.uint8, device=verts.device)]
         if amb is not None:
             saved.append(amb)
         ctx.save_for_backward(*saved)
@@ -206,14 +218,15 @@ class FusedPhongRenderer(torch.autograd.Function):
         needs_light_grads: some of light_positions / light_intensities / ambient requires grad;
         needs_normal_grad / needs_diffuse_grad: False leaves that gradient (None) and its sums out."""
         (clip, ids, bary, normals, verts, diffuse, triangles, lp, li, corner_records, offsets,
-         entries, xf) = saved[:13]
-        amb = saved[13] if len(saved) > 13 else None
+         entries, xf, prepared) = saved[:14]
+        amb = saved[14] if len(saved) > 14 else None
         dclip, dn, dverts, dd, dlp, dli, damb = _native.shade_backward(
             upstream, ids, bary, clip, normals, verts, diffuse, triangles, lp, li, amb,
             corner_records=corner_records, adjacency=(offsets, entries), l1_signs=l1_signs, transforms=xf,
             want_light_grads=needs_light_grads, want_normal_grads=needs_normal_grad,
             want_diffuse_grads=needs_diffuse_grad,
             want_clip_grads=needs_transform_grad,   # d clip on its own only feeds d transforms below
+            prepared=prepared if prepared.numel() else None,
             normalised_gbuffer=True)   # this function's own forward wrote ids / bary
         dxf = None
         if needs_transform_grad:  # d clip[b,v,r] / d xf[b,r,k] = (vertex, 1)[k]

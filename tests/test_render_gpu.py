@@ -1040,6 +1040,70 @@ def test_shade_backward_lane_kernel_matches_rows_kernel(device, w, h, res, n_lig
         _native.debug_set_shade_backward_kernel(0)
 
 
+def test_prepared_backward_block_serves_repeated_backward_calls(device):
+    """Round 4: render() differentiated to the vertices only has its forward's setup kernel write the folded
+    backward's records and clear its accumulator rows (mr_render_forward's backward_prepared); the backward then
+    launches no setup kernel and its per-vertex gather leaves the rows clear again.  Same gradients as with the
+    backward's own setup (PREPARE_BACKWARD = False), through both routes (losses.l1_loss's sign-coded one and a
+    dense upstream gradient), and the SAME gradient again from a second backward over a retained graph."""
+    from pytorch_mesh_renderer_amd import _native
+    from pytorch_mesh_renderer_amd.mesh_renderer import rasterize_triangles_ext as ext
+    job = synthetic.sphere_job(2, 200, 150, 12)
+    target = torch.rand(2, 150, 200, 4, generator=torch.Generator().manual_seed(3)).to(device)
+    tris = job["triangles"].to(device)
+
+    def grads(prepare, loss_fn, repeats):
+        before = ext.PREPARE_BACKWARD
+        ext.PREPARE_BACKWARD = prepare
+        try:
+            v = job["vertices"].clone().to(device).requires_grad_(True)
+            with _CountCalls("render_forward") as fwd:
+                img = mesh_renderer.render(v, tris, job["normals"].to(device), job["diffuse"].to(device), job["eyes"],
+                                           torch.zeros(2, 3), torch.tensor([0.0, 1.0, 0.0]),
+                                           job["light_positions"].to(device), job["light_intensities"].to(device),
+                                           200, 150)
+            assert fwd.calls == 1
+            loss = loss_fn(img)
+            out = []
+            for k in range(repeats):
+                v.grad = None
+                loss.backward(retain_graph=k + 1 < repeats)
+                out.append(v.grad.clone())
+            return out
+        finally:
+            ext.PREPARE_BACKWARD = before
+
+    for loss_fn in (lambda img: mesh_renderer.losses.l1_loss(img, target) * 50.0,
+                    lambda img: ((img - target) ** 2).mean() * 50.0):
+        own = grads(False, loss_fn, 1)[0]
+        first, second, third = grads(True, loss_fn, 3)
+        scale = float(own.abs().max())
+        assert scale > 0
+        for name, got in (("first", first), ("second", second), ("third", third)):
+            np.testing.assert_allclose(got.cpu().numpy(), own.cpu().numpy(), rtol=2e-4, atol=2e-6 * scale,
+                                       err_msg="%s backward over the prepared block" % name)
+    # the block is only asked for when the vertices alone require grad
+    v = job["vertices"].clone().to(device).requires_grad_(True)
+    n = job["normals"].clone().to(device).requires_grad_(True)
+    seen = {}
+    orig = _native.render_forward
+    def spy(*a, **k):
+        seen["prepare"] = k.get("prepare_backward")
+        return orig(*a, **k)
+    _native.render_forward = spy
+    try:
+        mesh_renderer.render(v, tris, n, job["diffuse"].to(device), job["eyes"], torch.zeros(2, 3),
+                             torch.tensor([0.0, 1.0, 0.0]), job["light_positions"].to(device),
+                             job["light_intensities"].to(device), 200, 150)
+        assert seen["prepare"] is False
+        mesh_renderer.render(v, tris, n.detach(), job["diffuse"].to(device), job["eyes"], torch.zeros(2, 3),
+                             torch.tensor([0.0, 1.0, 0.0]), job["light_positions"].to(device),
+                             job["light_intensities"].to(device), 200, 150)
+        assert seen["prepare"] is True
+    finally:
+        _native.render_forward = orig
+
+
 def test_shade_backward_gather_matches_scatter(device):
     """mr_shade_backward with the CSR vertex adjacency (per-vertex gather, what render() uses) vs
     without it (float-atomic scatter), incl. a triangle with a repeated and an out-of-range vertex."""
