@@ -155,9 +155,11 @@ def make_step(job, device, gather, handover="u8"):
         image = forward()
         state["image"] = image
         if gather is not None and state["handover"]:
-            gather.wait()                # the previous step's hand-over (no-op the first time) ...
-            # ... then this one; conversion (u8) and transfer both run on the side stream,
-            # overlapping the loss, the backward and the next step's forward
+            # two hand-overs may be in flight (ImageGather depth 2): the one of the step BEFORE the previous one
+            # is waited for, then this step's starts; conversion (u8) and transfer run on the side stream and
+            # have two whole steps to finish in -- a link-bound hand-over then costs bandwidth, not latency on top
+            if gather.in_flight() >= gather.depth:
+                gather.wait()
             gather.start(image, transform=transform)
         loss = mesh_renderer.losses.l1_loss(image, target)   # mean |image - target|, one HIP pass each way
         loss.backward()
@@ -288,7 +290,7 @@ def main():
         torch.distributed.init_process_group(backend=backend, rank=0, world_size=1,
                                              **({"device_id": device} if backend == "nccl" else {}))
     grouped = world > 1 or forced
-    gather = distributed.ImageGather(batch * world, mode="root", force_collective=forced) if grouped else None
+    gather = distributed.ImageGather(batch * world, mode="root", force_collective=forced, depth=2) if grouped else None
     step, vertices, step_state = make_step(job, device, gather, args.handover)
 
     def barrier():
@@ -311,7 +313,7 @@ def main():
             ev_l1.arm(i)
         step()
     if gather is not None:
-        gather.wait()                    # the last step's hand-over belongs to the timed region
+        gather.drain()                   # the last steps' hand-overs belong to the timed region
     barrier()
     elapsed = time.perf_counter() - t0
 
@@ -333,7 +335,7 @@ def main():
                 ev_gbuffer.arm(i - 2)
             step()
     if gather is not None:
-        gather.wait()
+        gather.drain()
     torch.cuda.synchronize(device)
 
     # N > 1, also outside the timed region: the same loop with the hand-over switched off, so that the
@@ -398,6 +400,13 @@ def main():
             # the same step with the hand-over off (after the timed region): rendering alone, max over ranks
             line["ms_per_step_render_only"] = round(render_only_ms, 4)
             line["ms_per_step_with_handover"] = line["ms_per_step"]
+            # the same two figures as the line's own units, so that a scaling curve can be read off either one:
+            # `value` contains the hand-over of every step's frames to rank 0, value_render_only does not
+            line["value_render_only"] = round(world * px / render_only_ms / 1e3, 2)
+            # what arrives at the root per second while the timed loop runs (N - 1 shards per step)
+            line["handover_GBps_into_root"] = round(
+                (world - 1) * line["rccl"]["handover_bytes_per_rank_per_step"] / (elapsed / args.steps) / 1e9, 2)
+            line["handover_depth"] = gather.depth
         if world == 1 and args.cpu_sample > 0:
             line["cpu_baseline"] = cpu_baseline(batch, width, height, sphere_k, args.cpu_sample)
         print(json.dumps(line), flush=True)

@@ -11,6 +11,7 @@ bound, 30 KB - 300 KB) all-reduce.
 
 torch.distributed's "nccl" backend is RCCL on ROCm; "gloo" is used by the CPU tests.
 """
+import collections
 import os
 
 import torch
@@ -66,20 +67,28 @@ class ImageGather:
     start(local) enqueues the collective on a side stream (GPU) and returns at once;
     wait() makes the current stream wait for it and returns the [B_total, H, W, C]
     tensor (mode "all": on every rank; mode "root": on rank `dst`, None elsewhere).
-    Shards may be uneven (they are padded to the largest one).  The returned tensor is one of two
-    receive buffers used alternately: it is overwritten by the second start() after the wait().
+    Shards may be uneven (they are padded to the largest one).
+
+    depth (round 4): how many hand-overs may be in flight at once.  wait() returns the OLDEST one; with
+    depth 2 a step waits for the hand-over of the step BEFORE the previous one right before it starts
+    its own, so a hand-over has two steps to finish in: bound by the root's inbound links it then costs
+    their bandwidth, not their latency on top.  The returned tensor is one of depth + 1 receive buffers
+    used in turn: it stays valid until the (depth + 1)-th start() after the start() that filled it.
 
     mode "all"  = all_gather: every rank ends up with every image.
     mode "root" = gather to one rank (RCCL point-to-point under the hood): on a fully
                   connected xGMI node the root receives its N-1 shards over N-1 different
                   links at once, the other ranks only send -- 1/N of the all-gather's traffic."""
 
-    def __init__(self, n_total, group=None, force_collective=False, mode="all", dst=0):
+    def __init__(self, n_total, group=None, force_collective=False, mode="all", dst=0, depth=1):
         """force_collective: run the collective even in a 1-rank group (smoke tests of the
         RCCL / side-stream path on a single GPU)."""
         if mode not in ("all", "root"):
             raise ValueError("mode must be 'all' or 'root'")
-        self.mode, self.dst = mode, dst
+        if depth < 1:
+            raise ValueError("depth must be at least 1")
+        self.mode, self.dst, self.depth = mode, dst, int(depth)
+        self._pending = collections.deque()   # (event or None, out or None, max_count, send buffer) per hand-over in flight
         self.group = group
         self.force = bool(force_collective) and dist.is_initialized()
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -88,12 +97,9 @@ class ImageGather:
         self.counts = [shard_bounds(n_total, r, self.world)[1] - shard_bounds(n_total, r, self.world)[0]
                        for r in range(self.world)]
         self._side = None
-        self._out = None
-        self._work = None
-        # receive buffers (two, used alternately) and the padded send buffer are allocated once per
+        # receive buffers (depth + 1, used in turn) and the padded send buffer are allocated once per
         # (shape, dtype, device): a step's hand-over allocates nothing (round 2 allocated `gathered`
-        # and its chunk list every step).  The tensor wait() returns stays valid until the second
-        # start() after it.
+        # and its chunk list every step).
         self._recv = {}
         self._turn = 0
         self._send_pad = {}
@@ -102,8 +108,11 @@ class ImageGather:
         """transform: optional callable applied to `local` ON THE SIDE STREAM before the
         collective (e.g. mesh_renderer.to_uint8: the 8-bit conversion then overlaps the caller's
         compute too instead of sitting on its stream)."""
+        if len(self._pending) >= self.depth:
+            raise RuntimeError("%d hand-over(s) already in flight (depth %d): call wait() first"
+                               % (len(self._pending), self.depth))
         if self.world == 1 and not self.force:
-            self._out = transform(local) if transform is not None else local
+            self._pending.append((None, transform(local) if transform is not None else local, 0, None))
             return
         max_count = max(self.counts)
         if local.shape[0] != self.counts[self.rank]:
@@ -133,44 +142,57 @@ class ImageGather:
             send = send.contiguous()
             if on_gpu:
                 send.record_stream(self._side)
-            self._max_count = max_count
             gathered, chunks = None, None
             if self.mode == "all" or self.rank == self.dst:
-                pair = self._recv.get(key)
-                if pair is None:
-                    pair = self._recv[key] = []
-                    for _ in range(2):
+                ring = self._recv.get(key)
+                if ring is None:
+                    ring = self._recv[key] = []
+                    for _ in range(self.depth + 1):
                         buf = torch.empty((self.world * max_count,) + key[0], dtype=send.dtype, device=send.device)
-                        pair.append((buf, list(buf.chunk(self.world, 0))))
-                gathered, chunks = pair[self._turn]
-                self._turn ^= 1
+                        ring.append((buf, list(buf.chunk(self.world, 0))))
+                gathered, chunks = ring[self._turn % len(ring)]
+                self._turn += 1
             if self.mode == "root":
                 dist.gather(send, chunks, dst=self.dst, group=self.group)
-                self._keep = send          # the send buffer must outlive the collective
-                self._out = gathered
-                return
-            if dist.get_backend(self.group) == "gloo":
+            elif dist.get_backend(self.group) == "gloo":
                 dist.all_gather(chunks, send, group=self.group)
             else:
                 dist.all_gather_into_tensor(gathered, send, group=self.group)
-            self._keep = send
-            self._out = gathered
+            done = None
+            if on_gpu:   # wait() orders the caller's stream behind THIS hand-over, not behind the whole side stream
+                done = torch.cuda.Event()
+                done.record(self._side)
+            # (the send buffer must outlive the collective: it rides along until the hand-over is waited for)
+            self._pending.append((done, gathered, max_count, send))
+
+    def in_flight(self):
+        return len(self._pending)
 
     def wait(self):
-        if self.world == 1 and not self.force:
-            return self._out
-        if self._side is not None:
-            torch.cuda.current_stream().wait_stream(self._side)
-        if self._out is None:              # mode "root" on a non-root rank
+        """The OLDEST hand-over in flight (None when there is none, and on a non-root rank of mode "root")."""
+        if not self._pending:
             return None
-        if self._out.is_cuda:
+        done, out, max_count, _send = self._pending.popleft()
+        if self.world == 1 and not self.force:
+            return out
+        if done is not None:
+            torch.cuda.current_stream().wait_event(done)
+        if out is None:                    # mode "root" on a non-root rank
+            return None
+        if out.is_cuda:
             # allocated on the side stream, consumed on the caller's: tell the caching allocator
-            self._out.record_stream(torch.cuda.current_stream(self._out.device))
-        if all(c == self._max_count for c in self.counts):
-            return self._out
-        pieces = [self._out[r * self._max_count: r * self._max_count + c]
-                  for r, c in enumerate(self.counts)]
+            out.record_stream(torch.cuda.current_stream(out.device))
+        if all(c == max_count for c in self.counts):
+            return out
+        pieces = [out[r * max_count: r * max_count + c] for r, c in enumerate(self.counts)]
         return torch.cat(pieces, 0)
+
+    def drain(self):
+        """wait() for everything in flight; returns the results, oldest first."""
+        out = []
+        while self._pending:
+            out.append(self.wait())
+        return out
 
 
 class _NullContext:

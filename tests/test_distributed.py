@@ -36,8 +36,8 @@ def _root_worker(rank, world, port, n_total, out_dir):
     job = synthetic.sphere_job(n_total, 24, 20, 6)
     shard = distributed.shard_batch(job, rank, world)
     handle = distributed.ImageGather(n_total, mode="root", dst=0)
-    for _ in range(2):                       # two steps, waiting one step late like bench.py
-        handle.wait() if handle._out is not None or handle._side is not None else None
+    for _ in range(2):                       # two steps, waiting one step late
+        handle.wait()                        # (nothing in flight the first time: None)
         handle.start(_oracle_render(shard, 24, 20))
     full = handle.wait()
     assert (full is not None) == (rank == 0)
@@ -50,6 +50,52 @@ def _root_worker(rank, world, port, n_total, out_dir):
         torch.save(full, os.path.join(out_dir, "root.pt"))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _depth2_worker(rank, world, port, n_total, out_dir):
+    """bench.py's hand-over loop at depth 2 (round 4): step k starts its gather after waiting for step k - 2's;
+    every step hands over DIFFERENT frames (scaled by the step number), so a receive buffer that is reused too
+    early -- or a wait() that returns the wrong step -- shows."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    distributed.init_from_env(backend="gloo")
+    job = synthetic.sphere_job(n_total, 24, 20, 6)
+    shard = distributed.shard_batch(job, rank, world)
+    base = _oracle_render(shard, 24, 20)
+    handle = distributed.ImageGather(n_total, mode="root", dst=0, depth=2)
+    received, held = [], []
+    for k in range(5):
+        if handle.in_flight() >= handle.depth:
+            out = handle.wait()              # step k - 2's frames
+            received.append(None if out is None else out.clone())
+            held.append(out)                 # still valid while the NEXT start() runs (depth + 1 buffers)
+        handle.start(base * float(k + 1))
+        if held and held[-1] is not None:    # the tensor wait() just returned was not touched by that start()
+            assert torch.equal(held[-1], received[-1])
+    assert handle.in_flight() == 2
+    try:
+        handle.start(base)                   # a third one in flight: refused
+        raise AssertionError("depth 2 accepted three hand-overs in flight")
+    except RuntimeError:
+        pass
+    for out in handle.drain():
+        received.append(None if out is None else out.clone())
+    assert handle.in_flight() == 0 and handle.wait() is None
+    if rank == 0:
+        torch.save(received, os.path.join(out_dir, "depth2.pt"))
+    else:
+        assert all(r is None for r in received)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_depth_two_world2(tmp_path):
+    mp.spawn(_depth2_worker, args=(2, _free_port(), 5, str(tmp_path)), nprocs=2, join=True)
+    full = _oracle_render(synthetic.sphere_job(5, 24, 20, 6), 24, 20)
+    received = torch.load(os.path.join(str(tmp_path), "depth2.pt"))
+    assert len(received) == 5                # steps 0..4, in order
+    for k in range(5):
+        assert torch.equal(received[k], full * float(k + 1)), "hand-over %d" % k
 
 
 def test_gather_to_root_world2(tmp_path):

@@ -369,6 +369,15 @@ def test_rccl_image_gather_single_rank(device):
         frames = (x * 255).to(torch.uint8)   # 8-bit frames, as bench.py hands them over
         r.start(frames)
         assert torch.equal(r.wait(), frames)
+        # round 4: two hand-overs in flight (bench.py's depth), each waited for by its own event
+        d2 = distributed.ImageGather(3, force_collective=True, mode="root", depth=2)
+        d2.start(x)
+        d2.start(x * 3.0)
+        assert d2.in_flight() == 2
+        first = d2.wait()
+        d2.start(x * 5.0)                    # does not overwrite `first` (depth + 1 receive buffers)
+        assert torch.equal(first, x) and torch.equal(d2.wait(), x * 3.0) and torch.equal(d2.wait(), x * 5.0)
+        assert d2.wait() is None
         grad = torch.ones(5, 3, device=device)
         assert torch.equal(distributed.allreduce_shared_mesh_grad(grad.clone()), grad)
     finally:
@@ -398,6 +407,9 @@ def test_bench_rank_path_meets_rccl_on_one_gpu(device, handover):
     assert line["rccl"]["backend"] == "nccl" and line["rccl"]["ranks"] == 1
     assert line["rccl"]["handover_bytes_per_rank_per_step"] == 32 * 1024 * 1024 * (4 if handover == "u8" else 16)
     assert 0 < line["ms_per_step_render_only"] and line["ms_per_step_with_handover"] == line["ms_per_step"]
+    assert line["handover_depth"] == 2 and line["handover_GBps_into_root"] == 0.0    # (one rank: nothing arrives)
+    px = 32 * 1024 * 1024
+    assert abs(line["value_render_only"] - px / line["ms_per_step_render_only"] / 1e3) < 1.0
     assert line["config"]["handover"] == handover and line["n_gpus"] == 1
 
 
