@@ -421,6 +421,7 @@ __global__ __launch_bounds__(kCoarseThreads) void k_coarse(
 struct PixelState {
   float z, b0, b1, b2;
   int id;
+  int ent;   // SHADE: bin entry (slot) of the winner, for the epilogue's record lookup
 };
 
 // ---------------------------------------------------------------------------------------
@@ -565,6 +566,10 @@ struct RasterShade {
 #endif
 #ifndef MR_RASTER_STORE_AUX_Z
 #define MR_RASTER_STORE_AUX_Z MR_RASTER_STORE_AUX
+#endif
+#ifndef MR_EPI_LDS_RECORDS
+#define MR_EPI_LDS_RECORDS 1  // round 4: the shading epilogue reads its winners' corner records per lane from LDS
+                              // (see "corner records in LDS" in k_raster) instead of one winner at a time through the scalar cache
 #endif
 #ifndef MR_RASTER_SHADE_WAVES
 #define MR_RASTER_SHADE_WAVES 6  // measured against 7 (more spills) and 5: 0.336 / 0.352 / 0.347 ms at 1024^2 x 32
@@ -813,9 +818,22 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : MR_RASTER
   // triangles), a crowded bin keeps the per-lane store.  Only whole-region (`full`) walks stage.
   constexpr int kStageDw = 3 * kWave;                                   // per wavefront
   constexpr int kStageEntries = (kWaves * kStageDw + kEntryDw - 1) / kEntryDw;  // bin entries the slots overlay
-  auto raster_pass = [&](auto fresh_tag, auto full_tag, auto stage_tag, const int far_word, const bool last_round) {
+  // Corner records in LDS (round 4).  The epilogue used to take a tile's winning triangles one at a time: the
+  // record through the scalar cache, 27 multiply-adds with a scalar operand under the winner's lanes -- ~33 vector
+  // instructions per winner, ~2.7 winners per covered tile, 89 of the epilogue's ~140 per tile.  A region's bin
+  // holds ~40 entries of its 256: when the region needs ONE bin round and the entries end below slot
+  // kRecordSlots, the unused top of the bin holds every entry's corner record (28 dwords, 16-byte aligned, four
+  // banks apart) -- loaded once per region, one thread per entry -- the depth loop remembers the winner's SLOT
+  // next to its id, and the epilogue is 7 per-lane ds_read_b128 and 27 multiply-adds per tile, whatever the
+  // number of winners.  LDS reads count on lgkmcnt like the scalar loads did: the G-buffer stores stay undisturbed.
+  constexpr int kRecordDw = 28;
+  constexpr int kRecordSlots = (kBin2Cap * kEntryDw) / (kEntryDw + kRecordDw);   // 106: entries + records fit the bin
+  auto record_of = [&](const int slot) -> const float * { return s_ent + (kBin2Cap * kEntryDw - (slot + 1) * kRecordDw); };
+  auto raster_pass = [&](auto fresh_tag, auto full_tag, auto stage_tag, auto recs_tag, const int far_word,
+                         const bool last_round) {
     constexpr bool fresh = decltype(fresh_tag)::value, full = decltype(full_tag)::value;
     constexpr bool stage = MR_BARY_STAGE && decltype(stage_tag)::value && full && !(PROBE & 64);
+    constexpr bool lds_recs = SHADE && MR_EPI_LDS_RECORDS && decltype(recs_tag)::value;
     const unsigned near_words = (1u << far_word) - 1u;  // far_word == kMaskWords: every word
     // wavefront w walks tiles w, w + 4, ... (row-major tile numbering).  (Walking pairs of
     // horizontally adjacent tiles back to back, so that both halves of a 128-byte line come from
@@ -838,6 +856,7 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : MR_RASTER
       if (fresh) {
         st.z = 1.0f; st.b0 = 0.0f; st.b1 = 0.0f; st.b2 = 0.0f;  // cpp:313-321
         st.id = ordered ? -1 : 0;  // -1: "nothing drawn yet" loses every tie; stored as 0
+        st.ent = 0;
       } else if (in_image) {
         st.z = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_z, lane_pix * 4u, tile_pix * 4, 0));
         st.id = (int)__builtin_amdgcn_raw_buffer_load_b32(rs_ids, lane_pix * 4u, tile_pix * 4, 0);
@@ -905,7 +924,8 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : MR_RASTER
           if (!valid) break;
           const unsigned bit = min((unsigned)(__ffs((int)mine) - 1), 31u);  // no candidate: slot 31
           mine &= mine - 1u;
-          const Entry t = read_entry(s_ent, ebase + (int)bit);  // per-lane LDS address
+          const int slot = ebase + (int)bit;
+          const Entry t = read_entry(s_ent, slot);  // per-lane LDS address
           const v2f e01 = (v2f{t.q0.x, t.q0.y} * px2 + v2f{t.q0.z, t.q0.w} * py2) +
                           v2f{t.q1.x, t.q1.y};                         // same bits as in (1)
           float e0 = e01.x, e1 = e01.y;
@@ -938,7 +958,8 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : MR_RASTER
                 "v_cndmask_b32_e32 %[id], %[id], %[tid], vcc\n\t"
                 "v_cndmask_b32_e32 %[c0], %[c0], %[b0], vcc\n\t"
                 "v_cndmask_b32_e32 %[c1], %[c1], %[b1], vcc\n\t"
-                "v_cndmask_b32_e32 %[c2], %[c2], %[b2], vcc"
+                "v_cndmask_b32_e32 %[c2], %[c2], %[b2], vcc\n\t"
+                "s_mov_b64 %[m], vcc"
                 : [z] "+v"(st.z), [id] "+v"(st.id), [c0] "+v"(st.b0), [c1] "+v"(st.b1), [c2] "+v"(st.b2),
                   [m] "=&s"(pass_mask), [valid2] "=&s"(pass_mask2)
                 : [zz] "v"(zz), [tid] "v"(t.q2.y), [b0] "v"(b0), [b1] "v"(b1), [b2] "v"(b2), [valid] "s"(valid)
@@ -953,11 +974,15 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : MR_RASTER
                 "v_cndmask_b32_e32 %[id], %[id], %[tid], vcc\n\t"
                 "v_cndmask_b32_e32 %[c0], %[c0], %[b0], vcc\n\t"
                 "v_cndmask_b32_e32 %[c1], %[c1], %[b1], vcc\n\t"
-                "v_cndmask_b32_e32 %[c2], %[c2], %[b2], vcc"
+                "v_cndmask_b32_e32 %[c2], %[c2], %[b2], vcc\n\t"
+                "s_mov_b64 %[m], vcc"
                 : [z] "+v"(st.z), [id] "+v"(st.id), [c0] "+v"(st.b0), [c1] "+v"(st.b1), [c2] "+v"(st.b2),
                   [m] "=&s"(pass_mask)
                 : [zz] "v"(zz), [tid] "v"(t.q2.y), [b0] "v"(b0), [b1] "v"(b1), [b2] "v"(b2), [valid] "s"(valid)
                 : "vcc");
+          }
+          if constexpr (lds_recs) {  // the winner's slot rides along with its id (pass_mask: the lanes that took this candidate)
+            asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(st.ent) : "v"(slot), "s"(pass_mask));
           }
         }
       }
@@ -977,7 +1002,25 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : MR_RASTER
         float interp[9];
 #pragma unroll
         for (int a = 0; a < 9; ++a) interp[a] = 0.0f;
-        unsigned long long todo = __ballot(live);
+        if constexpr (lds_recs) {
+          // (lanes without a winner hold slot 0 and read a record they do not use)
+          const float4 *rec = (const float4 *)record_of(st.ent);
+          float c[28];
+#pragma unroll
+          for (int q = 0; q < 7; ++q) {
+            const float4 f = rec[q];
+            c[4 * q] = f.x; c[4 * q + 1] = f.y; c[4 * q + 2] = f.z; c[4 * q + 3] = f.w;
+          }
+          const float bk[3] = {st.b0, st.b1, st.b2};
+          {
+#pragma clang fp contract(fast)
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+              for (int a = 0; a < 9; ++a) interp[a] = c[k * 9 + a] * bk[k] + interp[a];
+          }
+        }
+        unsigned long long todo = lds_recs ? 0ull : __ballot(live);
         while (todo) {  // wave-uniform
           const int src = __builtin_ctzll(todo);
           const int t = __builtin_amdgcn_readlane(st.id, src);
@@ -1224,12 +1267,33 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : MR_RASTER
     const bool last_round = next_base >= n_cand;
     // the staging slots overlay the last kStageEntries entries of the bin (see "staged barycentric store")
     const bool stage = max(n_near, far_base + n_far) <= kBin2Cap - kStageEntries;
+    // the epilogue's corner records fit the unused top of the bin (see "corner records in LDS"): ONE bin round
+    // (the slots of an earlier round's winners would be gone) with every entry below slot kRecordSlots
+    const bool recs = SHADE && MR_EPI_LDS_RECORDS && first_pass && last_round && max(n_near, far_base + n_far) <= kRecordSlots;
+    if (recs) {  // workgroup-uniform; build_tile_masks' barriers order these stores before the walk
+      const int total = n_near + n_far;
+      if (tid < total) {
+        const int slot = tid < n_near ? tid : far_base + (tid - n_near);
+        const int t = __builtin_bit_cast(int, s_ent[slot * kEntryDw + 9]);
+        const float4 *src = (const float4 *)(img_corners + min((unsigned)max(t, 0), (unsigned)(T - 1)));
+        float4 *dst = (float4 *)(s_ent + (kBin2Cap * kEntryDw - (slot + 1) * kRecordDw));
+        float4 q[7];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) q[i] = src[i];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) dst[i] = q[i];
+      }
+    }
     auto walk = [&]() {
-      if (!first_pass) raster_pass(std::false_type{}, std::false_type{}, std::false_type{}, far_word, last_round);
+      constexpr std::false_type no{};
+      constexpr std::true_type yes{};
+      if (!first_pass) raster_pass(no, no, no, no, far_word, last_round);
       else if (X1 - X0 == R && Y1 - Y0 == R) {
-        if (MR_BARY_STAGE && stage) raster_pass(std::true_type{}, std::true_type{}, std::true_type{}, far_word, last_round);
-        else raster_pass(std::true_type{}, std::true_type{}, std::false_type{}, far_word, last_round);
-      } else raster_pass(std::true_type{}, std::false_type{}, std::false_type{}, far_word, last_round);
+        if (MR_BARY_STAGE && stage) raster_pass(yes, yes, yes, no, far_word, last_round);
+        else if (recs) raster_pass(yes, yes, no, yes, far_word, last_round);
+        else raster_pass(yes, yes, no, no, far_word, last_round);
+      } else if (recs) raster_pass(yes, no, no, yes, far_word, last_round);
+      else raster_pass(yes, no, no, no, far_word, last_round);
     };
     if constexpr (PROBE == 0 || PROBE >= 8) {
       build_tile_masks(n_near, far_base, n_far);
