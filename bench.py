@@ -383,11 +383,11 @@ def main():
                       "off (rasterize_triangles_ext.shading_epilogue(False)); `value` / `ms_per_step` do not "
                       "contain them" % (n_gb + 2)),
             # ids + barycentrics (16 B/px) and the loss's sign codes (1 B/px) read, the triangles'
-            # attribute and adjugate records (128 + 64 B) read
+            # difference-basis records (FoldRec, 160 B) read
             "roofline_shade_backward": roofline(
-                "k_accumulate_lanes<ShadeLaneFn> (fused shading backward, pixel pass: vertex gradients only, "
-                "18 sums per triangle kept in registers down each lane's vertical run)",
-                px * 17 + batch * T * (128 + 64), ev_shade.mean_ms(n_ev), "shade_backward", args.config),
+                "k_accumulate_lanes<ShadeFoldLaneFn> (fused shading backward, pixel pass: vertex gradients only, "
+                "clip-space pull-back folded in: 9 sums per triangle kept in registers down each lane's vertical run)",
+                px * 17 + batch * T * 160, ev_shade.mean_ms(n_ev), "shade_backward", args.config),
             # the loss: image and target read (2 x 16 B/px), the sign codes written (1 B/px)
             "roofline_l1_forward": roofline(
                 "k_l1_forward (mean |image - target| and its sign codes, one streaming pass)",

@@ -114,6 +114,20 @@ int mr_interpolate_backward(const float *dout, const int32_t *ids,
  * mr_interpolate_records_bytes(B, T, A) bytes, 256-byte aligned, caller-owned). */
 int mr_interpolate_raster_max_attributes(void);
 size_t mr_interpolate_records_bytes(int B, int T, int A);
+
+/* rasterize_clip_space()'s forward (src/mesh_renderer/rasterize.py:66-152) for 1 <= A <=
+ * mr_interpolate_raster_max_attributes() attributes in ONE pass over the pixels: mr_rasterize_forward with
+ * mr_interpolate_forward_records' arithmetic as the epilogue of the tile walk, on the pixel state still in
+ * registers (the G-buffer is not read back; the winners' attribute records come from LDS).  Outputs: ids and
+ * bary exactly as mr_rasterize_forward writes them, `out` [B,H,W,A] exactly mr_interpolate_forward_records'
+ * expression (G-buffer row order), `records` as that call fills them (for mr_interpolate_raster_backward).
+ *   z          [B,H,W] f32: scratch -- written only where a crowded region needs it as state between its bin
+ *              rounds; undefined afterwards
+ *   workspace  mr_rasterize_forward_workspace_bytes() bytes */
+int mr_rasterize_interpolate_forward(const float *clip, const float *attrs, const int32_t *triangles,
+                                     const float *background, int B, int V, int T, int W, int H, int A,
+                                     int32_t *ids, float *bary, float *z, float *out, void *records,
+                                     size_t records_bytes, void *workspace, size_t workspace_bytes, void *stream);
 int mr_interpolate_forward_records(const int32_t *ids, const float *bary, const float *attrs,
                                    const int32_t *triangles, const float *background, int B, int V,
                                    int T, int W, int H, int A, float *out, void *records,

@@ -198,6 +198,8 @@ def lib():
         L.mr_interpolate_records_bytes.restype = sz
         L.mr_interpolate_forward_records.argtypes = [vp] * 5 + [ci] * 6 + [vp, vp, sz, vp]
         L.mr_interpolate_forward_records.restype = ci
+        L.mr_rasterize_interpolate_forward.argtypes = [vp] * 4 + [ci] * 6 + [vp] * 5 + [sz, vp, sz, vp]
+        L.mr_rasterize_interpolate_forward.restype = ci
         L.mr_interpolate_raster_backward.argtypes = [vp] * 10 + [ci] * 6 + [vp, vp, vp, sz, vp]
         L.mr_interpolate_raster_backward.restype = ci
         L.mr_vertex_transform.argtypes = [vp, vp, ci, ci, vp, vp]
@@ -561,6 +563,35 @@ def interpolate_forward_records(ids, bary, attrs, triangles, background):
                                               need, _stream(dev))
     _check(rc, "mr_interpolate_forward_records")
     return out, records
+
+
+def rasterize_interpolate_forward(clip, attrs, triangles, background, width, height):
+    """rasterize_clip_space()'s forward in one pass over the pixels (the interpolation is the epilogue of the
+    rasterizer's tile walk) for at most interpolate_raster_max_attributes() attributes
+    -> (ids [B,H,W], bary [B,H,W,3], out [B,H,W,A], records for interpolate_raster_backward)."""
+    B, V, T = _chk_mesh(clip, triangles)
+    _chk("attributes", attrs, _F32, B, V, None)
+    A = attrs.shape[2]
+    _chk("background", background, _F32, A)
+    if not 1 <= A <= interpolate_raster_max_attributes():
+        raise ValueError("1..%d attributes are supported here" % interpolate_raster_max_attributes())
+    dev = _require_device(clip, attrs, triangles, background)
+    L = lib()
+    clip, attrs, triangles, background = [t.contiguous() for t in (clip, attrs, triangles, background)]
+    ids = torch.empty(B, height, width, dtype=torch.int32, device=dev)
+    bary = torch.empty(B, height, width, 3, dtype=torch.float32, device=dev)
+    z = torch.empty(B, height, width, dtype=torch.float32, device=dev)
+    out = torch.empty(B, height, width, A, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        need_rec = L.mr_interpolate_records_bytes(B, T, A)
+        records = _aligned_bytes(need_rec, dev)
+        need = L.mr_rasterize_forward_workspace_bytes(B, V, T, width, height)
+        ws, have = _workspace(dev, need)
+        rc = L.mr_rasterize_interpolate_forward(_ptr(clip), _ptr(attrs), _ptr(triangles), _ptr(background), B, V, T,
+                                                width, height, A, _ptr(ids), _ptr(bary), _ptr(z), _ptr(out),
+                                                _ptr(records), need_rec, _ptr(ws), have, _stream(dev))
+    _check(rc, "mr_rasterize_interpolate_forward")
+    return ids, bary, out, records
 
 
 def interpolate_raster_backward(dout, ids, bary, clip, attrs, triangles, background, adjacency,

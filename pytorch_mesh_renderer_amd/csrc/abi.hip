@@ -175,6 +175,23 @@ int mr_interpolate_forward_records(const int32_t *ids, const float *bary, const 
                                            records, (hipStream_t)stream);
 }
 
+int mr_rasterize_interpolate_forward(const float *clip, const float *attrs, const int32_t *triangles,
+                                     const float *background, int B, int V, int T, int W, int H, int A,
+                                     int32_t *ids, float *bary, float *z, float *out, void *records,
+                                     size_t records_bytes, void *workspace, size_t workspace_bytes, void *stream) {
+  if (bad_dims(B, V, T, W, H) || A < 1 || A > mr::interp_raster_max_attrs() || T < 1 || V < 1) return MR_EINVAL;
+  if (B == 0) return MR_OK;
+  if (!clip || !attrs || !triangles || !background || !ids || !bary || !z || !out || ((uintptr_t)clip & 15u) ||
+      ((uintptr_t)records & 255u))
+    return MR_EINVAL;
+  int rc = check_ws(records, records_bytes, mr::interp_records_bytes(B, T, A));
+  if (rc != MR_OK) return rc;
+  rc = check_ws(workspace, workspace_bytes, mr::raster_forward_ws(B, V, T, W, H));
+  if (rc != MR_OK) return rc;
+  return mr::launch_rasterize_interpolate_forward(clip, attrs, triangles, background, B, V, T, W, H, A, ids, bary, z, out,
+                                                  records, workspace, (hipStream_t)stream);
+}
+
 int mr_interpolate_raster_backward(const float *dout, const int32_t *ids, const float *bary,
                                    const float *clip, const float *attributes,
                                    const int32_t *triangles, const float *background,

@@ -378,6 +378,19 @@ size_t interp_raster_backward_ws(int B, int V, int T, int W, int H, int A) {
 
 size_t interp_records_bytes(int B, int T, int A) { return corner_bytes(B, T, padded_attrs(A)); }
 
+// The per-(image, triangle) attribute records alone: [corner][AP] floats, AP = A rounded up to 4 / 8 / 12 / 16
+// (what the rasterizer's INTERP epilogue reads, raster_forward.hip, and the fused backward reuses).
+int launch_attr_records(const float *attrs, const int32_t *tris, int B, int V, int T, int A, void *records, hipStream_t s) {
+  if ((size_t)B * T == 0) return MR_OK;
+  float *corners = (float *)records;
+  switch (padded_attrs(A)) {
+    case 4: return setup_records<4>(attrs, tris, B, V, T, A, corners, s);
+    case 8: return setup_records<8>(attrs, tris, B, V, T, A, corners, s);
+    case 12: return setup_records<12>(attrs, tris, B, V, T, A, corners, s);
+    default: return setup_records<16>(attrs, tris, B, V, T, A, corners, s);
+  }
+}
+
 int launch_interp_forward_records(const int32_t *ids, const float *bary, const float *attrs, const int32_t *tris,
                                   const float *bg, int B, int V, int T, int W, int H, int A, float *out,
                                   void *records, hipStream_t s) {

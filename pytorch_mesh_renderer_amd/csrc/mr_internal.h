@@ -141,6 +141,10 @@ int launch_interp_raster_backward(const float *dout, const int32_t *ids, const f
                                   void *ws, hipStream_t s);
 int launch_vertex_transform(const float *vertices, const float *transforms, int B, int V, float *clip,
                             hipStream_t s);
+int launch_attr_records(const float *attrs, const int32_t *tris, int B, int V, int T, int A, void *records, hipStream_t s);
+int launch_rasterize_interpolate_forward(const float *clip, const float *attrs, const int32_t *tris, const float *background,
+                                         int B, int V, int T, int W, int H, int A, int32_t *ids, float *bary, float *z,
+                                         float *out, void *records, void *ws, hipStream_t s);
 int launch_render_forward(const float *vertices, const float *transforms, const float *normals,
                           const float *diffuse, const int32_t *tris, const float *light_pos,
                           const float *light_col, const float *ambient, int B, int V, int T, int W, int H,

@@ -538,6 +538,12 @@ struct RasterShade {
                                           // examples' `(image * 255.0).astype(np.uint8)`, loss.hip's to_u8)
   int keep_z;                             // 0: the caller does not want the depth plane -- it is then only
                                           // written between the bin rounds of a crowded region (as state)
+  // INTERP (round 4): rasterize()'s attribute interpolation (src/mesh_renderer/rasterize.py:118-150) as the
+  // epilogue instead of the shading -- k_interp_forward_rec's arithmetic on the pixel state in registers
+  const float *__restrict__ attr_records;  // [B*T][3 * AP]: the corners' attributes, [corner][attribute] (interp_fused.hip)
+  const float *__restrict__ background;    // [A]
+  float *__restrict__ attr_out;            // [B,H,W,A], G-buffer row order (row 0 = bottom, like ids / bary)
+  int A;
 };
 
 #ifndef MR_EPI_LDS_LIGHTS
@@ -574,8 +580,17 @@ struct RasterShade {
 #ifndef MR_RASTER_SHADE_WAVES
 #define MR_RASTER_SHADE_WAVES 6  // measured against 7 (more spills) and 5: 0.336 / 0.352 / 0.347 ms at 1024^2 x 32
 #endif
-template <int R, int PROBE, bool SHADE>
-__global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : MR_RASTER_WAVES) void k_raster(
+#ifndef MR_RASTER_INTERP_STORE_AUX
+#define MR_RASTER_INTERP_STORE_AUX 0   // the interpolated image's stores: per-lane pieces of A floats -- through the caches (merged in L2)
+#endif
+#ifndef MR_RASTER_INTERP_STAGE
+#define MR_RASTER_INTERP_STAGE 1   // see stage_slot in k_raster
+#endif
+#ifndef MR_RASTER_INTERP_WAVES
+#define MR_RASTER_INTERP_WAVES 5
+#endif
+template <int R, int PROBE, bool SHADE, int INTERP = 0>
+__global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : INTERP >= 12 ? 4 : INTERP ? MR_RASTER_INTERP_WAVES : MR_RASTER_WAVES) void k_raster(
     const TriRec *__restrict__ recs, const TriBox *__restrict__ bbs,
     const float *__restrict__ pxtab, const float *__restrict__ pytab, int T, int W, int H,
     int regions_x, int regions_per_image, int n_regions, int regions_per_xcd,
@@ -587,6 +602,8 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : MR_RASTER
     float *__restrict__ zbuf, const RasterShade shade) {
   static_assert(R == 64 || R == 32, "region edge");
   static_assert(!SHADE || PROBE == 0, "the shading epilogue has no timing probes");
+  static_assert(INTERP == 0 || (!SHADE && PROBE == 0 && INTERP % 4 == 0 && INTERP <= 16), "one epilogue at a time");
+  constexpr bool EPI = SHADE || INTERP > 0;   // an epilogue runs on a region's last bin round
   // A wavefront's tile is kTileW x kTileH pixels, one per lane.  16 x 4: every row of a tile's
   // G-buffer stores is a whole, aligned 64-byte sector (16 ids / depths) or three of them (16
   // barycentric triples); with 8 x 8 tiles two wavefronts shared each sector and the L2 had to
@@ -753,6 +770,31 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : MR_RASTER
       SHADE ? shade.rgba + 4 * ((ptrdiff_t)img_px + ((ptrdiff_t)H - R - Y0) * W + X0) : nullptr, 0, 0x7fffffff,
       kRsrcWord3);
   const CornerRec *img_corners = SHADE ? shade.corners + (size_t)img * T : nullptr;
+  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
+      INTERP ? shade.attr_out + region_pix * (size_t)shade.A : nullptr, 0, 0x7fffffff, kRsrcWord3);
+  const float *img_attr_records = INTERP ? shade.attr_records + (size_t)img * T * (3 * INTERP) : nullptr;
+  const unsigned lane_out = INTERP ? lane_pix * (unsigned)shade.A * 4u : 0u;   // byte offset of the lane's pixel inside a tile
+  int ent_init = 0;   // slot a pixel without a winner looks up (INTERP: the background's record, set per round)
+  // INTERP: a pixel's A floats are A * 4 bytes apart from its neighbour's: stored per lane they reach memory as
+  // 16-byte (or smaller) pieces at a stride of A * 4 bytes -- partial sectors from every store instruction (measured
+  // at A = 9: 505 us for the kernel; with nontemporal stores 1.4 ms).  A tile's 64 x A floats are four rows of
+  // 16 A contiguous floats: the lanes park their values pixel-major in an LDS slot of their wavefront
+  // (write width chosen by A's alignment: conflict-free for odd A and A = 4, 12) and read the tile back as
+  // 16-byte chunks, lane + 64 i: every store instruction then writes whole, contiguous 1 KB pieces of a row.
+  // (The INTERP instantiations run at 4-5 waves per SIMD on their registers: the slot costs no occupancy.)
+  float *stage_slot = nullptr;
+  unsigned stage_goff[INTERP > 0 ? INTERP / 4 : 1] = {};
+  if constexpr (INTERP > 0) {
+    __shared__ __attribute__((aligned(16))) float s_stage[kWaves * kWave * INTERP];
+    stage_slot = s_stage + wave * (kWave * INTERP);
+    const unsigned chunks_per_row = (unsigned)(kTileW * shade.A) / 4u;      // 16-byte chunks in one tile row: 4 A
+#pragma unroll
+    for (int i = 0; i < INTERP / 4; ++i) {
+      const unsigned j = (unsigned)lane + 64u * i;                          // this lane's chunk in trip i
+      const unsigned r = j / chunks_per_row;                                // tile row
+      stage_goff[i] = r * (unsigned)(W * shade.A) * 4u + (j - r * chunks_per_row) * 16u;
+    }
+  }
 #if MR_EPI_LDS_LIGHTS
   const float *s_lights_ptr = nullptr;
   if constexpr (SHADE) {  // (no LDS at all in the G-buffer-only instantiation: its 23040 B are exactly 18 granules)
@@ -779,7 +821,7 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : MR_RASTER
     for (int y = wave * kRowsPerInst + lane / R; y < R; y += kWaves * kRowsPerInst) {
       const unsigned pix = (unsigned)(y * W + x);
       __builtin_amdgcn_raw_buffer_store_b32(0u, rs_ids, pix * 4u, 0, MR_RASTER_STORE_AUX_IDS);
-      if (!SHADE || shade.keep_z)
+      if (!EPI || shade.keep_z)
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, 1.0f), rs_z, pix * 4u, 0, MR_RASTER_STORE_AUX_Z);
       __builtin_amdgcn_raw_buffer_store_b96(v3u{0u, 0u, 0u}, rs_bary, pix * 12u, 0, MR_RASTER_STORE_AUX);
       if constexpr (SHADE) {
@@ -787,6 +829,16 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : MR_RASTER
         __builtin_amdgcn_raw_buffer_store_b128(v4u{0u, 0u, 0u, 0u}, rs_rgba, (unsigned)((R - 1 - y) * W + x) * 16u, 0,
                                                MR_RASTER_STORE_AUX);
         if (shade.rgba8) __builtin_nontemporal_store(0u, &shade.rgba8[img_px + (size_t)(H - 1 - (Y0 + y)) * W + X0 + x]);
+      }
+      if constexpr (INTERP > 0) {
+        // an uncovered pixel: id 0, barycentrics 0 -> alpha 0: 0 * (triangle 0's attributes, weighted by zeros) + 1 * background
+        // (rasterize.py:137-150; the products are kept: a non-finite attribute of triangle 0 shows here as in the reference)
+        for (int a = 0; a < shade.A; ++a) {
+          const float value = (img_attr_records[a] * 0.0f + img_attr_records[INTERP + a] * 0.0f) + img_attr_records[2 * INTERP + a] * 0.0f;
+          const float o = 0.0f * value + 1.0f * shade.background[a];
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rs_out, pix * (unsigned)shade.A * 4u + 4u * a, 0,
+                                                0);
+        }
       }
     }
     return;
@@ -826,14 +878,14 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : MR_RASTER
   // banks apart) -- loaded once per region, one thread per entry -- the depth loop remembers the winner's SLOT
   // next to its id, and the epilogue is 7 per-lane ds_read_b128 and 27 multiply-adds per tile, whatever the
   // number of winners.  LDS reads count on lgkmcnt like the scalar loads did: the G-buffer stores stay undisturbed.
-  constexpr int kRecordDw = 28;
-  constexpr int kRecordSlots = (kBin2Cap * kEntryDw) / (kEntryDw + kRecordDw);   // 106: entries + records fit the bin
+  constexpr int kRecordDw = INTERP > 0 ? 3 * INTERP : 28;  // (INTERP: the attribute record of interp_fused.hip, [corner][AP])
+  constexpr int kRecordSlots = (kBin2Cap * kEntryDw) / (kEntryDw + kRecordDw);   // 106 (SHADE): entries + records fit the bin
   auto record_of = [&](const int slot) -> const float * { return s_ent + (kBin2Cap * kEntryDw - (slot + 1) * kRecordDw); };
   auto raster_pass = [&](auto fresh_tag, auto full_tag, auto stage_tag, auto recs_tag, const int far_word,
                          const bool last_round) {
     constexpr bool fresh = decltype(fresh_tag)::value, full = decltype(full_tag)::value;
     constexpr bool stage = MR_BARY_STAGE && decltype(stage_tag)::value && full && !(PROBE & 64);
-    constexpr bool lds_recs = SHADE && MR_EPI_LDS_RECORDS && decltype(recs_tag)::value;
+    constexpr bool lds_recs = EPI && MR_EPI_LDS_RECORDS && decltype(recs_tag)::value;
     const unsigned near_words = (1u << far_word) - 1u;  // far_word == kMaskWords: every word
     // wavefront w walks tiles w, w + 4, ... (row-major tile numbering).  (Walking pairs of
     // horizontally adjacent tiles back to back, so that both halves of a 128-byte line come from
@@ -856,8 +908,9 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : MR_RASTER
       if (fresh) {
         st.z = 1.0f; st.b0 = 0.0f; st.b1 = 0.0f; st.b2 = 0.0f;  // cpp:313-321
         st.id = ordered ? -1 : 0;  // -1: "nothing drawn yet" loses every tie; stored as 0
-        st.ent = 0;
+        st.ent = ent_init;
       } else if (in_image) {
+        st.ent = 0;
         st.z = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_z, lane_pix * 4u, tile_pix * 4, 0));
         st.id = (int)__builtin_amdgcn_raw_buffer_load_b32(rs_ids, lane_pix * 4u, tile_pix * 4, 0);
         st.b0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_bary, lane_pix * 12u, tile_pix * 12, 0));
@@ -990,6 +1043,76 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : MR_RASTER
       words = far_words;
       far_words = 0u;
       }
+      if constexpr (INTERP > 0) {
+        if (last_round) {  // workgroup-uniform
+          constexpr int AP = INTERP;
+          typedef unsigned v4u __attribute__((ext_vector_type(4)));
+          typedef unsigned v2u __attribute__((ext_vector_type(2)));
+          // the record: [corner][AP] floats, from LDS by the winner's slot, or -- a crowded region -- per lane from
+          // memory by triangle id (no winner: triangle 0, as the reference)
+          const float *rec;
+          if constexpr (lds_recs) rec = record_of(st.ent);
+          else rec = img_attr_records + (size_t)min((unsigned)max(st.id, 0), (unsigned)(T - 1)) * (3 * AP);
+          const float pre = (2.0f * st.b0 + 2.0f * st.b1) + 2.0f * st.b2;
+          const float alpha = fminf(fmaxf(pre, 0.0f), 1.0f);
+          const float one_m = 1.0f - alpha;
+          const int tile_out = tile_pix * shade.A * 4;
+          constexpr bool staged = full && MR_RASTER_INTERP_STAGE;
+          float *mine = stage_slot + lane * shade.A;
+          // four attributes at a time: three 16-byte reads (one per corner), four results, straight to their
+          // destination -- the whole record at once was 36 + 12 live registers at A = 9
+#pragma unroll
+          for (int q = 0; q < AP / 4; ++q) {
+            if (4 * q >= shade.A) break;   // wave-uniform
+            const float4 c0 = *(const float4 *)(rec + 4 * q), c1 = *(const float4 *)(rec + AP + 4 * q),
+                         c2 = *(const float4 *)(rec + 2 * AP + 4 * q);
+            float o[4];
+            {
+#pragma clang fp contract(fast)
+              const float k0[4] = {c0.x, c0.y, c0.z, c0.w}, k1[4] = {c1.x, c1.y, c1.z, c1.w}, k2[4] = {c2.x, c2.y, c2.z, c2.w};
+#pragma unroll
+              for (int a = 0; a < 4; ++a) {
+                const float value = (k0[a] * st.b0 + k1[a] * st.b1) + k2[a] * st.b2;
+                o[a] = alpha * value + one_m * (4 * q + a < shade.A ? shade.background[4 * q + a] : 0.0f);
+              }
+            }
+            const int left = shade.A - 4 * q;   // wave-uniform, >= 1
+            if constexpr (staged) {
+              if ((shade.A & 3) == 0) *(float4 *)(mine + 4 * q) = make_float4(o[0], o[1], o[2], o[3]);
+              else if ((shade.A & 1) == 0) {
+                *(float2 *)(mine + 4 * q) = make_float2(o[0], o[1]);
+                if (left >= 4) *(float2 *)(mine + 4 * q + 2) = make_float2(o[2], o[3]);
+              } else {
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+                  if (a < left) mine[4 * q + a] = o[a];
+              }
+            } else if (in_image) {
+              const unsigned u0 = __builtin_bit_cast(unsigned, o[0]), u1 = __builtin_bit_cast(unsigned, o[1]),
+                             u2 = __builtin_bit_cast(unsigned, o[2]), u3 = __builtin_bit_cast(unsigned, o[3]);
+              if (left >= 4) __builtin_amdgcn_raw_buffer_store_b128(v4u{u0, u1, u2, u3}, rs_out, lane_out + 16u * q, tile_out, MR_RASTER_INTERP_STORE_AUX);
+              else if (left == 3) __builtin_amdgcn_raw_buffer_store_b96(v3u{u0, u1, u2}, rs_out, lane_out + 16u * q, tile_out, MR_RASTER_INTERP_STORE_AUX);
+              else if (left == 2) __builtin_amdgcn_raw_buffer_store_b64(v2u{u0, u1}, rs_out, lane_out + 16u * q, tile_out, MR_RASTER_INTERP_STORE_AUX);
+              else __builtin_amdgcn_raw_buffer_store_b32(u0, rs_out, lane_out + 16u * q, tile_out, MR_RASTER_INTERP_STORE_AUX);
+            }
+          }
+          if constexpr (staged) {
+            // (same wavefront: LDS operations complete in order) the tile back as 16-byte chunks, lane + 64 i
+            const unsigned n_chunks = 16u * (unsigned)shade.A;   // 64 pixels x A floats / 4
+#pragma unroll
+            for (int i = 0; i < AP / 4; ++i) {
+              const unsigned jc = (unsigned)lane + 64u * i;
+              if (64u * i < n_chunks) {  // wave-uniform
+                const float4 v = *(const float4 *)(stage_slot + 4u * jc);   // (beyond n_chunks: inside the slot, not stored)
+                if (jc < n_chunks)
+                  __builtin_amdgcn_raw_buffer_store_b128(v4u{__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y),
+                                                             __builtin_bit_cast(unsigned, v.z), __builtin_bit_cast(unsigned, v.w)},
+                                                         rs_out, stage_goff[i], tile_out, MR_RASTER_STORE_AUX);
+              }
+            }
+          }
+        }
+      }
       if (SHADE && last_round) {  // workgroup-uniform
         // the rule of k_shade_forward: a pixel is shaded iff alpha = clamp(2 sum(bary)) > 0
         const bool live = in_image && ((2.0f * st.b0 + 2.0f * st.b1) + 2.0f * st.b2) > 0.0f;
@@ -1088,7 +1211,7 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : MR_RASTER
         const int st_tile = ((PROBE & 64) && R == 64) ? (ty * kTileH + tx) * W : tile_pix;
         __builtin_amdgcn_raw_buffer_store_b32((unsigned)max(st.id, 0), rs_ids, st_lane * 4u, st_tile * 4,
                                               (PROBE & 64) ? MR_RASTER_STORE_AUX : MR_RASTER_STORE_AUX_IDS);
-        if (!SHADE || !last_round || shade.keep_z)  // workgroup-uniform
+        if (!EPI || !last_round || shade.keep_z)  // workgroup-uniform
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, st.z), rs_z, st_lane * 4u, st_tile * 4, MR_RASTER_STORE_AUX_Z);
         if constexpr (stage) {
           typedef float v4f __attribute__((ext_vector_type(4)));
@@ -1269,19 +1392,23 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : MR_RASTER
     const bool stage = max(n_near, far_base + n_far) <= kBin2Cap - kStageEntries;
     // the epilogue's corner records fit the unused top of the bin (see "corner records in LDS"): ONE bin round
     // (the slots of an earlier round's winners would be gone) with every entry below slot kRecordSlots
-    const bool recs = SHADE && MR_EPI_LDS_RECORDS && first_pass && last_round && max(n_near, far_base + n_far) <= kRecordSlots;
+    // (INTERP keeps one slot more: the record a pixel WITHOUT a winner looks up -- triangle 0's, as in the reference)
+    const int top_slot = max(n_near, far_base + n_far);
+    const bool recs = EPI && MR_EPI_LDS_RECORDS && first_pass && last_round && top_slot + (INTERP > 0 ? 1 : 0) <= kRecordSlots;
     if (recs) {  // workgroup-uniform; build_tile_masks' barriers order these stores before the walk
       const int total = n_near + n_far;
-      if (tid < total) {
-        const int slot = tid < n_near ? tid : far_base + (tid - n_near);
-        const int t = __builtin_bit_cast(int, s_ent[slot * kEntryDw + 9]);
-        const float4 *src = (const float4 *)(img_corners + min((unsigned)max(t, 0), (unsigned)(T - 1)));
+      if (INTERP > 0) ent_init = top_slot;
+      if (tid < total + (INTERP > 0 ? 1 : 0)) {
+        const int slot = tid < n_near ? tid : tid < total ? far_base + (tid - n_near) : top_slot;
+        const int t = tid < total ? __builtin_bit_cast(int, s_ent[slot * kEntryDw + 9]) : 0;
+        const unsigned tc = min((unsigned)max(t, 0), (unsigned)(T - 1));
+        const float4 *src = SHADE ? (const float4 *)(img_corners + tc) : (const float4 *)(img_attr_records + (size_t)tc * kRecordDw);
         float4 *dst = (float4 *)(s_ent + (kBin2Cap * kEntryDw - (slot + 1) * kRecordDw));
-        float4 q[7];
+        float4 q[kRecordDw / 4];
 #pragma unroll
-        for (int i = 0; i < 7; ++i) q[i] = src[i];
+        for (int i = 0; i < kRecordDw / 4; ++i) q[i] = src[i];
 #pragma unroll
-        for (int i = 0; i < 7; ++i) dst[i] = q[i];
+        for (int i = 0; i < kRecordDw / 4; ++i) dst[i] = q[i];
       }
     }
     auto walk = [&]() {
@@ -1353,9 +1480,9 @@ struct RasterArgs {
   RasterShade shade;  // rgba == nullptr: G-buffer only
 };
 
-template <int R, int PROBE, bool SHADE = false>
+template <int R, int PROBE, bool SHADE = false, int INTERP = 0>
 void launch_k_raster(const RasterArgs &a, dim3 grid, hipStream_t s) {
-  hipLaunchKernelGGL((k_raster<R, PROBE, SHADE>), grid, dim3(kThreads), 0, s, a.recs, a.bbs, a.pxtab, a.pytab, a.T,
+  hipLaunchKernelGGL((k_raster<R, PROBE, SHADE, INTERP>), grid, dim3(kThreads), 0, s, a.recs, a.bbs, a.pxtab, a.pytab, a.T,
                      a.W, a.H, a.regions_x, a.per_image, a.n_regions, a.per_xcd, a.cell_ids, a.cell_count,
                      a.cell_split, a.cells_x, a.cells_per_image, a.region_ids, a.region_count, a.order_count,
                      a.order_list, a.ids, a.bary, a.z, a.shade);
@@ -1364,6 +1491,14 @@ void launch_k_raster(const RasterArgs &a, dim3 grid, hipStream_t s) {
 template <int R>
 void launch_k_raster_probe(const RasterArgs &a, dim3 grid, hipStream_t s) {
   if (a.shade.rgba) return launch_k_raster<R, 0, true>(a, grid, s);
+  if (a.shade.attr_out) {  // rasterize()'s interpolation as the epilogue, attribute count padded to 4 / 8 / 12 / 16
+    switch ((a.shade.A + 3) / 4) {
+      case 1: return launch_k_raster<R, 0, false, 4>(a, grid, s);
+      case 2: return launch_k_raster<R, 0, false, 8>(a, grid, s);
+      case 3: return launch_k_raster<R, 0, false, 12>(a, grid, s);
+      default: return launch_k_raster<R, 0, false, 16>(a, grid, s);
+    }
+  }
 #ifdef MR_PROBES
   switch (g_raster_probe) {
     case 1: return launch_k_raster<R, 1>(a, grid, s);
@@ -1446,7 +1581,23 @@ int raster_forward(const float *clip, const int32_t *tris, int B, int V, int T, 
 int launch_raster_forward(const float *clip, const int32_t *tris, int B, int V, int T, int W,
                           int H, int32_t *ids, float *bary, float *z, void *ws, hipStream_t s) {
   return raster_forward(clip, tris, B, V, T, W, H, ids, bary, z,
-                        RasterShade{nullptr, Lights{nullptr, nullptr, nullptr, 0}, nullptr, nullptr, 1},
+                        RasterShade{nullptr, Lights{nullptr, nullptr, nullptr, 0}, nullptr, nullptr, 1, nullptr, nullptr, nullptr, 0},
+                        SetupAttributes{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, ws, s);
+}
+
+// rasterize_clip_space() forward for up to 16 attributes in ONE pass over the pixels (round 4): the attribute
+// records (interp_fused.hip: one [3][AP] record per (image, triangle)), then k_setup / k_coarse / k_raster with
+// the interpolation as the tile walk's epilogue.  The depth plane is scratch (`z`: a [B,H,W] buffer the kernel
+// may use as state between the bin rounds of a crowded region).
+int launch_rasterize_interpolate_forward(const float *clip, const float *attrs, const int32_t *tris, const float *background,
+                                         int B, int V, int T, int W, int H, int A, int32_t *ids, float *bary, float *z,
+                                         float *out, void *records, void *ws, hipStream_t s) {
+  if ((size_t)B * W * H == 0) return MR_OK;
+  const int rc = launch_attr_records(attrs, tris, B, V, T, A, records, s);
+  if (rc != MR_OK) return rc;
+  return raster_forward(clip, tris, B, V, T, W, H, ids, bary, z,
+                        RasterShade{nullptr, Lights{nullptr, nullptr, nullptr, 0}, nullptr, nullptr, 0, (const float *)records,
+                                    background, out, A},
                         SetupAttributes{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, ws, s);
 }
 
@@ -1473,7 +1624,8 @@ int launch_render_forward(const float *vertices, const float *transforms, const 
   if ((size_t)B * W * H == 0) return MR_OK;
   CornerRec *corners = (CornerRec *)corner_records;
   return raster_forward(clip, tris, B, V, T, W, H, ids, bary, z,
-                        RasterShade{corners, Lights{light_pos, light_col, ambient, L}, rgba, (uint32_t *)rgba_u8, want_z},
+                        RasterShade{corners, Lights{light_pos, light_col, ambient, L}, rgba, (uint32_t *)rgba_u8, want_z, nullptr,
+                                    nullptr, nullptr, 0},
                         SetupAttributes{(const F3 *)normals, (const F3 *)vertices, (const F3 *)diffuse, corners,
                                         (FoldRec *)backward_prepared,
                                         backward_prepared ? (float4 *)((char *)backward_prepared + fold_prepared_recs_bytes(B, T))

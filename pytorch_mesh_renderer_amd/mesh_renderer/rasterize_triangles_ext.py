@@ -79,6 +79,10 @@ class AttributeInterpolator(torch.autograd.Function):
         return None, dbary, dattrs, None, dbackground
 
 
+# False (or MR_FUSED_INTERPOLATION=0 in the environment at import): k_raster, then k_interp_forward_rec over the G-buffer
+FUSED_INTERPOLATION_EPILOGUE = os.environ.get("MR_FUSED_INTERPOLATION", "1") != "0"
+
+
 class FusedAttributeRasterizer(torch.autograd.Function):
     """rasterize_clip_space() as ONE differentiable op for up to 16 attributes: G-buffer
     rasterization + attribute interpolation forward, and a single pass over the G-buffer backward
@@ -89,8 +93,12 @@ class FusedAttributeRasterizer(torch.autograd.Function):
     def forward(ctx, clip, attributes, triangles, background, image_width, image_height):
         clip_d = clip.detach().contiguous()
         attrs_d, bg_d = attributes.detach().contiguous(), background.detach().contiguous()
-        ids, bary, _ = _native.rasterize_forward(clip_d, triangles, int(image_width), int(image_height))
-        out, records = _native.interpolate_forward_records(ids, bary, attrs_d, triangles, bg_d)
+        if FUSED_INTERPOLATION_EPILOGUE:   # round 4: one pass over the pixels (the interpolation is k_raster's epilogue)
+            ids, bary, out, records = _native.rasterize_interpolate_forward(clip_d, attrs_d, triangles, bg_d,
+                                                                            int(image_width), int(image_height))
+        else:
+            ids, bary, _ = _native.rasterize_forward(clip_d, triangles, int(image_width), int(image_height))
+            out, records = _native.interpolate_forward_records(ids, bary, attrs_d, triangles, bg_d)
         offsets, entries = _native.vertex_adjacency(triangles, clip_d.shape[1])   # cached per mesh
         ctx.save_for_backward(clip_d, ids, bary, attrs_d, triangles, bg_d, offsets, entries, records)
         return out

@@ -262,6 +262,42 @@ def test_rasterize_matches_oracle_on_random_soups(device, n_attrs):
         np.testing.assert_allclose(results["hip"][1][k], want, atol=ATOL, rtol=0, err_msg=k)
 
 
+@pytest.mark.parametrize("n_attrs", [1, 3, 4, 7, 9, 12, 13, 16])
+@pytest.mark.parametrize("scene", ["sphere_ragged", "crowded", "soup"])
+def test_rasterize_interpolation_epilogue_matches_two_passes(device, scene, n_attrs):
+    """Round 4: rasterize()'s forward as ONE pass -- the interpolation is the epilogue of k_raster's tile walk, the
+    winners' attribute records come from LDS -- against k_raster followed by k_interp_forward_rec over the
+    G-buffer: ids and barycentrics bit-identical, the interpolated image to 1e-6.  "crowded": a 28k-triangle
+    sphere at 64 x 64, whose regions need several bin rounds (the records are then read per lane from memory);
+    "sphere_ragged": a size that is no multiple of the region / tile edges; "soup": random triangles with an
+    infinite attribute on triangle 0 -- uncovered pixels multiply it by zero, as the reference does."""
+    from pytorch_mesh_renderer_amd import _native
+    gen = torch.Generator().manual_seed(n_attrs)
+    if scene == "soup":
+        soup, tris, proj = _random_soup(40 + n_attrs, n_attrs)
+        clip = camera_utils.transform_homogeneous(proj, soup["vertices"]).contiguous()
+        attrs, w, h = soup["attributes"].clone(), 57, 41
+        attrs[0, tris[0, 1].long(), 0] = float("inf")
+    else:
+        w, h, res = (201, 123, 10) if scene == "sphere_ragged" else (64, 64, 120)
+        job = synthetic.sphere_job(2, w, h, res)
+        clip, tris = job["clip"], job["triangles"]
+        attrs = torch.rand(2, clip.shape[1], n_attrs, generator=gen)
+    bg = torch.linspace(-1.0, 0.5, n_attrs)
+    clip, tris, attrs, bg = clip.to(device), tris.to(device), attrs.to(device), bg.to(device)
+    ids, bary, out, records = _native.rasterize_interpolate_forward(clip, attrs, tris, bg, w, h)
+    ids2, bary2, _ = _native.rasterize_forward(clip, tris, w, h)
+    out2, records2 = _native.interpolate_forward_records(ids2, bary2, attrs, tris, bg)
+    assert torch.equal(ids, ids2) and torch.equal(bary.view(torch.int32), bary2.view(torch.int32))
+    used = clip.shape[0] * tris.shape[0] * 3 * (4 * ((n_attrs + 3) // 4)) * 4     # bytes: [B*T][3][A padded to 4 / 8 / 12 / 16]
+    assert torch.equal(records.view(torch.uint8)[:used], records2.view(torch.uint8)[:used])
+    got, want = out.cpu().numpy(), out2.cpu().numpy()
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    ok = np.isfinite(want)
+    np.testing.assert_allclose(got[ok], want[ok], atol=1e-6, rtol=1e-6)
+    assert 0.05 < float((bary.sum(-1) > 0.5).float().mean()) < 0.98
+
+
 def test_rasterize_seventeen_attributes_golden(device):
     """The reference's own rasterize() on a random soup with 17 attributes (tools/make_goldens_r4.py attrs)."""
     g = golden_npz("rasterize_soup_a17_40x30.npz")
