@@ -254,8 +254,10 @@ int mr_render_forward(const float *vertices, const float *transforms, const floa
  *                   inputs (256-byte aligned).  Used -- the setup launch skipped -- when the call is one
  *                   the folded kernel serves (dclip, dnormals, ddiffuse, light_grads NULL; transforms and
  *                   the adjacency given; MR_GBUFFER_NORMALISED; not deterministic), ignored otherwise.  The
- *                   block's accumulator rows are clear on entry and are left clear (the per-vertex gather
- *                   zeroes what it reads): one block serves any number of backward calls, one at a time.
+ *                   block's accumulator rows are clear on entry and DIRTY afterwards: a block serves ONE
+ *                   backward call that uses it (differentiating a second time: pass NULL -- the call then
+ *                   runs its own setup kernel -- or clear the rows, the block's last
+ *                   B * T * 48 bytes rounded up to 256).
  * dclip, dnormals, dpositions, ddiffuse, light_grads laid out back to back in that order are
  * zeroed with a single memset (none at all with the vertex adjacency: every output is written
  * exactly once). */

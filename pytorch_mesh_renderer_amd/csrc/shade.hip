@@ -674,9 +674,9 @@ __global__ __launch_bounds__(kThreads) void k_shade_gather(
 // gradient of the corner's world-space position -- in 48 bytes, so a vertex needs three sums, not thirteen:
 // four lanes per (image, vertex) (the fourth idles), 320 k threads instead of 1.3 M at 32 x 2502 vertices, a third
 // of the bytes.  Same fixed summation order as k_shade_gather (the adjacency's).
-// CLEAR: every accumulator float is read by exactly one lane of one vertex -- entry e = 3 t + k belongs to
-// vertex triangles[t][k] alone -- which stores a zero behind its read: the rows are clear again when the kernel
-// ends (a `prepared` block serves any number of backward calls; its first clearing is k_setup's).
+// CLEAR (not used, see the launch): every accumulator float is read by exactly one lane of one vertex -- entry
+// e = 3 t + k belongs to vertex triangles[t][k] alone -- which stores a zero behind its read: the rows are clear
+// again when the kernel ends.
 template <bool CLEAR>
 __global__ __launch_bounds__(kThreads) void k_shade_gather_fold(
     float *__restrict__ acc, const int32_t *__restrict__ offsets, const int32_t *__restrict__ entries, int B, int V,
@@ -1043,12 +1043,12 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
   }
   if (fold_diff) {  // compact rows, position gradient only
     const long nbv = (long)B * V * 4;
-    if (use_prepared)
-      hipLaunchKernelGGL(k_shade_gather_fold<true>, dim3((unsigned)((nbv + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
-                         acc, vertex_offsets, vertex_entries, B, V, T, dpositions);
-    else
-      hipLaunchKernelGGL(k_shade_gather_fold<false>, dim3((unsigned)((nbv + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
-                         acc, vertex_offsets, vertex_entries, B, V, T, dpositions);
+    // (a `prepared` block's rows are left dirty: it serves ONE backward call.  A gather that zeroes what it reads --
+    //  k_shade_gather_fold<true> -- would let a block serve any number of calls, but its scattered 4-byte stores
+    //  took the gather from 12.7 to 22.3 us; the host side falls back to this call's own setup kernel instead when
+    //  a retained graph is differentiated a second time.)
+    hipLaunchKernelGGL(k_shade_gather_fold<false>, dim3((unsigned)((nbv + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
+                       acc, vertex_offsets, vertex_entries, B, V, T, dpositions);
     return check_launch();
   }
   if (vertex_offsets && vertex_entries) {

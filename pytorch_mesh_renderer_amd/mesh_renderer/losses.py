@@ -53,5 +53,6 @@ def l1_loss(image, target):
         if record is not None:
             # image.detach(): the renderer's own node must not be part of this loss's graph (autograd
             # would run it on a materialised all-zero gradient image)
-            return FusedPhongL1Loss.apply(image.detach(), target, *record["inputs"], record["saved"])
+            return FusedPhongL1Loss.apply(image.detach(), target, *record["inputs"], record["saved"],
+                                          record.get("prepared_state"))
     return _MeanAbsError.apply(image, target)

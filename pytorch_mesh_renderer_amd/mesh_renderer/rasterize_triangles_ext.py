@@ -214,13 +214,17 @@ class FusedPhongRenderer(torch.autograd.Function):
             saved.append(amb)
         ctx.save_for_backward(*saved)
         ctx.has_ambient = amb is not None
+        # the prepared block serves ONE backward call (its accumulator rows are left dirty): a second backward over
+        # a retained graph -- through this node or through FusedPhongL1Loss, which shares this dict -- runs the
+        # backward's own setup kernel instead
+        ctx.prepared_state = {"used": prepared is None}
         if frames is not None:
             ctx.mark_non_differentiable(frames)
         return rgba, frames
 
     @staticmethod
     def _input_grads(saved, needs_transform_grad, needs_light_grads, upstream, l1_signs=None,
-                     needs_normal_grad=True, needs_diffuse_grad=True):
+                     needs_normal_grad=True, needs_diffuse_grad=True, prepared_state=None):
         """The shading backward on the tensors forward() saved -> gradients in the order of forward()'s
         tensor arguments (vertices, transforms, normals, diffuse, None, lights..., ambient).
         needs_light_grads: some of light_positions / light_intensities / ambient requires grad;
@@ -228,13 +232,16 @@ class FusedPhongRenderer(torch.autograd.Function):
         (clip, ids, bary, normals, verts, diffuse, triangles, lp, li, corner_records, offsets,
          entries, xf, prepared) = saved[:14]
         amb = saved[14] if len(saved) > 14 else None
+        use_prepared = prepared.numel() > 0 and prepared_state is not None and not prepared_state["used"]
+        if use_prepared:
+            prepared_state["used"] = True
         dclip, dn, dverts, dd, dlp, dli, damb = _native.shade_backward(
             upstream, ids, bary, clip, normals, verts, diffuse, triangles, lp, li, amb,
             corner_records=corner_records, adjacency=(offsets, entries), l1_signs=l1_signs, transforms=xf,
             want_light_grads=needs_light_grads, want_normal_grads=needs_normal_grad,
             want_diffuse_grads=needs_diffuse_grad,
             want_clip_grads=needs_transform_grad,   # d clip on its own only feeds d transforms below
-            prepared=prepared if prepared.numel() else None,
+            prepared=prepared if use_prepared else None,
             normalised_gbuffer=True)   # this function's own forward wrote ids / bary
         dxf = None
         if needs_transform_grad:  # d clip[b,v,r] / d xf[b,r,k] = (vertex, 1)[k]
@@ -247,7 +254,8 @@ class FusedPhongRenderer(torch.autograd.Function):
         grads = FusedPhongRenderer._input_grads(ctx.saved_tensors, ctx.needs_input_grad[1],
                                                 any(ctx.needs_input_grad[5:8]), drgba.contiguous(),
                                                 needs_normal_grad=ctx.needs_input_grad[2],
-                                                needs_diffuse_grad=ctx.needs_input_grad[3])
+                                                needs_diffuse_grad=ctx.needs_input_grad[3],
+                                                prepared_state=ctx.prepared_state)
         return grads + (None, None)
 
 
@@ -258,7 +266,8 @@ _fused_renders = weakref.WeakKeyDictionary()
 
 
 def remember_fused_render(node, inputs):
-    _fused_renders[node] = {"saved": tuple(node.saved_tensors), "inputs": inputs}
+    _fused_renders[node] = {"saved": tuple(node.saved_tensors), "inputs": inputs,
+                            "prepared_state": getattr(node, "prepared_state", None)}
 
 
 def take_fused_render(image):
@@ -285,9 +294,10 @@ class FusedPhongL1Loss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, image, target, vertices, transforms, normals, diffuse, light_positions,
-                light_intensities, ambient, render_saved):
+                light_intensities, ambient, render_saved, prepared_state=None):
         loss, signs = _native.l1_loss_forward(image.detach(), target.detach(), want_signs=True)
         ctx.image_shape = image.shape
+        ctx.prepared_state = prepared_state
         # the renderer's own saved tensors (G-buffer, corner records, adjacency, ...): held here too,
         # because the renderer's node frees its copies as soon as the image tensor is dropped
         ctx.save_for_backward(signs, *render_saved)
@@ -299,11 +309,12 @@ class FusedPhongL1Loss(torch.autograd.Function):
         upstream = grad.to(torch.float32).reshape(1)
         dverts, dxf, dn, dd, _, dlp, dli, damb = FusedPhongRenderer._input_grads(
             ctx.saved_tensors[1:], ctx.needs_input_grad[3], any(ctx.needs_input_grad[6:9]), upstream,
-            l1_signs=signs, needs_normal_grad=ctx.needs_input_grad[4], needs_diffuse_grad=ctx.needs_input_grad[5])
+            l1_signs=signs, needs_normal_grad=ctx.needs_input_grad[4], needs_diffuse_grad=ctx.needs_input_grad[5],
+            prepared_state=ctx.prepared_state)
         dtarget = None
         if ctx.needs_input_grad[1]:
             dtarget = -_native.l1_loss_backward(signs, ctx.image_shape, upstream)
-        return None, dtarget, dverts, dxf, dn, dd, dlp, dli, damb, None
+        return None, dtarget, dverts, dxf, dn, dd, dlp, dli, damb, None, None
 
 
 class FusedSpecularPhongRenderer(torch.autograd.Function):
