@@ -42,7 +42,11 @@ def l1_loss(image, target):
     (rasterize_triangles_ext.FusedPhongL1Loss).  That route never forms d loss / d image, so it is
     taken only while nothing observes that gradient -- no image.retain_grad(), no hook on the image
     -- and once per rendered image; torch.autograd.grad(loss, image) needs the generic op
-    (USE_FUSED_RENDER_LOSS = False, or any op between render() and the loss)."""
+    (USE_FUSED_RENDER_LOSS = False, or any op between render() and the loss).
+
+    ORDERING: whether the image's gradient is observed is decided when this function is CALLED.  A hook or
+    retain_grad() put on `image` AFTER the loss was built never fires / never fills image.grad (the fused
+    backward differentiates image.detach()); register them before calling l1_loss, or switch the fused route off."""
     if image.shape != target.shape:
         raise ValueError("image and target must have the same shape")
     if image.dtype != torch.float32 or target.dtype != torch.float32:

@@ -148,7 +148,13 @@ def _fused_path_applies(vertices, normals, diffuse_colors, light_positions, spec
     """The fused HIP shading kernels cover Phong shading on float32 inputs of matching [B,V,3] shape
     with 1..32 lights: ambient + diffuse, and the specular term (per-image or per-vertex shininess;
     four lights per pass, rasterize_triangles_ext.FusedSpecularPhongRenderer); everything else takes
-    the composed path."""
+    the composed path.
+
+    COST beyond four lights: the diffuse forward and the vertex-side backward loop over any light count in one
+    pass, but light GRADIENTS are formed four lights at a time -- 1 + ceil(L / 4) passes over the G-buffer --
+    and the specular kernels render / differentiate the lights in groups of four (ceil(L / 4) forward passes,
+    as many backward ones, their images / gradients added with torch ops): 32 lights with every gradient cost
+    about 8 times the pixel work of 4."""
     from .. import _native
     limit = _native.shade_max_lights()
     return (USE_FUSED_SHADING and vertices.dtype == torch.float32 and normals.shape == vertices.shape and

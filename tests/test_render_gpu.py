@@ -1382,6 +1382,30 @@ def test_fused_render_loss_keeps_autograd_semantics_of_the_image(device):
     mesh_renderer.losses.l1_loss(img, target).backward()
     assert len(seen) == 1 and seen[0] > 0
     np.testing.assert_allclose(v2.grad.cpu().numpy(), v0.grad.cpu().numpy(), rtol=2e-4, atol=1e-9)
+    # the decision is taken when l1_loss() is CALLED.  A hook (or retain_grad) put on the image AFTER the
+    # loss was built observes nothing -- the fused route differentiates image.detach() -- which is the documented
+    # ordering requirement (losses.l1_loss); the vertex gradient is unaffected.  To observe d loss / d image, register
+    # before building the loss (above) or set losses.USE_FUSED_RENDER_LOSS = False.
+    v2b = leaf()
+    img = render(v2b)
+    loss = mesh_renderer.losses.l1_loss(img, target)
+    late = []
+    img.register_hook(lambda g: late.append(1))
+    img.retain_grad()
+    loss.backward()
+    assert late == [] and img.grad is None
+    np.testing.assert_allclose(v2b.grad.cpu().numpy(), v0.grad.cpu().numpy(), rtol=2e-4, atol=1e-9)
+    before = mesh_renderer.losses.USE_FUSED_RENDER_LOSS
+    mesh_renderer.losses.USE_FUSED_RENDER_LOSS = False
+    try:
+        v2c = leaf()
+        img = render(v2c)
+        loss = mesh_renderer.losses.l1_loss(img, target)
+        img.register_hook(lambda g: late.append(2))
+        loss.backward()
+        assert late == [2]
+    finally:
+        mesh_renderer.losses.USE_FUSED_RENDER_LOSS = before
     # torch.autograd.grad w.r.t. the image: generic route on request
     v3 = leaf()
     img = render(v3)
