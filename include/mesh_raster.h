@@ -109,6 +109,10 @@ int mr_interpolate_backward(const float *dout, const int32_t *ids,
  *                                   both are written completely, no pre-zeroing needed
  *   corner_records  NULL, or the `records` buffer mr_interpolate_forward_records filled for the
  *                   SAME inputs: reused instead of rebuilt
+ *   gbuffer_flags   MR_GBUFFER_NORMALISED (see mr_shade_backward): ids / bary are the rasterizer's own
+ *                   output for these vertices -- alpha is exactly 1 on every covered pixel, so up to 12
+ *                   attributes the pixel pass keeps the 3 A + 9 products in registers down each lane's
+ *                   vertical run over difference-basis records (round 4); 0: any G-buffer, general kernels
  * mr_interpolate_forward_records is mr_interpolate_forward for 1 <= A <= that maximum, through
  * per-(image, triangle) corner records (two dependent load levels instead of three; `records`:
  * mr_interpolate_records_bytes(B, T, A) bytes, 256-byte aligned, caller-owned). */
@@ -138,8 +142,8 @@ int mr_interpolate_raster_backward(const float *dout, const int32_t *ids, const 
                                    const int32_t *triangles, const float *background,
                                    const int32_t *vertex_offsets, const int32_t *vertex_entries,
                                    const void *corner_records, int B, int V, int T, int W, int H,
-                                   int A, float *dattributes, float *dclip, void *workspace,
-                                   size_t workspace_bytes, void *stream);
+                                   int A, float *dattributes, float *dclip, int gbuffer_flags,
+                                   void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- fused deferred shading (diffuse + ambient Phong) ---------------------------
  * Replaces, for render() without specular terms, attribute interpolation

@@ -200,7 +200,7 @@ def lib():
         L.mr_interpolate_forward_records.restype = ci
         L.mr_rasterize_interpolate_forward.argtypes = [vp] * 4 + [ci] * 6 + [vp] * 5 + [sz, vp, sz, vp]
         L.mr_rasterize_interpolate_forward.restype = ci
-        L.mr_interpolate_raster_backward.argtypes = [vp] * 10 + [ci] * 6 + [vp, vp, vp, sz, vp]
+        L.mr_interpolate_raster_backward.argtypes = [vp] * 10 + [ci] * 6 + [vp, vp, ci, vp, sz, vp]
         L.mr_interpolate_raster_backward.restype = ci
         L.mr_vertex_transform.argtypes = [vp, vp, ci, ci, vp, vp]
         L.mr_vertex_transform.restype = ci
@@ -595,7 +595,7 @@ def rasterize_interpolate_forward(clip, attrs, triangles, background, width, hei
 
 
 def interpolate_raster_backward(dout, ids, bary, clip, attrs, triangles, background, adjacency,
-                                corner_records=None):
+                                corner_records=None, normalised_gbuffer=False):
     """One-pass backward of interpolation + rasterization -> (dattributes [B,V,A], dclip [B,V,4])."""
     tensors = [dout, ids, bary, clip, attrs, triangles, background, adjacency[0], adjacency[1]]
     B, V, _ = _chk_mesh(clip, triangles)
@@ -620,7 +620,7 @@ def interpolate_raster_backward(dout, ids, bary, clip, attrs, triangles, backgro
         rc = L.mr_interpolate_raster_backward(
             _ptr(dout), _ptr(ids), _ptr(bary), _ptr(clip), _ptr(attrs), _ptr(triangles), _ptr(background),
             _ptr(offsets), _ptr(entries), _ptr(corner_records), B, V, T, W, H, A, _ptr(dattrs), _ptr(dclip),
-            _ptr(ws), have, _stream(dev))
+            GBUFFER_NORMALISED if normalised_gbuffer else 0, _ptr(ws), have, _stream(dev))
     _check(rc, "mr_interpolate_raster_backward")
     return dattrs, dclip
 

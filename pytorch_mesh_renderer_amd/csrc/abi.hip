@@ -197,9 +197,10 @@ int mr_interpolate_raster_backward(const float *dout, const int32_t *ids, const 
                                    const int32_t *triangles, const float *background,
                                    const int32_t *vertex_offsets, const int32_t *vertex_entries,
                                    const void *corner_records, int B, int V, int T, int W, int H, int A,
-                                   float *dattributes, float *dclip, void *workspace,
+                                   float *dattributes, float *dclip, int gbuffer_flags, void *workspace,
                                    size_t workspace_bytes, void *stream) {
-  if (bad_dims(B, V, T, W, H) || A < 0 || A > mr::interp_raster_max_attrs()) return MR_EINVAL;
+  if (bad_dims(B, V, T, W, H) || A < 0 || A > mr::interp_raster_max_attrs() || (gbuffer_flags & ~MR_GBUFFER_NORMALISED))
+    return MR_EINVAL;
   if (B == 0 || V == 0) return MR_OK;
   if (!dclip || (A > 0 && !dattributes)) return MR_EINVAL;
   if (((uintptr_t)dclip & 15u) != 0) return MR_EINVAL;
@@ -213,7 +214,7 @@ int mr_interpolate_raster_backward(const float *dout, const int32_t *ids, const 
   if (((uintptr_t)corner_records & 15u) != 0) return MR_EINVAL;
   return mr::launch_interp_raster_backward(dout, ids, bary, clip, attributes, triangles, background,
                                            vertex_offsets, vertex_entries, corner_records, B, V, T, W, H, A,
-                                           dattributes, dclip, workspace, (hipStream_t)stream);
+                                           dattributes, dclip, gbuffer_flags, workspace, (hipStream_t)stream);
 }
 
 int mr_shade_max_lights(void) { return mr::shade_max_lights(); }

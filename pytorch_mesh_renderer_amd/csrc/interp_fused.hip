@@ -248,6 +248,135 @@ struct AttrLaneFn : AttrRowsFn<AP> {
   }
 };
 
+// ---------------------------------------------------------------------------------------------------------
+// Round 4: the backward for a G-buffer the caller declares NORMALISED (MR_GBUFFER_NORMALISED: ids / bary are what
+// mr_rasterize_forward / mr_rasterize_interpolate_forward wrote for these vertices -- rasterize() always).
+// Every covered pixel's barycentrics sum to 1 within rounding, so alpha = clamp(2 sum b) is exactly 1 and lies
+// outside the clamp's pass band: out = value, d value = dout, nothing flows through alpha (no `value`, no
+// d alpha: 5 AP vector instructions per pixel gone).  The gradient through the barycentrics enters the
+// rasterizer's backward only through differences (its brackets sum to ~0 over the corners, see ShadeFoldLaneFn
+// in shade.hip), so the record holds the attributes as e0 = c0 - c2, e1 = c1 - c2 and two adjugate rows:
+//   g0 = dout . e0, g1 = dout . e1;  q_c = (g0 (s_c b0 - u_0c) + g1 (s_c b1 - u_1c)) / |det|
+//   sums: b_k dout[a] (3 A) and b_k q_c (9), kept in registers down the lane's vertical run (k_accumulate_lanes).
+// Templated on the EXACT attribute count (A = 9 is 36 sums, not the 45 of its padded width).
+constexpr int fold_rec_floats(int AP) { return 2 * AP + 12; }   // e0[AP] e1[AP] | u0[3] u1[3] s[3] 1/|det| - -
+
+template <int AP>
+__global__ __launch_bounds__(kThreads) void k_attr_fold_setup(const float *__restrict__ corners,
+                                                              const BwdRec *__restrict__ recs, long nbt,
+                                                              float *__restrict__ out) {
+  const long gid = (long)blockIdx.x * kThreads + threadIdx.x;
+  if (gid >= nbt) return;
+  const float4 *src = (const float4 *)(corners + gid * (3 * AP));
+  float c[3 * AP];
+#pragma unroll
+  for (int q = 0; q < 3 * AP / 4; ++q) {
+    const float4 f = src[q];
+    c[4 * q] = f.x; c[4 * q + 1] = f.y; c[4 * q + 2] = f.z; c[4 * q + 3] = f.w;
+  }
+  const BwdRec r = recs[gid];
+  float v[fold_rec_floats(AP)];
+#pragma unroll
+  for (int a = 0; a < AP; ++a) {
+    v[a] = c[a] - c[2 * AP + a];
+    v[AP + a] = c[AP + a] - c[2 * AP + a];
+  }
+  float *t = v + 2 * AP;
+  t[0] = r.a.x; t[1] = r.a.y; t[2] = r.a.z;          // adjugate row of corner 0 (clip components x, y, w)
+  t[3] = r.a.w; t[4] = r.b.x; t[5] = r.b.y;          // ... of corner 1
+  t[6] = r.c.y; t[7] = r.c.z; t[8] = r.c.w;          // column sums
+  t[9] = r.d.x; t[10] = 0.f; t[11] = 0.f;            // 1 / |det|
+  float4 *dst = (float4 *)(out + gid * fold_rec_floats(AP));
+#pragma unroll
+  for (int q = 0; q < fold_rec_floats(AP) / 4; ++q) dst[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+}
+
+template <int A>
+struct AttrFoldLaneFn {
+  static constexpr int AP = A <= 4 ? 4 : (A <= 8 ? 8 : (A <= 12 ? 12 : 16));
+  static constexpr int kN = 3 * A + 9;
+  static constexpr int kStride = AttrRowsFn<AP>::kStride;   // the gather reads rows of the padded layout
+  static constexpr int kLaneRowsPerWave = 8;
+  static constexpr int kMinWavesPerSimd = kN <= 21 ? 5 : (kN <= 36 ? 4 : 3);
+  static constexpr bool kCountBackground = false;
+  const float *__restrict__ dout;       // [B,H,W,A]
+  const int32_t *__restrict__ ids;
+  const F3 *__restrict__ bary;
+  const float *__restrict__ fold;       // [B,T,fold_rec_floats(AP)]
+  int T_, W, H;
+
+  struct Pixel { F3 b; float g[A]; };
+  struct Raw { F3 b; int t; float g[A]; };
+  struct Triangle { float e0[A], e1[A], u0[3], u1[3], s[3], inv; };
+  struct Image { int n_bg; };
+  // sum o < 3 A: corner o / A, attribute o % A -> row column corner * AP + attribute; then the nine clip sums
+  __device__ static int column(int o) { return o < 3 * A ? (o / A) * AP + o % A : 3 * AP + (o - 3 * A); }
+  __device__ __forceinline__ void begin_image(int, Image &) const {}
+  __device__ __forceinline__ void end_strip(int, int, Image &) const {}
+  __device__ __forceinline__ void fetch(int img, int x, int y, size_t, Raw &r) const {
+    // wave-uniform image bases + 32-bit offsets (W * H * A * 4 < 2^31 is checked by the launcher)
+    const size_t img_px = (size_t)img * H * W;
+    const unsigned pix = (unsigned)(y * W) + (unsigned)x;
+    r.b = *(const F3 *)((const char *)(bary + img_px) + pix * 12u);
+    r.t = *(const int32_t *)((const char *)(ids + img_px) + pix * 4u);
+    const float *g = (const float *)((const char *)(dout + img_px * A) + pix * (unsigned)(A * 4));
+#pragma unroll
+    for (int a = 0; a < A; ++a) r.g[a] = g[a];
+  }
+  __device__ __forceinline__ bool prepare(const Raw &r, int T, int &tri, Pixel &p) const {
+    const float pre = (2.0f * r.b.x + 2.0f * r.b.y) + 2.0f * r.b.z;
+    if (!(pre > 0.0f)) return false;   // uncovered: alpha = 0, nothing reaches the attributes or the vertices
+    if ((unsigned)r.t >= (unsigned)T) return false;
+    p.b = r.b;
+#pragma unroll
+    for (int a = 0; a < A; ++a) p.g[a] = r.g[a];
+    tri = r.t;
+    return true;
+  }
+  __device__ __forceinline__ void load_triangle(int img, int tri, Triangle &t) const {
+    const float4 *src = (const float4 *)(fold + ((size_t)img * T_ + tri) * fold_rec_floats(AP));
+    float v[fold_rec_floats(AP)];
+#pragma unroll
+    for (int q = 0; q < fold_rec_floats(AP) / 4; ++q) {
+      if (4 * q >= A && 4 * q < AP) continue;               // padding of e0
+      if (4 * q >= AP + A && 4 * q < 2 * AP) continue;      // padding of e1
+      const float4 f = src[q];
+      v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w;
+    }
+#pragma unroll
+    for (int a = 0; a < A; ++a) { t.e0[a] = v[a]; t.e1[a] = v[AP + a]; }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { t.u0[c] = v[2 * AP + c]; t.u1[c] = v[2 * AP + 3 + c]; t.s[c] = v[2 * AP + 6 + c]; }
+    t.inv = v[2 * AP + 9];
+  }
+  __device__ __forceinline__ void accumulate(const Pixel &p, const Triangle &t, float (&acc)[kN], Image &) const {
+    float g0 = 0.f, g1 = 0.f;
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+      g0 = fmaf(p.g[a], t.e0[a], g0);
+      g1 = fmaf(p.g[a], t.e1[a], g1);
+    }
+    float q[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float w0 = t.s[c] * p.b.x - t.u0[c];
+      const float w1 = t.s[c] * p.b.y - t.u1[c];
+      q[c] = (g0 * w0 + g1 * w1) * t.inv;
+    }
+    const float b[3] = {p.b.x, p.b.y, p.b.z};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+      for (int a = 0; a < A; ++a) acc[k * A + a] = fmaf(b[k], p.g[a], acc[k * A + a]);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) acc[3 * A + k * 3 + c] = fmaf(b[k], q[c], acc[3 * A + k * 3 + c]);
+    }
+  }
+};
+#ifndef MR_ATTR_FOLD_MAX_A
+#define MR_ATTR_FOLD_MAX_A 12   // wider: the rows kernel
+#endif
+
 // One thread per (image, vertex): sums the rows of the triangles incident to its vertex (CSR
 // adjacency: entry = 3 * triangle + corner).  Every output is written exactly once, no atomics.
 // DET (mr_set_deterministic): the rows hold 64-bit fixed-point sums (run_accum.h), converted here.
@@ -319,7 +448,7 @@ template <int AP>
 int run(const float *dout, const int32_t *ids, const float *bary, const float *clip, const float *attrs,
         const int32_t *tris, const float *bg, const int32_t *offsets, const int32_t *entries,
         const float *corner_records, int B, int V, int T, int W, int H, int A, float *dattrs, float *dclip,
-        void *ws, hipStream_t s) {
+        int gbuffer_flags, void *ws, hipStream_t s) {
   char *p = (char *)ws;
   float *acc = (float *)p;
   p += acc_bytes(B, T, AP);
@@ -328,6 +457,8 @@ int run(const float *dout, const int32_t *ids, const float *bary, const float *c
   float *corners = (float *)p;
   p += corner_bytes(B, T, AP);
   float *det_block = (float *)p;
+  p += kDetBlockBytes;
+  float *fold_recs = (float *)p;
   const bool det = g_deterministic != 0;
   if (hipMemsetAsync(acc, 0, (size_t)B * T * AttrRowsFn<AP>::kStride * (det ? sizeof(long long) : sizeof(float)), s) !=
       hipSuccess)
@@ -342,6 +473,28 @@ int run(const float *dout, const int32_t *ids, const float *bary, const float *c
     rc = setup_records<AP>(attrs, tris, B, V, T, A, corners, s);
     if (rc != MR_OK) return rc;
   }
+  // a normalised G-buffer (rasterize()'s own): the folded lane kernel, templated on the exact attribute count
+  const bool folded = (gbuffer_flags & MR_GBUFFER_NORMALISED) != 0 && !det && g_shade_backward_kernel != 1 &&
+                      A <= MR_ATTR_FOLD_MAX_A && (size_t)W * H * A * sizeof(float) < (size_t)1 << 31;
+  if (folded) {
+    const long nbt = (long)B * T;
+    hipLaunchKernelGGL(k_attr_fold_setup<AP>, dim3((unsigned)((nbt + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, corners,
+                       recs, nbt, fold_recs);
+    if ((rc = check_launch()) != MR_OK) return rc;
+    auto go = [&](auto tag) {
+      constexpr int kA = decltype(tag)::value;
+      if constexpr (kA >= 1 && kA <= MR_ATTR_FOLD_MAX_A && (kA + 3) / 4 * 4 == AP) {
+        AttrFoldLaneFn<kA> fn{dout, ids, (const F3 *)bary, fold_recs, T, W, H};
+        rc = launch_accumulate_lanes(fn, B, T, W, H, acc, s);
+      }
+    };
+    switch (A - (AP - 4)) {   // A = AP - 3 .. AP
+      case 1: go(std::integral_constant<int, AP - 3>{}); break;
+      case 2: go(std::integral_constant<int, AP - 2>{}); break;
+      case 3: go(std::integral_constant<int, AP - 1>{}); break;
+      default: go(std::integral_constant<int, AP>{}); break;
+    }
+  } else
   if constexpr (AP <= MR_ATTR_LANES_MAX_AP) {
     if (!det && g_shade_backward_kernel != 1) {   // (debug switch: 1 = rows kernel)
       AttrLaneFn<AP> fn{{dout, ids, (const F3 *)bary, corners, recs, bg, A, T}};
@@ -373,7 +526,8 @@ int interp_raster_max_attrs() { return 16; }
 size_t interp_raster_backward_ws(int B, int V, int T, int W, int H, int A) {
   (void)V; (void)W; (void)H;
   const int AP = padded_attrs(A);
-  return acc_bytes(B, T, AP) + align_up((size_t)B * T * sizeof(BwdRec), 256) + corner_bytes(B, T, AP) + kDetBlockBytes;
+  return acc_bytes(B, T, AP) + align_up((size_t)B * T * sizeof(BwdRec), 256) + corner_bytes(B, T, AP) + kDetBlockBytes +
+         align_up((size_t)B * T * fold_rec_floats(AP) * sizeof(float), 256);   // last: the folded kernel's records
 }
 
 size_t interp_records_bytes(int B, int T, int A) { return corner_bytes(B, T, padded_attrs(A)); }
@@ -408,7 +562,7 @@ int launch_interp_raster_backward(const float *dout, const int32_t *ids, const f
                                   const float *attrs, const int32_t *tris, const float *bg,
                                   const int32_t *offsets, const int32_t *entries, const void *corner_records,
                                   int B, int V, int T, int W, int H, int A, float *dattrs, float *dclip,
-                                  void *ws, hipStream_t s) {
+                                  int gbuffer_flags, void *ws, hipStream_t s) {
   if (B == 0 || V == 0) return MR_OK;
   if (T == 0 || (size_t)W * H == 0 || A == 0) {  // nothing contributes: the outputs are zeros
     if ((size_t)A > 0 && hipMemsetAsync(dattrs, 0, (size_t)B * V * A * sizeof(float), s) != hipSuccess)
@@ -418,10 +572,10 @@ int launch_interp_raster_backward(const float *dout, const int32_t *ids, const f
   }
   const float *cr = (const float *)corner_records;
   switch (padded_attrs(A)) {
-    case 4: return run<4>(dout, ids, bary, clip, attrs, tris, bg, offsets, entries, cr, B, V, T, W, H, A, dattrs, dclip, ws, s);
-    case 8: return run<8>(dout, ids, bary, clip, attrs, tris, bg, offsets, entries, cr, B, V, T, W, H, A, dattrs, dclip, ws, s);
-    case 12: return run<12>(dout, ids, bary, clip, attrs, tris, bg, offsets, entries, cr, B, V, T, W, H, A, dattrs, dclip, ws, s);
-    default: return run<16>(dout, ids, bary, clip, attrs, tris, bg, offsets, entries, cr, B, V, T, W, H, A, dattrs, dclip, ws, s);
+    case 4: return run<4>(dout, ids, bary, clip, attrs, tris, bg, offsets, entries, cr, B, V, T, W, H, A, dattrs, dclip, gbuffer_flags, ws, s);
+    case 8: return run<8>(dout, ids, bary, clip, attrs, tris, bg, offsets, entries, cr, B, V, T, W, H, A, dattrs, dclip, gbuffer_flags, ws, s);
+    case 12: return run<12>(dout, ids, bary, clip, attrs, tris, bg, offsets, entries, cr, B, V, T, W, H, A, dattrs, dclip, gbuffer_flags, ws, s);
+    default: return run<16>(dout, ids, bary, clip, attrs, tris, bg, offsets, entries, cr, B, V, T, W, H, A, dattrs, dclip, gbuffer_flags, ws, s);
   }
 }
 

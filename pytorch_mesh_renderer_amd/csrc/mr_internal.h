@@ -138,7 +138,7 @@ int launch_interp_raster_backward(const float *dout, const int32_t *ids, const f
                                   const float *attrs, const int32_t *tris, const float *bg,
                                   const int32_t *offsets, const int32_t *entries, const void *corner_records,
                                   int B, int V, int T, int W, int H, int A, float *dattrs, float *dclip,
-                                  void *ws, hipStream_t s);
+                                  int gbuffer_flags, void *ws, hipStream_t s);
 int launch_vertex_transform(const float *vertices, const float *transforms, int B, int V, float *clip,
                             hipStream_t s);
 int launch_attr_records(const float *attrs, const int32_t *tris, int B, int V, int T, int A, void *records, hipStream_t s);

@@ -109,7 +109,8 @@ class FusedAttributeRasterizer(torch.autograd.Function):
         dout = dout.contiguous()
         dattrs, dclip = _native.interpolate_raster_backward(dout, ids, bary, clip, attributes, triangles,
                                                             background, (offsets, entries),
-                                                            corner_records=records)
+                                                            corner_records=records,
+                                                            normalised_gbuffer=True)   # forward() above wrote ids / bary
         dbackground = None
         if ctx.needs_input_grad[3]:
             # d/d background = sum over pixels of (1 - alpha) * dout  (rasterize.py:149-150)
