@@ -565,6 +565,81 @@ struct ShadeFoldLaneFn : ShadeGradFn<L, SIGNS, false> {
   }
 };
 
+// The same difference-basis pixel pass for the other gradients a caller may want next to the vertices' (round 4):
+// GROUPS selects the attribute groups (bit 0 normals, bit 1 positions, bit 2 diffuse colours) exactly as in
+// ShadeLaneFn, FOLD the clip-space pull-back (dclip == nullptr with transforms; needs the position group).  Rows of
+// acc keep ShadeGradFn's 36-float layout (the generic gather reads them): 9 sums per selected group, + 9 clip
+// sums unless folded.  Needs the G-buffer normalised (alpha = 1) and no light gradients.
+template <int L, bool SIGNS, int GROUPS, bool FOLD>
+struct ShadeDiffLaneFn : ShadeGradFn<L, SIGNS, false> {
+  using Base = ShadeGradFn<L, SIGNS, false>;
+  static_assert(GROUPS >= 1 && GROUPS < 8 && (!FOLD || (GROUPS & 2)), "attribute groups: normals | positions | diffuse");
+  static constexpr int kGroups = (GROUPS & 1) + ((GROUPS >> 1) & 1) + ((GROUPS >> 2) & 1);
+  static constexpr int kN = 9 * kGroups + (FOLD ? 0 : 9);
+  static constexpr int kStride = 36;
+  static constexpr int kLaneRowsPerWave = kN <= 18 ? MR_FOLD_LANE_ROWS : MR_LANE_ROWS;
+  static constexpr int kMinWavesPerSimd = kN > 27 ? 3 : MR_LANE_WAVES;
+  const FoldRec *__restrict__ fold_recs;
+  using Triangle = FoldTriangle;
+  __host__ __device__ static constexpr int group(int gi) {
+    int g = 0;
+    for (int seen = 0; g < 3; ++g) {
+      if ((GROUPS >> g) & 1) {
+        if (seen == gi) break;
+        ++seen;
+      }
+    }
+    return g;
+  }
+  __device__ static int column(int o) {
+    if (o >= 9 * kGroups) return 27 + (o - 9 * kGroups);
+    const int gi = o / 9, k = (o % 9) / 3, c = o % 3;
+    const int g = gi == 0 ? group(0) : gi == 1 ? group(1) : group(2);
+    return k * 9 + g * 3 + c;
+  }
+  __device__ __forceinline__ void load_triangle(int img, int tri, Triangle &t) const {
+    load_fold_triangle(fold_recs + (size_t)img * this->T_ + tri, t);
+  }
+  __device__ __forceinline__ void accumulate(const typename Base::Pixel &p, const Triangle &t, float (&a)[kN],
+                                             typename Base::Image &im) const {
+    float at[9], dat[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) at[k] = fmaf(p.b.x, t.e0[k], fmaf(p.b.y, t.e1[k], t.c2[k]));
+    Base::attribute_gradients(at, p.g, im, dat);
+    float g0 = 0.f, g1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      g0 = fmaf(dat[k], t.e0[k], g0);
+      g1 = fmaf(dat[k], t.e1[k], g1);
+    }
+    float q[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float w0 = t.s[c] * p.b.x - t.u0[c];
+      const float w1 = t.s[c] * p.b.y - t.u1[c];
+      q[c] = (g0 * w0 + g1 * w1) * t.inv;
+    }
+    if (FOLD) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        dat[3 + c] += (im.pull[0][c] * q[0] + im.pull[1][c] * q[1]) + im.pull[2][c] * q[2];
+    }
+    const float b[3] = {p.b.x, p.b.y, p.b.z};
+#pragma unroll
+    for (int gi = 0; gi < kGroups; ++gi)
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a[(gi * 3 + k) * 3 + c] = fmaf(b[k], dat[group(gi) * 3 + c], a[(gi * 3 + k) * 3 + c]);
+    if (!FOLD) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a[9 * kGroups + k * 3 + c] = fmaf(b[k], q[c], a[9 * kGroups + k * 3 + c]);
+    }
+  }
+};
+
 __global__ __launch_bounds__(kThreads) void k_shade_scatter(
     const float *__restrict__ acc, const int32_t *__restrict__ tris, int B, int V, int T,
     float *__restrict__ dnormals, float *__restrict__ dpositions, float *__restrict__ ddiffuse,
@@ -837,8 +912,12 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
   // dclip == nullptr (with transforms): the caller wants the gradient of the world-space positions only.  Where
   // the lane kernel has the variant, the pull-back through the transforms is folded into the pixel pass
   // (ShadeLaneFn<..., FOLD>) and no clip-space sums exist at all; elsewhere the clip gradient goes to scratch.
-  const bool fold = !dclip && transforms && MR_SHADE_LANES_FOLD && !light_grads && !det && !dnormals && !ddiffuse &&
-                    (gbuffer_flags & MR_GBUFFER_NORMALISED) != 0 && g_shade_backward_kernel != 1 && T > 0 && V > 0;
+  const int groups_wanted = (dnormals ? 1 : 0) | 2 | (ddiffuse ? 4 : 0);   // (6 -- positions + diffuse -- has no lane kernel)
+  const bool fold_any = !dclip && transforms && MR_SHADE_LANES_FOLD && !light_grads && !det && groups_wanted != 6 &&
+                        (gbuffer_flags & MR_GBUFFER_NORMALISED) != 0 && g_shade_backward_kernel != 1 && T > 0 && V > 0 &&
+                        (corner_records != nullptr || prepared != nullptr) && MR_SHADE_FOLD_DIFF;   // (any attribute groups)
+  const bool fold = fold_any || (!dclip && transforms && MR_SHADE_LANES_FOLD && !light_grads && !det && !dnormals && !ddiffuse &&
+                    (gbuffer_flags & MR_GBUFFER_NORMALISED) != 0 && g_shade_backward_kernel != 1 && T > 0 && V > 0);
   if (!dclip && !fold)
     dclip = (float *)((char *)ws + shade_backward_ws(B, V, T, W, H) - align_up((size_t)B * V * 4 * sizeof(float), 256));
   const float sign_inv_n = 1.0f / (float)((size_t)B * H * W * 4);  // the L1 mean runs over the whole image
@@ -871,10 +950,16 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
   int *max_bits = (int *)(det_scale + 4);
   float *light_rows = (float *)((char *)det_scale + kDetMiscBytes);
   FoldRec *fold_recs = (FoldRec *)((char *)light_rows + light_rows_bytes(B, W, H));
-  const bool fold_diff = fold && MR_SHADE_FOLD_DIFF && (corner_records != nullptr || prepared != nullptr);
+  const bool fold_diff = fold && MR_SHADE_FOLD_DIFF && (corner_records != nullptr || prepared != nullptr) && !dnormals && !ddiffuse;
+  // the difference-basis pixel pass for every other lane-kernel case on a normalised G-buffer (no light gradients):
+  // normals / diffuse wanted, and / or the clip-space gradient wanted on its own
+  const bool diff_general = !fold_diff && MR_SHADE_FOLD_DIFF && corner_records != nullptr && !light_grads && !det &&
+                            (gbuffer_flags & MR_GBUFFER_NORMALISED) != 0 && g_shade_backward_kernel != 1 &&
+                            vertex_offsets && vertex_entries && T > 0 && V > 0 && groups_wanted != 6;
   // `prepared` (mr_render_forward's backward_prepared: FoldRec[B*T] + cleared compact accumulator rows): the folded
   // kernel's setup launch is skipped, and the gather leaves the rows cleared again for the next backward call
   const bool use_prepared = fold_diff && prepared != nullptr && MR_SHADE_USE_PREPARED;
+  if (fold && !fold_diff && !diff_general && !dclip) return MR_EINVAL;   // (cannot happen: every folding path is one of the two)
   if (use_prepared) {
     fold_recs = (FoldRec *)prepared;
     acc = (float *)((char *)prepared + fold_prepared_recs_bytes(B, T));
@@ -897,8 +982,8 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
   if (use_prepared) rc = MR_OK;
   else
   rc = fused_clear ? launch_bwd_setup(clip, tris, B, V, T, recs, s, acc, (fold_diff ? kFoldAccStride : 36) * sizeof(float), light_grads,
-                                      light_grads ? B * (L * 6 + 3) : 0, fold_diff ? corner_records : nullptr,
-                                      fold_diff ? fold_recs : nullptr)
+                                      light_grads ? B * (L * 6 + 3) : 0, (fold_diff || diff_general) ? corner_records : nullptr,
+                                      (fold_diff || diff_general) ? fold_recs : nullptr)
                    : launch_bwd_setup(clip, tris, B, V, T, recs, s);
   if (rc != MR_OK) return rc;
   if (corner_records) {  // the forward's records (same inputs): skip the gather
@@ -983,7 +1068,37 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
 #define MR_SHADE_LANES_GL(NL)                                                                   \
   if (groups == 2) MR_SHADE_LANES_LIGHTS(NL, 2) else MR_SHADE_LANES_LIGHTS(NL, 3)
 #endif
-  if (use_lanes) {
+  if (diff_general && use_lanes) {
+    const bool folded = dclip == nullptr;   // (implies transforms)
+#define MR_SHADE_DIFF(NL, G, F)                                                                 \
+  {                                                                                             \
+    KernelTimer timer(MR_TIMER_SHADE_BACKWARD, s);                                              \
+    if (signs) {                                                                                \
+      ShadeDiffLaneFn<NL, true, G, F> fn{{nullptr, signs, sign_upstream, sign_inv_n, ids, (const F3 *)bary, corners, recs, \
+                                          lights, nullptr, T, W, H, transforms}, fold_recs};    \
+      rc = launch_accumulate_lanes(fn, B, T, W, H, acc, s);                                     \
+    } else {                                                                                    \
+      ShadeDiffLaneFn<NL, false, G, F> fn{{(const float4 *)drgba, nullptr, nullptr, 0.0f, ids, (const F3 *)bary, corners,  \
+                                           recs, lights, nullptr, T, W, H, transforms}, fold_recs};                         \
+      rc = launch_accumulate_lanes(fn, B, T, W, H, acc, s);                                     \
+    }                                                                                           \
+  }
+#define MR_SHADE_DIFF_G(NL)                                                                     \
+  if (folded) {                                                                                 \
+    if (groups == 2) MR_SHADE_DIFF(NL, 2, true) else if (groups == 3) MR_SHADE_DIFF(NL, 3, true) else MR_SHADE_DIFF(NL, 7, true) \
+  } else {                                                                                      \
+    if (groups == 2) MR_SHADE_DIFF(NL, 2, false) else if (groups == 3) MR_SHADE_DIFF(NL, 3, false) else MR_SHADE_DIFF(NL, 7, false) \
+  }
+    switch (L) {
+      case 1: MR_SHADE_DIFF_G(1); break;
+      case 2: MR_SHADE_DIFF_G(2); break;
+      case 3: MR_SHADE_DIFF_G(3); break;
+      case 4: MR_SHADE_DIFF_G(4); break;
+      default: MR_SHADE_DIFF_G(0); break;
+    }
+#undef MR_SHADE_DIFF_G
+#undef MR_SHADE_DIFF
+  } else if (use_lanes) {
     switch (L) {
       case 1: MR_SHADE_LANES_GL(1); break;
       case 2: MR_SHADE_LANES_GL(2); break;

@@ -28,17 +28,21 @@ tail = (ids, bary, clip, d["normals"], d["vertices"], d["diffuse"], d["triangles
 for upstream_name, upstream, extra in (("signs", up, {"l1_signs": signs}), ("dense", g, {})):
     for want_n, want_d in ((False, False), (True, False), (True, True)):
         for lights in (False, True):
-            for kernel in (1, 2):
+            # rows kernel | lane kernel, general G-buffer | lane kernel, normalised G-buffer (difference-basis records,
+            # round 4) | the same without the clip-space gradient (pull-back folded into the pixel pass)
+            for kernel, normalised, want_clip in ((1, False, True), (2, False, True), (2, True, True), (2, True, False)):
                 _native.debug_set_shade_backward_kernel(kernel)
                 def fn():
                     return _native.shade_backward(upstream, *tail, corner_records=records, adjacency=adjacency,
                                                   transforms=xf, want_light_grads=lights, want_normal_grads=want_n,
-                                                  want_diffuse_grads=want_d, **extra)
+                                                  want_diffuse_grads=want_d, normalised_gbuffer=normalised,
+                                                  want_clip_grads=want_clip, **extra)
                 for _ in range(3): fn()
                 torch.cuda.synchronize(); t0 = time.perf_counter()
                 for _ in range(args.iters): fn()
                 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / args.iters
                 print("upstream=%s grads=%s lights=%d kernel=%s: %.3f ms" % (
                     upstream_name, "P" + ("N" if want_n else "") + ("K" if want_d else ""), lights,
-                    "rows" if kernel == 1 else "lanes(if built)", dt * 1e3), flush=True)
+                    "rows" if kernel == 1 else "lanes" + (" normalised" if normalised else "") + ("" if want_clip else " no-dclip"),
+                    dt * 1e3), flush=True)
 _native.debug_set_shade_backward_kernel(0)
