@@ -16,6 +16,10 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--trials", type=int, default=300)
 ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--edge", type=int, default=0, help="force 32 / 64 pixel regions (0 = automatic)")
+ap.add_argument("--epilogues", action="store_true",
+                help="round 4: also run the one-pass forwards on every soup -- mr_rasterize_interpolate_forward (random "
+                     "attribute count) and mr_render_forward -- whose G-buffers must be bit-identical to mr_rasterize_forward's "
+                     "and whose images must equal the two-pass results (same NaNs, 1e-5)")
 args = ap.parse_args()
 rng = np.random.default_rng(args.seed)
 dev = torch.device("cuda:0")
@@ -66,6 +70,38 @@ for trial in range(args.trials):
             got[2].view(np.uint32)[tuple(sample[0])], want[2].view(np.uint32)[tuple(sample[0])])
         print(f"{'nan-bits' if real == 0 else 'MISMATCH'} trial {trial} kind {kind} B={B} V={V} T={T} {W}x{H}: "
               f"ids {(got[0] != want[0]).sum()} z {dz.sum()} bary {db.sum()} non-NaN differences {real}{ex}", flush=True)
+    if args.epilogues and kind != 3:   # (NaN / Inf coordinates: covered above; the images' NaN patterns are not comparable)
+        clip_d, tris_d = torch.from_numpy(clip).to(dev), torch.from_numpy(tris).to(dev)
+        A = int(rng.integers(1, 17))
+        attrs = torch.from_numpy(rng.normal(size=(B, V, A)).astype(np.float32)).to(dev)
+        bg = torch.from_numpy(rng.normal(size=(A,)).astype(np.float32)).to(dev)
+        i2, b2, out, _ = _native.rasterize_interpolate_forward(clip_d, attrs, tris_d, bg, W, H)
+        out_ref, _ = _native.interpolate_forward_records(ids, bary, attrs, tris_d, bg)
+        same_g = torch.equal(i2, ids) and torch.equal(b2.view(torch.int32), bary.view(torch.int32))
+        o, r = out.cpu().numpy(), out_ref.cpu().numpy()
+        same_o = np.array_equal(np.isnan(o), np.isnan(r)) and np.allclose(np.nan_to_num(o, posinf=1e30, neginf=-1e30),
+                                                                          np.nan_to_num(r, posinf=1e30, neginf=-1e30),
+                                                                          atol=1e-5, rtol=1e-5)
+        # render(): identity transforms turn world-space positions into these clip coordinates' xyz with w = 1, so
+        # use the soup's own (x, y, z) / keep w through a per-image scale matrix is not possible -- feed positions
+        # = clip.xyz and a transform whose last row reproduces w is not affine either: compare on w = 1 soups only
+        same_r = True
+        if kind == 0:
+            pos = clip_d[..., :3].contiguous()
+            xf = torch.eye(4, device=dev).repeat(B, 1, 1).contiguous()
+            nrm = torch.nn.functional.normalize(torch.from_numpy(rng.normal(size=(B, V, 3)).astype(np.float32)).to(dev), dim=2)
+            kd = torch.from_numpy(rng.random(size=(B, V, 3)).astype(np.float32)).to(dev)
+            lp = torch.from_numpy(rng.normal(size=(B, 2, 3)).astype(np.float32)).to(dev) * 3.0
+            li = torch.from_numpy(rng.random(size=(B, 2, 3)).astype(np.float32)).to(dev)
+            c3, i3, b3, _, rgba, _ = _native.render_forward(pos, xf, nrm, kd, tris_d, lp, li, None, W, H, want_z=False)
+            i4, b4, _ = _native.rasterize_forward(c3, tris_d, W, H)
+            rgba_ref = _native.shade_forward(i4, b4, nrm, pos, kd, tris_d, lp, li, None)
+            same_r = (torch.equal(i3, i4) and torch.equal(b3.view(torch.int32), b4.view(torch.int32)) and
+                      bool(torch.allclose(rgba, rgba_ref, atol=1e-5, rtol=1e-5, equal_nan=True)))
+        if not (same_g and same_o and same_r):
+            bad += 1
+            print(f"EPILOGUE MISMATCH trial {trial} kind {kind} B={B} V={V} T={T} {W}x{H} A={A}: g-buffer {same_g} interp {same_o} "
+                  f"render {same_r}", flush=True)
     if trial % 50 == 49:
         print(f"{trial + 1} trials, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
 print("FUZZ", "FAILED" if bad else "OK", f"{args.trials} trials, {bad} mismatches, {nan_only} with NaN-encoding differences only")
