@@ -211,14 +211,20 @@ int mr_vertex_transform(const float *vertices, const float *transforms, int B, i
  *                   and the sign-corrected adjugate in registers anyway -- also writes the records of the
  *                   folded shading backward and clears its accumulator rows.  Handed to
  *                   mr_shade_backward[_l1] as `prepared`, the backward then needs no setup launch.
+ *   empty_regions   NULL, or out: mr_empty_regions_bytes(B, W, H) bytes, [B][ceil(H/64)][ceil(W/64)]: 1 = the
+ *                   64 x 64-pixel block (G-buffer rows 64 by .. 64 by + 63, i.e. image rows H - 1 - y) is whole and
+ *                   holds no candidate triangle: background in the G-buffer, transparent black in the image.
+ *                   mr_l1_loss_forward_regions and mr_shade_backward[_l1] skip such blocks without reading them.
+ *                   (Launches small enough for 32-pixel regions flag nothing.)
  *   workspace       mr_rasterize_forward_workspace_bytes() bytes */
+size_t mr_empty_regions_bytes(int B, int W, int H);
 int mr_render_forward(const float *vertices, const float *transforms, const float *normals,
                       const float *diffuse, const int32_t *triangles,
                       const float *light_positions, const float *light_intensities,
                       const float *ambient, int B, int V, int T, int W, int H, int L,
                       float *clip, int32_t *ids, float *bary, float *z, int want_z, float *rgba,
-                      uint8_t *rgba_u8, void *corner_records, void *backward_prepared, void *workspace,
-                      size_t workspace_bytes, void *stream);
+                      uint8_t *rgba_u8, void *corner_records, void *backward_prepared, uint8_t *empty_regions,
+                      void *workspace, size_t workspace_bytes, void *stream);
 
 /* Backward of mr_shade_forward AND of the rasterizer underneath it, in one pass
  * over the G-buffer (reads 32 B/px).  All outputs are zeroed here.
@@ -262,6 +268,8 @@ int mr_render_forward(const float *vertices, const float *transforms, const floa
  *                   backward call that uses it (differentiating a second time: pass NULL -- the call then
  *                   runs its own setup kernel -- or clear the rows, the block's last
  *                   B * T * 48 bytes rounded up to 256).
+ *   empty_regions   NULL, or mr_render_forward's `empty_regions` for the SAME G-buffer: the difference-basis lane
+ *                   kernels leave a strip that lies inside an empty block without reading it.
  * dclip, dnormals, dpositions, ddiffuse, light_grads laid out back to back in that order are
  * zeroed with a single memset (none at all with the vertex adjacency: every output is written
  * exactly once). */
@@ -275,8 +283,8 @@ int mr_shade_backward(const float *drgba, const int32_t *ids, const float *bary,
                       float *dclip, float *dnormals, float *dpositions,
                       float *ddiffuse, float *light_grads, const void *corner_records,
                       const int32_t *vertex_offsets, const int32_t *vertex_entries,
-                      const float *transforms, int gbuffer_flags, void *prepared, void *workspace,
-                      size_t workspace_bytes,
+                      const float *transforms, int gbuffer_flags, void *prepared, const uint8_t *empty_regions,
+                      void *workspace, size_t workspace_bytes,
                       void *stream);
 /* gbuffer_flags, bit 0 = MR_GBUFFER_NORMALISED: the caller vouches that ids / bary are what
  * mr_rasterize_forward (or mr_render_forward) wrote for these very vertices -- every covered pixel's
@@ -301,8 +309,8 @@ int mr_shade_backward_l1(const uint8_t *signs, const float *upstream, const int3
                          float *dclip, float *dnormals, float *dpositions, float *ddiffuse,
                          float *light_grads, const void *corner_records,
                          const int32_t *vertex_offsets, const int32_t *vertex_entries,
-                         const float *transforms, int gbuffer_flags, void *prepared, void *workspace,
-                         size_t workspace_bytes, void *stream);
+                         const float *transforms, int gbuffer_flags, void *prepared, const uint8_t *empty_regions,
+                         void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- fused deferred shading with the specular term --------------------------------
  * The same replacement as mr_shade_forward / mr_shade_backward for render() calls that pass
@@ -401,6 +409,14 @@ int mr_soft_backward(const float *drgba, const float *rgba, const float *aux,
  * partials: MR_L1_PARTIALS floats of scratch: the workgroups' partial sums, added in a fixed
  * order by one wavefront -- the loss value is bit-identical from run to run. */
 #define MR_L1_PARTIALS 2048
+/* The same loss for [B,H,W,4] images whose EMPTY 64 x 64 blocks are known (round 4): empty_a / empty_b are
+ * mr_empty_regions_bytes(B, W, H) byte maps as mr_render_forward writes them for its image and
+ * mr_image_empty_regions computes them for any image (once per target).  Where both say 1 the block is neither read
+ * nor compared -- |0 - 0| = 0, sign codes 0 -- which for an object over an empty background is the share of the
+ * frame it leaves free.  Same loss value up to the grouping of the sum (still a fixed order), same sign codes. */
+int mr_image_empty_regions(const float *image, int B, int H, int W, uint8_t *map, void *stream);
+int mr_l1_loss_forward_regions(const float *a, const float *b, int B, int H, int W, const uint8_t *empty_a,
+                               const uint8_t *empty_b, float *loss, uint8_t *signs, float *partials, void *stream);
 int mr_l1_loss_partials(void); /* MR_L1_PARTIALS of the library that was loaded (a binding without the header asks) */
 int mr_l1_loss_forward(const float *a, const float *b, size_t n, float *loss, uint8_t *signs,
                        float *partials, void *stream);

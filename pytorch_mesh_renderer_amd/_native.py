@@ -16,7 +16,7 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 # build libmesh_raster_hip_probes.so this way); the product always loads the in-tree library.
 LIB_PATH = os.environ.get("MR_NATIVE_LIB_PATH") or os.path.join(_CSRC, "libmesh_raster_hip.so")
 
-ABI_VERSION = 350
+ABI_VERSION = 351
 GBUFFER_NORMALISED = 1   # mesh_raster.h, MR_GBUFFER_NORMALISED
 TIMER_RASTER_FORWARD, TIMER_SHADE_BACKWARD, TIMER_SHADE_FORWARD, TIMER_RASTER_BACKWARD, TIMER_L1_FORWARD = 0, 1, 2, 3, 4
 MR_OK, MR_EINVAL, MR_EWORKSPACE, MR_ELAUNCH = 0, -1, -2, -3
@@ -164,11 +164,11 @@ def lib():
         L.mr_shade_backward_workspace_bytes.restype = sz
         L.mr_shade_backward_prepared_bytes.argtypes = [ci] * 2
         L.mr_shade_backward_prepared_bytes.restype = sz
-        L.mr_shade_backward.argtypes = [vp] * 11 + [ci] * 6 + [vp] * 9 + [ci, vp, vp, sz, vp]
+        L.mr_shade_backward.argtypes = [vp] * 11 + [ci] * 6 + [vp] * 9 + [ci, vp, vp, vp, sz, vp]
         L.mr_shade_backward.restype = ci
         L.mr_shade_backward_l1_workspace_bytes.argtypes = [ci] * 5
         L.mr_shade_backward_l1_workspace_bytes.restype = sz
-        L.mr_shade_backward_l1.argtypes = [vp] * 12 + [ci] * 6 + [vp] * 9 + [ci, vp, vp, sz, vp]
+        L.mr_shade_backward_l1.argtypes = [vp] * 12 + [ci] * 6 + [vp] * 9 + [ci, vp, vp, vp, sz, vp]
         L.mr_shade_backward_l1.restype = ci
         L.mr_soft_max_lights.restype = ci
         L.mr_soft_workspace_bytes.argtypes = [ci] * 5
@@ -204,7 +204,13 @@ def lib():
         L.mr_interpolate_raster_backward.restype = ci
         L.mr_vertex_transform.argtypes = [vp, vp, ci, ci, vp, vp]
         L.mr_vertex_transform.restype = ci
-        L.mr_render_forward.argtypes = [vp] * 8 + [ci] * 6 + [vp, vp, vp, vp, ci] + [vp] * 5 + [sz, vp]
+        L.mr_render_forward.argtypes = [vp] * 8 + [ci] * 6 + [vp, vp, vp, vp, ci] + [vp] * 6 + [sz, vp]
+        L.mr_empty_regions_bytes.argtypes = [ci] * 3
+        L.mr_empty_regions_bytes.restype = sz
+        L.mr_image_empty_regions.argtypes = [vp, ci, ci, ci, vp, vp]
+        L.mr_image_empty_regions.restype = ci
+        L.mr_l1_loss_forward_regions.argtypes = [vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, vp]
+        L.mr_l1_loss_forward_regions.restype = ci
         L.mr_render_forward.restype = ci
         L.mr_shade_specular_forward_workspace_bytes.argtypes = [ci] * 5
         L.mr_shade_specular_forward_workspace_bytes.restype = sz
@@ -490,7 +496,7 @@ def vertex_transform(vertices, transforms):
 
 
 def render_forward(vertices, transforms, normals, diffuse, triangles, light_positions, light_intensities,
-                   ambient, width, height, want_z=True, want_u8=False, prepare_backward=False):
+                   ambient, width, height, want_z=True, want_u8=False, prepare_backward=False, want_empty_regions=False):
     """render()'s forward from world-space vertices: clip-space transform, rasterizer and shading
     (the shading is the epilogue of the rasterizer's tile walk: one pass over the pixels)
     -> (clip, ids, bary, z, rgba, corner_records); with want_z=False the depth plane is not written
@@ -499,7 +505,11 @@ def render_forward(vertices, transforms, normals, diffuse, triangles, light_posi
 
     prepare_backward=True (the caller will differentiate to the world-space vertices only): the setup kernel
     also writes the folded shading backward's records and clears its accumulator rows; the block is returned as
-    the LAST value and goes to shade_backward(..., prepared=), which then launches no setup kernel."""
+    the LAST value and goes to shade_backward(..., prepared=), which then launches no setup kernel.
+
+    want_empty_regions=True: a [B, ceil(H/64), ceil(W/64)] uint8 map follows the optional frames (before the
+    prepared block): 1 = that 64 x 64 block of the G-buffer holds no candidate triangle (background / transparent
+    black); l1_loss_forward(..., empty_a=, empty_b=) and shade_backward(..., empty_regions=) skip such blocks."""
     tensors = [vertices, transforms, normals, diffuse, triangles, light_positions, light_intensities]
     _chk("vertices", vertices, _F32, None, None, 3)
     _chk("triangles", triangles, _I32, None, 3)
@@ -523,16 +533,19 @@ def render_forward(vertices, transforms, normals, diffuse, triangles, light_posi
     with torch.cuda.device(dev):
         records = _aligned_bytes(L.mr_shade_forward_workspace_bytes(B, V, T, width, height), dev)
         prepared = _aligned_bytes(L.mr_shade_backward_prepared_bytes(B, T), dev) if prepare_backward else None
+        empty = (torch.empty(B, (height + 63) // 64, (width + 63) // 64, dtype=torch.uint8, device=dev)
+                 if want_empty_regions else None)
         need = L.mr_rasterize_forward_workspace_bytes(B, V, T, width, height)
         ws, have = _workspace(dev, need)
         _arm_timer(TIMER_RASTER_FORWARD)
         rc = L.mr_render_forward(_ptr(vertices), _ptr(transforms), _ptr(normals), _ptr(diffuse), _ptr(triangles),
                                  _ptr(light_positions), _ptr(light_intensities), _ptr(ambient), B, V, T,
                                  width, height, nl, _ptr(clip), _ptr(ids), _ptr(bary), _ptr(z), int(bool(want_z)),
-                                 _ptr(rgba), _ptr(frames), _ptr(records), _ptr(prepared), _ptr(ws), have, _stream(dev))
+                                 _ptr(rgba), _ptr(frames), _ptr(records), _ptr(prepared), _ptr(empty), _ptr(ws), have,
+                                 _stream(dev))
     _check(rc, "mr_render_forward")
     out = (clip, ids, bary, (z if want_z else None), rgba, records) + ((frames,) if want_u8 else ())
-    return out + ((prepared,) if prepare_backward else ())
+    return out + ((empty,) if want_empty_regions else ()) + ((prepared,) if prepare_backward else ())
 
 
 def interpolate_raster_max_attributes():
@@ -653,7 +666,7 @@ def vertex_adjacency(triangles, vertex_count):
 def shade_backward(drgba, ids, bary, clip, normals, positions, diffuse, triangles, light_positions,
                    light_intensities, ambient, corner_records=None, adjacency=None, l1_signs=None,
                    transforms=None, want_light_grads=True, want_normal_grads=True, want_diffuse_grads=True,
-                   normalised_gbuffer=False, want_clip_grads=True, prepared=None):
+                   normalised_gbuffer=False, want_clip_grads=True, prepared=None, empty_regions=None):
     """_shade_backward_call for any light count up to shade_max_lights().  The kernels keep the light
     gradients' 6 L sums in registers, four lights per call; with more lights the vertex-side gradients
     come from one call over all lights (a run-time loop, no light gradients) and each group of four
@@ -664,7 +677,8 @@ def shade_backward(drgba, ids, bary, clip, normals, positions, diffuse, triangle
     nl = light_positions.shape[1]
     kw = dict(corner_records=corner_records, adjacency=adjacency, l1_signs=l1_signs, transforms=transforms,
               want_normal_grads=want_normal_grads, want_diffuse_grads=want_diffuse_grads,
-              normalised_gbuffer=normalised_gbuffer, want_clip_grads=want_clip_grads, prepared=prepared)
+              normalised_gbuffer=normalised_gbuffer, want_clip_grads=want_clip_grads, prepared=prepared,
+              empty_regions=empty_regions)
     fast = shade_fast_lights() if nl > 4 else nl
     if nl <= fast or not want_light_grads:
         return _shade_backward_call(drgba, ids, bary, clip, normals, positions, diffuse, triangles,
@@ -689,7 +703,7 @@ def shade_backward(drgba, ids, bary, clip, normals, positions, diffuse, triangle
 def _shade_backward_call(drgba, ids, bary, clip, normals, positions, diffuse, triangles, light_positions,
                          light_intensities, ambient, corner_records=None, adjacency=None, l1_signs=None,
                          transforms=None, want_light_grads=True, want_normal_grads=True, want_diffuse_grads=True,
-                         normalised_gbuffer=False, want_clip_grads=True, prepared=None):
+                         normalised_gbuffer=False, want_clip_grads=True, prepared=None, empty_regions=None):
     """-> (dclip [B,V,4], dnormals, dpositions, ddiffuse [B,V,3], dlight_positions,
     dlight_intensities [B,L,3], dambient [B,3] or None); with want_light_grads=False the last three
     are None and the kernel leaves their accumulation out; want_normal_grads / want_diffuse_grads=False
@@ -709,7 +723,11 @@ def _shade_backward_call(drgba, ids, bary, clip, normals, positions, diffuse, tr
     the world-space vertices only; the pull-back through the transforms is then folded into the pixel
     pass where the library has that variant (9 sums per triangle instead of 18).
 
-    prepared: the block render_forward(..., prepare_backward=True) returned for these inputs (or None)."""
+    prepared: the block render_forward(..., prepare_backward=True) returned for these inputs (or None).
+    empty_regions: render_forward(..., want_empty_regions=True)'s map for this G-buffer (or None)."""
+    if empty_regions is not None:
+        _chk("empty_regions", empty_regions, _U8, clip.shape[0], (ids.shape[1] + 63) // 64, (ids.shape[2] + 63) // 64)
+        empty_regions = empty_regions.contiguous()
     if prepared is not None and (prepared.dtype != torch.uint8 or
                                  prepared.numel() < lib().mr_shade_backward_prepared_bytes(clip.shape[0], triangles.shape[0])):
         raise ValueError("prepared must be the block render_forward(prepare_backward=True) returned for these inputs")
@@ -761,7 +779,7 @@ def _shade_backward_call(drgba, ids, bary, clip, normals, positions, diffuse, tr
     tail = (B, V, T, W, H, nl, _ptr(dclip), _ptr(dn), _ptr(dp), _ptr(dd), _ptr(lg), _ptr(corner_records),
             _ptr(adjacency[0]) if adjacency is not None else None,
             _ptr(adjacency[1]) if adjacency is not None else None, _ptr(transforms),
-            GBUFFER_NORMALISED if normalised_gbuffer else 0, _ptr(prepared))
+            GBUFFER_NORMALISED if normalised_gbuffer else 0, _ptr(prepared), _ptr(empty_regions))
     with torch.cuda.device(dev):
         _arm_timer(TIMER_SHADE_BACKWARD)
         _sync_deterministic()
@@ -975,10 +993,28 @@ def soft_backward(drgba, rgba, aux, clip, positions, normals, diffuse, triangles
     return dclip, dp, dn, dd, dlp, dli
 
 
-def l1_loss_forward(a, b, want_signs=True):
+def image_empty_regions(image):
+    """[B, ceil(H/64), ceil(W/64)] uint8 map of a [B,H,W,4] float32 device image: 1 = the 64 x 64 block (counted in
+    G-buffer rows, i.e. from the image's LAST row up) is whole and all zeros.  What render_forward writes for its own
+    image; l1_loss_forward skips blocks that are empty on both sides."""
+    _chk("image", image, _F32, None, None, None, 4)
+    dev = _require_device(image)
+    image = image.contiguous()
+    B, H, W = image.shape[:3]
+    out = torch.empty(B, (H + 63) // 64, (W + 63) // 64, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib().mr_image_empty_regions(_ptr(image), B, H, W, _ptr(out), _stream(dev))
+    _check(rc, "mr_image_empty_regions")
+    return out
+
+
+def l1_loss_forward(a, b, want_signs=True, empty_a=None, empty_b=None):
     """mean |a - b| over all elements -> (0-D tensor, packed signs or None), on the device.
 
-    The signs ((n + 3) // 4 bytes, 2 bits per element) are all the backward pass needs."""
+    The signs ((n + 3) // 4 bytes, 2 bits per element) are all the backward pass needs.
+
+    empty_a, empty_b (both or neither; [B,H,W,4] images only): the images' empty-block maps (render_forward's
+    want_empty_regions / image_empty_regions): blocks empty on both sides are not read."""
     if a.dtype != _F32 or b.dtype != _F32:
         raise RuntimeError("l1_loss expects float32 tensors")
     if a.shape != b.shape:
@@ -990,8 +1026,17 @@ def l1_loss_forward(a, b, want_signs=True):
     partials = torch.empty(lib().mr_l1_loss_partials(), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         _arm_timer(TIMER_L1_FORWARD)
-        rc = lib().mr_l1_loss_forward(_ptr(a), _ptr(b), a.numel(), _ptr(out),
-                                      _ptr(signs) if want_signs else None, _ptr(partials), _stream(dev))
+        if empty_a is not None and empty_b is not None:
+            _chk("image", a, _F32, None, None, None, 4)
+            B, H, W = a.shape[:3]
+            for name, m in (("empty_a", empty_a), ("empty_b", empty_b)):
+                _chk(name, m, _U8, B, (H + 63) // 64, (W + 63) // 64)
+            rc = lib().mr_l1_loss_forward_regions(_ptr(a), _ptr(b), B, H, W, _ptr(empty_a.contiguous()),
+                                                  _ptr(empty_b.contiguous()), _ptr(out),
+                                                  _ptr(signs) if want_signs else None, _ptr(partials), _stream(dev))
+        else:
+            rc = lib().mr_l1_loss_forward(_ptr(a), _ptr(b), a.numel(), _ptr(out),
+                                          _ptr(signs) if want_signs else None, _ptr(partials), _stream(dev))
     _check(rc, "mr_l1_loss_forward")
     return out, signs
 

@@ -31,7 +31,7 @@ extern thread_local int g_shade_backward_kernel;
 
 extern "C" {
 
-int mr_version(void) { return 350; /* 0.5.0: dclip optional, backward_prepared / prepared, mr_debug_soft_nearest, two's-complement sign codes */ }
+int mr_version(void) { return 351; /* 0.5.0: dclip optional, backward_prepared / prepared, mr_debug_soft_nearest, two's-complement sign codes */ }
 
 int mr_last_hip_error(void) { return mr::g_last_hip_error; }
 
@@ -252,7 +252,7 @@ int mr_render_forward(const float *vertices, const float *transforms, const floa
                       const float *light_intensities, const float *ambient, int B, int V, int T, int W,
                       int H, int L, float *clip, int32_t *ids, float *bary, float *z, int want_z,
                       float *rgba, uint8_t *rgba_u8, void *corner_records, void *backward_prepared,
-                      void *workspace, size_t workspace_bytes, void *stream) {
+                      uint8_t *empty_regions, void *workspace, size_t workspace_bytes, void *stream) {
   if (bad_dims(B, V, T, W, H) || T < 1 || V < 1 || L < 1 || L > mr::shade_max_lights())
     return MR_EINVAL;
   if (B == 0) return MR_OK;
@@ -265,7 +265,7 @@ int mr_render_forward(const float *vertices, const float *transforms, const floa
   if (rc != MR_OK) return rc;
   return mr::launch_render_forward(vertices, transforms, normals, diffuse, triangles, light_positions,
                                    light_intensities, ambient, B, V, T, W, H, L, clip, ids, bary, z,
-                                   want_z, rgba, rgba_u8, corner_records, backward_prepared, workspace,
+                                   want_z, rgba, rgba_u8, corner_records, backward_prepared, empty_regions, workspace,
                                    (hipStream_t)stream);
 }
 
@@ -291,8 +291,8 @@ int mr_shade_backward(const float *drgba, const int32_t *ids, const float *bary,
                       int W, int H, int L, float *dclip, float *dnormals, float *dpositions,
                       float *ddiffuse, float *light_grads, const void *corner_records,
                       const int32_t *vertex_offsets, const int32_t *vertex_entries,
-                      const float *transforms, int gbuffer_flags, void *prepared, void *workspace,
-                      size_t workspace_bytes, void *stream) {
+                      const float *transforms, int gbuffer_flags, void *prepared, const uint8_t *empty_regions,
+                      void *workspace, size_t workspace_bytes, void *stream) {
   if (bad_dims(B, V, T, W, H) || T < 1 || V < 1 || L < 1 || L > mr::shade_max_lights() ||
       (gbuffer_flags & ~MR_GBUFFER_NORMALISED))
     return MR_EINVAL;
@@ -311,7 +311,7 @@ int mr_shade_backward(const float *drgba, const int32_t *ids, const float *bary,
   return mr::launch_shade_backward(drgba, nullptr, nullptr, ids, bary, clip, normals, positions, diffuse,
                                    triangles, light_positions, light_intensities, ambient, B, V, T, W, H, L,
                                    dclip, dnormals, dpositions, ddiffuse, light_grads, corner_records,
-                                   vertex_offsets, vertex_entries, transforms, gbuffer_flags, prepared, workspace,
+                                   vertex_offsets, vertex_entries, transforms, gbuffer_flags, prepared, empty_regions, workspace,
                                    (hipStream_t)stream);
 }
 
@@ -328,7 +328,8 @@ int mr_shade_backward_l1(const uint8_t *signs, const float *upstream, const int3
                          float *dnormals, float *dpositions, float *ddiffuse, float *light_grads,
                          const void *corner_records, const int32_t *vertex_offsets,
                          const int32_t *vertex_entries, const float *transforms, int gbuffer_flags,
-                         void *prepared, void *workspace, size_t workspace_bytes, void *stream) {
+                         void *prepared, const uint8_t *empty_regions, void *workspace, size_t workspace_bytes,
+                         void *stream) {
   if (bad_dims(B, V, T, W, H) || T < 1 || V < 1 || L < 1 || L > mr::shade_max_lights() ||
       (gbuffer_flags & ~MR_GBUFFER_NORMALISED))
     return MR_EINVAL;
@@ -347,7 +348,7 @@ int mr_shade_backward_l1(const uint8_t *signs, const float *upstream, const int3
   return mr::launch_shade_backward(nullptr, signs, upstream, ids, bary, clip, normals, positions, diffuse,
                                    triangles, light_positions, light_intensities, ambient, B, V, T, W, H, L,
                                    dclip, dnormals, dpositions, ddiffuse, light_grads, corner_records,
-                                   vertex_offsets, vertex_entries, transforms, gbuffer_flags, prepared, workspace,
+                                   vertex_offsets, vertex_entries, transforms, gbuffer_flags, prepared, empty_regions, workspace,
                                    (hipStream_t)stream);
 }
 
@@ -477,6 +478,26 @@ int mr_l1_loss_forward(const float *a, const float *b, size_t n, float *loss, ui
   if (!loss || (n > 0 && (!a || !b || !partials))) return MR_EINVAL;
   if ((((uintptr_t)a | (uintptr_t)b) & 15u) != 0) return MR_EINVAL;
   return mr::launch_l1_forward(a, b, n, loss, signs, partials, (hipStream_t)stream);
+}
+
+size_t mr_empty_regions_bytes(int B, int W, int H) {
+  if (B < 0 || W < 0 || H < 0) return 0;
+  return (size_t)B * ((H + 63) / 64) * ((W + 63) / 64);
+}
+
+int mr_image_empty_regions(const float *image, int B, int H, int W, uint8_t *map, void *stream) {
+  if (B < 0 || H < 0 || W < 0 || H > 65535 || W > 65535) return MR_EINVAL;
+  if ((size_t)B * H * W == 0) return MR_OK;
+  if (!image || !map || ((uintptr_t)image & 15u)) return MR_EINVAL;
+  return mr::launch_image_empty_regions(image, B, H, W, map, (hipStream_t)stream);
+}
+
+int mr_l1_loss_forward_regions(const float *a, const float *b, int B, int H, int W, const uint8_t *empty_a,
+                               const uint8_t *empty_b, float *loss, uint8_t *signs, float *partials, void *stream) {
+  if (B < 0 || H < 0 || W < 0 || H > 65535 || W > 65535 || !loss) return MR_EINVAL;
+  if ((size_t)B * H * W > 0 && (!a || !b || !partials || !empty_a || !empty_b)) return MR_EINVAL;
+  if ((((uintptr_t)a | (uintptr_t)b) & 15u) != 0) return MR_EINVAL;
+  return mr::launch_l1_forward_regions(a, b, B, H, W, empty_a, empty_b, loss, signs, partials, (hipStream_t)stream);
 }
 
 int mr_l1_loss_backward(const uint8_t *signs, size_t n, const float *upstream, float *da, void *stream) {

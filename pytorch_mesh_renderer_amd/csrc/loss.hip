@@ -282,6 +282,103 @@ __global__ __launch_bounds__(kThreads) void k_tone_map(const float *__restrict__
   }
 }
 
+// ---- round 4: the loss over an image with KNOWN empty blocks ---------------------------------------------------
+// A rendered image of an object over an empty background is, region by region, exactly zero where the rasterizer
+// found no candidate triangle (mr_render_forward's `empty_regions`: 64 x 64-pixel blocks of the G-buffer, i.e. image
+// rows H - 1 - y); a target made the same way has its own such blocks (mr_image_empty_regions, computed once per
+// target).  Where BOTH are empty |a - b| = 0 and every sign code is 0: the block is neither read (2 x 16 B/px)
+// nor compared -- a quarter of the benchmark's pixels.  One 256-thread workgroup walks blocks (grid stride); a
+// block's row is 64 pixels = 1 KB = one wave-instruction of 16-byte loads per image.
+constexpr int kBlockEdge = 64;
+
+__global__ __launch_bounds__(kThreads) void k_image_empty_regions(const float4 *__restrict__ image, int B, int H, int W,
+                                                                 int blocks_x, int blocks_y, uint8_t *__restrict__ map) {
+  __shared__ int s_any;
+  const int lane_x = (int)threadIdx.x & (kBlockEdge - 1), row0 = (int)threadIdx.x / kBlockEdge;   // 64 columns x 4 rows per trip
+  for (int blk = (int)blockIdx.x; blk < B * blocks_x * blocks_y; blk += (int)gridDim.x) {
+    const int img = blk / (blocks_x * blocks_y), rem = blk - img * blocks_x * blocks_y;
+    const int by = rem / blocks_x, bx = rem - by * blocks_x;
+    if (threadIdx.x == 0) s_any = 0;
+    __syncthreads();
+    const bool whole = bx * kBlockEdge + kBlockEdge <= W && by * kBlockEdge + kBlockEdge <= H;
+    unsigned bits = 0u;
+    if (whole) {
+      for (int r = row0; r < kBlockEdge; r += kThreads / kBlockEdge) {
+        const int yi = H - 1 - (by * kBlockEdge + r);   // image row of G-buffer row by * 64 + r
+        const float4 v = nt_load(&image[((size_t)img * H + yi) * W + bx * kBlockEdge + lane_x]);
+        bits |= __float_as_uint(v.x) | __float_as_uint(v.y) | __float_as_uint(v.z) | __float_as_uint(v.w);
+      }
+      bits &= 0x7fffffffu;   // (-0.0 is zero; a NaN has bits set)
+    }
+    if (__ballot(bits != 0u) != 0ull && (threadIdx.x & (kWave - 1)) == 0) atomicOr(&s_any, 1);
+    __syncthreads();
+    if (threadIdx.x == 0) map[blk] = (whole && s_any == 0) ? 1 : 0;
+    __syncthreads();
+  }
+}
+
+// mean |a - b| over [B,H,W,4] images with their empty-block maps: the flat kernel's streaming order (whole image rows,
+// back to front, consecutive workgroups on consecutive rows), and a 64-pixel segment of a row whose block is empty on
+// both sides is not loaded (its sign codes are zeros).  A first version walked block by block (1 KB row segments
+// 16 KB apart): it skipped a quarter of the benchmark's pixels and was no faster than the flat pass (176 vs 182 us).
+__global__ __launch_bounds__(kThreads) void k_l1_forward_regions(
+    const float4 *__restrict__ a, const float4 *__restrict__ b, int B, int H, int W, int blocks_x, int blocks_y,
+    const uint8_t *__restrict__ empty_a, const uint8_t *__restrict__ empty_b, float inv_n, float *__restrict__ partials,
+    uint8_t *__restrict__ signs) {
+  constexpr int kInFlight = MR_L1_UNROLL;
+  float s = 0.f;
+  const long n_rows = (long)B * H;
+  for (long k = (long)blockIdx.x; k < n_rows; k += (long)gridDim.x) {
+    const long row = MR_L1_REVERSE ? n_rows - 1 - k : k;   // workgroup-uniform
+    const int img = (int)(row / H), yi = (int)(row - (long)img * H);
+    const int band = (H - 1 - yi) / kBlockEdge;   // the maps count rows from the image's LAST row (G-buffer order)
+    const uint8_t *ma = empty_a + ((size_t)img * blocks_y + band) * blocks_x;
+    const uint8_t *mb = empty_b + ((size_t)img * blocks_y + band) * blocks_x;
+    const size_t base = (size_t)row * W;
+    for (int x0 = (int)threadIdx.x; x0 < W; x0 += kThreads * kInFlight) {
+      float4 va[kInFlight], vb[kInFlight];
+      bool live[kInFlight];
+#pragma unroll
+      for (int u = 0; u < kInFlight; ++u) {
+        const int x = x0 + u * kThreads;
+        const int xc = min(x, W - 1);
+        live[u] = !(ma[xc / kBlockEdge] != 0 && mb[xc / kBlockEdge] != 0) && x < W;
+      }
+#pragma unroll
+      for (int u = 0; u < kInFlight; ++u) {
+        va[u] = vb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live[u]) {
+          va[u] = nt_load(&a[base + x0 + u * kThreads]);
+          vb[u] = nt_load(&b[base + x0 + u * kThreads]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kInFlight; ++u) {
+        const int x = x0 + u * kThreads;
+        if (x >= W) break;
+        const float d0 = va[u].x - vb[u].x, d1 = va[u].y - vb[u].y, d2 = va[u].z - vb[u].z, d3 = va[u].w - vb[u].w;
+        s += (fabsf(d0) + fabsf(d1)) + (fabsf(d2) + fabsf(d3));
+        if (signs) {
+          const uint8_t code =
+              (uint8_t)(sign_code(d0) | (sign_code(d1) << 2) | (sign_code(d2) << 4) | (sign_code(d3) << 6));
+          __builtin_nontemporal_store(code, &signs[base + x]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+  __shared__ float s_part[kThreads / kWave];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  if (lane == 0) s_part[wave] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < kThreads / kWave; ++w) t += s_part[w];
+    partials[blockIdx.x] = t * inv_n;  // summed in a fixed order by k_l1_finish: reproducible bits
+  }
+}
+
 inline unsigned blocks_for(size_t n4) {
   const size_t want = (n4 + kThreads - 1) / kThreads;
   return (unsigned)(want < MR_L1_BLOCKS ? (want ? want : 1) : MR_L1_BLOCKS);
@@ -302,6 +399,40 @@ int launch_l1_forward(const float *a, const float *b, size_t n, float *out, uint
     hipLaunchKernelGGL(k_l1_forward, dim3(blocks), dim3(kThreads), 0, s, (const float4 *)a,
                        (const float4 *)b, n4, a + 4 * n4, b + 4 * n4, (int)(n - 4 * n4), 1.0f / (float)n, partials,
                        signs);
+  }
+  int rc = check_launch();
+  if (rc != MR_OK) return rc;
+  hipLaunchKernelGGL(k_l1_finish, dim3(1), dim3(kFinishThreads), 0, s, partials, (int)blocks, out);
+  return check_launch();
+}
+
+int launch_image_empty_regions(const float *image, int B, int H, int W, uint8_t *map, hipStream_t s) {
+  const int bx = (W + kBlockEdge - 1) / kBlockEdge, by = (H + kBlockEdge - 1) / kBlockEdge;
+  const long n = (long)B * bx * by;
+  if (n == 0) return MR_OK;
+  hipLaunchKernelGGL(k_image_empty_regions, dim3((unsigned)(n < 4096 ? n : 4096)), dim3(kThreads), 0, s, (const float4 *)image, B,
+                     H, W, bx, by, map);
+  return check_launch();
+}
+
+// mean |a - b| over [B,H,W,4] images whose empty 64 x 64 blocks are known (see k_l1_forward_regions); same outputs as
+// launch_l1_forward (the sum's grouping differs: whole rows per workgroup instead of a flat stride -- still a fixed order).
+int launch_l1_forward_regions(const float *a, const float *b, int B, int H, int W, const uint8_t *empty_a,
+                              const uint8_t *empty_b, float *out, uint8_t *signs, float *partials, hipStream_t s) {
+  const size_t n = (size_t)B * H * W * 4;
+  if (n == 0) {
+    if (hipMemsetAsync(out, 0, sizeof(float), s) != hipSuccess) return check_launch();
+    return MR_OK;
+  }
+  const int bx = (W + kBlockEdge - 1) / kBlockEdge, by = (H + kBlockEdge - 1) / kBlockEdge;
+  if (W < kThreads)   // a row is less than one trip of the workgroup: the flat pass (reads everything) serves it better
+    return launch_l1_forward(a, b, n, out, signs, partials, s);
+  const long n_rows = (long)B * H;
+  const unsigned blocks = (unsigned)(n_rows < MR_L1_BLOCKS ? n_rows : MR_L1_BLOCKS);
+  {
+    KernelTimer timer(MR_TIMER_L1_FORWARD, s);
+    hipLaunchKernelGGL(k_l1_forward_regions, dim3(blocks), dim3(kThreads), 0, s, (const float4 *)a, (const float4 *)b, B, H, W,
+                       bx, by, empty_a, empty_b, 1.0f / (float)n, partials, signs);
   }
   int rc = check_launch();
   if (rc != MR_OK) return rc;

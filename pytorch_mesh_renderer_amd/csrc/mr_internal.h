@@ -125,7 +125,8 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
                           int H, int L, float *dclip, float *dnormals, float *dpositions,
                           float *ddiffuse, float *light_grads, const void *corner_records,
                           const int32_t *vertex_offsets, const int32_t *vertex_entries,
-                          const float *transforms, int gbuffer_flags, void *prepared, void *ws, hipStream_t s);
+                          const float *transforms, int gbuffer_flags, void *prepared, const uint8_t *empty_regions, void *ws,
+                          hipStream_t s);
 size_t shade_backward_prepared_bytes(int B, int T);
 
 int interp_raster_max_attrs();
@@ -149,7 +150,8 @@ int launch_render_forward(const float *vertices, const float *transforms, const 
                           const float *diffuse, const int32_t *tris, const float *light_pos,
                           const float *light_col, const float *ambient, int B, int V, int T, int W, int H,
                           int L, float *clip, int32_t *ids, float *bary, float *z, int want_z, float *rgba,
-                          uint8_t *rgba_u8, void *corner_records, void *backward_prepared, void *ws, hipStream_t s);
+                          uint8_t *rgba_u8, void *corner_records, void *backward_prepared, uint8_t *empty_regions, void *ws,
+                          hipStream_t s);
 size_t shade_specular_forward_ws(int B, int V, int T, int W, int H);
 int launch_shade_specular_forward(const int32_t *ids, const float *bary, const float *normals,
                                   const float *positions, const float *diffuse, const float *specular,
@@ -171,6 +173,9 @@ int launch_shade_specular_backward(const float *drgba, const int32_t *ids, const
 int launch_l1_forward(const float *a, const float *b, size_t n, float *out, uint8_t *signs, float *partials,
                       hipStream_t s);
 int launch_l1_backward(const uint8_t *signs, size_t n, const float *upstream, float *da, hipStream_t s);
+int launch_image_empty_regions(const float *image, int B, int H, int W, uint8_t *map, hipStream_t s);
+int launch_l1_forward_regions(const float *a, const float *b, int B, int H, int W, const uint8_t *empty_a,
+                              const uint8_t *empty_b, float *out, uint8_t *signs, float *partials, hipStream_t s);
 int launch_export_u8(const float *in, size_t n, uint8_t *out, hipStream_t s);
 int launch_vertex_normals(const float *vertices, const int32_t *tris, const int32_t *offsets,
                           const int32_t *entries, int B, int V, float *sums, float *normals, hipStream_t s);

@@ -544,6 +544,10 @@ struct RasterShade {
   const float *__restrict__ background;    // [A]
   float *__restrict__ attr_out;            // [B,H,W,A], G-buffer row order (row 0 = bottom, like ids / bary)
   int A;
+  // Round 4: nullptr, or [B][ceil(H / 64)][ceil(W / 64)] bytes out (64-pixel regions only): 1 = the region is a whole
+  // 64 x 64 block without a single candidate triangle -- every pixel of it is background in the G-buffer and transparent
+  // black in the image.  Consumers (the loss, the shading backward) skip such blocks without reading them.
+  uint8_t *__restrict__ empty_map;
 };
 
 #ifndef MR_EPI_LDS_LIGHTS
@@ -683,6 +687,8 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : INTERP >=
   const int32_t *cand = region_n >= 0 ? region_ids + (size_t)region * kRegionListCap
                                       : cell_ids + ((size_t)img * cells_per_image + cell) * T;
   const int n_cand = region_n >= 0 ? region_n : cell_count[(size_t)img * cells_per_image + cell];
+  if (R == 64 && shade.empty_map && threadIdx.x == 0)
+    shade.empty_map[region] = (n_cand == 0 && X1 - X0 == R && Y1 - Y0 == R) ? 1 : 0;
   // Front-to-back classes (see depth_lower_bound): when every triangle of the cell is tame, the
   // bin holds the candidates whose depth bound lies below the cell's split first ("near"), in id
   // order, then the others ("far"), in id order.  A tile whose pixels all hold a depth below the
@@ -1581,7 +1587,7 @@ int raster_forward(const float *clip, const int32_t *tris, int B, int V, int T, 
 int launch_raster_forward(const float *clip, const int32_t *tris, int B, int V, int T, int W,
                           int H, int32_t *ids, float *bary, float *z, void *ws, hipStream_t s) {
   return raster_forward(clip, tris, B, V, T, W, H, ids, bary, z,
-                        RasterShade{nullptr, Lights{nullptr, nullptr, nullptr, 0}, nullptr, nullptr, 1, nullptr, nullptr, nullptr, 0},
+                        RasterShade{nullptr, Lights{nullptr, nullptr, nullptr, 0}, nullptr, nullptr, 1, nullptr, nullptr, nullptr, 0, nullptr},
                         SetupAttributes{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, ws, s);
 }
 
@@ -1597,7 +1603,7 @@ int launch_rasterize_interpolate_forward(const float *clip, const float *attrs, 
   if (rc != MR_OK) return rc;
   return raster_forward(clip, tris, B, V, T, W, H, ids, bary, z,
                         RasterShade{nullptr, Lights{nullptr, nullptr, nullptr, 0}, nullptr, nullptr, 0, (const float *)records,
-                                    background, out, A},
+                                    background, out, A, nullptr},
                         SetupAttributes{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, ws, s);
 }
 
@@ -1618,14 +1624,18 @@ int launch_render_forward(const float *vertices, const float *transforms, const 
                           const float *diffuse, const int32_t *tris, const float *light_pos,
                           const float *light_col, const float *ambient, int B, int V, int T, int W, int H,
                           int L, float *clip, int32_t *ids, float *bary, float *z, int want_z, float *rgba,
-                          uint8_t *rgba_u8, void *corner_records, void *backward_prepared, void *ws, hipStream_t s) {
+                          uint8_t *rgba_u8, void *corner_records, void *backward_prepared, uint8_t *empty_regions, void *ws,
+                          hipStream_t s) {
   const int rc = launch_vertex_transform(vertices, transforms, B, V, clip, s);
   if (rc != MR_OK) return rc;
+  if (empty_regions && region_edge(B, W, H) != 64 && (size_t)B * W * H > 0) {   // 32-pixel regions (small launches): nothing is flagged
+    if (hipMemsetAsync(empty_regions, 0, (size_t)B * ((H + 63) / 64) * ((W + 63) / 64), s) != hipSuccess) return check_launch();
+  }
   if ((size_t)B * W * H == 0) return MR_OK;
   CornerRec *corners = (CornerRec *)corner_records;
   return raster_forward(clip, tris, B, V, T, W, H, ids, bary, z,
                         RasterShade{corners, Lights{light_pos, light_col, ambient, L}, rgba, (uint32_t *)rgba_u8, want_z, nullptr,
-                                    nullptr, nullptr, 0},
+                                    nullptr, nullptr, 0, region_edge(B, W, H) == 64 ? empty_regions : nullptr},
                         SetupAttributes{(const F3 *)normals, (const F3 *)vertices, (const F3 *)diffuse, corners,
                                         (FoldRec *)backward_prepared,
                                         backward_prepared ? (float4 *)((char *)backward_prepared + fold_prepared_recs_bytes(B, T))

@@ -517,6 +517,13 @@ struct LanesPipelinedConditional<Fn, decltype((void)Fn::kPipelinedConditionalRec
   static constexpr bool value = Fn::kPipelinedConditionalRecords;
 };
 
+// Fn::kSkipsStrips (optional member, default false): the functor can tell from a side table that a whole strip has
+// nothing to contribute -- fn.skip_strip(img, strip column, first row, end row) -- and the wavefront leaves at once
+template <class Fn, class = void>
+struct LanesSkipStrips { static constexpr bool value = false; };
+template <class Fn>
+struct LanesSkipStrips<Fn, decltype((void)Fn::kSkipsStrips)> { static constexpr bool value = Fn::kSkipsStrips; };
+
 template <class Fn, bool DET>
 __global__ __launch_bounds__(kWave, Fn::kMinWavesPerSimd) void k_accumulate_lanes(
     Fn fn, int T, int W, int H, int regions_x, int regions_per_image, int n_regions,
@@ -541,6 +548,9 @@ __global__ __launch_bounds__(kWave, Fn::kMinWavesPerSimd) void k_accumulate_lane
   const int xc = in_range ? x : W - 1;
   const int y_begin = ry * rows_per_wave;
   const int y_end = min(y_begin + rows_per_wave, H);
+  if constexpr (LanesSkipStrips<Fn>::value) {
+    if (fn.skip_strip(img, rx, y_begin, y_end)) return;   // wave-uniform
+  }
   float *acc_img = acc + (size_t)img * T * STRIDE;
   long long *acc_fixed = (long long *)acc + (size_t)img * T * STRIDE;  // DET: 8-byte elements
   const float to_fixed = DET ? det_scale[0] : 0.0f;

@@ -164,6 +164,16 @@ struct ShadeGradFn {
   float *__restrict__ light_rows;     // LG: [strips][L*6 + 3] per strip: dpos (L x 3), dcol (L x 3), dambient (3)
   int T_, W, H;
   const float *__restrict__ transforms = nullptr;  // [B,4,4] clip = M (position, 1): ShadeLaneFn<..., FOLD> only
+  // mr_render_forward's empty_regions ([B][ceil(H / 64)][ceil(W / 64)], 1 = a whole 64 x 64 block of background) or nullptr:
+  // the difference-basis lane kernels leave a strip that lies in such a block without reading it (skip_strip)
+  const uint8_t *__restrict__ empty_map = nullptr;
+  __device__ __forceinline__ bool strip_is_empty(int img, int rx, int y_begin, int y_end) const {
+    if (!empty_map) return false;
+    const int by0 = y_begin >> 6, by1 = (y_end - 1) >> 6;   // (a strip is 64 pixels wide: block column = strip column)
+    if (by0 != by1) return false;
+    const int blocks_x = (W + 63) >> 6, blocks_y = (H + 63) >> 6;
+    return empty_map[((size_t)img * blocks_y + by0) * blocks_x + rx] != 0;
+  }
 
   struct Pixel {
     F3 b, g;
@@ -524,6 +534,10 @@ struct ShadeLaneFn : ShadeGradFn<L, SIGNS, LG> {
 template <int L, bool SIGNS>
 struct ShadeFoldLaneFn : ShadeGradFn<L, SIGNS, false> {
   using Base = ShadeGradFn<L, SIGNS, false>;
+  static constexpr bool kSkipsStrips = true;
+  __device__ __forceinline__ bool skip_strip(int img, int rx, int y_begin, int y_end) const {
+    return Base::strip_is_empty(img, rx, y_begin, y_end);
+  }
   static constexpr int kN = 9;
   static constexpr int kStride = kFoldAccStride;  // COMPACT rows: [corner][c] + 3 of padding (k_shade_gather_fold reads them)
   static constexpr int kLaneRowsPerWave = MR_FOLD_LANE_ROWS;   // 8: 0.2323 -> 0.2281 ms against 16 (32: 0.2507), same box
@@ -573,6 +587,10 @@ struct ShadeFoldLaneFn : ShadeGradFn<L, SIGNS, false> {
 template <int L, bool SIGNS, int GROUPS, bool FOLD>
 struct ShadeDiffLaneFn : ShadeGradFn<L, SIGNS, false> {
   using Base = ShadeGradFn<L, SIGNS, false>;
+  static constexpr bool kSkipsStrips = true;
+  __device__ __forceinline__ bool skip_strip(int img, int rx, int y_begin, int y_end) const {
+    return Base::strip_is_empty(img, rx, y_begin, y_end);
+  }
   static_assert(GROUPS >= 1 && GROUPS < 8 && (!FOLD || (GROUPS & 2)), "attribute groups: normals | positions | diffuse");
   static constexpr int kGroups = (GROUPS & 1) + ((GROUPS >> 1) & 1) + ((GROUPS >> 2) & 1);
   static constexpr int kN = 9 * kGroups + (FOLD ? 0 : 9);
@@ -902,7 +920,8 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
                           int H, int L, float *dclip, float *dnormals, float *dpositions,
                           float *ddiffuse, float *light_grads, const void *corner_records,
                           const int32_t *vertex_offsets, const int32_t *vertex_entries,
-                          const float *transforms, int gbuffer_flags, void *prepared, void *ws, hipStream_t s) {
+                          const float *transforms, int gbuffer_flags, void *prepared, const uint8_t *empty_regions, void *ws,
+                          hipStream_t s) {
   if (B == 0) return MR_OK;
   if (transforms && !(vertex_offsets && vertex_entries)) return MR_EINVAL;  // the gather applies them
   if (!dclip && !transforms) return MR_EINVAL;  // without the pull-back the clip-space gradient IS the vertex gradient
@@ -1034,11 +1053,11 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
     KernelTimer timer(MR_TIMER_SHADE_BACKWARD, s);                                              \
     if (signs) {                                                                                \
       ShadeFoldLaneFn<NL, true> fn{{nullptr, signs, sign_upstream, sign_inv_n, ids, (const F3 *)bary, corners, recs, \
-                                    lights, nullptr, T, W, H, transforms}, fold_recs};          \
+                                    lights, nullptr, T, W, H, transforms, empty_regions}, fold_recs};          \
       rc = launch_accumulate_lanes(fn, B, T, W, H, acc, s);                                     \
     } else {                                                                                    \
       ShadeFoldLaneFn<NL, false> fn{{(const float4 *)drgba, nullptr, nullptr, 0.0f, ids, (const F3 *)bary, corners,  \
-                                     recs, lights, nullptr, T, W, H, transforms}, fold_recs};   \
+                                     recs, lights, nullptr, T, W, H, transforms, empty_regions}, fold_recs};   \
       rc = launch_accumulate_lanes(fn, B, T, W, H, acc, s);                                     \
     }                                                                                           \
   } else {                                                                                      \
@@ -1075,11 +1094,11 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
     KernelTimer timer(MR_TIMER_SHADE_BACKWARD, s);                                              \
     if (signs) {                                                                                \
       ShadeDiffLaneFn<NL, true, G, F> fn{{nullptr, signs, sign_upstream, sign_inv_n, ids, (const F3 *)bary, corners, recs, \
-                                          lights, nullptr, T, W, H, transforms}, fold_recs};    \
+                                          lights, nullptr, T, W, H, transforms, empty_regions}, fold_recs};    \
       rc = launch_accumulate_lanes(fn, B, T, W, H, acc, s);                                     \
     } else {                                                                                    \
       ShadeDiffLaneFn<NL, false, G, F> fn{{(const float4 *)drgba, nullptr, nullptr, 0.0f, ids, (const F3 *)bary, corners,  \
-                                           recs, lights, nullptr, T, W, H, transforms}, fold_recs};                         \
+                                           recs, lights, nullptr, T, W, H, transforms, empty_regions}, fold_recs};                         \
       rc = launch_accumulate_lanes(fn, B, T, W, H, acc, s);                                     \
     }                                                                                           \
   }

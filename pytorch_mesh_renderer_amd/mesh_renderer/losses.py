@@ -58,5 +58,5 @@ def l1_loss(image, target):
             # image.detach(): the renderer's own node must not be part of this loss's graph (autograd
             # would run it on a materialised all-zero gradient image)
             return FusedPhongL1Loss.apply(image.detach(), target, *record["inputs"], record["saved"],
-                                          record.get("prepared_state"))
+                                          record.get("prepared_state"), record.get("empty_regions"))
     return _MeanAbsError.apply(image, target)

@@ -163,6 +163,8 @@ def emit_uint8_frames(on):
 
 
 PREPARE_BACKWARD = True   # False: the backward always runs its own setup kernel (A/B, tests)
+# False (or MR_EMPTY_REGIONS=0 at import): no empty-block map -- the loss and the backward read every pixel (A/B, tests)
+EMPTY_REGIONS = os.environ.get("MR_EMPTY_REGIONS", "1") != "0"
 
 
 class FusedPhongRenderer(torch.autograd.Function):
@@ -192,13 +194,16 @@ class FusedPhongRenderer(torch.autograd.Function):
         prepare = bool(epilogue and PREPARE_BACKWARD and needs[0] and not any(needs[i] for i in (1, 2, 3, 5, 6, 7))
                        and not _native.deterministic())
         prepared = None
+        empty_regions = None
         if epilogue:
             out = _native.render_forward(
                 verts, xf, args[0], args[1], triangles, lp, li, amb, int(image_width), int(image_height),
-                want_z=False, want_u8=bool(want_frames), prepare_backward=prepare)
+                want_z=False, want_u8=bool(want_frames), prepare_backward=prepare, want_empty_regions=EMPTY_REGIONS)
             clip, ids, bary, _, rgba, corner_records = out[:6]
             if want_frames:
                 frames = out[6]
+            if EMPTY_REGIONS:   # which 64 x 64 blocks of the image are known to be empty (the loss and the backward skip them)
+                empty_regions = out[7] if want_frames else out[6]
             if prepare:
                 prepared = out[-1]
         else:
@@ -219,13 +224,14 @@ class FusedPhongRenderer(torch.autograd.Function):
         # a retained graph -- through this node or through FusedPhongL1Loss, which shares this dict -- runs the
         # backward's own setup kernel instead
         ctx.prepared_state = {"used": prepared is None}
+        ctx.empty_regions = empty_regions
         if frames is not None:
             ctx.mark_non_differentiable(frames)
         return rgba, frames
 
     @staticmethod
     def _input_grads(saved, needs_transform_grad, needs_light_grads, upstream, l1_signs=None,
-                     needs_normal_grad=True, needs_diffuse_grad=True, prepared_state=None):
+                     needs_normal_grad=True, needs_diffuse_grad=True, prepared_state=None, empty_regions=None):
         """The shading backward on the tensors forward() saved -> gradients in the order of forward()'s
         tensor arguments (vertices, transforms, normals, diffuse, None, lights..., ambient).
         needs_light_grads: some of light_positions / light_intensities / ambient requires grad;
@@ -242,7 +248,7 @@ class FusedPhongRenderer(torch.autograd.Function):
             want_light_grads=needs_light_grads, want_normal_grads=needs_normal_grad,
             want_diffuse_grads=needs_diffuse_grad,
             want_clip_grads=needs_transform_grad,   # d clip on its own only feeds d transforms below
-            prepared=prepared if use_prepared else None,
+            prepared=prepared if use_prepared else None, empty_regions=empty_regions,
             normalised_gbuffer=True)   # this function's own forward wrote ids / bary
         dxf = None
         if needs_transform_grad:  # d clip[b,v,r] / d xf[b,r,k] = (vertex, 1)[k]
@@ -256,7 +262,7 @@ class FusedPhongRenderer(torch.autograd.Function):
                                                 any(ctx.needs_input_grad[5:8]), drgba.contiguous(),
                                                 needs_normal_grad=ctx.needs_input_grad[2],
                                                 needs_diffuse_grad=ctx.needs_input_grad[3],
-                                                prepared_state=ctx.prepared_state)
+                                                prepared_state=ctx.prepared_state, empty_regions=ctx.empty_regions)
         return grads + (None, None)
 
 
@@ -268,7 +274,8 @@ _fused_renders = weakref.WeakKeyDictionary()
 
 def remember_fused_render(node, inputs):
     _fused_renders[node] = {"saved": tuple(node.saved_tensors), "inputs": inputs,
-                            "prepared_state": getattr(node, "prepared_state", None)}
+                            "prepared_state": getattr(node, "prepared_state", None),
+                            "empty_regions": getattr(node, "empty_regions", None)}
 
 
 def take_fused_render(image):
@@ -286,6 +293,23 @@ def take_fused_render(image):
         return None
 
 
+def _target_empty_regions(target):
+    """image_empty_regions(target), kept on the tensor object while its data pointer and version do not change
+    (an optimisation loop compares every step's render with the same target)."""
+    if target.dim() != 4 or target.shape[-1] != 4 or target.dtype != torch.float32 or not target.is_cuda:
+        return None
+    key = (target.data_ptr(), target._version, tuple(target.shape))
+    kept = getattr(target, "_mr_empty_regions", None)
+    if kept is not None and kept[0] == key:
+        return kept[1]
+    found = _native.image_empty_regions(target.detach())
+    try:
+        target._mr_empty_regions = (key, found)
+    except AttributeError:   # (a tensor subclass without a __dict__)
+        pass
+    return found
+
+
 class FusedPhongL1Loss(torch.autograd.Function):
     """mean|image - target| for an `image` that FusedPhongRenderer produced, differentiated straight
     to the renderer's inputs: the backward hands the loss's 1-byte-per-pixel sign codes to the
@@ -295,10 +319,15 @@ class FusedPhongL1Loss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, image, target, vertices, transforms, normals, diffuse, light_positions,
-                light_intensities, ambient, render_saved, prepared_state=None):
-        loss, signs = _native.l1_loss_forward(image.detach(), target.detach(), want_signs=True)
+                light_intensities, ambient, render_saved, prepared_state=None, empty_regions=None):
+        # the renderer knows which 64 x 64 blocks of its image are empty; the target's are found once per target
+        # tensor (cached on it by value of its version counter): blocks empty on both sides are not read
+        empty_target = _target_empty_regions(target) if empty_regions is not None else None
+        loss, signs = _native.l1_loss_forward(image.detach(), target.detach(), want_signs=True,
+                                              empty_a=empty_regions, empty_b=empty_target)
         ctx.image_shape = image.shape
         ctx.prepared_state = prepared_state
+        ctx.empty_regions = empty_regions
         # the renderer's own saved tensors (G-buffer, corner records, adjacency, ...): held here too,
         # because the renderer's node frees its copies as soon as the image tensor is dropped
         ctx.save_for_backward(signs, *render_saved)
@@ -311,11 +340,11 @@ class FusedPhongL1Loss(torch.autograd.Function):
         dverts, dxf, dn, dd, _, dlp, dli, damb = FusedPhongRenderer._input_grads(
             ctx.saved_tensors[1:], ctx.needs_input_grad[3], any(ctx.needs_input_grad[6:9]), upstream,
             l1_signs=signs, needs_normal_grad=ctx.needs_input_grad[4], needs_diffuse_grad=ctx.needs_input_grad[5],
-            prepared_state=ctx.prepared_state)
+            prepared_state=ctx.prepared_state, empty_regions=ctx.empty_regions)
         dtarget = None
         if ctx.needs_input_grad[1]:
             dtarget = -_native.l1_loss_backward(signs, ctx.image_shape, upstream)
-        return None, dtarget, dverts, dxf, dn, dd, dlp, dli, damb, None, None
+        return None, dtarget, dverts, dxf, dn, dd, dlp, dli, damb, None, None, None
 
 
 class FusedSpecularPhongRenderer(torch.autograd.Function):

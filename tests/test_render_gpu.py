@@ -4,6 +4,7 @@ Counterparts of the reference's rasterize_triangles_test.py and mesh_renderer_te
 (golden-image, Jacobian and optimisation tests) plus float goldens captured from the
 reference (tools/make_goldens.py).  Bar: RGBA and gradients within 1e-4 abs.
 """
+import math
 import os
 import sys
 
@@ -1322,6 +1323,110 @@ def test_fused_render_l1_loss_matches_generic_loss(device, ambient, target_grad)
         got = results[True][1][k]
         assert np.abs(want).max() > 0, k
         np.testing.assert_allclose(got, want, atol=1e-9, rtol=2e-4, err_msg=k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("h,w", [(256, 320), (130, 200), (64, 64), (70, 50), (1, 3)])
+def test_l1_loss_over_empty_block_maps_matches_the_flat_loss(device, h, w):
+    """Round 4: mr_image_empty_regions / mr_l1_loss_forward_regions.  A 64 x 64 block (counted from the image's last
+    row up, the G-buffer's row order) that is whole and all zeros (-0.0 included) on both sides is not read: same
+    loss (another fixed summation order: 1e-6 relative), byte-identical sign codes, ragged edges never skipped, and
+    a NaN in the target keeps its block in play."""
+    from pytorch_mesh_renderer_amd import _native
+    gen = torch.Generator().manual_seed(h * 1000 + w)
+    a = torch.rand(2, h, w, 4, generator=gen) - 0.5
+    b = torch.rand(2, h, w, 4, generator=gen) - 0.5
+    by, bx = (h + 63) // 64, (w + 63) // 64
+    want_a = np.zeros((2, by, bx), np.uint8)
+    want_b = np.zeros((2, by, bx), np.uint8)
+    pick = np.random.RandomState(5)
+    for img in range(2):
+        for j in range(by):
+            for i in range(bx):
+                if (i + 1) * 64 > w or (j + 1) * 64 > h:
+                    continue
+                rows = slice(h - 64 * (j + 1), h - 64 * j)
+                kind = pick.randint(4)
+                if kind in (0, 1):
+                    a[img, rows, 64 * i:64 * i + 64] = 0.0
+                    want_a[img, j, i] = 1
+                if kind in (0, 2):
+                    b[img, rows, 64 * i:64 * i + 64] = -0.0 if (i + j) % 2 else 0.0
+                    want_b[img, j, i] = 1
+    a, b = a.to(device), b.to(device)
+    map_a, map_b = _native.image_empty_regions(a), _native.image_empty_regions(b)
+    assert np.array_equal(map_a.cpu().numpy(), want_a) and np.array_equal(map_b.cpu().numpy(), want_b)
+    flat, flat_signs = _native.l1_loss_forward(a, b)
+    got, got_signs = _native.l1_loss_forward(a, b, empty_a=map_a, empty_b=map_b)
+    assert abs(float(got) - float(flat)) <= 1e-6 * abs(float(flat))
+    assert abs(float(got) - float((a - b).abs().mean())) <= 1e-6 * abs(float(flat))
+    assert torch.equal(got_signs, flat_signs)
+    no_signs, none = _native.l1_loss_forward(a, b, want_signs=False, empty_a=map_a, empty_b=map_b)
+    assert none is None and float(no_signs) == float(got)
+    if h >= 64 and w >= 64:
+        # a NaN target pixel inside a block that is zero in the image: the target's map keeps the block
+        a[0, h - 64:h, 0:64] = 0.0
+        b[0, h - 64:h, 0:64] = 0.0
+        b[0, h - 10, 7, 2] = float("nan")
+        map_a, map_b = _native.image_empty_regions(a), _native.image_empty_regions(b)
+        assert int(map_a[0, 0, 0]) == 1 and int(map_b[0, 0, 0]) == 0
+        assert math.isnan(float(_native.l1_loss_forward(a, b, empty_a=map_a, empty_b=map_b)[0]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,batch", [(768, 768, 8), (448, 320, 2), (200, 150, 2)])
+def test_render_empty_block_map_serves_the_loss_and_the_backward(device, w, h, batch):
+    """Round 4: mr_render_forward's empty_regions map (1 = the 64 x 64 block had no candidate triangle).  Every
+    marked block is transparent black in the image (the map is conservative, so it is a subset of the image's own
+    map); with it the fused loss and the shading backward skip those blocks: the same loss to 1e-6 and the same
+    gradients as with ext.EMPTY_REGIONS = False."""
+    from pytorch_mesh_renderer_amd import _native
+    from pytorch_mesh_renderer_amd.mesh_renderer import rasterize_triangles_ext as ext
+    job = synthetic.sphere_job(batch, w, h, 12)
+    tris = job["triangles"].to(device)
+    target = torch.zeros(batch, h, w, 4)
+    target[:, h // 3:h // 2, w // 4:w // 2] = torch.rand(batch, h // 2 - h // 3, w // 2 - w // 4, 4,
+                                                        generator=torch.Generator().manual_seed(2))
+    target = target.to(device)
+    out = _native.render_forward(job["vertices"].to(device), synthetic.clip_transforms(job["eyes"], w, h).to(device),
+                                 job["normals"].to(device), job["diffuse"].to(device), tris,
+                                 job["light_positions"].to(device), job["light_intensities"].to(device), None, w, h,
+                                 want_empty_regions=True)
+    rgba, marked = out[4], out[-1]
+    assert marked.shape == (batch, (h + 63) // 64, (w + 63) // 64)
+    own = _native.image_empty_regions(rgba)
+    assert bool(((marked == 0) | (own == 1)).all()), "a block marked empty holds pixels"
+    if batch == 8:   # (64-pixel regions: smaller jobs run 32-pixel regions and mark nothing)
+        assert int(marked.sum()) > 0, "the scene leaves whole blocks empty"
+
+    def run(use_map, loss_kind):
+        before = ext.EMPTY_REGIONS
+        ext.EMPTY_REGIONS = use_map
+        try:
+            v = job["vertices"].clone().to(device).requires_grad_(True)
+            d = job["diffuse"].clone().to(device).requires_grad_(loss_kind == "l1-all")
+            img = mesh_renderer.render(v, tris, job["normals"].to(device), d, job["eyes"], torch.zeros(batch, 3),
+                                       torch.tensor([0.0, 1.0, 0.0]), job["light_positions"].to(device),
+                                       job["light_intensities"].to(device), w, h)
+            loss = (mesh_renderer.losses.l1_loss(img, target) if loss_kind.startswith("l1")
+                    else ((img - target) ** 2).mean())
+            loss.backward()
+            return float(loss), v.grad.clone(), (d.grad.clone() if d.grad is not None else None)
+        finally:
+            ext.EMPTY_REGIONS = before
+
+    for kind in ("l1", "l1-all", "mse"):
+        l0, gv0, gd0 = run(False, kind)
+        l1, gv1, gd1 = run(True, kind)
+        assert abs(l1 - l0) <= 1e-6 * abs(l0), kind
+        scale = float(gv0.abs().max())
+        assert scale > 0
+        # (the skipped strips add nothing; the per-triangle sums are float atomics, so not bit for bit)
+        np.testing.assert_allclose(gv1.cpu().numpy(), gv0.cpu().numpy(), rtol=1e-4, atol=1e-6 * scale, err_msg=kind)
+        assert (gd0 is None) == (gd1 is None)
+        if gd0 is not None:
+            np.testing.assert_allclose(gd1.cpu().numpy(), gd0.cpu().numpy(), rtol=1e-4,
+                                       atol=1e-6 * float(gd0.abs().max()), err_msg=kind)
 
 
 def test_l1_loss_on_a_derived_image_takes_the_generic_path(device):
