@@ -336,9 +336,30 @@ int mr_shade_backward_l1(const uint8_t *signs, const float *upstream, const int3
  *                                 gathered per vertex (no atomics, every output written once, fixed
  *                                 order) instead of scattered with float atomics; required in the
  *                                 deterministic mode
+ *   transforms, gbuffer_flags, grads_wanted (backward, round 4)
+ *                                 grads_wanted: MR_GRAD_* bits of the gradients the caller will read; an
+ *                                 output whose bit is clear still has to be a valid buffer and holds
+ *                                 unspecified values afterwards (MR_GRAD_ALL: everything, as before).
+ *                                 When only MR_GRAD_POSITIONS / MR_GRAD_CLIP are wanted -- render()
+ *                                 differentiated to the vertices alone -- and gbuffer_flags has
+ *                                 MR_GBUFFER_NORMALISED (see mr_shade_backward) and the deterministic mode is
+ *                                 off, the pixel pass keeps its 18 sums per triangle in registers down each
+ *                                 lane's vertical run instead of reducing 45 through LDS per pixel
+ *                                 (0.64 -> 0.3x ms at 1024^2 x 32).  transforms ([B,4,4], clip = M (position,
+ *                                 1)) or NULL: with them and MR_GRAD_CLIP clear the pull-back M^T dclip is
+ *                                 folded into dpositions, which is then the whole gradient w.r.t. the
+ *                                 world-space vertices (9 sums).
  * Only pixels that pass render()'s mask (render.py:215) evaluate the power; the reference's
  * autograd multiplies the masked pixels' zero gradient by pow(0, -1) = inf of the background
  * exponent -1 and returns NaN for every per-vertex-shininess call with a background pixel. */
+#define MR_GRAD_NORMALS 1
+#define MR_GRAD_POSITIONS 2
+#define MR_GRAD_DIFFUSE 4
+#define MR_GRAD_SPECULAR 8
+#define MR_GRAD_SHININESS 16   /* per-vertex (dshininess) or per-image (light_grads' last column) */
+#define MR_GRAD_LIGHTS 32      /* light_grads: light positions / intensities, ambient, camera position */
+#define MR_GRAD_CLIP 64
+#define MR_GRAD_ALL 127
 size_t mr_shade_specular_forward_workspace_bytes(int B, int V, int T, int W, int H);
 int mr_shade_specular_forward(const int32_t *ids, const float *bary, const float *normals,
                               const float *positions, const float *diffuse, const float *specular,
@@ -359,8 +380,8 @@ int mr_shade_specular_backward(const float *drgba, const int32_t *ids, const flo
                                int W, int H, int L, float *dclip, float *dnormals, float *dpositions,
                                float *ddiffuse, float *dspecular, float *dshininess,
                                float *light_grads, const int32_t *vertex_offsets,
-                               const int32_t *vertex_entries, void *workspace, size_t workspace_bytes,
-                               void *stream);
+                               const int32_t *vertex_entries, const float *transforms, int gbuffer_flags,
+                               int grads_wanted, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- SoftRas renderer ---------------------------------------------------------------
  * Replaces rasterize_batch / rasterize of the reference's second renderer

@@ -16,7 +16,7 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 # build libmesh_raster_hip_probes.so this way); the product always loads the in-tree library.
 LIB_PATH = os.environ.get("MR_NATIVE_LIB_PATH") or os.path.join(_CSRC, "libmesh_raster_hip.so")
 
-ABI_VERSION = 351
+ABI_VERSION = 352
 GBUFFER_NORMALISED = 1   # mesh_raster.h, MR_GBUFFER_NORMALISED
 TIMER_RASTER_FORWARD, TIMER_SHADE_BACKWARD, TIMER_SHADE_FORWARD, TIMER_RASTER_BACKWARD, TIMER_L1_FORWARD = 0, 1, 2, 3, 4
 MR_OK, MR_EINVAL, MR_EWORKSPACE, MR_ELAUNCH = 0, -1, -2, -3
@@ -218,7 +218,7 @@ def lib():
         L.mr_shade_specular_forward.restype = ci
         L.mr_shade_specular_backward_workspace_bytes.argtypes = [ci] * 5
         L.mr_shade_specular_backward_workspace_bytes.restype = sz
-        L.mr_shade_specular_backward.argtypes = [vp] * 14 + [ci, vp] + [ci] * 6 + [vp] * 7 + [vp, vp] + [vp, sz, vp]
+        L.mr_shade_specular_backward.argtypes = [vp] * 14 + [ci, vp] + [ci] * 6 + [vp] * 7 + [vp, vp] + [vp, ci, ci] + [vp, sz, vp]
         L.mr_shade_specular_backward.restype = ci
         L.mr_export_u8.argtypes = [vp, sz, vp, vp]
         L.mr_export_u8.restype = ci
@@ -845,13 +845,24 @@ def shade_specular_forward(ids, bary, normals, positions, diffuse, specular, tri
     return rgba, norms2
 
 
+# grads_wanted bits of shade_specular_backward (include/mesh_raster.h: MR_GRAD_*)
+GRAD_NORMALS, GRAD_POSITIONS, GRAD_DIFFUSE, GRAD_SPECULAR, GRAD_SHININESS, GRAD_LIGHTS, GRAD_CLIP = 1, 2, 4, 8, 16, 32, 64
+GRAD_ALL = 127
+
+
 def shade_specular_backward(drgba, ids, bary, clip, normals, positions, diffuse, specular, triangles,
                             light_positions, light_intensities, ambient, camera_position, shininess,
-                            norms2, adjacency=None):
+                            norms2, adjacency=None, transforms=None, normalised_gbuffer=False,
+                            grads_wanted=GRAD_ALL):
     """-> (dclip [B,V,4], dnormals, dpositions, ddiffuse, dspecular [B,V,3], dlight_positions,
     dlight_intensities [B,L,3], dambient [B,3] or None, dcamera_position [B,3], dshininess shaped
     like shininess ([B] or [B,V])).  adjacency: vertex_adjacency(triangles, V) -- the per-triangle
-    sums are then gathered per vertex (no atomics; required by the deterministic mode)."""
+    sums are then gathered per vertex (no atomics; required by the deterministic mode).
+
+    grads_wanted: GRAD_* bits of the results the caller will read (the others come back unspecified).  With only
+    GRAD_POSITIONS / GRAD_CLIP wanted and normalised_gbuffer=True (ids / bary are rasterize_forward's own output
+    for `clip`) the pixel pass is the lane-accumulating kernel; with transforms ([B,4,4], clip = M (position, 1))
+    and GRAD_CLIP not wanted, dpositions is the whole gradient w.r.t. the world-space vertices."""
     tensors = [drgba, ids, bary, clip, normals, positions, diffuse, specular, triangles,
                light_positions, light_intensities, camera_position, shininess, norms2]
     B, V, _ = _chk_mesh(clip, triangles)
@@ -878,6 +889,10 @@ def shade_specular_backward(drgba, ids, bary, clip, normals, positions, diffuse,
     if adjacency is not None:
         _chk("adjacency offsets", adjacency[0], _I32, V + 1)
         _chk("adjacency entries", adjacency[1], _I32, None)
+    if transforms is not None:
+        _chk("transforms", transforms, _F32, B, 4, 4)
+        _require_device(transforms)
+        transforms = transforms.contiguous()
     with torch.cuda.device(dev):
         _sync_deterministic()
         need = L.mr_shade_specular_backward_workspace_bytes(B, V, T, W, H)
@@ -888,7 +903,8 @@ def shade_specular_backward(drgba, ids, bary, clip, normals, positions, diffuse,
             _ptr(light_intensities), _ptr(ambient), _ptr(camera_position), _ptr(shininess),
             int(per_vertex), _ptr(norms2), B, V, T, W, H, nl, _ptr(dclip), _ptr(dn), _ptr(dp), _ptr(dd),
             _ptr(dsp), _ptr(dshin_v), _ptr(lg), _ptr(adjacency[0]) if adjacency is not None else None,
-            _ptr(adjacency[1]) if adjacency is not None else None, _ptr(ws), have, _stream(dev))
+            _ptr(adjacency[1]) if adjacency is not None else None, _ptr(transforms),
+            GBUFFER_NORMALISED if normalised_gbuffer else 0, int(grads_wanted), _ptr(ws), have, _stream(dev))
     _check(rc, "mr_shade_specular_backward")
     dlpos = lg[:, :3 * nl].reshape(B, nl, 3)
     dlint = lg[:, 3 * nl:6 * nl].reshape(B, nl, 3)

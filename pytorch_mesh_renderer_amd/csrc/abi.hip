@@ -31,7 +31,7 @@ extern thread_local int g_shade_backward_kernel;
 
 extern "C" {
 
-int mr_version(void) { return 351; /* 0.5.0: dclip optional, backward_prepared / prepared, mr_debug_soft_nearest, two's-complement sign codes */ }
+int mr_version(void) { return 352; /* 0.5.0: dclip optional, backward_prepared / prepared, mr_debug_soft_nearest, two's-complement sign codes */ }
 
 int mr_last_hip_error(void) { return mr::g_last_hip_error; }
 
@@ -395,10 +395,11 @@ int mr_shade_specular_backward(const float *drgba, const int32_t *ids, const flo
                                int W, int H, int L, float *dclip, float *dnormals, float *dpositions,
                                float *ddiffuse, float *dspecular, float *dshininess,
                                float *light_grads, const int32_t *vertex_offsets,
-                               const int32_t *vertex_entries, void *workspace, size_t workspace_bytes,
-                               void *stream) {
+                               const int32_t *vertex_entries, const float *transforms, int gbuffer_flags,
+                               int grads_wanted, void *workspace, size_t workspace_bytes, void *stream) {
   if (bad_dims(B, V, T, W, H) || T < 1 || V < 1 || L < 1 || L > mr::shade_light_gradient_max_lights())
     return MR_EINVAL;
+  if ((gbuffer_flags & ~MR_GBUFFER_NORMALISED) != 0 || (grads_wanted & ~MR_GRAD_ALL) != 0) return MR_EINVAL;
   if ((vertex_offsets == nullptr) != (vertex_entries == nullptr)) return MR_EINVAL;
   if (vertex_offsets && ((uintptr_t)dclip & 15u) != 0) return MR_EINVAL;
   if (B == 0) return MR_OK;
@@ -414,7 +415,8 @@ int mr_shade_specular_backward(const float *drgba, const int32_t *ids, const flo
                                             ambient, camera_position, shininess, shininess_per_vertex,
                                             norms2, B, V, T, W, H, L, dclip, dnormals, dpositions,
                                             ddiffuse, dspecular, dshininess, light_grads, vertex_offsets,
-                                            vertex_entries, workspace, (hipStream_t)stream);
+                                            vertex_entries, transforms, gbuffer_flags, grads_wanted, workspace,
+                                            (hipStream_t)stream);
 }
 
 int mr_soft_max_lights(void) { return mr::soft_max_lights(); }

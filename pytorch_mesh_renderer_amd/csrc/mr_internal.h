@@ -169,7 +169,8 @@ int launch_shade_specular_backward(const float *drgba, const int32_t *ids, const
                                    const float *norms2, int B, int V, int T, int W, int H, int L, float *dclip,
                                    float *dnormals, float *dpositions, float *ddiffuse, float *dspecular,
                                    float *dshininess, float *light_grads, const int32_t *vertex_offsets,
-                                   const int32_t *vertex_entries, void *ws, hipStream_t s);
+                                   const int32_t *vertex_entries, const float *transforms, int gbuffer_flags,
+                                   int grads_wanted, void *ws, hipStream_t s);
 int launch_l1_forward(const float *a, const float *b, size_t n, float *out, uint8_t *signs, float *partials,
                       hipStream_t s);
 int launch_l1_backward(const uint8_t *signs, size_t n, const float *upstream, float *da, hipStream_t s);

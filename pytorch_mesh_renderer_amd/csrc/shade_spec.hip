@@ -38,6 +38,9 @@
 #ifndef MR_SPEC_NT
 #define MR_SPEC_NT 1  // nontemporal access to the streamed planes
 #endif
+#ifndef MR_SPEC_LANES
+#define MR_SPEC_LANES 1  // 0: the backward's pixel pass always runs the rows kernel (A/B)
+#endif
 
 namespace mr {
 extern thread_local int g_deterministic;  // mr_set_deterministic (shade.hip)
@@ -469,8 +472,11 @@ struct SpecGradFn {
   // Back-propagates (g = dLoss/d rgb of this pixel, plus the norm coupling) to the interpolated
   // attributes `dat`, accumulating light / ambient / camera gradients in `im` scaled by `weight`.
   // `shaded` = the pixel passed the render.py:215 mask; the others have g = 0 and only feel the norm.
+  // SUMS = false (the lane kernel below, which serves callers that want no image-wide gradient): those sums are
+  // not formed.
+  template <bool SUMS = true, class Im = Image>
   __device__ __forceinline__ void shade_backward(const float (&at)[kA], const float (&g)[3], bool shaded,
-                                                 float weight, Image &im, float (&dat)[kA]) const {
+                                                 float weight, Im &im, float (&dat)[kA]) const {
     const SpecScene<L> &sc = im.sc;
     float dshin = 0.f;
     PixelFrame f;
@@ -479,7 +485,8 @@ struct SpecGradFn {
     float dKd[3] = {g[0] * sc.amb[0], g[1] * sc.amb[1], g[2] * sc.amb[2]};
     float dKs[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-    for (int c = 0; c < 3; ++c) im.damb[c] += weight * g[c] * at[6 + c];
+    for (int c = 0; c < 3; ++c)
+      if constexpr (SUMS) im.damb[c] += weight * g[c] * at[6 + c];
 #pragma unroll
     for (int l = 0; l < L; ++l) {
       LightTerm lt;
@@ -491,7 +498,7 @@ struct SpecGradFn {
       for (int c = 0; c < 3; ++c) {
         dKd[c] += g[c] * lt.ndl * sc.li[l][c];
         dKs[c] += g[c] * st.spec * sc.li[l][c];
-        im.dcol[l][c] += weight * g[c] * (at[6 + c] * lt.ndl + at[9 + c] * st.spec);
+        if constexpr (SUMS) im.dcol[l][c] += weight * g[c] * (at[6 + c] * lt.ndl + at[9 + c] * st.spec);
         t_l += g[c] * at[6 + c] * sc.li[l][c];
         dspec += g[c] * at[9 + c] * sc.li[l][c];
       }
@@ -532,7 +539,7 @@ struct SpecGradFn {
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const float dv = (lt.vn > kNormEps ? (dD[k] - lt.D[k] * dd) : dD[k]) * lt.inv_vn;
-        im.dpos[l][k] += weight * dv;
+        if constexpr (SUMS) im.dpos[l][k] += weight * dv;
         dP[k] -= dv;
       }
     }
@@ -543,7 +550,7 @@ struct SpecGradFn {
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const float dc = (f.cn > kNormEps ? (dCd[k] - f.Cd[k] * dc_dot) : dCd[k]) * f.inv_cn;
-        im.dcam[k] += weight * dc;
+        if constexpr (SUMS) im.dcam[k] += weight * dc;
         dP[k] -= dc;
       }
     }
@@ -557,7 +564,7 @@ struct SpecGradFn {
         dat[9 + c] = dKs[c];
       }
       if (PV) dat[kA - 1] = dshin;
-      else im.dshin += weight * dshin;
+      else if constexpr (SUMS) im.dshin += weight * dshin;
     }
   }
 
@@ -626,6 +633,167 @@ struct SpecGradFn {
     }
     reduce_add(PV ? 0.0f : im.dshin, L * 6 + 6);
   }
+};
+
+// ---- the same pass for callers that want the VERTEX gradients only (round 4) ----------------------------------
+// render() differentiated to the vertices alone -- the optimisation loops of the reference's tests -- needs, of the
+// 45 sums per triangle above, the nine of the position attribute and the nine clip-space ones, and none of the
+// image-wide sums (lights, camera, per-image shininess).  That fits k_accumulate_lanes (run_accum.h: the sums stay
+// in registers down a lane's vertical run; the rows kernel spends one LDS reduction step per pixel), in the
+// difference basis of shade.hip's ShadeFoldLaneFn: for a G-buffer whose barycentrics sum to 1 (MR_GBUFFER_NORMALISED:
+// alpha = 1, nothing flows through it)
+//   at = c2 + b0 e0 + b1 e1,  dat = shade_backward(at, g),  g0 = dat . e0,  g1 = dat . e1,
+//   q_c = (g0 (s_c b0 - u_0c) + g1 (s_c b1 - u_1c)) / |det|          (cpp:202-269 less the common shift d L / d b2)
+//   a[k][c] += b_k dat[3 + c]   and   a[9 + k][c] += b_k q_c,
+// or, FOLD (the caller has the transforms M with clip = M (position, 1) and wants no clip gradient of its own):
+//   a[k][c] += b_k (dat[3 + c] + (M^T q)_c), nine sums.
+// Record per (image, triangle): e0[A] e1[A] c2[A] | u0[3] u1[3] s[3] 1/|det|  (3 A + 10 floats, 192 / 208 bytes).
+template <int A>
+struct alignas(16) SpecFoldRec {
+  static constexpr int kFloats = 3 * A + 10;
+  static constexpr int kQuads = (kFloats + 3) / 4;
+  float4 q[kQuads];
+};
+template <int A>
+struct SpecFoldTriangle {
+  float e0[A], e1[A], c2[A], u0[3], u1[3], s[3], inv;
+};
+template <int A>
+__device__ __forceinline__ void load_spec_fold_triangle(const SpecFoldRec<A> *__restrict__ rec, SpecFoldTriangle<A> &t) {
+  float v[4 * SpecFoldRec<A>::kQuads];
+#pragma unroll
+  for (int q = 0; q < SpecFoldRec<A>::kQuads; ++q) {
+    const float4 f = rec->q[q];
+    v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w;
+  }
+#pragma unroll
+  for (int a = 0; a < A; ++a) { t.e0[a] = v[a]; t.e1[a] = v[A + a]; t.c2[a] = v[2 * A + a]; }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { t.u0[c] = v[3 * A + c]; t.u1[c] = v[3 * A + 3 + c]; t.s[c] = v[3 * A + 6 + c]; }
+  t.inv = v[3 * A + 9];
+}
+
+// One thread per (image, triangle): SpecFoldRec from the corner record and the clip-space corners (the sign-corrected
+// adjugate, its column sums and 1 / |det| exactly as k_bwd_setup forms them, rasterize_triangles.cpp:180-198).
+template <int A>
+__global__ __launch_bounds__(kThreads) void k_spec_fold_setup(const float4 *__restrict__ clip, const int32_t *__restrict__ tris,
+                                                              const SpecCornerRec<A> *__restrict__ corners, int B, int V,
+                                                              int T, SpecFoldRec<A> *__restrict__ out) {
+  const long gid = (long)blockIdx.x * kThreads + threadIdx.x;
+  if (gid >= (long)B * T) return;
+  const int b = (int)(gid / T);
+  const int t = (int)(gid - (long)b * T);
+  SpecCorners<A> cr;
+  load_spec_corners(corners + gid, cr);
+  float v[4 * SpecFoldRec<A>::kQuads];
+#pragma unroll
+  for (int a = 0; a < A; ++a) {
+    v[a] = cr.c[0][a] - cr.c[2][a];
+    v[A + a] = cr.c[1][a] - cr.c[2][a];
+    v[2 * A + a] = cr.c[2][a];
+  }
+#pragma unroll
+  for (int k = 3 * A; k < 4 * SpecFoldRec<A>::kQuads; ++k) v[k] = 0.0f;   // a triangle with a foreign corner is never drawn
+  const int i0 = tris[3 * t], i1 = tris[3 * t + 1], i2 = tris[3 * t + 2];
+  if ((unsigned)i0 < (unsigned)V && (unsigned)i1 < (unsigned)V && (unsigned)i2 < (unsigned)V) {
+#pragma clang fp contract(off)   // the adjugate's differences of products round as in k_bwd_setup (raster_backward.hip)
+    const float4 p0 = clip[(long)b * V + i0], p1 = clip[(long)b * V + i1], p2 = clip[(long)b * V + i2];
+    const float a11 = p0.x, a12 = p1.x, a13 = p2.x;
+    const float a21 = p0.y, a22 = p1.y, a23 = p2.y;
+    const float a31 = p0.w, a32 = p1.w, a33 = p2.w;
+    float u0 = a22 * a33 - a32 * a23, u1 = a13 * a32 - a33 * a12, u2 = a12 * a23 - a22 * a13;
+    float u3 = a23 * a31 - a33 * a21, u4 = a11 * a33 - a31 * a13, u5 = a13 * a21 - a23 * a11;
+    float u6 = a21 * a32 - a31 * a22, u7 = a12 * a31 - a32 * a11, u8 = a11 * a22 - a21 * a12;
+    const float det = a11 * u0 + a12 * u3 + a13 * u6;
+    if (det < 0.0f) {
+      u0 = -u0; u1 = -u1; u2 = -u2; u3 = -u3; u4 = -u4; u5 = -u5; u6 = -u6; u7 = -u7; u8 = -u8;
+    }
+    v[3 * A + 0] = u0; v[3 * A + 1] = u1; v[3 * A + 2] = u2;
+    v[3 * A + 3] = u3; v[3 * A + 4] = u4; v[3 * A + 5] = u5;
+    v[3 * A + 6] = (u0 + u3) + u6; v[3 * A + 7] = (u1 + u4) + u7; v[3 * A + 8] = (u2 + u5) + u8;   // cpp:187-198
+    v[3 * A + 9] = 1.0f / fabsf(det);
+  }
+#pragma unroll
+  for (int q = 0; q < SpecFoldRec<A>::kQuads; ++q)
+    out[gid].q[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+}
+
+#ifndef MR_SPEC_LANE_ROWS
+#define MR_SPEC_LANE_ROWS 8
+#endif
+#ifndef MR_SPEC_LANE_WAVES
+#define MR_SPEC_LANE_WAVES 3
+#endif
+template <int L, bool PV, bool FOLD>
+struct SpecFoldLaneFn : SpecGradFn<L, PV> {
+  using Base = SpecGradFn<L, PV>;
+  static constexpr int kA = Base::kA;
+  static constexpr int kN = FOLD ? 9 : 18;
+  static constexpr int kStride = Base::kStride;   // the rows of acc keep SpecGradFn's layout: k_spec_gather reads them
+  static constexpr int kLaneRowsPerWave = MR_SPEC_LANE_ROWS;
+  static constexpr int kMinWavesPerSimd = L <= 2 ? MR_SPEC_LANE_WAVES : 2;   // (three or four lights at 168 registers: spills)
+  static constexpr bool kCountBackground = false;   // (background pixels only feed the image-wide sums)
+  const SpecFoldRec<kA> *__restrict__ fold_recs;
+  const float *__restrict__ transforms;   // FOLD: [B,4,4]
+  using Triangle = SpecFoldTriangle<kA>;
+  struct Image {
+    SpecScene<L> sc;
+    float pull[3][3];   // FOLD: pull[r][c] = M[{0, 1, 3}[r]][c], the clip x / y / w rows' position columns
+    int n_bg;           // unused
+  };
+  // sum o = corner * 3 + c -> position attribute, acc column corner * kA + 3 + c;  o = 9 + corner * 3 + c -> clip
+  __device__ static int column(int o) {
+    return o < 9 ? (o / 3) * kA + 3 + o % 3 : 3 * kA + (o - 9);
+  }
+  __device__ __forceinline__ void begin_image(int img, Image &im) const {
+    load_scene(this->scene_in, img, im.sc);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) im.pull[r][c] = FOLD ? transforms[(size_t)img * 16 + (r == 2 ? 3 : r) * 4 + c] : 0.f;
+    im.n_bg = 0;
+  }
+  __device__ __forceinline__ void load_triangle(int img, int tri, Triangle &t) const {
+    load_spec_fold_triangle(fold_recs + (size_t)img * this->T_ + tri, t);
+  }
+  __device__ __forceinline__ void accumulate(const typename Base::Pixel &p, const Triangle &t, float (&a)[kN],
+                                             Image &im) const {
+    float at[kA], dat[kA];
+#pragma unroll
+    for (int k = 0; k < kA; ++k) at[k] = fmaf(p.b.x, t.e0[k], fmaf(p.b.y, t.e1[k], t.c2[k]));
+    const bool mask = (at[6] >= 0.0f) || (at[7] >= 0.0f) || (at[8] >= 0.0f);   // render.py:215
+    const float g[3] = {mask ? p.g.x : 0.f, mask ? p.g.y : 0.f, mask ? p.g.z : 0.f};
+    Base::template shade_backward<false>(at, g, mask, 1.0f, im, dat);
+    float g0 = 0.f, g1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < kA; ++k) {
+      g0 = fmaf(dat[k], t.e0[k], g0);
+      g1 = fmaf(dat[k], t.e1[k], g1);
+    }
+    float q[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float w0 = t.s[c] * p.b.x - t.u0[c];
+      const float w1 = t.s[c] * p.b.y - t.u1[c];
+      q[c] = (g0 * w0 + g1 * w1) * t.inv;
+    }
+    float y[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      y[c] = FOLD ? dat[3 + c] + ((im.pull[0][c] * q[0] + im.pull[1][c] * q[1]) + im.pull[2][c] * q[2]) : dat[3 + c];
+    const float b[3] = {p.b.x, p.b.y, p.b.z};
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) a[k * 3 + c] = fmaf(b[k], y[c], a[k * 3 + c]);
+    if (!FOLD) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a[9 + k * 3 + c] = fmaf(b[k], q[c], a[9 + k * 3 + c]);
+    }
+  }
+  __device__ __forceinline__ void end_strip(int, int, Image &) const {}
 };
 
 template <int A>
@@ -799,9 +967,14 @@ int spec_backward(const float *drgba, const int32_t *ids, const float *bary, con
                   const float *camera, const float *shininess, const float *norms2, int B, int V, int T, int W,
                   int H, int L, float *dclip, float *dnormals, float *dpositions, float *ddiffuse,
                   float *dspecular, float *dshininess, float *light_grads, const int32_t *vertex_offsets,
-                  const int32_t *vertex_entries, void *ws, hipStream_t s) {
+                  const int32_t *vertex_entries, const float *transforms, int gbuffer_flags, int grads_wanted,
+                  void *ws, hipStream_t s) {
   constexpr int A = attr_count(PV);
   const bool det = g_deterministic != 0;
+  // the lane kernel (SpecFoldLaneFn): vertex gradients only, a normalised G-buffer, float atomics
+  const bool lanes = MR_SPEC_LANES && !det && (gbuffer_flags & MR_GBUFFER_NORMALISED) != 0 &&
+                     (grads_wanted & ~(MR_GRAD_POSITIONS | MR_GRAD_CLIP)) == 0;
+  const bool fold = lanes && transforms && (grads_wanted & MR_GRAD_CLIP) == 0;
   if (det && !(vertex_offsets && vertex_entries)) return MR_EINVAL;  // the scatter path is float atomics only
   char *p = (char *)ws;
   float *acc = (float *)p;
@@ -817,15 +990,25 @@ int spec_backward(const float *drgba, const int32_t *ids, const float *bary, con
   float *light_rows = (float *)p;
   p += spec_light_rows_bytes(B, W, H);
   float *det_block = (float *)p;
+  p += kDetBlockBytes;
+  SpecFoldRec<A> *fold_recs = (SpecFoldRec<A> *)p;
   if (hipMemsetAsync(acc, 0, (size_t)B * T * 48 * (det ? sizeof(long long) : sizeof(float)), s) != hipSuccess)
     return check_launch();
   int rc = MR_OK;
   if (det && (rc = launch_det_scale(drgba, (size_t)B * H * W * 4, 1.0f, det_block, s)) != MR_OK) return rc;
-  rc = launch_bwd_setup(clip, tris, B, V, T, recs, s);
-  if (rc != MR_OK) return rc;
+  if (!lanes) {
+    rc = launch_bwd_setup(clip, tris, B, V, T, recs, s);
+    if (rc != MR_OK) return rc;
+  }
   rc = launch_spec_corner_setup<PV>(normals, positions, diffuse, specular, PV ? shininess : nullptr, tris, B, V, T,
                                     corners, s);
   if (rc != MR_OK) return rc;
+  if (lanes) {
+    const long nbt = (long)B * T;
+    hipLaunchKernelGGL((k_spec_fold_setup<A>), dim3((unsigned)((nbt + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
+                       (const float4 *)clip, tris, (const SpecCornerRec<A> *)corners, B, V, T, fold_recs);
+    if ((rc = check_launch()) != MR_OK) return rc;
+  }
   SpecSceneIn scene{light_pos, light_col, ambient, camera, PV ? nullptr : shininess, norms2, nullptr};
   rc = launch_spec_pixels<kGsum, PV>(L, ids, bary, corners, scene, B, T, W, H, drgba, nullptr, gsum, partials, s);
   if (rc != MR_OK) return rc;
@@ -836,17 +1019,40 @@ int spec_backward(const float *drgba, const int32_t *ids, const float *bary, con
                           recs, scene, light_rows, T, W, H};                                          \
     rc = launch_accumulate_rows(fn, B, T, W, H, acc, s, det ? det_block : nullptr);                   \
   }
-  switch (L) {
-    case 1: MR_SPEC_BWD(1); break;
-    case 2: MR_SPEC_BWD(2); break;
-    case 3: MR_SPEC_BWD(3); break;
-    case 4: MR_SPEC_BWD(4); break;
-    default: return MR_EINVAL;
+#define MR_SPEC_BWD_LANES(NL, FOLDED)                                                                    \
+  {                                                                                                      \
+    SpecFoldLaneFn<NL, PV, FOLDED> fn{{(const float4 *)drgba, ids, (const F3 *)bary, nullptr, nullptr, scene, \
+                                       nullptr, T, W, H}, fold_recs, transforms};                        \
+    rc = launch_accumulate_lanes(fn, B, T, W, H, acc, s);                                                \
+  }
+  if (lanes) {   // (the image-wide sums are not wanted: light_grads stays as the caller's launcher cleared it)
+    switch (L * 2 + (fold ? 1 : 0)) {
+      case 2: MR_SPEC_BWD_LANES(1, false); break;
+      case 3: MR_SPEC_BWD_LANES(1, true); break;
+      case 4: MR_SPEC_BWD_LANES(2, false); break;
+      case 5: MR_SPEC_BWD_LANES(2, true); break;
+      case 6: MR_SPEC_BWD_LANES(3, false); break;
+      case 7: MR_SPEC_BWD_LANES(3, true); break;
+      case 8: MR_SPEC_BWD_LANES(4, false); break;
+      case 9: MR_SPEC_BWD_LANES(4, true); break;
+      default: return MR_EINVAL;
+    }
+  } else {
+    switch (L) {
+      case 1: MR_SPEC_BWD(1); break;
+      case 2: MR_SPEC_BWD(2); break;
+      case 3: MR_SPEC_BWD(3); break;
+      case 4: MR_SPEC_BWD(4); break;
+      default: return MR_EINVAL;
+    }
   }
 #undef MR_SPEC_BWD
+#undef MR_SPEC_BWD_LANES
   if (rc != MR_OK) return rc;
-  rc = launch_sum_strip_rows(light_rows, B, strips_per_image<SpecGradFn<1, PV>>(W, H), L * 6 + 7, light_grads, s);
-  if (rc != MR_OK) return rc;
+  if (!lanes) {
+    rc = launch_sum_strip_rows(light_rows, B, strips_per_image<SpecGradFn<1, PV>>(W, H), L * 6 + 7, light_grads, s);
+    if (rc != MR_OK) return rc;
+  }
   if (vertex_offsets && vertex_entries) {
     const long nbv = (long)B * V * 16;  // sixteen lanes per vertex
     const dim3 grid((unsigned)((nbv + kThreads - 1) / kThreads));
@@ -889,7 +1095,8 @@ int launch_shade_specular_forward(const int32_t *ids, const float *bary, const f
 size_t shade_specular_backward_ws(int B, int V, int T, int W, int H) {
   (void)V;
   return spec_acc_bytes(B, T) + align_up((size_t)B * T * sizeof(BwdRec), 256) + spec_corner_bytes(B, T) +
-         spec_sums_bytes(B) + spec_partials_bytes(B, W, H) + spec_light_rows_bytes(B, W, H) + kDetBlockBytes;
+         spec_sums_bytes(B) + spec_partials_bytes(B, W, H) + spec_light_rows_bytes(B, W, H) + kDetBlockBytes +
+         align_up((size_t)B * T * sizeof(SpecFoldRec<kAttrMax>), 256);
 }
 
 int launch_shade_specular_backward(const float *drgba, const int32_t *ids, const float *bary,
@@ -900,7 +1107,8 @@ int launch_shade_specular_backward(const float *drgba, const int32_t *ids, const
                                    const float *norms2, int B, int V, int T, int W, int H, int L, float *dclip,
                                    float *dnormals, float *dpositions, float *ddiffuse, float *dspecular,
                                    float *dshininess, float *light_grads, const int32_t *vertex_offsets,
-                                   const int32_t *vertex_entries, void *ws, hipStream_t s) {
+                                   const int32_t *vertex_entries, const float *transforms, int gbuffer_flags,
+                                   int grads_wanted, void *ws, hipStream_t s) {
   if (B == 0) return MR_OK;
   const size_t v3 = (size_t)B * V * 3 * sizeof(float);
   const bool gathered = vertex_offsets && vertex_entries && T > 0 && (size_t)W * H > 0;  // every output written once
@@ -921,11 +1129,11 @@ int launch_shade_specular_backward(const float *drgba, const int32_t *ids, const
              ? spec_backward<true>(drgba, ids, bary, clip, normals, positions, diffuse, specular, tris, light_pos,
                                    light_col, ambient, camera, shininess, norms2, B, V, T, W, H, L, dclip,
                                    dnormals, dpositions, ddiffuse, dspecular, dshininess, light_grads,
-                                   vertex_offsets, vertex_entries, ws, s)
+                                   vertex_offsets, vertex_entries, transforms, gbuffer_flags, grads_wanted, ws, s)
              : spec_backward<false>(drgba, ids, bary, clip, normals, positions, diffuse, specular, tris, light_pos,
                                     light_col, ambient, camera, shininess, norms2, B, V, T, W, H, L, dclip,
                                     dnormals, dpositions, ddiffuse, dspecular, dshininess, light_grads,
-                                    vertex_offsets, vertex_entries, ws, s);
+                                    vertex_offsets, vertex_entries, transforms, gbuffer_flags, grads_wanted, ws, s);
 }
 
 }  // namespace mr

@@ -356,7 +356,12 @@ class FusedSpecularPhongRenderer(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, clip, positions, normals, diffuse, specular, triangles, light_positions,
-                light_intensities, ambient, camera_position, shininess, image_width, image_height):
+                light_intensities, ambient, camera_position, shininess, image_width, image_height,
+                transforms=None):
+        """transforms ([B,4,4], not differentiated here) or None: the caller vouches that
+        clip = transform_homogeneous(transforms, positions).  When the positions require a gradient and nothing
+        else but `clip` does, the backward then returns the WHOLE vertex gradient as d positions and None for
+        d clip (the pull-back through the transform is folded into the pixel pass)."""
         clip_d = clip.detach().contiguous()
         ids, bary, _ = _native.rasterize_forward(clip_d, triangles, int(image_width), int(image_height))
         attrs = [t.detach().contiguous() for t in (normals, positions, diffuse, specular)]
@@ -383,6 +388,9 @@ class FusedSpecularPhongRenderer(torch.autograd.Function):
         saved = [clip_d, ids, bary] + attrs + [triangles, lp, li, cam, shin, norms2, offsets, entries]
         if amb is not None:
             saved.append(amb)
+        ctx.has_transforms = transforms is not None
+        if transforms is not None:
+            saved.append(transforms.detach().to(torch.float32).contiguous())
         ctx.save_for_backward(*saved)
         ctx.has_ambient = amb is not None
         return rgba
@@ -393,6 +401,19 @@ class FusedSpecularPhongRenderer(torch.autograd.Function):
         clip, ids, bary, normals, positions, diffuse, specular, triangles, lp, li, cam, shin, norms2 = saved[:13]
         offsets, entries = saved[13:15]
         amb = saved[15] if ctx.has_ambient else None
+        transforms = saved[-1] if ctx.has_transforms else None
+        need = ctx.needs_input_grad   # clip, positions, normals, diffuse, specular, -, lpos, lint, ambient, camera, shininess
+        wanted = ((_native.GRAD_CLIP if need[0] else 0) | (_native.GRAD_POSITIONS if need[1] else 0)
+                  | (_native.GRAD_NORMALS if need[2] else 0) | (_native.GRAD_DIFFUSE if need[3] else 0)
+                  | (_native.GRAD_SPECULAR if need[4] else 0) | (_native.GRAD_SHININESS if need[10] else 0)
+                  | (_native.GRAD_LIGHTS if (need[6] or need[7] or need[8] or need[9]) else 0))
+        if need[10] and shin.dim() == 1:
+            wanted |= _native.GRAD_LIGHTS   # the per-image exponent's gradient rides the image-wide sums
+        # vertices alone: the transform's pull-back is folded in (see forward) and clip gets no gradient of its own
+        fold = (transforms is not None and need[0] and need[1]
+                and (wanted & ~(_native.GRAD_CLIP | _native.GRAD_POSITIONS)) == 0 and not _native.deterministic())
+        if fold:
+            wanted &= ~_native.GRAD_CLIP
         # per-vertex gather over the adjacency (round 3): no atomics, every output written once
         drgba = drgba.contiguous()
         step = _native.shade_fast_lights()
@@ -402,7 +423,8 @@ class FusedSpecularPhongRenderer(torch.autograd.Function):
                 drgba, ids, bary, clip, normals, positions, diffuse, specular, triangles,
                 lp[:, first:first + step].contiguous(), li[:, first:first + step].contiguous(),
                 amb if first == 0 else None, cam, shin, norms2[:, first:first + step].contiguous(),
-                adjacency=(offsets, entries))
+                adjacency=(offsets, entries), transforms=transforms if fold else None, normalised_gbuffer=True,
+                grads_wanted=wanted)
             if total is None:
                 total = list(part)
                 continue
@@ -411,4 +433,6 @@ class FusedSpecularPhongRenderer(torch.autograd.Function):
             total[5] = torch.cat([total[5], part[5]], 1)   # d light_positions / d light_intensities: per light
             total[6] = torch.cat([total[6], part[6]], 1)
         dclip, dn, dp, dd, dsp, dlp, dli, damb, dcam, dshin = total
-        return dclip, dp, dn, dd, dsp, None, dlp, dli, damb, dcam, dshin, None, None
+        if fold:
+            dclip = None
+        return dclip, dp, dn, dd, dsp, None, dlp, dli, damb, dcam, dshin, None, None, None

@@ -193,7 +193,8 @@ def _render_fused(vertices, triangles, normals, diffuse_colors, camera_position,
             light_positions.to(device), light_intensities.to(device).to(torch.float32),
             ambient_color.to(device) if ambient_color is not None else None,
             camera_position.to(device=device, dtype=torch.float32), shininess,
-            image_width, image_height)
+            image_width, image_height,
+            clip_space_transforms if not clip_space_transforms.requires_grad else None)
     lp, li = light_positions.to(device), light_intensities.to(device).to(torch.float32)
     amb = ambient_color.to(device) if ambient_color is not None else None
     transforms = clip_space_transforms.to(torch.float32)

@@ -765,6 +765,62 @@ def test_specular_backward_gather_matches_scatter(device):
                                        rtol=1e-4, err_msg="output %d" % i)
 
 
+@pytest.mark.parametrize("n_lights,per_vertex", [(1, False), (2, True), (3, False), (4, True)])
+def test_specular_backward_lane_kernel_matches_rows_kernel(device, n_lights, per_vertex):
+    """Round 4: mr_shade_specular_backward's grads_wanted.  With the vertex gradients alone wanted
+    (MR_GRAD_POSITIONS | MR_GRAD_CLIP) on the rasterizer's own G-buffer, the pixel pass is the lane-accumulating
+    kernel (SpecFoldLaneFn, 18 sums in a difference basis); with the transforms and no clip gradient wanted, the
+    pull-back is folded in (9 sums).  Same d clip / d positions as the rows kernel's 45-sum pass."""
+    from pytorch_mesh_renderer_amd import _native
+    job = synthetic.sphere_job(2, 200, 150, 12)
+    d = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in job.items()}
+    gen = torch.Generator().manual_seed(n_lights)
+    V = d["vertices"].shape[1]
+    spec = torch.rand(2, V, 3, generator=gen).to(device)
+    diffuse = torch.rand(2, V, 3, generator=gen).to(device)
+    lp = (torch.randn(2, n_lights, 3, generator=gen) * 3.0 + torch.tensor([0.0, 0.0, 4.0])).to(device)
+    li = (torch.rand(2, n_lights, 3, generator=gen) + 0.2).to(device)
+    amb = (torch.rand(2, 3, generator=gen) * 0.3).to(device)
+    xf = synthetic.clip_transforms(job["eyes"], 200, 150).to(device)
+    clip = _native.vertex_transform(d["vertices"], xf)
+    ids, bary, _ = _native.rasterize_forward(clip, d["triangles"], 200, 150)
+    cam = job["eyes"].to(device)
+    g = torch.randn(2, 150, 200, 4, generator=gen).to(device) / (150 * 200)
+    shin = (0.3 + 2.0 * torch.rand(2, V, generator=gen)).to(device) if per_vertex else torch.tensor([1.5, 3.0], device=device)
+    rgba, norms2 = _native.shade_specular_forward(ids, bary, d["normals"], d["vertices"], diffuse, spec, d["triangles"],
+                                                  lp, li, amb, cam, shin)
+    args = (g, ids, bary, clip, d["normals"], d["vertices"], diffuse, spec, d["triangles"], lp, li, amb, cam, shin, norms2)
+    adjacency = _native.vertex_adjacency(d["triangles"], V)
+    rows = _native.shade_specular_backward(*args, adjacency=adjacency)
+    if True:
+        lanes = _native.shade_specular_backward(*args, adjacency=adjacency, normalised_gbuffer=True,
+                                                grads_wanted=_native.GRAD_POSITIONS | _native.GRAD_CLIP)
+        folded = _native.shade_specular_backward(*args, adjacency=adjacency, normalised_gbuffer=True, transforms=xf,
+                                                 grads_wanted=_native.GRAD_POSITIONS)
+        scattered = _native.shade_specular_backward(*args, normalised_gbuffer=True,
+                                                    grads_wanted=_native.GRAD_POSITIONS | _native.GRAD_CLIP)
+    dclip, dpos = rows[0].cpu().numpy(), rows[2].cpu().numpy()
+    assert np.abs(dclip).max() > 0 and np.abs(dpos).max() > 0
+    for name, got in (("lanes", lanes), ("lanes + scatter", scattered)):
+        np.testing.assert_allclose(got[0].cpu().numpy(), dclip, rtol=2e-4, atol=2e-6 * np.abs(dclip).max(), err_msg=name)
+        np.testing.assert_allclose(got[2].cpu().numpy(), dpos, rtol=2e-4, atol=2e-6 * np.abs(dpos).max(), err_msg=name)
+    whole = dpos + np.einsum("bij,bvi->bvj", xf.cpu().numpy()[:, :, :3], dclip)
+    np.testing.assert_allclose(folded[2].cpu().numpy(), whole, rtol=2e-4, atol=2e-6 * np.abs(whole).max())
+    # through render(): differentiated to the vertices alone (the folded pass) against all leaves requiring grad
+    shininess = shin if per_vertex else torch.tensor([1.5, 3.0], device=device)
+    grads = {}
+    for only_vertices in (True, False):
+        v = d["vertices"].clone().requires_grad_(True)
+        n = d["normals"].clone().requires_grad_(not only_vertices)
+        img = mesh_renderer.render(v, d["triangles"], n, diffuse, job["eyes"], torch.zeros(2, 3),
+                                   torch.tensor([0.0, 1.0, 0.0]), lp, li, 200, 150, specular_colors=spec,
+                                   shininess_coefficients=shininess, ambient_color=amb)
+        (img * g).sum().backward()
+        grads[only_vertices] = v.grad.cpu().numpy()
+    np.testing.assert_allclose(grads[True], grads[False], rtol=2e-4, atol=2e-6 * np.abs(grads[False]).max())
+    np.testing.assert_allclose(grads[True], whole, rtol=2e-4, atol=2e-6 * np.abs(whole).max())
+
+
 @pytest.mark.parametrize("kind", ["vertex", "image", "scalar"])
 def test_fused_specular_shininess_gradient_matches_composed_path(device, kind):
     """A shininess that requires grad -- [B,V], [B] or 0-D -- through the fused kernels vs torch autograd
