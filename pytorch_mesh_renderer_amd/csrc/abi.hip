@@ -64,7 +64,7 @@ int mr_debug_set_shade_backward_kernel(int which) {
 
 int mr_debug_set_raster_probe(int probe) {
 #ifdef MR_PROBES
-  static const int kProbes[] = {0, 1, 2, 3, 8, 16, 32, 40, 64};
+  static const int kProbes[] = {0, 1, 2, 3, 8, 16, 32, 40, 48, 64};
   for (int v : kProbes) {
     if (v == probe) {
       mr::g_raster_probe = probe;

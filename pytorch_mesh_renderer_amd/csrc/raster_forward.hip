@@ -47,6 +47,9 @@
 #include "mr_internal.h"
 #include "shade_pixel.h"
 
+#ifndef MR_FAST_COVERAGE
+#define MR_FAST_COVERAGE 1  // see "conservative coverage" in k_raster's tile walk
+#endif
 namespace mr {
 
 thread_local int g_last_hip_error = 0;
@@ -219,6 +222,15 @@ __global__ __launch_bounds__(kThreads) void k_setup(
         bb.lr = box.x;
         bb.bt = box.y;
         bb.zlo = depth_lower_bound(p0.z, p1.z, p2.z, w0, w1, w2);
+#if MR_FAST_COVERAGE
+        {  // "tame" also means edge coefficients that cannot overflow (k_raster's conservative coverage test, stage 1)
+          const float big = fmaxf(fmaxf(fmaxf(fabsf(m0), fabsf(m1)), fmaxf(fabsf(m2), fabsf(m3))),
+                                  fmaxf(fmaxf(fabsf(m4), fabsf(m5)), fmaxf(fmaxf(fabsf(m6), fabsf(m7)), fabsf(m8))));
+          const bool finite = (m0 - m0 == 0.0f) & (m1 - m1 == 0.0f) & (m2 - m2 == 0.0f) & (m3 - m3 == 0.0f) & (m4 - m4 == 0.0f) &
+                              (m5 - m5 == 0.0f) & (m6 - m6 == 0.0f) & (m7 - m7 == 0.0f) & (m8 - m8 == 0.0f);
+          if (!(finite && big <= 0x1p100f)) bb.zlo = -INFINITY;
+        }
+#endif
         TriRec rec;
         // edge i = (m[3i], m[3i+1], m[3i+2]); edges 0 and 1 interleaved for packed fp32 math
         rec.a = make_float4(m0, m3, m1, m4);
@@ -433,13 +445,14 @@ constexpr int kWaves = kThreads / kWave;
 constexpr int kBin2Cap = kSubCap * kWaves;
 static_assert(kSubCap >= kWave, "a 64-triangle chunk must always fit an empty sub-bin (progress)");
 
-// Entry layout (dwords): 0-3 a0 a1 b0 b1 | 4-7 c0 c1 a2 b2 | 8 c2 | 9 id | 10-15 z0 w0 z1 w1 z2 w2 |
-// 16 bbox clipped to the region, region-relative: l | bottom << 16 | 17 (w-1) | (h-1) << 16 |
-// 18-19 scratch
-// where edge_i(px, py) = (a_i * px + b_i * py) + c_i  (cpp:46).
+// Entry layout (dwords): 0-3 a0 a1 b0 b1 | 4-7 c0 c1 a2 b2 | 8 c2 | 9 -tolerance of the conservative coverage
+// test | 10-15 z0 w0 z1 w1 z2 w2 | 16 bbox clipped to the region, region-relative: l | bottom << 16 |
+// 17 (w-1) | (h-1) << 16 | 18 id | 19 unused
+// where edge_i(px, py) = (a_i * px + b_i * py) + c_i  (cpp:46).  (While the bin is being filled the id sits in
+// dword 9 and 18-19 hold the entry's (chunk, rank in class) tag; the final placement writes the layout above.)
 struct Entry {
   float4 q0, q1, q2, q3;
-  uint2 bb;
+  uint4 tail;   // bbox (2), id, unused
 };
 
 typedef float v2f __attribute__((ext_vector_type(2)));  // packed fp32 (v_pk_mul_f32 / v_pk_add_f32)
@@ -460,7 +473,7 @@ __device__ __forceinline__ Entry read_entry(const float *s_ent, int e) {
   r.q1 = *(const float4 *)(p + 4);
   r.q2 = *(const float4 *)(p + 8);
   r.q3 = *(const float4 *)(p + 12);
-  r.bb = *(const uint2 *)(p + 16);
+  r.tail = *(const uint4 *)(p + 16);
   return r;
 }
 
@@ -502,11 +515,14 @@ __device__ __forceinline__ bool rect_outside_triangle(const float4 q0, const flo
 __device__ __forceinline__ void div3_common_denominator(float n0, float n1, float n2, float s,
                                                         unsigned long long valid, float &q0, float &q1,
                                                         float &q2) {
-  const bool plain = (__builtin_fminf(__builtin_fminf(n0, n1), n2) >= 0x1p-60f) &
-                     (__builtin_amdgcn_fmed3f(s, 0x1p-20f, 0x1p20f) == s);
-  // One path for the whole wavefront (the ordinary division is correct for every operand):
-  // lanes without a candidate (`valid` clear) must not force the slow one.
-  if ((__builtin_amdgcn_ballot_w64(!plain) & valid) == 0ull) {
+  // plain = min(n) >= 2^-60 and s in [2^-20, 2^20].  One path for the whole wavefront (the ordinary division is
+  // correct for every operand): lanes without a candidate (`valid` clear) must not force the slow one.  (Two
+  // ballots combined on the scalar side: the ballot of one compound condition went through a 0 / 1 vector
+  // register and a second compare.)
+  const unsigned long long not_plain =
+      __builtin_amdgcn_ballot_w64(!(__builtin_fminf(__builtin_fminf(n0, n1), n2) >= 0x1p-60f)) |
+      __builtin_amdgcn_ballot_w64(__builtin_amdgcn_fmed3f(s, 0x1p-20f, 0x1p20f) != s);
+  if ((not_plain & valid) == 0ull) {
     const float r0 = __builtin_amdgcn_rcpf(s);
     const float r = __builtin_fmaf(__builtin_fmaf(-s, r0, 1.0f), r0, r0);
     auto quotient = [&](const float n) {
@@ -913,7 +929,7 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : INTERP >=
       unsigned long long pass_mask, pass_mask2;  // scratch of the depth loop's compares
       if (fresh) {
         st.z = 1.0f; st.b0 = 0.0f; st.b1 = 0.0f; st.b2 = 0.0f;  // cpp:313-321
-        st.id = ordered ? -1 : 0;  // -1: "nothing drawn yet" loses every tie; stored as 0
+        st.id = -1;  // "nothing drawn yet" loses every tie; stored as 0
         st.ent = ent_init;
       } else if (in_image) {
         st.ent = 0;
@@ -938,6 +954,40 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : INTERP >=
         //     +5 VGPRs cost the seventh wave per SIMD, 0.371 -> 0.394 ms; two candidates per trip
         //     at 70 VGPRs changed nothing: the loop does not wait on LDS latency.)
         unsigned mine = 0u;
+#if MR_FAST_COVERAGE
+        // Conservative coverage (round 4).  This loop is 60 % of the kernel's arithmetic (stage probes: walk without
+        // it 31 us, with it 113, with the depth loop 138) at 18 vector instructions per (candidate, tile), eight
+        // of them the reference's un-fused edge expression.  Its result only SELECTS the candidates a lane then
+        // evaluates exactly in (2), so when the cell's triangles are all tame (`ordered`: edge coefficients
+        // bounded by 2^100, no NaN) a superset will do: the edges with fused multiply-adds (4 instructions
+        // instead of 8), against the entry's -tolerance instead of 0, without the "some value > 0" sum and without
+        // the bbox test -- 8 vector instructions and 3 LDS reads instead of 18 and 4 -- and (2) applies the exact
+        // tests to the values it forms anyway.  |px|, |py| < 1 and
+        // M_i = |a_i| + |b_i| + |c_i|: the un-fused value differs from the true one by at most 3u M_i, the fused
+        // one by 2u M_i (u = 2^-24), so an edge whose reference value is >= 0 has a fused value >= -5u M_i >
+        // -2^-20 M_i; underflowing products add less than 2^-146.
+        if (ordered) {
+          do {
+            const int j = __builtin_ctz(todo);
+            asm("s_bitset0_b32 %0, %1" : "+s"(todo) : "s"(j));   // todo &= todo - 1 in one scalar instruction
+            const float *p = s_ent + (ebase + j) * kEntryDw;  // wave-uniform address
+            const float4 q0 = *(const float4 *)(p), q1 = *(const float4 *)(p + 4);
+            const float2 ct = *(const float2 *)(p + 8);   // c2, -tolerance
+            const v2f e01 = __builtin_elementwise_fma(v2f{q0.x, q0.y}, px2,
+                                                      __builtin_elementwise_fma(v2f{q0.z, q0.w}, py2, v2f{q1.x, q1.y}));
+            const float e2 = __builtin_fmaf(q1.z, px, __builtin_fmaf(q1.w, py, ct.x));
+            float emin;
+            asm volatile(
+                "v_min3_f32 %[emin], %[e0], %[e1], %[e2]\n\t"
+                "v_cmpx_le_f32_e32 vcc, %[ntol], %[emin]\n\t"
+                "v_lshl_or_b32 %[mine], 1, %[j], %[mine]\n\t"
+                "s_mov_b64 exec, -1"
+                : [mine] "+v"(mine), [emin] "=&v"(emin)
+                : [e0] "v"(e01.x), [e1] "v"(e01.y), [e2] "v"(e2), [ntol] "v"(ct.y), [j] "s"(j)
+                : "vcc");
+          } while (todo);
+        } else
+#endif
         do {
           const int j = __builtin_ctz(todo);
           todo &= todo - 1;
@@ -979,8 +1029,8 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : INTERP >=
         // because vector instructions cost the same whatever EXEC holds, and a divergent
         // `if (mine)` made the compiler keep two copies of the pixel state (10 moves per trip).
         for (;;) {
-          const unsigned long long valid = __ballot(mine != 0u);
-          if (!valid) break;
+          const unsigned long long has = __ballot(mine != 0u);   // lanes with a candidate left
+          if (!has) break;
           const unsigned bit = min((unsigned)(__ffs((int)mine) - 1), 31u);  // no candidate: slot 31
           mine &= mine - 1u;
           const int slot = ebase + (int)bit;
@@ -991,6 +1041,16 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : INTERP >=
           float e2 = (t.q1.z * px + t.q1.w * py) + t.q2.x;
           asm("" : "+v"(e0), "+v"(e1), "+v"(e2));  // scalar from here on: no re-packing moves
           const float s = (e0 + e1) + e2;                              // cpp:384
+#if MR_FAST_COVERAGE
+          // cpp:96-97 exactly, on the reference's own values (see (1): its conservative variant lets a few pixels
+          // next to an edge through; after the exact variant this is true for every lane that has a candidate)
+          const unsigned dxy = pk_sub_u16(lane_xy, t.tail.x);   // inside the bbox: see (1), exact variant
+          const unsigned long long valid = has & __builtin_amdgcn_ballot_w64(__builtin_fminf(__builtin_fminf(e0, e1), e2) >= 0.0f) &
+                                           __builtin_amdgcn_ballot_w64(s > 0.0f) &
+                                           __builtin_amdgcn_ballot_w64(pk_min_u16(dxy, t.tail.y) == dxy);
+#else
+          const unsigned long long valid = has;
+#endif
           float b0, b1, b2;
           div3_common_denominator(e0, e1, e2, s, valid, b0, b1, b2);   // cpp:385-387
           // cpp:395-396: cz = (b0 z0 + b1 z1) + b2 z2 and cw likewise, as (z, w) pairs
@@ -1003,43 +1063,31 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : INTERP >=
           // the candidates do not arrive in id order, so the tie the sequential loop resolves
           // implicitly (equal depth: the later id overwrites) is tested explicitly; depths are
           // finite in that mode.
-          if (ordered) {
-            asm volatile(
-                "v_cmp_ngt_f32_e64 vcc, |%[zz]|, 1.0\n\t"
-                "v_cmp_eq_f32_e64 %[m], %[zz], %[z]\n\t"
-                "s_and_b64 %[valid2], vcc, %[valid]\n\t"
-                "v_cmp_gt_i32_e64 vcc, %[tid], %[id]\n\t"
-                "s_and_b64 %[m], %[m], vcc\n\t"
-                "v_cmp_lt_f32_e64 vcc, %[zz], %[z]\n\t"
-                "s_or_b64 vcc, vcc, %[m]\n\t"
-                "s_and_b64 vcc, vcc, %[valid2]\n\t"
-                "v_cndmask_b32_e32 %[z], %[z], %[zz], vcc\n\t"
-                "v_cndmask_b32_e32 %[id], %[id], %[tid], vcc\n\t"
-                "v_cndmask_b32_e32 %[c0], %[c0], %[b0], vcc\n\t"
-                "v_cndmask_b32_e32 %[c1], %[c1], %[b1], vcc\n\t"
-                "v_cndmask_b32_e32 %[c2], %[c2], %[b2], vcc\n\t"
-                "s_mov_b64 %[m], vcc"
-                : [z] "+v"(st.z), [id] "+v"(st.id), [c0] "+v"(st.b0), [c1] "+v"(st.b1), [c2] "+v"(st.b2),
-                  [m] "=&s"(pass_mask), [valid2] "=&s"(pass_mask2)
-                : [zz] "v"(zz), [tid] "v"(t.q2.y), [b0] "v"(b0), [b1] "v"(b1), [b2] "v"(b2), [valid] "s"(valid)
-                : "vcc");
-          } else {
-            asm volatile(
-                "v_cmp_ngt_f32_e64 vcc, |%[zz]|, 1.0\n\t"
-                "v_cmp_ngt_f32_e64 %[m], %[zz], %[z]\n\t"
-                "s_and_b64 vcc, vcc, %[valid]\n\t"
-                "s_and_b64 vcc, vcc, %[m]\n\t"
-                "v_cndmask_b32_e32 %[z], %[z], %[zz], vcc\n\t"
-                "v_cndmask_b32_e32 %[id], %[id], %[tid], vcc\n\t"
-                "v_cndmask_b32_e32 %[c0], %[c0], %[b0], vcc\n\t"
-                "v_cndmask_b32_e32 %[c1], %[c1], %[b1], vcc\n\t"
-                "v_cndmask_b32_e32 %[c2], %[c2], %[b2], vcc\n\t"
-                "s_mov_b64 %[m], vcc"
-                : [z] "+v"(st.z), [id] "+v"(st.id), [c0] "+v"(st.b0), [c1] "+v"(st.b1), [c2] "+v"(st.b2),
-                  [m] "=&s"(pass_mask)
-                : [zz] "v"(zz), [tid] "v"(t.q2.y), [b0] "v"(b0), [b1] "v"(b1), [b2] "v"(b2), [valid] "s"(valid)
-                : "vcc");
-          }
+          // ONE test for both modes (round 4; a run-time `if (ordered)` around two variants made the compiler keep
+          // two copies of the pixel state: ten moves and two branches per trip).  The candidate takes the pixel
+          // unless zz > z, or zz == z and the pixel already holds a LATER triangle: in id order (one class) the
+          // second clause never fires and a NaN passes, as in the reference; with front-to-back classes depths are
+          // finite and the clause resolves the tie the sequential loop resolves implicitly.  ("Nothing drawn yet"
+          // is id -1 in both modes, stored as 0.)
+          asm volatile(
+              "v_cmp_ngt_f32_e64 vcc, |%[zz]|, 1.0\n\t"
+              "v_cmp_ngt_f32_e64 %[m], %[zz], %[z]\n\t"
+              "s_and_b64 %[valid2], vcc, %[valid]\n\t"
+              "s_and_b64 %[valid2], %[valid2], %[m]\n\t"
+              "v_cmp_eq_f32_e64 vcc, %[zz], %[z]\n\t"
+              "v_cmp_gt_i32_e64 %[m], %[id], %[tid]\n\t"
+              "s_and_b64 vcc, vcc, %[m]\n\t"
+              "s_andn2_b64 vcc, %[valid2], vcc\n\t"
+              "v_cndmask_b32_e32 %[z], %[z], %[zz], vcc\n\t"
+              "v_cndmask_b32_e32 %[id], %[id], %[tid], vcc\n\t"
+              "v_cndmask_b32_e32 %[c0], %[c0], %[b0], vcc\n\t"
+              "v_cndmask_b32_e32 %[c1], %[c1], %[b1], vcc\n\t"
+              "v_cndmask_b32_e32 %[c2], %[c2], %[b2], vcc\n\t"
+              "s_mov_b64 %[m], vcc"
+              : [z] "+v"(st.z), [id] "+v"(st.id), [c0] "+v"(st.b0), [c1] "+v"(st.b1), [c2] "+v"(st.b2),
+                [m] "=&s"(pass_mask), [valid2] "=&s"(pass_mask2)
+              : [zz] "v"(zz), [tid] "v"(t.tail.z), [b0] "v"(b0), [b1] "v"(b1), [b2] "v"(b2), [valid] "s"(valid)
+              : "vcc");
           if constexpr (lds_recs) {  // the winner's slot rides along with its id (pass_mask: the lanes that took this candidate)
             asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(st.ent) : "v"(slot), "s"(pass_mask));
           }
@@ -1385,9 +1433,14 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : INTERP >=
       float *p = s_ent + slot * kEntryDw;
       *(float4 *)(p) = mine.q0;
       *(float4 *)(p + 4) = mine.q1;
-      *(float4 *)(p + 8) = mine.q2;
+      // -tolerance of the walk's conservative coverage test (see there): 2^-20 (|a_i| + |b_i| + |c_i|), the largest of the three edges
+      const float m0 = (fabsf(mine.q0.x) + fabsf(mine.q0.z)) + fabsf(mine.q1.x);
+      const float m1 = (fabsf(mine.q0.y) + fabsf(mine.q0.w)) + fabsf(mine.q1.y);
+      const float m2 = (fabsf(mine.q1.z) + fabsf(mine.q1.w)) + fabsf(mine.q2.x);
+      const float ntol = -(0x1p-20f * fmaxf(fmaxf(m0, m1), m2) + 0x1p-140f);
+      *(float4 *)(p + 8) = make_float4(mine.q2.x, ntol, mine.q2.z, mine.q2.w);
       *(float4 *)(p + 12) = mine.q3;
-      *(uint2 *)(p + 16) = mine.bb;
+      *(uint4 *)(p + 16) = make_uint4(mine.tail.x, mine.tail.y, __builtin_bit_cast(unsigned, mine.q2.y), 0u);
     }
     const int next_base = round_base + keep_chunks * kWave;
     __syncthreads();
@@ -1406,7 +1459,7 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : INTERP >=
       if (INTERP > 0) ent_init = top_slot;
       if (tid < total + (INTERP > 0 ? 1 : 0)) {
         const int slot = tid < n_near ? tid : tid < total ? far_base + (tid - n_near) : top_slot;
-        const int t = tid < total ? __builtin_bit_cast(int, s_ent[slot * kEntryDw + 9]) : 0;
+        const int t = tid < total ? __builtin_bit_cast(int, s_ent[slot * kEntryDw + 18]) : 0;
         const unsigned tc = min((unsigned)max(t, 0), (unsigned)(T - 1));
         const float4 *src = SHADE ? (const float4 *)(img_corners + tc) : (const float4 *)(img_attr_records + (size_t)tc * kRecordDw);
         float4 *dst = (float4 *)(s_ent + (kBin2Cap * kEntryDw - (slot + 1) * kRecordDw));
@@ -1514,6 +1567,7 @@ void launch_k_raster_probe(const RasterArgs &a, dim3 grid, hipStream_t s) {
     case 16: return launch_k_raster<R, 16>(a, grid, s);
     case 32: return launch_k_raster<R, 32>(a, grid, s);
     case 40: return launch_k_raster<R, 40>(a, grid, s);
+    case 48: return launch_k_raster<R, 48>(a, grid, s);
     case 64: return launch_k_raster<R, 64>(a, grid, s);
     default: break;
   }
