@@ -47,9 +47,6 @@
 #include "mr_internal.h"
 #include "shade_pixel.h"
 
-#ifndef MR_FAST_COVERAGE
-#define MR_FAST_COVERAGE 1  // see "conservative coverage" in k_raster's tile walk
-#endif
 namespace mr {
 
 thread_local int g_last_hip_error = 0;
@@ -222,15 +219,6 @@ __global__ __launch_bounds__(kThreads) void k_setup(
         bb.lr = box.x;
         bb.bt = box.y;
         bb.zlo = depth_lower_bound(p0.z, p1.z, p2.z, w0, w1, w2);
-#if MR_FAST_COVERAGE
-        {  // "tame" also means edge coefficients that cannot overflow (k_raster's conservative coverage test, stage 1)
-          const float big = fmaxf(fmaxf(fmaxf(fabsf(m0), fabsf(m1)), fmaxf(fabsf(m2), fabsf(m3))),
-                                  fmaxf(fmaxf(fabsf(m4), fabsf(m5)), fmaxf(fmaxf(fabsf(m6), fabsf(m7)), fabsf(m8))));
-          const bool finite = (m0 - m0 == 0.0f) & (m1 - m1 == 0.0f) & (m2 - m2 == 0.0f) & (m3 - m3 == 0.0f) & (m4 - m4 == 0.0f) &
-                              (m5 - m5 == 0.0f) & (m6 - m6 == 0.0f) & (m7 - m7 == 0.0f) & (m8 - m8 == 0.0f);
-          if (!(finite && big <= 0x1p100f)) bb.zlo = -INFINITY;
-        }
-#endif
         TriRec rec;
         // edge i = (m[3i], m[3i+1], m[3i+2]); edges 0 and 1 interleaved for packed fp32 math
         rec.a = make_float4(m0, m3, m1, m4);
@@ -954,72 +942,34 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : INTERP >=
         //     +5 VGPRs cost the seventh wave per SIMD, 0.371 -> 0.394 ms; two candidates per trip
         //     at 70 VGPRs changed nothing: the loop does not wait on LDS latency.)
         unsigned mine = 0u;
-#if MR_FAST_COVERAGE
-        // Conservative coverage (round 4).  This loop is 60 % of the kernel's arithmetic (stage probes: walk without
-        // it 31 us, with it 113, with the depth loop 138) at 18 vector instructions per (candidate, tile), eight
-        // of them the reference's un-fused edge expression.  Its result only SELECTS the candidates a lane then
-        // evaluates exactly in (2), so when the cell's triangles are all tame (`ordered`: edge coefficients
-        // bounded by 2^100, no NaN) a superset will do: the edges with fused multiply-adds (4 instructions
-        // instead of 8), against the entry's -tolerance instead of 0, without the "some value > 0" sum and without
-        // the bbox test -- 8 vector instructions and 3 LDS reads instead of 18 and 4 -- and (2) applies the exact
-        // tests to the values it forms anyway.  |px|, |py| < 1 and
-        // M_i = |a_i| + |b_i| + |c_i|: the un-fused value differs from the true one by at most 3u M_i, the fused
-        // one by 2u M_i (u = 2^-24), so an edge whose reference value is >= 0 has a fused value >= -5u M_i >
-        // -2^-20 M_i; underflowing products add less than 2^-146.
-        if (ordered) {
-          do {
-            const int j = __builtin_ctz(todo);
-            asm("s_bitset0_b32 %0, %1" : "+s"(todo) : "s"(j));   // todo &= todo - 1 in one scalar instruction
-            const float *p = s_ent + (ebase + j) * kEntryDw;  // wave-uniform address
-            const float4 q0 = *(const float4 *)(p), q1 = *(const float4 *)(p + 4);
-            const float2 ct = *(const float2 *)(p + 8);   // c2, -tolerance
-            const v2f e01 = __builtin_elementwise_fma(v2f{q0.x, q0.y}, px2,
-                                                      __builtin_elementwise_fma(v2f{q0.z, q0.w}, py2, v2f{q1.x, q1.y}));
-            const float e2 = __builtin_fmaf(q1.z, px, __builtin_fmaf(q1.w, py, ct.x));
-            float emin;
-            asm volatile(
-                "v_min3_f32 %[emin], %[e0], %[e1], %[e2]\n\t"
-                "v_cmpx_le_f32_e32 vcc, %[ntol], %[emin]\n\t"
-                "v_lshl_or_b32 %[mine], 1, %[j], %[mine]\n\t"
-                "s_mov_b64 exec, -1"
-                : [mine] "+v"(mine), [emin] "=&v"(emin)
-                : [e0] "v"(e01.x), [e1] "v"(e01.y), [e2] "v"(e2), [ntol] "v"(ct.y), [j] "s"(j)
-                : "vcc");
-          } while (todo);
-        } else
-#endif
+        // Conservative coverage (round 4).  The result of this loop only SELECTS the candidates a lane then
+        // evaluates exactly in (2), so a superset will do: the three edges with fused multiply-adds (4 vector
+        // instructions instead of the 8 of the reference's un-fused expression), compared with the entry's
+        // -tolerance instead of 0, no "some value > 0" sum, no bbox test -- 8 vector instructions, 3 LDS reads and
+        // 7 scalar ones per (candidate, tile) instead of 18 + 4 + 9 -- and (2) applies the exact tests (cpp:96-97) to
+        // the reference's values, which it forms anyway.  |px|, |py| < 1 and M_i = |a_i| + |b_i| + |c_i|: the
+        // un-fused value differs from the true one by at most 3u M_i, the fused one by 2u M_i (u = 2^-24), so an
+        // edge whose reference value is >= 0 has a fused value >= -5u M_i > -2^-20 max(M); underflowing products
+        // add less than 2^-146.  An entry whose coefficients could overflow (max M > 2^100, or a NaN) carries
+        // -inf (or NaN) as its tolerance, and "not less than" lets every pixel -- and a NaN minimum -- through.
+        // (Stage probes before: walk without this loop 31 us, with it 113, with the depth loop 138.)
         do {
           const int j = __builtin_ctz(todo);
-          todo &= todo - 1;
+          asm("s_bitset0_b32 %0, %1" : "+s"(todo) : "s"(j));   // todo &= todo - 1 in one scalar instruction
           const float *p = s_ent + (ebase + j) * kEntryDw;  // wave-uniform address
           const float4 q0 = *(const float4 *)(p), q1 = *(const float4 *)(p + 4);
-          const float m8 = p[8];
-          // bbox test, 3 VALU ops and no scalar work: (x - l, y - b) as packed u16 with
-          // wrap-around, then "<= (w - 1, h - 1)" on both halves at once via a packed min.
-          const uint2 box = *(const uint2 *)(p + 16);  // wave-uniform values
-          const unsigned dxy = pk_sub_u16(lane_xy, box.x);
-          const unsigned dmin = pk_min_u16(dxy, box.y);
-          const v2f e01 = (v2f{q0.x, q0.y} * px2 + v2f{q0.z, q0.w} * py2) + v2f{q1.x, q1.y};  // cpp:46
-          float e2 = (q1.z * px + q1.w * py) + m8;
-          asm("" : "+v"(e2));  // keeps the vectoriser from pairing e2 with the sum below
-          const float s = (e01.x + e01.y) + e2;
-          // cpp:96-97: all three edge values >= 0 and some > 0, inside the bbox.  With every
-          // value >= 0 "some > 0" is s > 0; a NaN edge value makes s NaN and fails there, so
-          // min3's NaN-ignoring result is harmless.  The three tests narrow EXEC one after the
-          // other (v_cmpx) -- no scalar instructions combine lane masks (the scalar unit, one per
-          // CU, is this kernel's busiest pipe) -- the candidate's bit is set in the surviving
-          // lanes and EXEC is restored.
+          const float2 ct = *(const float2 *)(p + 8);   // c2, -tolerance
+          const v2f e01 = __builtin_elementwise_fma(v2f{q0.x, q0.y}, px2,
+                                                    __builtin_elementwise_fma(v2f{q0.z, q0.w}, py2, v2f{q1.x, q1.y}));
+          const float e2 = __builtin_fmaf(q1.z, px, __builtin_fmaf(q1.w, py, ct.x));
           float emin;
           asm volatile(
               "v_min3_f32 %[emin], %[e0], %[e1], %[e2]\n\t"
-              "v_cmpx_le_f32_e32 vcc, 0, %[emin]\n\t"
-              "v_cmpx_lt_f32_e32 vcc, 0, %[s]\n\t"
-              "v_cmpx_eq_u32_e32 vcc, %[dmin], %[dxy]\n\t"
+              "v_cmpx_nlt_f32_e32 vcc, %[emin], %[ntol]\n\t"
               "v_lshl_or_b32 %[mine], 1, %[j], %[mine]\n\t"
               "s_mov_b64 exec, -1"
               : [mine] "+v"(mine), [emin] "=&v"(emin)
-              : [e0] "v"(e01.x), [e1] "v"(e01.y), [e2] "v"(e2), [s] "v"(s), [dmin] "v"(dmin), [dxy] "v"(dxy),
-                [j] "s"(j)
+              : [e0] "v"(e01.x), [e1] "v"(e01.y), [e2] "v"(e2), [ntol] "v"(ct.y), [j] "s"(j)
               : "vcc");
         } while (todo);
         // (2) depth: every lane walks its own candidates in ascending id
@@ -1041,16 +991,12 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : INTERP >=
           float e2 = (t.q1.z * px + t.q1.w * py) + t.q2.x;
           asm("" : "+v"(e0), "+v"(e1), "+v"(e2));  // scalar from here on: no re-packing moves
           const float s = (e0 + e1) + e2;                              // cpp:384
-#if MR_FAST_COVERAGE
-          // cpp:96-97 exactly, on the reference's own values (see (1): its conservative variant lets a few pixels
-          // next to an edge through; after the exact variant this is true for every lane that has a candidate)
-          const unsigned dxy = pk_sub_u16(lane_xy, t.tail.x);   // inside the bbox: see (1), exact variant
+          // cpp:96-97 exactly, on the reference's own values (see (1): its conservative test lets a few pixels
+          // next to an edge through)
+          const unsigned dxy = pk_sub_u16(lane_xy, t.tail.x);   // inside the bbox (cpp:96)
           const unsigned long long valid = has & __builtin_amdgcn_ballot_w64(__builtin_fminf(__builtin_fminf(e0, e1), e2) >= 0.0f) &
                                            __builtin_amdgcn_ballot_w64(s > 0.0f) &
                                            __builtin_amdgcn_ballot_w64(pk_min_u16(dxy, t.tail.y) == dxy);
-#else
-          const unsigned long long valid = has;
-#endif
           float b0, b1, b2;
           div3_common_denominator(e0, e1, e2, s, valid, b0, b1, b2);   // cpp:385-387
           // cpp:395-396: cz = (b0 z0 + b1 z1) + b2 z2 and cw likewise, as (z, w) pairs
@@ -1437,7 +1383,9 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : INTERP >=
       const float m0 = (fabsf(mine.q0.x) + fabsf(mine.q0.z)) + fabsf(mine.q1.x);
       const float m1 = (fabsf(mine.q0.y) + fabsf(mine.q0.w)) + fabsf(mine.q1.y);
       const float m2 = (fabsf(mine.q1.z) + fabsf(mine.q1.w)) + fabsf(mine.q2.x);
-      const float ntol = -(0x1p-20f * fmaxf(fmaxf(m0, m1), m2) + 0x1p-140f);
+      const float mmax = fmaxf(fmaxf(m0, m1), m2);
+      // coefficients that could overflow (or a NaN: the comparison is false): the test lets every pixel through
+      const float ntol = mmax <= 0x1p100f ? -(0x1p-20f * mmax + 0x1p-140f) : -INFINITY;
       *(float4 *)(p + 8) = make_float4(mine.q2.x, ntol, mine.q2.z, mine.q2.w);
       *(float4 *)(p + 12) = mine.q3;
       *(uint4 *)(p + 16) = make_uint4(mine.tail.x, mine.tail.y, __builtin_bit_cast(unsigned, mine.q2.y), 0u);
