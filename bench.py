@@ -304,13 +304,16 @@ def main():
     # region (the driver's --steps 20 is 14 ms of GPU time) that starts a few milliseconds after the chip was idle
     # measures its clock ramp -- the same code gave 0.742 ms/step at --steps 20 against 0.681 at --steps 200 on one
     # box, every kernel 4-7 % slower -- so the measurement legs that are not the timed region run first.
-    n_gb = 20
+    # Its own lead-in of untimed steps (12: ~10 ms of GPU time) plays the part the warm-up steps play for the timed
+    # region: measured straight after process start the same kernel read 140 us against 134.7 in the rocprofv3
+    # trace of the same box (profiles/r04_c_*).
+    n_gb, n_gb_lead = 20, 12
     ev_gbuffer = KernelEvents(n_gb, _native.TIMER_RASTER_FORWARD)
     from pytorch_mesh_renderer_amd.mesh_renderer import rasterize_triangles_ext as ext
     with ext.shading_epilogue(False):
-        for i in range(n_gb + 2):
-            if i >= 2:
-                ev_gbuffer.arm(i - 2)
+        for i in range(n_gb + n_gb_lead):
+            if i >= n_gb_lead:
+                ev_gbuffer.arm(i - n_gb_lead)
             step()
     if gather is not None:
         gather.drain()
@@ -384,7 +387,7 @@ def main():
                          px * 20 + batch * V * 16 + T * 12, ev_gbuffer.mean_ms(n_gb), "k_raster", args.config),
                 timed="OUTSIDE the timed region: %d extra steps run BEFORE the warm-up steps with the shading epilogue "
                       "switched off (rasterize_triangles_ext.shading_epilogue(False)); `value` / `ms_per_step` do not "
-                      "contain them" % (n_gb + 2)),
+                      "contain them; the first %d of them are an untimed lead-in" % (n_gb + n_gb_lead, n_gb_lead)),
             # ids + barycentrics (16 B/px) and the loss's sign codes (1 B/px) read, the triangles'
             # difference-basis records (FoldRec, 160 B) read
             "roofline_shade_backward": roofline(

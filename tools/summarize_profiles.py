@@ -47,7 +47,7 @@ json.dump(lines, open(os.path.join(prof, tag + suffix + "_bench.json"), "w"), in
 # G-buffer kernel alone (bench.py runs 22 such steps after its timed region)
 wanted = {"k_raster_shade": "k_raster<64, 0, true,", "k_raster": "k_raster<64, 0, false, 0>",
           "k_shade_forward": "k_shade_forward(", "ShadeGradFn": ("ShadeFoldLaneFn", "ShadeLaneFn", "ShadeGradFn"),
-          "k_l1_forward": "k_l1_forward(", "k_l1_backward": "k_l1_backward("}
+          "k_l1_forward": ("k_l1_forward(", "k_l1_forward_regions("), "k_l1_backward": "k_l1_backward("}
 raw = {k: {} for k in wanted}
 for counter in ("WRITE_SIZE", "FETCH_SIZE"):
     acc = {k: [] for k in wanted}
