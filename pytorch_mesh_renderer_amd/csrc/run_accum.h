@@ -590,6 +590,11 @@ __global__ __launch_bounds__(kWave, Fn::kMinWavesPerSimd) void k_accumulate_lane
   //          a segment where the triangle changes (a ballot tells where), like the rows kernel.
   // A segment's sum goes into its triangle's merge-table slot with ONE LDS operation that returns
   // nothing (ds_add_f32, or a plain store into a slot claimed by this segment): nothing to wait for.
+  // (Measured in round 4 and dropped: DEFERRING the pass -- a finished run only parks, the lane remembers its
+  //  triangle in a register, and the pass runs when a lane needs its slot again and at the end of the strip:
+  //  ~3 passes per 8-row strip instead of one per row.  Shading backward per launch 115.8 -> 112.3 M vector, 57.1
+  //  -> 50.0 M scalar, 19.5 -> 16.3 M branch, 6.8 -> 5.7 M LDS instructions, and 0.2213 -> 0.2224 ms: the pass is
+  //  not where this kernel's time goes.)
   constexpr int kDense = MR_LANES_DENSE;
   auto flush = [&](const bool fin) __attribute__((always_inline)) {
     const unsigned long long finm = __ballot(fin);
