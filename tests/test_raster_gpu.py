@@ -218,6 +218,29 @@ def assert_forward_equal_up_to_nan_encoding(got, want):
         assert not differ.any(), "%s differs in %d non-NaN elements" % (name, int(differ.sum()))
 
 
+@pytest.mark.parametrize("exponent", [-62, -40, 0, 30, 48, 50, 52, 61])
+def test_coverage_tolerance_across_coefficient_magnitudes(device, exponent):
+    """Round 4: the tile walk selects a lane's candidates with a CONSERVATIVE coverage test (fused multiply-adds
+    against a per-entry tolerance of 2^-20 (|a| + |b| + |c|), -inf once a coefficient could overflow: max > 2^100) and
+    applies rasterize_triangles.cpp:96-97 exactly in the depth trip.  Scaling all clip coordinates by 2^k leaves
+    the geometry alone and moves the edge coefficients (products of two coordinates) by 2^2k -- from denormal
+    to either side of 2^100: bit-exact against the oracle at every magnitude, on a soup and on the 5k sphere."""
+    rng = np.random.default_rng(7)
+    scale = np.float32(2.0) ** np.float32(exponent)
+    for trial in range(3):
+        V, T = int(rng.integers(20, 120)), int(rng.integers(50, 900))
+        W, H = int(rng.integers(60, 300)), int(rng.integers(40, 200))
+        clip = (rng.normal(size=(2, V, 4)) * [0.6, 0.6, 1.0, 1.0]).astype(np.float32)
+        clip[..., 3] = np.abs(clip[..., 3]) + 0.05
+        tris = rng.integers(0, V, size=(T, 3)).astype(np.int32)
+        assert_forward_bitwise(hip_forward(clip * scale, tris, W, H, device), oracle.forward(clip * scale, tris, W, H))
+    job = synthetic.sphere_job(2, 192, 128, 50)
+    clip = job["clip"].numpy() * scale
+    got = hip_forward(clip, job["triangles"].numpy(), 192, 128, device)
+    assert_forward_bitwise(got, oracle.forward(clip, job["triangles"].numpy(), 192, 128))
+    assert (got[1].sum(-1) > 0.5).mean() > 0.3   # the sphere is drawn at every magnitude
+
+
 def test_random_soups_with_nonfinite_vertices(device):
     """NaN / Inf / 1e38 coordinates sprinkled over random soups: a NaN depth PASSES the
     reference's z-test (cpp:401) and is stored, so NaNs reach the G-buffer."""
