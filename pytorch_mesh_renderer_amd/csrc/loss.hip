@@ -9,6 +9,9 @@
 // (reads 1 B/px, writes 16 B/px).  Both are HBM-bound; 49 B/px in total instead of 80.
 #include "mr_internal.h"
 
+#ifndef MR_L1_REGIONS_NT_A
+#define MR_L1_REGIONS_NT_A 1   // the image stream of k_l1_forward_regions nontemporal too
+#endif
 #ifndef MR_L1_REVERSE
 #define MR_L1_REVERSE 1
 #endif
@@ -348,7 +351,7 @@ __global__ __launch_bounds__(kThreads) void k_l1_forward_regions(
       for (int u = 0; u < kInFlight; ++u) {
         va[u] = vb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (live[u]) {
-          va[u] = nt_load(&a[base + x0 + u * kThreads]);
+          va[u] = MR_L1_REGIONS_NT_A ? nt_load(&a[base + x0 + u * kThreads]) : a[base + x0 + u * kThreads];
           vb[u] = nt_load(&b[base + x0 + u * kThreads]);
         }
       }

@@ -581,6 +581,9 @@ struct RasterShade {
 #ifndef MR_RASTER_STORE_AUX_Z
 #define MR_RASTER_STORE_AUX_Z MR_RASTER_STORE_AUX
 #endif
+#ifndef MR_RASTER_STORE_AUX_RGBA
+#define MR_RASTER_STORE_AUX_RGBA MR_RASTER_STORE_AUX   // the image plane of the fused forward (its consumer, the loss, reads it back to front)
+#endif
 #ifndef MR_EPI_LDS_RECORDS
 #define MR_EPI_LDS_RECORDS 1  // round 4: the shading epilogue reads its winners' corner records per lane from LDS
                               // (see "corner records in LDS" in k_raster) instead of one winner at a time through the scalar cache
@@ -837,7 +840,7 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : INTERP >=
       if constexpr (SHADE) {
         typedef unsigned v4u __attribute__((ext_vector_type(4)));
         __builtin_amdgcn_raw_buffer_store_b128(v4u{0u, 0u, 0u, 0u}, rs_rgba, (unsigned)((R - 1 - y) * W + x) * 16u, 0,
-                                               MR_RASTER_STORE_AUX);
+                                               MR_RASTER_STORE_AUX_RGBA);
         if (shade.rgba8) __builtin_nontemporal_store(0u, &shade.rgba8[img_px + (size_t)(H - 1 - (Y0 + y)) * W + X0 + x]);
       }
       if constexpr (INTERP > 0) {
@@ -1194,7 +1197,7 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : INTERP >=
           const unsigned lane_rgba = (unsigned)((kTileH - 1 - ly) * W + lx) * 16u;
           const int tile_rgba = ((R - kTileH - ty * kTileH) * W + tx * kTileW) * 16;
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v4f{rgba.x, rgba.y, rgba.z, rgba.w}), rs_rgba,
-                                                 lane_rgba, tile_rgba, MR_RASTER_STORE_AUX);
+                                                 lane_rgba, tile_rgba, MR_RASTER_STORE_AUX_RGBA);
           if (shade.rgba8) {  // workgroup-uniform: the 8-bit frame for the multi-GPU hand-over, 4 B/px
             auto u8 = [](float v) { return (unsigned)(fminf(fmaxf(v, 0.0f), 1.0f) * 255.0f); };  // NaN -> 0
             const unsigned packed = u8(rgba.x) | (u8(rgba.y) << 8) | (u8(rgba.z) << 16) | (u8(rgba.w) << 24);
