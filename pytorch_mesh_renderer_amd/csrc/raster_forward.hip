@@ -797,9 +797,14 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : INTERP >=
   // (The INTERP instantiations run at 4-5 waves per SIMD on their registers: the slot costs no occupancy.)
   float *stage_slot = nullptr;
   unsigned stage_goff[INTERP > 0 ? INTERP / 4 : 1] = {};
+  __shared__ __attribute__((aligned(16))) float s_background[INTERP > 0 ? INTERP : 4];   // (INTERP only)
   if constexpr (INTERP > 0) {
     __shared__ __attribute__((aligned(16))) float s_stage[kWaves * kWave * INTERP];
     stage_slot = s_stage + wave * (kWave * INTERP);
+    // The background colour in LDS (the bin stage's barriers come before its first use): read per tile from memory it
+    // was 9-12 VECTOR loads, and vmcnt retires in order -- their wait drained the previous tile's stores
+    // (SQ_INSTS_VMEM_RD 13 per tile; the same trap as the corner records of the shading epilogue).
+    if (tid < INTERP) s_background[tid] = tid < shade.A ? shade.background[tid] : 0.0f;
     const unsigned chunks_per_row = (unsigned)(kTileW * shade.A) / 4u;      // 16-byte chunks in one tile row: 4 A
 #pragma unroll
     for (int i = 0; i < INTERP / 4; ++i) {
@@ -1069,14 +1074,16 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : INTERP >=
             if (4 * q >= shade.A) break;   // wave-uniform
             const float4 c0 = *(const float4 *)(rec + 4 * q), c1 = *(const float4 *)(rec + AP + 4 * q),
                          c2 = *(const float4 *)(rec + 2 * AP + 4 * q);
+            const float4 bg4 = *(const float4 *)(s_background + 4 * q);   // (zeros beyond A)
             float o[4];
             {
 #pragma clang fp contract(fast)
               const float k0[4] = {c0.x, c0.y, c0.z, c0.w}, k1[4] = {c1.x, c1.y, c1.z, c1.w}, k2[4] = {c2.x, c2.y, c2.z, c2.w};
+              const float bg[4] = {bg4.x, bg4.y, bg4.z, bg4.w};
 #pragma unroll
               for (int a = 0; a < 4; ++a) {
                 const float value = (k0[a] * st.b0 + k1[a] * st.b1) + k2[a] * st.b2;
-                o[a] = alpha * value + one_m * (4 * q + a < shade.A ? shade.background[4 * q + a] : 0.0f);
+                o[a] = alpha * value + one_m * bg[a];
               }
             }
             const int left = shade.A - 4 * q;   // wave-uniform, >= 1
