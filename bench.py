@@ -396,7 +396,9 @@ def main():
                 px * 17 + batch * T * 160, ev_shade.mean_ms(n_ev), "shade_backward", args.config),
             # the loss: image and target read (2 x 16 B/px), the sign codes written (1 B/px)
             "roofline_l1_forward": roofline(
-                "k_l1_forward (mean |image - target| and its sign codes, one streaming pass)",
+                "k_l1_forward_regions (mean |image - target| and its sign codes, one streaming pass; 64 x 64 blocks that "
+                "the renderer's and the target's empty-block maps both mark are not read: `achieved` still counts the "
+                "full 33 B/px)",
                 px * 33, ev_l1.mean_ms(n_ev), "l1_forward", args.config),
         }
         if grouped:
