@@ -33,6 +33,12 @@ import os
 USE_FUSED_RENDER_LOSS = os.environ.get("MR_FUSED_RENDER_LOSS", "1") != "0"   # False: always the generic op (dense gradient image)
 
 
+def forget_target(target):
+    """Drops what l1_loss keeps on a target tensor (its empty-block map); see l1_loss, TARGET."""
+    if hasattr(target, "_mr_empty_regions"):
+        del target._mr_empty_regions
+
+
 def l1_loss(image, target):
     """mean(|image - target|) over every element; same value and gradients as
     torch.mean(torch.abs(image - target)) (sign(0) = 0).
@@ -46,7 +52,13 @@ def l1_loss(image, target):
 
     ORDERING: whether the image's gradient is observed is decided when this function is CALLED.  A hook or
     retain_grad() put on `image` AFTER the loss was built never fires / never fills image.grad (the fused
-    backward differentiates image.detach()); register them before calling l1_loss, or switch the fused route off."""
+    backward differentiates image.detach()); register them before calling l1_loss, or switch the fused route off.
+
+    TARGET: on that route the 64 x 64 blocks that are all zeros in BOTH images are not read (the renderer knows
+    its own; the target's map is found once and kept on the target tensor, keyed by its data pointer, shape and
+    autograd version counter).  Every in-place torch operation on the target bumps that counter; a write that
+    does not -- through `target.data`, DLPack, a raw pointer -- leaves a stale map behind: call
+    forget_target(target) after such a write (or set MR_EMPTY_REGIONS=0)."""
     if image.shape != target.shape:
         raise ValueError("image and target must have the same shape")
     if image.dtype != torch.float32 or target.dtype != torch.float32:

@@ -1485,6 +1485,35 @@ def test_render_empty_block_map_serves_the_loss_and_the_backward(device, w, h, b
                                        atol=1e-6 * float(gd0.abs().max()), err_msg=kind)
 
 
+def test_target_empty_block_map_follows_in_place_edits(device):
+    """The target's empty-block map is kept on the tensor, keyed by its version counter: an in-place torch edit that
+    fills a formerly empty block is seen by the next loss; losses.forget_target drops the map by hand."""
+    from pytorch_mesh_renderer_amd.mesh_renderer import rasterize_triangles_ext as ext
+    job = synthetic.sphere_job(8, 768, 768, 12)
+    tris = job["triangles"].to(device)
+    target = torch.zeros(8, 768, 768, 4, device=device)
+
+    def loss_of():
+        v = job["vertices"].clone().to(device).requires_grad_(True)
+        img = mesh_renderer.render(v, tris, job["normals"].to(device), job["diffuse"].to(device), job["eyes"],
+                                   torch.zeros(8, 3), torch.tensor([0.0, 1.0, 0.0]), job["light_positions"].to(device),
+                                   job["light_intensities"].to(device), 768, 768)
+        return float(mesh_renderer.losses.l1_loss(img, target)), float((img.detach() - target).abs().mean())
+
+    got, want = loss_of()
+    assert abs(got - want) <= 1e-6 * want
+    first = target._mr_empty_regions[1]
+    assert int(first.sum()) == first.numel()   # an all-zero target: every block empty
+    target[3, 710:760, 5:60] = 0.75            # inside ONE corner block the sphere does not reach (G-buffer rows 7..57)
+    got, want = loss_of()
+    assert abs(got - want) <= 1e-6 * want, "the edit was not seen"
+    assert int(target._mr_empty_regions[1].sum()) == first.numel() - 1
+    mesh_renderer.losses.forget_target(target)
+    assert not hasattr(target, "_mr_empty_regions")
+    got, want = loss_of()
+    assert abs(got - want) <= 1e-6 * want
+
+
 def test_l1_loss_on_a_derived_image_takes_the_generic_path(device):
     """Only render()'s own output carries the fused-loss record; a slice or a scaled copy does not."""
     job = synthetic.sphere_job(1, 64, 48, 8)
