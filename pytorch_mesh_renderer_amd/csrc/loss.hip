@@ -332,6 +332,10 @@ __global__ __launch_bounds__(kThreads) void k_l1_forward_regions(
   float s = 0.f;
   const long n_rows = (long)B * H;
   const int lane_in_wave = (int)threadIdx.x & (kWave - 1);
+  // (Also measured at the end of round 4, both slower in the benchmark's step: the flat kernel's own walk with one
+  //  test per wavefront and load -- equal to the flat kernel with nothing to skip, but skipping scattered 1 KB
+  //  segments saved only a third of their share: 0.1852 -> 0.1874 ms in the step -- and four rows a grid stride
+  //  apart per workgroup, +8 %.)
   // A row's skip flags: lane i of every wavefront holds "block i of the row's band is empty on both sides"; their
   // ballot is the row's 64-bit skip mask (rows of more than 64 blocks -- W > 4096 -- skip nothing).  Requested ONE
   // ROW AHEAD: read per element in front of the image loads (the first version) the map bytes were a dependent
