@@ -321,17 +321,23 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    n_ev = min(args.steps, 64)             # kernel timers on the first n_ev timed steps
+    # Kernel timers (a hipEvent pair around each of the three big kernels) on every `ev_every`-th timed step, at
+    # most 16 of them, spread over the whole timed region.  An event pair costs the stream ~5 us of idle time around
+    # the kernel it brackets (seen as gaps in the rocprofv3 trace): on EVERY step, as until the end of round 4, the
+    # three pairs took ~2.5 % off `value` in a 20-step run.
+    n_ev = max(1, min(16, args.steps // 4)) if "MR_BENCH_TIMER_STEPS" not in os.environ else \
+        max(0, min(args.steps, int(os.environ["MR_BENCH_TIMER_STEPS"])))
+    ev_every = max(1, args.steps // n_ev) if n_ev else 0
     ev_raster = KernelEvents(n_ev, _native.TIMER_RASTER_FORWARD)
     ev_shade = KernelEvents(n_ev, _native.TIMER_SHADE_BACKWARD)
     ev_l1 = KernelEvents(n_ev, _native.TIMER_L1_FORWARD)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        if i < n_ev:
-            ev_raster.arm(i)
-            ev_shade.arm(i)
-            ev_l1.arm(i)
+        if ev_every and i % ev_every == ev_every // 2 and i // ev_every < n_ev:
+            ev_raster.arm(i // ev_every)
+            ev_shade.arm(i // ev_every)
+            ev_l1.arm(i // ev_every)
         step()
     if gather is not None:
         gather.drain()                   # the last steps' hand-overs belong to the timed region
