@@ -525,6 +525,35 @@ __device__ __forceinline__ void div3_common_denominator(float n0, float n1, floa
   }
 }
 
+// A hardware hazard LLVM does not cover on this target (found at the end of round 4 with the fuzzer: attribute 0 of
+// lanes 12-15 of every 16 came out as the pixel's triangle id).  A MUBUF store of more than 64 bits reads its data
+// registers over several cycles; a vector instruction that overwrites one of them in the very next issue slot
+// corrupts what the last lanes store.  The hazard recognizer inserts the documented wait state only for stores
+// WITHOUT a register soffset (GCNHazardRecognizer::createsVALUHazard); the tile walk's stores carry their tile
+// offset there.  The data registers are kept alive through an `s_nop` behind the store -- an asm with side
+// effects stays behind the store, and nothing can overwrite its inputs before it.
+#ifndef MR_WIDE_STORE_NOPS
+#define MR_WIDE_STORE_NOPS 1   // s_nop operand: 1 = two wait states; -1 = no protection (to reproduce the corruption)
+#endif
+typedef unsigned mr_v4u __attribute__((ext_vector_type(4)));
+typedef unsigned mr_v3u __attribute__((ext_vector_type(3)));
+template <int AUX>
+__device__ __forceinline__ void store_b128_soffset(const mr_v4u d, const __amdgpu_buffer_rsrc_t rs, const unsigned voffset,
+                                                   const int soffset) {
+  __builtin_amdgcn_raw_buffer_store_b128(d, rs, voffset, soffset, AUX);
+#if MR_WIDE_STORE_NOPS >= 0
+  asm volatile("s_nop %4" ::"v"(d.x), "v"(d.y), "v"(d.z), "v"(d.w), "n"(MR_WIDE_STORE_NOPS));
+#endif
+}
+template <int AUX>
+__device__ __forceinline__ void store_b96_soffset(const mr_v3u d, const __amdgpu_buffer_rsrc_t rs, const unsigned voffset,
+                                                  const int soffset) {
+  __builtin_amdgcn_raw_buffer_store_b96(d, rs, voffset, soffset, AUX);
+#if MR_WIDE_STORE_NOPS >= 0
+  asm volatile("s_nop %3" ::"v"(d.x), "v"(d.y), "v"(d.z), "n"(MR_WIDE_STORE_NOPS));
+#endif
+}
+
 // R = region edge in pixels: 64, or 32 for small launches (configs[1]: 8 x 256^2 is only 128
 // regions of 64^2 -- half the CUs idle and >256 candidates per region; 512 regions of 32^2 fill
 // the chip with one bin round each).
@@ -603,7 +632,7 @@ struct RasterShade {
 #ifndef MR_RASTER_INTERP_WAVES
 #define MR_RASTER_INTERP_WAVES 5
 #endif
-template <int R, int PROBE, bool SHADE, int INTERP = 0>
+template <int R, int PROBE, bool SHADE, int INTERP = 0, int AX = 0>
 __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : INTERP >= 12 ? 4 : INTERP ? MR_RASTER_INTERP_WAVES : MR_RASTER_WAVES) void k_raster(
     const TriRec *__restrict__ recs, const TriBox *__restrict__ bbs,
     const float *__restrict__ pxtab, const float *__restrict__ pytab, int T, int W, int H,
@@ -617,6 +646,7 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : INTERP >=
   static_assert(R == 64 || R == 32, "region edge");
   static_assert(!SHADE || PROBE == 0, "the shading epilogue has no timing probes");
   static_assert(INTERP == 0 || (!SHADE && PROBE == 0 && INTERP % 4 == 0 && INTERP <= 16), "one epilogue at a time");
+  static_assert(AX == 0 || (INTERP > 0 && AX <= INTERP && AX > INTERP - 4), "a fixed attribute count belongs to its padded variant");
   constexpr bool EPI = SHADE || INTERP > 0;   // an epilogue runs on a region's last bin round
   // A wavefront's tile is kTileW x kTileH pixels, one per lane.  16 x 4: every row of a tile's
   // G-buffer stores is a whole, aligned 64-byte sector (16 ids / depths) or three of them (16
@@ -686,6 +716,10 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : INTERP >=
 
   const int tid = (int)threadIdx.x;
   const int lane = tid & (kWave - 1);
+  // INTERP: the attribute count -- a compile-time constant in the instantiations for the usual counts (AX: 3, 9), where
+  // the staging stores' shapes fold to straight-line code (with a run-time count they were ~20 branches per tile on
+  // spilled lane masks), else the launch's
+  const int attr_n = AX ? AX : shade.A;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const TriRec *img_recs = recs + (size_t)img * T;
   const TriBox *img_bbs = bbs + (size_t)img * T;
@@ -787,9 +821,9 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : INTERP >=
       kRsrcWord3);
   const CornerRec *img_corners = SHADE ? shade.corners + (size_t)img * T : nullptr;
   const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
-      INTERP ? shade.attr_out + region_pix * (size_t)shade.A : nullptr, 0, 0x7fffffff, kRsrcWord3);
+      INTERP ? shade.attr_out + region_pix * (size_t)attr_n : nullptr, 0, 0x7fffffff, kRsrcWord3);
   const float *img_attr_records = INTERP ? shade.attr_records + (size_t)img * T * (3 * INTERP) : nullptr;
-  const unsigned lane_out = INTERP ? lane_pix * (unsigned)shade.A * 4u : 0u;   // byte offset of the lane's pixel inside a tile
+  const unsigned lane_out = INTERP ? lane_pix * (unsigned)attr_n * 4u : 0u;   // byte offset of the lane's pixel inside a tile
   int ent_init = 0;   // slot a pixel without a winner looks up (INTERP: the background's record, set per round)
   // INTERP: a pixel's A floats are A * 4 bytes apart from its neighbour's: stored per lane they reach memory as
   // 16-byte (or smaller) pieces at a stride of A * 4 bytes -- partial sectors from every store instruction (measured
@@ -807,13 +841,13 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : INTERP >=
     // The background colour in LDS (the bin stage's barriers come before its first use): read per tile from memory it
     // was 9-12 VECTOR loads, and vmcnt retires in order -- their wait drained the previous tile's stores
     // (SQ_INSTS_VMEM_RD 13 per tile; the same trap as the corner records of the shading epilogue).
-    if (tid < INTERP) s_background[tid] = tid < shade.A ? shade.background[tid] : 0.0f;
-    const unsigned chunks_per_row = (unsigned)(kTileW * shade.A) / 4u;      // 16-byte chunks in one tile row: 4 A
+    if (tid < INTERP) s_background[tid] = tid < attr_n ? shade.background[tid] : 0.0f;
+    const unsigned chunks_per_row = (unsigned)(kTileW * attr_n) / 4u;      // 16-byte chunks in one tile row: 4 A
 #pragma unroll
     for (int i = 0; i < INTERP / 4; ++i) {
       const unsigned j = (unsigned)lane + 64u * i;                          // this lane's chunk in trip i
       const unsigned r = j / chunks_per_row;                                // tile row
-      stage_goff[i] = r * (unsigned)(W * shade.A) * 4u + (j - r * chunks_per_row) * 16u;
+      stage_goff[i] = r * (unsigned)(W * attr_n) * 4u + (j - r * chunks_per_row) * 16u;
     }
   }
 #if MR_EPI_LDS_LIGHTS
@@ -854,10 +888,10 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : INTERP >=
       if constexpr (INTERP > 0) {
         // an uncovered pixel: id 0, barycentrics 0 -> alpha 0: 0 * (triangle 0's attributes, weighted by zeros) + 1 * background
         // (rasterize.py:137-150; the products are kept: a non-finite attribute of triangle 0 shows here as in the reference)
-        for (int a = 0; a < shade.A; ++a) {
+        for (int a = 0; a < attr_n; ++a) {
           const float value = (img_attr_records[a] * 0.0f + img_attr_records[INTERP + a] * 0.0f) + img_attr_records[2 * INTERP + a] * 0.0f;
           const float o = 0.0f * value + 1.0f * shade.background[a];
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rs_out, pix * (unsigned)shade.A * 4u + 4u * a, 0,
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rs_out, pix * (unsigned)attr_n * 4u + 4u * a, 0,
                                                 0);
         }
       }
@@ -1067,14 +1101,14 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : INTERP >=
           const float pre = (2.0f * st.b0 + 2.0f * st.b1) + 2.0f * st.b2;
           const float alpha = fminf(fmaxf(pre, 0.0f), 1.0f);
           const float one_m = 1.0f - alpha;
-          const int tile_out = tile_pix * shade.A * 4;
+          const int tile_out = tile_pix * attr_n * 4;
           constexpr bool staged = full && MR_RASTER_INTERP_STAGE;
-          float *mine = stage_slot + lane * shade.A;
+          float *mine = stage_slot + lane * attr_n;
           // four attributes at a time: three 16-byte reads (one per corner), four results, straight to their
           // destination -- the whole record at once was 36 + 12 live registers at A = 9
 #pragma unroll
           for (int q = 0; q < AP / 4; ++q) {
-            if (4 * q >= shade.A) break;   // wave-uniform
+            if (4 * q >= attr_n) break;   // wave-uniform
             const float4 c0 = *(const float4 *)(rec + 4 * q), c1 = *(const float4 *)(rec + AP + 4 * q),
                          c2 = *(const float4 *)(rec + 2 * AP + 4 * q);
             const float4 bg4 = *(const float4 *)(s_background + 4 * q);   // (zeros beyond A)
@@ -1089,10 +1123,10 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : INTERP >=
                 o[a] = alpha * value + one_m * bg[a];
               }
             }
-            const int left = shade.A - 4 * q;   // wave-uniform, >= 1
+            const int left = attr_n - 4 * q;   // wave-uniform, >= 1
             if constexpr (staged) {
-              if ((shade.A & 3) == 0) *(float4 *)(mine + 4 * q) = make_float4(o[0], o[1], o[2], o[3]);
-              else if ((shade.A & 1) == 0) {
+              if ((attr_n & 3) == 0) *(float4 *)(mine + 4 * q) = make_float4(o[0], o[1], o[2], o[3]);
+              else if ((attr_n & 1) == 0) {
                 *(float2 *)(mine + 4 * q) = make_float2(o[0], o[1]);
                 if (left >= 4) *(float2 *)(mine + 4 * q + 2) = make_float2(o[2], o[3]);
               } else {
@@ -1103,24 +1137,24 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : INTERP >=
             } else if (in_image) {
               const unsigned u0 = __builtin_bit_cast(unsigned, o[0]), u1 = __builtin_bit_cast(unsigned, o[1]),
                              u2 = __builtin_bit_cast(unsigned, o[2]), u3 = __builtin_bit_cast(unsigned, o[3]);
-              if (left >= 4) __builtin_amdgcn_raw_buffer_store_b128(v4u{u0, u1, u2, u3}, rs_out, lane_out + 16u * q, tile_out, MR_RASTER_INTERP_STORE_AUX);
-              else if (left == 3) __builtin_amdgcn_raw_buffer_store_b96(v3u{u0, u1, u2}, rs_out, lane_out + 16u * q, tile_out, MR_RASTER_INTERP_STORE_AUX);
+              if (left >= 4) store_b128_soffset<MR_RASTER_INTERP_STORE_AUX>(v4u{u0, u1, u2, u3}, rs_out, lane_out + 16u * q, tile_out);
+              else if (left == 3) store_b96_soffset<MR_RASTER_INTERP_STORE_AUX>(v3u{u0, u1, u2}, rs_out, lane_out + 16u * q, tile_out);
               else if (left == 2) __builtin_amdgcn_raw_buffer_store_b64(v2u{u0, u1}, rs_out, lane_out + 16u * q, tile_out, MR_RASTER_INTERP_STORE_AUX);
               else __builtin_amdgcn_raw_buffer_store_b32(u0, rs_out, lane_out + 16u * q, tile_out, MR_RASTER_INTERP_STORE_AUX);
             }
           }
           if constexpr (staged) {
             // (same wavefront: LDS operations complete in order) the tile back as 16-byte chunks, lane + 64 i
-            const unsigned n_chunks = 16u * (unsigned)shade.A;   // 64 pixels x A floats / 4
+            const unsigned n_chunks = 16u * (unsigned)attr_n;   // 64 pixels x A floats / 4
 #pragma unroll
             for (int i = 0; i < AP / 4; ++i) {
               const unsigned jc = (unsigned)lane + 64u * i;
               if (64u * i < n_chunks) {  // wave-uniform
                 const float4 v = *(const float4 *)(stage_slot + 4u * jc);   // (beyond n_chunks: inside the slot, not stored)
                 if (jc < n_chunks)
-                  __builtin_amdgcn_raw_buffer_store_b128(v4u{__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y),
-                                                             __builtin_bit_cast(unsigned, v.z), __builtin_bit_cast(unsigned, v.w)},
-                                                         rs_out, stage_goff[i], tile_out, MR_RASTER_STORE_AUX);
+                  store_b128_soffset<MR_RASTER_STORE_AUX>(v4u{__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y),
+                                                              __builtin_bit_cast(unsigned, v.z), __builtin_bit_cast(unsigned, v.w)},
+                                                          rs_out, stage_goff[i], tile_out);
               }
             }
           }
@@ -1211,8 +1245,8 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : INTERP >=
           typedef unsigned v4u __attribute__((ext_vector_type(4)));
           const unsigned lane_rgba = (unsigned)((kTileH - 1 - ly) * W + lx) * 16u;
           const int tile_rgba = ((R - kTileH - ty * kTileH) * W + tx * kTileW) * 16;
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v4f{rgba.x, rgba.y, rgba.z, rgba.w}), rs_rgba,
-                                                 lane_rgba, tile_rgba, MR_RASTER_STORE_AUX_RGBA);
+          store_b128_soffset<MR_RASTER_STORE_AUX_RGBA>(__builtin_bit_cast(v4u, v4f{rgba.x, rgba.y, rgba.z, rgba.w}), rs_rgba,
+                                                       lane_rgba, tile_rgba);
           if (shade.rgba8) {  // workgroup-uniform: the 8-bit frame for the multi-GPU hand-over, 4 B/px
             auto u8 = [](float v) { return (unsigned)(fminf(fmaxf(v, 0.0f), 1.0f) * 255.0f); };  // NaN -> 0
             const unsigned packed = u8(rgba.x) | (u8(rgba.y) << 8) | (u8(rgba.z) << 16) | (u8(rgba.w) << 24);
@@ -1239,11 +1273,11 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : INTERP >=
           // (same wavefront, LDS operations complete in order: no barrier between the two)
           const v4f run = *(const v4f *)(slot + lx);
           if (lx < kTileW * 3 / 4)
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, run), rs_bary, lane_pix * 12u + (unsigned)lx * 4u,
-                                                   tile_pix * 12, MR_RASTER_STORE_AUX);
+            store_b128_soffset<MR_RASTER_STORE_AUX>(__builtin_bit_cast(v4u, run), rs_bary, lane_pix * 12u + (unsigned)lx * 4u,
+                                                    tile_pix * 12);
         } else {
-          __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(v3u, v3f{st.b0, st.b1, st.b2}), rs_bary, st_lane * 12u,
-                                                st_tile * 12, MR_RASTER_STORE_AUX);
+          store_b96_soffset<MR_RASTER_STORE_AUX>(__builtin_bit_cast(v3u, v3f{st.b0, st.b1, st.b2}), rs_bary, st_lane * 12u,
+                                                 st_tile * 12);
         }
       }
       // Later rounds re-LOAD the pixel state.  vmcnt is in order on gfx950, so the compiler's wait
@@ -1517,9 +1551,9 @@ struct RasterArgs {
   RasterShade shade;  // rgba == nullptr: G-buffer only
 };
 
-template <int R, int PROBE, bool SHADE = false, int INTERP = 0>
+template <int R, int PROBE, bool SHADE = false, int INTERP = 0, int AX = 0>
 void launch_k_raster(const RasterArgs &a, dim3 grid, hipStream_t s) {
-  hipLaunchKernelGGL((k_raster<R, PROBE, SHADE, INTERP>), grid, dim3(kThreads), 0, s, a.recs, a.bbs, a.pxtab, a.pytab, a.T,
+  hipLaunchKernelGGL((k_raster<R, PROBE, SHADE, INTERP, AX>), grid, dim3(kThreads), 0, s, a.recs, a.bbs, a.pxtab, a.pytab, a.T,
                      a.W, a.H, a.regions_x, a.per_image, a.n_regions, a.per_xcd, a.cell_ids, a.cell_count,
                      a.cell_split, a.cells_x, a.cells_per_image, a.region_ids, a.region_count, a.order_count,
                      a.order_list, a.ids, a.bary, a.z, a.shade);
@@ -1529,6 +1563,8 @@ template <int R>
 void launch_k_raster_probe(const RasterArgs &a, dim3 grid, hipStream_t s) {
   if (a.shade.rgba) return launch_k_raster<R, 0, true>(a, grid, s);
   if (a.shade.attr_out) {  // rasterize()'s interpolation as the epilogue, attribute count padded to 4 / 8 / 12 / 16
+    if (a.shade.A == 9) return launch_k_raster<R, 0, false, 12, 9>(a, grid, s);   // (normal, position, colour: render()'s set)
+    if (a.shade.A == 3) return launch_k_raster<R, 0, false, 4, 3>(a, grid, s);
     switch ((a.shade.A + 3) / 4) {
       case 1: return launch_k_raster<R, 0, false, 4>(a, grid, s);
       case 2: return launch_k_raster<R, 0, false, 8>(a, grid, s);

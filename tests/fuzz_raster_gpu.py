@@ -104,8 +104,18 @@ for trial in range(args.trials):
                       bool(torch.allclose(rgba, rgba_ref, atol=1e-5, rtol=1e-5, equal_nan=True)))
         if not (same_g and same_o and same_r):
             bad += 1
+            where = ""
+            if not same_o:
+                d = ~np.isclose(np.nan_to_num(o, posinf=1e30, neginf=-1e30), np.nan_to_num(r, posinf=1e30, neginf=-1e30),
+                                atol=1e-5, rtol=1e-5) | (np.isnan(o) != np.isnan(r))
+                at = np.argwhere(d)
+                print("   differing (b, y, x, a):", [tuple(int(v) for v in t) for t in at[:60]], flush=True)
+                where = " %d elements differ, first (b, y, x, a) = %s: got %r want %r; x range %d..%d, y range %d..%d" % (
+                    len(at), tuple(at[0]), o[tuple(at[0])], r[tuple(at[0])], at[:, 2].min(), at[:, 2].max(), at[:, 1].min(), at[:, 1].max())
+            if os.environ.get("MR_FUZZ_DUMP"):
+                np.savez(os.environ["MR_FUZZ_DUMP"], clip=clip, tris=tris, attrs=attrs.cpu().numpy(), bg=bg.cpu().numpy(), W=W, H=H)
             print(f"EPILOGUE MISMATCH trial {trial} kind {kind} B={B} V={V} T={T} {W}x{H} A={A}: g-buffer {same_g} interp {same_o} "
-                  f"render {same_r}", flush=True)
+                  f"render {same_r}{where}", flush=True)
     if trial % 50 == 49:
         print(f"{trial + 1} trials, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
 print("FUZZ", "FAILED" if bad else "OK", f"{args.trials} trials, {bad} mismatches, {nan_only} with NaN-encoding differences only")

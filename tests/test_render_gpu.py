@@ -299,6 +299,23 @@ def test_rasterize_interpolation_epilogue_matches_two_passes(device, scene, n_at
     assert 0.05 < float((bary.sum(-1) > 0.5).float().mean()) < 0.98
 
 
+def test_wide_store_hazard_soup(device):
+    """Round 4: the soup on which the fuzzer caught a hardware hazard (k_raster's 12- / 16-byte buffer stores with a
+    register soffset, followed at once by a vector write of their data registers: attribute 0 of lanes 12-15 of every
+    16 came out as the pixel's triangle id, on a few tiles, differently from run to run; LLVM inserts the wait
+    state only for stores without a register soffset).  The one-pass forward must equal the two-pass one, every time."""
+    from pytorch_mesh_renderer_amd import _native
+    d = np.load(os.path.join(GOLDEN, "soup_a3_wide_store_hazard.npz"))
+    clip, tris, attrs, bg = [torch.from_numpy(d[k]).to(device) for k in ("clip", "tris", "attrs", "bg")]
+    w, h = int(d["W"]), int(d["H"])
+    ids, bary, _ = _native.rasterize_forward(clip, tris, w, h)
+    want, _ = _native.interpolate_forward_records(ids, bary, attrs, tris, bg)
+    for _ in range(6):
+        ids2, bary2, out, _ = _native.rasterize_interpolate_forward(clip, attrs, tris, bg, w, h)
+        assert torch.equal(ids2, ids) and torch.equal(bary2.view(torch.int32), bary.view(torch.int32))
+        assert bool(torch.isclose(out, want, atol=1e-5, rtol=1e-5, equal_nan=True).all())
+
+
 def test_rasterize_seventeen_attributes_golden(device):
     """The reference's own rasterize() on a random soup with 17 attributes (tools/make_goldens_r4.py attrs)."""
     g = golden_npz("rasterize_soup_a17_40x30.npz")
