@@ -28,6 +28,12 @@ int mr_debug_set_raster_region_edge(int edge);
  * the two kernels on the same inputs. */
 int mr_debug_set_shade_backward_kernel(int which);
 
+/* The functor of the most recent per-triangle accumulation pass (k_accumulate_rows / _lanes / _runs: the pixel pass
+ * of every backward entry point) launched by any thread of this process, as the compiler spells the launcher's
+ * instantiation, e.g. "... [Fn = mr::ShadeFoldLaneFn<1, true>]"; "" before the first one.  The parity tests use it to
+ * make sure the specialised kernel they pin to the reference's gradients is the one that ran.  Static storage. */
+const char *mr_debug_last_accumulate_kernel(void);
+
 /* Stage-timing probes of k_raster.  Only a library built with -DMR_PROBES (make probes ->
  * libmesh_raster_hip_probes.so) contains the probe instantiations; the production library
  * returns MR_EINVAL for every value but 0, its kernel has no probe code at all.

@@ -65,6 +65,13 @@ def debug_set_shade_backward_kernel(which):
     return before
 
 
+def debug_last_accumulate_kernel():
+    """Tests only (include/mesh_raster_debug.h): the functor of the most recent backward pixel pass any thread
+    launched, e.g. 'ShadeFoldLaneFn<1, true>' ('' before the first)."""
+    text = lib().mr_debug_last_accumulate_kernel().decode()
+    return text.split("Fn = mr::")[-1].rstrip("]").replace("(anonymous namespace)::", "") if "Fn = " in text else text
+
+
 def debug_soft_nearest(points, seg_a, seg_b):
     """Tests only (include/mesh_raster_debug.h): the SoftRas kernels' nearest-point-on-a-segment
     evaluation for [n,2] device points / segment ends -> [n,4] = (nearest x, y, t, squared distance)."""
@@ -136,6 +143,8 @@ def lib():
         L.mr_debug_set_raster_region_edge.restype = ci
         L.mr_debug_set_shade_backward_kernel.argtypes = [ci]
         L.mr_debug_set_shade_backward_kernel.restype = ci
+        L.mr_debug_last_accumulate_kernel.argtypes = []
+        L.mr_debug_last_accumulate_kernel.restype = ctypes.c_char_p
         L.mr_debug_soft_nearest.argtypes = [vp, vp, vp, ci, vp, vp]
         L.mr_debug_soft_nearest.restype = ci
         L.mr_rasterize_forward_workspace_bytes.argtypes = [ci] * 5

@@ -27,6 +27,7 @@ extern thread_local int g_raster_probe;
 thread_local KernelTimerSlot g_kernel_timers[MR_TIMER_COUNT];
 extern thread_local int g_deterministic;
 extern thread_local int g_shade_backward_kernel;
+const char *volatile g_last_accumulate_kernel = "";
 }
 
 extern "C" {
@@ -61,6 +62,8 @@ int mr_debug_set_shade_backward_kernel(int which) {
   mr::g_shade_backward_kernel = which;
   return MR_OK;
 }
+
+const char *mr_debug_last_accumulate_kernel(void) { return mr::g_last_accumulate_kernel; }
 
 int mr_debug_set_raster_probe(int probe) {
 #ifdef MR_PROBES

@@ -65,6 +65,12 @@ inline int check_launch() {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// mr_debug_last_accumulate_kernel (mesh_raster_debug.h): the functor of the most recent per-triangle accumulation
+// pass launched by ANY thread of the process (autograd launches backward passes on a thread of its own), as the
+// compiler spells it -- e.g. "... [Fn = mr::ShadeFoldLaneFn<1, true>]".  The parity tests read it to make sure the
+// specialised kernel they mean to pin to the reference is the one that ran.  One relaxed pointer store per launch.
+extern const char *volatile g_last_accumulate_kernel;
+
 // mr_time_next_kernel (mesh_raster.h): per-thread, one-shot pairs of HIP events recorded on the
 // launch stream immediately around one named kernel.  A caller arms a pair, the next launch of
 // that kernel ON THE ARMING THREAD consumes it; nothing is recorded otherwise.

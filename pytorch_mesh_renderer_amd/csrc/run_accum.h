@@ -859,6 +859,7 @@ inline int launch_sum_strip_rows(const float *rows, int B, int per_image, int ro
 template <class Fn>
 inline int launch_accumulate_rows(const Fn &fn, int B, int T, int W, int H, float *acc,
                                   hipStream_t s, const float *det_scale = nullptr) {
+  g_last_accumulate_kernel = __PRETTY_FUNCTION__;
   const int regions_x = (W + kWave - 1) / kWave;
   constexpr int kRowsRegionH = Fn::kRowsPerWave * (kRowsThreads / kWave);
   const int regions_y = (H + kRowsRegionH - 1) / kRowsRegionH;
@@ -895,6 +896,7 @@ inline int lanes_strips_per_image(int B, int W, int H) {
 template <class Fn>
 inline int launch_accumulate_lanes(const Fn &fn, int B, int T, int W, int H, float *acc,
                                    hipStream_t s, const float *det_scale = nullptr) {
+  g_last_accumulate_kernel = __PRETTY_FUNCTION__;
   const int rows = lanes_rows_per_wave<Fn>(B, W, H);
   const int regions_x = (W + kWave - 1) / kWave;
   const int regions_y = (H + rows - 1) / rows;
@@ -910,6 +912,7 @@ inline int launch_accumulate_lanes(const Fn &fn, int B, int T, int W, int H, flo
 template <class Fn>
 inline int launch_accumulate_runs(const Fn &fn, int B, int T, int W, int H, float *acc,
                                   hipStream_t s) {
+  g_last_accumulate_kernel = __PRETTY_FUNCTION__;
   const int regions_x = (W + kWave - 1) / kWave;
   const int regions_y = (H + kRunRegionH - 1) / kRunRegionH;
   const int per_image = regions_x * regions_y;
@@ -925,6 +928,7 @@ inline int launch_accumulate_runs(const Fn &fn, int B, int T, int W, int H, floa
 template <class Fn>
 inline int launch_accumulate_runs_fixed(const Fn &fn, int B, int T, int W, int H, float *acc,
                                         const float *det_scale, hipStream_t s) {
+  g_last_accumulate_kernel = __PRETTY_FUNCTION__;
   const int regions_x = (W + kWave - 1) / kWave;
   const int regions_y = (H + kRunRegionH - 1) / kRunRegionH;
   const int per_image = regions_x * regions_y;
