@@ -1435,9 +1435,11 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : INTERP >=
       const float m0 = (fabsf(mine.q0.x) + fabsf(mine.q0.z)) + fabsf(mine.q1.x);
       const float m1 = (fabsf(mine.q0.y) + fabsf(mine.q0.w)) + fabsf(mine.q1.y);
       const float m2 = (fabsf(mine.q1.z) + fabsf(mine.q1.w)) + fabsf(mine.q2.x);
-      const float mmax = fmaxf(fmaxf(m0, m1), m2);
-      // coefficients that could overflow (or a NaN: the comparison is false): the test lets every pixel through
-      const float ntol = mmax <= 0x1p100f ? -(0x1p-20f * mmax + 0x1p-140f) : -INFINITY;
+      const float mmax = fmaxf(fmaxf(m0, m1), m2);   // (fmaxf drops a NaN operand: the three sums are tested one by one)
+      // coefficients that could overflow, or a NaN in ANY of the three edges (every comparison with it is false):
+      // the test lets every pixel through and the exact test of the depth trip decides
+      const bool tame = (m0 <= 0x1p100f) & (m1 <= 0x1p100f) & (m2 <= 0x1p100f);
+      const float ntol = tame ? -(0x1p-20f * mmax + 0x1p-140f) : -INFINITY;
       *(float4 *)(p + 8) = make_float4(mine.q2.x, ntol, mine.q2.z, mine.q2.w);
       *(float4 *)(p + 12) = mine.q3;
       *(uint4 *)(p + 16) = make_uint4(mine.tail.x, mine.tail.y, __builtin_bit_cast(unsigned, mine.q2.y), 0u);

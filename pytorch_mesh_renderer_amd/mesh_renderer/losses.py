@@ -35,30 +35,29 @@ USE_FUSED_RENDER_LOSS = os.environ.get("MR_FUSED_RENDER_LOSS", "1") != "0"   # F
 
 def forget_target(target):
     """Drops what l1_loss keeps on a target tensor (its empty-block map); see l1_loss, TARGET."""
-    if hasattr(target, "_mr_empty_regions"):
-        del target._mr_empty_regions
+    from .rasterize_triangles_ext import forget_target_map
+    forget_target_map(target)
 
 
 def l1_loss(image, target):
     """mean(|image - target|) over every element; same value and gradients as
-    torch.mean(torch.abs(image - target)) (sign(0) = 0).
+    torch.mean(torch.abs(image - target)) (sign(0) = 0) -- which, written on render()'s own output, arrives here by
+    itself (mesh_renderer/rendered_image.py).
 
     When `image` is the direct output of render()'s fused diffuse path, the backward skips the
     dense gradient image: the loss's sign codes go straight into the shading backward
-    (rasterize_triangles_ext.FusedPhongL1Loss).  That route never forms d loss / d image, so it is
-    taken only while nothing observes that gradient -- no image.retain_grad(), no hook on the image
-    -- and once per rendered image; torch.autograd.grad(loss, image) needs the generic op
-    (USE_FUSED_RENDER_LOSS = False, or any op between render() and the loss).
-
-    ORDERING: whether the image's gradient is observed is decided when this function is CALLED.  A hook or
-    retain_grad() put on `image` AFTER the loss was built never fires / never fills image.grad (the fused
-    backward differentiates image.detach()); register them before calling l1_loss, or switch the fused route off.
+    (rasterize_triangles_ext.FusedPhongL1Loss).  Whether something observes d loss / d image -- image.retain_grad(),
+    a hook on the image, torch.autograd.grad(loss, image) -- is decided when the BACKWARD runs (round 5; until then it
+    was decided here, and a hook registered after this call never fired): the node then behaves like the generic op.
+    One hole remains: torch.autograd.backward(loss, inputs=[image]) spelled through the module function (not
+    loss.backward(inputs=...), not torch.autograd.grad) is not seen; USE_FUSED_RENDER_LOSS = False for that.
 
     TARGET: on that route the 64 x 64 blocks that are all zeros in BOTH images are not read (the renderer knows
-    its own; the target's map is found once and kept on the target tensor, keyed by its data pointer, shape and
-    autograd version counter).  Every in-place torch operation on the target bumps that counter; a write that
-    does not -- through `target.data`, DLPack, a raw pointer -- leaves a stale map behind: call
-    forget_target(target) after such a write (or set MR_EMPTY_REGIONS=0)."""
+    its own; the target's map is found once per target tensor object and kept in a weak map, valid while its
+    data pointer, shape and autograd version counter stay the same).  Every in-place torch operation on the target
+    bumps that counter; a write that does not -- through `target.data`, DLPack, a raw pointer -- leaves a stale
+    map behind until the map's periodic refresh (every 64th use): call forget_target(target) after such a write,
+    set MR_DEBUG_EMPTY_REGIONS=1 to have every use checked, or MR_EMPTY_REGIONS=0 to switch the maps off."""
     if image.shape != target.shape:
         raise ValueError("image and target must have the same shape")
     if image.dtype != torch.float32 or target.dtype != torch.float32:
@@ -67,8 +66,6 @@ def l1_loss(image, target):
         from .rasterize_triangles_ext import FusedPhongL1Loss, take_fused_render
         record = take_fused_render(image)
         if record is not None:
-            # image.detach(): the renderer's own node must not be part of this loss's graph (autograd
-            # would run it on a materialised all-zero gradient image)
-            return FusedPhongL1Loss.apply(image.detach(), target, *record["inputs"], record["saved"],
+            return FusedPhongL1Loss.apply(image, target, *record["inputs"], record["saved"],
                                           record.get("prepared_state"), record.get("empty_regions"))
     return _MeanAbsError.apply(image, target)

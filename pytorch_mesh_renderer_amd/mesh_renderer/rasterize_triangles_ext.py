@@ -227,7 +227,11 @@ class FusedPhongRenderer(torch.autograd.Function):
         ctx.empty_regions = empty_regions
         if frames is not None:
             ctx.mark_non_differentiable(frames)
-        return rgba, frames
+        # FusedPhongL1Loss on this image hands it NO gradient (it differentiates straight to the inputs above): the
+        # node is then called with None and returns at once instead of running a backward over materialised zeros
+        ctx.set_materialize_grads(False)
+        from .rendered_image import wrap
+        return wrap(rgba), frames
 
     @staticmethod
     def _input_grads(saved, needs_transform_grad, needs_light_grads, upstream, l1_signs=None,
@@ -258,6 +262,8 @@ class FusedPhongRenderer(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, drgba, _dframes=None):
+        if drgba is None:   # (set_materialize_grads(False): nothing upstream depends on the image's values)
+            return (None,) * 10
         grads = FusedPhongRenderer._input_grads(ctx.saved_tensors, ctx.needs_input_grad[1],
                                                 any(ctx.needs_input_grad[5:8]), drgba.contiguous(),
                                                 needs_normal_grad=ctx.needs_input_grad[2],
@@ -272,50 +278,124 @@ class FusedPhongRenderer(torch.autograd.Function):
 _fused_renders = weakref.WeakKeyDictionary()
 
 
-def remember_fused_render(node, inputs):
+def remember_fused_render(node, inputs, image=None):
     _fused_renders[node] = {"saved": tuple(node.saved_tensors), "inputs": inputs,
                             "prepared_state": getattr(node, "prepared_state", None),
-                            "empty_regions": getattr(node, "empty_regions", None)}
+                            "empty_regions": getattr(node, "empty_regions", None),
+                            # the empty-block map describes what the renderer WROTE: an in-place edit of the image
+                            # (image[..., 3] = 1 under no_grad keeps the grad_fn) bumps this counter and voids it
+                            "image_version": image._version if image is not None else None}
 
 
 def take_fused_render(image):
-    """The record of render()'s node behind `image` -- once: the caller (losses.l1_loss) hands the saved
-    tensors to FusedPhongL1Loss, which keeps them itself; a second loss on the same image goes
-    through the renderer's own node like any other op.  None when `image` is not such an output, or
-    when something observes the image's own gradient (retain_grad(), a tensor hook): the fused
-    route never forms that gradient."""
+    """The record of render()'s node behind `image` (None when `image` is not render()'s own output: a tensor derived
+    from it has another node).  The record stays with the node: any number of losses may be built on one image, each
+    differentiates straight to the renderer's inputs and the contributions add up.  If the image was edited in place
+    since the renderer wrote it, the record comes back WITHOUT the renderer's empty-block map (the loss then reads
+    every pixel)."""
     node = image.grad_fn
-    if node is None or image.retains_grad or image._backward_hooks:
+    if node is None:
         return None
     try:
-        return _fused_renders.pop(node, None)
+        record = _fused_renders.get(node)
     except TypeError:   # a built-in node (MulBackward0, ...) cannot even be weakly referenced: not ours
         return None
+    if record is not None and record.get("image_version") != image._version:
+        record = dict(record, empty_regions=None)
+    return record
+
+
+# The loss target's empty-block map, kept per target tensor OBJECT (weakly: nothing is written onto the user's tensor,
+# the entry dies with it), valid while its data pointer, shape and autograd version counter stay what they were.
+# A write that bypasses the version counter (target.data, DLPack, a raw kernel) is not seen: every
+# _TARGET_MAP_REFRESH-th use recomputes the map anyway (one small kernel over the target), so a stale map heals
+# itself within that many steps; losses.forget_target(target) drops it at once, and MR_DEBUG_EMPTY_REGIONS=1
+# recomputes on EVERY use and raises if the kept map had gone stale (costs a device synchronisation per loss).
+class _WeakIdMap:
+    """Weak map keyed by object IDENTITY (a WeakKeyDictionary compares keys with ==, which tensors answer elementwise)."""
+
+    def __init__(self):
+        self._entries = {}
+
+    def get(self, obj):
+        entry = self._entries.get(id(obj))
+        return entry[1] if entry is not None and entry[0]() is obj else None
+
+    def set(self, obj, value):
+        key = id(obj)
+        self._entries[key] = (weakref.ref(obj, lambda _, key=key: self._entries.pop(key, None)), value)
+
+    def pop(self, obj):
+        entry = self._entries.get(id(obj))
+        if entry is not None and entry[0]() is obj:
+            del self._entries[id(obj)]
+
+    def __contains__(self, obj):
+        return self.get(obj) is not None
+
+    def __len__(self):
+        return len(self._entries)
+
+
+_target_maps = _WeakIdMap()
+_TARGET_MAP_REFRESH = 64
+_DEBUG_TARGET_MAPS = os.environ.get("MR_DEBUG_EMPTY_REGIONS", "0") == "1"
+
+
+def forget_target_map(target):
+    try:
+        _target_maps.pop(target)
+    except TypeError:
+        pass
 
 
 def _target_empty_regions(target):
-    """image_empty_regions(target), kept on the tensor object while its data pointer and version do not change
+    """image_empty_regions(target), kept per target tensor while its data pointer, shape and version do not change
     (an optimisation loop compares every step's render with the same target)."""
     if target.dim() != 4 or target.shape[-1] != 4 or target.dtype != torch.float32 or not target.is_cuda:
         return None
     key = (target.data_ptr(), target._version, tuple(target.shape))
-    kept = getattr(target, "_mr_empty_regions", None)
-    if kept is not None and kept[0] == key:
-        return kept[1]
-    found = _native.image_empty_regions(target.detach())
     try:
-        target._mr_empty_regions = (key, found)
-    except AttributeError:   # (a tensor subclass without a __dict__)
+        kept = _target_maps.get(target)
+    except TypeError:
+        kept = None
+    if kept is not None and kept[0] == key and not torch.cuda.is_current_stream_capturing():
+        kept[2] += 1
+        if _DEBUG_TARGET_MAPS:
+            found = _native.image_empty_regions(target.detach())
+            if not torch.equal(found, kept[1]):
+                raise RuntimeError("the kept empty-block map of this loss target is stale: the target was written without "
+                                   "its version counter moving (target.data / DLPack / a raw kernel); call "
+                                   "mesh_renderer.losses.forget_target(target) after such a write")
+        if kept[2] % _TARGET_MAP_REFRESH:
+            return kept[1]
+    elif kept is not None and kept[0] == key:
+        return kept[1]   # (inside a stream capture: no counting, the captured graph holds this map)
+    found = _native.image_empty_regions(target.detach())
+    if kept is not None and kept[1].shape == found.shape and kept[1].device == found.device:
+        # refreshed IN PLACE: a captured HIP graph that holds the kept map's address keeps reading a live, current map
+        kept[1].copy_(found)
+        kept[0] = key
+        return kept[1]
+    try:
+        _target_maps.set(target, [key, found, 0])
+    except TypeError:   # (an object that cannot be weakly referenced: recomputed per call)
         pass
     return found
 
 
 class FusedPhongL1Loss(torch.autograd.Function):
     """mean|image - target| for an `image` that FusedPhongRenderer produced, differentiated straight
-    to the renderer's inputs: the backward hands the loss's 1-byte-per-pixel sign codes to the
+    to the renderer's inputs: the backward hands the loss's 2-bit-per-element sign codes to the
     shading backward instead of first writing -- and then re-reading -- a [B,H,W,4] float gradient
-    image (losses.l1_loss routes here; same value, same gradients).  `image` itself receives no
-    gradient from this node: the chain through the renderer is evaluated here, fused."""
+    image (losses.l1_loss routes here; same value, same gradients).
+
+    `image` is an input of this node like any other, but in the fused mode it receives None: the chain through the
+    renderer is evaluated here.  Round 5: whether anybody LOOKS at d loss / d image is decided when the backward runs
+    -- retain_grad() or a tensor hook on the image (registered before or after the loss was built), or a
+    torch.autograd.grad / backward(inputs=...) call that names the image (rendered_image.py) -- and the node then
+    behaves exactly like the generic op: the image gets its dense gradient (formed from the sign codes), the
+    renderer's own node carries it on, and this node adds nothing to the renderer's inputs itself."""
 
     @staticmethod
     def forward(ctx, image, target, vertices, transforms, normals, diffuse, light_positions,
@@ -326,6 +406,7 @@ class FusedPhongL1Loss(torch.autograd.Function):
         loss, signs = _native.l1_loss_forward(image.detach(), target.detach(), want_signs=True,
                                               empty_a=empty_regions, empty_b=empty_target)
         ctx.image_shape = image.shape
+        ctx.image_ref = weakref.ref(image)   # (weak: this node must not keep 16 B/px alive for the caller)
         ctx.prepared_state = prepared_state
         ctx.empty_regions = empty_regions
         # the renderer's own saved tensors (G-buffer, corner records, adjacency, ...): held here too,
@@ -334,14 +415,30 @@ class FusedPhongL1Loss(torch.autograd.Function):
         return loss
 
     @staticmethod
+    def _image_gradient_observed(ctx):
+        from .rendered_image import image_gradient_requested
+        if image_gradient_requested():
+            return True
+        image = ctx.image_ref()
+        if image is None:     # nobody holds the image any more: nothing of it can be looked at
+            return False
+        with torch._C.DisableTorchFunctionSubclass():
+            return bool(image.retains_grad or image._backward_hooks)
+
+    @staticmethod
     def backward(ctx, grad):
         signs = ctx.saved_tensors[0]
         upstream = grad.to(torch.float32).reshape(1)
+        dtarget = None
+        if ctx.needs_input_grad[0] and FusedPhongL1Loss._image_gradient_observed(ctx):
+            dimage = _native.l1_loss_backward(signs, ctx.image_shape, upstream)
+            if ctx.needs_input_grad[1]:
+                dtarget = -dimage
+            return (dimage, dtarget) + (None,) * 10
         dverts, dxf, dn, dd, _, dlp, dli, damb = FusedPhongRenderer._input_grads(
             ctx.saved_tensors[1:], ctx.needs_input_grad[3], any(ctx.needs_input_grad[6:9]), upstream,
             l1_signs=signs, needs_normal_grad=ctx.needs_input_grad[4], needs_diffuse_grad=ctx.needs_input_grad[5],
             prepared_state=ctx.prepared_state, empty_regions=ctx.empty_regions)
-        dtarget = None
         if ctx.needs_input_grad[1]:
             dtarget = -_native.l1_loss_backward(signs, ctx.image_shape, upstream)
         return None, dtarget, dverts, dxf, dn, dd, dlp, dli, damb, None, None, None
@@ -393,7 +490,10 @@ class FusedSpecularPhongRenderer(torch.autograd.Function):
             saved.append(transforms.detach().to(torch.float32).contiguous())
         ctx.save_for_backward(*saved)
         ctx.has_ambient = amb is not None
-        return rgba
+        # (a RenderedImage: the reference's L1 spelling on it runs as losses.l1_loss's generic op -- one pass forward,
+        #  the dense gradient formed from sign codes -- instead of six torch passes over the image)
+        from .rendered_image import wrap
+        return wrap(rgba)
 
     @staticmethod
     def backward(ctx, drgba):

@@ -200,6 +200,8 @@ def _render_fused(vertices, triangles, normals, diffuse_colors, camera_position,
     transforms = clip_space_transforms.to(torch.float32)
     image, frames = FusedPhongRenderer.apply(vertices, transforms, normals, diffuse_colors, triangles, lp, li,
                                              amb, image_width, image_height)
+    if image.grad_fn is None and type(image) is not torch.Tensor:
+        image = image.as_subclass(torch.Tensor)   # nothing to differentiate: no loss spelling to recognise either
     if frames is not None:  # rasterize_triangles_ext.emit_uint8_frames: see to_uint8
         image._mr_frames_u8 = (frames, image._version)
     if image.grad_fn is not None:
@@ -208,7 +210,7 @@ def _render_fused(vertices, triangles, normals, diffuse_colors, camera_position,
         # picklable / deep-copyable), a tensor derived from `image` has another node and never takes
         # that path, and the record dies with the node.
         from .rasterize_triangles_ext import remember_fused_render
-        remember_fused_render(image.grad_fn, (vertices, transforms, normals, diffuse_colors, lp, li, amb))
+        remember_fused_render(image.grad_fn, (vertices, transforms, normals, diffuse_colors, lp, li, amb), image)
     return image
 
 

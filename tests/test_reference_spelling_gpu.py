@@ -1,0 +1,222 @@
+"""The reference's own loss spelling on render()'s output (GPU).
+
+The reference's tests and examples write `torch.mean(torch.abs(render - target))`
+(/root/reference/src/mesh_renderer/mesh_renderer_test.py:250, src/examples/example5.py:70-92).  render() returns a
+RenderedImage (mesh_renderer/rendered_image.py) that recognises exactly that chain and runs it as losses.l1_loss --
+and must be indistinguishable from a plain tensor for everything else.  Every case here is compared with the same
+expression evaluated by plain torch on a detached copy of the image (autograd through torch's own ops).
+"""
+import io
+
+import numpy as np
+import pytest
+import torch
+
+from pytorch_mesh_renderer_amd import _native, mesh_renderer
+from pytorch_mesh_renderer_amd.common import synthetic
+from pytorch_mesh_renderer_amd.mesh_renderer import rendered_image
+from pytorch_mesh_renderer_amd.mesh_renderer.rendered_image import RenderedImage
+
+pytestmark = pytest.mark.gpu
+
+
+class _Scene:
+    def __init__(self, device, B=2, W=96, H=72):
+        self.job = synthetic.sphere_job(B, W, H, 10)
+        self.dev, self.W, self.H = device, W, H
+        self.target = torch.rand(B, H, W, 4, generator=torch.Generator().manual_seed(3)).to(device)
+
+    def render(self, vertices=None, **leaves):
+        j, d = self.job, self.dev
+        v = vertices if vertices is not None else j["vertices"].clone().to(d).requires_grad_(True)
+        img = mesh_renderer.render(v, j["triangles"].to(d), leaves.get("normals", j["normals"].to(d)), j["diffuse"].to(d),
+                                   j["eyes"], torch.zeros(j["eyes"].shape[0], 3), torch.tensor([0.0, 1.0, 0.0]),
+                                   j["light_positions"].to(d), j["light_intensities"].to(d), self.W, self.H)
+        return v, img
+
+
+def _reference_gradient(scene, expression):
+    """d expression(image) / d vertices with the recognition switched off (plain torch ops on the image)."""
+    before = rendered_image.RECOGNISE_L1_SPELLING
+    rendered_image.RECOGNISE_L1_SPELLING = False
+    try:
+        v, img = scene.render()
+        value = expression(img, scene.target)
+        value.backward()
+        return float(value), v.grad.clone()
+    finally:
+        rendered_image.RECOGNISE_L1_SPELLING = before
+
+
+SPELLINGS = {
+    "reference": lambda i, t: torch.mean(torch.abs(i - t)),
+    "methods": lambda i, t: (i - t).abs().mean(),
+    "reversed": lambda i, t: torch.mean(torch.abs(t - i)),
+    "functional": lambda i, t: torch.nn.functional.l1_loss(i, t),
+    "functional_kw": lambda i, t: torch.nn.functional.l1_loss(input=i, target=t, reduction="mean"),
+    "torch_sub": lambda i, t: torch.abs(torch.sub(i, t)).mean(),
+    "subtract_absolute": lambda i, t: torch.absolute(torch.subtract(i, t)).mean(),
+    "dunder": lambda i, t: abs(i - t).mean(),
+}
+
+
+@pytest.mark.parametrize("name", sorted(SPELLINGS))
+def test_the_references_spelling_runs_the_fused_loss(device, name):
+    scene = _Scene(device)
+    want_loss, want_grad = _reference_gradient(scene, SPELLINGS[name])
+    v, img = scene.render()
+    assert isinstance(img, RenderedImage) and isinstance(img, torch.Tensor)
+    before = {k: getattr(_native, k) for k in ("l1_loss_backward",)}
+    calls = {"dense": 0}
+
+    def counted(*a, **k):
+        calls["dense"] += 1
+        return before["l1_loss_backward"](*a, **k)
+    _native.l1_loss_backward = counted
+    try:
+        loss = SPELLINGS[name](img, scene.target)
+        assert type(loss) is torch.Tensor and loss.dim() == 0
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        _native.l1_loss_backward = before["l1_loss_backward"]
+    assert calls["dense"] == 0, "the dense gradient image was formed: not the fused route"
+    ran = _native.debug_last_accumulate_kernel()
+    assert ran.startswith("ShadeFoldLaneFn<1, true>"), ran     # sign-coded upstream, vertices only
+    assert abs(float(loss) - want_loss) <= 2e-6 * want_loss
+    np.testing.assert_allclose(v.grad.cpu().numpy(), want_grad.cpu().numpy(), rtol=2e-4, atol=1e-9)
+
+
+FALLBACKS = {
+    "mean_over_a_dim": lambda i, t: torch.mean(torch.abs(i - t), dim=(1, 2)).sum(),
+    "sum_not_mean": lambda i, t: torch.abs(i - t).sum() * 1e-4,
+    "squared": lambda i, t: ((i - t) ** 2).mean(),
+    "difference_used_twice": lambda i, t: (lambda d: d.abs().mean() + (d * d).mean())(i - t),
+    "abs_used_twice": lambda i, t: (lambda a: a.mean() + a.max())(torch.abs(i - t)),
+    "scaled_target": lambda i, t: torch.mean(torch.abs(i - 2.0 * t)),
+    "alpha": lambda i, t: torch.mean(torch.abs(torch.sub(i, t, alpha=2.0))),
+    "broadcast_target": lambda i, t: torch.mean(torch.abs(i - t[:1])),
+    "scalar": lambda i, t: torch.mean(torch.abs(i - 0.25)),
+    "slice_of_image": lambda i, t: torch.mean(torch.abs(i[..., :3] - t[..., :3])),
+    "scaled_image": lambda i, t: torch.mean(torch.abs(i * 1.5 - t)),
+    "mean_dtype": lambda i, t: torch.mean(torch.abs(i - t), dtype=torch.float64).float(),
+    "inplace_on_difference": lambda i, t: (i - t).abs_().mean(),
+    "sum_reduction": lambda i, t: torch.nn.functional.l1_loss(i, t, reduction="sum") * 1e-4,
+    "mse": lambda i, t: torch.nn.functional.mse_loss(i, t),
+    "clamped": lambda i, t: torch.mean(torch.abs(torch.clamp(i, 0, 1) - t)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(FALLBACKS))
+def test_everything_else_behaves_like_plain_torch(device, name):
+    """Expressions that are NOT the recognised chain: value and vertex gradient with the recognition on must equal
+    those with it off (every op then goes through plain torch)."""
+    scene = _Scene(device)
+    want_loss, want_grad = _reference_gradient(scene, FALLBACKS[name])
+    v, img = scene.render()
+    loss = FALLBACKS[name](img, scene.target)
+    assert type(loss) is torch.Tensor
+    loss.backward()
+    assert abs(float(loss) - want_loss) <= 2e-6 * abs(want_loss)
+    np.testing.assert_allclose(v.grad.cpu().numpy(), want_grad.cpu().numpy(), rtol=2e-4, atol=1e-9 + 1e-6 * float(want_grad.abs().max()))
+
+
+def test_pending_results_answer_like_tensors(device):
+    scene = _Scene(device)
+    v, img = scene.render()
+    d = img - scene.target
+    assert isinstance(d, torch.Tensor) and d.shape == img.shape and d.dtype == torch.float32 and d.device == img.device
+    assert d.dim() == 4 and d.ndim == 4 and d.numel() == img.numel() and d.requires_grad and d.is_cuda and d.size() == img.shape
+    assert d._mr_value is None, "metadata must not compute the difference"
+    want = img.detach() - scene.target
+    assert torch.equal(d.detach(), want) and d._mr_value is not None and d.grad_fn is not None
+    a = torch.abs(img - scene.target)
+    assert "tensor(" in repr(a) and torch.equal(a.cpu(), want.abs().cpu())
+    assert float(a.sum()) == float(want.abs().sum())
+    assert torch.equal(np.abs(0) + a.detach(), want.abs())
+    # a hook on the pending difference: it is computed, the hook fires, the chain continues on the real tensor
+    v2, img2 = scene.render()
+    d2 = img2 - scene.target
+    seen = []
+    d2.register_hook(lambda g: seen.append(tuple(g.shape)))
+    torch.mean(torch.abs(d2)).backward()
+    assert seen == [tuple(img2.shape)] and float(v2.grad.abs().max()) > 0
+    # under no_grad nothing is recognised and nothing is pending
+    with torch.no_grad():
+        plain = img - scene.target
+        assert type(plain) is torch.Tensor and torch.equal(plain, want)
+    # results of ordinary ops are plain tensors; in-place ops and views keep working
+    assert type(img * 2.0) is torch.Tensor and type(img[..., :3]) is torch.Tensor and type(img.detach()) is torch.Tensor
+    assert type(img.clone()) is torch.Tensor and type(img.cpu()) is torch.Tensor
+    buf = io.BytesIO()
+    torch.save(img, buf)
+    buf.seek(0)
+    back = torch.load(buf, weights_only=False)
+    assert type(back) is torch.Tensor and torch.equal(back.to(device), img.detach())
+
+
+def test_the_images_gradient_can_be_observed_at_any_time(device):
+    """d loss / d image through the recognised spelling: a hook registered AFTER the loss was built, retain_grad,
+    torch.autograd.grad naming the image (alone, and together with the vertices), loss.backward(inputs=[image])."""
+    scene = _Scene(device)
+    spelled = SPELLINGS["reference"]
+    want_loss, want_grad = _reference_gradient(scene, spelled)
+    # a late hook
+    v, img = scene.render()
+    loss = spelled(img, scene.target)
+    seen = []
+    img.register_hook(lambda g: seen.append(float(g.abs().sum())))
+    loss.backward()
+    assert len(seen) == 1 and seen[0] > 0
+    np.testing.assert_allclose(v.grad.cpu().numpy(), want_grad.cpu().numpy(), rtol=2e-4, atol=1e-9)
+    # retain_grad, before or after
+    for late in (False, True):
+        v, img = scene.render()
+        if not late:
+            img.retain_grad()
+        loss = spelled(img, scene.target)
+        if late:
+            img.retain_grad()
+        loss.backward()
+        want_dimg = torch.sign(img.detach() - scene.target) / img.numel()
+        assert img.grad is not None and torch.equal(img.grad, want_dimg)
+        np.testing.assert_allclose(v.grad.cpu().numpy(), want_grad.cpu().numpy(), rtol=2e-4, atol=1e-9)
+    # torch.autograd.grad
+    v, img = scene.render()
+    (dimg,) = torch.autograd.grad(spelled(img, scene.target), img)
+    assert torch.equal(dimg, torch.sign(img.detach() - scene.target) / img.numel())
+    v, img = scene.render()
+    dimg, dv = torch.autograd.grad(spelled(img, scene.target), [img, v])
+    assert torch.equal(dimg, torch.sign(img.detach() - scene.target) / img.numel())
+    np.testing.assert_allclose(dv.cpu().numpy(), want_grad.cpu().numpy(), rtol=2e-4, atol=1e-9)
+    v, img = scene.render()
+    (dv,) = torch.autograd.grad(spelled(img, scene.target), [v])
+    np.testing.assert_allclose(dv.cpu().numpy(), want_grad.cpu().numpy(), rtol=2e-4, atol=1e-9)
+    # nobody looks: the image gets no gradient, and a second backward over a retained graph adds the same again
+    v, img = scene.render()
+    loss = spelled(img, scene.target)
+    loss.backward(retain_graph=True)
+    loss.backward()
+    np.testing.assert_allclose(v.grad.cpu().numpy(), 2.0 * want_grad.cpu().numpy(), rtol=2e-4, atol=1e-9)
+    # two losses on one image, one of them an unrecognised expression: contributions add up
+    v, img = scene.render()
+    (spelled(img, scene.target) + (img * img).mean()).backward()
+    _, extra = _reference_gradient(scene, lambda i, t: (i * i).mean())
+    np.testing.assert_allclose(v.grad.cpu().numpy(), (want_grad + extra).cpu().numpy(), rtol=3e-4, atol=1e-9)
+
+
+def test_switches(device):
+    scene = _Scene(device)
+    before = rendered_image.RETURN_SUBCLASS
+    rendered_image.RETURN_SUBCLASS = False
+    try:
+        _, img = scene.render()
+        assert type(img) is torch.Tensor
+    finally:
+        rendered_image.RETURN_SUBCLASS = before
+    _, img = scene.render()
+    assert type(img) is RenderedImage
+    # an image that nothing will differentiate is a plain tensor
+    with torch.no_grad():
+        _, still = scene.render(vertices=scene.job["vertices"].to(device))
+    assert type(still) is torch.Tensor and type(still - scene.target) is torch.Tensor

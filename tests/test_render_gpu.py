@@ -1503,8 +1503,10 @@ def test_render_empty_block_map_serves_the_loss_and_the_backward(device, w, h, b
 
 
 def test_target_empty_block_map_follows_in_place_edits(device):
-    """The target's empty-block map is kept on the tensor, keyed by its version counter: an in-place torch edit that
-    fills a formerly empty block is seen by the next loss; losses.forget_target drops the map by hand."""
+    """The target's empty-block map is kept per target tensor (weakly, nothing is written onto the tensor), keyed by
+    its version counter: an in-place torch edit that fills a formerly empty block is seen by the next loss.  Round 5
+    (ADVICE r4): a write that bypasses the counter (target.data) leaves a stale map -- losses.forget_target drops it
+    at once, the periodic refresh heals it within _TARGET_MAP_REFRESH uses, MR_DEBUG_EMPTY_REGIONS-mode raises."""
     from pytorch_mesh_renderer_amd.mesh_renderer import rasterize_triangles_ext as ext
     job = synthetic.sphere_job(8, 768, 768, 12)
     tris = job["triangles"].to(device)
@@ -1519,16 +1521,73 @@ def test_target_empty_block_map_follows_in_place_edits(device):
 
     got, want = loss_of()
     assert abs(got - want) <= 1e-6 * want
-    first = target._mr_empty_regions[1]
+    assert not hasattr(target, "_mr_empty_regions")          # nothing lives on the user's tensor
+    first = ext._target_maps.get(target)[1]
     assert int(first.sum()) == first.numel()   # an all-zero target: every block empty
     target[3, 710:760, 5:60] = 0.75            # inside ONE corner block the sphere does not reach (G-buffer rows 7..57)
     got, want = loss_of()
     assert abs(got - want) <= 1e-6 * want, "the edit was not seen"
-    assert int(target._mr_empty_regions[1].sum()) == first.numel() - 1
+    assert int(ext._target_maps.get(target)[1].sum()) == first.numel() - 1
+    assert ext._target_maps.get(target)[1] is first, "refreshed in place: a captured graph keeps reading a live map"
+    # a write the version counter does not see: the kept map is stale, the loss silently misses the new block ...
+    version = target._version
+    target.data[5, 10:60, 700:760] = 0.5
+    assert target._version == version
+    got, want = loss_of()
+    assert abs(got - want) > 1e-6 * want, "this is the documented hole: the stale map skips the block"
+    # ... the debug mode raises on it ...
+    before = ext._DEBUG_TARGET_MAPS
+    ext._DEBUG_TARGET_MAPS = True
+    try:
+        with pytest.raises(RuntimeError, match="stale"):
+            loss_of()
+    finally:
+        ext._DEBUG_TARGET_MAPS = before
+    # ... forget_target drops the map at once ...
     mesh_renderer.losses.forget_target(target)
-    assert not hasattr(target, "_mr_empty_regions")
+    assert target not in ext._target_maps
     got, want = loss_of()
     assert abs(got - want) <= 1e-6 * want
+    # ... and without it the periodic refresh heals the map within _TARGET_MAP_REFRESH uses
+    target.data[6, 700:760, 700:760] = 0.25
+    before = ext._TARGET_MAP_REFRESH
+    ext._TARGET_MAP_REFRESH = 4
+    try:
+        healed = False
+        for _ in range(5):
+            got, want = loss_of()
+            healed = healed or abs(got - want) <= 1e-6 * want
+        assert healed and abs(got - want) <= 1e-6 * want
+    finally:
+        ext._TARGET_MAP_REFRESH = before
+    n_maps = len(ext._target_maps)
+    del target
+    import gc
+    gc.collect()
+    assert len(ext._target_maps) == n_maps - 1   # weak: the entry died with the tensor
+
+
+def test_l1_loss_drops_the_renderers_map_when_the_image_was_edited(device):
+    """an in-place edit of render()'s output under no_grad keeps its grad_fn, so the fused loss route still
+    applies -- but the renderer's empty-block map no longer describes the image.  The record carries the image's version
+    counter; after an edit the loss reads every pixel and equals torch.mean(torch.abs())."""
+    job = synthetic.sphere_job(4, 512, 512, 12)
+    tris = job["triangles"].to(device)
+    target = torch.zeros(4, 512, 512, 4, device=device)
+    v = job["vertices"].clone().to(device).requires_grad_(True)
+    img = mesh_renderer.render(v, tris, job["normals"].to(device), job["diffuse"].to(device), job["eyes"],
+                               torch.zeros(4, 3), torch.tensor([0.0, 1.0, 0.0]), job["light_positions"].to(device),
+                               job["light_intensities"].to(device), 512, 512)
+    node = img.grad_fn
+    with torch.no_grad():
+        img[..., 3] = 1.0          # fills every block that was empty (corner blocks of the sphere's frame)
+    assert img.grad_fn is node
+    with _CountCalls("_shade_backward_call") as bwd:
+        loss = mesh_renderer.losses.l1_loss(img, target)
+        want = torch.mean(torch.abs(img.detach() - target))
+        assert abs(float(loss) - float(want)) <= 1e-6 * float(want)
+        loss.backward()
+    assert bwd.calls == 1 and v.grad is not None and float(v.grad.abs().max()) > 0
 
 
 def test_l1_loss_on_a_derived_image_takes_the_generic_path(device):
@@ -1589,18 +1648,18 @@ def test_fused_render_loss_keeps_autograd_semantics_of_the_image(device):
     mesh_renderer.losses.l1_loss(img, target).backward()
     assert len(seen) == 1 and seen[0] > 0
     np.testing.assert_allclose(v2.grad.cpu().numpy(), v0.grad.cpu().numpy(), rtol=2e-4, atol=1e-9)
-    # the decision is taken when l1_loss() is CALLED.  A hook (or retain_grad) put on the image AFTER the
-    # loss was built observes nothing -- the fused route differentiates image.detach() -- which is the documented
-    # ordering requirement (losses.l1_loss); the vertex gradient is unaffected.  To observe d loss / d image, register
-    # before building the loss (above) or set losses.USE_FUSED_RENDER_LOSS = False.
+    # Round 5: the decision is taken when the BACKWARD runs (until round 4: when l1_loss() was called, and a hook put on
+    # the image afterwards never fired -- ADVICE r3's documented hole).  A hook / retain_grad registered AFTER the loss
+    # was built is honoured: the node then behaves like the generic op.
     v2b = leaf()
     img = render(v2b)
     loss = mesh_renderer.losses.l1_loss(img, target)
     late = []
     img.register_hook(lambda g: late.append(1))
     img.retain_grad()
-    loss.backward()
-    assert late == [] and img.grad is None
+    with _CountCalls("l1_loss_backward") as dense:
+        loss.backward()
+    assert late == [1] and img.grad is not None and dense.calls == 1
     np.testing.assert_allclose(v2b.grad.cpu().numpy(), v0.grad.cpu().numpy(), rtol=2e-4, atol=1e-9)
     before = mesh_renderer.losses.USE_FUSED_RENDER_LOSS
     mesh_renderer.losses.USE_FUSED_RENDER_LOSS = False
@@ -1610,15 +1669,22 @@ def test_fused_render_loss_keeps_autograd_semantics_of_the_image(device):
         loss = mesh_renderer.losses.l1_loss(img, target)
         img.register_hook(lambda g: late.append(2))
         loss.backward()
-        assert late == [2]
+        assert late == [1, 2]
     finally:
         mesh_renderer.losses.USE_FUSED_RENDER_LOSS = before
-    # torch.autograd.grad w.r.t. the image: generic route on request
+    # torch.autograd.grad w.r.t. the image (no retain_grad needed since round 5: the call names a RenderedImage)
     v3 = leaf()
     img = render(v3)
-    img.retain_grad()
     (dimg,) = torch.autograd.grad(mesh_renderer.losses.l1_loss(img, target), img)
-    assert dimg.shape == img.shape
+    assert dimg.shape == img.shape and type(dimg) is torch.Tensor
+    want = torch.sign(img.detach() - target) / img.numel()
+    assert torch.equal(dimg, want)
+    # ... together with the vertices: both gradients, neither counted twice
+    v3b = leaf()
+    img = render(v3b)
+    dimg, dv = torch.autograd.grad(mesh_renderer.losses.l1_loss(img, target), [img, v3b])
+    assert torch.equal(dimg, want)
+    np.testing.assert_allclose(dv.cpu().numpy(), v0.grad.cpu().numpy(), rtol=2e-4, atol=1e-9)
     # nothing on the tensor: it pickles and deep-copies; two losses on one image add up
     v4 = leaf()
     img = render(v4)
@@ -1630,6 +1696,8 @@ def test_fused_render_loss_keeps_autograd_semantics_of_the_image(device):
     (mesh_renderer.losses.l1_loss(img, target) + mesh_renderer.losses.l1_loss(img, target)).backward()
     np.testing.assert_allclose(v4.grad.cpu().numpy(), 2.0 * v0.grad.cpu().numpy(), rtol=2e-4, atol=1e-9)
     # the record lives exactly as long as the renderer's node
+    del img
+    gc.collect()
     n_before = len(ext._fused_renders)
     img = render(leaf())
     assert len(ext._fused_renders) == n_before + 1
