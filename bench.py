@@ -119,9 +119,14 @@ class KernelEvents:
         return sum(out) / len(out) if out else 0.0
 
 
-def make_step(job, device, gather, handover="u8"):
+def make_step(job, device, gather, handover="f32", spelling="l1_loss", all_gradients=False, device_cameras=False):
     """Returns (step, vertices, state): state["image"] / state["target"] hold the last rendered
-    batch and the fixed target (the full-size parity test checks them against the oracle)."""
+    batch and the fixed target (the full-size parity test checks them against the oracle).
+
+    spelling: "l1_loss" = mesh_renderer.losses.l1_loss(image, target); "reference" = the reference's own words,
+              torch.mean(torch.abs(image - target)) (mesh_renderer_test.py:250) -- the same kernels since round 5.
+    all_gradients: normals, diffuse colours, light positions and intensities require grad next to the vertices.
+    device_cameras: cameras as device tensors (what a captured HIP graph needs)."""
     width, height = job["width"], job["height"]
     tri = job["triangles"].to(device)
     vertices = job["vertices"].to(device).requires_grad_(True)
@@ -129,15 +134,20 @@ def make_step(job, device, gather, handover="u8"):
     eyes = job["eyes"]                      # cameras stay host tensors, as in the reference's usage
     center = torch.zeros_like(eyes)
     up = torch.tensor([0.0, 1.0, 0.0])
+    if device_cameras:
+        eyes, center, up = eyes.to(device), center.to(device), up.to(device)
     lpos, lint = job["light_positions"].to(device), job["light_intensities"].to(device)
-    transform = mesh_renderer.to_uint8 if handover == "u8" else None
+    leaves = [vertices]
+    if all_gradients:
+        normals, diffuse, lpos, lint = [t.clone().requires_grad_(True) for t in (normals, diffuse, lpos, lint)]
+        leaves += [normals, diffuse, lpos, lint]
     from pytorch_mesh_renderer_amd.mesh_renderer import rasterize_triangles_ext
-    # every frame is handed over: the forward kernel then writes the 8-bit frames itself (4 B/px)
+    # every frame is handed over: with 8-bit frames the forward kernel writes them itself (4 B/px)
     # instead of a conversion pass over the float image on the side stream
-    emit_frames = gather is not None and handover == "u8"
+    state = {"image": None, "handover": True, "handover_dtype": handover}
 
     def forward():
-        with rasterize_triangles_ext.emit_uint8_frames(emit_frames):
+        with rasterize_triangles_ext.emit_uint8_frames(gather is not None and state["handover_dtype"] == "u8"):
             return mesh_renderer.render(vertices, tri, normals, diffuse, eyes, center, up, lpos, lint,
                                         width, height)
 
@@ -148,10 +158,11 @@ def make_step(job, device, gather, handover="u8"):
         rot = torch.tensor([[c, 0.0, s], [0.0, 1.0, 0.0], [-s, 0.0, c]], device=device)
         target = mesh_renderer.render(vertices @ rot.T, tri, normals @ rot.T, diffuse, eyes, center, up,
                                       lpos, lint, width, height)
-    state = {"target": target, "image": None, "handover": True}
+    state["target"] = target
 
     def step():
-        vertices.grad = None
+        for leaf in leaves:
+            leaf.grad = None
         image = forward()
         state["image"] = image
         if gather is not None and state["handover"]:
@@ -160,11 +171,22 @@ def make_step(job, device, gather, handover="u8"):
             # have two whole steps to finish in -- a link-bound hand-over then costs bandwidth, not latency on top
             if gather.in_flight() >= gather.depth:
                 gather.wait()
-            gather.start(image, transform=transform)
-        loss = mesh_renderer.losses.l1_loss(image, target)   # mean |image - target|, one HIP pass each way
+            gather.start(image, transform=mesh_renderer.to_uint8 if state["handover_dtype"] == "u8" else None)
+        if spelling == "reference":
+            loss = torch.mean(torch.abs(image - target))         # /root/reference/src/mesh_renderer/mesh_renderer_test.py:250
+        else:
+            loss = mesh_renderer.losses.l1_loss(image, target)   # mean |image - target|, one HIP pass each way
         loss.backward()
         return loss
 
+    def graph_step():   # for mesh_renderer.capture_step: .grad stays the graph's static memory
+        image = forward()
+        loss = torch.mean(torch.abs(image - target)) if spelling == "reference" else mesh_renderer.losses.l1_loss(image, target)
+        loss.backward()
+        return loss
+
+    state["graph_step"] = graph_step
+    state["leaves"] = leaves
     return step, vertices, state
 
 
@@ -227,6 +249,111 @@ def cpu_baseline(batch, width, height, sphere_k, sample_images):
     }
 
 
+def _loop_ms(fn, n, lead=4):
+    for _ in range(lead):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+def extra_legs(job, device, batch, width, height):
+    """What used to be builder-run only, AFTER the timed region, one GPU, ~20 s in all: the same
+    step through the reference's own loss spelling, with every gradient wanted, replayed as a captured HIP graph, and
+    the other BASELINE.json configurations (ms per step / call and the dominant kernel's fraction of the HBM peak)."""
+    out = {}
+    px = batch * width * height
+    n = 40
+
+    def value(ms):
+        return round(px / ms / 1e3, 2)
+
+    # (a) torch.mean(torch.abs(image - target)), as /root/reference/src/mesh_renderer/mesh_renderer_test.py:250 writes it
+    step_ref, _, _ = make_step(job, device, None, spelling="reference")
+    ms = _loop_ms(step_ref, n)
+    out["ms_per_step_reference_spelling"] = round(ms, 4)
+    out["value_reference_spelling"] = value(ms)
+    del step_ref
+    # (b) every gradient wanted: vertices, normals, diffuse colours, light positions and intensities
+    step_all, _, st = make_step(job, device, None, all_gradients=True)
+    ms = _loop_ms(step_all, n)
+    assert all(leaf.grad is not None for leaf in st["leaves"])
+    out["ms_per_step_all_gradients"] = round(ms, 4)
+    out["value_all_gradients"] = value(ms)
+    del step_all, st
+    # (c) the step (reference spelling, cameras on the device) captured once and replayed: mesh_renderer.capture_step
+    _, _, st = make_step(job, device, None, spelling="reference", device_cameras=True)
+    captured = mesh_renderer.capture_step(st["graph_step"], st["leaves"])
+    ms = _loop_ms(captured.replay, n)
+    out["ms_per_step_graph"] = round(ms, 4)
+    out["value_graph"] = value(ms)
+    del captured, st
+    torch.cuda.empty_cache()
+
+    configs = {}
+    # configs[1]: 5k tris, 256^2, batch 8, forward G-buffer (mr_rasterize_forward)
+    j2 = synthetic.sphere_job(8, 256, 256, 50)
+    clip2, tris2 = j2["clip"].to(device), j2["triangles"].to(device)
+    ms = _loop_ms(lambda: _native.rasterize_forward(clip2, tris2, 256, 256), 100, lead=10)
+    configs["c2"] = {"what": "BASELINE configs[1]: 5k tris, 256x256, batch 8, forward G-buffer, whole mr_rasterize_forward call "
+                             "(setup + binning + raster; launch-bound at this size)", "ms_per_call": round(ms, 4),
+                     "Mpixels_per_s": round(8 * 256 * 256 / ms / 1e3, 1),
+                     "frac_of_hbm_peak": round(8 * 256 * 256 * 20 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+    # configs[3]'s per-GPU share: 50k tris, 2048^2, 8 images -- the step, its forward kernel and the G-buffer kernel
+    j4 = synthetic.sphere_job(8, 2048, 2048, 158)
+    V4, T4, px4 = j4["vertices"].shape[1], j4["triangles"].shape[0], 8 * 2048 * 2048
+    step4, _, _ = make_step(j4, device, None)
+    ms4 = _loop_ms(step4, 30)
+    ev = KernelEvents(4, _native.TIMER_RASTER_FORWARD)
+    for i in range(4):
+        ev.arm(i)
+        step4()
+    torch.cuda.synchronize()
+    fwd_ms = ev.mean_ms(4)
+    del step4
+    clip4, tris4 = j4["clip"].to(device), j4["triangles"].to(device)
+    evg = KernelEvents(3, _native.TIMER_RASTER_FORWARD)
+    _native.debug_set_raster_repeat(8)
+    try:
+        for i in range(4):
+            if i:
+                evg.arm(i - 1)
+            _native.rasterize_forward(clip4, tris4, 2048, 2048)
+    finally:
+        _native.debug_set_raster_repeat(1)
+    torch.cuda.synchronize()
+    gb_ms = evg.mean_ms(3) / 8
+    configs["c4"] = {"what": "BASELINE configs[3], one GPU's share: 50k tris (V=%d, T=%d), 2048x2048, 8 images, render fwd + L1 + "
+                             "bwd to vertex positions" % (V4, T4),
+                     "ms_per_step": round(ms4, 4), "Mpixels_per_s": round(px4 / ms4 / 1e3, 1),
+                     "forward_kernel_ms": round(fwd_ms, 4),
+                     "forward_kernel_frac": round((px4 * 32 + 8 * V4 * 16 + T4 * 12 + 8 * T4 * 128) / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                     "gbuffer_kernel_ms": round(gb_ms, 4),
+                     "gbuffer_kernel_frac": round((px4 * 20 + 8 * V4 * 16 + T4 * 12) / (gb_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+    del clip4, tris4, j4
+    torch.cuda.empty_cache()
+    # configs[4]: SoftRas, 5k tris, 512^2, batch 16, full autograd
+    from pytorch_mesh_renderer_amd import soft_mesh_renderer
+    j5 = synthetic.sphere_job(16, 512, 512, 50)
+    v5 = j5["vertices"].to(device).requires_grad_(True)
+    tri5, kd5, lp5 = j5["triangles"].to(device), j5["diffuse"].to(device), j5["light_positions"].to(device)
+    eyes5, zero5, up5 = j5["eyes"], torch.zeros(16, 3), torch.tensor([0.0, 1.0, 0.0])   # host cameras, as in the reference's usage
+    li5 = torch.ones(16, 1, device=device)
+
+    def step5():
+        v5.grad = None
+        soft_mesh_renderer.render(v5, tri5, kd5, eyes5, zero5, up5, lp5, li5, 512, 512).mean().backward()
+    ms5 = _loop_ms(step5, 30)
+    configs["c5"] = {"what": "BASELINE configs[4]: soft_mesh_renderer (SoftRas aggregation), 5k tris, 512x512, batch 16, forward + "
+                             "mean() + backward to the vertices (tools/soft_bench.py's step)", "ms_per_step": round(ms5, 4),
+                     "Mpixels_per_s": round(16 * 512 * 512 / ms5 / 1e3, 1)}
+    out["configs"] = configs
+    return out
+
+
 def roofline(kernel, algorithmic, avg_ms, traffic_key, config="c3"):
     achieved = algorithmic / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     out = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
@@ -250,8 +377,12 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c3")
-    ap.add_argument("--handover", choices=("u8", "f32"), default="u8",
-                    help="what the ranks hand over to rank 0 when --gpus > 1")
+    ap.add_argument("--handover", choices=("u8", "f32"), default="f32",
+                    help="what the ranks hand over to rank 0 when --gpus > 1 inside the timed region: the fp32 images "
+                         "render() returns (default, the reference's output type) or 8-bit frames; the other one is "
+                         "timed after the region and reported next to it")
+    ap.add_argument("--extras", type=int, default=1,
+                    help="0: skip the legs that run after the timed region (other spellings, gradient sets, configurations)")
     ap.add_argument("--cpu-sample", type=int, default=12, help="images timed for cpu_baseline (0 = skip)")
     args = ap.parse_args()
 
@@ -292,6 +423,7 @@ def main():
     grouped = world > 1 or forced
     gather = distributed.ImageGather(batch * world, mode="root", force_collective=forced, depth=2) if grouped else None
     step, vertices, step_state = make_step(job, device, gather, args.handover)
+    from pytorch_mesh_renderer_amd.mesh_renderer import rasterize_triangles_ext as ext
 
     def barrier():
         if grouped:
@@ -307,17 +439,25 @@ def main():
     # Its own lead-in of untimed steps (12: ~10 ms of GPU time) plays the part the warm-up steps play for the timed
     # region: measured straight after process start the same kernel read 140 us against 134.7 in the rocprofv3
     # trace of the same box (profiles/r04_c_*).
-    n_gb, n_gb_lead = 20, 12
+    # Round 5: the kernel is timed through the product entry point mr_rasterize_forward (what rasterize_barycentric()
+    # launches: ids + barycentrics + depth, 20 B/px) with its k_raster launch repeated 16 times inside ONE event pair
+    # (mr_debug_set_raster_repeat: identical launches, same outputs): an event pair costs the stream ~5 us of idle
+    # time, which on a single 133 us launch decided whether the figure read 0.59 or 0.63.
+    n_gb_rep, n_gb, n_gb_lead = 16, 6, 2
     ev_gbuffer = KernelEvents(n_gb, _native.TIMER_RASTER_FORWARD)
-    from pytorch_mesh_renderer_amd.mesh_renderer import rasterize_triangles_ext as ext
-    with ext.shading_epilogue(False):
+    clip_gb = job["clip"].to(device)
+    tris_gb = job["triangles"].to(device)
+    _native.debug_set_raster_repeat(n_gb_rep)
+    try:
         for i in range(n_gb + n_gb_lead):
             if i >= n_gb_lead:
                 ev_gbuffer.arm(i - n_gb_lead)
-            step()
-    if gather is not None:
-        gather.drain()
+            gb_ids, gb_bary, gb_z = _native.rasterize_forward(clip_gb, tris_gb, width, height)
+    finally:
+        _native.debug_set_raster_repeat(1)
     torch.cuda.synchronize(device)
+    gbuffer_ms = ev_gbuffer.mean_ms(n_gb) / n_gb_rep
+    del gb_ids, gb_bary, gb_z, clip_gb
 
     for _ in range(args.warmup):
         step()
@@ -352,23 +492,51 @@ def main():
 
     # N > 1, also outside the timed region: the same loop with the hand-over switched off, so that the
     # first scaling run separates how the rendering scales from what the root's inbound links cost.
-    render_only_ms = None
-    if grouped:
-        step_state["handover"] = False
-        n_ro = min(args.steps, 50)
+    render_only_ms = other_handover_ms = None
+    other_handover = "u8" if args.handover == "f32" else "f32"
+
+    def max_over_ranks_ms(n):
         barrier()
         t1 = time.perf_counter()
-        for _ in range(n_ro):
+        for _ in range(n):
             step()
+        if gather is not None:
+            gather.drain()
         barrier()
         t = torch.tensor([time.perf_counter() - t1], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        render_only_ms = float(t.item()) / n_ro * 1e3
+        return float(t.item()) / n * 1e3
+
+    if grouped:
+        n_ro = min(args.steps, 50)
+        step_state["handover"] = False
+        render_only_ms = max_over_ranks_ms(n_ro)
         step_state["handover"] = True
+        # ... and the same loop handing over the OTHER image type (8-bit frames from the forward's epilogue / fp32 images)
+        step_state["handover_dtype"] = other_handover
+        for _ in range(3):
+            step()
+        other_handover_ms = max_over_ranks_ms(n_ro)
+        step_state["handover_dtype"] = args.handover
+
+    extras = {}
+    if rank == 0 and world == 1 and args.extras and args.config == "c3":
+        extras = extra_legs(job, device, batch, width, height)
 
     if rank == 0:
         V, T = job["vertices"].shape[1], job["triangles"].shape[0]
         px = batch * width * height
+        # the loss's streaming pass reads a 64 x 64 block unless BOTH maps mark it empty (count those bytes)
+        l1_read_fraction = 1.0
+        if ext.EMPTY_REGIONS and step_state["image"] is not None:
+            with torch.no_grad():
+                # the renderer's own map (blocks without a candidate triangle: what the kernel is handed), not "all zeros"
+                m_img = getattr(step_state["image"].grad_fn, "empty_regions", None)
+                if m_img is None:
+                    m_img = _native.image_empty_regions(step_state["image"].detach())
+                m_tgt = _native.image_empty_regions(step_state["target"].detach())
+                l1_read_fraction = 1.0 - float((m_img.bool() & m_tgt.bool()).float().mean())
+        l1_bytes = int(px * 32 * l1_read_fraction + px * 1)
         line = {
             "metric": "Mpixels/sec forward+backward, %dx%d batch=%d" % (width, height, batch),
             "value": round(world * px * args.steps / elapsed / 1e6, 2),
@@ -389,11 +557,11 @@ def main():
                                  px * 32 + batch * V * 16 + T * 12 + batch * T * 128,
                                  ev_raster.mean_ms(n_ev), "k_raster_shade", args.config),
             "roofline_gbuffer": dict(
-                roofline("k_raster (G-buffer write alone: %d steps with the shading epilogue off)" % n_gb,
-                         px * 20 + batch * V * 16 + T * 12, ev_gbuffer.mean_ms(n_gb), "k_raster", args.config),
-                timed="OUTSIDE the timed region: %d extra steps run BEFORE the warm-up steps with the shading epilogue "
-                      "switched off (rasterize_triangles_ext.shading_epilogue(False)); `value` / `ms_per_step` do not "
-                      "contain them; the first %d of them are an untimed lead-in" % (n_gb + n_gb_lead, n_gb_lead)),
+                roofline("k_raster (G-buffer write: ids + barycentrics + depth, 20 B/px, through mr_rasterize_forward)",
+                         px * 20 + batch * V * 16 + T * 12, gbuffer_ms, "k_raster", args.config),
+                timed="OUTSIDE the timed region, BEFORE the warm-up steps: %d calls of mr_rasterize_forward (after %d untimed "
+                      "ones), each launching its k_raster kernel %d times back to back inside ONE hipEvent pair "
+                      "(mr_debug_set_raster_repeat); avg_kernel_ms = pair time / %d" % (n_gb, n_gb_lead, n_gb_rep, n_gb_rep)),
             # ids + barycentrics (16 B/px) and the loss's sign codes (1 B/px) read, the triangles'
             # difference-basis records (FoldRec, 160 B) read
             "roofline_shade_backward": roofline(
@@ -401,12 +569,15 @@ def main():
                 "clip-space pull-back folded in: 9 sums per triangle kept in registers down each lane's vertical run)",
                 px * 17 + batch * T * 160, ev_shade.mean_ms(n_ev), "shade_backward", args.config),
             # the loss: image and target read (2 x 16 B/px), the sign codes written (1 B/px)
-            "roofline_l1_forward": roofline(
-                "k_l1_forward_regions (mean |image - target| and its sign codes, one streaming pass; 64 x 64 blocks that "
-                "the renderer's and the target's empty-block maps both mark are not read: `achieved` still counts the "
-                "full 33 B/px)",
-                px * 33, ev_l1.mean_ms(n_ev), "l1_forward", args.config),
+            "roofline_l1_forward": dict(
+                roofline("k_l1_forward_regions (mean |image - target| and its sign codes, one streaming pass; 64 x 64 blocks "
+                         "that the renderer's and the target's empty-block maps both mark are not read)",
+                         l1_bytes, ev_l1.mean_ms(n_ev), "l1_forward", args.config),
+                nominal_bytes=px * 33, blocks_read_fraction=round(l1_read_fraction, 4),
+                note="`achieved` counts the bytes of the blocks that ARE read (32 B/px) plus the sign codes written for every "
+                     "pixel (1 B/px); nominal_bytes is the figure earlier rounds divided by the same time"),
         }
+        line.update(extras)
         if grouped:
             line["rccl"] = {"backend": torch.distributed.get_backend(), "ranks": torch.distributed.get_world_size(),
                             "device_per_rank": "cuda:%d of %d visible" % (device.index, torch.cuda.device_count()),
@@ -421,6 +592,11 @@ def main():
             line["handover_GBps_into_root"] = round(
                 (world - 1) * line["rccl"]["handover_bytes_per_rank_per_step"] / (elapsed / args.steps) / 1e9, 2)
             line["handover_depth"] = gather.depth
+            # the other image type through the same loop, after the timed region (f32 is what render() returns and what
+            # SURVEY.md row E sizes; u8 is the reference examples' frame conversion, written by the forward's epilogue)
+            line["ms_per_step_handover_" + other_handover] = round(other_handover_ms, 4)
+            line["value_handover_" + other_handover] = round(world * px / other_handover_ms / 1e3, 2)
+            line["value_handover_" + args.handover] = line["value"]
         if world == 1 and args.cpu_sample > 0:
             line["cpu_baseline"] = cpu_baseline(batch, width, height, sphere_k, args.cpu_sample)
         print(json.dumps(line), flush=True)

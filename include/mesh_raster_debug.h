@@ -28,6 +28,12 @@ int mr_debug_set_raster_region_edge(int edge);
  * the two kernels on the same inputs. */
 int mr_debug_set_shade_backward_kernel(int which);
 
+/* Measurement: the calling thread's next forward calls launch their k_raster kernel n times back to back (1 <= n <= 64;
+ * default 1) -- identical launches that rewrite the same outputs -- inside the ONE event pair of mr_time_next_kernel
+ * (MR_TIMER_RASTER_FORWARD): bench.py times the G-buffer kernel this way, so that the ~5 us of stream idle time an event
+ * pair costs is spread over n launches instead of deciding a 130 us figure.  Results are those of one launch. */
+int mr_debug_set_raster_repeat(int n);
+
 /* The functor of the most recent per-triangle accumulation pass (k_accumulate_rows / _lanes / _runs: the pixel pass
  * of every backward entry point) launched by any thread of this process, as the compiler spells the launcher's
  * instantiation, e.g. "... [Fn = mr::ShadeFoldLaneFn<1, true>]"; "" before the first one.  The parity tests use it to

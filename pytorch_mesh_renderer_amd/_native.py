@@ -65,6 +65,11 @@ def debug_set_shade_backward_kernel(which):
     return before
 
 
+def debug_set_raster_repeat(n):
+    """Measurement only (include/mesh_raster_debug.h): this thread's next forward calls launch k_raster n times."""
+    _check(lib().mr_debug_set_raster_repeat(int(n)), "mr_debug_set_raster_repeat")
+
+
 def debug_last_accumulate_kernel():
     """Tests only (include/mesh_raster_debug.h): the functor of the most recent backward pixel pass any thread
     launched, e.g. 'ShadeFoldLaneFn<1, true>' ('' before the first)."""
@@ -143,6 +148,8 @@ def lib():
         L.mr_debug_set_raster_region_edge.restype = ci
         L.mr_debug_set_shade_backward_kernel.argtypes = [ci]
         L.mr_debug_set_shade_backward_kernel.restype = ci
+        L.mr_debug_set_raster_repeat.argtypes = [ci]
+        L.mr_debug_set_raster_repeat.restype = ci
         L.mr_debug_last_accumulate_kernel.argtypes = []
         L.mr_debug_last_accumulate_kernel.restype = ctypes.c_char_p
         L.mr_debug_soft_nearest.argtypes = [vp, vp, vp, ci, vp, vp]

@@ -21,6 +21,7 @@ inline int check_ws(const void *ws, size_t have, size_t need) {
 
 namespace mr {
 extern thread_local int g_raster_region_edge;
+extern thread_local int g_raster_repeat;
 #ifdef MR_PROBES
 extern thread_local int g_raster_probe;
 #endif
@@ -60,6 +61,12 @@ int mr_debug_set_raster_region_edge(int edge) {
 int mr_debug_set_shade_backward_kernel(int which) {
   if (which < 0 || which > 2) return MR_EINVAL;
   mr::g_shade_backward_kernel = which;
+  return MR_OK;
+}
+
+int mr_debug_set_raster_repeat(int n) {
+  if (n < 1 || n > 64) return MR_EINVAL;
+  mr::g_raster_repeat = n;
   return MR_OK;
 }
 

@@ -460,7 +460,7 @@ int run(const float *dout, const int32_t *ids, const float *bary, const float *c
   p += kDetBlockBytes;
   float *fold_recs = (float *)p;
   const bool det = g_deterministic != 0;
-  if (hipMemsetAsync(acc, 0, (size_t)B * T * AttrRowsFn<AP>::kStride * (det ? sizeof(long long) : sizeof(float)), s) !=
+  if (zero_async(acc, (size_t)B * T * AttrRowsFn<AP>::kStride * (det ? sizeof(long long) : sizeof(float)), s) !=
       hipSuccess)
     return check_launch();
   int rc = MR_OK;
@@ -565,9 +565,9 @@ int launch_interp_raster_backward(const float *dout, const int32_t *ids, const f
                                   int gbuffer_flags, void *ws, hipStream_t s) {
   if (B == 0 || V == 0) return MR_OK;
   if (T == 0 || (size_t)W * H == 0 || A == 0) {  // nothing contributes: the outputs are zeros
-    if ((size_t)A > 0 && hipMemsetAsync(dattrs, 0, (size_t)B * V * A * sizeof(float), s) != hipSuccess)
+    if ((size_t)A > 0 && zero_async(dattrs, (size_t)B * V * A * sizeof(float), s) != hipSuccess)
       return check_launch();
-    if (hipMemsetAsync(dclip, 0, (size_t)B * V * 4 * sizeof(float), s) != hipSuccess) return check_launch();
+    if (zero_async(dclip, (size_t)B * V * 4 * sizeof(float), s) != hipSuccess) return check_launch();
     return MR_OK;
   }
   const float *cr = (const float *)corner_records;

@@ -203,7 +203,7 @@ int launch_interp_backward(const float *dout, const int32_t *ids, const float *b
   const size_t px_per_image = (size_t)W * H;
   const size_t n_px = px_per_image * B;
   if ((size_t)B * V * A > 0 &&
-      hipMemsetAsync(dattrs, 0, (size_t)B * V * A * sizeof(float), s) != hipSuccess)
+      zero_async(dattrs, (size_t)B * V * A * sizeof(float), s) != hipSuccess)
     return check_launch();
   if (n_px == 0 || A == 0) return MR_OK;
   hipLaunchKernelGGL(k_interp_dbary, dim3(capped_blocks(n_px)), dim3(kThreads), 0, s, dout, ids,
@@ -213,7 +213,7 @@ int launch_interp_backward(const float *dout, const int32_t *ids, const float *b
   float *acc = (float *)ws;
   const long nbt = (long)B * T;
   for (int a_begin = 0; a_begin < A; a_begin += kChunk) {
-    if (hipMemsetAsync(acc, 0, (size_t)nbt * kAccStride * sizeof(float), s) != hipSuccess)
+    if (zero_async(acc, (size_t)nbt * kAccStride * sizeof(float), s) != hipSuccess)
       return check_launch();
     AttrGradFn fn{dout, ids, (const F3 *)bary, A, a_begin};
     rc = launch_accumulate_runs(fn, B, T, W, H, acc, s);

@@ -407,7 +407,7 @@ inline unsigned blocks_for(size_t n4) {
 int launch_l1_forward(const float *a, const float *b, size_t n, float *out, uint8_t *signs, float *partials,
                       hipStream_t s) {
   if (n == 0) {
-    if (hipMemsetAsync(out, 0, sizeof(float), s) != hipSuccess) return check_launch();
+    if (zero_async(out, sizeof(float), s) != hipSuccess) return check_launch();
     return MR_OK;
   }
   const size_t n4 = n / 4;
@@ -439,7 +439,7 @@ int launch_l1_forward_regions(const float *a, const float *b, int B, int H, int 
                               const uint8_t *empty_b, float *out, uint8_t *signs, float *partials, hipStream_t s) {
   const size_t n = (size_t)B * H * W * 4;
   if (n == 0) {
-    if (hipMemsetAsync(out, 0, sizeof(float), s) != hipSuccess) return check_launch();
+    if (zero_async(out, sizeof(float), s) != hipSuccess) return check_launch();
     return MR_OK;
   }
   const int bx = (W + kBlockEdge - 1) / kBlockEdge, by = (H + kBlockEdge - 1) / kBlockEdge;

@@ -264,7 +264,7 @@ int launch_camera_transforms(const float *eye, const float *center, const float 
                              const float *near_clip, const float *far_clip, float aspect, int B, float *transforms,
                              int *degenerate, hipStream_t s) {
   if (B == 0) return MR_OK;
-  if (hipMemsetAsync(degenerate, 0, sizeof(int), s) != hipSuccess) return check_launch();
+  if (zero_async(degenerate, sizeof(int), s) != hipSuccess) return check_launch();
   hipLaunchKernelGGL(k_camera_transforms, dim3((unsigned)((B + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
                      (const V3 *)eye, (const V3 *)center, (const V3 *)up, fov_y, near_clip, far_clip, aspect, B,
                      transforms, degenerate);

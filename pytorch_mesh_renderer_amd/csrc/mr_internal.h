@@ -65,6 +65,30 @@ inline int check_launch() {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Zero-fill as a KERNEL, never hipMemsetAsync.  Round 5: a memset NODE of a captured HIP graph replayed after eager work
+// had run on the same device wrote another value than the one captured (ROCm 7.2: the 8-byte empty-block map came out as
+// 0xC6 bytes on the second replay, tests/test_render_gpu.py::test_capture_step_replays_the_references_loop); kernel
+// nodes carry their arguments by value.  Any alignment, any size; 16-byte stores over the aligned body.
+static __global__ __launch_bounds__(256) void k_zero_bytes(unsigned char *__restrict__ p, size_t head, size_t n16, size_t tail) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  uint4 *body = (uint4 *)(p + head);
+  for (size_t k = i; k < n16; k += (size_t)gridDim.x * 256) body[k] = make_uint4(0u, 0u, 0u, 0u);
+  if (i < head) p[i] = 0;
+  if (i < tail) p[head + n16 * 16 + i] = 0;
+}
+inline hipError_t zero_async(void *ptr, size_t bytes, hipStream_t s) {
+  if (bytes == 0 || ptr == nullptr) return hipSuccess;
+  unsigned char *p = (unsigned char *)ptr;
+  size_t head = (size_t)((16 - ((uintptr_t)p & 15)) & 15);
+  if (head > bytes) head = bytes;
+  const size_t n16 = (bytes - head) / 16, tail = bytes - head - n16 * 16;
+  size_t blocks = (n16 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_zero_bytes, dim3((unsigned)blocks), dim3(256), 0, s, p, head, n16, tail);
+  return hipPeekAtLastError();
+}
+
 // mr_debug_last_accumulate_kernel (mesh_raster_debug.h): the functor of the most recent per-triangle accumulation
 // pass launched by ANY thread of the process (autograd launches backward passes on a thread of its own), as the
 // compiler spells it -- e.g. "... [Fn = mr::ShadeFoldLaneFn<1, true>]".  The parity tests read it to make sure the

@@ -339,12 +339,12 @@ int launch_raster_backward(const float *dbary, const float *clip, const int32_t 
                            const int32_t *ids, const float *bary, int B, int V, int T, int W,
                            int H, float *dclip, void *ws, hipStream_t s) {
   if (B == 0 || V == 0) return MR_OK;
-  if (hipMemsetAsync(dclip, 0, (size_t)B * V * 4 * sizeof(float), s) != hipSuccess) return check_launch();
+  if (zero_async(dclip, (size_t)B * V * 4 * sizeof(float), s) != hipSuccess) return check_launch();
   if (T == 0) return MR_OK;
   float *acc = (float *)ws;
   BwdRec *recs = (BwdRec *)((char *)ws + acc_bytes(B, T));
   const bool det = g_deterministic != 0;
-  if (hipMemsetAsync(acc, 0, (size_t)B * T * kStride * (det ? sizeof(long long) : sizeof(float)), s) != hipSuccess)
+  if (zero_async(acc, (size_t)B * T * kStride * (det ? sizeof(long long) : sizeof(float)), s) != hipSuccess)
     return check_launch();
   int rc = launch_bwd_setup(clip, tris, B, V, T, recs, s);
   if (rc != MR_OK) return rc;
@@ -353,7 +353,7 @@ int launch_raster_backward(const float *dbary, const float *clip, const int32_t 
     long long *dclip_fixed = (long long *)((char *)recs + align_up((size_t)B * T * sizeof(BwdRec), 256));
     float *det_scale = (float *)((char *)dclip_fixed + dclip_fixed_bytes(B, V));
     int *max_bits = (int *)(det_scale + 4);
-    if (hipMemsetAsync(dclip_fixed, 0, dclip_fixed_bytes(B, V) + 256, s) != hipSuccess) return check_launch();
+    if (zero_async(dclip_fixed, dclip_fixed_bytes(B, V) + 256, s) != hipSuccess) return check_launch();
     const size_t n = (size_t)B * H * W * 3;
     const size_t want = (n + kThreads - 1) / kThreads;
     hipLaunchKernelGGL(k_abs_max_f, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(kThreads), 0, s, dbary, n, max_bits);

@@ -1516,6 +1516,7 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : INTERP >=
 // workgroups (fewer than four per CU).  Pure function of the dimensions: the workspace query and
 // the launcher must agree on the cell grid.
 thread_local int g_raster_region_edge = 0;  // 0: automatic; 32 / 64: forced (mr_debug_set_raster_region_edge)
+thread_local int g_raster_repeat = 1;       // k_raster launches per call (mr_debug_set_raster_repeat: measurement only)
 
 static int region_edge(int B, int W, int H) {
   if (g_raster_region_edge != 0) return g_raster_region_edge;
@@ -1647,8 +1648,12 @@ int raster_forward(const float *clip, const int32_t *tris, int B, int V, int T, 
                         order_count, order_list, ids, bary, z, shade};
   {
     KernelTimer timer(MR_TIMER_RASTER_FORWARD, s);  // records only when a caller armed it
-    if (edge == 32) launch_k_raster_probe<32>(args, grid, s);
-    else launch_k_raster_probe<64>(args, grid, s);
+    // (mr_debug_set_raster_repeat: the same launch n times back to back inside ONE event pair -- the kernel rewrites
+    //  the same outputs from the same lists -- so that the ~5 us an event pair costs is spread over n launches)
+    for (int r = 0; r < g_raster_repeat; ++r) {
+      if (edge == 32) launch_k_raster_probe<32>(args, grid, s);
+      else launch_k_raster_probe<64>(args, grid, s);
+    }
   }
   return check_launch();
 }
@@ -1699,7 +1704,7 @@ int launch_render_forward(const float *vertices, const float *transforms, const 
   const int rc = launch_vertex_transform(vertices, transforms, B, V, clip, s);
   if (rc != MR_OK) return rc;
   if (empty_regions && region_edge(B, W, H) != 64 && (size_t)B * W * H > 0) {   // 32-pixel regions (small launches): nothing is flagged
-    if (hipMemsetAsync(empty_regions, 0, (size_t)B * ((H + 63) / 64) * ((W + 63) / 64), s) != hipSuccess) return check_launch();
+    if (zero_async(empty_regions, (size_t)B * ((H + 63) / 64) * ((W + 63) / 64), s) != hipSuccess) return check_launch();
   }
   if ((size_t)B * W * H == 0) return MR_OK;
   CornerRec *corners = (CornerRec *)corner_records;

@@ -103,7 +103,7 @@ static __global__ void k_det_scale_from_bits(const int *__restrict__ max_bits, f
 // gain: the largest factor a contribution may carry over the upstream gradient beyond the 2^21 of
 // headroom the scale leaves (1 for the rasterizer / shading passes; 1 / min(sigma, gamma) for SoftRas).
 inline int launch_det_scale(const float *x, size_t n, float gain, float *det_block, hipStream_t s) {
-  if (hipMemsetAsync(det_block, 0, kDetBlockBytes, s) != hipSuccess) return check_launch();
+  if (zero_async(det_block, kDetBlockBytes, s) != hipSuccess) return check_launch();
   const size_t want = (n + 255) / 256;
   hipLaunchKernelGGL(k_det_abs_max, dim3((unsigned)(want < 2048 ? (want ? want : 1) : 2048)), dim3(256), 0, s, x, n,
                      (int *)det_block + 4);

@@ -951,15 +951,15 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
   if (fused_clear) {   // (always the case with `fold`: transforms imply the adjacency, and it excludes det)
   } else if (dnormals && ddiffuse && (char *)dnormals == (char *)dclip + v4 && (char *)dpositions == (char *)dnormals + v3 &&
              (char *)ddiffuse == (char *)dpositions + v3 && (char *)light_grads == (char *)ddiffuse + v3) {
-    if (hipMemsetAsync(dclip, 0, v4 + 3 * v3 + lg, s) != hipSuccess) return check_launch();
+    if (zero_async(dclip, v4 + 3 * v3 + lg, s) != hipSuccess) return check_launch();
   } else {
     if (V > 0) {
-      if (hipMemsetAsync(dclip, 0, v4, s) != hipSuccess) return check_launch();
-      if (dnormals && hipMemsetAsync(dnormals, 0, v3, s) != hipSuccess) return check_launch();
-      if (hipMemsetAsync(dpositions, 0, v3, s) != hipSuccess) return check_launch();
-      if (ddiffuse && hipMemsetAsync(ddiffuse, 0, v3, s) != hipSuccess) return check_launch();
+      if (zero_async(dclip, v4, s) != hipSuccess) return check_launch();
+      if (dnormals && zero_async(dnormals, v3, s) != hipSuccess) return check_launch();
+      if (zero_async(dpositions, v3, s) != hipSuccess) return check_launch();
+      if (ddiffuse && zero_async(ddiffuse, v3, s) != hipSuccess) return check_launch();
     }
-    if (light_grads && hipMemsetAsync(light_grads, 0, lg, s) != hipSuccess) return check_launch();
+    if (light_grads && zero_async(light_grads, lg, s) != hipSuccess) return check_launch();
   }
   if (T == 0 || V == 0) return MR_OK;
   float *acc = (float *)ws;
@@ -985,10 +985,10 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
   }
   if (det && !(vertex_offsets && vertex_entries)) return MR_EINVAL;  // the scatter path is atomics only
   const size_t acc_bytes = (size_t)B * T * 36 * (det ? sizeof(long long) : sizeof(float));
-  if (!fused_clear && hipMemsetAsync(acc, 0, acc_bytes, s) != hipSuccess) return check_launch();
+  if (!fused_clear && zero_async(acc, acc_bytes, s) != hipSuccess) return check_launch();
   int rc = MR_OK;
   if (det) {
-    if (hipMemsetAsync(det_scale, 0, kDetMiscBytes, s) != hipSuccess) return check_launch();
+    if (zero_async(det_scale, kDetMiscBytes, s) != hipSuccess) return check_launch();
     if (!signs) {
       const size_t n4 = (size_t)B * H * W;
       const unsigned blocks = capped_blocks(n4) < 2048u ? capped_blocks(n4) : 2048u;

@@ -992,7 +992,7 @@ int spec_backward(const float *drgba, const int32_t *ids, const float *bary, con
   float *det_block = (float *)p;
   p += kDetBlockBytes;
   SpecFoldRec<A> *fold_recs = (SpecFoldRec<A> *)p;
-  if (hipMemsetAsync(acc, 0, (size_t)B * T * 48 * (det ? sizeof(long long) : sizeof(float)), s) != hipSuccess)
+  if (zero_async(acc, (size_t)B * T * 48 * (det ? sizeof(long long) : sizeof(float)), s) != hipSuccess)
     return check_launch();
   int rc = MR_OK;
   if (det && (rc = launch_det_scale(drgba, (size_t)B * H * W * 4, 1.0f, det_block, s)) != MR_OK) return rc;
@@ -1113,16 +1113,16 @@ int launch_shade_specular_backward(const float *drgba, const int32_t *ids, const
   const size_t v3 = (size_t)B * V * 3 * sizeof(float);
   const bool gathered = vertex_offsets && vertex_entries && T > 0 && (size_t)W * H > 0;  // every output written once
   if (V > 0 && !gathered) {
-    if (hipMemsetAsync(dclip, 0, (size_t)B * V * 4 * sizeof(float), s) != hipSuccess) return check_launch();
-    if (hipMemsetAsync(dnormals, 0, v3, s) != hipSuccess) return check_launch();
-    if (hipMemsetAsync(dpositions, 0, v3, s) != hipSuccess) return check_launch();
-    if (hipMemsetAsync(ddiffuse, 0, v3, s) != hipSuccess) return check_launch();
-    if (hipMemsetAsync(dspecular, 0, v3, s) != hipSuccess) return check_launch();
+    if (zero_async(dclip, (size_t)B * V * 4 * sizeof(float), s) != hipSuccess) return check_launch();
+    if (zero_async(dnormals, v3, s) != hipSuccess) return check_launch();
+    if (zero_async(dpositions, v3, s) != hipSuccess) return check_launch();
+    if (zero_async(ddiffuse, v3, s) != hipSuccess) return check_launch();
+    if (zero_async(dspecular, v3, s) != hipSuccess) return check_launch();
     if (shininess_per_vertex &&
-        hipMemsetAsync(dshininess, 0, (size_t)B * V * sizeof(float), s) != hipSuccess)
+        zero_async(dshininess, (size_t)B * V * sizeof(float), s) != hipSuccess)
       return check_launch();
   }
-  if (hipMemsetAsync(light_grads, 0, (size_t)B * (L * 6 + 7) * sizeof(float), s) != hipSuccess)
+  if (zero_async(light_grads, (size_t)B * (L * 6 + 7) * sizeof(float), s) != hipSuccess)
     return check_launch();
   if (T == 0 || V == 0 || (size_t)W * H == 0) return MR_OK;
   return shininess_per_vertex

@@ -932,16 +932,16 @@ int launch_soft_backward(const float *drgba, const float *rgba, const float *aux
   if ((char *)dpositions == (char *)dclip + v4 && (char *)dnormals == (char *)dpositions + v3 &&
       (char *)ddiffuse == (char *)dnormals + v3 && (char *)dlpos == (char *)ddiffuse + v3 &&
       (char *)dlint == (char *)dlpos + l3) {
-    if (hipMemsetAsync(dclip, 0, v4 + 3 * v3 + l3 + l1, s) != hipSuccess) return check_launch();
+    if (zero_async(dclip, v4 + 3 * v3 + l3 + l1, s) != hipSuccess) return check_launch();
   } else {
     if (V > 0) {
-      if (hipMemsetAsync(dclip, 0, v4, s) != hipSuccess) return check_launch();
-      if (hipMemsetAsync(dpositions, 0, v3, s) != hipSuccess) return check_launch();
-      if (hipMemsetAsync(dnormals, 0, v3, s) != hipSuccess) return check_launch();
-      if (hipMemsetAsync(ddiffuse, 0, v3, s) != hipSuccess) return check_launch();
+      if (zero_async(dclip, v4, s) != hipSuccess) return check_launch();
+      if (zero_async(dpositions, v3, s) != hipSuccess) return check_launch();
+      if (zero_async(dnormals, v3, s) != hipSuccess) return check_launch();
+      if (zero_async(ddiffuse, v3, s) != hipSuccess) return check_launch();
     }
-    if (hipMemsetAsync(dlpos, 0, l3, s) != hipSuccess) return check_launch();
-    if (hipMemsetAsync(dlint, 0, l1, s) != hipSuccess) return check_launch();
+    if (zero_async(dlpos, l3, s) != hipSuccess) return check_launch();
+    if (zero_async(dlint, l1, s) != hipSuccess) return check_launch();
   }
   if (T == 0 || V == 0 || (size_t)W * H == 0) return MR_OK;
   SoftRec *recs;
@@ -971,7 +971,7 @@ int launch_soft_backward(const float *drgba, const float *rgba, const float *aux
   if (det) {
     // the scale: a contribution carries up to 1 / sigma (or 1 / gamma) over the upstream gradient before the
     // geometry factors; the fixed point's 2^21 of headroom takes those
-    if (hipMemsetAsync(det_fixed, 0, (size_t)B * V * 13 * sizeof(long long), s) != hipSuccess) return check_launch();
+    if (zero_async(det_fixed, (size_t)B * V * 13 * sizeof(long long), s) != hipSuccess) return check_launch();
     const float gain = 1.0f / fminf(fminf(sigma, gamma), 1.0f);
     const int rcd = launch_det_scale(drgba, (size_t)B * H * W * 4, gain, det_block, s);
     if (rcd != MR_OK) return rcd;

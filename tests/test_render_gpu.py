@@ -1253,6 +1253,46 @@ def test_step_is_capturable_into_a_hip_graph(device):
     assert float(got_grad.abs().max()) > 0
 
 
+def test_capture_step_replays_the_references_loop(device):
+    """mesh_renderer.capture_step (round 5): the step as the reference's optimisation tests write it
+    (mesh_renderer_test.py:238-262: render, mean(abs(image - target)), backward, an optimizer update in place) captured
+    once and replayed: every replay equals the eager step on the same parameter values."""
+    job = synthetic.sphere_job(2, 96, 96, 8)
+    d = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in job.items()}
+    vertices = d["vertices"].clone().requires_grad_(True)
+    center, up = torch.zeros_like(d["eyes"]), torch.tensor([0.0, 1.0, 0.0], device=device)
+
+    def render():
+        return mesh_renderer.render(vertices, d["triangles"], d["normals"], d["diffuse"], d["eyes"], center, up,
+                                    d["light_positions"], d["light_intensities"], 96, 96)
+    with torch.no_grad():
+        target = render().roll(4, 2).contiguous()
+
+    def step():
+        loss = torch.mean(torch.abs(render() - target))     # the reference's spelling
+        loss.backward()
+        return loss
+    captured = mesh_renderer.capture_step(step, [vertices])
+    assert isinstance(captured, mesh_renderer.CapturedStep)
+    optimizer = torch.optim.SGD([vertices], lr=0.5)
+    losses = []
+    for it in range(4):
+        loss = captured.replay()
+        torch.cuda.synchronize()
+        got_loss, got_grad = float(loss), vertices.grad.clone()
+        # the same step eagerly, on the same values
+        keep = vertices.grad
+        vertices.grad = None
+        want_loss = float(step().detach())
+        want_grad = vertices.grad
+        vertices.grad = keep
+        assert abs(got_loss - want_loss) < 1e-7
+        np.testing.assert_allclose(got_grad.cpu().numpy(), want_grad.cpu().numpy(), atol=1e-9, rtol=1e-5, err_msg="replay %d" % it)
+        losses.append(got_loss)
+        optimizer.step()                                     # in place: the next replay reads the new vertices
+    assert losses[-1] < losses[0], losses
+
+
 def test_host_camera_memo_stays_out_of_graph_captures_and_orders_streams(device):
     """(1) the host-camera memo is neither read nor written while a stream is capturing -- a
     warm-up render() must not make a capture with host cameras succeed by baking the kept tensor's address
