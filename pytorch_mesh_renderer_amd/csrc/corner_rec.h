@@ -87,8 +87,17 @@ __device__ __forceinline__ void load_fold_triangle(const FoldRec *__restrict__ r
 
 // FoldRec from a corner record's 27 values c[corner * 9 + attribute], the sign-corrected adjugate u[9] (row i =
 // edge i, column c = clip component x / y / w) and 1 / |det| (rasterize_triangles.cpp:180-198).
+//
+// pull (round 5; nullptr = the layout above): the image's clip-space transform rows x / y / w, pull[r * 4 + c'] =
+// M[{0, 1, 3}[r]][c'] -- the record then carries the rasterizer's backward ALREADY pulled back to world space, for
+// the kernel that wants the whole vertex gradient and nothing else (ShadeFoldLaneFn).  With g0 = dL/db0 - dL/db2,
+// g1 = dL/db1 - dL/db2 the clip-space bracket of a pixel is q_c = (g0 (s_c b0 - u_0c) + g1 (s_c b1 - u_1c)) / |det|
+// and its pull-back (M^T q)_c' = (g0 b0 + g1 b1) S_c' + g0 P0_c' + g1 P1_c' with the per-TRIANGLE vectors
+//   S_c' = sum_r pull[r][c'] s_r / |det|,  P0_c' = -sum_r pull[r][c'] u_0r / |det|,  P1_c' = -sum_r pull[r][c'] u_1r / |det|:
+// 11 multiply-adds per pixel instead of 24, and still one cancellation PER PIXEL between the b S and the P terms
+// (nothing is summed over pixels before it).  Slots 27..35 = S, P0, P1; the record's tenth quad is unused.
 __device__ __forceinline__ void store_fold_record(const float (&c)[32], const float (&u)[9], float inv_abs_det,
-                                                  FoldRec *__restrict__ out) {
+                                                  FoldRec *__restrict__ out, const float *__restrict__ pull = nullptr) {
   float v[40];
 #pragma unroll
   for (int a = 0; a < 9; ++a) {
@@ -96,13 +105,51 @@ __device__ __forceinline__ void store_fold_record(const float (&c)[32], const fl
     v[9 + a] = c[9 + a] - c[18 + a];
     v[18 + a] = c[18 + a];
   }
+  float s3[3];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) v[27 + k] = u[k];
+  for (int c3 = 0; c3 < 3; ++c3) s3[c3] = (u[c3] + u[3 + c3]) + u[6 + c3];  // cpp:187-198
+  if (pull) {
 #pragma unroll
-  for (int c3 = 0; c3 < 3; ++c3) v[33 + c3] = (u[c3] + u[3 + c3]) + u[6 + c3];  // cpp:187-198
-  v[36] = inv_abs_det; v[37] = 0.f; v[38] = 0.f; v[39] = 0.f;
+    for (int cw = 0; cw < 3; ++cw) {
+      const float p0 = pull[cw], p1 = pull[4 + cw], p2 = pull[8 + cw];   // column c' of the x, y, w rows
+      v[27 + cw] = ((p0 * s3[0] + p1 * s3[1]) + p2 * s3[2]) * inv_abs_det;
+      v[30 + cw] = -(((p0 * u[0] + p1 * u[1]) + p2 * u[2]) * inv_abs_det);
+      v[33 + cw] = -(((p0 * u[3] + p1 * u[4]) + p2 * u[5]) * inv_abs_det);
+    }
+    v[36] = 0.f;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) v[27 + k] = u[k];
+#pragma unroll
+    for (int c3 = 0; c3 < 3; ++c3) v[33 + c3] = s3[c3];
+    v[36] = inv_abs_det;
+  }
+  v[37] = 0.f; v[38] = 0.f; v[39] = 0.f;
 #pragma unroll
   for (int q = 0; q < 10; ++q) out->q[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+}
+// the three transform rows a pulled record needs, as 12 floats (rows x, y, w of image b's [4][4] matrix)
+__device__ __forceinline__ void load_pull_rows(const float *__restrict__ transforms, int b, float (&pull)[12]) {
+  const float *m = transforms + (size_t)b * 16;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) pull[r * 4 + c] = m[(r == 2 ? 3 : r) * 4 + c];
+}
+struct FoldTriangleW {   // the pulled record: see store_fold_record
+  float e0[9], e1[9], c2[9], S[3], P0[3], P1[3];
+};
+__device__ __forceinline__ void load_fold_triangle_w(const FoldRec *__restrict__ rec, FoldTriangleW &t) {
+  float v[36];
+#pragma unroll
+  for (int q = 0; q < 9; ++q) {
+    const float4 f = rec->q[q];
+    v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w;
+  }
+#pragma unroll
+  for (int a = 0; a < 9; ++a) { t.e0[a] = v[a]; t.e1[a] = v[9 + a]; t.c2[a] = v[18 + a]; }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { t.S[c] = v[27 + c]; t.P0[c] = v[30 + c]; t.P1[c] = v[33 + c]; }
 }
 
 // The block mr_render_forward can prepare for the folded shading backward (include/mesh_raster.h,

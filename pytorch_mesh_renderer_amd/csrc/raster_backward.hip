@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void k_bwd_setup(
     const float4 *__restrict__ clip, const int32_t *__restrict__ tris, int B, int V, int T,
     BwdRec *__restrict__ recs, float4 *__restrict__ zero_rows, int zero_row_quads,
     float *__restrict__ zero_tail, int zero_tail_count, const CornerRec *__restrict__ corners,
-    FoldRec *__restrict__ fold_recs) {
+    FoldRec *__restrict__ fold_recs, const float *__restrict__ pull_transforms) {
   const long gid = (long)blockIdx.x * 256 + threadIdx.x;
   for (long i = gid; i < zero_tail_count; i += (long)gridDim.x * 256) zero_tail[i] = 0.0f;
   {  // the workgroup's 256 rows are one contiguous range: cleared with coalesced 16-byte stores
@@ -79,20 +79,26 @@ __global__ __launch_bounds__(256) void k_bwd_setup(
       c[4 * q] = f.x; c[4 * q + 1] = f.y; c[4 * q + 2] = f.z; c[4 * q + 3] = f.w;
     }
     const float u[9] = {r.a.x, r.a.y, r.a.z, r.a.w, r.b.x, r.b.y, r.b.z, r.b.w, r.c.x};
-    store_fold_record(c, u, r.d.x, fold_recs + gid);
+    if (pull_transforms) {   // (launch-uniform) the pulled form, for ShadeFoldLaneFn
+      float pull[12];
+      load_pull_rows(pull_transforms, b, pull);
+      store_fold_record(c, u, r.d.x, fold_recs + gid, pull);
+    } else {
+      store_fold_record(c, u, r.d.x, fold_recs + gid);
+    }
   }
 }
 
 int launch_bwd_setup(const float *clip, const int32_t *tris, int B, int V, int T, BwdRec *recs,
                      hipStream_t s, void *zero_rows, size_t zero_row_bytes, float *zero_tail,
-                     int zero_tail_count, const void *corners, void *fold_recs) {
+                     int zero_tail_count, const void *corners, void *fold_recs, const float *pull_transforms) {
   const long nbt = (long)B * T;
   if (nbt == 0) return MR_OK;
   if (zero_row_bytes % 16 != 0 || ((corners == nullptr) != (fold_recs == nullptr))) return MR_EINVAL;
   hipLaunchKernelGGL(k_bwd_setup, dim3((unsigned)((nbt + 255) / 256)), dim3(256), 0, s,
                      (const float4 *)clip, tris, B, V, T, recs, (float4 *)zero_rows,
                      zero_rows ? (int)(zero_row_bytes / 16) : 0, zero_tail, zero_tail ? zero_tail_count : 0,
-                     (const CornerRec *)corners, (FoldRec *)fold_recs);
+                     (const CornerRec *)corners, (FoldRec *)fold_recs, pull_transforms);
   return check_launch();
 }
 

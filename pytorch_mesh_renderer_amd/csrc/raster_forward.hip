@@ -125,6 +125,7 @@ struct SetupAttributes {
   // accumulator row, so that the backward needs no setup launch of its own (k_bwd_setup: 19 us at 1024^2 x 32).
   FoldRec *__restrict__ fold_recs;
   float4 *__restrict__ fold_acc;   // [B*T][kFoldAccStride / 4]
+  const float *__restrict__ fold_transforms;   // [B,4,4] (with fold_recs): the records carry the pulled form (corner_rec.h)
 };
 
 // Heaviest regions first (round 3).  k_raster's workgroups cost anything between ~5 us (background)
@@ -229,7 +230,9 @@ __global__ __launch_bounds__(kThreads) void k_setup(
         recs[gid] = rec;
         if (attrs.fold_recs) {  // (only triangles that can be drawn are ever looked up by a pixel)
           const float u[9] = {m0, m1, m2, m3, m4, m5, m6, m7, m8};
-          store_fold_record(corner_values, u, 1.0f / fabsf(det), attrs.fold_recs + gid);
+          float pull[12];
+          load_pull_rows(attrs.fold_transforms, b, pull);
+          store_fold_record(corner_values, u, 1.0f / fabsf(det), attrs.fold_recs + gid, pull);
         }
       }
     }
@@ -1663,7 +1666,7 @@ int launch_raster_forward(const float *clip, const int32_t *tris, int B, int V, 
                           int H, int32_t *ids, float *bary, float *z, void *ws, hipStream_t s) {
   return raster_forward(clip, tris, B, V, T, W, H, ids, bary, z,
                         RasterShade{nullptr, Lights{nullptr, nullptr, nullptr, 0}, nullptr, nullptr, 1, nullptr, nullptr, nullptr, 0, nullptr},
-                        SetupAttributes{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, ws, s);
+                        SetupAttributes{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, ws, s);
 }
 
 // rasterize_clip_space() forward for up to 16 attributes in ONE pass over the pixels (round 4): the attribute
@@ -1679,7 +1682,7 @@ int launch_rasterize_interpolate_forward(const float *clip, const float *attrs, 
   return raster_forward(clip, tris, B, V, T, W, H, ids, bary, z,
                         RasterShade{nullptr, Lights{nullptr, nullptr, nullptr, 0}, nullptr, nullptr, 0, (const float *)records,
                                     background, out, A, nullptr},
-                        SetupAttributes{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, ws, s);
+                        SetupAttributes{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, ws, s);
 }
 
 int launch_vertex_transform(const float *vertices, const float *transforms, int B, int V, float *clip,
@@ -1714,7 +1717,8 @@ int launch_render_forward(const float *vertices, const float *transforms, const 
                         SetupAttributes{(const F3 *)normals, (const F3 *)vertices, (const F3 *)diffuse, corners,
                                         (FoldRec *)backward_prepared,
                                         backward_prepared ? (float4 *)((char *)backward_prepared + fold_prepared_recs_bytes(B, T))
-                                                          : nullptr},
+                                                          : nullptr,
+                                        transforms},
                         ws, s);
 }
 

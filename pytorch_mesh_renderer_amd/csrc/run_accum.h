@@ -1020,10 +1020,10 @@ __device__ __forceinline__ void raster_pixel_partials(const F3 bary, const F3 g,
 // One thread per (image, triangle): fills BwdRec from clip-space vertices.
 // zero_rows / zero_tail: see k_bwd_setup (raster_backward.hip); zero_row_bytes is a multiple of 16.
 // corners + fold_recs (both or neither): also write the folded lane kernel's FoldRec[B*T] (corner_rec.h) from
-// the CornerRec[B*T] of the same inputs.
+// the CornerRec[B*T] of the same inputs; pull_transforms ([B,4,4], optional): in the pulled form (store_fold_record).
 int launch_bwd_setup(const float *clip, const int32_t *tris, int B, int V, int T, BwdRec *recs,
                      hipStream_t s, void *zero_rows = nullptr, size_t zero_row_bytes = 0,
                      float *zero_tail = nullptr, int zero_tail_count = 0, const void *corners = nullptr,
-                     void *fold_recs = nullptr);
+                     void *fold_recs = nullptr, const float *pull_transforms = nullptr);
 
 }  // namespace mr

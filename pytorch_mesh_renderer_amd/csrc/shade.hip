@@ -278,18 +278,22 @@ struct ShadeGradFn {
   // The shading's backward at one pixel: from the interpolated attributes at[9] = (normal, position, diffuse
   // colour) and the upstream gradient g of the pixel's RGB to dat[9] = d L / d at (render.py:199-228, 287-323
   // differentiated by hand); the light / ambient gradients go to the per-lane sums of `im` (LG).
+  // UNSCALED (sign-coded upstream only): g stays the bare sign (-1, 0, +1); every output is linear in g, so the
+  // caller's consumer multiplies the finished sums by the loss's scale once per vertex instead of once per pixel.
+  template <bool UNSCALED = false>
   __device__ __forceinline__ void attribute_gradients(const float (&at)[9], const F3 &pg, Image &im,
                                                       float (&dat_out)[9]) const {
     // render.py:215 mask: where() sends no gradient to a masked pixel.  All 36 outputs are
     // linear in g, so a masked pixel simply runs with g = 0 (every output must be assigned).
     const bool mask = (at[6] >= 0.0f) || (at[7] >= 0.0f) || (at[8] >= 0.0f);
 
-    const float gs = SIGNS ? im.g_scale : 1.0f;
+    const float gs = (SIGNS && !UNSCALED) ? im.g_scale : 1.0f;
     const float g[3] = {mask ? pg.x * gs : 0.f, mask ? pg.y * gs : 0.f, mask ? pg.z * gs : 0.f};
     const float nn2 = at[0] * at[0] + at[1] * at[1] + at[2] * at[2];
     const float inv_nn = inv_norm(nn2);
     const float N[3] = {at[0] * inv_nn, at[1] * inv_nn, at[2] * inv_nn};
     float dN[3] = {0.f, 0.f, 0.f}, dP[3] = {0.f, 0.f, 0.f};
+    float nd = 0.f;   // N . dN, kept as a running scalar (round 5): dN = sum_l t_l D_l, so N . dN = sum_l t_l (N . D_l)
     float dKd[3] = {g[0] * im.amb[0], g[1] * im.amb[1], g[2] * im.amb[2]};
 #pragma unroll
     for (int c = 0; c < 3; ++c) if (LG) im.damb[c] += g[c] * at[6 + c];
@@ -318,17 +322,16 @@ struct ShadeGradFn {
         t_l += g[c] * at[6 + c] * lcol[c];
       }
       if (pre_l >= 0.0f && pre_l <= 1.0f) {  // torch.clamp passes the gradient inclusively
-        float dD[3], dd = 0.f;
+        // d ndl / d N = D and d ndl / d D = N, so both projections' dot products are t_l (N . D) = t_l pre_l:
+        // the backward of v / max(|v|, eps) is (dD - D (D . dD)) / |v| = t_l (N - D pre_l) / |v|
+        const float tp = t_l * pre_l;
+        nd += tp;
+        const float k = t_l * inv_vn;
+        const bool unit = vn2 > kNormEpsSquared;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           dN[c] += t_l * D[c];
-          dD[c] = t_l * N[c];
-          dd += D[c] * dD[c];
-        }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          // backward of v / max(|v|, eps)
-          const float dv = (vn2 > kNormEpsSquared ? (dD[c] - D[c] * dd) : dD[c]) * inv_vn;
+          const float dv = unit ? k * (N[c] - D[c] * pre_l) : k * N[c];
           if (LG) im.dpos[L > 0 ? l : 0][c] += dv;
           dP[c] -= dv;
         }
@@ -336,7 +339,6 @@ struct ShadeGradFn {
     }
     float dat[9];
     {
-      const float nd = N[0] * dN[0] + N[1] * dN[1] + N[2] * dN[2];
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         dat[c] = (nn2 > kNormEpsSquared ? (dN[c] - N[c] * nd) : dN[c]) * inv_nn;
@@ -519,7 +521,9 @@ struct ShadeLaneFn : ShadeGradFn<L, SIGNS, LG> {
 //   g0 = dat . e0, g1 = dat . e1                  (d L / d b0 - d L / d b2 and d L / d b1 - d L / d b2: 18, not 27)
 //   q_c = (g0 (s_c b0 - u_0c) + g1 (s_c b1 - u_1c)) / |det|     (cpp:202-269 with the common shift d L / d b2
 //                                                  taken out: its brackets sum to s_c (sum b - 1) ~ 0 over the corners)
-//   y_c = dat[3 + c] + (M^T q)_c                  (position attribute + clip-space pull-back, see FOLD above)
+//   y_c = dat[3 + c] + (M^T q)_c                  (position attribute + clip-space pull-back, see FOLD above);
+//         round 5: M^T is applied to the per-TRIANGLE coefficients instead (the record's S, P0, P1:
+//         (M^T q) = (g0 b0 + g1 b1) S + g0 P0 + g1 P1), 11 multiply-adds per pixel instead of 24
 //   a[k][c] += b_k y_c                            (9 sums per triangle)
 // ~50 vector instructions per pixel row fewer than ShadeLaneFn<L, SIGNS, false, 2, true, true>.
 #ifndef MR_SHADE_FOLD_DIFF
@@ -542,35 +546,32 @@ struct ShadeFoldLaneFn : ShadeGradFn<L, SIGNS, false> {
   static constexpr int kStride = kFoldAccStride;  // COMPACT rows: [corner][c] + 3 of padding (k_shade_gather_fold reads them)
   static constexpr int kLaneRowsPerWave = MR_FOLD_LANE_ROWS;   // 8: 0.2323 -> 0.2281 ms against 16 (32: 0.2507), same box
   static constexpr int kMinWavesPerSimd = MR_LANE_WAVES;
-  const FoldRec *__restrict__ fold_recs;
-  using Triangle = FoldTriangle;
+  const FoldRec *__restrict__ fold_recs;   // in the PULLED form (store_fold_record with the image's transform rows)
+  using Triangle = FoldTriangleW;
+  // SIGNS: the sums are formed from the bare sign codes; k_shade_gather_fold multiplies by the loss's scale
+  static constexpr bool kUnscaled = SIGNS;
   __device__ static int column(int o) { return o; }  // sum o = corner * 3 + c
   __device__ __forceinline__ void load_triangle(int img, int tri, Triangle &t) const {
-    load_fold_triangle(fold_recs + (size_t)img * this->T_ + tri, t);
+    load_fold_triangle_w(fold_recs + (size_t)img * this->T_ + tri, t);
   }
   __device__ __forceinline__ void accumulate(const typename Base::Pixel &p, const Triangle &t, float (&a)[kN],
                                              typename Base::Image &im) const {
     float at[9], dat[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) at[k] = fmaf(p.b.x, t.e0[k], fmaf(p.b.y, t.e1[k], t.c2[k]));
-    Base::attribute_gradients(at, p.g, im, dat);
+    Base::template attribute_gradients<kUnscaled>(at, p.g, im, dat);
     float g0 = 0.f, g1 = 0.f;
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
       g0 = fmaf(dat[k], t.e0[k], g0);
       g1 = fmaf(dat[k], t.e1[k], g1);
     }
+    // the rasterizer's backward, pulled back to world space per TRIANGLE (corner_rec.h: store_fold_record):
+    //   y = d L / d position attribute + (g0 b0 + g1 b1) S + g0 P0 + g1 P1
+    const float h = fmaf(g0, p.b.x, g1 * p.b.y);
     float y[3];
-    float q[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const float w0 = t.s[c] * p.b.x - t.u0[c];
-      const float w1 = t.s[c] * p.b.y - t.u1[c];
-      q[c] = (g0 * w0 + g1 * w1) * t.inv;
-    }
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-      y[c] = dat[3 + c] + ((im.pull[0][c] * q[0] + im.pull[1][c] * q[1]) + im.pull[2][c] * q[2]);
+    for (int c = 0; c < 3; ++c) y[c] = fmaf(h, t.S[c], fmaf(g0, t.P0[c], fmaf(g1, t.P1[c], dat[3 + c])));
     const float b[3] = {p.b.x, p.b.y, p.b.z};
 #pragma unroll
     for (int k = 0; k < 3; ++k)
@@ -770,10 +771,12 @@ __global__ __launch_bounds__(kThreads) void k_shade_gather(
 // CLEAR (not used, see the launch): every accumulator float is read by exactly one lane of one vertex -- entry
 // e = 3 t + k belongs to vertex triangles[t][k] alone -- which stores a zero behind its read: the rows are clear
 // again when the kernel ends.
+// scale_src / scale_mul: the sums were formed from bare sign codes (ShadeFoldLaneFn<L, true>): every output is
+// multiplied by scale_src[0] * scale_mul (the loss's upstream gradient over its element count); nullptr: by 1.
 template <bool CLEAR>
 __global__ __launch_bounds__(kThreads) void k_shade_gather_fold(
     float *__restrict__ acc, const int32_t *__restrict__ offsets, const int32_t *__restrict__ entries, int B, int V,
-    int T, float *__restrict__ dpositions) {
+    int T, float *__restrict__ dpositions, const float *__restrict__ scale_src, float scale_mul) {
   const long tid = (long)blockIdx.x * kThreads + threadIdx.x;
   const long gid = tid >> 2;   // (image, vertex)
   const int c = (int)(tid & 3);
@@ -804,7 +807,7 @@ __global__ __launch_bounds__(kThreads) void k_shade_gather_fold(
 #pragma unroll
     for (int u = 0; u < kChunk; ++u) sum += val[u];
   }
-  dpositions[gid * 3 + c] = sum;
+  dpositions[gid * 3 + c] = scale_src ? sum * (scale_src[0] * scale_mul) : sum;
 }
 
 inline unsigned capped_blocks(size_t n) {
@@ -1002,7 +1005,8 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
   else
   rc = fused_clear ? launch_bwd_setup(clip, tris, B, V, T, recs, s, acc, (fold_diff ? kFoldAccStride : 36) * sizeof(float), light_grads,
                                       light_grads ? B * (L * 6 + 3) : 0, (fold_diff || diff_general) ? corner_records : nullptr,
-                                      (fold_diff || diff_general) ? fold_recs : nullptr)
+                                      (fold_diff || diff_general) ? fold_recs : nullptr,
+                                      fold_diff ? transforms : nullptr)   // ShadeFoldLaneFn reads the pulled form
                    : launch_bwd_setup(clip, tris, B, V, T, recs, s);
   if (rc != MR_OK) return rc;
   if (corner_records) {  // the forward's records (same inputs): skip the gather
@@ -1182,7 +1186,7 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
     //  took the gather from 12.7 to 22.3 us; the host side falls back to this call's own setup kernel instead when
     //  a retained graph is differentiated a second time.)
     hipLaunchKernelGGL(k_shade_gather_fold<false>, dim3((unsigned)((nbv + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
-                       acc, vertex_offsets, vertex_entries, B, V, T, dpositions);
+                       acc, vertex_offsets, vertex_entries, B, V, T, dpositions, signs ? sign_upstream : nullptr, sign_inv_n);
     return check_launch();
   }
   if (vertex_offsets && vertex_entries) {
