@@ -585,9 +585,11 @@ struct ShadeFoldLaneFn : ShadeGradFn<L, SIGNS, false> {
 // ShadeLaneFn, FOLD the clip-space pull-back (dclip == nullptr with transforms; needs the position group).  Rows of
 // acc keep ShadeGradFn's 36-float layout (the generic gather reads them): 9 sums per selected group, + 9 clip
 // sums unless folded.  Needs the G-buffer normalised (alpha = 1) and no light gradients.
-template <int L, bool SIGNS, int GROUPS, bool FOLD>
-struct ShadeDiffLaneFn : ShadeGradFn<L, SIGNS, false> {
-  using Base = ShadeGradFn<L, SIGNS, false>;
+// LG (round 5): the light / ambient gradients ride along as per-lane image sums (6 L + 3 of them, one or two lights),
+// exactly as in ShadeLaneFn<..., LG = true>: the strips are then MR_LANE_ROWS_LG rows tall (k_sum_strip_rows' geometry).
+template <int L, bool SIGNS, int GROUPS, bool FOLD, bool LG = false>
+struct ShadeDiffLaneFn : ShadeGradFn<L, SIGNS, LG> {
+  using Base = ShadeGradFn<L, SIGNS, LG>;
   static constexpr bool kSkipsStrips = true;
   __device__ __forceinline__ bool skip_strip(int img, int rx, int y_begin, int y_end) const {
     return Base::strip_is_empty(img, rx, y_begin, y_end);
@@ -596,8 +598,8 @@ struct ShadeDiffLaneFn : ShadeGradFn<L, SIGNS, false> {
   static constexpr int kGroups = (GROUPS & 1) + ((GROUPS >> 1) & 1) + ((GROUPS >> 2) & 1);
   static constexpr int kN = 9 * kGroups + (FOLD ? 0 : 9);
   static constexpr int kStride = 36;
-  static constexpr int kLaneRowsPerWave = kN <= 18 ? MR_FOLD_LANE_ROWS : MR_LANE_ROWS;
-  static constexpr int kMinWavesPerSimd = kN > 27 ? 3 : MR_LANE_WAVES;
+  static constexpr int kLaneRowsPerWave = LG ? MR_LANE_ROWS_LG : (kN <= 18 ? MR_FOLD_LANE_ROWS : MR_LANE_ROWS);
+  static constexpr int kMinWavesPerSimd = (LG || kN > 27) ? 3 : MR_LANE_WAVES;
   const FoldRec *__restrict__ fold_recs;
   using Triangle = FoldTriangle;
   __host__ __device__ static constexpr int group(int gi) {
@@ -935,7 +937,8 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
   // the lane kernel has the variant, the pull-back through the transforms is folded into the pixel pass
   // (ShadeLaneFn<..., FOLD>) and no clip-space sums exist at all; elsewhere the clip gradient goes to scratch.
   const int groups_wanted = (dnormals ? 1 : 0) | 2 | (ddiffuse ? 4 : 0);   // (6 -- positions + diffuse -- has no lane kernel)
-  const bool fold_any = !dclip && transforms && MR_SHADE_LANES_FOLD && !light_grads && !det && groups_wanted != 6 &&
+  const bool lg_lanes = light_grads && MR_SHADE_LANES_LG && L >= 1 && L <= 2 && corner_records != nullptr;   // ShadeDiffLaneFn<..., LG>
+  const bool fold_any = !dclip && transforms && MR_SHADE_LANES_FOLD && (!light_grads || lg_lanes) && !det && groups_wanted != 6 &&
                         (gbuffer_flags & MR_GBUFFER_NORMALISED) != 0 && g_shade_backward_kernel != 1 && T > 0 && V > 0 &&
                         (corner_records != nullptr || prepared != nullptr) && MR_SHADE_FOLD_DIFF;   // (any attribute groups)
   const bool fold = fold_any || (!dclip && transforms && MR_SHADE_LANES_FOLD && !light_grads && !det && !dnormals && !ddiffuse &&
@@ -972,10 +975,12 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
   int *max_bits = (int *)(det_scale + 4);
   float *light_rows = (float *)((char *)det_scale + kDetMiscBytes);
   FoldRec *fold_recs = (FoldRec *)((char *)light_rows + light_rows_bytes(B, W, H));
-  const bool fold_diff = fold && MR_SHADE_FOLD_DIFF && (corner_records != nullptr || prepared != nullptr) && !dnormals && !ddiffuse;
-  // the difference-basis pixel pass for every other lane-kernel case on a normalised G-buffer (no light gradients):
-  // normals / diffuse wanted, and / or the clip-space gradient wanted on its own
-  const bool diff_general = !fold_diff && MR_SHADE_FOLD_DIFF && corner_records != nullptr && !light_grads && !det &&
+  const bool fold_diff = fold && MR_SHADE_FOLD_DIFF && (corner_records != nullptr || prepared != nullptr) && !dnormals && !ddiffuse &&
+                         !light_grads;   // (with light gradients: ShadeDiffLaneFn<..., LG>, below)
+  // the difference-basis pixel pass for every other lane-kernel case on a normalised G-buffer: normals / diffuse
+  // wanted, and / or the clip-space gradient wanted on its own, and (round 5, one or two lights) the light gradients
+  const bool diff_general = !fold_diff && MR_SHADE_FOLD_DIFF && corner_records != nullptr &&
+                            (!light_grads || (MR_SHADE_LANES_LG && L >= 1 && L <= 2)) && !det &&
                             (gbuffer_flags & MR_GBUFFER_NORMALISED) != 0 && g_shade_backward_kernel != 1 &&
                             vertex_offsets && vertex_entries && T > 0 && V > 0 && groups_wanted != 6;
   // `prepared` (mr_render_forward's backward_prepared: FoldRec[B*T] + cleared compact accumulator rows): the folded
@@ -1093,34 +1098,41 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
 #endif
   if (diff_general && use_lanes) {
     const bool folded = dclip == nullptr;   // (implies transforms)
-#define MR_SHADE_DIFF(NL, G, F)                                                                 \
+#define MR_SHADE_DIFF_LG(NL, G, F, LGV)                                                         \
   {                                                                                             \
     KernelTimer timer(MR_TIMER_SHADE_BACKWARD, s);                                              \
     if (signs) {                                                                                \
-      ShadeDiffLaneFn<NL, true, G, F> fn{{nullptr, signs, sign_upstream, sign_inv_n, ids, (const F3 *)bary, corners, recs, \
-                                          lights, nullptr, T, W, H, transforms, empty_regions}, fold_recs};    \
+      ShadeDiffLaneFn<NL, true, G, F, LGV> fn{{nullptr, signs, sign_upstream, sign_inv_n, ids, (const F3 *)bary, corners, recs, \
+                                               lights, LGV ? light_rows : nullptr, T, W, H, transforms, empty_regions}, fold_recs};    \
       rc = launch_accumulate_lanes(fn, B, T, W, H, acc, s);                                     \
     } else {                                                                                    \
-      ShadeDiffLaneFn<NL, false, G, F> fn{{(const float4 *)drgba, nullptr, nullptr, 0.0f, ids, (const F3 *)bary, corners,  \
-                                           recs, lights, nullptr, T, W, H, transforms, empty_regions}, fold_recs};                         \
+      ShadeDiffLaneFn<NL, false, G, F, LGV> fn{{(const float4 *)drgba, nullptr, nullptr, 0.0f, ids, (const F3 *)bary, corners,  \
+                                                recs, lights, LGV ? light_rows : nullptr, T, W, H, transforms, empty_regions}, fold_recs};                         \
       rc = launch_accumulate_lanes(fn, B, T, W, H, acc, s);                                     \
     }                                                                                           \
   }
-#define MR_SHADE_DIFF_G(NL)                                                                     \
+#define MR_SHADE_DIFF(NL, G, F) MR_SHADE_DIFF_LG(NL, G, F, false)
+#define MR_SHADE_DIFF_GV(NL, LGV)                                                               \
   if (folded) {                                                                                 \
-    if (groups == 2) MR_SHADE_DIFF(NL, 2, true) else if (groups == 3) MR_SHADE_DIFF(NL, 3, true) else MR_SHADE_DIFF(NL, 7, true) \
+    if (groups == 2) MR_SHADE_DIFF_LG(NL, 2, true, LGV) else if (groups == 3) MR_SHADE_DIFF_LG(NL, 3, true, LGV) else MR_SHADE_DIFF_LG(NL, 7, true, LGV) \
   } else {                                                                                      \
-    if (groups == 2) MR_SHADE_DIFF(NL, 2, false) else if (groups == 3) MR_SHADE_DIFF(NL, 3, false) else MR_SHADE_DIFF(NL, 7, false) \
+    if (groups == 2) MR_SHADE_DIFF_LG(NL, 2, false, LGV) else if (groups == 3) MR_SHADE_DIFF_LG(NL, 3, false, LGV) else MR_SHADE_DIFF_LG(NL, 7, false, LGV) \
   }
+#define MR_SHADE_DIFF_G(NL) MR_SHADE_DIFF_GV(NL, false)
+#define MR_SHADE_DIFF_GL(NL)   /* one or two lights: the variant with light gradients exists */ \
+  if (light_grads) { MR_SHADE_DIFF_GV(NL, true) } else { MR_SHADE_DIFF_GV(NL, false) }
     switch (L) {
-      case 1: MR_SHADE_DIFF_G(1); break;
-      case 2: MR_SHADE_DIFF_G(2); break;
+      case 1: MR_SHADE_DIFF_GL(1); break;
+      case 2: MR_SHADE_DIFF_GL(2); break;
       case 3: MR_SHADE_DIFF_G(3); break;
       case 4: MR_SHADE_DIFF_G(4); break;
       default: MR_SHADE_DIFF_G(0); break;
     }
+#undef MR_SHADE_DIFF_GL
 #undef MR_SHADE_DIFF_G
+#undef MR_SHADE_DIFF_GV
 #undef MR_SHADE_DIFF
+#undef MR_SHADE_DIFF_LG
   } else if (use_lanes) {
     switch (L) {
       case 1: MR_SHADE_LANES_GL(1); break;

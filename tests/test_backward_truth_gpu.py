@@ -33,12 +33,13 @@ def _render(g, device, wanted, spelling):
     h, w = g["image"].shape[1:3]
     dev = lambda k: torch.tensor(g[k], device=device)
     leaves = {k: dev(k).requires_grad_(k in wanted) for k in ("vertices", "normals", "diffuse")}
+    lights = {k: dev(k).requires_grad_(k in wanted) for k in ("light_positions", "light_intensities")}
     spec = dev("specular") if "specular" in g.files else None
     shine = dev("shininess") if "shininess" in g.files else None
     amb = dev("ambient") if "ambient" in g.files else None
     kw = {"fov_y": float(g["fov_y"])} if "fov_y" in g.files else {}
     img = mesh_renderer.render(leaves["vertices"], dev("triangles"), leaves["normals"], leaves["diffuse"], dev("eye"),
-                               dev("center"), dev("up"), dev("light_positions"), dev("light_intensities"), w, h,
+                               dev("center"), dev("up"), lights["light_positions"], lights["light_intensities"], w, h,
                                specular_colors=spec, shininess_coefficients=shine, ambient_color=amb, **kw)
     weight = float(g["loss_weight"]) if "loss_weight" in g.files else 1.0
     if spelling == "mean_abs":     # the reference's own spelling, mesh_renderer_test.py:250
@@ -47,7 +48,8 @@ def _render(g, device, wanted, spelling):
         loss = mesh_renderer.losses.l1_loss(img, dev("target"))
     (loss * weight).backward()
     torch.cuda.synchronize()
-    return img, {k: t.grad for k, t in leaves.items() if t.requires_grad}, _native.debug_last_accumulate_kernel()
+    grads = {k: t.grad for k, t in list(leaves.items()) + list(lights.items()) if t.requires_grad}
+    return img, grads, _native.debug_last_accumulate_kernel()
 
 
 def _compare(g, grads, what):
@@ -72,6 +74,19 @@ def test_diffuse_goldens_through_the_specialised_backward_kernels(device, name, 
     np.testing.assert_allclose(img.detach().cpu().numpy(), g["image"], atol=ATOL, rtol=0)
     if kernel is not None:
         assert ran.startswith(kernel), "%s with %s requiring grad ran %s" % (name, wanted, ran)
+    _compare(g, grads, "%s %s %s (%s)" % (name, wanted, spelling, ran))
+
+
+@pytest.mark.parametrize("spelling", ["mean_abs", "l1_loss"])
+@pytest.mark.parametrize("wanted", [("vertices", "light_positions", "light_intensities"),
+                                    ("vertices", "normals", "diffuse", "light_positions", "light_intensities")])
+@pytest.mark.parametrize("name", ["render_gray_cube_64x48.npz", "render_lit_cube_64x48.npz", "render_sphere5k_128.npz"])
+def test_diffuse_goldens_with_light_gradients_through_the_lane_kernel(device, name, wanted, spelling):
+    """Round 5: one or two lights WITH their gradients take the difference-basis lane kernel too (ShadeDiffLaneFn<...,
+    LG>: the light sums ride along per lane), folded to world space when the cameras are not differentiated."""
+    g = golden_npz(name)
+    img, grads, ran = _render(g, device, wanted, spelling)
+    assert ran.startswith("ShadeDiffLaneFn") and ran.rstrip(">").endswith("true, true"), ran   # <L, SIGNS, GROUPS, FOLD, LG>
     _compare(g, grads, "%s %s %s (%s)" % (name, wanted, spelling, ran))
 
 
