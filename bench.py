@@ -119,7 +119,7 @@ class KernelEvents:
         return sum(out) / len(out) if out else 0.0
 
 
-def make_step(job, device, gather, handover="f32", spelling="l1_loss", all_gradients=False, device_cameras=False):
+def make_step(job, device, gather, handover="u8", spelling="l1_loss", all_gradients=False, device_cameras=False):
     """Returns (step, vertices, state): state["image"] / state["target"] hold the last rendered
     batch and the fixed target (the full-size parity test checks them against the oracle).
 
@@ -377,10 +377,11 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c3")
-    ap.add_argument("--handover", choices=("u8", "f32"), default="f32",
-                    help="what the ranks hand over to rank 0 when --gpus > 1 inside the timed region: the fp32 images "
-                         "render() returns (default, the reference's output type) or 8-bit frames; the other one is "
-                         "timed after the region and reported next to it")
+    ap.add_argument("--handover", choices=("u8", "f32"), default="u8",
+                    help="what the ranks hand over to rank 0 when --gpus > 1 inside the timed region: 8-bit frames (default: "
+                         "the reference examples' frame conversion, written by the forward's epilogue) or the fp32 images "
+                         "render() returns; the OTHER one is timed after the region and reported next to it "
+                         "(ms_per_step_handover_f32 / value_handover_f32)")
     ap.add_argument("--extras", type=int, default=1,
                     help="0: skip the legs that run after the timed region (other spellings, gradient sets, configurations)")
     ap.add_argument("--cpu-sample", type=int, default=12, help="images timed for cpu_baseline (0 = skip)")

@@ -675,10 +675,13 @@ __device__ __forceinline__ void load_spec_fold_triangle(const SpecFoldRec<A> *__
 
 // One thread per (image, triangle): SpecFoldRec from the corner record and the clip-space corners (the sign-corrected
 // adjugate, its column sums and 1 / |det| exactly as k_bwd_setup forms them, rasterize_triangles.cpp:180-198).
+// pull_transforms ([B,4,4] or nullptr, round 5): the last ten slots carry the rasterizer's backward pulled back to world
+// space per triangle -- S[3], P0[3], P1[3] as corner_rec.h's store_fold_record forms them -- instead of u0, u1, s, 1/|det|.
 template <int A>
 __global__ __launch_bounds__(kThreads) void k_spec_fold_setup(const float4 *__restrict__ clip, const int32_t *__restrict__ tris,
                                                               const SpecCornerRec<A> *__restrict__ corners, int B, int V,
-                                                              int T, SpecFoldRec<A> *__restrict__ out) {
+                                                              int T, SpecFoldRec<A> *__restrict__ out,
+                                                              const float *__restrict__ pull_transforms) {
   const long gid = (long)blockIdx.x * kThreads + threadIdx.x;
   if (gid >= (long)B * T) return;
   const int b = (int)(gid / T);
@@ -708,10 +711,25 @@ __global__ __launch_bounds__(kThreads) void k_spec_fold_setup(const float4 *__re
     if (det < 0.0f) {
       u0 = -u0; u1 = -u1; u2 = -u2; u3 = -u3; u4 = -u4; u5 = -u5; u6 = -u6; u7 = -u7; u8 = -u8;
     }
-    v[3 * A + 0] = u0; v[3 * A + 1] = u1; v[3 * A + 2] = u2;
-    v[3 * A + 3] = u3; v[3 * A + 4] = u4; v[3 * A + 5] = u5;
-    v[3 * A + 6] = (u0 + u3) + u6; v[3 * A + 7] = (u1 + u4) + u7; v[3 * A + 8] = (u2 + u5) + u8;   // cpp:187-198
-    v[3 * A + 9] = 1.0f / fabsf(det);
+    const float s0 = (u0 + u3) + u6, s1 = (u1 + u4) + u7, s2 = (u2 + u5) + u8;   // cpp:187-198
+    const float inv = 1.0f / fabsf(det);
+    if (pull_transforms) {
+      float pull[12];
+      load_pull_rows(pull_transforms, b, pull);
+#pragma unroll
+      for (int cw = 0; cw < 3; ++cw) {
+        const float q0 = pull[cw], q1 = pull[4 + cw], q2 = pull[8 + cw];
+        v[3 * A + cw] = ((q0 * s0 + q1 * s1) + q2 * s2) * inv;
+        v[3 * A + 3 + cw] = -(((q0 * u0 + q1 * u1) + q2 * u2) * inv);
+        v[3 * A + 6 + cw] = -(((q0 * u3 + q1 * u4) + q2 * u5) * inv);
+      }
+      v[3 * A + 9] = 0.0f;
+    } else {
+      v[3 * A + 0] = u0; v[3 * A + 1] = u1; v[3 * A + 2] = u2;
+      v[3 * A + 3] = u3; v[3 * A + 4] = u4; v[3 * A + 5] = u5;
+      v[3 * A + 6] = s0; v[3 * A + 7] = s1; v[3 * A + 8] = s2;
+      v[3 * A + 9] = inv;
+    }
   }
 #pragma unroll
   for (int q = 0; q < SpecFoldRec<A>::kQuads; ++q)
@@ -795,6 +813,248 @@ struct SpecFoldLaneFn : SpecGradFn<L, PV> {
   }
   __device__ __forceinline__ void end_strip(int, int, Image &) const {}
 };
+
+// ---- round 5: the vertex-only backward WITHOUT the separate G pass ----------------------------------------------
+// The across-pixels norm couples every pixel's rdc to the image-wide sum G = sum_p (dL / d rn_p) rdc_p:
+//   d rdc_p = a_p / norm - rdc_p G / norm^3,      a_p = dL / d rn_p.
+// Everything downstream of d rdc_p is LINEAR in it, with a per-pixel direction J_p (the gradient of rdc_p w.r.t. the
+// vertices, through the attributes and through the barycentrics): the vertex gradient is
+//   sum_p [ y_diffuse,p + (a_p / norm) J_p ]  -  (G / norm^3) sum_p rdc_p J_p.
+// k_spec_pixels<kGsum> used to find G in a pass of its own (0.25 ms at 1024^2 x 32: the whole shading recomputed)
+// before the pixel pass could start.  Here ONE pass evaluates J_p once per pixel and light and keeps BOTH sums --
+// S1 = sum_p (y_diffuse + (a_p / norm) J_p) and S2_l = sum_p rdc_p J_p, 9 + 9 L per triangle -- next to the per-lane
+// partial sums of G; the per-vertex gather forms S1 - sum_l (G_l / norm_l^3) S2_l.  One or two lights, the clip-space
+// pull-back folded into the record (pulled SpecFoldRec); three or four lights keep the two-pass scheme.
+#ifndef MR_SPEC_COUPLED
+#define MR_SPEC_COUPLED 1
+#endif
+template <int A>
+struct SpecPulledTriangle {
+  float e0[A], e1[A], c2[A], S[3], P0[3], P1[3];
+};
+template <int L, bool PV>
+struct SpecCoupledLaneFn : SpecGradFn<L, PV> {
+  using Base = SpecGradFn<L, PV>;
+  static_assert(L == 1 || L == 2, "the second light's sums take the normal columns of the accumulator rows");
+  static constexpr int kA = Base::kA;
+  static constexpr int kN = 9 + 9 * L;
+  static constexpr int kStride = Base::kStride;
+  static constexpr int kLaneRowsPerWave = MR_SPEC_LANE_ROWS;
+  static constexpr int kMinWavesPerSimd = L == 1 ? MR_SPEC_LANE_WAVES : 2;
+  static constexpr bool kCountBackground = false;   // (background pixels do not depend on the vertices)
+  const SpecFoldRec<kA> *__restrict__ fold_recs;    // in the pulled form
+  float *__restrict__ g_rows;                       // [strips][L]: every strip's partial sums of G
+  using Triangle = SpecPulledTriangle<kA>;
+  struct Image {
+    SpecScene<L> sc;
+    float gpart[L];
+    int n_bg;   // unused
+  };
+  // S1 -> the position columns; S2 of light 0 -> the clip columns; S2 of light 1 -> the normal columns
+  __device__ static int column(int o) {
+    if (o < 9) return (o / 3) * kA + 3 + o % 3;
+    if (o < 18) return 3 * kA + (o - 9);
+    return ((o - 18) / 3) * kA + (o - 18) % 3;
+  }
+  __device__ __forceinline__ void begin_image(int img, Image &im) const {
+    load_scene(this->scene_in, img, im.sc);   // (scene_in.gsum is null: no coupling coefficient in this pass)
+#pragma unroll
+    for (int l = 0; l < L; ++l) im.gpart[l] = 0.f;
+    im.n_bg = 0;
+  }
+  __device__ __forceinline__ void load_triangle(int img, int tri, Triangle &t) const {
+    const SpecFoldRec<kA> *rec = fold_recs + (size_t)img * this->T_ + tri;
+    float v[4 * SpecFoldRec<kA>::kQuads];
+#pragma unroll
+    for (int q = 0; q < SpecFoldRec<kA>::kQuads; ++q) {
+      const float4 f = rec->q[q];
+      v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w;
+    }
+#pragma unroll
+    for (int a = 0; a < kA; ++a) { t.e0[a] = v[a]; t.e1[a] = v[kA + a]; t.c2[a] = v[2 * kA + a]; }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { t.S[c] = v[3 * kA + c]; t.P0[c] = v[3 * kA + 3 + c]; t.P1[c] = v[3 * kA + 6 + c]; }
+  }
+  // y = (position attribute's gradient) + the barycentric path pulled back to world space, for attribute gradients d[n]
+  template <int N_>
+  __device__ __forceinline__ void pulled(const float (&d)[N_], const typename Base::Pixel &p, const Triangle &t,
+                                         float (&y)[3]) const {
+    float g0 = 0.f, g1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < N_; ++k) {
+      g0 = fmaf(d[k], t.e0[k], g0);
+      g1 = fmaf(d[k], t.e1[k], g1);
+    }
+    const float h = fmaf(g0, p.b.x, g1 * p.b.y);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) y[c] = fmaf(h, t.S[c], fmaf(g0, t.P0[c], fmaf(g1, t.P1[c], d[3 + c])));
+  }
+  __device__ __forceinline__ void accumulate(const typename Base::Pixel &p, const Triangle &t, float (&a)[kN],
+                                             Image &im) const {
+    float at[kA];
+#pragma unroll
+    for (int k = 0; k < kA; ++k) at[k] = fmaf(p.b.x, t.e0[k], fmaf(p.b.y, t.e1[k], t.c2[k]));
+    const bool shaded = (at[6] >= 0.0f) || (at[7] >= 0.0f) || (at[8] >= 0.0f);   // render.py:215
+    const float g[3] = {shaded ? p.g.x : 0.f, shaded ? p.g.y : 0.f, shaded ? p.g.z : 0.f};
+    const SpecScene<L> &sc = im.sc;
+    PixelFrame f;
+    pixel_frame(at, sc.cam, f);
+    float dN[3] = {0.f, 0.f, 0.f}, dP[3] = {0.f, 0.f, 0.f}, nd_d = 0.f, dshin = 0.f;
+    float dKd[3] = {g[0] * sc.amb[0], g[1] * sc.amb[1], g[2] * sc.amb[2]};
+    float dKs[3] = {0.f, 0.f, 0.f};
+    float y1[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      LightTerm lt;
+      light_term(at, f, sc.lp[l], lt);
+      SpecTerm st{0.f, 0.f, 0.f};
+      if (shaded) specularity(lt.rdc, sc.inv_norm[l], lt.ndl, PV ? at[kA - 1] : sc.shin, st);
+      float t_l = 0.f, dspec = 0.f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        dKd[c] += g[c] * lt.ndl * sc.li[l][c];
+        dKs[c] += g[c] * st.spec * sc.li[l][c];
+        t_l += g[c] * at[6 + c] * sc.li[l][c];
+        dspec += g[c] * at[9 + c] * sc.li[l][c];
+      }
+      dshin += dspec * st.dspec_dshin;
+      const float aprime = dspec * st.dspec_drn;   // dL / d rn
+      im.gpart[l] += aprime * lt.rdc;
+      const bool pass = lt.pre >= 0.0f && lt.pre <= 1.0f;   // torch.clamp passes the gradient inclusively
+      // the diffuse term's part (d rdc = 0): d ndl = t_l
+      if (pass) {
+        const float k = t_l * lt.inv_vn;
+        nd_d += t_l * lt.pre;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          dN[c] += t_l * lt.D[c];
+          dP[c] -= lt.vn > kNormEps ? k * (f.N[c] - lt.D[c] * lt.pre) : k * f.N[c];
+        }
+      }
+      // J: the same chain for d rdc = 1 (SpecGradFn::shade_backward with dM = Cd, dCd = M, whose projections' dot
+      // products are both M . Cd = rdc)
+      float dJ[6];
+      {
+        float dm[3], n_dot_dm = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          dm[k] = (lt.mn > kNormEps ? (f.Cd[k] - lt.M[k] * lt.rdc) : f.Cd[k]) * lt.inv_mn;
+          n_dot_dm += f.N[k] * dm[k];
+        }
+        float dNj[3], dD[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          dNj[k] = 2.0f * lt.ndl * dm[k];
+          dD[k] = -dm[k];
+        }
+        if (pass) {
+          const float d_ndl = 2.0f * n_dot_dm;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            dNj[k] += d_ndl * lt.D[k];
+            dD[k] += d_ndl * f.N[k];
+          }
+        }
+        float dd = 0.f, nd = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          dd += lt.D[k] * dD[k];
+          nd += f.N[k] * dNj[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const float dv = (lt.vn > kNormEps ? (dD[k] - lt.D[k] * dd) : dD[k]) * lt.inv_vn;
+          const float dc = (f.cn > kNormEps ? (lt.M[k] - f.Cd[k] * lt.rdc) : lt.M[k]) * f.inv_cn;
+          dJ[k] = (f.nn > kNormEps ? (dNj[k] - f.N[k] * nd) : dNj[k]) * f.inv_nn;
+          dJ[3 + k] = -(dv + dc);
+        }
+      }
+      float yj[3];
+      pulled(dJ, p, t, yj);
+      const float a1 = aprime * sc.inv_norm[l];
+      const float b[3] = {p.b.x, p.b.y, p.b.z};
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        y1[c] = fmaf(a1, yj[c], y1[c]);
+        const float y2 = lt.rdc * yj[c];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) a[9 + 9 * l + k * 3 + c] = fmaf(b[k], y2, a[9 + 9 * l + k * 3 + c]);
+      }
+    }
+    float dat[kA];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      dat[c] = (f.nn > kNormEps ? (dN[c] - f.N[c] * nd_d) : dN[c]) * f.inv_nn;
+      dat[3 + c] = dP[c];
+      dat[6 + c] = dKd[c];
+      dat[9 + c] = dKs[c];
+    }
+    if (PV) dat[kA - 1] = dshin;
+    float yd[3];
+    pulled(dat, p, t, yd);
+    const float b[3] = {p.b.x, p.b.y, p.b.z};
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) a[k * 3 + c] = fmaf(b[k], yd[c] + y1[c], a[k * 3 + c]);
+  }
+  __device__ __forceinline__ void end_strip(int, int strip, Image &im) const {
+    const int lane = lane_id();
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      float v = im.gpart[l];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);   // fixed tree
+      if (lane == 0) g_rows[(size_t)strip * L + l] = v;
+    }
+  }
+};
+
+// The coupled pass's per-vertex gather: four lanes per (image, vertex), d positions = S1 - sum_l (G_l / norm_l^3) S2_l
+// over the incident triangles' rows (CSR adjacency, fixed order, every output written once).
+template <int A, int L>
+__global__ __launch_bounds__(kThreads) void k_spec_gather_coupled(
+    const float *__restrict__ acc, const int32_t *__restrict__ offsets, const int32_t *__restrict__ entries,
+    const float *__restrict__ gsum, const float *__restrict__ norms2, int B, int V, int T,
+    float *__restrict__ dpositions) {
+  const long tid = (long)blockIdx.x * kThreads + threadIdx.x;
+  const long gid = tid >> 2;   // (image, vertex)
+  const int c = (int)(tid & 3);
+  if (gid >= (long)B * V || c == 3) return;
+  const int b = (int)(gid / V);
+  const int v = (int)(gid - (long)b * V);
+  float gc[L];
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    const float nrm = fast_sqrt(norms2[(size_t)b * L + l]);
+    const float inv = fast_rcp(fmaxf(nrm, kNormEps));
+    gc[l] = nrm > kNormEps ? gsum[(size_t)b * L + l] * inv * inv * inv : 0.0f;   // (as load_scene forms gcoef)
+  }
+  const float *acc_f = acc + (size_t)b * T * 48;
+  float s1 = 0.f, s2[L];
+#pragma unroll
+  for (int l = 0; l < L; ++l) s2[l] = 0.f;
+  const int e1 = offsets[v + 1];
+  constexpr int kChunk = 4;
+  for (int i = offsets[v]; i < e1; i += kChunk) {
+    int e[kChunk];
+#pragma unroll
+    for (int u = 0; u < kChunk; ++u) e[u] = i + u < e1 ? entries[i + u] : -1;
+#pragma unroll
+    for (int u = 0; u < kChunk; ++u) {
+      if (e[u] < 0) continue;
+      const unsigned t = (unsigned)e[u] / 3u, k = (unsigned)e[u] - 3u * t;
+      const float *row = acc_f + (size_t)t * 48u;
+      s1 += row[k * A + 3u + (unsigned)c];
+      s2[0] += row[3u * A + k * 3u + (unsigned)c];
+      if (L > 1) s2[L > 1 ? 1 : 0] += row[k * A + (unsigned)c];
+    }
+  }
+  float out = s1;
+#pragma unroll
+  for (int l = 0; l < L; ++l) out -= gc[l] * s2[l];
+  dpositions[gid * 3 + c] = out;
+}
 
 template <int A>
 __global__ __launch_bounds__(kThreads) void k_spec_scatter(
@@ -957,7 +1217,10 @@ int spec_forward(const int32_t *ids, const float *bary, const float *normals, co
 
 // one row of light / camera / shininess sums per strip of the backward's pixel pass
 inline size_t spec_light_rows_bytes(int B, int W, int H) {
-  return align_up((size_t)B * strips_per_image<SpecGradFn<1, false>>(W, H) * kSumRowSlots * sizeof(float), 256);
+  // (also the coupled lane pass's G rows: two floats per 64-column strip of at least four rows)
+  const size_t rows_kernel = (size_t)B * strips_per_image<SpecGradFn<1, false>>(W, H) * kSumRowSlots;
+  const size_t lanes_g = (size_t)B * ((W + 63) / 64) * ((H + 3) / 4) * 2;
+  return align_up((rows_kernel > lanes_g ? rows_kernel : lanes_g) * sizeof(float), 256);
 }
 
 template <bool PV>
@@ -975,6 +1238,8 @@ int spec_backward(const float *drgba, const int32_t *ids, const float *bary, con
   const bool lanes = MR_SPEC_LANES && !det && (gbuffer_flags & MR_GBUFFER_NORMALISED) != 0 &&
                      (grads_wanted & ~(MR_GRAD_POSITIONS | MR_GRAD_CLIP)) == 0;
   const bool fold = lanes && transforms && (grads_wanted & MR_GRAD_CLIP) == 0;
+  // one pass instead of G pass + pixel pass (SpecCoupledLaneFn): one or two lights, folded, per-vertex gather
+  const bool coupled = MR_SPEC_COUPLED && fold && L <= 2 && vertex_offsets && vertex_entries;
   if (det && !(vertex_offsets && vertex_entries)) return MR_EINVAL;  // the scatter path is float atomics only
   char *p = (char *)ws;
   float *acc = (float *)p;
@@ -1006,10 +1271,30 @@ int spec_backward(const float *drgba, const int32_t *ids, const float *bary, con
   if (lanes) {
     const long nbt = (long)B * T;
     hipLaunchKernelGGL((k_spec_fold_setup<A>), dim3((unsigned)((nbt + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
-                       (const float4 *)clip, tris, (const SpecCornerRec<A> *)corners, B, V, T, fold_recs);
+                       (const float4 *)clip, tris, (const SpecCornerRec<A> *)corners, B, V, T, fold_recs,
+                       coupled ? transforms : nullptr);
     if ((rc = check_launch()) != MR_OK) return rc;
   }
   SpecSceneIn scene{light_pos, light_col, ambient, camera, PV ? nullptr : shininess, norms2, nullptr};
+  if (coupled) {
+#define MR_SPEC_BWD_COUPLED(NL)                                                                                      \
+    {                                                                                                                \
+      SpecCoupledLaneFn<NL, PV> fn{{(const float4 *)drgba, ids, (const F3 *)bary, nullptr, nullptr, scene, nullptr, T, W, H}, \
+                                   fold_recs, light_rows};                                                           \
+      rc = launch_accumulate_lanes(fn, B, T, W, H, acc, s);                                                          \
+      if (rc == MR_OK)                                                                                               \
+        rc = launch_sum_strip_rows(light_rows, B, lanes_strips_per_image<SpecCoupledLaneFn<NL, PV>>(B, W, H), NL, gsum, s); \
+      if (rc == MR_OK) {                                                                                             \
+        const long nbv4 = (long)B * V * 4;                                                                           \
+        hipLaunchKernelGGL((k_spec_gather_coupled<A, NL>), dim3((unsigned)((nbv4 + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, \
+                           acc, vertex_offsets, vertex_entries, gsum, norms2, B, V, T, dpositions);                  \
+        rc = check_launch();                                                                                         \
+      }                                                                                                              \
+    }
+    if (L == 1) MR_SPEC_BWD_COUPLED(1) else MR_SPEC_BWD_COUPLED(2)
+#undef MR_SPEC_BWD_COUPLED
+    return rc;
+  }
   rc = launch_spec_pixels<kGsum, PV>(L, ids, bary, corners, scene, B, T, W, H, drgba, nullptr, gsum, partials, s);
   if (rc != MR_OK) return rc;
   scene.gsum = gsum;

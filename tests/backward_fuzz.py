@@ -9,7 +9,7 @@ orders of magnitude more than the bound.
 
   shade_trial     mr_shade_backward / _l1 (diffuse Phong): rows kernel, ShadeFoldLaneFn, ShadeDiffLaneFn variants,
                   dense and sign-coded upstream
-  specular_trial  mr_shade_specular_backward: rows kernel, SpecFoldLaneFn lanes / folded
+  specular_trial  mr_shade_specular_backward: rows kernel, SpecFoldLaneFn lanes / folded, SpecCoupledLaneFn (one pass, L <= 2)
   attr_trial      mr_interpolate_raster_backward (rasterize()): rows kernel, AttrFoldLaneFn
 
 Used by tests/test_backward_truth_gpu.py (a fixed-seed slice inside `pytest -m gpu`) and by the stand-alone
@@ -177,7 +177,9 @@ def specular_case(report, what, pos, xf, tris, nrm, kd, ks, lp, li, amb, cam, sh
     folded = _native.shade_specular_backward(*sargs, adjacency=adjacency, normalised_gbuffer=True, transforms=xf_d,
                                              grads_wanted=_native.GRAD_POSITIONS)
     k_folded = _native.debug_last_accumulate_kernel().split("<")[0] + "/folded"
-    assert k_rows.startswith("SpecGradFn") and k_lanes.startswith("SpecFoldLaneFn") and k_folded.startswith("SpecFoldLaneFn"), (k_rows, k_lanes, k_folded)
+    # (folded: one or two lights take the coupled one-pass kernel, three or four the G pass + SpecFoldLaneFn)
+    assert k_rows.startswith("SpecGradFn") and k_lanes.startswith("SpecFoldLaneFn") and \
+        k_folded.startswith("SpecCoupledLaneFn" if lp.shape[1] <= 2 else "SpecFoldLaneFn"), (k_rows, k_lanes, k_folded)
     for kernel, out in ((k_rows, rows), (k_lanes, lanes)):
         report.check(kernel, "d clip", out[0], t["d_clip"], t["noise_clip"], what)
         report.check(kernel, "d positions", out[2], t["d_positions"], t["noise_positions"], what)

@@ -94,11 +94,15 @@ def test_diffuse_goldens_with_light_gradients_through_the_lane_kernel(device, na
 @pytest.mark.parametrize("name", SPECULAR)
 def test_specular_goldens_through_the_vertex_only_lane_kernel(device, name, spelling):
     """render() with a specular term differentiated to the vertices alone: SpecFoldLaneFn with the clip-space
-    pull-back folded in, against the reference's stored d_vertices."""
+    pull-back folded in (one or two lights: SpecCoupledLaneFn, the across-pixels coupling in the same pass), against the
+    reference's stored d_vertices."""
     g = golden_npz(name)
     img, grads, ran = _render(g, device, ("vertices",), spelling)
     np.testing.assert_allclose(img.detach().cpu().numpy(), g["image"], atol=ATOL, rtol=0)
-    if g["light_positions"].shape[1] <= _native.shade_fast_lights():
+    n_lights = g["light_positions"].shape[1]
+    if n_lights <= 2:      # round 5: one pass, no separate G pass (SpecCoupledLaneFn<L, PV>)
+        assert ran.startswith("SpecCoupledLaneFn<%d" % n_lights), ran
+    elif n_lights <= _native.shade_fast_lights():
         assert ran.startswith("SpecFoldLaneFn") and ran.rstrip(">").endswith("true"), ran   # <L, PV, FOLD = true>
     _compare(g, grads, "%s vertices %s (%s)" % (name, spelling, ran))
 
@@ -158,7 +162,7 @@ def test_backward_kernels_against_float64_on_random_soups(device, which, trials)
     assert not report.failures, "%d failures, first: %s" % (len(report.failures), "\n".join(report.failures[:5]))
     assert report.with_gradients >= trials // 2
     expected = {"shade": ("ShadeGradFn/dense", "ShadeFoldLaneFn/dense", "ShadeFoldLaneFn/signs", "ShadeDiffLaneFn/dense", "ShadeDiffLaneFn/signs"),
-                "specular": ("SpecGradFn", "SpecFoldLaneFn/lanes", "SpecFoldLaneFn/folded"),
+                "specular": ("SpecGradFn", "SpecFoldLaneFn/lanes", "SpecFoldLaneFn/folded", "SpecCoupledLaneFn/folded"),
                 "attr": ("AttrFoldLaneFn",)}[which]
     for kernel in expected:
         assert kernel in report.worst, (kernel, sorted(report.worst))

@@ -20,7 +20,9 @@ ap.add_argument("--backward", action="store_true")
 ap.add_argument("--edge", type=int, default=0, help="force 32 / 64 pixel regions")
 args = ap.parse_args()
 B, W, H, K = {"c2": (8, 256, 256, 50), "c3": (32, 1024, 1024, 50), "c4": (8, 2048, 2048, 158),
-              "c3s": (4, 1024, 1024, 50)}[args.config]
+              "c3s": (4, 1024, 1024, 50),
+              # configs[3]'s pixel count on row strides that are not powers of two (HBM channel spread of the stores)
+              "c4a": (8, 2176, 1928, 158), "c4b": (8, 2080, 2016, 158), "c3a": (32, 1088, 964, 50)}[args.config]
 dev = torch.device("cuda:0")
 job = synthetic.sphere_job(B, W, H, K)
 clip, tris = job["clip"].to(dev), job["triangles"].to(dev)

@@ -13,16 +13,24 @@ tri, n, kd = job["triangles"].to(dev), job["normals"].to(dev), job["diffuse"].to
 ks = torch.full_like(kd, 0.5)
 eyes = job["eyes"]
 lp, li = job["light_positions"].to(dev), job["light_intensities"].to(dev)
-def step(spec):
+target = torch.rand(B, H, W, 4, device=dev)
+upstream = torch.randn(B, H, W, 4, device=dev) / (B * H * W * 4)
+def step(spec, loss):
     v.grad = None
     kw = dict(specular_colors=ks, shininess_coefficients=6.0) if spec else {}
     img = mesh_renderer.render(v, tri, n, kd, eyes, torch.zeros_like(eyes), torch.tensor([0.0, 1.0, 0.0]),
                                lp, li, W, H, **kw)
-    img.mean().backward()
+    if loss == "mean":            # the figure of rounds 2-4: ~0.23 ms of it are torch's mean() and its backward
+        img.mean().backward()
+    elif loss == "l1":            # the reference's spelling (mesh_renderer_test.py:250), recognised by render()'s output type
+        torch.mean(torch.abs(img - target)).backward()
+    else:                         # no loss at all: a given upstream gradient -- the renderer's kernels and nothing else
+        img.backward(gradient=upstream)
 for spec in (False, True):
-    for _ in range(2): step(spec)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    n_it = 3
-    for _ in range(n_it): step(spec)
-    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n_it
-    print(f"render fwd+bwd specular={spec}: {dt*1e3:.2f} ms/step -> {B*W*H/dt/1e6:.0f} Mpix/s  peak mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB", flush=True)
+    for loss in ("mean", "l1", "given upstream"):
+        for _ in range(3): step(spec, loss)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        n_it = 10
+        for _ in range(n_it): step(spec, loss)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n_it
+        print(f"render fwd+bwd specular={spec} loss={loss}: {dt*1e3:.2f} ms/step -> {B*W*H/dt/1e6:.0f} Mpix/s  peak mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB", flush=True)
