@@ -459,6 +459,21 @@ def main():
     torch.cuda.synchronize(device)
     gbuffer_ms = ev_gbuffer.mean_ms(n_gb) / n_gb_rep
     del gb_ids, gb_bary, gb_z, clip_gb
+    # ... and as rounds 2-4 measured it: ONE launch per event pair inside the step (the shading epilogue switched off:
+    # k_raster, then k_shade_forward, loss, backward).  Behind the kernel runs another kind of work, under which the
+    # tail of its 671 MB of stores drains; back to back with itself the kernel runs at the sustained write rate.  Both
+    # are this kernel's duration -- in a renderer's step and in a write-only burst -- and the line carries both.
+    n_gs, n_gs_lead = 12, 6
+    ev_gstep = KernelEvents(n_gs, _native.TIMER_RASTER_FORWARD)
+    with ext.shading_epilogue(False):
+        for i in range(n_gs + n_gs_lead):
+            if i >= n_gs_lead:
+                ev_gstep.arm(i - n_gs_lead)
+            step()
+    if gather is not None:
+        gather.drain()
+    torch.cuda.synchronize(device)
+    gbuffer_in_step_ms = ev_gstep.mean_ms(n_gs)
 
     for _ in range(args.warmup):
         step()
@@ -563,6 +578,12 @@ def main():
                 timed="OUTSIDE the timed region, BEFORE the warm-up steps: %d calls of mr_rasterize_forward (after %d untimed "
                       "ones), each launching its k_raster kernel %d times back to back inside ONE hipEvent pair "
                       "(mr_debug_set_raster_repeat); avg_kernel_ms = pair time / %d" % (n_gb, n_gb_lead, n_gb_rep, n_gb_rep)),
+            "roofline_gbuffer_in_step": dict(
+                roofline("k_raster (the same kernel, one launch per hipEvent pair inside the step with the shading epilogue off)",
+                         px * 20 + batch * V * 16 + T * 12, gbuffer_in_step_ms, "k_raster", args.config),
+                timed="OUTSIDE the timed region, BEFORE the warm-up steps: %d steps (after %d untimed ones) with "
+                      "rasterize_triangles_ext.shading_epilogue(False); an event pair costs the stream ~5 us around a single "
+                      "launch (rounds 2-4 reported this figure)" % (n_gs, n_gs_lead)),
             # ids + barycentrics (16 B/px) and the loss's sign codes (1 B/px) read, the triangles'
             # difference-basis records (FoldRec, 160 B) read
             "roofline_shade_backward": roofline(

@@ -619,6 +619,9 @@ struct RasterShade {
 #ifndef MR_RASTER_STORE_AUX_RGBA
 #define MR_RASTER_STORE_AUX_RGBA MR_RASTER_STORE_AUX   // the image plane of the fused forward (its consumer, the loss, reads it back to front)
 #endif
+#ifndef MR_TILE_BANDS
+#define MR_TILE_BANDS 0   // round 5, measured, OFF: see the tile loop of raster_pass
+#endif
 #ifndef MR_EPI_LDS_RECORDS
 #define MR_EPI_LDS_RECORDS 1  // round 4: the shading epilogue reads its winners' corner records per lane from LDS
                               // (see "corner records in LDS" in k_raster) instead of one winner at a time through the scalar cache
@@ -949,7 +952,16 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : INTERP >=
     // horizontally adjacent tiles back to back, so that both halves of a 128-byte line come from
     // one wavefront, was measured: no difference.)
     {
+#if MR_TILE_BANDS
+    // Round 5 (measured, OFF): wavefront w walking a BAND of the region -- tile rows w kTilesY / 4 .. -- instead of every
+    // fourth tile (with four tiles per row that is tile COLUMN w over all the region's rows), so that a wavefront's
+    // stores stay within 16 rows of the image.  Same-box A/B: at 1024-pixel rows +-0 (G-buffer kernel inside the step
+    // 0.140 -> 0.132 ms, back to back 0.157 -> 0.155, fused forward 0.188 -> 0.188); at configs[3]'s 2048-pixel rows
+    // WORSE: G-buffer kernel 0.217 -> 0.266 ms, fused forward 0.315 -> 0.392 (profiles/r05_c4_stage_times.txt).
+    for (int tile = wave * (kTiles / kWaves); tile < (wave + 1) * (kTiles / kWaves); ++tile) {
+#else
     for (int tile = wave; tile < kTiles; tile += kWaves) {
+#endif
       const int ty = tile / kTilesX, tx = tile % kTilesX;
       const int x0 = X0 + tx * kTileW, y0 = Y0 + ty * kTileH;
       if (!full && (x0 >= X1 || y0 >= Y1)) continue;  // wave-uniform

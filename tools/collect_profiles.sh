@@ -12,10 +12,10 @@ OUT=gpurun_out/prof_final
 [ "$CFG" != c3 ] && OUT=gpurun_out/prof_final_$CFG
 rm -rf "$OUT" && mkdir -p "$OUT"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- \
-    python3 bench.py --config $CFG --steps 20 --warmup 3 --cpu-sample 0 > "$OUT/bench_under_rocprof.log" 2>&1
+    python3 bench.py --config $CFG --steps 20 --warmup 3 --cpu-sample 0 --extras 0 > "$OUT/bench_under_rocprof.log" 2>&1
 for counter in WRITE_SIZE FETCH_SIZE; do
   timeout -k 10 400 rocprofv3 --kernel-trace --pmc $counter --output-format csv -d "$OUT/pmc_$counter" -o run -- \
-      python3 bench.py --config $CFG --steps 3 --warmup 1 --cpu-sample 0 > "$OUT/pmc_$counter.log" 2>&1
+      python3 bench.py --config $CFG --steps 3 --warmup 1 --cpu-sample 0 --extras 0 > "$OUT/pmc_$counter.log" 2>&1
 done
 timeout -k 10 250 python3 bench.py --config $CFG $( [ "$CFG" != c3 ] && echo --cpu-sample 0 ) > "$OUT/bench.log" 2>&1
 grep '"metric"' "$OUT/bench.log" | cut -c1-200
