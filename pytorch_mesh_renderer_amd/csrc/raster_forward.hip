@@ -255,11 +255,75 @@ constexpr int kCoarseThreads = 1024;
 constexpr int kRegionListCap = 512;
 constexpr int kCellStash = 2048;  // hits of a cell kept in LDS between k_coarse's two levels (24 KB)
 
+// Round 5: a level ABOVE the cells for large triangle counts.  k_coarse's workgroups each scan ALL T boxes for their
+// cell -- at 50k triangles and 2048^2 x 8 that is 512 workgroups x 13 trips of 4096 boxes, 55 us.  A SUPER-CELL is
+// kSuperCells x kSuperCells cells (1024 pixels at 64-pixel regions); one workgroup per (image, super-cell, chunk of
+// 4096 triangles) tests its chunk against the super-cell once, in two passes -- k_coarse_top<false> counts the hits
+// per chunk, k_coarse_top<true> writes them behind the earlier chunks' (so a super-cell's list is one contiguous,
+// id-ordered array) -- and a cell's workgroup then scans its super-cell's list (~T / 4 + overlap at 2 x 2 super-cells)
+// instead of all T.  Used when T >= kTopMinTriangles and the image has more than one super-cell; lists and results are
+// the same either way (the cell lists are built from a superset of their hits, in id order).
+constexpr int kSuperCells = 4;
+constexpr int kTopUnroll = 4, kTopChunk = kCoarseThreads * kTopUnroll;
+constexpr int kTopMinTriangles = 4 * kTopChunk;
+template <bool WRITE>
+__global__ __launch_bounds__(kCoarseThreads) void k_coarse_top(
+    const TriBox *__restrict__ bbs, int T, int W, int H, int sc_x, int sc_per_image, int sc_size, int n_chunks,
+    int32_t *__restrict__ counts, int32_t *__restrict__ top_ids) {
+  static_assert(kTopUnroll * (kCoarseThreads / kWave) == kWave, "one lane per (sub-chunk, wavefront) count");
+  __shared__ int s_counts[kWave];
+  const int chunk = (int)blockIdx.x % n_chunks;
+  const int rest = (int)blockIdx.x / n_chunks;
+  const int sc = rest % sc_per_image, img = rest / sc_per_image;
+  const int sy = sc / sc_x, sx = sc - sy * sc_x;
+  const int X0 = sx * sc_size, Y0 = sy * sc_size;
+  const int X1 = min(X0 + sc_size, W), Y1 = min(Y0 + sc_size, H);
+  const int tid = (int)threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+  const TriBox *img_bbs = bbs + (size_t)img * T;
+  unsigned long long m[kTopUnroll];
+#pragma unroll
+  for (int u = 0; u < kTopUnroll; ++u) {
+    const int t = chunk * kTopChunk + u * kCoarseThreads + tid;
+    const TriBox bb = (t < T) ? img_bbs[t] : TriBox{0u, 0u, 0.0f, 0u};
+    const int l = (int)(bb.lr & 0xffffu), r = (int)(bb.lr >> 16);
+    const int bt = (int)(bb.bt & 0xffffu), tp = (int)(bb.bt >> 16);
+    m[u] = __ballot((l < X1) && (r > X0) && (bt < Y1) && (tp > Y0));   // empty bbox = all zeros
+    if (lane == 0) s_counts[u * (kCoarseThreads / kWave) + wave] = __builtin_popcountll(m[u]);
+  }
+  __syncthreads();
+  int incl = s_counts[lane];
+  const int own = incl;
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    const int up = __shfl_up(incl, off);
+    if (lane >= off) incl += up;
+  }
+  int32_t *cnt = counts + ((size_t)img * sc_per_image + sc) * n_chunks;
+  if (!WRITE) {
+    if (tid == kWave - 1) cnt[chunk] = incl;
+    return;
+  }
+  int base = 0;
+  for (int c = 0; c < chunk; ++c) base += cnt[c];   // (workgroup-uniform scalar loads; a handful of chunks)
+  const int excl = incl - own;
+  int32_t *out = top_ids + ((size_t)img * sc_per_image + sc) * T;
+#pragma unroll
+  for (int u = 0; u < kTopUnroll; ++u) {
+    const int offset = base + __shfl(excl, u * (kCoarseThreads / kWave) + wave);   // (every lane takes part in the shuffle)
+    if ((m[u] >> lane) & 1ull) {
+      const int pos = offset + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m[u] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m[u], 0u));
+      out[pos] = chunk * kTopChunk + u * kCoarseThreads + tid;
+    }
+  }
+}
+
 __global__ __launch_bounds__(kCoarseThreads) void k_coarse(
     const TriBox *__restrict__ bbs, int T, int W, int H, int cells_x, int cells_per_image, int cell_size,
     int32_t *__restrict__ cell_ids, int32_t *__restrict__ cell_count, float *__restrict__ cell_split,
     int regions_x, int regions_y, int32_t *__restrict__ region_ids, int32_t *__restrict__ region_count,
-    int regions_per_xcd, int32_t *__restrict__ order_count, int32_t *__restrict__ order_list) {
+    int regions_per_xcd, int32_t *__restrict__ order_count, int32_t *__restrict__ order_list,
+    const int32_t *__restrict__ top_ids, const int32_t *__restrict__ top_counts, int sc_x, int sc_per_image,
+    int n_chunks) {
   static_assert(kCoarseThreads / kWave == kCellRegions * kCellRegions, "one wavefront per region of the cell");
   __shared__ float s_wave_lo[kCoarseThreads / kWave], s_wave_hi[kCoarseThreads / kWave];
   __shared__ uint2 s_hit_box[kCellStash];  // (lr, bt) of the cell's first kCellStash hits, for the second level
@@ -273,6 +337,19 @@ __global__ __launch_bounds__(kCoarseThreads) void k_coarse(
   const int tid = (int)threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
   const TriBox *img_bbs = bbs + (size_t)img * T;
   int32_t *out = cell_ids + ((size_t)img * cells_per_image + cell) * T;
+  // the boxes to scan: all T, or (k_coarse_top ran) the id-ordered list of this cell's super-cell
+  const int32_t *src = nullptr;
+  int n_src = T;
+  if (top_ids) {   // launch-uniform
+    const int sc = (cy / kSuperCells) * sc_x + cx / kSuperCells;
+    src = top_ids + ((size_t)img * sc_per_image + sc) * T;
+    const int32_t *cnt = top_counts + ((size_t)img * sc_per_image + sc) * n_chunks;
+    n_src = 0;
+    for (int c = 0; c < n_chunks; ++c) n_src += cnt[c];
+#ifdef MR_COARSE_TOP_DEBUG
+    if (MR_COARSE_TOP_DEBUG == 1) { src = nullptr; n_src = T; }   // run the top kernels, ignore their lists
+#endif
+  }
   int n = 0;  // workgroup-uniform
   float lo = INFINITY, hi = -INFINITY;  // range of the depth bounds of this thread's hits
   constexpr int kUnroll = 4;
@@ -286,12 +363,18 @@ __global__ __launch_bounds__(kCoarseThreads) void k_coarse(
   int trip = 0;
   // (Measured, no gain: requesting the next trip's boxes a trip ahead; keeping the hits in LDS and
   // copying the list out at the end; skipping 64-triangle chunks by a union box -- see DESIGN.md 4.1.)
-  for (int base = 0; base < T; base += kUnroll * kCoarseThreads, trip ^= 1) {
+  for (int base = 0; base < n_src; base += kUnroll * kCoarseThreads, trip ^= 1) {
     TriBox bb[kUnroll];
+    int tri[kUnroll];
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
-      const int t = base + u * kCoarseThreads + tid;
-      bb[u] = (t < T) ? img_bbs[t] : TriBox{0u, 0u, 0.0f, 0u};
+      const int k = base + u * kCoarseThreads + tid;
+      tri[u] = src ? (k < n_src ? src[k] : -1) : k;
+    }
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int t = tri[u];
+      bb[u] = (t >= 0 && t < T) ? img_bbs[t] : TriBox{0u, 0u, 0.0f, 0u};
     }
     unsigned long long m[kUnroll];
 #pragma unroll
@@ -319,7 +402,7 @@ __global__ __launch_bounds__(kCoarseThreads) void k_coarse(
     for (int u = 0; u < kUnroll; ++u) {
       const int offset = n + __shfl(excl, u * (kCoarseThreads / kWave) + wave);
       if ((m[u] >> lane) & 1ull) {
-        const int t = base + u * kCoarseThreads + tid;
+        const int t = tri[u];
         const int pos = offset + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m[u] >> 32),
                                                                 __builtin_amdgcn_mbcnt_lo((unsigned)m[u], 0u));
         out[pos] = t;
@@ -618,6 +701,9 @@ struct RasterShade {
 #endif
 #ifndef MR_RASTER_STORE_AUX_RGBA
 #define MR_RASTER_STORE_AUX_RGBA MR_RASTER_STORE_AUX   // the image plane of the fused forward (its consumer, the loss, reads it back to front)
+#endif
+#ifndef MR_COARSE_TOP
+#define MR_COARSE_TOP 1   // 0: k_coarse always scans all T boxes (A/B)
 #endif
 #ifndef MR_TILE_BANDS
 #define MR_TILE_BANDS 0   // round 5, measured, OFF: see the tile loop of raster_pass
@@ -1539,6 +1625,19 @@ static int region_edge(int B, int W, int H) {
   return regions64 < 4L * 256 ? 32 : 64;
 }
 
+// super-cell lists + per-chunk counts of k_coarse_top (0 when the level is not used)
+static bool coarse_top_used(int T, int W, int H, int cell) {
+  const int sc = kSuperCells * cell;
+  return MR_COARSE_TOP && T >= kTopMinTriangles && ((W + sc - 1) / sc) * ((H + sc - 1) / sc) > 1;
+}
+static size_t coarse_top_bytes(int B, int T, int W, int H, int cell) {
+  if (!coarse_top_used(T, W, H, cell)) return 0;
+  const int sc = kSuperCells * cell;
+  const size_t n_sc = (size_t)((W + sc - 1) / sc) * ((H + sc - 1) / sc) * B;
+  const size_t n_chunks = (size_t)(T + kTopChunk - 1) / kTopChunk;
+  return align_up(n_sc * T * sizeof(int32_t), 256) + align_up(n_sc * n_chunks * sizeof(int32_t), 256);
+}
+
 size_t raster_forward_ws(int B, int V, int T, int W, int H) {
   (void)V;
   const size_t nbt = (size_t)B * T;
@@ -1550,7 +1649,8 @@ size_t raster_forward_ws(int B, int V, int T, int W, int H) {
          align_up((size_t)W * sizeof(float), 256) + align_up((size_t)H * sizeof(float), 256) +
          align_up(cells * T * sizeof(int32_t), 256) + 2 * align_up(cells * sizeof(int32_t), 256) +
          align_up(regions * kRegionListCap * sizeof(int32_t), 256) + align_up(regions * sizeof(int32_t), 256) +
-         256 + align_up((size_t)kXcds * kWeightClasses * ((regions + kXcds - 1) / kXcds) * sizeof(int32_t), 256);
+         256 + align_up((size_t)kXcds * kWeightClasses * ((regions + kXcds - 1) / kXcds) * sizeof(int32_t), 256) +
+         coarse_top_bytes(B, T, W, H, cell);
 }
 
 #ifdef MR_PROBES
@@ -1643,6 +1743,12 @@ int raster_forward(const float *clip, const int32_t *tris, int B, int V, int T, 
   int32_t *order_count = (int32_t *)p;   // [kXcds][kWeightClasses]
   p += 256;
   int32_t *order_list = (int32_t *)p;    // [kXcds][kWeightClasses][per_xcd]
+  p += align_up((size_t)kXcds * kWeightClasses * per_xcd * sizeof(int32_t), 256);
+  const bool top = coarse_top_used(T, W, H, cell);
+  const int sc_size = kSuperCells * cell, sc_x = (W + sc_size - 1) / sc_size, sc_per_image = sc_x * ((H + sc_size - 1) / sc_size);
+  const int n_chunks = (T + kTopChunk - 1) / kTopChunk;
+  int32_t *top_ids = top ? (int32_t *)p : nullptr;
+  int32_t *top_counts = top ? (int32_t *)(p + align_up((size_t)sc_per_image * B * T * sizeof(int32_t), 256)) : nullptr;
 
   const long setup_threads = (long)nbt + W + H;
   const unsigned setup_blocks = (unsigned)((setup_threads + kThreads - 1) / kThreads);
@@ -1651,9 +1757,18 @@ int raster_forward(const float *clip, const int32_t *tris, int B, int V, int T, 
   int rc = check_launch();
   if (rc != MR_OK) return rc;
   if (B == 0) return MR_OK;
+  if (top) {
+    const dim3 top_grid((unsigned)((size_t)B * sc_per_image * n_chunks));
+    hipLaunchKernelGGL(k_coarse_top<false>, top_grid, dim3(kCoarseThreads), 0, s, bbs, T, W, H, sc_x, sc_per_image, sc_size,
+                       n_chunks, top_counts, top_ids);
+    hipLaunchKernelGGL(k_coarse_top<true>, top_grid, dim3(kCoarseThreads), 0, s, bbs, T, W, H, sc_x, sc_per_image, sc_size,
+                       n_chunks, top_counts, top_ids);
+    if ((rc = check_launch()) != MR_OK) return rc;
+  }
   hipLaunchKernelGGL(k_coarse, dim3((unsigned)(cells_per_image * B)), dim3(kCoarseThreads), 0, s, bbs, T,
                      W, H, cells_x, cells_per_image, cell, cell_ids, cell_count, cell_split, regions_x, regions_y,
-                     region_ids, region_count, per_xcd, order_count, order_list);
+                     region_ids, region_count, per_xcd, order_count, order_list, top_ids, top_counts, sc_x, sc_per_image,
+                     n_chunks);
   rc = check_launch();
   if (rc != MR_OK) return rc;
 

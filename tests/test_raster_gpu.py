@@ -262,6 +262,36 @@ def test_random_soups_with_nonfinite_vertices(device):
     assert nan_pixels > 0   # the case is actually exercised
 
 
+@pytest.mark.parametrize("edge", [0, 32, 64])
+def test_many_triangles_take_the_super_cell_level_bit_exactly(device, edge):
+    """Round 5: from 16384 triangles on (and more than one super-cell of 4 x 4 cells in the image) the coarse binning gets
+    a level above the cells (k_coarse_top: per-super-cell id-ordered lists, the cells scan those instead of all T).  20 000
+    random small triangles -- duplicates for exact depth ties, a few huge ones that touch every super-cell, some behind
+    the eye -- on an image that is not a multiple of anything: ids, depths and barycentrics bit for bit the oracle's."""
+    rng = np.random.default_rng(20)
+    T, w, h = 20000, 1100, 1300
+    centre = rng.uniform(-1.1, 1.1, size=(T, 1, 2))
+    offs = rng.normal(size=(T, 3, 2)) * 0.015
+    offs[::997] *= 60.0                                        # a few triangles as large as the image
+    xy = (centre + offs).astype(np.float32)
+    clip = np.zeros((1, 3 * T, 4), np.float32)
+    clip[0, :, :2] = xy.reshape(-1, 2)
+    clip[0, :, 2] = rng.uniform(-0.9, 0.9, size=3 * T)
+    clip[0, :, 3] = rng.uniform(0.7, 1.3, size=3 * T)
+    clip[0, rng.integers(0, 3 * T, size=40), 3] *= -1.0        # some vertices behind the eye (full-screen bbox path)
+    tris = np.arange(3 * T, dtype=np.int32).reshape(T, 3)
+    tris[T // 2] = tris[7]
+    tris[T - 1] = tris[11][::-1]                               # duplicates: exact ties, the later id wins
+    assert _native.lib().mr_debug_set_raster_region_edge(edge) == 0
+    try:
+        ids, bary, z = _native.rasterize_forward(torch.from_numpy(clip).to(device), torch.from_numpy(tris).to(device), w, h)
+    finally:
+        _native.lib().mr_debug_set_raster_region_edge(0)
+    o_ids, o_bary, o_z = oracle.forward(clip, tris, w, h, threads=8)
+    assert bits_equal(ids.cpu().numpy(), o_ids) and bits_equal(z.cpu().numpy(), o_z) and bits_equal(bary.cpu().numpy(), o_bary)
+    assert (o_ids > 0).mean() > 0.3
+
+
 def test_bin_overflow_many_triangles_one_region(device):
     """More triangles over one 64x64 region than the LDS bin holds (multi-pass path)."""
     rng = np.random.default_rng(5)
