@@ -712,6 +712,17 @@ struct RasterShade {
 #define MR_EPI_LDS_RECORDS 1  // round 4: the shading epilogue reads its winners' corner records per lane from LDS
                               // (see "corner records in LDS" in k_raster) instead of one winner at a time through the scalar cache
 #endif
+#ifndef MR_RASTER_XREC
+#define MR_RASTER_XREC 64         // extra record slots of the crowded-launch instantiation (0: no such instantiation).
+                                  // configs[3], same box, fused forward: none 0.3169 / 0.3148 ms; 128 slots at four workgroups
+                                  // per CU 0.3116 / 0.3109; 64 slots (144 in all) at five 0.3057; 128 at five (spills) 0.3135
+#endif
+#ifndef MR_RASTER_XREC_WAVES
+#define MR_RASTER_XREC_WAVES 5
+#endif
+#ifndef MR_RASTER_XREC_DENSITY
+#define MR_RASTER_XREC_DENSITY 32  // triangles per 64 x 64 pixels of image (T * 4096 / (W H)) from which it is used
+#endif
 #ifndef MR_RASTER_SHADE_WAVES
 #define MR_RASTER_SHADE_WAVES 6  // measured against 7 (more spills) and 5: 0.336 / 0.352 / 0.347 ms at 1024^2 x 32
 #endif
@@ -724,8 +735,12 @@ struct RasterShade {
 #ifndef MR_RASTER_INTERP_WAVES
 #define MR_RASTER_INTERP_WAVES 5
 #endif
-template <int R, int PROBE, bool SHADE, int INTERP = 0, int AX = 0>
-__global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : INTERP >= 12 ? 4 : INTERP ? MR_RASTER_INTERP_WAVES : MR_RASTER_WAVES) void k_raster(
+// XREC (round 5, SHADE only): that many extra corner-record slots of LDS behind the bin, for launches whose regions are
+// crowded (configs[3]: ~170 entries per 64 x 64 region against the 106 record slots the bin's unused top offers): the
+// epilogue then reads its winners' records per lane from LDS there too instead of one winner at a time through the scalar
+// cache.  64 slots = 7 KB more LDS: five workgroups per CU instead of six.  Chosen on the host (launch_k_raster_probe).
+template <int R, int PROBE, bool SHADE, int INTERP = 0, int AX = 0, int XREC = 0>
+__global__ __launch_bounds__(kThreads, SHADE ? (XREC ? MR_RASTER_XREC_WAVES : MR_RASTER_SHADE_WAVES) : INTERP >= 12 ? 4 : INTERP ? MR_RASTER_INTERP_WAVES : MR_RASTER_WAVES) void k_raster(
     const TriRec *__restrict__ recs, const TriBox *__restrict__ bbs,
     const float *__restrict__ pxtab, const float *__restrict__ pytab, int T, int W, int H,
     int regions_x, int regions_per_image, int n_regions, int regions_per_xcd,
@@ -736,6 +751,7 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : INTERP >=
     const int32_t *__restrict__ order_list, int32_t *__restrict__ ids, float *__restrict__ bary,
     float *__restrict__ zbuf, const RasterShade shade) {
   static_assert(R == 64 || R == 32, "region edge");
+  static_assert(XREC == 0 || (SHADE && XREC % 4 == 0), "extra record slots: the shading epilogue's");
   static_assert(!SHADE || PROBE == 0, "the shading epilogue has no timing probes");
   static_assert(INTERP == 0 || (!SHADE && PROBE == 0 && INTERP % 4 == 0 && INTERP <= 16), "one epilogue at a time");
   static_assert(AX == 0 || (INTERP > 0 && AX <= INTERP && AX > INTERP - 4), "a fixed attribute count belongs to its padded variant");
@@ -749,7 +765,8 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : INTERP >=
   constexpr int kTilesX = R / kTileW, kTilesY = R / kTileH;
   constexpr int kTiles = kTilesX * kTilesY;  // tiles per region: 64 or 16
   constexpr int kMaskWords = kBin2Cap / 32;
-  __shared__ __attribute__((aligned(16))) float s_ent[kBin2Cap * kEntryDw];
+  constexpr int kEntDw = kBin2Cap * kEntryDw + XREC * 28;   // the bin, then XREC more record slots (records grow down from the end)
+  __shared__ __attribute__((aligned(16))) float s_ent[kEntDw];
   // LDS budget at R = 64: 20480 (entries) + 2048 (masks / bin bookkeeping) + 512 (pixel centres)
   // = 23040 B = 18 allocation granules of 1280 B, so that SEVEN workgroups fit the 160 KB of a CU.
   // The bin-stage bookkeeping is dead by the time the tile masks are built and shares their storage.
@@ -1026,8 +1043,9 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : INTERP >=
   // next to its id, and the epilogue is 7 per-lane ds_read_b128 and 27 multiply-adds per tile, whatever the
   // number of winners.  LDS reads count on lgkmcnt like the scalar loads did: the G-buffer stores stay undisturbed.
   constexpr int kRecordDw = INTERP > 0 ? 3 * INTERP : 28;  // (INTERP: the attribute record of interp_fused.hip, [corner][AP])
-  constexpr int kRecordSlots = (kBin2Cap * kEntryDw) / (kEntryDw + kRecordDw);   // 106 (SHADE): entries + records fit the bin
-  auto record_of = [&](const int slot) -> const float * { return s_ent + (kBin2Cap * kEntryDw - (slot + 1) * kRecordDw); };
+  constexpr int kRecordSlotsRaw = kEntDw / (kEntryDw + kRecordDw);   // 106 (SHADE): entries + records fit the bin; XREC = 128: 181
+  constexpr int kRecordSlots = kRecordSlotsRaw < kBin2Cap ? kRecordSlotsRaw : kBin2Cap;
+  auto record_of = [&](const int slot) -> const float * { return s_ent + (kEntDw - (slot + 1) * kRecordDw); };
   auto raster_pass = [&](auto fresh_tag, auto full_tag, auto stage_tag, auto recs_tag, const int far_word,
                          const bool last_round) {
     constexpr bool fresh = decltype(fresh_tag)::value, full = decltype(full_tag)::value;
@@ -1565,7 +1583,7 @@ __global__ __launch_bounds__(kThreads, SHADE ? MR_RASTER_SHADE_WAVES : INTERP >=
         const int t = tid < total ? __builtin_bit_cast(int, s_ent[slot * kEntryDw + 18]) : 0;
         const unsigned tc = min((unsigned)max(t, 0), (unsigned)(T - 1));
         const float4 *src = SHADE ? (const float4 *)(img_corners + tc) : (const float4 *)(img_attr_records + (size_t)tc * kRecordDw);
-        float4 *dst = (float4 *)(s_ent + (kBin2Cap * kEntryDw - (slot + 1) * kRecordDw));
+        float4 *dst = (float4 *)(s_ent + (kEntDw - (slot + 1) * kRecordDw));
         float4 q[kRecordDw / 4];
 #pragma unroll
         for (int i = 0; i < kRecordDw / 4; ++i) q[i] = src[i];
@@ -1669,9 +1687,9 @@ struct RasterArgs {
   RasterShade shade;  // rgba == nullptr: G-buffer only
 };
 
-template <int R, int PROBE, bool SHADE = false, int INTERP = 0, int AX = 0>
+template <int R, int PROBE, bool SHADE = false, int INTERP = 0, int AX = 0, int XREC = 0>
 void launch_k_raster(const RasterArgs &a, dim3 grid, hipStream_t s) {
-  hipLaunchKernelGGL((k_raster<R, PROBE, SHADE, INTERP, AX>), grid, dim3(kThreads), 0, s, a.recs, a.bbs, a.pxtab, a.pytab, a.T,
+  hipLaunchKernelGGL((k_raster<R, PROBE, SHADE, INTERP, AX, XREC>), grid, dim3(kThreads), 0, s, a.recs, a.bbs, a.pxtab, a.pytab, a.T,
                      a.W, a.H, a.regions_x, a.per_image, a.n_regions, a.per_xcd, a.cell_ids, a.cell_count,
                      a.cell_split, a.cells_x, a.cells_per_image, a.region_ids, a.region_count, a.order_count,
                      a.order_list, a.ids, a.bary, a.z, a.shade);
@@ -1679,7 +1697,12 @@ void launch_k_raster(const RasterArgs &a, dim3 grid, hipStream_t s) {
 
 template <int R>
 void launch_k_raster_probe(const RasterArgs &a, dim3 grid, hipStream_t s) {
-  if (a.shade.rgba) return launch_k_raster<R, 0, true>(a, grid, s);
+  if (a.shade.rgba) {
+    // crowded launches (triangles per 64 x 64 pixels of image): the instantiation with extra record slots, see XREC
+    if (MR_RASTER_XREC > 0 && R == 64 && (double)a.T * 4096.0 >= (double)MR_RASTER_XREC_DENSITY * a.W * a.H)
+      return launch_k_raster<R, 0, true, 0, 0, (R == 64 ? MR_RASTER_XREC : 0)>(a, grid, s);
+    return launch_k_raster<R, 0, true>(a, grid, s);
+  }
   if (a.shade.attr_out) {  // rasterize()'s interpolation as the epilogue, attribute count padded to 4 / 8 / 12 / 16
     if (a.shade.A == 9) return launch_k_raster<R, 0, false, 12, 9>(a, grid, s);   // (normal, position, colour: render()'s set)
     if (a.shade.A == 3) return launch_k_raster<R, 0, false, 4, 3>(a, grid, s);
