@@ -600,8 +600,8 @@ struct ShadeDiffLaneFn : ShadeGradFn<L, SIGNS, LG> {
   static constexpr int kStride = 36;
   static constexpr int kLaneRowsPerWave = LG ? MR_LANE_ROWS_LG : (kN <= 18 ? MR_FOLD_LANE_ROWS : MR_LANE_ROWS);
   static constexpr int kMinWavesPerSimd = (LG || kN > 27) ? 3 : MR_LANE_WAVES;
-  const FoldRec *__restrict__ fold_recs;
-  using Triangle = FoldTriangle;
+  const FoldRec *__restrict__ fold_recs;   // FOLD: in the pulled form (store_fold_record with the image's transform rows)
+  using Triangle = std::conditional_t<FOLD, FoldTriangleW, FoldTriangle>;
   __host__ __device__ static constexpr int group(int gi) {
     int g = 0;
     for (int seen = 0; g < 3; ++g) {
@@ -619,7 +619,8 @@ struct ShadeDiffLaneFn : ShadeGradFn<L, SIGNS, LG> {
     return k * 9 + g * 3 + c;
   }
   __device__ __forceinline__ void load_triangle(int img, int tri, Triangle &t) const {
-    load_fold_triangle(fold_recs + (size_t)img * this->T_ + tri, t);
+    if constexpr (FOLD) load_fold_triangle_w(fold_recs + (size_t)img * this->T_ + tri, t);
+    else load_fold_triangle(fold_recs + (size_t)img * this->T_ + tri, t);
   }
   __device__ __forceinline__ void accumulate(const typename Base::Pixel &p, const Triangle &t, float (&a)[kN],
                                              typename Base::Image &im) const {
@@ -633,17 +634,18 @@ struct ShadeDiffLaneFn : ShadeGradFn<L, SIGNS, LG> {
       g0 = fmaf(dat[k], t.e0[k], g0);
       g1 = fmaf(dat[k], t.e1[k], g1);
     }
-    float q[3];
+    [[maybe_unused]] float q[3];
+    if constexpr (FOLD) {   // the pulled record (round 5, as ShadeFoldLaneFn): (M^T q) = (g0 b0 + g1 b1) S + g0 P0 + g1 P1
+      const float h = fmaf(g0, p.b.x, g1 * p.b.y);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const float w0 = t.s[c] * p.b.x - t.u0[c];
-      const float w1 = t.s[c] * p.b.y - t.u1[c];
-      q[c] = (g0 * w0 + g1 * w1) * t.inv;
-    }
-    if (FOLD) {
+      for (int c = 0; c < 3; ++c) dat[3 + c] = fmaf(h, t.S[c], fmaf(g0, t.P0[c], fmaf(g1, t.P1[c], dat[3 + c])));
+    } else {
 #pragma unroll
-      for (int c = 0; c < 3; ++c)
-        dat[3 + c] += (im.pull[0][c] * q[0] + im.pull[1][c] * q[1]) + im.pull[2][c] * q[2];
+      for (int c = 0; c < 3; ++c) {
+        const float w0 = t.s[c] * p.b.x - t.u0[c];
+        const float w1 = t.s[c] * p.b.y - t.u1[c];
+        q[c] = (g0 * w0 + g1 * w1) * t.inv;
+      }
     }
     const float b[3] = {p.b.x, p.b.y, p.b.z};
 #pragma unroll
@@ -1011,7 +1013,7 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
   rc = fused_clear ? launch_bwd_setup(clip, tris, B, V, T, recs, s, acc, (fold_diff ? kFoldAccStride : 36) * sizeof(float), light_grads,
                                       light_grads ? B * (L * 6 + 3) : 0, (fold_diff || diff_general) ? corner_records : nullptr,
                                       (fold_diff || diff_general) ? fold_recs : nullptr,
-                                      fold_diff ? transforms : nullptr)   // ShadeFoldLaneFn reads the pulled form
+                                      fold ? transforms : nullptr)   // the folded kernels read the pulled form
                    : launch_bwd_setup(clip, tris, B, V, T, recs, s);
   if (rc != MR_OK) return rc;
   if (corner_records) {  // the forward's records (same inputs): skip the gather
