@@ -537,7 +537,10 @@ def main():
 
     extras = {}
     if rank == 0 and world == 1 and args.extras and args.config == "c3":
-        extras = extra_legs(job, device, batch, width, height)
+        try:
+            extras = extra_legs(job, device, batch, width, height)
+        except Exception as exc:   # the legs after the timed region must never cost the line its headline
+            extras = {"extras_error": "%s: %s" % (type(exc).__name__, exc)}
 
     if rank == 0:
         V, T = job["vertices"].shape[1], job["triangles"].shape[0]
