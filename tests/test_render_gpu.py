@@ -1010,6 +1010,37 @@ def test_render_with_and_without_shading_epilogue(device):
         np.testing.assert_allclose(results[True][1][k], want, atol=ATOL, rtol=0, err_msg=k)
 
 
+@pytest.mark.parametrize("res", [52, 70, 110])
+def test_render_forward_with_extra_record_slots_matches_raster_then_shade(device, res):
+    """Round 5: launches with 32 or more triangles per 64 x 64 pixels of image take k_raster<..., XREC = 64>, whose bin is
+    followed by 64 more LDS slots for the shading epilogue's corner records (144 in all instead of 106).  Spheres of
+    5.4k / 9.8k / 24k triangles at 192 x 128 with 64-pixel regions forced: regions below 106 entries, between 106 and
+    144 (records in the extra slots), above (the scalar-cache loop), and several bin rounds -- all against
+    mr_rasterize_forward + mr_shade_forward: G-buffer bit for bit, RGBA to 1e-6."""
+    from pytorch_mesh_renderer_amd import _native
+    w, h = 192, 128
+    job = synthetic.sphere_job(2, w, h, res)
+    d = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in job.items()}
+    assert d["triangles"].shape[0] * 4096 >= 32 * w * h, "dense enough for the XREC instantiation"
+    gen = torch.Generator().manual_seed(res)
+    diffuse = torch.rand(d["vertices"].shape, generator=gen).to(device)
+    lp = (torch.rand(2, 2, 3, generator=gen) * 6 - 3).to(device)
+    li = (torch.rand(2, 2, 3, generator=gen) + 0.2).to(device)
+    xf = synthetic.clip_transforms(job["eyes"], w, h).to(device)
+    assert _native.lib().mr_debug_set_raster_region_edge(64) == 0
+    try:
+        clip = _native.vertex_transform(d["vertices"], xf)
+        ids, bary, z = _native.rasterize_forward(clip, d["triangles"], w, h)
+        rgba = _native.shade_forward(ids, bary, d["normals"], d["vertices"], diffuse, d["triangles"], lp, li, None)
+        _, ids2, bary2, _, rgba2, _ = _native.render_forward(d["vertices"], xf, d["normals"], diffuse, d["triangles"], lp, li,
+                                                            None, w, h, want_z=False)
+    finally:
+        _native.lib().mr_debug_set_raster_region_edge(0)
+    assert torch.equal(ids2, ids) and torch.equal(bary2.view(torch.int32), bary.view(torch.int32))
+    np.testing.assert_allclose(rgba2.cpu().numpy(), rgba.cpu().numpy(), atol=1e-6, rtol=0)
+    assert float(rgba[..., 3].mean()) > 0.3
+
+
 @pytest.mark.parametrize("w,h,res,n_lights,ambient", [(96, 80, 12, 1, False), (130, 67, 10, 3, True),
                                                         (64, 64, 120, 2, True), (33, 31, 6, 4, False)])
 def test_render_forward_matches_raster_then_shade(device, w, h, res, n_lights, ambient):
