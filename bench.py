@@ -463,7 +463,9 @@ def main():
     # k_raster, then k_shade_forward, loss, backward).  Behind the kernel runs another kind of work, under which the
     # tail of its 671 MB of stores drains; back to back with itself the kernel runs at the sustained write rate.  Both
     # are this kernel's duration -- in a renderer's step and in a write-only burst -- and the line carries both.
-    n_gs, n_gs_lead = 12, 6
+    # (its lead-in also lets the chip settle: from idle the step time falls for ~40 steps -- 0.71 -> 0.66 ms on one box,
+    #  tools/step_series.py -- and a 20-step timed region that starts earlier measures that ramp)
+    n_gs, n_gs_lead = 12, 36
     ev_gstep = KernelEvents(n_gs, _native.TIMER_RASTER_FORWARD)
     with ext.shading_epilogue(False):
         for i in range(n_gs + n_gs_lead):
