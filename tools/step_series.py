@@ -1,6 +1,7 @@
-"""Per-step GPU time of the benchmarked step from an idle chip (events around every step): the clock ramp a short timed\nregion sits on.   python tools/step_series.py"""
+"""Per-step GPU time of the benchmarked step from an idle chip (events around every step): the clock ramp a short
+timed region sits on.   python tools/step_series.py"""
 import os, sys, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
 from pytorch_mesh_renderer_amd.common import synthetic
 dev = torch.device("cuda:0")
