@@ -382,6 +382,27 @@ int mr_shade_specular_backward(const float *drgba, const int32_t *ids, const flo
                                float *light_grads, const int32_t *vertex_offsets,
                                const int32_t *vertex_entries, const float *transforms, int gbuffer_flags,
                                int grads_wanted, void *workspace, size_t workspace_bytes, void *stream);
+/* mr_shade_specular_backward for an upstream gradient that is the backward of mr_l1_loss_forward(rgba, target)
+ * -- the reference's optimisation loop, mesh_renderer_test.py:238-262, on the specular renderer (render.py:224-246):
+ * `signs` / `upstream` as in mr_shade_backward_l1, in place of drgba.  Same outputs as
+ * mr_shade_specular_backward(drgba = upstream * sign / (B*H*W*4)).  The one-pass vertex-gradient kernel (one or two
+ * lights, transforms given, only MR_GRAD_POSITIONS wanted, MR_GBUFFER_NORMALISED, adjacency given, deterministic mode
+ * off) reads the codes directly, 1 B/px instead of 16; every other case writes the dense image into the workspace
+ * first and runs mr_shade_specular_backward's kernels.  The workspace must be
+ * mr_shade_specular_backward_l1_workspace_bytes() long. */
+size_t mr_shade_specular_backward_l1_workspace_bytes(int B, int V, int T, int W, int H);
+int mr_shade_specular_backward_l1(const uint8_t *signs, const float *upstream, const int32_t *ids,
+                                  const float *bary, const float *clip, const float *normals,
+                                  const float *positions, const float *diffuse, const float *specular,
+                                  const int32_t *triangles, const float *light_positions,
+                                  const float *light_intensities, const float *ambient,
+                                  const float *camera_position, const float *shininess,
+                                  int shininess_per_vertex, const float *norms2, int B, int V, int T,
+                                  int W, int H, int L, float *dclip, float *dnormals, float *dpositions,
+                                  float *ddiffuse, float *dspecular, float *dshininess,
+                                  float *light_grads, const int32_t *vertex_offsets,
+                                  const int32_t *vertex_entries, const float *transforms, int gbuffer_flags,
+                                  int grads_wanted, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- SoftRas renderer ---------------------------------------------------------------
  * Replaces rasterize_batch / rasterize of the reference's second renderer

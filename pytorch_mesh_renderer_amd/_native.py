@@ -236,6 +236,10 @@ def lib():
         L.mr_shade_specular_backward_workspace_bytes.restype = sz
         L.mr_shade_specular_backward.argtypes = [vp] * 14 + [ci, vp] + [ci] * 6 + [vp] * 7 + [vp, vp] + [vp, ci, ci] + [vp, sz, vp]
         L.mr_shade_specular_backward.restype = ci
+        L.mr_shade_specular_backward_l1_workspace_bytes.argtypes = [ci] * 5
+        L.mr_shade_specular_backward_l1_workspace_bytes.restype = sz
+        L.mr_shade_specular_backward_l1.argtypes = [vp] * 15 + [ci, vp] + [ci] * 6 + [vp] * 7 + [vp, vp] + [vp, ci, ci] + [vp, sz, vp]
+        L.mr_shade_specular_backward_l1.restype = ci
         L.mr_export_u8.argtypes = [vp, sz, vp, vp]
         L.mr_export_u8.restype = ci
         L.mr_tone_map.argtypes = [vp, ci, sz, cf, vp, vp, vp, vp]
@@ -869,7 +873,7 @@ GRAD_ALL = 127
 def shade_specular_backward(drgba, ids, bary, clip, normals, positions, diffuse, specular, triangles,
                             light_positions, light_intensities, ambient, camera_position, shininess,
                             norms2, adjacency=None, transforms=None, normalised_gbuffer=False,
-                            grads_wanted=GRAD_ALL):
+                            grads_wanted=GRAD_ALL, l1_signs=None):
     """-> (dclip [B,V,4], dnormals, dpositions, ddiffuse, dspecular [B,V,3], dlight_positions,
     dlight_intensities [B,L,3], dambient [B,3] or None, dcamera_position [B,3], dshininess shaped
     like shininess ([B] or [B,V])).  adjacency: vertex_adjacency(triangles, V) -- the per-triangle
@@ -878,7 +882,11 @@ def shade_specular_backward(drgba, ids, bary, clip, normals, positions, diffuse,
     grads_wanted: GRAD_* bits of the results the caller will read (the others come back unspecified).  With only
     GRAD_POSITIONS / GRAD_CLIP wanted and normalised_gbuffer=True (ids / bary are rasterize_forward's own output
     for `clip`) the pixel pass is the lane-accumulating kernel; with transforms ([B,4,4], clip = M (position, 1))
-    and GRAD_CLIP not wanted, dpositions is the whole gradient w.r.t. the world-space vertices."""
+    and GRAD_CLIP not wanted, dpositions is the whole gradient w.r.t. the world-space vertices.
+
+    l1_signs ([B,H,W] uint8, l1_loss_forward's sign codes for the image these inputs shaded): drgba is then the
+    device scalar d L / d loss and the upstream image is upstream * sign / (B*H*W*4) without being written out where
+    the pixel kernel can read the codes (mr_shade_specular_backward_l1)."""
     tensors = [drgba, ids, bary, clip, normals, positions, diffuse, specular, triangles,
                light_positions, light_intensities, camera_position, shininess, norms2]
     B, V, _ = _chk_mesh(clip, triangles)
@@ -887,7 +895,15 @@ def shade_specular_backward(drgba, ids, bary, clip, normals, positions, diffuse,
         _chk(name, t, _F32, B, V, 3)
     h, w = _chk_gbuffer(ids, bary, B)
     nl_ = _chk_lights(light_positions, light_intensities, ambient, B, shade_fast_lights())
-    _chk("upstream gradient", drgba, _F32, B, h, w, 4)
+    if l1_signs is None:
+        _chk("upstream gradient", drgba, _F32, B, h, w, 4)
+    else:
+        if drgba.dtype != torch.float32 or drgba.numel() != 1:
+            raise ValueError("with l1_signs the upstream gradient is one float32 (d L / d loss)")
+        if l1_signs.dtype != torch.uint8 or l1_signs.numel() != B * h * w:
+            raise ValueError("l1_signs must hold one byte per pixel")
+        _require_device(l1_signs)
+        l1_signs = l1_signs.contiguous()
     _chk("camera_position", camera_position, _F32, B, 3)
     per_vertex = _chk_shininess(shininess, B, V)
     _chk("norms2", norms2, _F32, B, nl_)
@@ -911,17 +927,22 @@ def shade_specular_backward(drgba, ids, bary, clip, normals, positions, diffuse,
         transforms = transforms.contiguous()
     with torch.cuda.device(dev):
         _sync_deterministic()
-        need = L.mr_shade_specular_backward_workspace_bytes(B, V, T, W, H)
+        if l1_signs is not None:
+            need = L.mr_shade_specular_backward_l1_workspace_bytes(B, V, T, W, H)
+            entry, head = L.mr_shade_specular_backward_l1, (_ptr(l1_signs), _ptr(drgba))
+        else:
+            need = L.mr_shade_specular_backward_workspace_bytes(B, V, T, W, H)
+            entry, head = L.mr_shade_specular_backward, (_ptr(drgba),)
         ws, have = _workspace(dev, need)
-        rc = L.mr_shade_specular_backward(
-            _ptr(drgba), _ptr(ids), _ptr(bary), _ptr(clip), _ptr(normals), _ptr(positions),
+        rc = entry(
+            *head, _ptr(ids), _ptr(bary), _ptr(clip), _ptr(normals), _ptr(positions),
             _ptr(diffuse), _ptr(specular), _ptr(triangles), _ptr(light_positions),
             _ptr(light_intensities), _ptr(ambient), _ptr(camera_position), _ptr(shininess),
             int(per_vertex), _ptr(norms2), B, V, T, W, H, nl, _ptr(dclip), _ptr(dn), _ptr(dp), _ptr(dd),
             _ptr(dsp), _ptr(dshin_v), _ptr(lg), _ptr(adjacency[0]) if adjacency is not None else None,
             _ptr(adjacency[1]) if adjacency is not None else None, _ptr(transforms),
             GBUFFER_NORMALISED if normalised_gbuffer else 0, int(grads_wanted), _ptr(ws), have, _stream(dev))
-    _check(rc, "mr_shade_specular_backward")
+    _check(rc, "mr_shade_specular_backward_l1" if l1_signs is not None else "mr_shade_specular_backward")
     dlpos = lg[:, :3 * nl].reshape(B, nl, 3)
     dlint = lg[:, 3 * nl:6 * nl].reshape(B, nl, 3)
     damb = lg[:, 6 * nl:6 * nl + 3] if ambient is not None else None

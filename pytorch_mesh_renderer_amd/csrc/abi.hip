@@ -420,7 +420,47 @@ int mr_shade_specular_backward(const float *drgba, const int32_t *ids, const flo
     return MR_EINVAL;
   const int rc = check_ws(workspace, workspace_bytes, mr::shade_specular_backward_ws(B, V, T, W, H));
   if (rc != MR_OK) return rc;
-  return mr::launch_shade_specular_backward(drgba, ids, bary, clip, normals, positions, diffuse,
+  return mr::launch_shade_specular_backward(drgba, nullptr, nullptr, ids, bary, clip, normals, positions, diffuse,
+                                            specular, triangles, light_positions, light_intensities,
+                                            ambient, camera_position, shininess, shininess_per_vertex,
+                                            norms2, B, V, T, W, H, L, dclip, dnormals, dpositions,
+                                            ddiffuse, dspecular, dshininess, light_grads, vertex_offsets,
+                                            vertex_entries, transforms, gbuffer_flags, grads_wanted, workspace,
+                                            (hipStream_t)stream);
+}
+
+size_t mr_shade_specular_backward_l1_workspace_bytes(int B, int V, int T, int W, int H) {
+  if (bad_dims(B, V, T, W, H)) return 0;
+  return mr::shade_specular_backward_l1_ws(B, V, T, W, H);
+}
+
+int mr_shade_specular_backward_l1(const uint8_t *signs, const float *upstream, const int32_t *ids,
+                                  const float *bary,
+                               const float *clip, const float *normals, const float *positions,
+                               const float *diffuse, const float *specular,
+                               const int32_t *triangles, const float *light_positions,
+                               const float *light_intensities, const float *ambient,
+                               const float *camera_position, const float *shininess,
+                               int shininess_per_vertex, const float *norms2, int B, int V, int T,
+                               int W, int H, int L, float *dclip, float *dnormals, float *dpositions,
+                               float *ddiffuse, float *dspecular, float *dshininess,
+                               float *light_grads, const int32_t *vertex_offsets,
+                               const int32_t *vertex_entries, const float *transforms, int gbuffer_flags,
+                               int grads_wanted, void *workspace, size_t workspace_bytes, void *stream) {
+  if (bad_dims(B, V, T, W, H) || T < 1 || V < 1 || L < 1 || L > mr::shade_light_gradient_max_lights())
+    return MR_EINVAL;
+  if ((gbuffer_flags & ~MR_GBUFFER_NORMALISED) != 0 || (grads_wanted & ~MR_GRAD_ALL) != 0) return MR_EINVAL;
+  if ((vertex_offsets == nullptr) != (vertex_entries == nullptr)) return MR_EINVAL;
+  if (vertex_offsets && ((uintptr_t)dclip & 15u) != 0) return MR_EINVAL;
+  if (B == 0) return MR_OK;
+  if (!signs || !upstream || !ids || !bary || !clip || !normals || !positions || !diffuse || !specular ||
+      !triangles || !light_positions || !light_intensities || !camera_position || !shininess ||
+      !norms2 || !dclip || !dnormals || !dpositions || !ddiffuse || !dspecular || !light_grads ||
+      (shininess_per_vertex && !dshininess))
+    return MR_EINVAL;
+  const int rc = check_ws(workspace, workspace_bytes, mr::shade_specular_backward_l1_ws(B, V, T, W, H));
+  if (rc != MR_OK) return rc;
+  return mr::launch_shade_specular_backward(nullptr, signs, upstream, ids, bary, clip, normals, positions, diffuse,
                                             specular, triangles, light_positions, light_intensities,
                                             ambient, camera_position, shininess, shininess_per_vertex,
                                             norms2, B, V, T, W, H, L, dclip, dnormals, dpositions,

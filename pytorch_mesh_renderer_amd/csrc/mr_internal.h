@@ -191,7 +191,10 @@ int launch_shade_specular_forward(const int32_t *ids, const float *bary, const f
                                   float *rgba, float *norms2,
                                   void *ws, hipStream_t s);
 size_t shade_specular_backward_ws(int B, int V, int T, int W, int H);
-int launch_shade_specular_backward(const float *drgba, const int32_t *ids, const float *bary,
+size_t shade_specular_backward_l1_ws(int B, int V, int T, int W, int H);
+// signs / sign_upstream: the upstream gradient as mean|image - target|'s sign codes instead of drgba (drgba null)
+int launch_shade_specular_backward(const float *drgba, const uint8_t *signs, const float *sign_upstream,
+                                   const int32_t *ids, const float *bary,
                                    const float *clip, const float *normals, const float *positions,
                                    const float *diffuse, const float *specular, const int32_t *tris,
                                    const float *light_pos, const float *light_col, const float *ambient,

@@ -390,7 +390,10 @@ __global__ __launch_bounds__(kThreads) void k_spec_sum(const float *__restrict__
 }
 
 // ---- the final backward pass, inside k_accumulate_rows (run_accum.h) -----------------------
-template <int L, bool PV>
+// SIGNS (round 5, the coupled lane kernel only): the upstream gradient is the backward of mean|image - target|
+// (loss.hip) and arrives as that loss's packed sign codes, one byte per pixel instead of sixteen; the pass is linear
+// in the upstream gradient, so the sums are formed from the bare codes and the gather multiplies by the loss's scale.
+template <int L, bool PV, bool SIGNS = false>
 struct SpecGradFn {
   static constexpr int kA = attr_count(PV);
   static constexpr int kN = 3 * kA + 9;  // attribute partials [corner][attr] + 9 clip partials: 45 / 48
@@ -416,6 +419,7 @@ struct SpecGradFn {
   // [B][L*6 + 7]: dpos (L x 3), dcol (L x 3), dambient (3), dcamera (3), d per-image shininess (1)
   float *__restrict__ light_rows;   // [strips][kLightRow]: every strip's row of image-wide sums
   int T_, W, H;
+  const uint8_t *__restrict__ signs;  // SIGNS: [B,H,W] bytes, image rows like drgba
 
   struct Pixel {
     F3 b, g;
@@ -424,7 +428,8 @@ struct SpecGradFn {
   struct Raw {
     F3 b;
     int t;
-    float4 g;
+    float4 g;       // !SIGNS
+    unsigned code;  // SIGNS
   };
   struct Triangle {
     SpecCorners<kA> cr;
@@ -451,15 +456,25 @@ struct SpecGradFn {
   __device__ __forceinline__ void fetch(int img, int x, int y, size_t pix, Raw &r) const {
     r.b = MR_SPEC_NT ? load_streamed(&bary[pix]) : bary[pix];
     r.t = MR_SPEC_NT ? __builtin_nontemporal_load(&ids[pix]) : ids[pix];
-    const float4 *gp = &drgba[((size_t)img * H + (H - 1 - y)) * W + x];  // un-flip
-    r.g = MR_SPEC_NT ? load_streamed(gp) : *gp;
+    const size_t image_pix = ((size_t)img * H + (H - 1 - y)) * W + x;  // un-flip
+    if (SIGNS) {
+      r.code = MR_SPEC_NT ? __builtin_nontemporal_load(&signs[image_pix]) : signs[image_pix];
+    } else {
+      r.g = MR_SPEC_NT ? load_streamed(&drgba[image_pix]) : drgba[image_pix];
+    }
   }
   __device__ __forceinline__ bool prepare(const Raw &r, int T, int &tri, Pixel &p) const {
     const float pre = (2.0f * r.b.x + 2.0f * r.b.y) + 2.0f * r.b.z;
     if (!(pre > 0.0f)) return false;  // background: counted by the kernel, handled in end_image
     if ((unsigned)r.t >= (unsigned)T) return false;
     p.b = r.b;
-    p.g.x = r.g.x; p.g.y = r.g.y; p.g.z = r.g.z;  // d/d alpha is dropped: the mask is not differentiable
+    if (SIGNS) {  // 2-bit two's-complement codes 0, +1, -1 (loss.hip: sign_code)
+      p.g.x = (float)(int)__builtin_amdgcn_sbfe(r.code, 0u, 2u);
+      p.g.y = (float)(int)__builtin_amdgcn_sbfe(r.code, 2u, 2u);
+      p.g.z = (float)(int)__builtin_amdgcn_sbfe(r.code, 4u, 2u);
+    } else {
+      p.g.x = r.g.x; p.g.y = r.g.y; p.g.z = r.g.z;  // d/d alpha is dropped: the mask is not differentiable
+    }
     p.tri = r.t;
     tri = r.t;
     return true;
@@ -832,9 +847,9 @@ template <int A>
 struct SpecPulledTriangle {
   float e0[A], e1[A], c2[A], S[3], P0[3], P1[3];
 };
-template <int L, bool PV>
-struct SpecCoupledLaneFn : SpecGradFn<L, PV> {
-  using Base = SpecGradFn<L, PV>;
+template <int L, bool PV, bool SIGNS = false>
+struct SpecCoupledLaneFn : SpecGradFn<L, PV, SIGNS> {
+  using Base = SpecGradFn<L, PV, SIGNS>;
   static_assert(L == 1 || L == 2, "the second light's sums take the normal columns of the accumulator rows");
   static constexpr int kA = Base::kA;
   static constexpr int kN = 9 + 9 * L;
@@ -1016,7 +1031,7 @@ template <int A, int L>
 __global__ __launch_bounds__(kThreads) void k_spec_gather_coupled(
     const float *__restrict__ acc, const int32_t *__restrict__ offsets, const int32_t *__restrict__ entries,
     const float *__restrict__ gsum, const float *__restrict__ norms2, int B, int V, int T,
-    float *__restrict__ dpositions) {
+    float *__restrict__ dpositions, const float *__restrict__ scale_src, float scale_mul) {
   const long tid = (long)blockIdx.x * kThreads + threadIdx.x;
   const long gid = tid >> 2;   // (image, vertex)
   const int c = (int)(tid & 3);
@@ -1053,7 +1068,8 @@ __global__ __launch_bounds__(kThreads) void k_spec_gather_coupled(
   float out = s1;
 #pragma unroll
   for (int l = 0; l < L; ++l) out -= gc[l] * s2[l];
-  dpositions[gid * 3 + c] = out;
+  // (sign-coded upstream: S1 and G were formed from the bare codes, both linear in the loss's scale)
+  dpositions[gid * 3 + c] = scale_src ? out * (scale_src[0] * scale_mul) : out;
 }
 
 template <int A>
@@ -1224,7 +1240,7 @@ inline size_t spec_light_rows_bytes(int B, int W, int H) {
 }
 
 template <bool PV>
-int spec_backward(const float *drgba, const int32_t *ids, const float *bary, const float *clip,
+int spec_backward(const float *drgba, const uint8_t *signs, const float *sign_upstream, const int32_t *ids, const float *bary, const float *clip,
                   const float *normals, const float *positions, const float *diffuse, const float *specular,
                   const int32_t *tris, const float *light_pos, const float *light_col, const float *ambient,
                   const float *camera, const float *shininess, const float *norms2, int B, int V, int T, int W,
@@ -1241,6 +1257,15 @@ int spec_backward(const float *drgba, const int32_t *ids, const float *bary, con
   // one pass instead of G pass + pixel pass (SpecCoupledLaneFn): one or two lights, folded, per-vertex gather
   const bool coupled = MR_SPEC_COUPLED && fold && L <= 2 && vertex_offsets && vertex_entries;
   if (det && !(vertex_offsets && vertex_entries)) return MR_EINVAL;  // the scatter path is float atomics only
+  const size_t n_image = (size_t)B * H * W * 4;
+  const float sign_inv_n = 1.0f / (float)n_image;
+  if (signs && !coupled) {  // the other pixel kernels take the dense image: the loss's backward, into the workspace's tail
+    float *dense = (float *)((char *)ws + align_up(shade_specular_backward_ws(B, V, T, W, H), 256));
+    const int rc_l1 = launch_l1_backward(signs, n_image, sign_upstream, dense, s);
+    if (rc_l1 != MR_OK) return rc_l1;
+    drgba = dense;
+    signs = nullptr;
+  }
   char *p = (char *)ws;
   float *acc = (float *)p;
   p += spec_acc_bytes(B, T);
@@ -1277,21 +1302,26 @@ int spec_backward(const float *drgba, const int32_t *ids, const float *bary, con
   }
   SpecSceneIn scene{light_pos, light_col, ambient, camera, PV ? nullptr : shininess, norms2, nullptr};
   if (coupled) {
-#define MR_SPEC_BWD_COUPLED(NL)                                                                                      \
+#define MR_SPEC_BWD_COUPLED(NL, SG)                                                                                  \
     {                                                                                                                \
-      SpecCoupledLaneFn<NL, PV> fn{{(const float4 *)drgba, ids, (const F3 *)bary, nullptr, nullptr, scene, nullptr, T, W, H}, \
-                                   fold_recs, light_rows};                                                           \
+      SpecCoupledLaneFn<NL, PV, SG> fn{{(const float4 *)drgba, ids, (const F3 *)bary, nullptr, nullptr, scene, nullptr, T, W, H, \
+                                        signs}, fold_recs, light_rows};                                              \
       rc = launch_accumulate_lanes(fn, B, T, W, H, acc, s);                                                          \
       if (rc == MR_OK)                                                                                               \
-        rc = launch_sum_strip_rows(light_rows, B, lanes_strips_per_image<SpecCoupledLaneFn<NL, PV>>(B, W, H), NL, gsum, s); \
+        rc = launch_sum_strip_rows(light_rows, B, lanes_strips_per_image<SpecCoupledLaneFn<NL, PV, SG>>(B, W, H), NL, gsum, s); \
       if (rc == MR_OK) {                                                                                             \
         const long nbv4 = (long)B * V * 4;                                                                           \
         hipLaunchKernelGGL((k_spec_gather_coupled<A, NL>), dim3((unsigned)((nbv4 + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, \
-                           acc, vertex_offsets, vertex_entries, gsum, norms2, B, V, T, dpositions);                  \
+                           acc, vertex_offsets, vertex_entries, gsum, norms2, B, V, T, dpositions,                   \
+                           SG ? sign_upstream : nullptr, sign_inv_n);                                                \
         rc = check_launch();                                                                                         \
       }                                                                                                              \
     }
-    if (L == 1) MR_SPEC_BWD_COUPLED(1) else MR_SPEC_BWD_COUPLED(2)
+    if (signs) {
+      if (L == 1) MR_SPEC_BWD_COUPLED(1, true) else MR_SPEC_BWD_COUPLED(2, true)
+    } else {
+      if (L == 1) MR_SPEC_BWD_COUPLED(1, false) else MR_SPEC_BWD_COUPLED(2, false)
+    }
 #undef MR_SPEC_BWD_COUPLED
     return rc;
   }
@@ -1384,8 +1414,13 @@ size_t shade_specular_backward_ws(int B, int V, int T, int W, int H) {
          align_up((size_t)B * T * sizeof(SpecFoldRec<kAttrMax>), 256);
 }
 
-int launch_shade_specular_backward(const float *drgba, const int32_t *ids, const float *bary,
-                                   const float *clip, const float *normals, const float *positions,
+size_t shade_specular_backward_l1_ws(int B, int V, int T, int W, int H) {
+  // + the dense upstream image for the pixel kernels that do not read sign codes
+  return align_up(shade_specular_backward_ws(B, V, T, W, H), 256) + align_up((size_t)B * H * W * 4 * sizeof(float), 256);
+}
+
+int launch_shade_specular_backward(const float *drgba, const uint8_t *signs, const float *sign_upstream,
+                                   const int32_t *ids, const float *bary, const float *clip, const float *normals, const float *positions,
                                    const float *diffuse, const float *specular, const int32_t *tris,
                                    const float *light_pos, const float *light_col, const float *ambient,
                                    const float *camera, const float *shininess, int shininess_per_vertex,
@@ -1411,11 +1446,11 @@ int launch_shade_specular_backward(const float *drgba, const int32_t *ids, const
     return check_launch();
   if (T == 0 || V == 0 || (size_t)W * H == 0) return MR_OK;
   return shininess_per_vertex
-             ? spec_backward<true>(drgba, ids, bary, clip, normals, positions, diffuse, specular, tris, light_pos,
+             ? spec_backward<true>(drgba, signs, sign_upstream, ids, bary, clip, normals, positions, diffuse, specular, tris, light_pos,
                                    light_col, ambient, camera, shininess, norms2, B, V, T, W, H, L, dclip,
                                    dnormals, dpositions, ddiffuse, dspecular, dshininess, light_grads,
                                    vertex_offsets, vertex_entries, transforms, gbuffer_flags, grads_wanted, ws, s)
-             : spec_backward<false>(drgba, ids, bary, clip, normals, positions, diffuse, specular, tris, light_pos,
+             : spec_backward<false>(drgba, signs, sign_upstream, ids, bary, clip, normals, positions, diffuse, specular, tris, light_pos,
                                     light_col, ambient, camera, shininess, norms2, B, V, T, W, H, L, dclip,
                                     dnormals, dpositions, ddiffuse, dspecular, dshininess, light_grads,
                                     vertex_offsets, vertex_entries, transforms, gbuffer_flags, grads_wanted, ws, s);

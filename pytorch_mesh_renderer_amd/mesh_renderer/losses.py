@@ -46,7 +46,7 @@ def l1_loss(image, target):
 
     When `image` is the direct output of render()'s fused diffuse path, the backward skips the
     dense gradient image: the loss's sign codes go straight into the shading backward
-    (rasterize_triangles_ext.FusedPhongL1Loss).  Whether something observes d loss / d image -- image.retain_grad(),
+    (rasterize_triangles_ext.FusedPhongL1Loss; FusedSpecularL1Loss for the specular path, round 5).  Whether something observes d loss / d image -- image.retain_grad(),
     a hook on the image, torch.autograd.grad(loss, image) -- is decided when the BACKWARD runs (round 5; until then it
     was decided here, and a hook registered after this call never fired): the node then behaves like the generic op.
     One hole remains: torch.autograd.backward(loss, inputs=[image]) spelled through the module function (not
@@ -63,8 +63,11 @@ def l1_loss(image, target):
     if image.dtype != torch.float32 or target.dtype != torch.float32:
         raise ValueError("l1_loss expects float32 tensors")
     if USE_FUSED_RENDER_LOSS and torch.is_grad_enabled() and image.requires_grad:
-        from .rasterize_triangles_ext import FusedPhongL1Loss, take_fused_render
+        from .rasterize_triangles_ext import FusedPhongL1Loss, FusedSpecularL1Loss, take_fused_render
         record = take_fused_render(image)
+        if record is not None and record["kind"] == "specular":
+            return FusedSpecularL1Loss.apply(image, target, *record["inputs"], record["saved"],
+                                             record["has_ambient"], record["has_transforms"])
         if record is not None:
             return FusedPhongL1Loss.apply(image, target, *record["inputs"], record["saved"],
                                           record.get("prepared_state"), record.get("empty_regions"))

@@ -278,8 +278,10 @@ class FusedPhongRenderer(torch.autograd.Function):
 _fused_renders = weakref.WeakKeyDictionary()
 
 
-def remember_fused_render(node, inputs, image=None):
-    _fused_renders[node] = {"saved": tuple(node.saved_tensors), "inputs": inputs,
+def remember_fused_render(node, inputs, image=None, kind="diffuse"):
+    _fused_renders[node] = {"saved": tuple(node.saved_tensors), "inputs": inputs, "kind": kind,
+                            "has_ambient": getattr(node, "has_ambient", None),
+                            "has_transforms": getattr(node, "has_transforms", None),
                             "prepared_state": getattr(node, "prepared_state", None),
                             "empty_regions": getattr(node, "empty_regions", None),
                             # the empty-block map describes what the renderer WROTE: an in-place edit of the image
@@ -490,19 +492,23 @@ class FusedSpecularPhongRenderer(torch.autograd.Function):
             saved.append(transforms.detach().to(torch.float32).contiguous())
         ctx.save_for_backward(*saved)
         ctx.has_ambient = amb is not None
-        # (a RenderedImage: the reference's L1 spelling on it runs as losses.l1_loss's generic op -- one pass forward,
-        #  the dense gradient formed from sign codes -- instead of six torch passes over the image)
+        # FusedSpecularL1Loss on this image hands it NO gradient (see FusedPhongRenderer.forward)
+        ctx.set_materialize_grads(False)
+        # (a RenderedImage: the reference's L1 spelling on it arrives at losses.l1_loss by itself)
         from .rendered_image import wrap
         return wrap(rgba)
 
     @staticmethod
-    def backward(ctx, drgba):
-        saved = ctx.saved_tensors
+    def _input_grads(saved, has_ambient, has_transforms, need, upstream, l1_signs=None):
+        """The specular shading backward on the tensors forward() saved -> gradients in the order of forward()'s first
+        eleven arguments.  need: which of them require a gradient (same order).  l1_signs: `upstream` is then the
+        scalar d L / d loss of mean|image - target| and the image gradient is that loss's sign codes
+        (_native.shade_specular_backward)."""
         clip, ids, bary, normals, positions, diffuse, specular, triangles, lp, li, cam, shin, norms2 = saved[:13]
         offsets, entries = saved[13:15]
-        amb = saved[15] if ctx.has_ambient else None
-        transforms = saved[-1] if ctx.has_transforms else None
-        need = ctx.needs_input_grad   # clip, positions, normals, diffuse, specular, -, lpos, lint, ambient, camera, shininess
+        amb = saved[15] if has_ambient else None
+        transforms = saved[-1] if has_transforms else None
+        # need: clip, positions, normals, diffuse, specular, -, lpos, lint, ambient, camera, shininess
         wanted = ((_native.GRAD_CLIP if need[0] else 0) | (_native.GRAD_POSITIONS if need[1] else 0)
                   | (_native.GRAD_NORMALS if need[2] else 0) | (_native.GRAD_DIFFUSE if need[3] else 0)
                   | (_native.GRAD_SPECULAR if need[4] else 0) | (_native.GRAD_SHININESS if need[10] else 0)
@@ -515,16 +521,15 @@ class FusedSpecularPhongRenderer(torch.autograd.Function):
         if fold:
             wanted &= ~_native.GRAD_CLIP
         # per-vertex gather over the adjacency (round 3): no atomics, every output written once
-        drgba = drgba.contiguous()
         step = _native.shade_fast_lights()
         total = None
         for first in range(0, lp.shape[1], step):    # groups of four lights: see forward()
             part = _native.shade_specular_backward(
-                drgba, ids, bary, clip, normals, positions, diffuse, specular, triangles,
+                upstream, ids, bary, clip, normals, positions, diffuse, specular, triangles,
                 lp[:, first:first + step].contiguous(), li[:, first:first + step].contiguous(),
                 amb if first == 0 else None, cam, shin, norms2[:, first:first + step].contiguous(),
                 adjacency=(offsets, entries), transforms=transforms if fold else None, normalised_gbuffer=True,
-                grads_wanted=wanted)
+                grads_wanted=wanted, l1_signs=l1_signs)
             if total is None:
                 total = list(part)
                 continue
@@ -535,4 +540,49 @@ class FusedSpecularPhongRenderer(torch.autograd.Function):
         dclip, dn, dp, dd, dsp, dlp, dli, damb, dcam, dshin = total
         if fold:
             dclip = None
-        return dclip, dp, dn, dd, dsp, None, dlp, dli, damb, dcam, dshin, None, None, None
+        return dclip, dp, dn, dd, dsp, None, dlp, dli, damb, dcam, dshin
+
+    @staticmethod
+    def backward(ctx, drgba):
+        if drgba is None:   # (set_materialize_grads(False): FusedSpecularL1Loss differentiated straight to the inputs)
+            return (None,) * 14
+        grads = FusedSpecularPhongRenderer._input_grads(ctx.saved_tensors, ctx.has_ambient, ctx.has_transforms,
+                                                        ctx.needs_input_grad, drgba.contiguous())
+        return grads + (None, None, None)
+
+
+class FusedSpecularL1Loss(torch.autograd.Function):
+    """FusedPhongL1Loss for an `image` that FusedSpecularPhongRenderer produced (round 5): mean|image - target|
+    differentiated straight to the specular renderer's inputs, the backward handing the loss's sign codes to
+    mr_shade_specular_backward_l1.  The one-pass vertex-gradient kernel -- the reference's optimisation loop
+    (mesh_renderer_test.py:238-262) with a specular term, one or two lights -- reads the codes directly, 1 B/px
+    instead of a 16 B/px gradient image written and read back; the other cases form the dense image inside the call.
+    An observed d loss / d image is honoured exactly as in FusedPhongL1Loss."""
+
+    @staticmethod
+    def forward(ctx, image, target, clip, positions, normals, diffuse, specular, light_positions,
+                light_intensities, ambient, camera_position, shininess, render_saved, has_ambient, has_transforms):
+        loss, signs = _native.l1_loss_forward(image.detach(), target.detach(), want_signs=True)
+        ctx.image_shape = image.shape
+        ctx.image_ref = weakref.ref(image)
+        ctx.has_ambient, ctx.has_transforms = has_ambient, has_transforms
+        ctx.save_for_backward(signs, *render_saved)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad):
+        signs = ctx.saved_tensors[0]
+        upstream = grad.to(torch.float32).reshape(1)
+        n = ctx.needs_input_grad
+        dtarget = None
+        if n[0] and FusedPhongL1Loss._image_gradient_observed(ctx):
+            dimage = _native.l1_loss_backward(signs, ctx.image_shape, upstream)
+            if n[1]:
+                dtarget = -dimage
+            return (dimage, dtarget) + (None,) * 13
+        need = (n[2], n[3], n[4], n[5], n[6], False, n[7], n[8], n[9], n[10], n[11])
+        dclip, dp, dn, dd, dsp, _, dlp, dli, damb, dcam, dshin = FusedSpecularPhongRenderer._input_grads(
+            ctx.saved_tensors[1:], ctx.has_ambient, ctx.has_transforms, need, upstream, l1_signs=signs)
+        if n[1]:
+            dtarget = -_native.l1_loss_backward(signs, ctx.image_shape, upstream)
+        return (None, dtarget, dclip, dp, dn, dd, dsp, dlp, dli, damb, dcam, dshin, None, None, None)

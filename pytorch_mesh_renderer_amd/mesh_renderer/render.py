@@ -188,13 +188,19 @@ def _render_fused(vertices, triangles, normals, diffuse_colors, camera_position,
         image_width / image_height, device)
     if specular_colors is not None:
         clip = camera_utils.transform_homogeneous(clip_space_transforms, vertices)
-        return FusedSpecularPhongRenderer.apply(
-            clip, vertices, normals, diffuse_colors, specular_colors.to(torch.float32), triangles,
-            light_positions.to(device), light_intensities.to(device).to(torch.float32),
-            ambient_color.to(device) if ambient_color is not None else None,
-            camera_position.to(device=device, dtype=torch.float32), shininess,
-            image_width, image_height,
+        inputs = (clip, vertices, normals, diffuse_colors, specular_colors.to(torch.float32),
+                  light_positions.to(device), light_intensities.to(device).to(torch.float32),
+                  ambient_color.to(device) if ambient_color is not None else None,
+                  camera_position.to(device=device, dtype=torch.float32), shininess)
+        image = FusedSpecularPhongRenderer.apply(
+            *inputs[:5], triangles, *inputs[5:], image_width, image_height,
             clip_space_transforms if not clip_space_transforms.requires_grad else None)
+        if image.grad_fn is None and type(image) is not torch.Tensor:
+            image = image.as_subclass(torch.Tensor)
+        if image.grad_fn is not None:   # (see the diffuse branch below: losses.l1_loss -> FusedSpecularL1Loss)
+            from .rasterize_triangles_ext import remember_fused_render
+            remember_fused_render(image.grad_fn, inputs, image, kind="specular")
+        return image
     lp, li = light_positions.to(device), light_intensities.to(device).to(torch.float32)
     amb = ambient_color.to(device) if ambient_color is not None else None
     transforms = clip_space_transforms.to(torch.float32)

@@ -187,6 +187,25 @@ def specular_case(report, what, pos, xf, tris, nrm, kd, ks, lp, li, amb, cam, sh
     report.check(k_rows, "d diffuse", rows[3], t["d_diffuse"], t["noise_diffuse"], what)
     report.check(k_rows, "d specular", rows[4], t["d_specular"], t["noise_specular"], what)
     report.check(k_folded, "d vertices", folded[2], t["d_vertices"], t["noise_vertices"], what)
+    # the same folded pass fed mean|image - target|'s sign codes (mr_shade_specular_backward_l1; the coupled kernel reads
+    # them directly and scales at the gather, the others get the dense image formed inside the call) against the
+    # pass on the dense gradient image of the same codes
+    target = torch.rand_like(rgba)
+    _, signs = _native.l1_loss_forward(rgba, target, want_signs=True)
+    upstream = torch.full((1,), 0.37 * rgba.numel() / (H * W), device=rgba.device)
+    dense = _native.l1_loss_backward(signs, rgba.shape, upstream)
+    kw = dict(adjacency=adjacency, normalised_gbuffer=True, transforms=xf_d, grads_wanted=_native.GRAD_POSITIONS)
+    from_dense = _native.shade_specular_backward(dense, *sargs[1:], **kw)[2]
+    from_signs = _native.shade_specular_backward(upstream, *sargs[1:], l1_signs=signs, **kw)[2]
+    k_signs = _native.debug_last_accumulate_kernel()
+    if lp.shape[1] <= 2:
+        assert k_signs.startswith("SpecCoupledLaneFn") and k_signs.endswith(", true>") and k_signs.count(",") == 2, k_signs
+    else:   # (the dense image formed inside the call; the lane kernels' float atomics still reorder the sums per run)
+        assert k_signs.startswith("SpecFoldLaneFn"), k_signs
+    scale = float(from_dense.abs().max())
+    worst = float((from_signs - from_dense).abs().max())
+    if not worst <= 2e-5 * scale + 1e-12:
+        report.failures.append("%s: sign-coded folded pass differs from the dense one by %.3g (scale %.3g)" % (what, worst, scale))
 
 
 def attr_trial(rng, trial, report, small=False):

@@ -44,6 +44,12 @@ def _render(g, device, wanted, spelling):
     weight = float(g["loss_weight"]) if "loss_weight" in g.files else 1.0
     if spelling == "mean_abs":     # the reference's own spelling, mesh_renderer_test.py:250
         loss = torch.mean(torch.abs(img - dev("target")))
+    elif spelling == "generic_op":   # the loss as an op of its own: the renderer's node gets the dense gradient image
+        mesh_renderer.losses.USE_FUSED_RENDER_LOSS = False
+        try:
+            loss = mesh_renderer.losses.l1_loss(img, dev("target"))
+        finally:
+            mesh_renderer.losses.USE_FUSED_RENDER_LOSS = True
     else:
         loss = mesh_renderer.losses.l1_loss(img, dev("target"))
     (loss * weight).backward()
@@ -59,6 +65,8 @@ def _compare(g, grads, what):
         ok = np.isfinite(want)   # per-vertex shininess + background: some of the reference's own entries are NaN
         got = got.cpu().numpy()
         assert np.isfinite(got).all(), (what, k)
+        if not ok.any():   # (the reference's whole gradient is NaN there: only finiteness to check)
+            continue
         np.testing.assert_allclose(got[ok], want[ok], atol=ATOL, rtol=0, err_msg="%s: d %s" % (what, k))
         # 1e-4 abs is loose against gradients of 1e-3: also within 2e-3 of the gradient's largest element
         assert np.abs(got[ok] - want[ok]).max() <= 2e-3 * np.abs(want[ok]).max() + 1e-7, (what, k)
@@ -90,7 +98,7 @@ def test_diffuse_goldens_with_light_gradients_through_the_lane_kernel(device, na
     _compare(g, grads, "%s %s %s (%s)" % (name, wanted, spelling, ran))
 
 
-@pytest.mark.parametrize("spelling", ["mean_abs", "l1_loss"])
+@pytest.mark.parametrize("spelling", ["mean_abs", "l1_loss", "generic_op"])
 @pytest.mark.parametrize("name", SPECULAR)
 def test_specular_goldens_through_the_vertex_only_lane_kernel(device, name, spelling):
     """render() with a specular term differentiated to the vertices alone: SpecFoldLaneFn with the clip-space
@@ -102,9 +110,26 @@ def test_specular_goldens_through_the_vertex_only_lane_kernel(device, name, spel
     n_lights = g["light_positions"].shape[1]
     if n_lights <= 2:      # round 5: one pass, no separate G pass (SpecCoupledLaneFn<L, PV>)
         assert ran.startswith("SpecCoupledLaneFn<%d" % n_lights), ran
+        # <L, PV, SIGNS>: the loss's sign codes go straight into the pixel pass unless the loss is an op of its own
+        # (the compiler's name leaves a defaulted SIGNS = false out: "<2, true>" is <L = 2, PV = true>)
+        assert (ran.count(",") == 2 and ran.endswith(", true>")) == (spelling != "generic_op"), ran
     elif n_lights <= _native.shade_fast_lights():
         assert ran.startswith("SpecFoldLaneFn") and ran.rstrip(">").endswith("true"), ran   # <L, PV, FOLD = true>
     _compare(g, grads, "%s vertices %s (%s)" % (name, spelling, ran))
+
+
+@pytest.mark.parametrize("name", SPECULAR)
+def test_specular_goldens_with_every_gradient_through_the_l1_entry(device, name):
+    """mr_shade_specular_backward_l1 outside its one-pass case (every leaf wants a gradient: SpecGradFn, the dense image
+    formed inside the call) equals the reference's stored gradients, and the generic op's bit for bit."""
+    g = golden_npz(name)
+    wanted = ("vertices", "normals", "diffuse", "light_positions", "light_intensities")
+    _, grads, ran = _render(g, device, wanted, "mean_abs")
+    assert ran.startswith("SpecGradFn"), ran
+    _compare(g, grads, "%s all gradients, l1 entry" % name)
+    _, generic, _ = _render(g, device, wanted, "generic_op")
+    for k in grads:
+        assert torch.equal(grads[k], generic[k]), k
 
 
 def test_specular_lane_kernel_with_its_own_clip_gradient_matches_reference_golden(device):
