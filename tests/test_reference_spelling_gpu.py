@@ -21,9 +21,12 @@ pytestmark = pytest.mark.gpu
 
 
 class _Scene:
-    def __init__(self, device, B=2, W=96, H=72):
+    def __init__(self, device, B=2, W=96, H=72, specular=False):
         self.job = synthetic.sphere_job(B, W, H, 10)
         self.dev, self.W, self.H = device, W, H
+        # (round 5: the specular renderer's image takes the same route, FusedSpecularL1Loss)
+        self.extra = dict(specular_colors=torch.full_like(self.job["diffuse"], 0.4).to(device),
+                          shininess_coefficients=7.0) if specular else {}
         self.target = torch.rand(B, H, W, 4, generator=torch.Generator().manual_seed(3)).to(device)
 
     def render(self, vertices=None, **leaves):
@@ -31,7 +34,8 @@ class _Scene:
         v = vertices if vertices is not None else j["vertices"].clone().to(d).requires_grad_(True)
         img = mesh_renderer.render(v, j["triangles"].to(d), leaves.get("normals", j["normals"].to(d)), j["diffuse"].to(d),
                                    j["eyes"], torch.zeros(j["eyes"].shape[0], 3), torch.tensor([0.0, 1.0, 0.0]),
-                                   j["light_positions"].to(d), j["light_intensities"].to(d), self.W, self.H)
+                                   j["light_positions"].to(d), j["light_intensities"].to(d), self.W, self.H,
+                                   **self.extra)
         return v, img
 
 
@@ -60,9 +64,10 @@ SPELLINGS = {
 }
 
 
+@pytest.mark.parametrize("specular", [False, True])
 @pytest.mark.parametrize("name", sorted(SPELLINGS))
-def test_the_references_spelling_runs_the_fused_loss(device, name):
-    scene = _Scene(device)
+def test_the_references_spelling_runs_the_fused_loss(device, name, specular):
+    scene = _Scene(device, specular=specular)
     want_loss, want_grad = _reference_gradient(scene, SPELLINGS[name])
     v, img = scene.render()
     assert isinstance(img, RenderedImage) and isinstance(img, torch.Tensor)
@@ -82,7 +87,8 @@ def test_the_references_spelling_runs_the_fused_loss(device, name):
         _native.l1_loss_backward = before["l1_loss_backward"]
     assert calls["dense"] == 0, "the dense gradient image was formed: not the fused route"
     ran = _native.debug_last_accumulate_kernel()
-    assert ran.startswith("ShadeFoldLaneFn<1, true>"), ran     # sign-coded upstream, vertices only
+    # sign-coded upstream, vertices only (specular: <L = 1, PV = false, SIGNS = true>)
+    assert ran.startswith("SpecCoupledLaneFn<1, false, true>" if specular else "ShadeFoldLaneFn<1, true>"), ran
     assert abs(float(loss) - want_loss) <= 2e-6 * want_loss
     np.testing.assert_allclose(v.grad.cpu().numpy(), want_grad.cpu().numpy(), rtol=2e-4, atol=1e-9)
 
@@ -155,10 +161,11 @@ def test_pending_results_answer_like_tensors(device):
     assert type(back) is torch.Tensor and torch.equal(back.to(device), img.detach())
 
 
-def test_the_images_gradient_can_be_observed_at_any_time(device):
+@pytest.mark.parametrize("specular", [False, True])
+def test_the_images_gradient_can_be_observed_at_any_time(device, specular):
     """d loss / d image through the recognised spelling: a hook registered AFTER the loss was built, retain_grad,
     torch.autograd.grad naming the image (alone, and together with the vertices), loss.backward(inputs=[image])."""
-    scene = _Scene(device)
+    scene = _Scene(device, specular=specular)
     spelled = SPELLINGS["reference"]
     want_loss, want_grad = _reference_gradient(scene, spelled)
     # a late hook
