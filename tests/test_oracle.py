@@ -296,6 +296,19 @@ def test_oracle_matches_reference_on_clipping_scenes(name, w, h):
     assert bits_equal(d, g["dclip"])
 
 
+@pytest.mark.parametrize("name", ["Barycentrics_Cube.png", "Simple_Tetrahedron.png"])
+def test_oracle_reproduces_the_references_unused_barycentric_fixtures(name):
+    """test_data/Barycentrics_Cube.png and Simple_Tetrahedron.png (held by the reference, loaded by none of its tests)
+    under the reference's own comparison (test_utils.py:105-160: at most 0.1 % of the pixels off by more than 0.01)."""
+    from conftest import barycentric_png_scenes, png_outlier_fraction
+    clip, tris = barycentric_png_scenes()[name]
+    ids, bary, z = oracle.forward(clip, tris, 640, 480)
+    assert png_outlier_fraction(name, bary) <= 0.001
+    if oracle.have_reference_kernel():
+        ref = oracle.reference_forward(clip, tris, 640, 480)
+        assert bits_equal(ids, ref[0]) and bits_equal(bary, ref[1]) and bits_equal(z, ref[2])
+
+
 def test_python_kernel_capture_documents_the_z_convention():
     """SURVEY row A11 (documentation, not a parity target): the reference's DEFAULT kernel,
     rasterize_triangles_python.py:33-133, draws the same pixels as the C++ kernel this package

@@ -484,6 +484,17 @@ def test_external_triangle_matches_reference_png_and_golden(device):
     assert outliers.mean() <= 0.001
 
 
+@pytest.mark.parametrize("name", ["Barycentrics_Cube.png", "Simple_Tetrahedron.png"])
+def test_unused_barycentric_fixtures_of_the_reference(device, name):
+    """Two more of the reference's own (unused) fixtures: barycentrics as RGB, 640 x 480, under its own comparison;
+    bit for bit the oracle's G-buffer."""
+    from conftest import barycentric_png_scenes, png_outlier_fraction
+    clip, tris = barycentric_png_scenes()[name]
+    got = hip_forward(clip, tris, 640, 480, device)
+    assert png_outlier_fraction(name, got[1]) <= 0.001
+    assert_forward_bitwise(got, oracle.forward(clip, tris, 640, 480))
+
+
 def test_camera_inside_cube_golden(device):
     """The eye inside a cube: side faces with vertices behind the eye cover the whole frame."""
     g = golden_npz("clip_camera_inside_cube.npz")
