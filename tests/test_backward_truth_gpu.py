@@ -121,15 +121,16 @@ def test_specular_goldens_through_the_vertex_only_lane_kernel(device, name, spel
 @pytest.mark.parametrize("name", SPECULAR)
 def test_specular_goldens_with_every_gradient_through_the_l1_entry(device, name):
     """mr_shade_specular_backward_l1 outside its one-pass case (every leaf wants a gradient: SpecGradFn, the dense image
-    formed inside the call) equals the reference's stored gradients, and the generic op's bit for bit."""
+    formed inside the call) equals the reference's stored gradients, and the generic op's to 1e-5 of their scale."""
     g = golden_npz(name)
     wanted = ("vertices", "normals", "diffuse", "light_positions", "light_intensities")
     _, grads, ran = _render(g, device, wanted, "mean_abs")
     assert ran.startswith("SpecGradFn"), ran
     _compare(g, grads, "%s all gradients, l1 entry" % name)
     _, generic, _ = _render(g, device, wanted, "generic_op")
-    for k in grads:
-        assert torch.equal(grads[k], generic[k]), k
+    for k in grads:   # (the same kernels on the same dense image; their float atomics reorder the sums from run to run)
+        scale = float(generic[k].abs().max())
+        assert float((grads[k] - generic[k]).abs().max()) <= 1e-5 * scale + 1e-12, k
 
 
 def test_specular_lane_kernel_with_its_own_clip_gradient_matches_reference_golden(device):
