@@ -249,7 +249,10 @@ def cpu_baseline(batch, width, height, sphere_k, sample_images):
     }
 
 
-def _loop_ms(fn, n, lead=4):
+def _loop_ms(fn, n, lead=24):
+    # (the lead-in covers a fresh step's one-time work -- adjacency, the target's block map, the allocator growing -- and
+    #  the clock ramp after the idle gap in front of it: with 4 steps the same leg read 0.65 ms on one box and 0.93 on
+    #  another, profiles/r05_b_bench.json)
     for _ in range(lead):
         fn()
     torch.cuda.synchronize()

@@ -45,7 +45,7 @@ json.dump(lines, open(os.path.join(prof, tag + suffix + "_bench.json"), "w"), in
 # 3. HBM traffic of the kernels of interest, per launch
 # k_raster<R, PROBE, SHADE>: "true>" = with the shading epilogue (the step's forward), "false>" = the
 # G-buffer kernel alone (bench.py runs 22 such steps after its timed region)
-wanted = {"k_raster_shade": "k_raster<64, 0, true,", "k_raster": ("k_raster<64, 0, false, 0>", "k_raster<64, 0, false, 0, 0>"),
+wanted = {"k_raster_shade": "k_raster<64, 0, true,", "k_raster": "k_raster<64, 0, false, 0",   # (SHADE = false, INTERP = 0; whatever template parameters follow)
           "k_shade_forward": "k_shade_forward(", "ShadeGradFn": ("ShadeFoldLaneFn", "ShadeLaneFn", "ShadeGradFn"),
           "k_l1_forward": ("k_l1_forward(", "k_l1_forward_regions("), "k_l1_backward": "k_l1_backward("}
 raw = {k: {} for k in wanted}
