@@ -17,10 +17,12 @@ world-space vertex positions.  All inputs are resident in HBM before the timed r
                          (batch 64 over 8 GPUs)
 
 With N ranks every rank renders its own batch (weak scaling; no data-path collective) and the
-finished images are handed over to rank 0 with one RCCL gather per step that overlaps the loss, the
-backward and the next forward: as 8-bit frames (--handover u8, default: mesh_renderer.to_uint8,
-the conversion the reference's examples apply before writing a frame) or as the fp32 images
-(--handover f32, 4x the bytes).
+finished images of EVERY step are handed over over RCCL, overlapping the loss, the backward and the
+next forwards: as 8-bit frames (--handover u8, default: mesh_renderer.to_uint8, the conversion the
+reference's examples apply before writing a frame) or as the fp32 images (--handover f32, 4x the bytes).
+--gather rotate (default, round 5): the global batch of step s is assembled on rank s mod N -- one balanced
+all_to_all_single per block of N steps, every xGMI link in use (distributed.RotatingImageGather);
+--gather root: on rank 0 every step (one gather per step; bound by rank 0's N - 1 inbound links).
 
 Extra objects in the line:
   roofline                 the step's forward kernel (k_raster with the shading epilogue: ids +
@@ -166,9 +168,10 @@ def make_step(job, device, gather, handover="u8", spelling="l1_loss", all_gradie
         image = forward()
         state["image"] = image
         if gather is not None and state["handover"]:
-            # two hand-overs may be in flight (ImageGather depth 2): the one of the step BEFORE the previous one
-            # is waited for, then this step's starts; conversion (u8) and transfer run on the side stream and
-            # have two whole steps to finish in -- a link-bound hand-over then costs bandwidth, not latency on top
+            # two hand-overs may be in flight (depth 2): the oldest one is waited for, then this step's starts (ImageGather:
+            # a gather per step; RotatingImageGather: this step's frames are staged and every N-th step exchanges the
+            # block); conversion (u8) and transfer run on the side stream and have whole steps to finish in -- a
+            # link-bound hand-over then costs bandwidth, not latency on top
             if gather.in_flight() >= gather.depth:
                 gather.wait()
             gather.start(image, transform=mesh_renderer.to_uint8 if state["handover_dtype"] == "u8" else None)
@@ -385,6 +388,10 @@ def main():
                          "the reference examples' frame conversion, written by the forward's epilogue) or the fp32 images "
                          "render() returns; the OTHER one is timed after the region and reported next to it "
                          "(ms_per_step_handover_f32 / value_handover_f32)")
+    ap.add_argument("--gather", choices=("rotate", "root"), default="rotate",
+                    help="N > 1: where a step's frames are assembled -- rotate (default): the global batch of step s on rank "
+                         "s mod N, one all_to_all_single per N steps, every xGMI link used (distributed.RotatingImageGather); "
+                         "root: every step's frames on rank 0, one gather per step, bound by rank 0's N - 1 inbound links")
     ap.add_argument("--extras", type=int, default=1,
                     help="0: skip the legs that run after the timed region (other spellings, gradient sets, configurations)")
     ap.add_argument("--cpu-sample", type=int, default=12, help="images timed for cpu_baseline (0 = skip)")
@@ -425,7 +432,13 @@ def main():
         torch.distributed.init_process_group(backend=backend, rank=0, world_size=1,
                                              **({"device_id": device} if backend == "nccl" else {}))
     grouped = world > 1 or forced
-    gather = distributed.ImageGather(batch * world, mode="root", force_collective=forced, depth=2) if grouped else None
+    # N > 1 (round 5): the root ROTATES -- step s's global batch is assembled on rank s mod N, one balanced
+    # all_to_all_single per block of N steps -- unless --gather root asks for rank 0 every step
+    rotating = grouped and args.gather == "rotate"
+    if rotating:
+        gather = distributed.RotatingImageGather(batch * world, depth=2, force_collective=forced)
+    else:
+        gather = distributed.ImageGather(batch * world, mode="root", force_collective=forced, depth=2) if grouped else None
     step, vertices, step_state = make_step(job, device, gather, args.handover)
     from pytorch_mesh_renderer_amd.mesh_renderer import rasterize_triangles_ext as ext
 
@@ -569,11 +582,13 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %dk-tri UV sphere (V=%d, T=%d), %dx%d, batch=%d per GPU, "
                                    "mesh_renderer.render forward + L1 loss + backward to vertex positions; "
-                                   "%s frames gathered to rank 0 over RCCL when n_gpus>1" % (
+                                   "%s frames of every step handed over over RCCL when n_gpus>1 (%s)" % (
                                        entry, round(T / 1000), V, T, width, height, batch,
-                                       "8-bit" if args.handover == "u8" else "fp32"),
+                                       "8-bit" if args.handover == "u8" else "fp32",
+                                       "step s's global batch assembled on rank s mod N" if args.gather == "rotate"
+                                       else "gathered to rank 0"),
                        "global_batch": batch * world, "image": [height, width], "triangles": T,
-                       "handover": args.handover},
+                       "handover": args.handover, "gather": args.gather},
             # the step's forward kernel: ids + barycentrics (16 B/px; render() does not ask for the
             # depth plane) + RGBA (16 B/px) written, clip-space vertices, triangle list and the
             # per-triangle attribute records (128 B) read
@@ -616,11 +631,20 @@ def main():
             line["ms_per_step_render_only"] = round(render_only_ms, 4)
             line["ms_per_step_with_handover"] = line["ms_per_step"]
             # the same two figures as the line's own units, so that a scaling curve can be read off either one:
-            # `value` contains the hand-over of every step's frames to rank 0, value_render_only does not
+            # `value` contains the hand-over of every step's frames, value_render_only does not
             line["value_render_only"] = round(world * px / render_only_ms / 1e3, 2)
-            # what arrives at the root per second while the timed loop runs (N - 1 shards per step)
-            line["handover_GBps_into_root"] = round(
-                (world - 1) * line["rccl"]["handover_bytes_per_rank_per_step"] / (elapsed / args.steps) / 1e9, 2)
+            if rotating:
+                line["rccl"]["gather"] = ("rotating root: the frames of step s (global batch) land on rank s mod N; one "
+                                          "all_to_all_single per block of N steps on a side stream, depth 2")
+                # what every rank sends (and receives) per second while the timed loop runs: (N - 1) / N of a shard per step,
+                # spread over its N - 1 links
+                line["handover_GBps_out_of_each_rank"] = round(
+                    (world - 1) / world * line["rccl"]["handover_bytes_per_rank_per_step"] / (elapsed / args.steps) / 1e9, 2)
+            else:
+                line["rccl"]["gather"] = "every step's frames to rank 0 (one gather per step, side stream, depth 2)"
+                # what arrives at the root per second while the timed loop runs (N - 1 shards per step)
+                line["handover_GBps_into_root"] = round(
+                    (world - 1) * line["rccl"]["handover_bytes_per_rank_per_step"] / (elapsed / args.steps) / 1e9, 2)
             line["handover_depth"] = gather.depth
             # the other image type through the same loop, after the timed region (f32 is what render() returns and what
             # SURVEY.md row E sizes; u8 is the reference examples' frame conversion, written by the forward's epilogue)

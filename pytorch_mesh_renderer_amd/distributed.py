@@ -4,8 +4,9 @@ The reference is single-process and loops over the batch serially
 (src/mesh_renderer/rasterize.py:112-121); every image is an independent (camera,
 mesh) job, so the batch shards across ranks with NO data-path collective.  The only
 exchange is the hand-over of the finished images: one all-gather (or gather to a
-root) of [B_local, H, W, 4] float32 over RCCL / xGMI, which is independent of the
-backward pass and therefore issued on a side stream so that it overlaps it.  When
+root; round 5: to a ROTATING root, RotatingImageGather -- bench.py's default at N > 1) of
+[B_local, H, W, 4] images over RCCL / xGMI, which is independent of the backward pass and
+therefore issued on a side stream so that it overlaps it.  When
 all ranks optimise one shared mesh, its [V,3] gradient is summed with a (latency
 bound, 30 KB - 300 KB) all-reduce.
 
@@ -193,6 +194,151 @@ class ImageGather:
         while self._pending:
             out.append(self.wait())
         return out
+
+
+class RotatingImageGather:
+    """Hand-over with a ROTATING root (round 5): the frames of step s -- the whole global batch of that step -- are
+    assembled on rank s mod N (the rank that encodes / writes that step's frames), not all on rank 0.
+
+    Why: xGMI is point-to-point.  Gathering every step's frames on ONE rank uses that rank's N - 1 inbound links and
+    nothing else: at N = 8 with 134 MB of 8-bit frames per rank and step that is >= 1.75 ms per step at ~77 GB/s per
+    link and direction, against a 0.65 ms render step -- the node would run at a third of N x one GPU (DESIGN.md section
+    6).  With the root rotating, every link carries one shard per N steps.  And instead of N concurrent gathers on N
+    communicators, the exchange is ONE balanced collective per block of N steps on the default communicator: every
+    rank keeps its last N steps' frames in a staging buffer [N, B_local, H, W, C] -- slot j = the frames of the block's
+    step j -- and one all_to_all_single sends slot j to rank j: afterwards rank j holds [N, B_local, ...] = the global
+    batch of step (block * N + j).  Per step and link that is 1/N of a shard (17 MB of 8-bit frames at N = 8: 0.22 ms),
+    all N (N - 1) links busy at once, one collective per N steps, on a side stream under the next block's compute.
+
+    start(local, transform)  stages this step's frames (on the side stream) and, when the block is full, issues the
+                             exchange; at most `depth` exchanges may be in flight (wait() first, as with ImageGather).
+    wait()                   the OLDEST exchange in flight -> (step, images [B_total, H, W, C]) for the step this rank
+                             roots in that block, or None if the block ended before that step (a drained tail).
+                             The tensor is one of depth + 1 receive buffers used in turn.
+    drain()                  flushes a partly filled block, then wait()s for everything; results oldest first.
+    in_flight()              exchanges in flight.
+    Latency: a step's frames reach their root up to N steps later than with a per-step gather."""
+
+    def __init__(self, n_total, group=None, depth=2, force_collective=False):
+        """force_collective: run the collective even in a 1-rank group (smoke tests of the RCCL / side-stream path on a
+        single GPU)."""
+        if depth < 1:
+            raise ValueError("depth must be at least 1")
+        self.group, self.depth = group, int(depth)
+        self.force = bool(force_collective) and dist.is_initialized()
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.n_total = n_total
+        self.counts = [shard_bounds(n_total, r, self.world)[1] - shard_bounds(n_total, r, self.world)[0]
+                       for r in range(self.world)]
+        self.max_count = max(self.counts)
+        self._pending = collections.deque()   # (event or None, receive buffer, first step of the block, steps in it)
+        self._stage, self._recv = {}, {}      # per (shape, dtype, device): depth + 1 buffers each, used in turn
+        self._block, self._filled, self._key = 0, 0, None
+        self._side = None
+
+    def _buffers(self, table, key):
+        ring = table.get(key)
+        if ring is None:
+            shape, dtype, device = key
+            # (zeros: the padding rows of an uneven shard are sent along)
+            ring = table[key] = [torch.zeros((self.world, self.max_count) + shape, dtype=dtype, device=device)
+                                 for _ in range(self.depth + 1)]
+        return ring[self._block % (self.depth + 1)]
+
+    def in_flight(self):
+        return len(self._pending)
+
+    def start(self, local, transform=None):
+        if local.shape[0] != self.counts[self.rank]:
+            raise ValueError("rank %d holds %d images, expected %d" % (self.rank, local.shape[0], self.counts[self.rank]))
+        closes_block = self._filled + 1 == self.world
+        if closes_block and len(self._pending) >= self.depth:
+            raise RuntimeError("%d exchange(s) already in flight (depth %d): call wait() first"
+                               % (len(self._pending), self.depth))
+        on_gpu = local.is_cuda
+        if on_gpu:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=local.device)
+            self._side.wait_stream(torch.cuda.current_stream(local.device))
+        with (torch.cuda.stream(self._side) if on_gpu else _NullContext()):
+            if transform is not None:
+                if on_gpu:
+                    local.record_stream(self._side)
+                send = transform(local).detach()
+            else:
+                send = local.detach()
+                if on_gpu:
+                    send.record_stream(self._side)
+            key = (tuple(send.shape[1:]), send.dtype, send.device)
+            if self._filled and key != self._key:
+                raise ValueError("the frames of one block must have one shape and dtype")
+            self._key = key
+            self._buffers(self._stage, key)[self._filled, :send.shape[0]].copy_(send)
+            self._filled += 1
+            if closes_block:
+                self._exchange()
+
+    def _exchange(self):
+        """(on the side stream) slot j of the staging buffer -> rank j; this rank receives its step's shard from everyone."""
+        key = self._key
+        inp, out = self._buffers(self._stage, key), self._buffers(self._recv, key)
+        if self.world == 1 and not self.force:
+            out.copy_(inp)
+        elif dist.get_backend(self.group) == "gloo":
+            # (the CPU tests' backend has no all_to_all: the same exchange as non-blocking sends and receives)
+            # (device tensors -- a rehearsal of N ranks on fewer GPUs, MR_DIST_BACKEND=gloo -- travel through the host)
+            src, dst = (inp.cpu(), torch.empty(out.shape, dtype=out.dtype)) if inp.is_cuda else (inp, out)
+            dst[self.rank].copy_(src[self.rank])
+            requests = []
+            for r in range(self.world):
+                if r != self.rank:
+                    requests.append(dist.isend(src[r], r, group=self.group, tag=self._block))
+                    requests.append(dist.irecv(dst[r], r, group=self.group, tag=self._block))
+            for q in requests:
+                q.wait()
+            if dst is not out:
+                out.copy_(dst)
+        else:
+            dist.all_to_all_single(out, inp, group=self.group)
+        done = None
+        if inp.is_cuda:
+            done = torch.cuda.Event()
+            done.record(self._side)
+        self._pending.append((done, out, self._block * self.world, self._filled))
+        self._block += 1
+        self._filled = 0
+
+    def wait(self):
+        if not self._pending:
+            return None
+        done, out, first, n_steps = self._pending.popleft()
+        if done is not None:
+            torch.cuda.current_stream().wait_event(done)
+        if self.rank >= n_steps:       # (a drained tail: the block ended before this rank's step)
+            return None
+        if out.is_cuda:
+            out.record_stream(torch.cuda.current_stream(out.device))
+        if all(c == self.max_count for c in self.counts):
+            images = out.reshape((self.world * self.max_count,) + tuple(out.shape[2:]))
+        else:
+            images = torch.cat([out[r, :c] for r, c in enumerate(self.counts)], 0)
+        return first + self.rank, images
+
+    def drain(self):
+        if self._filled:
+            if len(self._pending) >= self.depth:
+                first = [self.wait()]
+            else:
+                first = []
+            ctx = torch.cuda.stream(self._side) if self._side is not None else _NullContext()
+            with ctx:
+                self._exchange()
+        else:
+            first = []
+        while self._pending:
+            first.append(self.wait())
+        return first
 
 
 class _NullContext:

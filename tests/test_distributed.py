@@ -89,6 +89,58 @@ def _depth2_worker(rank, world, port, n_total, out_dir):
     dist.destroy_process_group()
 
 
+def _rotating_worker(rank, world, port, n_total, n_steps, out_dir):
+    """bench.py's hand-over loop at N > 1 since round 5: RotatingImageGather -- step s's global batch lands on rank
+    s mod N, one exchange per block of N steps, depth 2.  Every step hands over different frames."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    distributed.init_from_env(backend="gloo")
+    job = synthetic.sphere_job(n_total, 24, 20, 6)
+    shard = distributed.shard_batch(job, rank, world)
+    base = _oracle_render(shard, 24, 20)
+    handle = distributed.RotatingImageGather(n_total, depth=2)
+    to_u8 = lambda t: (t.clamp(0, 8) * 31).to(torch.uint8)
+    got = []
+    for k in range(n_steps):
+        if handle.in_flight() >= handle.depth:
+            out = handle.wait()
+            got.append(None if out is None else (out[0], out[1].clone()))
+        handle.start(base * float(k + 1), transform=to_u8)
+        assert handle.in_flight() <= handle.depth
+    for out in handle.drain():
+        got.append(None if out is None else (out[0], out[1].clone()))
+    assert handle.in_flight() == 0 and handle.wait() is None
+    torch.save([g for g in got if g is not None], os.path.join(out_dir, "rotating%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_total,n_steps", [(2, 5, 7), (3, 5, 7), (3, 6, 9)])   # uneven / even shards, with and without a tail
+def test_rotating_gather(tmp_path, world, n_total, n_steps):
+    mp.spawn(_rotating_worker, args=(world, _free_port(), n_total, n_steps, str(tmp_path)), nprocs=world, join=True)
+    full = _oracle_render(synthetic.sphere_job(n_total, 24, 20, 6), 24, 20)
+    seen = {}
+    for rank in range(world):
+        for step, images in torch.load(os.path.join(str(tmp_path), "rotating%d.pt" % rank)):
+            assert step % world == rank and step not in seen
+            seen[step] = images
+    assert sorted(seen) == list(range(n_steps))          # every step's global batch landed on exactly one rank
+    for step, images in seen.items():
+        want = ((full * float(step + 1)).clamp(0, 8) * 31).to(torch.uint8)
+        assert torch.equal(images, want), "step %d" % step
+
+
+def test_rotating_gather_single_process_is_identity():
+    handle = distributed.RotatingImageGather(3, depth=1)
+    for k in range(3):
+        if handle.in_flight() >= handle.depth:
+            step, images = handle.wait()
+            assert step == k - 1 and torch.equal(images, torch.full((3, 2, 2, 4), float(k - 1)))
+        handle.start(torch.full((3, 2, 2, 4), float(k)))
+    (last,) = handle.drain()
+    assert last[0] == 2 and torch.equal(last[1], torch.full((3, 2, 2, 4), 2.0))
+
+
 def test_gather_depth_two_world2(tmp_path):
     mp.spawn(_depth2_worker, args=(2, _free_port(), 5, str(tmp_path)), nprocs=2, join=True)
     full = _oracle_render(synthetic.sphere_job(5, 24, 20, 6), 24, 20)

@@ -437,30 +437,34 @@ def test_rccl_image_gather_single_rank(device):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("handover", ["u8", "f32"])
-def test_bench_rank_path_meets_rccl_on_one_gpu(device, handover):
+@pytest.mark.parametrize("handover,gather", [("u8", "rotate"), ("f32", "rotate"), ("u8", "root")])
+def test_bench_rank_path_meets_rccl_on_one_gpu(device, handover, gather):
     """bench.py's N > 1 path -- 8-bit frames written by the forward's epilogue (or the fp32 image), the
     side-stream hand-over, gather.wait() inside the timed loop, the render-only loop after it -- under
     a 1-rank RCCL group (MR_BENCH_FORCE_GROUP=1): the line names the backend and the rank count that
-    torch.distributed reports, and carries both per-step figures."""
+    torch.distributed reports, and carries both per-step figures.  gather = rotate: bench.py's default at N > 1
+    (distributed.RotatingImageGather: staging on the side stream + all_to_all_single on RCCL); root: one gather per step."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MR_BENCH_FORCE_GROUP="1", MASTER_ADDR="127.0.0.1",
-               MASTER_PORT="29541" if handover == "u8" else "29542")
+               MASTER_PORT={"u8rotate": "29541", "f32rotate": "29542", "u8root": "29543"}[handover + gather])
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     proc = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "1",
-                           "--cpu-sample", "0", "--handover", handover], env=env, capture_output=True, text=True,
-                          timeout=600)
+                           "--cpu-sample", "0", "--handover", handover, "--gather", gather], env=env, capture_output=True,
+                          text=True, timeout=600)
     assert proc.returncode == 0, proc.stderr[-2000:]
     line = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["rccl"]["backend"] == "nccl" and line["rccl"]["ranks"] == 1
     assert line["rccl"]["handover_bytes_per_rank_per_step"] == 32 * 1024 * 1024 * (4 if handover == "u8" else 16)
     assert 0 < line["ms_per_step_render_only"] and line["ms_per_step_with_handover"] == line["ms_per_step"]
-    assert line["handover_depth"] == 2 and line["handover_GBps_into_root"] == 0.0    # (one rank: nothing arrives)
+    assert line["handover_depth"] == 2 and line["config"]["gather"] == gather
+    # (one rank: nothing arrives / leaves)
+    assert line["handover_GBps_into_root" if gather == "root" else "handover_GBps_out_of_each_rank"] == 0.0
+    assert line["rccl"]["gather"].startswith("rotating root" if gather == "rotate" else "every step's frames to rank 0")
     px = 32 * 1024 * 1024
     assert abs(line["value_render_only"] / (px / line["ms_per_step_render_only"] / 1e3) - 1.0) < 1e-3   # (rounded figures)
     assert line["config"]["handover"] == handover and line["n_gpus"] == 1
