@@ -264,12 +264,14 @@ class RotatingImageGather:
         with (torch.cuda.stream(self._side) if on_gpu else _NullContext()):
             if transform is not None:
                 if on_gpu:
-                    local.record_stream(self._side)
-                send = transform(local).detach()
+                    local.record_stream(self._side)   # read by the side stream: keep it alive for it
+                send = transform(local).detach()     # (the tensor itself: it may carry ready-made frames)
             else:
                 send = local.detach()
-                if on_gpu:
-                    send.record_stream(self._side)
+            if on_gpu:
+                # the staging copy below reads `send` on the side stream, possibly long after the caller dropped it (the
+                # side stream may sit behind an exchange): the caching allocator must not hand its memory out before
+                send.record_stream(self._side)
             key = (tuple(send.shape[1:]), send.dtype, send.device)
             if self._filled and key != self._key:
                 raise ValueError("the frames of one block must have one shape and dtype")
