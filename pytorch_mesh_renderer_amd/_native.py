@@ -16,7 +16,7 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 # build libmesh_raster_hip_probes.so this way); the product always loads the in-tree library.
 LIB_PATH = os.environ.get("MR_NATIVE_LIB_PATH") or os.path.join(_CSRC, "libmesh_raster_hip.so")
 
-ABI_VERSION = 352
+ABI_VERSION = 353
 GBUFFER_NORMALISED = 1   # mesh_raster.h, MR_GBUFFER_NORMALISED
 TIMER_RASTER_FORWARD, TIMER_SHADE_BACKWARD, TIMER_SHADE_FORWARD, TIMER_RASTER_BACKWARD, TIMER_L1_FORWARD = 0, 1, 2, 3, 4
 MR_OK, MR_EINVAL, MR_EWORKSPACE, MR_ELAUNCH = 0, -1, -2, -3

@@ -33,7 +33,7 @@ const char *volatile g_last_accumulate_kernel = "";
 
 extern "C" {
 
-int mr_version(void) { return 352; /* 0.5.0: dclip optional, backward_prepared / prepared, mr_debug_soft_nearest, two's-complement sign codes */ }
+int mr_version(void) { return 353; /* + mr_shade_specular_backward_l1 (352: dclip optional, backward_prepared / prepared, mr_debug_soft_nearest, two's-complement sign codes) */ }
 
 int mr_last_hip_error(void) { return mr::g_last_hip_error; }
 
