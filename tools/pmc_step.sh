@@ -22,7 +22,7 @@ done
 python3 - <<'PY' | tee "$OUT/summary.txt"
 import csv, glob, collections, os
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-keys = tuple(os.environ["PMC_KEYS"].split(",")) if os.environ.get("PMC_KEYS") else ("k_accumulate_lanes", "k_accumulate_rows", "k_raster<64, 0, true,", "k_raster<64, 0, false, 0>", "k_l1_forward", "k_shade_gather")
+keys = tuple(os.environ["PMC_KEYS"].split(",")) if os.environ.get("PMC_KEYS") else ("k_accumulate_lanes", "k_accumulate_rows", "k_raster<64, 0, true,", "k_raster<64, 0, false, 0,", "k_l1_forward", "k_shade_gather")
 for f in glob.glob(os.environ["PMC_OUT"] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         for key in keys:
