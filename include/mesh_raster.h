@@ -367,8 +367,23 @@ int mr_shade_specular_forward(const int32_t *ids, const float *bary, const float
                               const float *light_intensities, const float *ambient,
                               const float *camera_position, const float *shininess,
                               int shininess_per_vertex, int B, int V, int T, int W, int H, int L,
-                              float *rgba, float *norms2,
+                              float *rgba, float *norms2, int norms2_given,
                               void *workspace, size_t workspace_bytes, void *stream);
+/* norms2_given = 1: norms2 is an INPUT -- what mr_rasterize_specular_norms_forward wrote for the same G-buffer, normals,
+ * positions, lights and camera -- and the norm pass over the G-buffer does not run (0: norms2 is an output, as before).
+ *
+ * mr_rasterize_specular_norms_forward (round 5): mr_rasterize_forward on `clip` AND those norms in one pass over the
+ * pixels.  The reference L2-normalises the reflection . camera dot product across ALL pixels of an image per light
+ * (render.py:342-348); that sum only needs every covered pixel's interpolated normal and position, which the
+ * rasterizer's tile walk holds when it has settled the pixel, and the uncovered pixels all carry the background's
+ * attributes -1 (render.py:197) and one common value.  ids / bary / z exactly as mr_rasterize_forward writes them (z is
+ * required as a buffer; want_z = 0: its contents are unspecified afterwards); norms2 [B,L] f32 out, 1 <= L <= 4. */
+size_t mr_rasterize_specular_norms_workspace_bytes(int B, int V, int T, int W, int H);
+int mr_rasterize_specular_norms_forward(const float *clip, const int32_t *triangles, const float *normals,
+                                        const float *positions, const float *light_positions,
+                                        const float *camera_position, int B, int V, int T, int W, int H, int L,
+                                        int32_t *ids, float *bary, float *z, int want_z, float *norms2,
+                                        void *workspace, size_t workspace_bytes, void *stream);
 size_t mr_shade_specular_backward_workspace_bytes(int B, int V, int T, int W, int H);
 int mr_shade_specular_backward(const float *drgba, const int32_t *ids, const float *bary,
                                const float *clip, const float *normals, const float *positions,

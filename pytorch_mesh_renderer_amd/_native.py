@@ -16,7 +16,7 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 # build libmesh_raster_hip_probes.so this way); the product always loads the in-tree library.
 LIB_PATH = os.environ.get("MR_NATIVE_LIB_PATH") or os.path.join(_CSRC, "libmesh_raster_hip.so")
 
-ABI_VERSION = 353
+ABI_VERSION = 354
 GBUFFER_NORMALISED = 1   # mesh_raster.h, MR_GBUFFER_NORMALISED
 TIMER_RASTER_FORWARD, TIMER_SHADE_BACKWARD, TIMER_SHADE_FORWARD, TIMER_RASTER_BACKWARD, TIMER_L1_FORWARD = 0, 1, 2, 3, 4
 MR_OK, MR_EINVAL, MR_EWORKSPACE, MR_ELAUNCH = 0, -1, -2, -3
@@ -230,8 +230,12 @@ def lib():
         L.mr_render_forward.restype = ci
         L.mr_shade_specular_forward_workspace_bytes.argtypes = [ci] * 5
         L.mr_shade_specular_forward_workspace_bytes.restype = sz
-        L.mr_shade_specular_forward.argtypes = [vp] * 12 + [ci] * 7 + [vp, vp, vp, sz, vp]
+        L.mr_shade_specular_forward.argtypes = [vp] * 12 + [ci] * 7 + [vp, vp, ci, vp, sz, vp]
         L.mr_shade_specular_forward.restype = ci
+        L.mr_rasterize_specular_norms_workspace_bytes.argtypes = [ci] * 5
+        L.mr_rasterize_specular_norms_workspace_bytes.restype = sz
+        L.mr_rasterize_specular_norms_forward.argtypes = [vp] * 6 + [ci] * 6 + [vp, vp, vp, ci, vp, vp, sz, vp]
+        L.mr_rasterize_specular_norms_forward.restype = ci
         L.mr_shade_specular_backward_workspace_bytes.argtypes = [ci] * 5
         L.mr_shade_specular_backward_workspace_bytes.restype = sz
         L.mr_shade_specular_backward.argtypes = [vp] * 14 + [ci, vp] + [ci] * 6 + [vp] * 7 + [vp, vp] + [vp, ci, ci] + [vp, sz, vp]
@@ -829,10 +833,46 @@ def _shade_backward_call(drgba, ids, bary, clip, normals, positions, diffuse, tr
     return dclip, dn, dp, dd, dlpos, dlint, damb
 
 
+def rasterize_specular_norms_forward(clip, triangles, normals, positions, light_positions, camera_position,
+                                     width, height, want_z=False):
+    """rasterize_forward(clip, triangles, width, height) AND the specular term's across-pixels norms in one pass over
+    the pixels -> (ids, bary, z or None, norms2 [B,L]); 1 <= L <= shade_fast_lights().  norms2 goes to
+    shade_specular_forward(..., norms2=) -- its norm pass over the G-buffer then does not run -- and to
+    shade_specular_backward as before."""
+    B, V, T = _chk_mesh(clip, triangles)
+    for name, t in (("normals", normals), ("positions", positions)):
+        _chk(name, t, _F32, B, V, 3)
+    _chk("light_positions", light_positions, _F32, B, None, 3)
+    nl = light_positions.shape[1]
+    if not 1 <= nl <= shade_fast_lights():
+        raise ValueError("1..%d lights per call" % shade_fast_lights())
+    _chk("camera_position", camera_position, _F32, B, 3)
+    dev = _require_device(clip, triangles, normals, positions, light_positions, camera_position)
+    clip, triangles, normals, positions, light_positions, camera_position = [
+        t.contiguous() for t in (clip, triangles, normals, positions, light_positions, camera_position)]
+    width, height = int(width), int(height)
+    ids = torch.empty(B, height, width, dtype=torch.int32, device=dev)
+    bary = torch.empty(B, height, width, 3, dtype=torch.float32, device=dev)
+    z = torch.empty(B, height, width, dtype=torch.float32, device=dev)
+    norms2 = torch.empty(B, nl, dtype=torch.float32, device=dev)
+    L = lib()
+    with torch.cuda.device(dev):
+        need = L.mr_rasterize_specular_norms_workspace_bytes(B, V, T, width, height)
+        ws, have = _workspace(dev, need)
+        rc = L.mr_rasterize_specular_norms_forward(
+            _ptr(clip), _ptr(triangles), _ptr(normals), _ptr(positions), _ptr(light_positions), _ptr(camera_position),
+            B, V, T, width, height, nl, _ptr(ids), _ptr(bary), _ptr(z), int(bool(want_z)), _ptr(norms2), _ptr(ws), have,
+            _stream(dev))
+    _check(rc, "mr_rasterize_specular_norms_forward")
+    return ids, bary, (z if want_z else None), norms2
+
+
 def shade_specular_forward(ids, bary, normals, positions, diffuse, specular, triangles, light_positions,
-                           light_intensities, ambient, camera_position, shininess):
+                           light_intensities, ambient, camera_position, shininess, norms2=None):
     """Fused interpolation + Phong with the specular term -> (rgba [B,H,W,4], norms2 [B,L]).
-    shininess: [B] (one exponent per image) or [B,V] (per vertex)."""
+    shininess: [B] (one exponent per image) or [B,V] (per vertex).
+    norms2 ([B,L], rasterize_specular_norms_forward's for the same G-buffer, normals, positions, lights and camera):
+    given, the norm pass does not run and the same tensor is returned."""
     tensors = [ids, bary, normals, positions, diffuse, specular, triangles, light_positions,
                light_intensities, camera_position, shininess]
     _chk("triangles", triangles, _I32, None, 3)
@@ -852,7 +892,13 @@ def shade_specular_forward(ids, bary, normals, positions, diffuse, specular, tri
     B, H, W = ids.shape
     V, T, nl = normals.shape[1], triangles.shape[0], light_positions.shape[1]
     rgba = torch.empty(B, H, W, 4, dtype=torch.float32, device=dev)
-    norms2 = torch.empty(B, nl, dtype=torch.float32, device=dev)
+    given = norms2 is not None
+    if given:
+        _chk("norms2", norms2, _F32, B, nl)
+        _require_device(norms2)
+        norms2 = norms2.contiguous()
+    else:
+        norms2 = torch.empty(B, nl, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         need = L.mr_shade_specular_forward_workspace_bytes(B, V, T, W, H)
         ws, have = _workspace(dev, need)
@@ -860,7 +906,7 @@ def shade_specular_forward(ids, bary, normals, positions, diffuse, specular, tri
             _ptr(ids), _ptr(bary), _ptr(normals), _ptr(positions), _ptr(diffuse), _ptr(specular),
             _ptr(triangles), _ptr(light_positions), _ptr(light_intensities), _ptr(ambient),
             _ptr(camera_position), _ptr(shininess), int(per_vertex), B, V, T, W, H, nl, _ptr(rgba),
-            _ptr(norms2), _ptr(ws), have, _stream(dev))
+            _ptr(norms2), int(given), _ptr(ws), have, _stream(dev))
     _check(rc, "mr_shade_specular_forward")
     return rgba, norms2
 

@@ -33,7 +33,7 @@ const char *volatile g_last_accumulate_kernel = "";
 
 extern "C" {
 
-int mr_version(void) { return 353; /* + mr_shade_specular_backward_l1 (352: dclip optional, backward_prepared / prepared, mr_debug_soft_nearest, two's-complement sign codes) */ }
+int mr_version(void) { return 354; /* + mr_rasterize_specular_norms_forward, norms2_given; 353: mr_shade_specular_backward_l1 (352: dclip optional, backward_prepared / prepared, mr_debug_soft_nearest, two's-complement sign codes) */ }
 
 int mr_last_hip_error(void) { return mr::g_last_hip_error; }
 
@@ -373,10 +373,11 @@ int mr_shade_specular_forward(const int32_t *ids, const float *bary, const float
                               const float *light_intensities, const float *ambient,
                               const float *camera_position, const float *shininess,
                               int shininess_per_vertex, int B, int V, int T, int W, int H, int L,
-                              float *rgba, float *norms2, void *workspace, size_t workspace_bytes,
+                              float *rgba, float *norms2, int norms2_given, void *workspace, size_t workspace_bytes,
                               void *stream) {
   if (bad_dims(B, V, T, W, H) || T < 1 || V < 1 || L < 1 || L > mr::shade_light_gradient_max_lights())
     return MR_EINVAL;
+  if (norms2_given != 0 && norms2_given != 1) return MR_EINVAL;
   if (B == 0) return MR_OK;
   if (!ids || !bary || !normals || !positions || !diffuse || !specular || !triangles ||
       !light_positions || !light_intensities || !camera_position || !shininess || !rgba || !norms2)
@@ -386,8 +387,30 @@ int mr_shade_specular_forward(const int32_t *ids, const float *bary, const float
   return mr::launch_shade_specular_forward(ids, bary, normals, positions, diffuse, specular, triangles,
                                            light_positions, light_intensities, ambient,
                                            camera_position, shininess, shininess_per_vertex, B, V, T, W,
-                                           H, L, rgba, norms2,
+                                           H, L, rgba, norms2, norms2_given,
                                            workspace, (hipStream_t)stream);
+}
+
+size_t mr_rasterize_specular_norms_workspace_bytes(int B, int V, int T, int W, int H) {
+  if (bad_dims(B, V, T, W, H)) return 0;
+  return mr::rasterize_specular_norms_ws(B, V, T, W, H);
+}
+
+int mr_rasterize_specular_norms_forward(const float *clip, const int32_t *triangles, const float *normals,
+                                        const float *positions, const float *light_positions,
+                                        const float *camera_position, int B, int V, int T, int W, int H, int L,
+                                        int32_t *ids, float *bary, float *z, int want_z, float *norms2,
+                                        void *workspace, size_t workspace_bytes, void *stream) {
+  if (bad_dims(B, V, T, W, H) || T < 1 || V < 1 || L < 1 || L > mr::shade_light_gradient_max_lights())
+    return MR_EINVAL;
+  if (B == 0) return MR_OK;
+  if (!clip || !triangles || !normals || !positions || !light_positions || !camera_position || !ids || !bary || !z ||
+      !norms2)
+    return MR_EINVAL;
+  const int rc = check_ws(workspace, workspace_bytes, mr::rasterize_specular_norms_ws(B, V, T, W, H));
+  if (rc != MR_OK) return rc;
+  return mr::launch_rasterize_specular_norms(clip, triangles, normals, positions, light_positions, camera_position, B, V, T,
+                                             W, H, L, ids, bary, z, want_z != 0, norms2, workspace, (hipStream_t)stream);
 }
 
 size_t mr_shade_specular_backward_workspace_bytes(int B, int V, int T, int W, int H) {

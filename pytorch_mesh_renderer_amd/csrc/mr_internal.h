@@ -182,13 +182,18 @@ int launch_render_forward(const float *vertices, const float *transforms, const 
                           int L, float *clip, int32_t *ids, float *bary, float *z, int want_z, float *rgba,
                           uint8_t *rgba_u8, void *corner_records, void *backward_prepared, uint8_t *empty_regions, void *ws,
                           hipStream_t s);
+// the G-buffer and the specular term's across-pixels norms (norms2 [B,L], L <= 4) in one pass (raster_forward.hip)
+size_t rasterize_specular_norms_ws(int B, int V, int T, int W, int H);
+int launch_rasterize_specular_norms(const float *clip, const int32_t *tris, const float *normals, const float *positions,
+                                    const float *light_pos, const float *camera, int B, int V, int T, int W, int H, int L,
+                                    int32_t *ids, float *bary, float *z, int want_z, float *norms2, void *ws, hipStream_t s);
 size_t shade_specular_forward_ws(int B, int V, int T, int W, int H);
 int launch_shade_specular_forward(const int32_t *ids, const float *bary, const float *normals,
                                   const float *positions, const float *diffuse, const float *specular,
                                   const int32_t *tris, const float *light_pos, const float *light_col,
                                   const float *ambient, const float *camera, const float *shininess,
                                   int shininess_per_vertex, int B, int V, int T, int W, int H, int L,
-                                  float *rgba, float *norms2,
+                                  float *rgba, float *norms2, int norms2_given,
                                   void *ws, hipStream_t s);
 size_t shade_specular_backward_ws(int B, int V, int T, int W, int H);
 size_t shade_specular_backward_l1_ws(int B, int V, int T, int W, int H);

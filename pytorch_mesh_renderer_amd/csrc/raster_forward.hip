@@ -46,6 +46,7 @@
 
 #include "mr_internal.h"
 #include "shade_pixel.h"
+#include "spec_pixel.h"
 
 namespace mr {
 
@@ -667,6 +668,11 @@ struct RasterShade {
   // 64 x 64 block without a single candidate triangle -- every pixel of it is background in the G-buffer and transparent
   // black in the image.  Consumers (the loss, the shading backward) skip such blocks without reading them.
   uint8_t *__restrict__ empty_map;
+  // NORMS (round 5; with attr_records = [corner][normal 3 | position 3 | 2 of padding], A = 6, attr_out = nullptr): the
+  // specular term's across-pixels norm (render.py:342-348) as the epilogue -- every covered pixel's squared
+  // reflection . camera dot product per light, summed per region; shade_spec.hip's norm pass then does not run.
+  const float *__restrict__ camera = nullptr;        // [B,3]
+  float *__restrict__ norm_partials = nullptr;       // [regions][8]: sums for up to four lights, the covered-pixel count, padding
 };
 
 #ifndef MR_EPI_LDS_LIGHTS
@@ -739,7 +745,7 @@ struct RasterShade {
 // crowded (configs[3]: ~170 entries per 64 x 64 region against the 106 record slots the bin's unused top offers): the
 // epilogue then reads its winners' records per lane from LDS there too instead of one winner at a time through the scalar
 // cache.  64 slots = 7 KB more LDS: five workgroups per CU instead of six.  Chosen on the host (launch_k_raster_probe).
-template <int R, int PROBE, bool SHADE, int INTERP = 0, int AX = 0, int XREC = 0>
+template <int R, int PROBE, bool SHADE, int INTERP = 0, int AX = 0, int XREC = 0, bool NORMS = false>
 __global__ __launch_bounds__(kThreads, SHADE ? (XREC ? MR_RASTER_XREC_WAVES : MR_RASTER_SHADE_WAVES) : INTERP >= 12 ? 4 : INTERP ? MR_RASTER_INTERP_WAVES : MR_RASTER_WAVES) void k_raster(
     const TriRec *__restrict__ recs, const TriBox *__restrict__ bbs,
     const float *__restrict__ pxtab, const float *__restrict__ pytab, int T, int W, int H,
@@ -755,6 +761,7 @@ __global__ __launch_bounds__(kThreads, SHADE ? (XREC ? MR_RASTER_XREC_WAVES : MR
   static_assert(!SHADE || PROBE == 0, "the shading epilogue has no timing probes");
   static_assert(INTERP == 0 || (!SHADE && PROBE == 0 && INTERP % 4 == 0 && INTERP <= 16), "one epilogue at a time");
   static_assert(AX == 0 || (INTERP > 0 && AX <= INTERP && AX > INTERP - 4), "a fixed attribute count belongs to its padded variant");
+  static_assert(!NORMS || (INTERP == 8 && AX == 6), "the norm epilogue interpolates normals and positions");
   constexpr bool EPI = SHADE || INTERP > 0;   // an epilogue runs on a region's last bin round
   // A wavefront's tile is kTileW x kTileH pixels, one per lane.  16 x 4: every row of a tile's
   // G-buffer stores is a whole, aligned 64-byte sector (16 ids / depths) or three of them (16
@@ -930,7 +937,7 @@ __global__ __launch_bounds__(kThreads, SHADE ? (XREC ? MR_RASTER_XREC_WAVES : MR
       kRsrcWord3);
   const CornerRec *img_corners = SHADE ? shade.corners + (size_t)img * T : nullptr;
   const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
-      INTERP ? shade.attr_out + region_pix * (size_t)attr_n : nullptr, 0, 0x7fffffff, kRsrcWord3);
+      (INTERP && !NORMS) ? shade.attr_out + region_pix * (size_t)attr_n : nullptr, 0, 0x7fffffff, kRsrcWord3);
   const float *img_attr_records = INTERP ? shade.attr_records + (size_t)img * T * (3 * INTERP) : nullptr;
   const unsigned lane_out = INTERP ? lane_pix * (unsigned)attr_n * 4u : 0u;   // byte offset of the lane's pixel inside a tile
   int ent_init = 0;   // slot a pixel without a winner looks up (INTERP: the background's record, set per round)
@@ -944,7 +951,21 @@ __global__ __launch_bounds__(kThreads, SHADE ? (XREC ? MR_RASTER_XREC_WAVES : MR
   float *stage_slot = nullptr;
   unsigned stage_goff[INTERP > 0 ? INTERP / 4 : 1] = {};
   __shared__ __attribute__((aligned(16))) float s_background[INTERP > 0 ? INTERP : 4];   // (INTERP only)
-  if constexpr (INTERP > 0) {
+  // NORMS: per-lane sums of rdc^2 (four lights) and the lane's covered pixels, over every tile it walks
+  [[maybe_unused]] float norm_acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  [[maybe_unused]] float norm_covered = 0.0f;
+  [[maybe_unused]] float norm_cam[3] = {0.0f, 0.0f, 0.0f}, norm_lp[4][3] = {};
+  [[maybe_unused]] const int norm_lights = NORMS ? min(shade.lights.L, 4) : 0;
+  if constexpr (NORMS) {
+    if (tid < INTERP) s_background[tid] = -1.0f;   // render.py:197 (unused by the epilogue below: uncovered pixels are counted)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) norm_cam[c] = shade.camera[(size_t)img * 3 + c];   // (wave-uniform: scalar loads)
+#pragma unroll
+    for (int l = 0; l < 4; ++l)
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        norm_lp[l][c] = l < norm_lights ? shade.lights.pos[((size_t)img * shade.lights.L + l) * 3 + c] : 0.0f;
+  } else if constexpr (INTERP > 0) {
     __shared__ __attribute__((aligned(16))) float s_stage[kWaves * kWave * INTERP];
     stage_slot = s_stage + wave * (kWave * INTERP);
     // The background colour in LDS (the bin stage's barriers come before its first use): read per tile from memory it
@@ -994,7 +1015,7 @@ __global__ __launch_bounds__(kThreads, SHADE ? (XREC ? MR_RASTER_XREC_WAVES : MR
                                                MR_RASTER_STORE_AUX_RGBA);
         if (shade.rgba8) __builtin_nontemporal_store(0u, &shade.rgba8[img_px + (size_t)(H - 1 - (Y0 + y)) * W + X0 + x]);
       }
-      if constexpr (INTERP > 0) {
+      if constexpr (INTERP > 0 && !NORMS) {   // (NORMS: an empty region adds nothing; its partial row was cleared by the launcher)
         // an uncovered pixel: id 0, barycentrics 0 -> alpha 0: 0 * (triangle 0's attributes, weighted by zeros) + 1 * background
         // (rasterize.py:137-150; the products are kept: a non-finite attribute of triangle 0 shows here as in the reference)
         for (int a = 0; a < attr_n; ++a) {
@@ -1207,7 +1228,43 @@ __global__ __launch_bounds__(kThreads, SHADE ? (XREC ? MR_RASTER_XREC_WAVES : MR
       words = far_words;
       far_words = 0u;
       }
-      if constexpr (INTERP > 0) {
+      if constexpr (NORMS) {
+        if (last_round) {  // workgroup-uniform
+          // a covered pixel (alpha = clamp(2 sum b) = 1: the barycentrics this kernel writes sum to 1): normal and
+          // position interpolated from the winner's record, then every light's reflection . camera dot product
+          // (spec_pixel.h, as shade_spec.hip's norm pass evaluates it); uncovered pixels are counted, see k_spec_norm_finish
+          const float pre = (2.0f * st.b0 + 2.0f * st.b1) + 2.0f * st.b2;
+          const bool live = in_image && pre > 0.0f;
+          const float *rec;
+          if constexpr (lds_recs) rec = record_of(st.ent);
+          else rec = img_attr_records + (size_t)min((unsigned)max(st.id, 0), (unsigned)(T - 1)) * (3 * INTERP);
+          const float4 c0a = *(const float4 *)(rec), c0b = *(const float4 *)(rec + 4);
+          const float4 c1a = *(const float4 *)(rec + INTERP), c1b = *(const float4 *)(rec + INTERP + 4);
+          const float4 c2a = *(const float4 *)(rec + 2 * INTERP), c2b = *(const float4 *)(rec + 2 * INTERP + 4);
+          float at[6];
+          {
+#pragma clang fp contract(fast)
+            const float alpha = fminf(fmaxf(pre, 0.0f), 1.0f), one_m = 1.0f - alpha;
+            const float k0[6] = {c0a.x, c0a.y, c0a.z, c0a.w, c0b.x, c0b.y}, k1[6] = {c1a.x, c1a.y, c1a.z, c1a.w, c1b.x, c1b.y},
+                        k2[6] = {c2a.x, c2a.y, c2a.z, c2a.w, c2b.x, c2b.y};
+#pragma unroll
+            for (int a = 0; a < 6; ++a) at[a] = alpha * ((k0[a] * st.b0 + k1[a] * st.b1) + k2[a] * st.b2) - one_m;
+          }
+          const float cam[3] = {norm_cam[0], norm_cam[1], norm_cam[2]};
+          spec::PixelFrame f;
+          spec::pixel_frame(at, cam, f);
+#pragma unroll
+          for (int l = 0; l < 4; ++l) {
+            if (l < norm_lights) {   // wave-uniform
+              const float lp[3] = {norm_lp[l][0], norm_lp[l][1], norm_lp[l][2]};
+              spec::LightTerm lt;
+              spec::light_term(at, f, lp, lt);
+              norm_acc[l] += live ? lt.rdc * lt.rdc : 0.0f;
+            }
+          }
+          norm_covered += live ? 1.0f : 0.0f;
+        }
+      } else if constexpr (INTERP > 0) {
         if (last_round) {  // workgroup-uniform
           constexpr int AP = INTERP;
           typedef unsigned v4u __attribute__((ext_vector_type(4)));
@@ -1627,6 +1684,22 @@ __global__ __launch_bounds__(kThreads, SHADE ? (XREC ? MR_RASTER_XREC_WAVES : MR
     round_base = next_base;
     if (round_base < n_cand) __syncthreads();  // tiles done with the bin; orders the state stores
   } while (round_base < n_cand);
+  if constexpr (NORMS) {   // the region's row of partial sums: fixed tree per wavefront, fixed order over the wavefronts
+    __shared__ float s_norm[kWaves][5];
+    float v[5] = {norm_acc[0], norm_acc[1], norm_acc[2], norm_acc[3], norm_covered};
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off);
+      if (lane == 0) s_norm[wave][k] = v[k];
+    }
+    __syncthreads();
+    if (tid < 5) {
+      float t = 0.0f;
+      for (int w = 0; w < kWaves; ++w) t += s_norm[w][tid];
+      shade.norm_partials[(size_t)region * 8 + tid] = t;
+    }
+  }
 }
 
 }  // namespace
@@ -1687,9 +1760,9 @@ struct RasterArgs {
   RasterShade shade;  // rgba == nullptr: G-buffer only
 };
 
-template <int R, int PROBE, bool SHADE = false, int INTERP = 0, int AX = 0, int XREC = 0>
+template <int R, int PROBE, bool SHADE = false, int INTERP = 0, int AX = 0, int XREC = 0, bool NORMS = false>
 void launch_k_raster(const RasterArgs &a, dim3 grid, hipStream_t s) {
-  hipLaunchKernelGGL((k_raster<R, PROBE, SHADE, INTERP, AX, XREC>), grid, dim3(kThreads), 0, s, a.recs, a.bbs, a.pxtab, a.pytab, a.T,
+  hipLaunchKernelGGL((k_raster<R, PROBE, SHADE, INTERP, AX, XREC, NORMS>), grid, dim3(kThreads), 0, s, a.recs, a.bbs, a.pxtab, a.pytab, a.T,
                      a.W, a.H, a.regions_x, a.per_image, a.n_regions, a.per_xcd, a.cell_ids, a.cell_count,
                      a.cell_split, a.cells_x, a.cells_per_image, a.region_ids, a.region_count, a.order_count,
                      a.order_list, a.ids, a.bary, a.z, a.shade);
@@ -1703,6 +1776,7 @@ void launch_k_raster_probe(const RasterArgs &a, dim3 grid, hipStream_t s) {
       return launch_k_raster<R, 0, true, 0, 0, (R == 64 ? MR_RASTER_XREC : 0)>(a, grid, s);
     return launch_k_raster<R, 0, true>(a, grid, s);
   }
+  if (a.shade.norm_partials) return launch_k_raster<R, 0, false, 8, 6, 0, true>(a, grid, s);   // the specular norm as the epilogue
   if (a.shade.attr_out) {  // rasterize()'s interpolation as the epilogue, attribute count padded to 4 / 8 / 12 / 16
     if (a.shade.A == 9) return launch_k_raster<R, 0, false, 12, 9>(a, grid, s);   // (normal, position, colour: render()'s set)
     if (a.shade.A == 3) return launch_k_raster<R, 0, false, 4, 3>(a, grid, s);
@@ -1833,6 +1907,106 @@ int launch_rasterize_interpolate_forward(const float *clip, const float *attrs, 
                         RasterShade{nullptr, Lights{nullptr, nullptr, nullptr, 0}, nullptr, nullptr, 0, (const float *)records,
                                     background, out, A, nullptr},
                         SetupAttributes{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, ws, s);
+}
+
+// ---- the G-buffer AND the specular term's across-pixels norms in one pass over the pixels (round 5) --------------
+// render() with a specular term used to rasterize, then run shade_spec.hip's norm pass over the G-buffer (150 us at
+// 1024^2 x 32: a dependent G-buffer -> corner record gather per pixel) before the pass that writes the image.  The
+// norm -- per (image, light) the sum over ALL pixels of (reflection . camera)^2, render.py:342-348 -- only needs each
+// covered pixel's interpolated normal and position, which the tile walk has at hand (k_raster<..., NORMS>); every
+// uncovered pixel carries the attributes -1 and the same value, added as count x value by k_spec_norm_finish.
+namespace {
+// [B*T][3][8]: corner k = normal (3), position (3), two zeros
+__global__ __launch_bounds__(kThreads) void k_norm_records(const F3 *__restrict__ normals, const F3 *__restrict__ positions,
+                                                           const int32_t *__restrict__ tris, int B, int V, int T,
+                                                           float4 *__restrict__ out) {
+  const long gid = (long)blockIdx.x * kThreads + threadIdx.x;
+  if (gid >= (long)B * T) return;
+  const int b = (int)(gid / T), t = (int)(gid - (long)b * T);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    int vi = tris[3 * t + k];
+    if ((unsigned)vi >= (unsigned)V) vi = 0;   // (as gather_corner_values: such a triangle is never drawn)
+    const F3 n = normals[(size_t)b * V + vi], p = positions[(size_t)b * V + vi];
+    out[gid * 6 + 2 * k] = make_float4(n.x, n.y, n.z, p.x);
+    out[gid * 6 + 2 * k + 1] = make_float4(p.y, p.z, 0.0f, 0.0f);
+  }
+}
+
+// One workgroup per image: norms2[image][l] = the regions' partial sums in a fixed order + (uncovered pixels) x the
+// background's value.
+__global__ __launch_bounds__(kThreads) void k_spec_norm_finish(const float *__restrict__ partials, int regions_per_image,
+                                                               const float *__restrict__ light_pos, const float *__restrict__ camera,
+                                                               int L, long pixels_per_image, float *__restrict__ norms2) {
+  __shared__ float s_part[kThreads / kWave][5];
+  const int img = (int)blockIdx.x, tid = (int)threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+  const float *mine = partials + (size_t)img * regions_per_image * 8;
+  float v[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+  for (int i = tid; i < regions_per_image; i += kThreads) {
+    const float4 a = *(const float4 *)(mine + (size_t)i * 8);
+    v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+    v[4] += mine[(size_t)i * 8 + 4];
+  }
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off);
+    if (lane == 0) s_part[wave][k] = v[k];
+  }
+  __syncthreads();
+  if (tid < L) {
+    float sum = 0.0f, covered = 0.0f;
+    for (int w = 0; w < kThreads / kWave; ++w) {
+      sum += s_part[w][tid];
+      covered += s_part[w][4];   // (whole numbers below 2^24 per region row: exact)
+    }
+    float at[6] = {-1.0f, -1.0f, -1.0f, -1.0f, -1.0f, -1.0f};   // the background of render.py:197
+    const float cam[3] = {camera[img * 3], camera[img * 3 + 1], camera[img * 3 + 2]};
+    const float *lp = light_pos + ((size_t)img * L + tid) * 3;
+    const float lpos[3] = {lp[0], lp[1], lp[2]};
+    spec::PixelFrame f;
+    spec::pixel_frame(at, cam, f);
+    spec::LightTerm lt;
+    spec::light_term(at, f, lpos, lt);
+    norms2[(size_t)img * L + tid] = sum + ((float)pixels_per_image - covered) * (lt.rdc * lt.rdc);
+  }
+}
+}  // namespace
+
+size_t rasterize_specular_norms_ws(int B, int V, int T, int W, int H) {
+  const int edge = region_edge(B, W, H);
+  const size_t regions = (size_t)((W + edge - 1) / edge) * ((H + edge - 1) / edge) * B;
+  return align_up(raster_forward_ws(B, V, T, W, H), 256) + align_up((size_t)B * T * 24 * sizeof(float), 256) +
+         align_up(regions * 8 * sizeof(float), 256);
+}
+
+int launch_rasterize_specular_norms(const float *clip, const int32_t *tris, const float *normals, const float *positions,
+                                    const float *light_pos, const float *camera, int B, int V, int T, int W, int H, int L,
+                                    int32_t *ids, float *bary, float *z, int want_z, float *norms2, void *ws, hipStream_t s) {
+  if (B == 0) return MR_OK;
+  if (L < 1 || L > 4 || T < 1 || V < 1) return MR_EINVAL;
+  const int edge = region_edge(B, W, H);
+  const int per_image = ((W + edge - 1) / edge) * ((H + edge - 1) / edge);
+  float *records = (float *)((char *)ws + align_up(raster_forward_ws(B, V, T, W, H), 256));
+  float *partials = (float *)((char *)records + align_up((size_t)B * T * 24 * sizeof(float), 256));
+  if (zero_async(partials, (size_t)B * per_image * 8 * sizeof(float), s) != hipSuccess) return check_launch();
+  const long nbt = (long)B * T;
+  if ((size_t)W * H > 0) {
+    hipLaunchKernelGGL(k_norm_records, dim3((unsigned)((nbt + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
+                       (const F3 *)normals, (const F3 *)positions, tris, B, V, T, (float4 *)records);
+    int rc = check_launch();
+    if (rc != MR_OK) return rc;
+    RasterShade shade{nullptr, Lights{light_pos, nullptr, nullptr, L}, nullptr, nullptr, want_z, records, nullptr, nullptr, 6,
+                      nullptr};
+    shade.camera = camera;
+    shade.norm_partials = partials;
+    rc = raster_forward(clip, tris, B, V, T, W, H, ids, bary, z, shade,
+                        SetupAttributes{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, ws, s);
+    if (rc != MR_OK) return rc;
+  }
+  hipLaunchKernelGGL(k_spec_norm_finish, dim3((unsigned)B), dim3(kThreads), 0, s, partials, per_image, light_pos, camera, L,
+                     (long)W * H, norms2);
+  return check_launch();
 }
 
 int launch_vertex_transform(const float *vertices, const float *transforms, int B, int V, float *clip,

@@ -34,6 +34,7 @@
 // contribute exactly what the mask says, nothing.  1..4 lights.
 // fp32 with FMA contraction and 1-ulp v_rcp / v_sqrt / v_exp / v_log: parity budget 1e-4.
 #include "corner_rec.h"
+#include "spec_pixel.h"
 
 #ifndef MR_SPEC_NT
 #define MR_SPEC_NT 1  // nontemporal access to the streamed planes
@@ -168,47 +169,11 @@ __device__ __forceinline__ void interpolate_attrs(const SpecCorners<A> &cr, cons
   }
 }
 
-// Geometry of one pixel that does not depend on the light.
-struct PixelFrame {
-  float N[3], nn, inv_nn;     // normalised normal (render.py:201)
-  float Cd[3], cn, inv_cn;    // direction to the camera (render.py:333-336)
-};
-__device__ __forceinline__ void pixel_frame(const float *at, const float *cam, PixelFrame &f) {
-  f.nn = fast_sqrt(at[0] * at[0] + at[1] * at[1] + at[2] * at[2]);
-  f.inv_nn = fast_rcp(fmaxf(f.nn, kNormEps));
-  const float c[3] = {cam[0] - at[3], cam[1] - at[4], cam[2] - at[5]};
-  f.cn = fast_sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
-  f.inv_cn = fast_rcp(fmaxf(f.cn, kNormEps));
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    f.N[k] = at[k] * f.inv_nn;
-    f.Cd[k] = c[k] * f.inv_cn;
-  }
-}
-
-// One light at one pixel (render.py:304-341).
-struct LightTerm {
-  float D[3], vn, inv_vn, pre, ndl;   // direction to the light, N . D and its clamp
-  float M[3], mn, inv_mn;             // mirror reflection direction
-  float rdc;                          // M . Cd, BEFORE the across-pixels normalisation
-};
-__device__ __forceinline__ void light_term(const float *at, const PixelFrame &f, const float *lp, LightTerm &o) {
-  const float v[3] = {lp[0] - at[3], lp[1] - at[4], lp[2] - at[5]};
-  o.vn = fast_sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-  o.inv_vn = fast_rcp(fmaxf(o.vn, kNormEps));
-#pragma unroll
-  for (int k = 0; k < 3; ++k) o.D[k] = v[k] * o.inv_vn;
-  o.pre = f.N[0] * o.D[0] + f.N[1] * o.D[1] + f.N[2] * o.D[2];
-  o.ndl = fminf(fmaxf(o.pre, 0.0f), 1.0f);
-  float m[3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) m[k] = 2.0f * o.ndl * f.N[k] - o.D[k];
-  o.mn = fast_sqrt(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]);
-  o.inv_mn = fast_rcp(fmaxf(o.mn, kNormEps));
-#pragma unroll
-  for (int k = 0; k < 3; ++k) o.M[k] = m[k] * o.inv_mn;
-  o.rdc = o.M[0] * f.Cd[0] + o.M[1] * f.Cd[1] + o.M[2] * f.Cd[2];
-}
+// (PixelFrame / LightTerm: the light-independent geometry of a pixel and one light's term, spec_pixel.h)
+using spec::LightTerm;
+using spec::PixelFrame;
+using spec::light_term;
+using spec::pixel_frame;
 
 // rn -> clamp -> where(ndl != 0) -> pow (render.py:342-366): value, d value / d rn and
 // d value / d shininess.  torch.pow(x, y) for x in [0, 1]: pow(x, 0) = 1, pow(0, y > 0) = 0,
@@ -1219,14 +1184,17 @@ template <bool PV>
 int spec_forward(const int32_t *ids, const float *bary, const float *normals, const float *positions,
                  const float *diffuse, const float *specular, const int32_t *tris, const float *light_pos,
                  const float *light_col, const float *ambient, const float *camera, const float *shininess,
-                 int B, int V, int T, int W, int H, int L, float *rgba, float *norms2, void *ws, hipStream_t s) {
+                 int B, int V, int T, int W, int H, int L, float *rgba, float *norms2, int norms2_given, void *ws,
+                 hipStream_t s) {
   int rc = launch_spec_corner_setup<PV>(normals, positions, diffuse, specular, PV ? shininess : nullptr, tris, B, V,
                                         T, ws, s);
   if (rc != MR_OK) return rc;
   float *partials = (float *)((char *)ws + spec_corner_bytes(B, T));
   SpecSceneIn scene{light_pos, light_col, ambient, camera, PV ? nullptr : shininess, nullptr, nullptr};
-  rc = launch_spec_pixels<kNorms, PV>(L, ids, bary, ws, scene, B, T, W, H, nullptr, nullptr, norms2, partials, s);
-  if (rc != MR_OK) return rc;
+  if (!norms2_given) {   // (given: the rasterizer formed them in its own pass, mr_rasterize_specular_norms_forward)
+    rc = launch_spec_pixels<kNorms, PV>(L, ids, bary, ws, scene, B, T, W, H, nullptr, nullptr, norms2, partials, s);
+    if (rc != MR_OK) return rc;
+  }
   scene.norms2 = norms2;
   return launch_spec_pixels<kShade, PV>(L, ids, bary, ws, scene, B, T, W, H, nullptr, rgba, nullptr, nullptr, s);
 }
@@ -1398,13 +1366,13 @@ int launch_shade_specular_forward(const int32_t *ids, const float *bary, const f
                                   const int32_t *tris, const float *light_pos, const float *light_col,
                                   const float *ambient, const float *camera, const float *shininess,
                                   int shininess_per_vertex, int B, int V, int T, int W, int H, int L,
-                                  float *rgba, float *norms2, void *ws, hipStream_t s) {
+                                  float *rgba, float *norms2, int norms2_given, void *ws, hipStream_t s) {
   if ((size_t)B * W * H == 0) return MR_OK;
   return shininess_per_vertex
              ? spec_forward<true>(ids, bary, normals, positions, diffuse, specular, tris, light_pos, light_col,
-                                  ambient, camera, shininess, B, V, T, W, H, L, rgba, norms2, ws, s)
+                                  ambient, camera, shininess, B, V, T, W, H, L, rgba, norms2, norms2_given, ws, s)
              : spec_forward<false>(ids, bary, normals, positions, diffuse, specular, tris, light_pos, light_col,
-                                   ambient, camera, shininess, B, V, T, W, H, L, rgba, norms2, ws, s);
+                                   ambient, camera, shininess, B, V, T, W, H, L, rgba, norms2, norms2_given, ws, s);
 }
 
 size_t shade_specular_backward_ws(int B, int V, int T, int W, int H) {

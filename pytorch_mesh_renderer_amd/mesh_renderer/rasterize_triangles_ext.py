@@ -446,6 +446,11 @@ class FusedPhongL1Loss(torch.autograd.Function):
         return None, dtarget, dverts, dxf, dn, dd, dlp, dli, damb, None, None, None
 
 
+# False (or MR_FUSE_SPECULAR_NORMS=0 at import): the specular renderer rasterizes with mr_rasterize_forward and runs the
+# norm pass over the G-buffer for every group of lights (A/B, tests)
+FUSE_SPECULAR_NORMS = os.environ.get("MR_FUSE_SPECULAR_NORMS", "1") != "0"
+
+
 class FusedSpecularPhongRenderer(torch.autograd.Function):
     """FusedPhongRenderer plus the specular term of phong_shader (src/mesh_renderer/render.py
     :326-372): two passes over the G-buffer each way (the reference L2-normalises the
@@ -462,11 +467,19 @@ class FusedSpecularPhongRenderer(torch.autograd.Function):
         else but `clip` does, the backward then returns the WHOLE vertex gradient as d positions and None for
         d clip (the pull-back through the transform is folded into the pixel pass)."""
         clip_d = clip.detach().contiguous()
-        ids, bary, _ = _native.rasterize_forward(clip_d, triangles, int(image_width), int(image_height))
         attrs = [t.detach().contiguous() for t in (normals, positions, diffuse, specular)]
         lp, li = light_positions.detach().contiguous(), light_intensities.detach().contiguous()
         amb = ambient.detach().contiguous() if ambient is not None else None
         cam, shin = camera_position.detach().contiguous(), shininess.detach().contiguous()
+        # Round 5: the rasterizer's pass also forms the across-pixels norms of the FIRST group of lights (its tile walk
+        # holds every covered pixel's normal and position): that group's norm pass over the G-buffer does not run
+        first_norms = None
+        if FUSE_SPECULAR_NORMS:
+            ids, bary, _, first_norms = _native.rasterize_specular_norms_forward(
+                clip_d, triangles, attrs[0], attrs[1], lp[:, :_native.shade_fast_lights()].contiguous(), cam,
+                int(image_width), int(image_height))
+        else:
+            ids, bary, _ = _native.rasterize_forward(clip_d, triangles, int(image_width), int(image_height))
         # The kernels keep four lights in registers.  More (round 3): every light's term -- diffuse and
         # specular, with its own across-pixels norm -- depends on that light alone, so the image is the
         # sum of the images of groups of four lights (ambient in the first group), and the gradients
@@ -476,7 +489,8 @@ class FusedSpecularPhongRenderer(torch.autograd.Function):
             last = first + _native.shade_fast_lights()
             part, part_norms = _native.shade_specular_forward(
                 ids, bary, attrs[0], attrs[1], attrs[2], attrs[3], triangles, lp[:, first:last].contiguous(),
-                li[:, first:last].contiguous(), amb if first == 0 else None, cam, shin)
+                li[:, first:last].contiguous(), amb if first == 0 else None, cam, shin,
+                norms2=first_norms if first == 0 else None)
             norms2.append(part_norms)
             if rgba is None:
                 rgba = part

@@ -161,6 +161,15 @@ def specular_case(report, what, pos, xf, tris, nrm, kd, ks, lp, li, amb, cam, sh
                                           camera_position=cam), g_d)
     adjacency = _native.vertex_adjacency(tris_d, V)
     rgba, norms2 = _native.shade_specular_forward(ids, bary, nrm_d, pos_d, kd_d, ks_d, tris_d, lp_d, li_d, amb_d, cam_d, shin_d)
+    # the rasterizer's own pass forms the same norms next to the same G-buffer (mr_rasterize_specular_norms_forward, round 5)
+    ids_f, bary_f, z_f, norms_f = _native.rasterize_specular_norms_forward(clip, tris_d, nrm_d, pos_d, lp_d, cam_d, W, H, want_z=True)
+    assert torch.equal(ids_f, ids) and torch.equal(bary_f.view(torch.int32), bary.view(torch.int32)), what
+    assert torch.equal(z_f.view(torch.int32), _.view(torch.int32)), what
+    if not bool(((norms_f - norms2).abs() <= 3e-5 * norms2.abs() + 1e-12).all()):
+        report.failures.append("%s: norms of the fused pass %s, of the norm pass %s" % (what, norms_f.tolist(), norms2.tolist()))
+    rgba_f, same = _native.shade_specular_forward(ids, bary, nrm_d, pos_d, kd_d, ks_d, tris_d, lp_d, li_d, amb_d, cam_d, shin_d,
+                                                  norms2=norms2)
+    assert same.data_ptr() == norms2.data_ptr() and torch.equal(rgba_f, rgba), what   # (given norms: the same image bits)
     t = truth64.phong(ids_h, bary_h, tris, nrm, pos, kd, lp, li, amb, g_d.cpu().numpy(), specular=ks, shininess=shin,
                       camera_position=cam)
     t["d_clip"], t["noise_clip"] = truth64.raster_pullback(clip_h, tris, ids_h, bary_h, t["dbary"], t["gabs"])

@@ -753,6 +753,45 @@ def test_deterministic_mode_covers_specular_and_rasterize_backward(device):
                                    err_msg="deterministic vs default, output %d" % i)
 
 
+@pytest.mark.parametrize("batch,size,k,n_lights", [(2, (96, 72), 10, 1), (16, (512, 512), 50, 2), (3, (333, 257), 20, 4),
+                                                   (17, (512, 448), 100, 3)])
+def test_rasterizer_forms_the_specular_norms_in_its_own_pass(device, batch, size, k, n_lights):
+    """mr_rasterize_specular_norms_forward (round 5): the G-buffer bit for bit mr_rasterize_forward's, and the
+    across-pixels norms of render.py:342-348 equal to those of shade_spec.hip's norm pass over that G-buffer -- 32- and
+    64-pixel regions, ragged sizes, 1..4 lights, a crowded mesh (20k triangles: regions whose records do not fit the
+    bin's top, several bin rounds); and render() with the specular term gives the same image either way."""
+    from pytorch_mesh_renderer_amd import _native
+    from pytorch_mesh_renderer_amd.mesh_renderer import rasterize_triangles_ext as ext
+    w, h = size
+    job = synthetic.sphere_job(batch, w, h, k)
+    d = {key: (v.to(device) if torch.is_tensor(v) else v) for key, v in job.items()}
+    gen = torch.Generator().manual_seed(batch)
+    lp = (torch.randn(batch, n_lights, 3, generator=gen) * 3.0 + torch.tensor([0.0, 0.0, 4.0])).to(device)
+    li = torch.rand(batch, n_lights, 3, generator=gen).to(device)
+    cam = d["eyes"].to(device)
+    ks = torch.rand(d["vertices"].shape, generator=gen).to(device)
+    shin = torch.full((batch,), 5.0, device=device)
+    ids, bary, z = _native.rasterize_forward(d["clip"], d["triangles"], w, h)
+    rgba, norms = _native.shade_specular_forward(ids, bary, d["normals"], d["vertices"], d["diffuse"], ks, d["triangles"], lp, li,
+                                                 None, cam, shin)
+    ids2, bary2, z2, norms2 = _native.rasterize_specular_norms_forward(d["clip"], d["triangles"], d["normals"], d["vertices"],
+                                                                       lp, cam, w, h, want_z=True)
+    assert torch.equal(ids2, ids) and torch.equal(bary2.view(torch.int32), bary.view(torch.int32))
+    assert torch.equal(z2.view(torch.int32), z.view(torch.int32))
+    np.testing.assert_allclose(norms2.cpu().numpy(), norms.cpu().numpy(), rtol=2e-5, atol=0)
+    assert float(norms.min()) > 0
+    images = []
+    for fused in (True, False):
+        ext.FUSE_SPECULAR_NORMS = fused
+        try:
+            images.append(mesh_renderer.render(d["vertices"], d["triangles"], d["normals"], d["diffuse"], job["eyes"],
+                                               torch.zeros(batch, 3), torch.tensor([0.0, 1.0, 0.0]), lp, li, w, h,
+                                               specular_colors=ks, shininess_coefficients=5.0))
+        finally:
+            ext.FUSE_SPECULAR_NORMS = True
+    np.testing.assert_allclose(images[0].cpu().numpy(), images[1].cpu().numpy(), atol=2e-5, rtol=0)
+
+
 def test_specular_backward_gather_matches_scatter(device):
     """mr_shade_specular_backward with the CSR vertex adjacency (per-vertex gather, what render() uses
     since round 3) vs without it (float-atomic scatter), per-vertex shininess included."""
