@@ -738,6 +738,9 @@ struct RasterShade {
 #ifndef MR_RASTER_INTERP_STAGE
 #define MR_RASTER_INTERP_STAGE 1   // see stage_slot in k_raster
 #endif
+#ifndef MR_RASTER_NORMS_WAVES
+#define MR_RASTER_NORMS_WAVES 6   // whole call at 1024^2 x 32: 4 -> 0.254, 5 -> 0.233, 6 -> 0.228 ms (same box)
+#endif
 #ifndef MR_RASTER_INTERP_WAVES
 #define MR_RASTER_INTERP_WAVES 5
 #endif
@@ -746,7 +749,7 @@ struct RasterShade {
 // epilogue then reads its winners' records per lane from LDS there too instead of one winner at a time through the scalar
 // cache.  64 slots = 7 KB more LDS: five workgroups per CU instead of six.  Chosen on the host (launch_k_raster_probe).
 template <int R, int PROBE, bool SHADE, int INTERP = 0, int AX = 0, int XREC = 0, bool NORMS = false>
-__global__ __launch_bounds__(kThreads, SHADE ? (XREC ? MR_RASTER_XREC_WAVES : MR_RASTER_SHADE_WAVES) : INTERP >= 12 ? 4 : INTERP ? MR_RASTER_INTERP_WAVES : MR_RASTER_WAVES) void k_raster(
+__global__ __launch_bounds__(kThreads, SHADE ? (XREC ? MR_RASTER_XREC_WAVES : MR_RASTER_SHADE_WAVES) : NORMS ? MR_RASTER_NORMS_WAVES : INTERP >= 12 ? 4 : INTERP ? MR_RASTER_INTERP_WAVES : MR_RASTER_WAVES) void k_raster(
     const TriRec *__restrict__ recs, const TriBox *__restrict__ bbs,
     const float *__restrict__ pxtab, const float *__restrict__ pytab, int T, int W, int H,
     int regions_x, int regions_per_image, int n_regions, int regions_per_xcd,
