@@ -357,6 +357,45 @@ def extra_legs(job, device, batch, width, height):
                              "mean() + backward to the vertices (tools/soft_bench.py's step)", "ms_per_step": round(ms5, 4),
                      "Mpixels_per_s": round(16 * 512 * 512 / ms5 / 1e3, 1)}
     out["configs"] = configs
+    torch.cuda.empty_cache()
+
+    # (e) the other two entry points of SURVEY.md 8 at the headline shape (builder-run until now):
+    # render() with the specular term, the loop as the reference writes it; rasterize() with nine attributes
+    v = job["vertices"].to(device).requires_grad_(True)
+    tri, nrm, kd = job["triangles"].to(device), job["normals"].to(device), job["diffuse"].to(device)
+    ks = torch.full_like(kd, 0.5)
+    eyes, zero, up = job["eyes"], torch.zeros_like(job["eyes"]), torch.tensor([0.0, 1.0, 0.0])
+    lp, li = job["light_positions"].to(device), job["light_intensities"].to(device)
+    with torch.no_grad():
+        target = torch.rand(batch, height, width, 4, device=device)
+
+    def step_spec():
+        v.grad = None
+        image = mesh_renderer.render(v, tri, nrm, kd, eyes, zero, up, lp, li, width, height, specular_colors=ks,
+                                     shininess_coefficients=6.0)
+        torch.mean(torch.abs(image - target)).backward()
+    ms = _loop_ms(step_spec, 30)
+    out["specular"] = {"what": "render() with specular_colors / shininess 6, torch.mean(torch.abs(image - target)), backward to the "
+                               "vertices (tools/specular_bench.py's step)", "ms_per_step": round(ms, 4), "Mpixels_per_s": value(ms)}
+    del target
+    attrs = torch.rand(batch, v.shape[1], 9, device=device, requires_grad=True)
+    proj = synthetic.clip_transforms(job["eyes"], width, height).to(device)
+    background = torch.full((9,), -1.0, device=device)
+    upstream = torch.randn(batch, height, width, 9, device=device) / (px * 9)
+
+    def forward_a9():
+        with torch.no_grad():
+            mesh_renderer.rasterize(v, attrs, tri, proj, width, height, background)
+
+    def step_a9():
+        v.grad = None
+        attrs.grad = None
+        mesh_renderer.rasterize(v, attrs, tri, proj, width, height, background).backward(gradient=upstream)
+    ms_f, ms_fb = _loop_ms(forward_a9, 30), _loop_ms(step_a9, 30)
+    out["rasterize_a9"] = {"what": "mesh_renderer.rasterize() with nine attributes: forward alone, and forward + backward to vertices and "
+                                   "attributes with a given upstream gradient (tools/rasterize_bench.py)",
+                           "ms_forward": round(ms_f, 4), "ms_forward_backward": round(ms_fb, 4),
+                           "forward_frac_of_hbm_peak": round(px * 52 / (ms_f * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
     return out
 
 
