@@ -205,19 +205,20 @@ class RotatingImageGather:
     link and direction, against a 0.65 ms render step -- the node would run at a third of N x one GPU (DESIGN.md section
     6).  With the root rotating, every link carries one shard per N steps.  And instead of N concurrent gathers on N
     communicators, the exchange is ONE balanced collective per block of N steps on the default communicator: every
-    rank keeps its last N steps' frames in a staging buffer [N, B_local, H, W, C] -- slot j = the frames of the block's
-    step j -- and one all_to_all_single sends slot j to rank j: afterwards rank j holds [N, B_local, ...] = the global
-    batch of step (block * N + j).  Per step and link that is 1/N of a shard (17 MB of 8-bit frames at N = 8: 0.22 ms),
+    rank keeps the frames of its last N steps (the tensors themselves: no staging copy) and one all_to_all sends the
+    frames of the block's step j to rank j, which receives that step's shard from every rank straight into its
+    [B_total, H, W, C] buffer.  Per step and link that is 1/N of a shard (17 MB of 8-bit frames at N = 8: 0.22 ms),
     all N (N - 1) links busy at once, one collective per N steps, on a side stream under the next block's compute.
 
-    start(local, transform)  stages this step's frames (on the side stream) and, when the block is full, issues the
-                             exchange; at most `depth` exchanges may be in flight (wait() first, as with ImageGather).
+    start(local, transform)  keeps this step's frames and, when the block is full, issues the exchange; at most
+                             `depth` exchanges may be in flight (wait() first, as with ImageGather).
     wait()                   the OLDEST exchange in flight -> (step, images [B_total, H, W, C]) for the step this rank
                              roots in that block, or None if the block ended before that step (a drained tail).
                              The tensor is one of depth + 1 receive buffers used in turn.
     drain()                  flushes a partly filled block, then wait()s for everything; results oldest first.
     in_flight()              exchanges in flight.
-    Latency: a step's frames reach their root up to N steps later than with a per-step gather."""
+    Latency: a step's frames reach their root up to N steps later than with a per-step gather; a rank holds the
+    frames of up to N steps (plus those of the exchanges in flight)."""
 
     def __init__(self, n_total, group=None, depth=2, force_collective=False):
         """force_collective: run the collective even in a 1-rank group (smoke tests of the RCCL / side-stream path on a
@@ -231,20 +232,11 @@ class RotatingImageGather:
         self.n_total = n_total
         self.counts = [shard_bounds(n_total, r, self.world)[1] - shard_bounds(n_total, r, self.world)[0]
                        for r in range(self.world)]
-        self.max_count = max(self.counts)
-        self._pending = collections.deque()   # (event or None, receive buffer, first step of the block, steps in it)
-        self._stage, self._recv = {}, {}      # per (shape, dtype, device): depth + 1 buffers each, used in turn
-        self._block, self._filled, self._key = 0, 0, None
+        self._pending = collections.deque()   # (event or None, receive buffer, first step of the block, steps in it, sent tensors)
+        self._recv = {}                       # per (shape, dtype, device): depth + 1 receive buffers, used in turn
+        self._held = []                       # this block's frames so far, one tensor per step
+        self._block = 0
         self._side = None
-
-    def _buffers(self, table, key):
-        ring = table.get(key)
-        if ring is None:
-            shape, dtype, device = key
-            # (zeros: the padding rows of an uneven shard are sent along)
-            ring = table[key] = [torch.zeros((self.world, self.max_count) + shape, dtype=dtype, device=device)
-                                 for _ in range(self.depth + 1)]
-        return ring[self._block % (self.depth + 1)]
 
     def in_flight(self):
         return len(self._pending)
@@ -252,7 +244,7 @@ class RotatingImageGather:
     def start(self, local, transform=None):
         if local.shape[0] != self.counts[self.rank]:
             raise ValueError("rank %d holds %d images, expected %d" % (self.rank, local.shape[0], self.counts[self.rank]))
-        closes_block = self._filled + 1 == self.world
+        closes_block = len(self._held) + 1 == self.world
         if closes_block and len(self._pending) >= self.depth:
             raise RuntimeError("%d exchange(s) already in flight (depth %d): call wait() first"
                                % (len(self._pending), self.depth))
@@ -268,29 +260,36 @@ class RotatingImageGather:
                 send = transform(local).detach()     # (the tensor itself: it may carry ready-made frames)
             else:
                 send = local.detach()
+            send = send.contiguous()
             if on_gpu:
-                # the staging copy below reads `send` on the side stream, possibly long after the caller dropped it (the
-                # side stream may sit behind an exchange): the caching allocator must not hand its memory out before
+                # read by the exchange on the side stream, possibly long after the caller dropped its own reference
                 send.record_stream(self._side)
-            key = (tuple(send.shape[1:]), send.dtype, send.device)
-            if self._filled and key != self._key:
+            if self._held and (send.shape != self._held[0].shape or send.dtype != self._held[0].dtype):
                 raise ValueError("the frames of one block must have one shape and dtype")
-            self._key = key
-            self._buffers(self._stage, key)[self._filled, :send.shape[0]].copy_(send)
-            self._filled += 1
+            self._held.append(send)
             if closes_block:
                 self._exchange()
 
     def _exchange(self):
-        """(on the side stream) slot j of the staging buffer -> rank j; this rank receives its step's shard from everyone."""
-        key = self._key
-        inp, out = self._buffers(self._stage, key), self._buffers(self._recv, key)
+        """(on the side stream) this block's step-j frames -> rank j; this rank receives its step's shard from everyone."""
+        held, n_steps = self._held, len(self._held)
+        key = (tuple(held[0].shape[1:]), held[0].dtype, held[0].device)
+        ring = self._recv.get(key)
+        if ring is None:
+            ring = self._recv[key] = [torch.empty((self.n_total,) + key[0], dtype=key[1], device=key[2])
+                                      for _ in range(self.depth + 1)]
+        out = ring[self._block % len(ring)]
+        outs = list(out.split(self.counts, 0))                       # from rank r: its counts[r] images
+        # a tail block has no frames for steps >= n_steps: their roots are sent the last step's again and ignore them
+        inputs = [held[j] if j < n_steps else held[n_steps - 1] for j in range(self.world)]
         if self.world == 1 and not self.force:
-            out.copy_(inp)
+            outs[0].copy_(inputs[0])
         elif dist.get_backend(self.group) == "gloo":
-            # (the CPU tests' backend has no all_to_all: the same exchange as non-blocking sends and receives)
-            # (device tensors -- a rehearsal of N ranks on fewer GPUs, MR_DIST_BACKEND=gloo -- travel through the host)
-            src, dst = (inp.cpu(), torch.empty(out.shape, dtype=out.dtype)) if inp.is_cuda else (inp, out)
+            # (the CPU tests' backend has no all_to_all: the same exchange as non-blocking sends and receives; device
+            #  tensors -- a rehearsal of N ranks on fewer GPUs, MR_DIST_BACKEND=gloo -- travel through the host)
+            on_gpu = inputs[0].is_cuda
+            src = [t.cpu() for t in inputs] if on_gpu else inputs
+            dst = [torch.empty(o.shape, dtype=o.dtype) for o in outs] if on_gpu else outs
             dst[self.rank].copy_(src[self.rank])
             requests = []
             for r in range(self.world):
@@ -299,45 +298,39 @@ class RotatingImageGather:
                     requests.append(dist.irecv(dst[r], r, group=self.group, tag=self._block))
             for q in requests:
                 q.wait()
-            if dst is not out:
-                out.copy_(dst)
+            if on_gpu:
+                for o, d in zip(outs, dst):
+                    o.copy_(d)
         else:
-            dist.all_to_all_single(out, inp, group=self.group)
+            dist.all_to_all(outs, inputs, group=self.group)
         done = None
-        if inp.is_cuda:
+        if out.is_cuda:
             done = torch.cuda.Event()
             done.record(self._side)
-        self._pending.append((done, out, self._block * self.world, self._filled))
+        # (the sent tensors ride along until the exchange is waited for)
+        self._pending.append((done, out, self._block * self.world, n_steps, inputs))
         self._block += 1
-        self._filled = 0
+        self._held = []
 
     def wait(self):
         if not self._pending:
             return None
-        done, out, first, n_steps = self._pending.popleft()
+        done, out, first, n_steps, _sent = self._pending.popleft()
         if done is not None:
             torch.cuda.current_stream().wait_event(done)
         if self.rank >= n_steps:       # (a drained tail: the block ended before this rank's step)
             return None
         if out.is_cuda:
             out.record_stream(torch.cuda.current_stream(out.device))
-        if all(c == self.max_count for c in self.counts):
-            images = out.reshape((self.world * self.max_count,) + tuple(out.shape[2:]))
-        else:
-            images = torch.cat([out[r, :c] for r, c in enumerate(self.counts)], 0)
-        return first + self.rank, images
+        return first + self.rank, out
 
     def drain(self):
-        if self._filled:
+        first = []
+        if self._held:
             if len(self._pending) >= self.depth:
-                first = [self.wait()]
-            else:
-                first = []
-            ctx = torch.cuda.stream(self._side) if self._side is not None else _NullContext()
-            with ctx:
+                first.append(self.wait())
+            with (torch.cuda.stream(self._side) if self._side is not None else _NullContext()):
                 self._exchange()
-        else:
-            first = []
         while self._pending:
             first.append(self.wait())
         return first
