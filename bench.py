@@ -21,7 +21,7 @@ finished images of EVERY step are handed over over RCCL, overlapping the loss, t
 next forwards: as 8-bit frames (--handover u8, default: mesh_renderer.to_uint8, the conversion the
 reference's examples apply before writing a frame) or as the fp32 images (--handover f32, 4x the bytes).
 --gather rotate (default, round 5): the global batch of step s is assembled on rank s mod N -- one balanced
-all_to_all_single per block of N steps, every xGMI link in use (distributed.RotatingImageGather);
+all_to_all per block of N steps, every xGMI link in use (distributed.RotatingImageGather);
 --gather root: on rank 0 every step (one gather per step; bound by rank 0's N - 1 inbound links).
 
 Extra objects in the line:
@@ -429,7 +429,7 @@ def main():
                          "(ms_per_step_handover_f32 / value_handover_f32)")
     ap.add_argument("--gather", choices=("rotate", "root"), default="rotate",
                     help="N > 1: where a step's frames are assembled -- rotate (default): the global batch of step s on rank "
-                         "s mod N, one all_to_all_single per N steps, every xGMI link used (distributed.RotatingImageGather); "
+                         "s mod N, one all_to_all per N steps, every xGMI link used (distributed.RotatingImageGather); "
                          "root: every step's frames on rank 0, one gather per step, bound by rank 0's N - 1 inbound links")
     ap.add_argument("--extras", type=int, default=1,
                     help="0: skip the legs that run after the timed region (other spellings, gradient sets, configurations)")
@@ -472,7 +472,7 @@ def main():
                                              **({"device_id": device} if backend == "nccl" else {}))
     grouped = world > 1 or forced
     # N > 1 (round 5): the root ROTATES -- step s's global batch is assembled on rank s mod N, one balanced
-    # all_to_all_single per block of N steps -- unless --gather root asks for rank 0 every step
+    # all_to_all per block of N steps -- unless --gather root asks for rank 0 every step
     rotating = grouped and args.gather == "rotate"
     if rotating:
         gather = distributed.RotatingImageGather(batch * world, depth=2, force_collective=forced)
@@ -674,7 +674,7 @@ def main():
             line["value_render_only"] = round(world * px / render_only_ms / 1e3, 2)
             if rotating:
                 line["rccl"]["gather"] = ("rotating root: the frames of step s (global batch) land on rank s mod N; one "
-                                          "all_to_all_single per block of N steps on a side stream, depth 2")
+                                          "all_to_all per block of N steps on a side stream, depth 2")
                 # what every rank sends (and receives) per second while the timed loop runs: (N - 1) / N of a shard per step,
                 # spread over its N - 1 links
                 line["handover_GBps_out_of_each_rank"] = round(
