@@ -443,7 +443,7 @@ def test_bench_rank_path_meets_rccl_on_one_gpu(device, handover, gather):
     side-stream hand-over, gather.wait() inside the timed loop, the render-only loop after it -- under
     a 1-rank RCCL group (MR_BENCH_FORCE_GROUP=1): the line names the backend and the rank count that
     torch.distributed reports, and carries both per-step figures.  gather = rotate: bench.py's default at N > 1
-    (distributed.RotatingImageGather: staging on the side stream + all_to_all on RCCL); root: one gather per step."""
+    (distributed.RotatingImageGather: the side-stream bookkeeping + all_to_all on RCCL); root: one gather per step."""
     import json
     import os
     import subprocess
