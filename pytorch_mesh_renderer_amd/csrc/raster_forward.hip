@@ -738,6 +738,9 @@ struct RasterShade {
 #ifndef MR_RASTER_INTERP_STAGE
 #define MR_RASTER_INTERP_STAGE 1   // see stage_slot in k_raster
 #endif
+#ifndef MR_RASTER_RGBA8_NT
+#define MR_RASTER_RGBA8_NT 0   // the 8-bit frames' store policy: no measurable difference (same-box A/B, step and kernel)
+#endif
 #ifndef MR_RASTER_NORMS_WAVES
 #define MR_RASTER_NORMS_WAVES 6   // whole call at 1024^2 x 32: 4 -> 0.254, 5 -> 0.233, 6 -> 0.228 ms (same box)
 #endif
@@ -1430,7 +1433,10 @@ __global__ __launch_bounds__(kThreads, SHADE ? (XREC ? MR_RASTER_XREC_WAVES : MR
             auto u8 = [](float v) { return (unsigned)(fminf(fmaxf(v, 0.0f), 1.0f) * 255.0f); };  // NaN -> 0
             const unsigned packed = u8(rgba.x) | (u8(rgba.y) << 8) | (u8(rgba.z) << 16) | (u8(rgba.w) << 24);
             const int y = Y0 + ty * kTileH + ly, x = X0 + tx * kTileW + lx;
-            __builtin_nontemporal_store(packed, &shade.rgba8[img_px + (size_t)(H - 1 - y) * W + x]);
+            // (through the caches, like the id plane -- MR_RASTER_STORE_AUX_IDS: a tile row is a 64-byte run, half a line,
+            //  and the neighbouring tile's half arrives from another wavefront; nontemporal, the halves reached memory apart)
+            if (MR_RASTER_RGBA8_NT) __builtin_nontemporal_store(packed, &shade.rgba8[img_px + (size_t)(H - 1 - y) * W + x]);
+            else shade.rgba8[img_px + (size_t)(H - 1 - y) * W + x] = packed;
           }
         }
       }
