@@ -127,6 +127,11 @@ struct SetupAttributes {
   FoldRec *__restrict__ fold_recs;
   float4 *__restrict__ fold_acc;   // [B*T][kFoldAccStride / 4]
   const float *__restrict__ fold_transforms;   // [B,4,4] (with fold_recs): the records carry the pulled form (corner_rec.h)
+  // Round 5 (with `positions`): the clip-space transform of render() happens HERE -- vertex thread gid writes clip_out[gid],
+  // and a triangle's thread transforms its own three corners (k_vertex_transform's expression, the same bits) instead of
+  // waiting for a launch of its own to have written them: one launch and one dependent round trip less per step.
+  const float4 *__restrict__ xf = nullptr;     // [B][4] rows of the clip-space transforms, or nullptr: `clip` is an input
+  float4 *__restrict__ clip_out = nullptr;     // [B,V,4]
 };
 
 // Heaviest regions first (round 3).  k_raster's workgroups cost anything between ~5 us (background)
@@ -141,19 +146,29 @@ __device__ __forceinline__ int region_weight_class(int count) {  // 0 = heaviest
   return min(kWeightClasses - 2, 8 - (32 - __builtin_clz((unsigned)count)));  // 128.. -> 1, 64.. -> 2, ..., 1..7 -> 6
 }
 
+__device__ __forceinline__ float4 clip_of(const F3 p, const float4 *__restrict__ rows) {   // k_vertex_transform's expression
+  float o[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float4 m = rows[r];
+    o[r] = ((m.x * p.x + m.y * p.y) + m.z * p.z) + m.w;
+  }
+  return make_float4(o[0], o[1], o[2], o[3]);
+}
+
 __global__ __launch_bounds__(kThreads) void k_setup(
     const float4 *__restrict__ clip, const int32_t *__restrict__ tris, int B, int V, int T,
     int W, int H, TriRec *__restrict__ recs, TriBox *__restrict__ bbs,
     float *__restrict__ pxtab, float *__restrict__ pytab, const SetupAttributes attrs,
-    int32_t *__restrict__ order_count) {
+    int32_t *__restrict__ order_count, long n_main) {
   const long gid = (long)blockIdx.x * kThreads + threadIdx.x;
   if (gid < kXcds * kWeightClasses) order_count[gid] = 0;  // k_coarse counts into it (a later kernel on the stream)
   const long nbt = (long)B * T;
   const float hw = (float)(0.5 * (double)W);  // cpp:309
   const float hh = (float)(0.5 * (double)H);  // cpp:310
-  if (gid >= nbt) {
+  if (gid >= n_main) {   // (n_main = max(B T, B V with attrs.xf): the threads behind fill the tables)
     // pixel-centre tables: binary64 expression, one rounding (cpp:376-377)
-    const long k = gid - nbt;
+    const long k = gid - n_main;
     if (k < W) {
       pxtab[k] = (float)(((double)k + 0.5) / (double)hw - 1.0);
     } else if (k < (long)W + H) {
@@ -162,6 +177,9 @@ __global__ __launch_bounds__(kThreads) void k_setup(
     }
     return;
   }
+  if (attrs.xf && gid < (long)B * V)   // launch-uniform pointer: this thread's vertex
+    attrs.clip_out[gid] = clip_of(attrs.positions[gid], attrs.xf + (size_t)(gid / V) * 4);
+  if (gid >= nbt) return;
   const int b = (int)(gid / T);
   const int t = (int)(gid - (long)b * T);
   float corner_values[32];
@@ -179,9 +197,17 @@ __global__ __launch_bounds__(kThreads) void k_setup(
   const int i0 = tris[3 * t + 0], i1 = tris[3 * t + 1], i2 = tris[3 * t + 2];
   TriBox bb{0u, 0u, -INFINITY, 0u};
   if ((unsigned)i0 < (unsigned)V && (unsigned)i1 < (unsigned)V && (unsigned)i2 < (unsigned)V) {
-    const float4 p0 = clip[(long)b * V + i0];
-    const float4 p1 = clip[(long)b * V + i1];
-    const float4 p2 = clip[(long)b * V + i2];
+    float4 p0, p1, p2;
+    if (attrs.xf) {   // (the same bits clip_out gets: one expression, no contraction in this file)
+      const float4 *rows = attrs.xf + (size_t)b * 4;
+      p0 = clip_of(attrs.positions[(long)b * V + i0], rows);
+      p1 = clip_of(attrs.positions[(long)b * V + i1], rows);
+      p2 = clip_of(attrs.positions[(long)b * V + i2], rows);
+    } else {
+      p0 = clip[(long)b * V + i0];
+      p1 = clip[(long)b * V + i1];
+      p2 = clip[(long)b * V + i2];
+    }
     const float w0 = p0.w, w1 = p1.w, w2 = p2.w;
     if (!(w0 < 0 && w1 < 0 && w2 < 0)) {  // cpp:339
       // rows of M: x, y, w; columns: the three corners (cpp:350-353)
@@ -737,6 +763,9 @@ struct RasterShade {
 #endif
 #ifndef MR_RASTER_INTERP_STAGE
 #define MR_RASTER_INTERP_STAGE 1   // see stage_slot in k_raster
+#endif
+#ifndef MR_SETUP_TRANSFORMS
+#define MR_SETUP_TRANSFORMS 1   // render()'s clip-space transform inside k_setup (0: its own launch, k_vertex_transform)
 #endif
 #ifndef MR_RASTER_RGBA8_NT
 #define MR_RASTER_RGBA8_NT 0   // the 8-bit frames' store policy: no measurable difference (same-box A/B, step and kernel)
@@ -1856,10 +1885,11 @@ int raster_forward(const float *clip, const int32_t *tris, int B, int V, int T, 
   int32_t *top_ids = top ? (int32_t *)p : nullptr;
   int32_t *top_counts = top ? (int32_t *)(p + align_up((size_t)sc_per_image * B * T * sizeof(int32_t), 256)) : nullptr;
 
-  const long setup_threads = (long)nbt + W + H;
+  const long n_main = (attrs.xf && (long)B * V > (long)nbt) ? (long)B * V : (long)nbt;
+  const long setup_threads = n_main + W + H;
   const unsigned setup_blocks = (unsigned)((setup_threads + kThreads - 1) / kThreads);
   hipLaunchKernelGGL(k_setup, dim3(setup_blocks), dim3(kThreads), 0, s, (const float4 *)clip, tris,
-                     B, V, T, W, H, recs, bbs, pxtab, pytab, attrs, order_count);
+                     B, V, T, W, H, recs, bbs, pxtab, pytab, attrs, order_count, n_main);
   int rc = check_launch();
   if (rc != MR_OK) return rc;
   if (B == 0) return MR_OK;
@@ -2037,22 +2067,29 @@ int launch_render_forward(const float *vertices, const float *transforms, const 
                           int L, float *clip, int32_t *ids, float *bary, float *z, int want_z, float *rgba,
                           uint8_t *rgba_u8, void *corner_records, void *backward_prepared, uint8_t *empty_regions, void *ws,
                           hipStream_t s) {
-  const int rc = launch_vertex_transform(vertices, transforms, B, V, clip, s);
-  if (rc != MR_OK) return rc;
+  if ((size_t)B * W * H == 0 || !MR_SETUP_TRANSFORMS)   // (no pixels: the setup kernel does not run; the clip-space vertices are still an output)
+  {
+    const int rc = launch_vertex_transform(vertices, transforms, B, V, clip, s);
+    if (rc != MR_OK) return rc;
+  }
   if (empty_regions && region_edge(B, W, H) != 64 && (size_t)B * W * H > 0) {   // 32-pixel regions (small launches): nothing is flagged
     if (zero_async(empty_regions, (size_t)B * ((H + 63) / 64) * ((W + 63) / 64), s) != hipSuccess) return check_launch();
   }
   if ((size_t)B * W * H == 0) return MR_OK;
   CornerRec *corners = (CornerRec *)corner_records;
+  SetupAttributes setup{(const F3 *)normals, (const F3 *)vertices, (const F3 *)diffuse, corners,
+                        (FoldRec *)backward_prepared,
+                        backward_prepared ? (float4 *)((char *)backward_prepared + fold_prepared_recs_bytes(B, T))
+                                          : nullptr,
+                        transforms};
+  if (MR_SETUP_TRANSFORMS) {   // the clip-space transform rides k_setup (SetupAttributes::xf)
+    setup.xf = (const float4 *)transforms;
+    setup.clip_out = (float4 *)clip;
+  }
   return raster_forward(clip, tris, B, V, T, W, H, ids, bary, z,
                         RasterShade{corners, Lights{light_pos, light_col, ambient, L}, rgba, (uint32_t *)rgba_u8, want_z, nullptr,
                                     nullptr, nullptr, 0, region_edge(B, W, H) == 64 ? empty_regions : nullptr},
-                        SetupAttributes{(const F3 *)normals, (const F3 *)vertices, (const F3 *)diffuse, corners,
-                                        (FoldRec *)backward_prepared,
-                                        backward_prepared ? (float4 *)((char *)backward_prepared + fold_prepared_recs_bytes(B, T))
-                                                          : nullptr,
-                                        transforms},
-                        ws, s);
+                        setup, ws, s);
 }
 
 }  // namespace mr
