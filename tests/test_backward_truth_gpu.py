@@ -176,13 +176,56 @@ def test_recorded_fuzz_failure_is_adjudicated_against_float64(device):
     assert report.with_gradients == 1
 
 
+def test_fuzz_harness_reports_a_changed_input_and_leaves_its_evidence(device, tmp_path, monkeypatch):
+    """The harness's own plumbing (round 6): a device input that changes under the backward calls -- here a vertex
+    normal, edited after the first call by a wrapper standing in for a stray write -- is reported BY NAME, the kernels
+    that ran after it are beyond the bound, and the case's inputs, truth and outputs are in the .npz the message names."""
+    import numpy as np
+    real = _native.shade_specular_backward
+    calls = []
+
+    def stray_write(*args, **kw):
+        out = real(*args, **kw)
+        if not calls:
+            args[4][0, :, :] += 3.0          # normals of image 0, after the rows kernel's call
+        calls.append(1)
+        return out
+    monkeypatch.setattr(_native, "shade_specular_backward", stray_write)
+    report = backward_fuzz.Report(dump_dir=str(tmp_path))
+    rng = np.random.default_rng(11)
+    backward_fuzz.specular_trial(rng, 0, report, small=True)
+    text = "\n".join(report.failures)
+    assert "DEVICE INPUT `normals` CHANGED under the backward calls" in text, text
+    assert "SpecFoldLaneFn" in text and "SpecGradFn" not in text.split("DEVICE INPUT")[0], text   # rows ran before the write
+    assert len(report.dumps) == 1 and report.dumps[0] in text
+    with np.load(report.dumps[0]) as z:
+        names = set(z.files)
+        assert {"in/normals", "in_after/normals", "in/upstream", "in/ids", "truth/d_vertices"} <= names, sorted(names)
+        assert any(n.startswith("out/SpecGradFn") for n in names) and any(n.startswith("out/SpecFoldLaneFn") for n in names)
+        assert not np.array_equal(z["in/normals"], z["in_after/normals"])
+    # ... and an input that is not what the truth was computed from is caught before any kernel runs
+    report2 = backward_fuzz.Report(dump_dir=str(tmp_path))
+    monkeypatch.setattr(_native, "shade_specular_backward", real)
+    real_forward = _native.shade_specular_forward
+
+    def late_edit(ids, bary, *rest, **kw):
+        out = real_forward(ids, bary, *rest, **kw)
+        if kw.get("norms2") is not None:      # the harness's last forward call: edit one barycentric afterwards
+            bary[0, 0, 0, 0] += 0.25
+        return out
+    monkeypatch.setattr(_native, "shade_specular_forward", late_edit)
+    backward_fuzz.specular_trial(np.random.default_rng(11), 0, report2, small=True)
+    assert any("`bary` is not what the truth was computed from" in f for f in report2.failures), report2.failures
+
+
 @pytest.mark.parametrize("which,trials", [("shade", 200), ("specular", 200), ("attr", 200)])
 def test_backward_kernels_against_float64_on_random_soups(device, which, trials):
     """A fixed-seed slice of the stand-alone fuzzers inside the suite: every pixel-pass variant of the three backward
     entry points on random soups (slivers, one-pixel triangles, crowded and ragged images), each within
-    backward_fuzz.K_ROUNDING * 2^-24 * (sum of |terms|) of the float64 truth."""
+    backward_fuzz.K_ROUNDING * 2^-24 * (sum of |terms|) of the float64 truth.  No retries: a trial beyond the bound
+    fails the test and leaves its inputs, the truth and every kernel's outputs in an .npz (backward_fuzz.Evidence)."""
     fn = {"shade": backward_fuzz.shade_trial, "specular": backward_fuzz.specular_trial, "attr": backward_fuzz.attr_trial}[which]
-    report = backward_fuzz.run(fn, trials, seed=505, small=True, retry_failed_trials=True)
+    report = backward_fuzz.run(fn, trials, seed=505, small=True)
     print("%s: %d trials (%d with gradients); excess over the rounding bound per kernel: %s" % (
         which, report.trials, report.with_gradients, report.summary()))
     assert not report.failures, "%d failures, first: %s" % (len(report.failures), "\n".join(report.failures[:5]))
