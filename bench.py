@@ -161,6 +161,7 @@ def make_step(job, device, gather, handover="u8", spelling="l1_loss", all_gradie
         target = mesh_renderer.render(vertices @ rot.T, tri, normals @ rot.T, diffuse, eyes, center, up,
                                       lpos, lint, width, height)
     state["target"] = target
+    mesh_renderer.losses.remember_target(target)   # a fixed target: its empty-block map is made once (losses.l1_loss, TARGET)
 
     def step():
         for leaf in leaves:

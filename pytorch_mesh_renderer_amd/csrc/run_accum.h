@@ -493,6 +493,11 @@ __global__ __launch_bounds__(kRowsThreads, Fn::kMinWavesPerSimd) void k_accumula
 #ifndef MR_LANES_MERGE_SLOTS
 #define MR_LANES_MERGE_SLOTS 16
 #endif
+#ifndef MR_LANES_SPARSE_ATOMICS
+#define MR_LANES_SPARSE_ATOMICS 1   // round 6: a FEW finished lanes (fewer than MR_LANES_DENSE: a triangle changed under them
+                                    // inside the strip) commit their own sums straight to the accumulator rows -- N no-return
+                                    // atomics under the finished lanes' mask -- instead of parking them for the scalar walk
+#endif
 
 constexpr int lanes_park_stride(int n) {  // multiple of 4 with an odd number of quads: per-lane b128 accesses are conflict-free
   int s = (n + 3) / 4;
@@ -600,6 +605,26 @@ __global__ __launch_bounds__(kWave, Fn::kMinWavesPerSimd) void k_accumulate_lane
     const unsigned long long finm = __ballot(fin);
     if (!finm) return;
     const bool dense = (int)__builtin_popcountll(finm) >= kDense;  // wave-uniform
+#if MR_LANES_SPARSE_ATOMICS
+    if (!dense) {
+      // the in-strip run ends: ~3 lanes of 64 per row.  Their walk through LDS (park, one scalar trip per finished lane
+      // with a readlane, a merge-table lookup per segment, a store per segment) was ~60 vector and ~50 scalar
+      // instructions per row for sums that meet nothing in the merge table most of the time; N atomics issued once
+      // under the finished lanes' mask are N + 2 instructions, return nothing and wait for nothing.
+      if (fin) {
+        const size_t row = (size_t)run_tri * STRIDE;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+          if (DET) atomic_add_fixed(&acc_fixed[row + Fn::column(k)], a[k], to_fixed, det_overflow_flag(det_scale));
+          else atomicAdd(&acc_img[row + Fn::column(k)], a[k]);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < N; ++k) a[k] = fin ? 0.0f : a[k];
+      if (fin) run_tri = -1;
+      return;
+    }
+#endif
     {
       float4 *dst = (float4 *)(s_park + lane * P);
       auto quad = [&](const int q) {

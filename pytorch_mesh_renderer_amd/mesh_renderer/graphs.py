@@ -10,6 +10,14 @@ The C ABI underneath neither allocates nor synchronises, so everything render() 
 be captured is host-side work: cameras must be DEVICE tensors (host cameras are turned into matrices on the host and
 uploaded: a capture would bake that one upload's values in), and Python-side decisions (which kernel variant, which
 tensors require grad) are those of the capture.
+
+Known limitations (round 5's two HIP-graph anomalies; tools/graph_memset_repro.py and DESIGN.md section 4.7):
+ * the library issues NO memset nodes: a captured hipMemsetAsync of a small buffer wrote 0xC6 on a later replay once
+   eager work had run in between, so every zero-fill is a kernel node (arguments by value).  Whether that was the
+   memset node or pool memory handed out again underneath it was not established by round 5; until it is, keep the
+   CapturedStep alive for as long as it is replayed and do not call torch.cuda.empty_cache() between replays.
+ * capture ONE stream: a step that forks to other streams inside the capture (tools/overlap_probe.py's four lockstep
+   chunks) crashed inside hipGraph capture; render()/loss/backward as written here stay on the current stream.
 """
 import torch
 

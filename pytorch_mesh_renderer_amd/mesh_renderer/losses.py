@@ -33,8 +33,16 @@ import os
 USE_FUSED_RENDER_LOSS = os.environ.get("MR_FUSED_RENDER_LOSS", "1") != "0"   # False: always the generic op (dense gradient image)
 
 
+def remember_target(target):
+    """Opt-in for a FIXED loss target (an optimisation loop compares every step's render with the same image): finds
+    which 64 x 64 blocks of `target` are all zeros, once, and keeps that map on the tensor; see l1_loss, TARGET."""
+    from .rasterize_triangles_ext import remember_target_map
+    remember_target_map(target)
+    return target
+
+
 def forget_target(target):
-    """Drops what l1_loss keeps on a target tensor (its empty-block map); see l1_loss, TARGET."""
+    """Drops remember_target's map."""
     from .rasterize_triangles_ext import forget_target_map
     forget_target_map(target)
 
@@ -52,12 +60,11 @@ def l1_loss(image, target):
     One hole remains: torch.autograd.backward(loss, inputs=[image]) spelled through the module function (not
     loss.backward(inputs=...), not torch.autograd.grad) is not seen; USE_FUSED_RENDER_LOSS = False for that.
 
-    TARGET: on that route the 64 x 64 blocks that are all zeros in BOTH images are not read (the renderer knows
-    its own; the target's map is found once per target tensor object and kept in a weak map, valid while its
-    data pointer, shape and autograd version counter stay the same).  Every in-place torch operation on the target
-    bumps that counter; a write that does not -- through `target.data`, DLPack, a raw pointer -- leaves a stale
-    map behind until the map's periodic refresh (every 64th use): call forget_target(target) after such a write,
-    set MR_DEBUG_EMPTY_REGIONS=1 to have every use checked, or MR_EMPTY_REGIONS=0 to switch the maps off."""
+    TARGET: on that route the 64 x 64 blocks that are all zeros in BOTH images are not read, if the caller has
+    named the target with remember_target(target): the renderer knows its own empty blocks, the target's map is made by
+    that call and used while the tensor's data pointer, shape and autograd version counter stay what they were (any
+    in-place torch operation on the target moves the counter: the loss then reads every block until the next
+    remember_target).  MR_EMPTY_REGIONS=0 switches the maps off."""
     if image.shape != target.shape:
         raise ValueError("image and target must have the same shape")
     if image.dtype != torch.float32 or target.dtype != torch.float32:

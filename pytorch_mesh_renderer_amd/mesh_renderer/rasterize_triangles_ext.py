@@ -307,83 +307,35 @@ def take_fused_render(image):
     return record
 
 
-# The loss target's empty-block map, kept per target tensor OBJECT (weakly: nothing is written onto the user's tensor,
-# the entry dies with it), valid while its data pointer, shape and autograd version counter stay what they were.
-# A write that bypasses the version counter (target.data, DLPack, a raw kernel) is not seen: every
-# _TARGET_MAP_REFRESH-th use recomputes the map anyway (one small kernel over the target), so a stale map heals
-# itself within that many steps; losses.forget_target(target) drops it at once, and MR_DEBUG_EMPTY_REGIONS=1
-# recomputes on EVERY use and raises if the kept map had gone stale (costs a device synchronisation per loss).
-class _WeakIdMap:
-    """Weak map keyed by object IDENTITY (a WeakKeyDictionary compares keys with ==, which tensors answer elementwise)."""
-
-    def __init__(self):
-        self._entries = {}
-
-    def get(self, obj):
-        entry = self._entries.get(id(obj))
-        return entry[1] if entry is not None and entry[0]() is obj else None
-
-    def set(self, obj, value):
-        key = id(obj)
-        self._entries[key] = (weakref.ref(obj, lambda _, key=key: self._entries.pop(key, None)), value)
-
-    def pop(self, obj):
-        entry = self._entries.get(id(obj))
-        if entry is not None and entry[0]() is obj:
-            del self._entries[id(obj)]
-
-    def __contains__(self, obj):
-        return self.get(obj) is not None
-
-    def __len__(self):
-        return len(self._entries)
-
-
-_target_maps = _WeakIdMap()
-_TARGET_MAP_REFRESH = 64
-_DEBUG_TARGET_MAPS = os.environ.get("MR_DEBUG_EMPTY_REGIONS", "0") == "1"
+# The loss target's empty-block map: only for a target the caller has NAMED with losses.remember_target(target)
+# (round 6).  Rounds 4-5 found the map by themselves on first use, kept it in an identity-keyed weak map and refreshed it
+# every 64th use against writes that bypass the version counter: more machinery than 5 us of a 650 us step deserve.
+# The map rides on the tensor object, like the adjacency on a triangle tensor, and is used while the tensor's data
+# pointer, shape and version counter are what they were when it was made; anything else -- another target, an in-place
+# torch write -- means no map, and the loss reads every block.  A write the counter does not see (target.data, DLPack,
+# a raw kernel) after remember_target is the caller's to follow with another remember_target / forget_target.
+def remember_target_map(target):
+    if target.dim() != 4 or target.shape[-1] != 4 or target.dtype != torch.float32 or not target.is_cuda:
+        raise ValueError("remember_target expects a [B, H, W, 4] float32 image on the GPU")
+    target._mr_empty_regions = ((target.data_ptr(), target._version, tuple(target.shape)),
+                                _native.image_empty_regions(target.detach()))
 
 
 def forget_target_map(target):
-    try:
-        _target_maps.pop(target)
-    except TypeError:
-        pass
+    if hasattr(target, "_mr_empty_regions"):
+        del target._mr_empty_regions
 
 
 def _target_empty_regions(target):
-    """image_empty_regions(target), kept per target tensor while its data pointer, shape and version do not change
-    (an optimisation loop compares every step's render with the same target)."""
-    if target.dim() != 4 or target.shape[-1] != 4 or target.dtype != torch.float32 or not target.is_cuda:
-        return None
-    key = (target.data_ptr(), target._version, tuple(target.shape))
-    try:
-        kept = _target_maps.get(target)
-    except TypeError:
-        kept = None
-    if kept is not None and kept[0] == key and not torch.cuda.is_current_stream_capturing():
-        kept[2] += 1
-        if _DEBUG_TARGET_MAPS:
-            found = _native.image_empty_regions(target.detach())
-            if not torch.equal(found, kept[1]):
-                raise RuntimeError("the kept empty-block map of this loss target is stale: the target was written without "
-                                   "its version counter moving (target.data / DLPack / a raw kernel); call "
-                                   "mesh_renderer.losses.forget_target(target) after such a write")
-        if kept[2] % _TARGET_MAP_REFRESH:
-            return kept[1]
-    elif kept is not None and kept[0] == key:
-        return kept[1]   # (inside a stream capture: no counting, the captured graph holds this map)
-    found = _native.image_empty_regions(target.detach())
-    if kept is not None and kept[1].shape == found.shape and kept[1].device == found.device:
-        # refreshed IN PLACE: a captured HIP graph that holds the kept map's address keeps reading a live, current map
-        kept[1].copy_(found)
-        kept[0] = key
+    kept = getattr(target, "_mr_empty_regions", None)
+    if kept is not None and kept[0] == (target.data_ptr(), target._version, tuple(target.shape)):
         return kept[1]
-    try:
-        _target_maps.set(target, [key, found, 0])
-    except TypeError:   # (an object that cannot be weakly referenced: recomputed per call)
-        pass
-    return found
+    return None
+
+
+def _hooks_of(image):
+    with torch._C.DisableTorchFunctionSubclass():
+        return image._backward_hooks
 
 
 class FusedPhongL1Loss(torch.autograd.Function):
@@ -402,13 +354,14 @@ class FusedPhongL1Loss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, image, target, vertices, transforms, normals, diffuse, light_positions,
                 light_intensities, ambient, render_saved, prepared_state=None, empty_regions=None):
-        # the renderer knows which 64 x 64 blocks of its image are empty; the target's are found once per target
-        # tensor (cached on it by value of its version counter): blocks empty on both sides are not read
+        # the renderer knows which 64 x 64 blocks of its image are empty; the target's are known if the caller named it
+        # (losses.remember_target): blocks empty on both sides are not read
         empty_target = _target_empty_regions(target) if empty_regions is not None else None
         loss, signs = _native.l1_loss_forward(image.detach(), target.detach(), want_signs=True,
                                               empty_a=empty_regions, empty_b=empty_target)
         ctx.image_shape = image.shape
         ctx.image_ref = weakref.ref(image)   # (weak: this node must not keep 16 B/px alive for the caller)
+        ctx.image_hooks = _hooks_of(image)   # ... but hooks that exist now stay observable if the caller drops the image
         ctx.prepared_state = prepared_state
         ctx.empty_regions = empty_regions
         # the renderer's own saved tensors (G-buffer, corner records, adjacency, ...): held here too,
@@ -421,8 +374,10 @@ class FusedPhongL1Loss(torch.autograd.Function):
         from .rendered_image import image_gradient_requested
         if image_gradient_requested():
             return True
+        if getattr(ctx, "image_hooks", None):   # hooks registered before the loss was built (the dict is the tensor's own)
+            return True
         image = ctx.image_ref()
-        if image is None:     # nobody holds the image any more: nothing of it can be looked at
+        if image is None:     # nobody holds the image any more (rendered_image.py: a hook registered late on it is lost)
             return False
         with torch._C.DisableTorchFunctionSubclass():
             return bool(image.retains_grad or image._backward_hooks)
@@ -579,6 +534,7 @@ class FusedSpecularL1Loss(torch.autograd.Function):
         loss, signs = _native.l1_loss_forward(image.detach(), target.detach(), want_signs=True)
         ctx.image_shape = image.shape
         ctx.image_ref = weakref.ref(image)
+        ctx.image_hooks = _hooks_of(image)
         ctx.has_ambient, ctx.has_transforms = has_ambient, has_transforms
         ctx.save_for_backward(signs, *render_saved)
         return loss

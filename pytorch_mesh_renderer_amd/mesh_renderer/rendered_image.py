@@ -18,10 +18,18 @@ torch.sub / torch.abs as if this module did not exist, and every result of an op
 torch.Tensor.  RECOGNISE_L1_SPELLING = False (or MR_RECOGNISE_L1=0) switches the recognition off, RETURN_SUBCLASS =
 False (MR_RENDERED_IMAGE=0) makes render() return plain tensors.
 
-Observing d loss / d image stays possible at any time: FusedPhongL1Loss decides in its BACKWARD whether the image's
-gradient is looked at (retain_grad, a tensor hook -- registered before or after the loss was built --, or
-torch.autograd.grad / Tensor.backward(inputs=...) naming the image, which this class sees as a torch function) and
-then behaves exactly like the generic op.
+Observing d loss / d image stays possible: FusedPhongL1Loss decides in its BACKWARD whether the image's gradient is
+looked at -- retain_grad(), a tensor hook (registered before or after the loss was built), or torch.autograd.grad naming
+the image (the image is among that function's arguments, so this class sees the call) -- and then behaves exactly like
+the generic op.  Two spellings are NOT seen (tests/test_reference_spelling_gpu.py pins both):
+`loss.backward(inputs=[image])` / torch.autograd.backward(loss, inputs=[image]) -- Tensor.backward dispatches on the loss,
+a plain tensor -- leave image.grad None; and a hook registered AFTER the loss was built on an image whose Python object
+is dropped before backward() does not fire (the node holds the image weakly; hooks that exist when the loss is built
+are kept alive with it).  losses.USE_FUSED_RENDER_LOSS = False restores stock autograd for both.
+
+A pending difference is evaluated LATE, so it remembers its operands' version counters: if the image or the target was
+written in place between `image - target` and the use of the result, eager torch would have computed the difference
+from the old values; here the use raises the error autograd raises for a saved tensor modified in place.
 """
 import os
 import threading
@@ -96,9 +104,6 @@ class RenderedImage(torch.Tensor):
             if _names_an_image(inputs):
                 with _ImageGradientRequest():
                     return _plain(func, args, kwargs)
-        elif func is _T.backward and _names_an_image(kwargs.get("inputs")):
-            with _ImageGradientRequest():
-                return _plain(func, args, kwargs)
         return _plain(func, args, kwargs)
 
     def __reduce_ex__(self, proto):   # pickles / deep-copies as the plain tensor it is
@@ -151,8 +156,16 @@ class _PendingL1(torch.Tensor):
         with torch._C.DisableTorchFunctionSubclass():
             t = torch.Tensor._make_subclass(_PendingL1, torch.empty(0, device=image.device))
         t._mr_pending = (image, target, negated, stage)
+        t._mr_versions = (image._version, target._version)
         t._mr_value = None
         return t
+
+    def _operands(self):
+        image, target, negated, stage = self._mr_pending
+        if (image._version, target._version) != self._mr_versions:
+            raise RuntimeError("one of the operands of this `image - target` has been modified by an inplace operation "
+                               "before the difference was used (it is evaluated late: mesh_renderer/rendered_image.py)")
+        return image, target, negated, stage
 
     @staticmethod
     def difference(func, args, kwargs):
@@ -164,7 +177,7 @@ class _PendingL1(torch.Tensor):
 
     def _materialise(self):
         if self._mr_value is None:
-            image, target, negated, stage = self._mr_pending
+            image, target, negated, stage = self._operands()
             with torch._C.DisableTorchFunctionSubclass():   # (the subclass then behaves as the plain tensor it is)
                 d = torch.sub(target, image) if negated else torch.sub(image, target)
                 self._mr_value = torch.abs(d) if stage == "abs" else d
@@ -176,10 +189,13 @@ class _PendingL1(torch.Tensor):
         if RECOGNISE_L1_SPELLING and len(args) == 1 and isinstance(args[0], cls) and args[0]._mr_value is None:
             image, target, negated, stage = args[0]._mr_pending
             if func in _ABS and not kwargs and stage == "sub":
-                return _PendingL1._make(image, target, negated, "abs")
+                pending = _PendingL1._make(image, target, negated, "abs")
+                pending._mr_versions = args[0]._mr_versions
+                return pending
             if func in _MEAN and stage == "abs" and all(v is None for v in kwargs.values()) and \
                     set(kwargs) <= {"dtype"} and torch.is_grad_enabled():
                 from . import losses
+                args[0]._operands()
                 return losses.l1_loss(image, target)
             answer = _CHEAP.get(func)
             if answer is not None:

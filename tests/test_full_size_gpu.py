@@ -390,3 +390,27 @@ def test_deterministic_mode_at_configs4_and_at_the_specular_c3_shape(device):
             scale = float(d.abs().max())
             np.testing.assert_allclose(a.cpu().numpy(), d.cpu().numpy(), atol=1e-4 * scale, rtol=1e-3,
                                        err_msg="%s: deterministic vs default, gradient %d" % (name, i))
+
+
+def test_config5_soft_step_time_guard(device):
+    """the SoftRas step of BASELINE configs[4] (5k triangles, 512 x 512, batch 16, forward + mean() +
+    backward to the vertices) has been recorded at 0.76-0.78 ms on eleven boxes (README) and at
+    2.5-3.3 ms on three with the same kernels, unexplained.  This guard runs bench.py's own c5 leg -- five chunks of 20
+    steps, each timed by the wall clock and by HIP events -- and fails if the MEDIAN chunk exceeds twice the recorded
+    time, printing every chunk so that the failure says whether the GPU (events) or the host (enqueue) was slow."""
+    sys.path.insert(0, ROOT)
+    import bench
+    j5 = synthetic.sphere_job(16, 512, 512, 50)
+    v5 = j5["vertices"].to(device).requires_grad_(True)
+    tri5, kd5, lp5 = j5["triangles"].to(device), j5["diffuse"].to(device), j5["light_positions"].to(device)
+    eyes5, zero5, up5 = j5["eyes"], torch.zeros(16, 3), torch.tensor([0.0, 1.0, 0.0])
+    li5 = torch.ones(16, 1, device=device)
+
+    def step5():
+        v5.grad = None
+        soft_mesh_renderer.render(v5, tri5, kd5, eyes5, zero5, up5, lp5, li5, 512, 512).mean().backward()
+    chunks = bench._chunked_ms(step5, chunks=5, n=20)
+    print("configs[4] step, chunks of 20:", chunks)
+    median = sorted(c["wall_ms"] for c in chunks)[2]
+    recorded = 0.78
+    assert median <= 2.0 * recorded, "SoftRas step %.3f ms (recorded %.2f): %s" % (median, recorded, chunks)

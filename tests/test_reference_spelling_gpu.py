@@ -164,7 +164,8 @@ def test_pending_results_answer_like_tensors(device):
 @pytest.mark.parametrize("specular", [False, True])
 def test_the_images_gradient_can_be_observed_at_any_time(device, specular):
     """d loss / d image through the recognised spelling: a hook registered AFTER the loss was built, retain_grad,
-    torch.autograd.grad naming the image (alone, and together with the vertices), loss.backward(inputs=[image])."""
+    torch.autograd.grad naming the image (alone, and together with the vertices).  The two spellings that are NOT seen
+    are pinned in test_the_two_documented_holes_of_the_fused_loss."""
     scene = _Scene(device, specular=specular)
     spelled = SPELLINGS["reference"]
     want_loss, want_grad = _reference_gradient(scene, spelled)
@@ -210,6 +211,77 @@ def test_the_images_gradient_can_be_observed_at_any_time(device, specular):
     (spelled(img, scene.target) + (img * img).mean()).backward()
     _, extra = _reference_gradient(scene, lambda i, t: (i * i).mean())
     np.testing.assert_allclose(v.grad.cpu().numpy(), (want_grad + extra).cpu().numpy(), rtol=3e-4, atol=1e-9)
+
+
+def test_the_two_documented_holes_of_the_fused_loss(device):
+    """ADVICE r5, rendered_image.py's docstring: (1) loss.backward(inputs=[image]) dispatches on the loss, a plain tensor,
+    so the fused node does not know the image is wanted: image.grad stays None (stock autograd would fill it), and
+    USE_FUSED_RENDER_LOSS = False restores it; (2) a hook registered BEFORE the loss was built keeps firing when the
+    caller drops the image (the node keeps the tensor's hook dict), one registered AFTER on a dropped image is lost."""
+    import gc
+    from pytorch_mesh_renderer_amd.mesh_renderer import losses
+    scene = _Scene(device)
+    spelled = SPELLINGS["reference"]
+    v, img = scene.render()
+    img.retain_grad()            # (so that .grad would be kept if a gradient arrived)
+    before = losses.USE_FUSED_RENDER_LOSS
+    try:
+        losses.USE_FUSED_RENDER_LOSS = False
+        spelled(img, scene.target).backward(inputs=[img])
+        want = torch.sign(img.detach() - scene.target) / img.numel()
+        assert torch.equal(img.grad, want)
+    finally:
+        losses.USE_FUSED_RENDER_LOSS = before
+    v, img = scene.render()
+    spelled(img, scene.target).backward(inputs=[img])
+    assert img.grad is None and v.grad is None, "if this starts working, take the hole out of the docstrings"
+    # (2) hook first, loss second, image dropped: fires
+    seen = []
+
+    def loss_with_early_hook():
+        _, image = scene.render()
+        image.register_hook(lambda g: seen.append(float(g.abs().sum())))
+        return spelled(image, scene.target)
+    loss = loss_with_early_hook()
+    gc.collect()
+    loss.backward()
+    assert len(seen) == 1 and seen[0] > 0
+
+    def loss_with_late_hook():
+        _, image = scene.render()
+        out = spelled(image, scene.target)
+        image.register_hook(lambda g: seen.append(-1.0))
+        return out
+    loss = loss_with_late_hook()
+    gc.collect()
+    loss.backward()
+    assert len(seen) == 1, "if this starts firing, take the hole out of the docstrings"
+
+
+def test_a_pending_difference_remembers_its_operands_versions(device):
+    """`d = image - target` is evaluated late; an in-place write to either operand before d is used would
+    silently change the loss (eager torch has computed d by then).  The use raises instead, on the fused route and on
+    the materialising one; an untouched pair still works, and the pending object IS a tensor (isinstance checks and
+    torch.is_tensor in caller code keep passing: the reason it is a torch.Tensor subclass and not a plain proxy)."""
+    scene = _Scene(device)
+    _, img = scene.render()
+    target = scene.target.clone()
+    d = img - target
+    assert isinstance(d, torch.Tensor) and torch.is_tensor(d) and isinstance(torch.abs(d), torch.Tensor)
+    target.add_(0.25)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        torch.mean(torch.abs(d))
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        d * 2.0
+    _, img = scene.render()
+    a = torch.abs(img - target)
+    with torch.no_grad():
+        img[..., 3] = 0.5
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        a.mean()
+    _, img = scene.render()
+    loss = torch.mean(torch.abs(img - target))
+    assert abs(float(loss) - float((img.detach() - target).abs().mean())) <= 1e-6 * float(loss)
 
 
 def test_switches(device):

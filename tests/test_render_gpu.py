@@ -1570,7 +1570,7 @@ def test_render_empty_block_map_serves_the_loss_and_the_backward(device, w, h, b
     target = torch.zeros(batch, h, w, 4)
     target[:, h // 3:h // 2, w // 4:w // 2] = torch.rand(batch, h // 2 - h // 3, w // 2 - w // 4, 4,
                                                         generator=torch.Generator().manual_seed(2))
-    target = target.to(device)
+    target = mesh_renderer.losses.remember_target(target.to(device))   # (round 6: the target's map is opt-in)
     out = _native.render_forward(job["vertices"].to(device), synthetic.clip_transforms(job["eyes"], w, h).to(device),
                                  job["normals"].to(device), job["diffuse"].to(device), tris,
                                  job["light_positions"].to(device), job["light_intensities"].to(device), None, w, h,
@@ -1612,11 +1612,11 @@ def test_render_empty_block_map_serves_the_loss_and_the_backward(device, w, h, b
                                        atol=1e-6 * float(gd0.abs().max()), err_msg=kind)
 
 
-def test_target_empty_block_map_follows_in_place_edits(device):
-    """The target's empty-block map is kept per target tensor (weakly, nothing is written onto the tensor), keyed by
-    its version counter: an in-place torch edit that fills a formerly empty block is seen by the next loss.  Round 5
-    (ADVICE r4): a write that bypasses the counter (target.data) leaves a stale map -- losses.forget_target drops it
-    at once, the periodic refresh heals it within _TARGET_MAP_REFRESH uses, MR_DEBUG_EMPTY_REGIONS-mode raises."""
+def test_target_empty_block_map_is_opt_in_and_dies_with_an_in_place_edit(device):
+    """Round 6: the target's empty-block map exists only for a target named with losses.remember_target, rides on the
+    tensor object and is used while data pointer, shape and version counter are unchanged: an in-place torch edit
+    voids it (the loss reads every block again and is right), remember_target after the edit makes a new one,
+    forget_target drops it; an un-named target never gets one."""
     from pytorch_mesh_renderer_amd.mesh_renderer import rasterize_triangles_ext as ext
     job = synthetic.sphere_job(8, 768, 768, 12)
     tris = job["triangles"].to(device)
@@ -1627,54 +1627,31 @@ def test_target_empty_block_map_follows_in_place_edits(device):
         img = mesh_renderer.render(v, tris, job["normals"].to(device), job["diffuse"].to(device), job["eyes"],
                                    torch.zeros(8, 3), torch.tensor([0.0, 1.0, 0.0]), job["light_positions"].to(device),
                                    job["light_intensities"].to(device), 768, 768)
-        return float(mesh_renderer.losses.l1_loss(img, target)), float((img.detach() - target).abs().mean())
+        loss = mesh_renderer.losses.l1_loss(img, target)
+        return float(loss), float((img.detach() - target).abs().mean()), loss.grad_fn
 
-    got, want = loss_of()
+    got, want, _ = loss_of()
     assert abs(got - want) <= 1e-6 * want
-    assert not hasattr(target, "_mr_empty_regions")          # nothing lives on the user's tensor
-    first = ext._target_maps.get(target)[1]
-    assert int(first.sum()) == first.numel()   # an all-zero target: every block empty
+    assert not hasattr(target, "_mr_empty_regions") and ext._target_empty_regions(target) is None   # not named: no map
+    assert mesh_renderer.losses.remember_target(target) is target
+    first = ext._target_empty_regions(target)
+    assert first is not None and int(first.sum()) == first.numel()   # an all-zero target: every block empty
+    got, want, _ = loss_of()
+    assert abs(got - want) <= 1e-6 * want
+    assert ext._target_empty_regions(target) is first                # the same map, not a new one per use
     target[3, 710:760, 5:60] = 0.75            # inside ONE corner block the sphere does not reach (G-buffer rows 7..57)
-    got, want = loss_of()
+    assert ext._target_empty_regions(target) is None, "an in-place edit voids the map"
+    got, want, _ = loss_of()
     assert abs(got - want) <= 1e-6 * want, "the edit was not seen"
-    assert int(ext._target_maps.get(target)[1].sum()) == first.numel() - 1
-    assert ext._target_maps.get(target)[1] is first, "refreshed in place: a captured graph keeps reading a live map"
-    # a write the version counter does not see: the kept map is stale, the loss silently misses the new block ...
-    version = target._version
-    target.data[5, 10:60, 700:760] = 0.5
-    assert target._version == version
-    got, want = loss_of()
-    assert abs(got - want) > 1e-6 * want, "this is the documented hole: the stale map skips the block"
-    # ... the debug mode raises on it ...
-    before = ext._DEBUG_TARGET_MAPS
-    ext._DEBUG_TARGET_MAPS = True
-    try:
-        with pytest.raises(RuntimeError, match="stale"):
-            loss_of()
-    finally:
-        ext._DEBUG_TARGET_MAPS = before
-    # ... forget_target drops the map at once ...
-    mesh_renderer.losses.forget_target(target)
-    assert target not in ext._target_maps
-    got, want = loss_of()
+    mesh_renderer.losses.remember_target(target)
+    again = ext._target_empty_regions(target)
+    assert int(again.sum()) == first.numel() - 1
+    got, want, _ = loss_of()
     assert abs(got - want) <= 1e-6 * want
-    # ... and without it the periodic refresh heals the map within _TARGET_MAP_REFRESH uses
-    target.data[6, 700:760, 700:760] = 0.25
-    before = ext._TARGET_MAP_REFRESH
-    ext._TARGET_MAP_REFRESH = 4
-    try:
-        healed = False
-        for _ in range(5):
-            got, want = loss_of()
-            healed = healed or abs(got - want) <= 1e-6 * want
-        assert healed and abs(got - want) <= 1e-6 * want
-    finally:
-        ext._TARGET_MAP_REFRESH = before
-    n_maps = len(ext._target_maps)
-    del target
-    import gc
-    gc.collect()
-    assert len(ext._target_maps) == n_maps - 1   # weak: the entry died with the tensor
+    mesh_renderer.losses.forget_target(target)
+    assert ext._target_empty_regions(target) is None and not hasattr(target, "_mr_empty_regions")
+    with pytest.raises(ValueError):
+        mesh_renderer.losses.remember_target(torch.zeros(4, 4, device=device))
 
 
 def test_l1_loss_drops_the_renderers_map_when_the_image_was_edited(device):

@@ -9,7 +9,7 @@ for set in "TCC_HIT_sum TCC_MISS_sum TCC_EA_RDREQ_sum TCC_REQ_sum" \
            "GRBM_GUI_ACTIVE GRBM_COUNT SQ_INSTS_VALU SQ_INSTS_VMEM_RD"; do
   i=$((i + 1))
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$OUT/p$i" -o run -- \
-      python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 > "$OUT/p$i.log" 2>&1 || true
+      python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 --extras 0 > "$OUT/p$i.log" 2>&1 || true
 done
 python3 - <<'PY' | tee gpurun_out/pmc_gather/summary.txt
 import csv, glob, collections

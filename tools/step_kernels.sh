@@ -1,6 +1,6 @@
 # Per-step kernel time accounting of the bench step (rocprofv3 --kernel-trace --stats over 20 steps).
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof_q -o run --output-format csv -- python3 bench.py --steps 20 --warmup 2 --cpu-sample 0 > gpurun_out/prof_q.log 2>&1
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof_q -o run --output-format csv -- python3 bench.py --steps 20 --warmup 2 --cpu-sample 0 --extras 0 > gpurun_out/prof_q.log 2>&1
 python3 - <<'PY'
 import csv, glob
 rows = list(csv.DictReader(open(glob.glob("gpurun_out/prof_q/*kernel_stats.csv")[0])))
