@@ -18,8 +18,9 @@ world-space vertex positions.  All inputs are resident in HBM before the timed r
 
 With N ranks every rank renders its own batch (weak scaling; no data-path collective) and the
 finished images of EVERY step are handed over over RCCL, overlapping the loss, the backward and the
-next forwards: as 8-bit frames (--handover u8, default: mesh_renderer.to_uint8, the conversion the
-reference's examples apply before writing a frame) or as the fp32 images (--handover f32, 4x the bytes).
+next forwards: as the fp32 images render() returns (--handover f32, the default since round 6: the reference's
+own output, render.py:384-386) or as 8-bit frames (--handover u8: mesh_renderer.to_uint8, the conversion the
+reference's examples apply before writing a frame, a quarter of the bytes; its figure rides in the same line).
 --gather rotate (default, round 5): the global batch of step s is assembled on rank s mod N -- one balanced
 all_to_all per block of N steps, every xGMI link in use (distributed.RotatingImageGather);
 --gather root: on rank 0 every step (one gather per step; bound by rank 0's N - 1 inbound links).
@@ -121,7 +122,7 @@ class KernelEvents:
         return sum(out) / len(out) if out else 0.0
 
 
-def make_step(job, device, gather, handover="u8", spelling="l1_loss", all_gradients=False, device_cameras=False):
+def make_step(job, device, gather, handover="f32", spelling="l1_loss", all_gradients=False, device_cameras=False):
     """Returns (step, vertices, state): state["image"] / state["target"] hold the last rendered
     batch and the fixed target (the full-size parity test checks them against the oracle).
 
@@ -450,11 +451,11 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c3")
-    ap.add_argument("--handover", choices=("u8", "f32"), default="u8",
-                    help="what the ranks hand over to rank 0 when --gpus > 1 inside the timed region: 8-bit frames (default: "
-                         "the reference examples' frame conversion, written by the forward's epilogue) or the fp32 images "
-                         "render() returns; the OTHER one is timed after the region and reported next to it "
-                         "(ms_per_step_handover_f32 / value_handover_f32)")
+    ap.add_argument("--handover", choices=("u8", "f32"), default="f32",
+                    help="what the ranks hand over when --gpus > 1 inside the timed region: the fp32 images render() returns "
+                         "(default since round 6: the reference's own output type, render.py:384-386, 16 B/px) or 8-bit frames "
+                         "(the reference examples' frame conversion, written by the forward's epilogue, 4 B/px); the OTHER one is "
+                         "timed after the region and reported next to it (ms_per_step_handover_u8 / value_handover_u8)")
     ap.add_argument("--gather", choices=("rotate", "root"), default="rotate",
                     help="N > 1: where a step's frames are assembled -- rotate (default): the global batch of step s on rank "
                          "s mod N, one all_to_all per N steps, every xGMI link used (distributed.RotatingImageGather); "

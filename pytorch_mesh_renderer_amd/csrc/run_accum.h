@@ -493,11 +493,6 @@ __global__ __launch_bounds__(kRowsThreads, Fn::kMinWavesPerSimd) void k_accumula
 #ifndef MR_LANES_MERGE_SLOTS
 #define MR_LANES_MERGE_SLOTS 16
 #endif
-#ifndef MR_LANES_SPARSE_ATOMICS
-#define MR_LANES_SPARSE_ATOMICS 1   // round 6: a FEW finished lanes (fewer than MR_LANES_DENSE: a triangle changed under them
-                                    // inside the strip) commit their own sums straight to the accumulator rows -- N no-return
-                                    // atomics under the finished lanes' mask -- instead of parking them for the scalar walk
-#endif
 
 constexpr int lanes_park_stride(int n) {  // multiple of 4 with an odd number of quads: per-lane b128 accesses are conflict-free
   int s = (n + 3) / 4;
@@ -538,7 +533,10 @@ __global__ __launch_bounds__(kWave, Fn::kMinWavesPerSimd) void k_accumulate_lane
   __shared__ __attribute__((aligned(16))) float s_park[kWave * P];
   constexpr int kMergeSlots = MR_LANES_MERGE_SLOTS;
   static_assert(kMergeSlots >= 1 && kMergeSlots <= 32, "lane i of merge_keys holds slot i's triangle; slot lookups keep the low 32 bits of the ballot");
-  __shared__ float s_merge[kMergeSlots * kWave];
+  // (round 6: [slot][sum] -- only lanes 0..N-1 hold a sum; lanes >= N idle along on lane N-1's address with its value --
+  //  0.6 KB instead of 4 KB per wavefront at N = 9: LDS no longer caps the kernel at five wavefronts per SIMD)
+  constexpr int kMergeStride = N;
+  __shared__ float s_merge[kMergeSlots * kMergeStride];
 
   const int region = xcd_contiguous_block((int)blockIdx.x, n_regions, regions_per_xcd);
   if (region < 0) return;
@@ -573,7 +571,7 @@ __global__ __launch_bounds__(kWave, Fn::kMinWavesPerSimd) void k_accumulate_lane
   auto flush_merge_table = [&]() {
 #pragma unroll 1
     for (int slot = 0; slot < merge_count; ++slot)
-      commit(__builtin_amdgcn_readlane(merge_keys, slot), s_merge[slot * kWave + lane]);
+      commit(__builtin_amdgcn_readlane(merge_keys, slot), s_merge[slot * kMergeStride + red]);
     merge_count = 0;
     merge_keys = -1;
   };
@@ -605,26 +603,11 @@ __global__ __launch_bounds__(kWave, Fn::kMinWavesPerSimd) void k_accumulate_lane
     const unsigned long long finm = __ballot(fin);
     if (!finm) return;
     const bool dense = (int)__builtin_popcountll(finm) >= kDense;  // wave-uniform
-#if MR_LANES_SPARSE_ATOMICS
-    if (!dense) {
-      // the in-strip run ends: ~3 lanes of 64 per row.  Their walk through LDS (park, one scalar trip per finished lane
-      // with a readlane, a merge-table lookup per segment, a store per segment) was ~60 vector and ~50 scalar
-      // instructions per row for sums that meet nothing in the merge table most of the time; N atomics issued once
-      // under the finished lanes' mask are N + 2 instructions, return nothing and wait for nothing.
-      if (fin) {
-        const size_t row = (size_t)run_tri * STRIDE;
-#pragma unroll
-        for (int k = 0; k < N; ++k) {
-          if (DET) atomic_add_fixed(&acc_fixed[row + Fn::column(k)], a[k], to_fixed, det_overflow_flag(det_scale));
-          else atomicAdd(&acc_img[row + Fn::column(k)], a[k]);
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < N; ++k) a[k] = fin ? 0.0f : a[k];
-      if (fin) run_tri = -1;
-      return;
-    }
-#endif
+    // (Measured in round 6 and dropped: the FEW finished lanes of an ordinary row -- ~3 of 64 -- committing their own N
+    //  sums straight to the accumulator rows, N no-return global atomics under the finished lanes' mask, instead of the
+    //  walk through LDS below.  Scalar instructions per launch 57.0 -> 34.7 M, vector 119.1 -> 117.8 M -- and the kernel
+    //  0.213 -> 1.17 ms, same box, twice: ~3.7 M atomic INSTRUCTIONS per launch instead of ~0.4 M; a float atomic
+    //  instruction costs the wavefront ~0.3 us whatever its mask.  profiles/r06_lanes_sparse_atomics.txt)
     {
       float4 *dst = (float4 *)(s_park + lane * P);
       auto quad = [&](const int q) {
@@ -654,7 +637,7 @@ __global__ __launch_bounds__(kWave, Fn::kMinWavesPerSimd) void k_accumulate_lane
     float sum = 0.0f, sum2 = 0.0f, merged = 0.0f;
     auto close_segment = [&]() {
       if (cur_t < 0) return;
-      float *slot = &s_merge[cur_slot * kWave + lane];
+      float *slot = &s_merge[cur_slot * kMergeStride + red];
 #if MR_LANES_DS_ADD   // measured: ds_add_f32 costs more than it saves (0.305 -> 0.368 ms): ~26 LDS cycles each
       if (cur_fresh) *slot = sum + sum2;
       else atomicAdd(slot, sum + sum2);
@@ -670,7 +653,7 @@ __global__ __launch_bounds__(kWave, Fn::kMinWavesPerSimd) void k_accumulate_lane
       merged = 0.0f;
       if (hit) {
         cur_slot = __builtin_ctz(hit);
-        if (!MR_LANES_DS_ADD) merged = s_merge[cur_slot * kWave + lane];
+        if (!MR_LANES_DS_ADD) merged = s_merge[cur_slot * kMergeStride + red];
       } else {
         if (merge_count == kMergeSlots) flush_merge_table();  // full: everything leaves, then slot 0
         cur_slot = merge_count;

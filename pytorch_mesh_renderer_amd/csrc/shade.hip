@@ -532,6 +532,9 @@ struct ShadeLaneFn : ShadeGradFn<L, SIGNS, LG> {
 #ifndef MR_FOLD_LANE_ROWS
 #define MR_FOLD_LANE_ROWS 8
 #endif
+#ifndef MR_FOLD_LANE_WAVES
+#define MR_FOLD_LANE_WAVES MR_LANE_WAVES
+#endif
 #ifndef MR_SHADE_USE_PREPARED
 #define MR_SHADE_USE_PREPARED 1   // 0: ignore mr_render_forward's prepared block (A/B)
 #endif
@@ -545,7 +548,7 @@ struct ShadeFoldLaneFn : ShadeGradFn<L, SIGNS, false> {
   static constexpr int kN = 9;
   static constexpr int kStride = kFoldAccStride;  // COMPACT rows: [corner][c] + 3 of padding (k_shade_gather_fold reads them)
   static constexpr int kLaneRowsPerWave = MR_FOLD_LANE_ROWS;   // 8: 0.2323 -> 0.2281 ms against 16 (32: 0.2507), same box
-  static constexpr int kMinWavesPerSimd = MR_LANE_WAVES;
+  static constexpr int kMinWavesPerSimd = MR_FOLD_LANE_WAVES;
   const FoldRec *__restrict__ fold_recs;   // in the PULLED form (store_fold_record with the image's transform rows)
   using Triangle = FoldTriangleW;
   // SIGNS: the sums are formed from the bare sign codes; k_shade_gather_fold multiplies by the loss's scale

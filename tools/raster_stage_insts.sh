@@ -1,21 +1,38 @@
-# Vector / scalar / LDS instruction counts of k_raster per stage-timing probe (probes build), one --pmc pass each.
-#   gpurun --timeout 900 -- 'bash tools/raster_stage_insts.sh [config]'
+# Instruction counts, wait cycles and written bytes of k_raster per stage-timing probe (probes build), one --pmc pass per
+# counter group (round 6: the wait / store counters DESIGN r5 named for configs[3]'s shape).
+#   gpurun --timeout 1200 -- 'make -C pytorch_mesh_renderer_amd/csrc -j8 probes >/dev/null 2>&1; bash tools/raster_stage_insts.sh [config]'
+# Probes (include/mesh_raster_debug.h): 0 whole kernel, 32 bin only, 8 bin + tile masks, 16 walk without stores,
+# 3 store-only walk, 1 / 2 see the header.  Output: gpurun_out/stage_insts_<config>/summary.txt
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 CFG=${1:-c3}
-OUT=gpurun_out/stage_insts
+OUT=gpurun_out/stage_insts_$CFG
 rm -rf "$OUT" && mkdir -p "$OUT"
-for v in ${PROBES:-0 32 8 16 3 1 2}; do
-  timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH --output-format csv -d "$OUT/v$v" -o run -- \
-      python3 tools/raster_bench.py --config $CFG --iters 3 --variant $v > "$OUT/v$v.log" 2>&1 || echo "variant $v failed"
+g=0
+for group in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH" \
+             "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VMEM_WR SQ_BUSY_CYCLES" \
+             "SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS" \
+             "WRITE_SIZE"; do
+  g=$((g + 1))
+  for v in ${PROBES:-0 32 8 16 3}; do
+    timeout -k 10 200 rocprofv3 --kernel-trace --pmc $group --output-format csv -d "$OUT/g$g/v$v" -o run -- \
+        python3 tools/raster_bench.py --config $CFG --iters 3 --variant $v > "$OUT/g$g.v$v.log" 2>&1 || echo "group $g variant $v failed"
+  done
 done
-python3 - <<'PY'
-import csv, glob, collections
-for v in [int(x) for x in __import__("os").environ.get("PROBES", "0 32 8 16 3 1 2").split()]:
+for v in ${PROBES:-0 32 8 16 3}; do timeout -k 10 100 python3 tools/raster_bench.py --config $CFG --iters 20 --variant $v 2>/dev/null | grep variant; done > "$OUT/times.txt"
+STAGE_OUT=$OUT python3 - <<'PY' | tee "$OUT/summary.txt"
+import csv, glob, collections, os
+out = os.environ["STAGE_OUT"]
+print(open(out + "/times.txt").read().rstrip())
+for v in [int(x) for x in os.environ.get("PROBES", "0 32 8 16 3").split()]:
     acc = collections.defaultdict(list)
-    for f in glob.glob("gpurun_out/stage_insts/v%d/**/*counter_collection.csv" % v, recursive=True):
+    for f in glob.glob(out + "/g*/v%d/**/*counter_collection.csv" % v, recursive=True):
         for r in csv.DictReader(open(f)):
             if "k_raster" in r["Kernel_Name"]:
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    print("probe %2d  " % v + "  ".join("%s %.1f M" % (k.replace("SQ_INSTS_", ""), sum(x) / len(x) / 1e6) for k, x in sorted(acc.items())))
+    def fmt(k, x):
+        m = sum(x) / len(x)
+        return "%s %.0f KB" % (k, m) if k.endswith("_SIZE") else "%s %.2f M" % (k.replace("SQ_", ""), m / 1e6)
+    print("probe %2d  " % v + "  ".join(fmt(k, x) for k, x in sorted(acc.items())))
 PY
+find "$OUT" -name '*.csv' -delete; find "$OUT" -name '*.log' -size -2k -delete
