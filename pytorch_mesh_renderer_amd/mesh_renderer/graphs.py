@@ -11,11 +11,14 @@ be captured is host-side work: cameras must be DEVICE tensors (host cameras are 
 uploaded: a capture would bake that one upload's values in), and Python-side decisions (which kernel variant, which
 tensors require grad) are those of the capture.
 
-Known limitations (round 5's two HIP-graph anomalies; tools/graph_memset_repro.py and DESIGN.md section 4.7):
- * the library issues NO memset nodes: a captured hipMemsetAsync of a small buffer wrote 0xC6 on a later replay once
-   eager work had run in between, so every zero-fill is a kernel node (arguments by value).  Whether that was the
-   memset node or pool memory handed out again underneath it was not established by round 5; until it is, keep the
-   CapturedStep alive for as long as it is replayed and do not call torch.cuda.empty_cache() between replays.
+Known limitations (round 5's two HIP-graph anomalies):
+ * the library issues NO memset nodes.  Round 6 reproduced the anomaly without any of this library
+   (tools/graph_memset_repro.py, profiles/r06_graph_memset_repro.txt; ROCm 7.2, torch 2.10): a captured hipMemsetAsync
+   of 64 bytes or more writes the bytes of a POINTER (0x7f66....) instead of the fill value on the second replay once
+   eager work has run in between -- for buffers of the graph's pool and for buffers allocated before the capture
+   alike, with no eager allocation at the node's address: the node's parameters, not pool memory handed out again.
+   8-byte memsets are unaffected.  Every zero-fill of the library is therefore a kernel node (arguments by value).
+   Capture nothing of your own that ends in hipMemsetAsync (torch.zeros / fill_ are kernels: fine).
  * capture ONE stream: a step that forks to other streams inside the capture (tools/overlap_probe.py's four lockstep
    chunks) crashed inside hipGraph capture; render()/loss/backward as written here stay on the current stream.
 """

@@ -213,29 +213,22 @@ def test_the_images_gradient_can_be_observed_at_any_time(device, specular):
     np.testing.assert_allclose(v.grad.cpu().numpy(), (want_grad + extra).cpu().numpy(), rtol=3e-4, atol=1e-9)
 
 
-def test_the_two_documented_holes_of_the_fused_loss(device):
-    """ADVICE r5, rendered_image.py's docstring: (1) loss.backward(inputs=[image]) dispatches on the loss, a plain tensor,
-    so the fused node does not know the image is wanted: image.grad stays None (stock autograd would fill it), and
-    USE_FUSED_RENDER_LOSS = False restores it; (2) a hook registered BEFORE the loss was built keeps firing when the
-    caller drops the image (the node keeps the tensor's hook dict), one registered AFTER on a dropped image is lost."""
+def test_backward_naming_the_image_and_hooks_on_dropped_images(device):
+    """ADVICE r5 said loss.backward(inputs=[image]) leaves image.grad None on the fused route (Tensor.backward
+    dispatches on the loss, a plain tensor, so RenderedImage never sees the call).  It does not: the engine calls
+    retain_grad() on every non-leaf tensor named in inputs= before it runs (accumulate_grad), and the fused node looks at
+    image.retains_grad when its backward runs -- both spellings fill image.grad with the dense gradient and leave the
+    vertices alone, exactly like stock autograd.  What IS a hole: a hook registered AFTER the loss was built on an image
+    whose Python object is dropped before backward() does not fire (the node holds the image weakly); one registered
+    BEFORE keeps firing (the node keeps the tensor's hook dict)."""
     import gc
-    from pytorch_mesh_renderer_amd.mesh_renderer import losses
     scene = _Scene(device)
     spelled = SPELLINGS["reference"]
-    v, img = scene.render()
-    img.retain_grad()            # (so that .grad would be kept if a gradient arrived)
-    before = losses.USE_FUSED_RENDER_LOSS
-    try:
-        losses.USE_FUSED_RENDER_LOSS = False
-        spelled(img, scene.target).backward(inputs=[img])
-        want = torch.sign(img.detach() - scene.target) / img.numel()
-        assert torch.equal(img.grad, want)
-    finally:
-        losses.USE_FUSED_RENDER_LOSS = before
-    v, img = scene.render()
-    spelled(img, scene.target).backward(inputs=[img])
-    assert img.grad is None and v.grad is None, "if this starts working, take the hole out of the docstrings"
-    # (2) hook first, loss second, image dropped: fires
+    for call in (lambda loss, img: loss.backward(inputs=[img]), lambda loss, img: torch.autograd.backward(loss, inputs=[img])):
+        v, img = scene.render()
+        call(spelled(img, scene.target), img)
+        assert torch.equal(img.grad, torch.sign(img.detach() - scene.target) / img.numel())
+        assert v.grad is None
     seen = []
 
     def loss_with_early_hook():
@@ -255,7 +248,7 @@ def test_the_two_documented_holes_of_the_fused_loss(device):
     loss = loss_with_late_hook()
     gc.collect()
     loss.backward()
-    assert len(seen) == 1, "if this starts firing, take the hole out of the docstrings"
+    assert len(seen) == 1, "if this starts firing, take the hole out of rendered_image.py's docstring"
 
 
 def test_a_pending_difference_remembers_its_operands_versions(device):

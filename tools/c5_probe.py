@@ -45,6 +45,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--lead", type=int, default=24)
+    ap.add_argument("--smi", type=int, default=0,
+                    help="1: after the three contexts, time the step again WHILE a child process polls rocm-smi in a loop -- "
+                         "the driver samples rocm-smi every 5 s during its bench run (BENCH_r05.json: gpu_busy.samples); does "
+                         "a poll that lands on this 40-ms leg explain a 3-4 x reading?")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     j5 = synthetic.sphere_job(16, 512, 512, 50)
@@ -91,6 +95,32 @@ def main():
     _native._workspaces.clear()
     torch.cuda.empty_cache()
     report("(c) scratch dropped, allocator emptied")
+    if args.smi:
+        import subprocess
+        import threading
+        stop = threading.Event()
+        polls = []
+
+        def poll():
+            while not stop.is_set():
+                t0 = time.perf_counter()
+                try:
+                    subprocess.run(["rocm-smi", "--showuse", "--showmemuse", "--showpower", "--showclocks", "--json"],
+                                   capture_output=True, timeout=60)
+                except Exception as exc:
+                    polls.append(str(exc))
+                    return
+                polls.append(round(time.perf_counter() - t0, 3))
+        th = threading.Thread(target=poll, daemon=True)
+        th.start()
+        time.sleep(0.3)
+        for i in range(6):
+            wall, gpu, host = timed(step5, 20, 4)
+            print("while rocm-smi polls, chunk %d of 20 steps: wall %.3f events %.3f host %.3f" % (i, wall, gpu, host), flush=True)
+        stop.set()
+        th.join(70)
+        print("rocm-smi poll durations (s): %s" % polls, flush=True)
+        report("(d) after the polling stopped")
     if slow:   # a slow box at last: what state is the GPU in, and does the step recover under sustained load?
         import subprocess
         print("SLOW in: %s" % slow, flush=True)

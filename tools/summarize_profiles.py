@@ -34,9 +34,21 @@ with open(os.path.join(prof, tag + suffix + "_bench_kernel_stats.csv"), "w", new
     for r in rows[:24]:
         w.writerow(r)
 
+# 1b. the same with the legs after the timed region (round 6): every kernel of every leg, 48 rows
+extras = glob.glob(os.path.join(SRC, "stats_extras/**/*kernel_stats.csv"), recursive=True)
+if extras:
+    rows_x = list(csv.DictReader(open(extras[0])))
+    with open(os.path.join(prof, tag + "_bench_extras_kernel_stats.csv"), "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=list(rows_x[0].keys()))
+        w.writeheader()
+        for r in rows_x[:48]:
+            w.writerow(r)
+
 # 2. bench lines (plain and under rocprof)
 lines = {}
-for name in ("bench.log", "bench_under_rocprof.log"):
+for name in ("bench.log", "bench_under_rocprof.log", "bench_extras_under_rocprof.log"):
+    if not os.path.exists(os.path.join(SRC, name)):
+        continue
     for line in open(os.path.join(SRC, name)):
         if line.startswith('{"metric"'):
             lines[name[:-4]] = json.loads(line)

@@ -31,13 +31,16 @@ enum Mode {
   kTileRaster,      // round 6 calibration: k_raster's OWN store instructions -- raw buffer stores with the tile offset in soffset,
                     // ids through the caches (aux 0), depth and barycentrics nontemporal (aux 2), 16x4 tiles, column walk
   kTileRasterNoZ,   // the same without the depth plane (render()'s forward does not write it): 16 B/px
+  kTile32Raster,    // k_raster's store instructions on 32x2 tiles (-DMR_TILE_W=32): every run a whole number of 128-byte lines
+  kTileRasterCached,   // kTileRaster with every plane through the caches (aux 0)
   kModes
 };
 static const char *kNames[kModes] = {"tile16x4 column walk, nt (k_raster today)", "tile16x4 column walk, cached",
                                      "tile16x4 row walk, nt", "row64x1, nt, bary b96", "row64x1, nt, bary 48 x b128",
                                      "row64x1, cached, bary b96", "rows 64x4 back to back, nt", "linear planes, nt, b128",
                                      "linear planes, cached, b128", "k_raster's store mix (buffer stores, ids cached, z + bary nt)",
-                                     "k_raster's store mix without the depth plane"};
+                                     "k_raster's store mix without the depth plane",
+                                     "k_raster's store mix on 32x2 tiles", "k_raster's stores, all planes cached"};
 
 template <bool NT, class T>
 __device__ __forceinline__ void put(T *p, T v) {
@@ -65,7 +68,25 @@ __global__ __launch_bounds__(256) void k_store(int32_t *__restrict__ ids, float 
       put<NT>(&z[pix], fv);
       put<NT>((v3f *)(bary + 3 * pix), v3f{fv, fv + 1.0f, fv + 2.0f});
     }
-  } else if constexpr (MODE == kTileRaster || MODE == kTileRasterNoZ) {
+  } else if constexpr (MODE == kTile32Raster) {
+    typedef unsigned v3u __attribute__((ext_vector_type(3)));
+    constexpr int kRsrcWord3 = 0x00020000;
+    const size_t region_pix = img_px + (size_t)Y0 * W + X0;
+    const __amdgpu_buffer_rsrc_t rs_ids = __builtin_amdgcn_make_buffer_rsrc(ids + region_pix, 0, 0x7fffffff, kRsrcWord3);
+    const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc(z + region_pix, 0, 0x7fffffff, kRsrcWord3);
+    const __amdgpu_buffer_rsrc_t rs_bary = __builtin_amdgcn_make_buffer_rsrc(bary + 3 * region_pix, 0, 0x7fffffff, kRsrcWord3);
+    const int lx = lane & 31, ly = lane >> 5;
+    const unsigned lane_pix = (unsigned)(ly * W + lx);
+    for (int i = 0; i < 16; ++i) {   // 2 x 32 tiles of 32 x 2 pixels per region: wavefront w walks tiles w, w + 4, ... (a 32-pixel-wide column pair)
+      const int tile = wave + 4 * i, ty = tile >> 1, tx = tile & 1;
+      const int tile_pix = ty * 2 * W + tx * 32;
+      __builtin_amdgcn_raw_buffer_store_b32((unsigned)(tile + lane), rs_ids, lane_pix * 4u, tile_pix * 4, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fv), rs_z, lane_pix * 4u, tile_pix * 4, 2);
+      __builtin_amdgcn_raw_buffer_store_b96(v3u{__builtin_bit_cast(unsigned, fv), __builtin_bit_cast(unsigned, fv + 1.0f),
+                                                __builtin_bit_cast(unsigned, fv + 2.0f)}, rs_bary, lane_pix * 12u, tile_pix * 12, 2);
+      asm volatile("s_nop 1" ::: "memory");
+    }
+  } else if constexpr (MODE == kTileRaster || MODE == kTileRasterNoZ || MODE == kTileRasterCached) {
     typedef unsigned v3u __attribute__((ext_vector_type(3)));
     constexpr int kRsrcWord3 = 0x00020000;  // raw 32-bit buffer on gfx9-family targets (raster_forward.hip)
     const size_t region_pix = img_px + (size_t)Y0 * W + X0;
@@ -78,9 +99,10 @@ __global__ __launch_bounds__(256) void k_store(int32_t *__restrict__ ids, float 
       const int tile = wave + 4 * i, ty = tile >> 2, tx = tile & 3;
       const int tile_pix = ty * 4 * W + tx * 16;   // wave-uniform: the stores' soffset
       __builtin_amdgcn_raw_buffer_store_b32((unsigned)(tile + lane), rs_ids, lane_pix * 4u, tile_pix * 4, 0);
-      if (MODE == kTileRaster) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fv), rs_z, lane_pix * 4u, tile_pix * 4, 2);
+      constexpr int kAux = MODE == kTileRasterCached ? 0 : 2;
+      if (MODE != kTileRasterNoZ) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fv), rs_z, lane_pix * 4u, tile_pix * 4, kAux);
       __builtin_amdgcn_raw_buffer_store_b96(v3u{__builtin_bit_cast(unsigned, fv), __builtin_bit_cast(unsigned, fv + 1.0f),
-                                                __builtin_bit_cast(unsigned, fv + 2.0f)}, rs_bary, lane_pix * 12u, tile_pix * 12, 2);
+                                                __builtin_bit_cast(unsigned, fv + 2.0f)}, rs_bary, lane_pix * 12u, tile_pix * 12, kAux);
       asm volatile("s_nop 1" ::: "memory");   // (raster_forward.hip's store_b96_soffset: the wide-store hazard guard)
     }
   } else if constexpr (MODE == kRowNt || MODE == kRowCached || MODE == kRowX4Nt) {
@@ -165,5 +187,7 @@ int main(int argc, char **argv) {
   run<kLinearCached>(ids, z, bary, B, W, H);
   run<kTileRaster>(ids, z, bary, B, W, H);
   run<kTileRasterNoZ>(ids, z, bary, B, W, H);
+  run<kTile32Raster>(ids, z, bary, B, W, H);
+  run<kTileRasterCached>(ids, z, bary, B, W, H);
   return 0;
 }
