@@ -57,9 +57,8 @@ def l1_loss(image, target):
     (rasterize_triangles_ext.FusedPhongL1Loss; FusedSpecularL1Loss for the specular path, round 5).  Whether something observes d loss / d image -- image.retain_grad(),
     a hook on the image, torch.autograd.grad(loss, image) -- is decided when the BACKWARD runs (round 5; until then it
     was decided here, and a hook registered after this call never fired): the node then behaves like the generic op.
-    (loss.backward(inputs=[image]) is seen too: the engine retain_grad()s what it is given.)  One hole remains: a hook
-    registered after this call on an image whose Python object is then dropped (rendered_image.py);
-    USE_FUSED_RENDER_LOSS = False for that.
+    (loss.backward(inputs=[image]) is seen too: the engine retain_grad()s what it is given.)
+    USE_FUSED_RENDER_LOSS = False takes the generic op always.
 
     TARGET: on that route the 64 x 64 blocks that are all zeros in BOTH images are not read, if the caller has
     named the target with remember_target(target): the renderer knows its own empty blocks, the target's map is made by

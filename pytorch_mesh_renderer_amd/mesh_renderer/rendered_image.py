@@ -19,13 +19,12 @@ torch.Tensor.  RECOGNISE_L1_SPELLING = False (or MR_RECOGNISE_L1=0) switches the
 False (MR_RENDERED_IMAGE=0) makes render() return plain tensors.
 
 Observing d loss / d image stays possible: FusedPhongL1Loss decides in its BACKWARD whether the image's gradient is
-looked at -- retain_grad(), a tensor hook (registered before or after the loss was built), torch.autograd.grad naming the
-image (the image is among that function's arguments, so this class sees the call), loss.backward(inputs=[image]) /
-torch.autograd.backward(loss, inputs=[image]) (the engine retain_grad()s the tensors it is given) -- and then behaves
-exactly like the generic op.  One spelling is NOT seen (tests/test_reference_spelling_gpu.py pins it): a hook registered
-AFTER the loss was built on an image whose Python object is dropped before backward() does not fire (the node holds
-the image weakly; hooks that exist when the loss is built are kept alive with it).  losses.USE_FUSED_RENDER_LOSS = False
-restores stock autograd.
+looked at -- retain_grad(), a tensor hook (registered before or after the loss was built, on an image the caller still
+holds or has dropped), torch.autograd.grad naming the image (the image is among that function's arguments, so this class
+sees the call), loss.backward(inputs=[image]) / torch.autograd.backward(loss, inputs=[image]) (the engine
+retain_grad()s the tensors it is given) -- and then behaves exactly like the generic op
+(tests/test_reference_spelling_gpu.py pins every one of them).  losses.USE_FUSED_RENDER_LOSS = False restores stock
+autograd.
 
 A pending difference is evaluated LATE, so it remembers its operands' version counters: if the image or the target was
 written in place between `image - target` and the use of the result, eager torch would have computed the difference
