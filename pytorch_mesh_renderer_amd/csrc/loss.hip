@@ -15,12 +15,6 @@
 #ifndef MR_L1_REVERSE
 #define MR_L1_REVERSE 1
 #endif
-#ifndef MR_L1_NT
-#define MR_L1_NT 2  // nontemporal loads of both streams: the step is 3-4 % faster (same-box A/B: 0 / target only / both)
-#endif
-#ifndef MR_L1_NT_STORE
-#define MR_L1_NT_STORE 1
-#endif
 #ifndef MR_L1_BLOCKS
 #define MR_L1_BLOCKS MR_L1_PARTIALS
 #endif
@@ -68,16 +62,8 @@ __global__ __launch_bounds__(kThreads) void k_l1_forward(const float4 *__restric
       const size_t ju = j + u * stride;
       const size_t jc = ju < n4 ? ju : j;   // out of range: re-read the first (adds nothing below)
       idx[u] = MR_L1_REVERSE ? n4 - 1 - jc : jc;
-#if MR_L1_NT == 1
-      x[u] = a[idx[u]];
-      y[u] = nt_load(&b[idx[u]]);
-#elif MR_L1_NT == 2
       x[u] = nt_load(&a[idx[u]]);
       y[u] = nt_load(&b[idx[u]]);
-#else
-      x[u] = a[idx[u]];
-      y[u] = b[idx[u]];
-#endif
     }
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
@@ -87,11 +73,7 @@ __global__ __launch_bounds__(kThreads) void k_l1_forward(const float4 *__restric
       if (signs) {
         const uint8_t code =
             (uint8_t)(sign_code(d0) | (sign_code(d1) << 2) | (sign_code(d2) << 4) | (sign_code(d3) << 6));
-#if MR_L1_NT_STORE
         __builtin_nontemporal_store(code, &signs[idx[u]]);
-#else
-        signs[idx[u]] = code;
-#endif
       }
     }
   }

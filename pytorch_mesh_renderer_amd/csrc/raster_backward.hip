@@ -108,9 +108,6 @@ constexpr int kThreads = 256;
 constexpr float kDegenerateCutoff = 0.9f;  // cpp:13
 constexpr int kStride = 12;                // floats per acc row (9 used): 48 B
 
-#ifndef MR_RASTER_BWD_NT
-#define MR_RASTER_BWD_NT 1
-#endif
 struct RasterGradFn {
   static constexpr int kN = 9;  // [corner j][component c] partials
   static constexpr int kStride = mr::kStride;
@@ -135,15 +132,9 @@ struct RasterGradFn {
   __device__ __forceinline__ void begin_image(int, Image &) const {}
   __device__ __forceinline__ void end_image(int, Image &) const {}
   __device__ __forceinline__ void fetch(int, int, int, size_t pix, Raw &r) const {
-#if MR_RASTER_BWD_NT
     r.t = __builtin_nontemporal_load(&ids[pix]);
     r.b = load_streamed(&bary[pix]);
     r.g = load_streamed(&dbary[pix]);
-#else
-    r.t = ids[pix];
-    r.b = bary[pix];
-    r.g = dbary[pix];
-#endif
   }
   __device__ __forceinline__ bool prepare(const Raw &r, int T, int &tri, Pixel &p) const {
     if ((unsigned)r.t >= (unsigned)T) return false;                             // foreign id
@@ -162,59 +153,8 @@ struct RasterGradFn {
   }
 };
 
-// MR_RASTER_BWD_KERNEL: 0 = column runs + LDS hash table, 1 = rows kernel, 2 = lane-accumulating (round 3).
-#ifndef MR_RASTER_BWD_KERNEL
-#define MR_RASTER_BWD_KERNEL 2
-#endif
-#if MR_RASTER_BWD_KERNEL == 1
-// The same sums through the row kernel (run_accum.h, k_accumulate_rows): acc[j * 3 + c] = sum over the
-// triangle's pixels of b_j q_c is a product of two per-pixel factors, so the lanes park b[3] and q[3]
-// and nine reduction lanes form the products -- the structure the fused shading backward uses, with
-// its 8-row strips, per-wavefront merge table and one contiguous atomic per (strip, triangle).
-struct RasterRowsFn {
-  static constexpr int kN = 9;
-  static constexpr int kStride = mr::kStride;
-  static constexpr int kRowsPerWave = MR_ROWS_PER_WAVE;
-  static constexpr int kFactors = 6, kFactorStride = 8;
-  static constexpr int kMinWavesPerSimd = 6;
-  static constexpr bool kCountBackground = false;
-  __device__ static void factor_pair(int o, int &ia, int &ib) { ia = o / 3; ib = 3 + o % 3; }
-  const F3 *__restrict__ dbary;
-  const int32_t *__restrict__ ids;
-  const F3 *__restrict__ bary;
-  const BwdRec *__restrict__ recs;
-  int T_;
-  struct Pixel { F3 b, g; };
-  struct Raw { F3 b, g; int t; };
-  using Triangle = BwdTriangle;
-  struct Image { int n_bg; };
-  __device__ __forceinline__ void begin_image(int, Image &) const {}
-  __device__ __forceinline__ void end_strip(int, int, Image &) const {}
-  __device__ __forceinline__ void fetch(int, int, int, size_t pix, Raw &r) const {
-    r.t = __builtin_nontemporal_load(&ids[pix]);
-    r.b = load_streamed(&bary[pix]);
-    r.g = load_streamed(&dbary[pix]);
-  }
-  __device__ __forceinline__ bool prepare(const Raw &r, int T, int &tri, Pixel &p) const {
-    if ((unsigned)r.t >= (unsigned)T) return false;                             // foreign id
-    if (r.t == 0 && (r.b.x + r.b.y) + r.b.z < kDegenerateCutoff) return false;  // cpp:162
-    p.b = r.b;
-    p.g = r.g;
-    tri = r.t;
-    return true;
-  }
-  __device__ __forceinline__ void load_triangle(int img, int tri, Triangle &t) const {
-    load_bwd_triangle(recs + (size_t)img * T_ + tri, t);
-  }
-  __device__ __forceinline__ void factors(const Pixel &p, const Triangle &t, float (&f)[kFactorStride], Image &) const {
-    float q[3];
-    raster_pixel_q(p.b, p.g, t, t.inv, q);
-    f[0] = p.b.x; f[1] = p.b.y; f[2] = p.b.z;
-    f[3] = q[0]; f[4] = q[1]; f[5] = q[2];
-    f[6] = 0.f; f[7] = 0.f;
-  }
-};
-#endif
+// The pixel pass is the lane-accumulating kernel (round 3); the column-run kernel with its LDS hash table stays for the
+// deterministic mode (launch_accumulate_runs_fixed) and interpolate.hip, the rows-kernel variant measured in round 3 is gone.
 
 // Round 3: the same nine sums through k_accumulate_lanes (run_accum.h) -- each lane keeps them in
 // registers down its vertical run (RasterGradFn's accumulate()), only finished runs go through LDS.
@@ -381,15 +321,8 @@ int launch_raster_backward(const float *dbary, const float *clip, const int32_t 
   }
   {
     KernelTimer timer(MR_TIMER_RASTER_BACKWARD, s);
-#if MR_RASTER_BWD_KERNEL == 2
     RasterLanesFn lanes{{(const F3 *)dbary, ids, (const F3 *)bary, recs, T}};
     rc = launch_accumulate_lanes(lanes, B, T, W, H, acc, s);
-#elif MR_RASTER_BWD_KERNEL == 1
-    RasterRowsFn rows{(const F3 *)dbary, ids, (const F3 *)bary, recs, T};
-    rc = launch_accumulate_rows(rows, B, T, W, H, acc, s);
-#else
-    rc = launch_accumulate_runs(fn, B, T, W, H, acc, s);
-#endif
   }
   if (rc != MR_OK) return rc;
   const long nbt = (long)B * T;

@@ -701,9 +701,6 @@ struct RasterShade {
   float *__restrict__ norm_partials = nullptr;       // [regions][8]: sums for up to four lights, the covered-pixel count, padding
 };
 
-#ifndef MR_EPI_LDS_LIGHTS
-#define MR_EPI_LDS_LIGHTS 1
-#endif
 #ifndef MR_RASTER_STORE_AUX
 #define MR_RASTER_STORE_AUX 2  // cache policy of the G-buffer / RGBA stores: 2 = nontemporal (written once, read by a
                                 // later kernel from HBM anyway): kernel -5 %, step -2 % against 0 (same-box A/B)
@@ -718,13 +715,6 @@ struct RasterShade {
 #define MR_BARY_STAGE 0  // round 4 (measured, OFF: WRITE_SIZE unchanged at 1.19x, kernel +3 %): the barycentric plane leaves as 16-byte-per-lane stores after a transpose through
                          // LDS (see "staged barycentric store" in k_raster) instead of one 12-byte store per lane
 #endif
-#ifndef MR_INTERLEAVE_EMPTY
-#define MR_INTERLEAVE_EMPTY 0  // measured, OFF: empty regions spread evenly over the order instead of closing it --
-                               // G-buffer kernel 0.1586 -> 0.1635 ms, fused forward 0.2366 -> 0.2421 (same box)
-#endif
-#ifndef MR_EMPTY_FAST
-#define MR_EMPTY_FAST 1        // see "empty regions" in k_raster: 0.1589 -> 0.1573 ms (same box)
-#endif
 #ifndef MR_RASTER_STORE_AUX_Z
 #define MR_RASTER_STORE_AUX_Z MR_RASTER_STORE_AUX
 #endif
@@ -736,9 +726,6 @@ struct RasterShade {
 #endif
 #ifndef MR_COARSE_TOP
 #define MR_COARSE_TOP 1   // 0: k_coarse always scans all T boxes (A/B)
-#endif
-#ifndef MR_TILE_BANDS
-#define MR_TILE_BANDS 0   // round 5, measured, OFF: see the tile loop of raster_pass
 #endif
 #ifndef MR_EPI_LDS_RECORDS
 #define MR_EPI_LDS_RECORDS 1  // round 4: the shading epilogue reads its winners' corner records per lane from LDS
@@ -834,23 +821,6 @@ __global__ __launch_bounds__(kThreads, SHADE ? (XREC ? MR_RASTER_XREC_WAVES : MR
     if (xcd * regions_per_xcd + pos >= n_regions || pos >= regions_per_xcd) return;  // padding block (whole workgroup)
     const int32_t *counts = order_count + xcd * kWeightClasses;
     int cls = 0;
-#if MR_INTERLEAVE_EMPTY
-    // Round 4: the EMPTY regions (last class: no candidate at all -- pure stores of the cleared G-buffer, a
-    // quarter of the benchmark's pixels) are spread evenly over the XCD's order instead of closing it: taken
-    // last, the launch ended in a phase that only stored while the vector units idled, after a phase that
-    // computed with the memory pipeline half empty.  Slot p of N is an empty one iff floor((p+1) E / N) >
-    // floor(p E / N); the other slots keep the heaviest-first order.
-    {
-      const int n_here = min(regions_per_xcd, n_regions - xcd * regions_per_xcd);
-      const int n_empty = counts[kWeightClasses - 1];
-      if (n_empty > 0 && n_empty < n_here) {
-        const int before = (int)((long)pos * n_empty / n_here), through = (int)((long)(pos + 1) * n_empty / n_here);
-        if (through > before) { cls = kWeightClasses - 1; pos = before; }
-        else pos -= before;
-      }
-    }
-    if (cls == 0)
-#endif
 #pragma unroll
     for (int c = 0; c < kWeightClasses - 1; ++c) {
       const int n = counts[c];   // wave-uniform scalar loads
@@ -1015,7 +985,6 @@ __global__ __launch_bounds__(kThreads, SHADE ? (XREC ? MR_RASTER_XREC_WAVES : MR
       stage_goff[i] = r * (unsigned)(W * attr_n) * 4u + (j - r * chunks_per_row) * 16u;
     }
   }
-#if MR_EPI_LDS_LIGHTS
   const float *s_lights_ptr = nullptr;
   if constexpr (SHADE) {  // (no LDS at all in the G-buffer-only instantiation: its 23040 B are exactly 18 granules)
     __shared__ float s_lights[(LightsInLds::kFloats + 31) / 32 * 32];  // 3 + 6 x 32 lights: 780 B, inside the 19th LDS granule
@@ -1023,13 +992,8 @@ __global__ __launch_bounds__(kThreads, SHADE ? (XREC ? MR_RASTER_XREC_WAVES : MR
     s_lights_ptr = s_lights;
   }
   const LightsInLds lights{s_lights_ptr, shade.lights.L, shade.lights.amb != nullptr};
-#else
-  LightsInRegisters lights;
-  if (SHADE) lights.load(shade.lights, img);
-#endif
   typedef float v3f __attribute__((ext_vector_type(3)));
   typedef unsigned v3u __attribute__((ext_vector_type(3)));
-#if MR_EMPTY_FAST
   // Empty regions (round 4): no candidate at all -- the cleared G-buffer (id 0, depth 1, barycentrics 0;
   // cpp:313-321) and, with the shading epilogue, transparent black.  The values do not depend on the lane,
   // so the lanes are laid along the region's ROWS: every store instruction covers 64 / R whole rows of the
@@ -1063,7 +1027,6 @@ __global__ __launch_bounds__(kThreads, SHADE ? (XREC ? MR_RASTER_XREC_WAVES : MR
     }
     return;
   }
-#endif
   // Every wavefront of this kernel is fully populated (256-thread workgroups, padding workgroups
   // leave as a whole), so EXEC is all ones in wave-uniform code: the coverage loop restores it
   // with a constant after its v_cmpx chain.
@@ -1112,16 +1075,7 @@ __global__ __launch_bounds__(kThreads, SHADE ? (XREC ? MR_RASTER_XREC_WAVES : MR
     // horizontally adjacent tiles back to back, so that both halves of a 128-byte line come from
     // one wavefront, was measured: no difference.)
     {
-#if MR_TILE_BANDS
-    // Round 5 (measured, OFF): wavefront w walking a BAND of the region -- tile rows w kTilesY / 4 .. -- instead of every
-    // fourth tile (with four tiles per row that is tile COLUMN w over all the region's rows), so that a wavefront's
-    // stores stay within 16 rows of the image.  Same-box A/B: at 1024-pixel rows +-0 (G-buffer kernel inside the step
-    // 0.140 -> 0.132 ms, back to back 0.157 -> 0.155, fused forward 0.188 -> 0.188); at configs[3]'s 2048-pixel rows
-    // WORSE: G-buffer kernel 0.217 -> 0.266 ms, fused forward 0.315 -> 0.392 (profiles/r05_c4_stage_times.txt).
-    for (int tile = wave * (kTiles / kWaves); tile < (wave + 1) * (kTiles / kWaves); ++tile) {
-#else
     for (int tile = wave; tile < kTiles; tile += kWaves) {
-#endif
       const int ty = tile / kTilesX, tx = tile % kTilesX;
       const int x0 = X0 + tx * kTileW, y0 = Y0 + ty * kTileH;
       if (!full && (x0 >= X1 || y0 >= Y1)) continue;  // wave-uniform

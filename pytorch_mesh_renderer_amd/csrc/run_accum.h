@@ -238,9 +238,6 @@ __global__ __launch_bounds__(kRunThreads, DET ? 1 : Fn::kMinWavesPerSimd) void k
 // prepare() rejected), kFactors, kFactorStride (multiple of 4, >= kFactors),
 //   static void factor_pair(int o, int &ia, int &ib);            // 0 <= o < kN
 //   void factors(const Pixel &, const Triangle &, float (&f)[kFactorStride], Image &) const;
-#ifndef MR_PROBE_ROWS
-#define MR_PROBE_ROWS 0
-#endif
 #ifndef MR_ROWS_MERGE_SLOTS
 #define MR_ROWS_MERGE_SLOTS 16  // per-wavefront merge table of k_accumulate_rows (0: commit every segment)
 #endif
@@ -392,11 +389,6 @@ __global__ __launch_bounds__(kRowsThreads, Fn::kMinWavesPerSimd) void k_accumula
     unsigned long long heads = __ballot(head);
     const unsigned long long valids = __ballot(valid);
     __builtin_amdgcn_wave_barrier();  // LDS executes one wavefront's operations in order
-#if MR_PROBE_ROWS == 2  // timing probe: no transposed reduction, no atomics
-    heads = 0;
-#elif MR_PROBE_ROWS == 3  // timing probe: one segment per row (the first head only)
-    heads &= -heads;
-#endif
     // ONE pass over the row's pixels in groups of eight (four 8-byte reads per factor): a group
     // without a head is eight FMAs straight; only at a head (~3.5 per row) the running sum is
     // closed -- into the merge table -- and restarted.  No per-segment loops, no masks, no tails.
@@ -405,12 +397,8 @@ __global__ __launch_bounds__(kRowsThreads, Fn::kMinWavesPerSimd) void k_accumula
     float merged = 0.0f;      // ... and that slot's value so far, requested at the same time
     float sum = 0.0f, sum2 = 0.0f;  // two chains (even / odd pixels): a dependent FMA issues every ~6.6 clocks, an independent one every 4
     auto close_segment = [&]() {
-#if MR_PROBE_ROWS == 1  // timing probe: reduction but no global atomics
-      if (cur_t >= 0 && lane < N && sum + sum2 == 123.456f) atomicAdd(&acc_img[(size_t)cur_t * STRIDE + lane], sum);
-#else
       if (cur_slot >= 0) merge[cur_slot * kWave + lane] = merged + (sum + sum2);
       else if (cur_t >= 0) commit(cur_t, sum + sum2);  // no table, or more segments in one row than it has slots
-#endif
     };
     auto open_segment = [&](const int pixel) {
       close_segment();
@@ -478,17 +466,8 @@ __global__ __launch_bounds__(kRowsThreads, Fn::kMinWavesPerSimd) void k_accumula
 // Functor interface as for k_accumulate_runs (accumulate() adds the pixel's N products to a[]) plus
 //   static int column(int o);          // float of the triangle's acc row that sum o belongs to
 //   static constexpr int kLaneRowsPerWave;
-#ifndef MR_PROBE_LANES
-#define MR_PROBE_LANES 0
-#endif
 #ifndef MR_LANES_DENSE
 #define MR_LANES_DENSE 20   // finished lanes from which a flush walks all 64 parked rows (65: never)
-#endif
-#ifndef MR_LANES_DS_ADD
-#define MR_LANES_DS_ADD 0
-#endif
-#ifndef MR_LANES_LOAD_FIRST
-#define MR_LANES_LOAD_FIRST 1
 #endif
 #ifndef MR_LANES_MERGE_SLOTS
 #define MR_LANES_MERGE_SLOTS 16
@@ -591,8 +570,8 @@ __global__ __launch_bounds__(kWave, Fn::kMinWavesPerSimd) void k_accumulate_lane
   //   dense  (kDense or more, e.g. the end of the strip, where every lane finishes): every lane parks
   //          -- the unfinished ones zeros -- and the pass walks all 64 rows in groups of eight, opening
   //          a segment where the triangle changes (a ballot tells where), like the rows kernel.
-  // A segment's sum goes into its triangle's merge-table slot with ONE LDS operation that returns
-  // nothing (ds_add_f32, or a plain store into a slot claimed by this segment): nothing to wait for.
+  // A segment's sum goes into its triangle's merge-table slot as read + add + store (ds_add_f32 instead: measured,
+  // 0.305 -> 0.368 ms, an LDS float atomic costs ~26 LDS cycles whatever it does).
   // (Measured in round 4 and dropped: DEFERRING the pass -- a finished run only parks, the lane remembers its
   //  triangle in a register, and the pass runs when a lane needs its slot again and at the end of the strip:
   //  ~3 passes per 8-row strip instead of one per row.  Shading backward per launch 115.8 -> 112.3 M vector, 57.1
@@ -633,27 +612,20 @@ __global__ __launch_bounds__(kWave, Fn::kMinWavesPerSimd) void k_accumulate_lane
     if (fin) run_tri = -1;
     __builtin_amdgcn_wave_barrier();  // LDS executes one wavefront's operations in order
     int cur_t = -1, cur_slot = -1;    // triangle of the running segment and its merge-table slot
-    [[maybe_unused]] bool cur_fresh = false;  // the slot was claimed by this segment: it holds nothing yet
     float sum = 0.0f, sum2 = 0.0f, merged = 0.0f;
     auto close_segment = [&]() {
       if (cur_t < 0) return;
       float *slot = &s_merge[cur_slot * kMergeStride + red];
-#if MR_LANES_DS_ADD   // measured: ds_add_f32 costs more than it saves (0.305 -> 0.368 ms): ~26 LDS cycles each
-      if (cur_fresh) *slot = sum + sum2;
-      else atomicAdd(slot, sum + sum2);
-#else
       *slot = merged + (sum + sum2);
-#endif
     };
     auto open_segment = [&](const int t) {
       close_segment();
       cur_t = t;
       const unsigned hit = (unsigned)__ballot(merge_keys == t);
-      cur_fresh = hit == 0u;
       merged = 0.0f;
       if (hit) {
         cur_slot = __builtin_ctz(hit);
-        if (!MR_LANES_DS_ADD) merged = s_merge[cur_slot * kMergeStride + red];
+        merged = s_merge[cur_slot * kMergeStride + red];
       } else {
         if (merge_count == kMergeSlots) flush_merge_table();  // full: everything leaves, then slot 0
         cur_slot = merge_count;
@@ -664,9 +636,6 @@ __global__ __launch_bounds__(kWave, Fn::kMinWavesPerSimd) void k_accumulate_lane
       sum2 = 0.0f;
     };
     const float *src = s_park + red;
-#if MR_PROBE_LANES == 1  // timing probe: finished runs are parked and dropped (the park is kept alive)
-    if (src[(lane & 7) * P] == 123.456f) open_segment(0);
-#else
     if (dense) {
       const int left = __shfl_up(old, 1);
       const unsigned long long heads = __ballot(fin && (lane == 0 || left != old));
@@ -712,7 +681,6 @@ __global__ __launch_bounds__(kWave, Fn::kMinWavesPerSimd) void k_accumulate_lane
         left -= 4;
       }
     }
-#endif
     close_segment();
     __builtin_amdgcn_wave_barrier();
   };
@@ -782,27 +750,11 @@ __global__ __launch_bounds__(kWave, Fn::kMinWavesPerSimd) void k_accumulate_lane
     if (!__ballot(valid)) continue;  // nothing in this row segment (background); open runs stay open
     // the new triangles' records are requested BEFORE the finished runs are reduced: the flush does
     // not touch them, so their L2 round trip (11 loads per lane) flies under its LDS work
-#if MR_LANES_LOAD_FIRST
-#if MR_PROBE_LANES == 3  // timing probe: records are loaded once per strip (results are garbage)
-    if (valid && data_tri < 0) {
-#else
     if (valid && tri != data_tri) {
-#endif
       data_tri = tri;
       fn.load_triangle(img, tri, tri_data);
     }
-#endif
-#if MR_PROBE_LANES == 2  // timing probe: runs never finish before the strip ends
-    flush(false);
-#else
     flush(valid && run_tri >= 0 && tri != run_tri);
-#endif
-#if !MR_LANES_LOAD_FIRST
-    if (valid && tri != data_tri) {
-      data_tri = tri;
-      fn.load_triangle(img, tri, tri_data);
-    }
-#endif
     if (valid) {
       run_tri = tri;
       fn.accumulate(p, tri_data, a, image_sums);

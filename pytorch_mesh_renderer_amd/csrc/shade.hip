@@ -59,9 +59,6 @@ __global__ __launch_bounds__(kThreads) void k_corner_setup(
 #define MR_SHADE_FWD_WAVES 1
 #endif
 constexpr int kShadeRows = MR_SHADE_ROWS;
-#ifndef MR_SHADE_FWD_NT
-#define MR_SHADE_FWD_NT 1
-#endif
 
 __global__ __launch_bounds__(kThreads, MR_SHADE_FWD_WAVES) void k_shade_forward(
     const int32_t *__restrict__ ids, const F3 *__restrict__ bary,
@@ -81,13 +78,8 @@ __global__ __launch_bounds__(kThreads, MR_SHADE_FWD_WAVES) void k_shade_forward(
   for (int r = 0; r < kShadeRows; ++r) {
     const int y = min(y0 + r, H - 1);
     const size_t pix = ((size_t)img * H + y) * W + x;
-#if MR_SHADE_FWD_NT
     b[r] = load_streamed(&bary[pix]);
     t[r] = __builtin_nontemporal_load(&ids[pix]);
-#else
-    b[r] = bary[pix];
-    t[r] = ids[pix];
-#endif
   }
   Corners cr[kShadeRows];
 #pragma unroll
@@ -103,24 +95,14 @@ __global__ __launch_bounds__(kThreads, MR_SHADE_FWD_WAVES) void k_shade_forward(
     if (y >= H) break;
     const float4 rgba = live[r] ? shade_pixel(cr[r], b[r], lights, img) : make_float4(0.f, 0.f, 0.f, 0.f);
     // render.py:384-386: the image is flipped vertically (G-buffer row 0 is the bottom)
-#if MR_SHADE_FWD_NT
     typedef float v4f __attribute__((ext_vector_type(4)));
     __builtin_nontemporal_store(v4f{rgba.x, rgba.y, rgba.z, rgba.w}, (v4f *)&out[((size_t)img * H + (H - 1 - y)) * W + x]);
-#else
-    out[((size_t)img * H + (H - 1 - y)) * W + x] = rgba;
-#endif
   }
 }
 
 // SIGNS: the upstream gradient is the backward of mean|image - target| (loss.hip): it arrives as
 // the 2-bit sign codes that loss's forward packed (1 B/px, image rows) and one device scalar
 // instead of a [B,H,W,4] float image (16 B/px that k_l1_backward would first have to write).
-#ifndef MR_SHADE_NT
-#define MR_SHADE_NT 1
-#endif
-#ifndef MR_SHADE_OFFSET_FETCH
-#define MR_SHADE_OFFSET_FETCH 1  // see ShadeGradFn::fetch
-#endif
 // LG: the caller wants the light / ambient gradients (false: light_grads == nullptr; their nine
 // per-lane accumulators and ~25 instructions per row are not compiled in: the kernel -4 %).
 // L = 1..4: that many lights, kept in registers and unrolled.  L = 0 (round 3): any count up to
@@ -224,7 +206,6 @@ struct ShadeGradFn {
   }
 
   __device__ __forceinline__ void fetch(int img, int x, int y, size_t pix, Raw &r) const {
-#if MR_SHADE_OFFSET_FETCH
     // Round 4: wave-uniform image bases (scalar registers) + 32-bit per-lane offsets inside the image --
     // global_load's saddr form -- instead of a 64-bit address per plane and row (12 of the row loop's
     // ~340 vector instructions were 64-bit multiply-adds forming them).  W * H < 2^27 pixels per image:
@@ -238,19 +219,6 @@ struct ShadeGradFn {
     r.t = __builtin_nontemporal_load((const int32_t *)(ids_img + gpix * 4u));
     if (SIGNS) r.code = __builtin_nontemporal_load(signs + img_px + ipix);
     else r.g = *(const float4 *)((const char *)(drgba + img_px) + ipix * 16u);
-#else
-#if MR_SHADE_NT
-    // streamed once, never reused: nontemporal
-    r.b = load_streamed(&bary[pix]);
-    r.t = __builtin_nontemporal_load(&ids[pix]);
-#else
-    r.b = bary[pix];
-    r.t = ids[pix];
-#endif
-    const size_t image_pix = ((size_t)img * H + (H - 1 - y)) * W + x;  // un-flip
-    if (SIGNS) r.code = MR_SHADE_NT ? __builtin_nontemporal_load(&signs[image_pix]) : signs[image_pix];
-    else r.g = drgba[image_pix];
-#endif
   }
   __device__ __forceinline__ bool prepare(const Raw &r, int T, int &tri, Pixel &p) const {
     const float pre = (2.0f * r.b.x + 2.0f * r.b.y) + 2.0f * r.b.z;
@@ -431,13 +399,6 @@ struct ShadeGradFn {
 #ifndef MR_LANE_ROWS
 #define MR_LANE_ROWS 16
 #endif
-#ifndef MR_SHADE_LANES_ALL
-#define MR_SHADE_LANES_ALL 1   // the 36-sum variant too (every attribute gradient wanted; three waves per SIMD):
-                               // 0.405 -> 0.385 ms sign-coded, 0.430 -> 0.399 dense upstream (whole call, 1024^2 x 32)
-#endif
-#ifndef MR_SHADE_LANES_PIPELINED
-#define MR_SHADE_LANES_PIPELINED 0   // 1: the pipelined row loop of k_accumulate_lanes, 2: with conditional record loads
-#endif
 #ifndef MR_SHADE_LANES_FOLD
 #define MR_SHADE_LANES_FOLD 1   // see ShadeLaneFn<..., FOLD>
 #endif
@@ -465,10 +426,6 @@ struct ShadeLaneFn : ShadeGradFn<L, SIGNS, LG> {
   static constexpr int kN = 9 * kGroups + (FOLD ? 0 : 9);
   static constexpr int kStride = 36;  // the rows of acc keep ShadeGradFn's layout: the gather reads it
   static constexpr int kLaneRowsPerWave = LG ? MR_LANE_ROWS_LG : MR_LANE_ROWS;
-#if MR_SHADE_LANES_PIPELINED
-  static constexpr bool kPipelinedRows = !LG;   // run_accum.h: streamed planes two rows ahead
-  static constexpr bool kPipelinedConditionalRecords = MR_SHADE_LANES_PIPELINED == 2;
-#endif
   // 36 accumulators: 137-145 VGPRs; with light gradients 6 L + 3 more per-lane sums ride along
   static constexpr int kMinWavesPerSimd = LG ? 3 : (kN > 27 ? 3 : MR_LANE_WAVES);   // LG: 134-161 VGPRs
   // the gi-th selected group
@@ -1033,7 +990,7 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
   const int groups = (dnormals ? 1 : 0) | 2 | (ddiffuse ? 4 : 0);
   // with light gradients: one or two lights (6 L + 3 more per-lane sums; three and four stay on the rows kernel)
   const bool lanes_exist = (!light_grads || (MR_SHADE_LANES_LG && L <= 2)) && !det && groups != 6 &&
-                           (groups != 7 || MR_SHADE_LANES_ALL);
+                           (groups != 7 || 1);
   const bool use_lanes = lanes_exist && g_shade_backward_kernel != 1;
   const bool opaque = (gbuffer_flags & MR_GBUFFER_NORMALISED) != 0;  // (the lane kernels only)
 #define MR_SHADE_LANES_O(NL, G, OPQ)                                                            \
@@ -1090,17 +1047,10 @@ int launch_shade_backward(const float *drgba, const uint8_t *signs, const float 
   if (fold) MR_SHADE_LANES_FOLDED(NL) else if (opaque) MR_SHADE_LANES_O(NL, G, true) else MR_SHADE_LANES_O(NL, G, false)
 #define MR_SHADE_LANES_LIGHTS(NL, G)   /* one or two lights: the variant with light gradients exists */ \
   if (light_grads) MR_SHADE_LANES_LGV(NL, G) else MR_SHADE_LANES(NL, G)
-#if MR_SHADE_LANES_ALL
 #define MR_SHADE_LANES_G(NL)                                                                    \
   if (groups == 2) MR_SHADE_LANES(NL, 2) else if (groups == 3) MR_SHADE_LANES(NL, 3) else MR_SHADE_LANES(NL, 7)
 #define MR_SHADE_LANES_GL(NL)                                                                   \
   if (groups == 2) MR_SHADE_LANES_LIGHTS(NL, 2) else if (groups == 3) MR_SHADE_LANES_LIGHTS(NL, 3) else MR_SHADE_LANES_LIGHTS(NL, 7)
-#else
-#define MR_SHADE_LANES_G(NL)                                                                    \
-  if (groups == 2) MR_SHADE_LANES(NL, 2) else MR_SHADE_LANES(NL, 3)
-#define MR_SHADE_LANES_GL(NL)                                                                   \
-  if (groups == 2) MR_SHADE_LANES_LIGHTS(NL, 2) else MR_SHADE_LANES_LIGHTS(NL, 3)
-#endif
   if (diff_general && use_lanes) {
     const bool folded = dclip == nullptr;   // (implies transforms)
 #define MR_SHADE_DIFF_LG(NL, G, F, LGV)                                                         \

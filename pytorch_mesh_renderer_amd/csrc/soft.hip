@@ -47,12 +47,6 @@ constexpr float kNormEps = 1e-12f;
 // value in all 64 lanes -- costs a vector instruction per wavefront and candidate.  The edges' unit
 // directions and inverse lengths (a sqrt and two reciprocals per edge at a quarter of the vector rate) and the
 // reciprocals of w are therefore formed once per triangle here, with the expressions the pixel kernels used.
-#ifndef MR_SOFT_LATE_CORNERS
-#define MR_SOFT_LATE_CORNERS 0   // 1: measured 0.765 -> 0.83-0.88 ms/step (scalar spills 43 -> 24, but the load's latency sits on the live path)
-#endif
-#ifndef MR_SOFT_EDGE_VECTORS
-#define MR_SOFT_EDGE_VECTORS 0   // 1: +9 wave-uniform values held in scalar registers, which the backward is out of
-#endif                           //    (109 spilled to vector lanes either way): configs[4] step 0.80 -> 0.825 ms
 struct alignas(64) SoftRec {
   float x[3], y[3], zn[3], w[3];   // NDC corners and clip w
   float minv[9];                   // rows = barycentric coefficients (a, b, c): bc_i = a x + b y + c
@@ -60,12 +54,7 @@ struct alignas(64) SoftRec {
   float valid;                     // 1 = front-facing, non-degenerate
   float nx[3], ny[3], ilen[3];     // edges 01, 12, 20: unit direction (rasterize.py:169-172) and 1 / length
   float iw[3];                     // 1 / w
-#if MR_SOFT_EDGE_VECTORS
-  float ex[3], ey[3], il2[3];      // edge vectors b - a and 1 / |b - a|^2
-  float pad[1];
-#else
   float pad[10];
-#endif
 };
 static_assert(sizeof(SoftRec) == 192, "three 64-byte scalar loads");
 
@@ -126,11 +115,6 @@ __global__ __launch_bounds__(kThreads) void k_soft_setup(
     const int a = e, b2 = (e + 1) % 3;
     const float abx = r.x[b2] - r.x[a], aby = r.y[b2] - r.y[a];
     edge_setup(abx, aby, r.nx[e], r.ny[e], r.ilen[e]);
-#if MR_SOFT_EDGE_VECTORS
-    r.ex[e] = abx;
-    r.ey[e] = aby;
-    r.il2[e] = 1.0f / (abx * abx + aby * aby);
-#endif
     r.iw[e] = 1.0f / r.w[e];
   }
   // rasterize.py:331-336: area > 0 back-facing, == 0 degenerate; a singular matrix leaves area 0
@@ -194,15 +178,9 @@ __device__ __forceinline__ bool eval_pair(const SoftRec &r, const CornerRec *__r
   if (!(px <= r.hi[0] && px >= r.lo[0] && py <= r.hi[1] && py >= r.lo[1])) return false;  // quadtree.py:18-31
 #pragma unroll
   for (int i = 0; i < 3; ++i) o.bc[i] = r.minv[3 * i] * px + r.minv[3 * i + 1] * py + r.minv[3 * i + 2];
-#if MR_SOFT_EDGE_VECTORS
-  edge_nearest(px, py, r.x[0], r.y[0], r.ex[0], r.ey[0], r.nx[0], r.ny[0], r.ilen[0], o.t[0], o.d2[0]);
-  edge_nearest(px, py, r.x[1], r.y[1], r.ex[1], r.ey[1], r.nx[1], r.ny[1], r.ilen[1], o.t[1], o.d2[1]);
-  edge_nearest(px, py, r.x[2], r.y[2], r.ex[2], r.ey[2], r.nx[2], r.ny[2], r.ilen[2], o.t[2], o.d2[2]);
-#else
   edge_nearest(px, py, r.x[0], r.y[0], r.x[1] - r.x[0], r.y[1] - r.y[0], r.nx[0], r.ny[0], r.ilen[0], o.t[0], o.d2[0]);
   edge_nearest(px, py, r.x[1], r.y[1], r.x[2] - r.x[1], r.y[2] - r.y[1], r.nx[1], r.ny[1], r.ilen[1], o.t[1], o.d2[1]);
   edge_nearest(px, py, r.x[2], r.y[2], r.x[0] - r.x[2], r.y[0] - r.y[2], r.nx[2], r.ny[2], r.ilen[2], o.t[2], o.d2[2]);
-#endif
   o.edge = 0;
   o.dist2 = o.d2[0];
   if (o.d2[1] < o.dist2) { o.edge = 1; o.dist2 = o.d2[1]; }
@@ -230,13 +208,6 @@ __device__ __forceinline__ bool eval_pair(const SoftRec &r, const CornerRec *__r
   const float zz = o.sb[0] * r.zn[0] + o.sb[1] * r.zn[1] + o.sb[2] * r.zn[2];
   o.z = 0.5f - zz / 2.0f;  // rasterize.py:368-370
   if (o.z < 0.0f || o.z > 1.0f) return false;
-#if MR_SOFT_LATE_CORNERS
-  // the corners' attributes (27 wave-uniform floats = scalar registers) are requested only now, by the
-  // wavefronts that have a pixel left after the culls: loaded with the record they were live through all of
-  // the geometry above, in a kernel that spills scalar registers to vector lanes
-  asm volatile("" ::: "memory");
-  load_corners(corner_rec, cr);
-#endif
 #pragma unroll
   for (int c = 0; c < 3; ++c) {  // rasterize.py:194-196; corner record rows: normal, position, diffuse
     o.nraw[c] = o.sb[0] * cr.c[0][c] + o.sb[1] * cr.c[1][c] + o.sb[2] * cr.c[2][c];
@@ -362,9 +333,6 @@ __global__ __launch_bounds__(kCoarseThreads) void k_soft_coarse(
   if (tid == 0) cell_count[(size_t)img * cells_per_image + cell] = n;
 }
 
-#ifndef MR_SOFT_WAVE_8X8
-#define MR_SOFT_WAVE_8X8 1
-#endif
 struct TileGeom {
   int img, x, y, cell, tile;  // tile: logical tile index over the whole batch
   bool in_image;
@@ -381,16 +349,11 @@ __device__ __forceinline__ bool tile_geometry(int W, int H, int tiles_x, int til
   const int ty = rr / tiles_x, tx = rr - ty * tiles_x;
   g.cell = (ty / kCellTiles) * ((tiles_x + kCellTiles - 1) / kCellTiles) + tx / kCellTiles;
   const int tid = (int)threadIdx.x;
-#if MR_SOFT_WAVE_8X8
   // a wavefront = an 8 x 8 quadrant of the tile, not a 16 x 4 strip: a triangle (~8 px across + the blur
   // margin at config 5) then touches ~10 % fewer wavefronts, and each of them pays the full pair math
   const int wv = tid >> 6, ln = tid & 63;
   g.x = tx * kTile + (wv & 1) * 8 + (ln & 7);
   g.y = ty * kTile + (wv >> 1) * 8 + (ln >> 3);
-#else
-  g.x = tx * kTile + (tid & (kTile - 1));
-  g.y = ty * kTile + (tid >> 4);
-#endif
   g.in_image = g.x < W && g.y < H;
   // pixel centres as the reference computes them: double arithmetic, then float32 (rasterize.py:315-317)
   g.px = (float)(2.0 * (((double)g.x + 0.5) / (double)W) - 1.0);
@@ -431,9 +394,7 @@ __global__ __launch_bounds__(kThreads) void k_soft_forward(
         const int t = __builtin_amdgcn_readfirstlane(s_list[k]);  // workgroup-uniform
         const SoftRec r = img_recs[t];
         Corners cr;
-#if !MR_SOFT_LATE_CORNERS
         load_corners(img_corners + t, cr);
-#endif
         Pair p;
         if (g.in_image && eval_pair(r, img_corners + t, cr, ls, pr, g.px, g.py, p)) {
           if (p.logit > m) {  // online softmax: rescale what has been summed so far
@@ -538,9 +499,7 @@ __global__ __launch_bounds__(kThreads, MR_SOFT_BWD_WAVES) void k_soft_backward(
         const int t = __builtin_amdgcn_readfirstlane(s_list[k]);  // workgroup-uniform
         const SoftRec r = img_recs[t];
         Corners cr;
-#if !MR_SOFT_LATE_CORNERS
         load_corners(img_corners + t, cr);
-#endif
         Pair p;
         const bool live = g.in_image && eval_pair(r, img_corners + t, cr, ls, pr, g.px, g.py, p);
         if (!__ballot(live)) continue;  // no pixel of this wavefront touches the triangle
@@ -662,16 +621,10 @@ __global__ __launch_bounds__(kThreads, MR_SOFT_BWD_WAVES) void k_soft_backward(
             const int ia = p.edge, ib = (ia == 0) ? 1 : (ia == 1 ? 2 : 0);
             const float ax2 = ia == 0 ? r.x[0] : (ia == 1 ? r.x[1] : r.x[2]);
             const float ay2 = ia == 0 ? r.y[0] : (ia == 1 ? r.y[1] : r.y[2]);
-#if MR_SOFT_EDGE_VECTORS
-            const float abx = ia == 0 ? r.ex[0] : (ia == 1 ? r.ex[1] : r.ex[2]);
-            const float aby = ia == 0 ? r.ey[0] : (ia == 1 ? r.ey[1] : r.ey[2]);
-            const float iL2 = ia == 0 ? r.il2[0] : (ia == 1 ? r.il2[1] : r.il2[2]);
-#else
             const float bx = ia == 0 ? r.x[1] : (ia == 1 ? r.x[2] : r.x[0]);
             const float by = ia == 0 ? r.y[1] : (ia == 1 ? r.y[2] : r.y[0]);
             const float abx = bx - ax2, aby = by - ay2;
             const float iL2 = 1.0f / (abx * abx + aby * aby);
-#endif
             const float tt = ia == 0 ? p.t[0] : (ia == 1 ? p.t[1] : p.t[2]);
             const float dvx = ax2 + tt * abx - g.px, dvy = ay2 + tt * aby - g.py;
             const float gxx = 2.0f * dvx * g_d2, gxy = 2.0f * dvy * g_d2;  // d/d nearest point

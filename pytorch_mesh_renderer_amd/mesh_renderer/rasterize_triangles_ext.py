@@ -333,11 +333,6 @@ def _target_empty_regions(target):
     return None
 
 
-def _hooks_of(image):
-    with torch._C.DisableTorchFunctionSubclass():
-        return image._backward_hooks
-
-
 class FusedPhongL1Loss(torch.autograd.Function):
     """mean|image - target| for an `image` that FusedPhongRenderer produced, differentiated straight
     to the renderer's inputs: the backward hands the loss's 2-bit-per-element sign codes to the
@@ -360,40 +355,36 @@ class FusedPhongL1Loss(torch.autograd.Function):
         loss, signs = _native.l1_loss_forward(image.detach(), target.detach(), want_signs=True,
                                               empty_a=empty_regions, empty_b=empty_target)
         ctx.image_shape = image.shape
-        ctx.image_ref = weakref.ref(image)   # (weak: this node must not keep 16 B/px alive for the caller)
-        ctx.image_hooks = _hooks_of(image)   # ... but hooks that exist now stay observable if the caller drops the image
         ctx.prepared_state = prepared_state
         ctx.empty_regions = empty_regions
-        # the renderer's own saved tensors (G-buffer, corner records, adjacency, ...): held here too,
-        # because the renderer's node frees its copies as soon as the image tensor is dropped
-        ctx.save_for_backward(signs, *render_saved)
+        # the image itself is SAVED (round 6; a weak reference until then): the backward looks at its retains_grad flag and
+        # its hooks, and a caller that drops its own reference before backward() -- a helper that returns only the loss --
+        # must not lose a hook it registered.  Freed with the graph after backward(), like any saved tensor.
+        # The renderer's own saved tensors (G-buffer, corner records, adjacency, ...) are held here too, because the
+        # renderer's node frees its copies as soon as the image tensor is dropped.
+        ctx.save_for_backward(signs, image, *render_saved)
         return loss
 
     @staticmethod
-    def _image_gradient_observed(ctx):
+    def _image_gradient_observed(image):
         from .rendered_image import image_gradient_requested
         if image_gradient_requested():
             return True
-        if getattr(ctx, "image_hooks", None):   # hooks registered before the loss was built (the dict is the tensor's own)
-            return True
-        image = ctx.image_ref()
-        if image is None:     # nobody holds the image any more (rendered_image.py: a hook registered late on it is lost)
-            return False
         with torch._C.DisableTorchFunctionSubclass():
             return bool(image.retains_grad or image._backward_hooks)
 
     @staticmethod
     def backward(ctx, grad):
-        signs = ctx.saved_tensors[0]
+        signs, image = ctx.saved_tensors[:2]
         upstream = grad.to(torch.float32).reshape(1)
         dtarget = None
-        if ctx.needs_input_grad[0] and FusedPhongL1Loss._image_gradient_observed(ctx):
+        if ctx.needs_input_grad[0] and FusedPhongL1Loss._image_gradient_observed(image):
             dimage = _native.l1_loss_backward(signs, ctx.image_shape, upstream)
             if ctx.needs_input_grad[1]:
                 dtarget = -dimage
             return (dimage, dtarget) + (None,) * 10
         dverts, dxf, dn, dd, _, dlp, dli, damb = FusedPhongRenderer._input_grads(
-            ctx.saved_tensors[1:], ctx.needs_input_grad[3], any(ctx.needs_input_grad[6:9]), upstream,
+            ctx.saved_tensors[2:], ctx.needs_input_grad[3], any(ctx.needs_input_grad[6:9]), upstream,
             l1_signs=signs, needs_normal_grad=ctx.needs_input_grad[4], needs_diffuse_grad=ctx.needs_input_grad[5],
             prepared_state=ctx.prepared_state, empty_regions=ctx.empty_regions)
         if ctx.needs_input_grad[1]:
@@ -533,26 +524,24 @@ class FusedSpecularL1Loss(torch.autograd.Function):
                 light_intensities, ambient, camera_position, shininess, render_saved, has_ambient, has_transforms):
         loss, signs = _native.l1_loss_forward(image.detach(), target.detach(), want_signs=True)
         ctx.image_shape = image.shape
-        ctx.image_ref = weakref.ref(image)
-        ctx.image_hooks = _hooks_of(image)
         ctx.has_ambient, ctx.has_transforms = has_ambient, has_transforms
-        ctx.save_for_backward(signs, *render_saved)
+        ctx.save_for_backward(signs, image, *render_saved)   # (the image: see FusedPhongL1Loss.forward)
         return loss
 
     @staticmethod
     def backward(ctx, grad):
-        signs = ctx.saved_tensors[0]
+        signs, image = ctx.saved_tensors[:2]
         upstream = grad.to(torch.float32).reshape(1)
         n = ctx.needs_input_grad
         dtarget = None
-        if n[0] and FusedPhongL1Loss._image_gradient_observed(ctx):
+        if n[0] and FusedPhongL1Loss._image_gradient_observed(image):
             dimage = _native.l1_loss_backward(signs, ctx.image_shape, upstream)
             if n[1]:
                 dtarget = -dimage
             return (dimage, dtarget) + (None,) * 13
         need = (n[2], n[3], n[4], n[5], n[6], False, n[7], n[8], n[9], n[10], n[11])
         dclip, dp, dn, dd, dsp, _, dlp, dli, damb, dcam, dshin = FusedSpecularPhongRenderer._input_grads(
-            ctx.saved_tensors[1:], ctx.has_ambient, ctx.has_transforms, need, upstream, l1_signs=signs)
+            ctx.saved_tensors[2:], ctx.has_ambient, ctx.has_transforms, need, upstream, l1_signs=signs)
         if n[1]:
             dtarget = -_native.l1_loss_backward(signs, ctx.image_shape, upstream)
         return (None, dtarget, dclip, dp, dn, dd, dsp, dlp, dli, damb, dcam, dshin, None, None, None)

@@ -20,7 +20,7 @@ False (MR_RENDERED_IMAGE=0) makes render() return plain tensors.
 
 Observing d loss / d image stays possible: FusedPhongL1Loss decides in its BACKWARD whether the image's gradient is
 looked at -- retain_grad(), a tensor hook (registered before or after the loss was built, on an image the caller still
-holds or has dropped), torch.autograd.grad naming the image (the image is among that function's arguments, so this class
+holds or has dropped: the loss node saves the image, so its hooks and its retains_grad flag stay visible), torch.autograd.grad naming the image (the image is among that function's arguments, so this class
 sees the call), loss.backward(inputs=[image]) / torch.autograd.backward(loss, inputs=[image]) (the engine
 retain_grad()s the tensors it is given) -- and then behaves exactly like the generic op
 (tests/test_reference_spelling_gpu.py pins every one of them).  losses.USE_FUSED_RENDER_LOSS = False restores stock

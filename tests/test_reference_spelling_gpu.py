@@ -220,8 +220,8 @@ def test_backward_naming_the_image_and_hooks_on_dropped_images(device):
     named in inputs= before it runs, and the fused node looks at image.retains_grad when its backward runs: image.grad
     is the dense gradient, the vertices get nothing, exactly like stock autograd.
     (2) a hook on an image whose Python object the caller dropped, registered before OR after the loss was built,
-    fires: the node keeps the hook dict of hooks that exist when the loss is built, and the image's own autograd node
-    keeps the tensor reachable for the weak reference that finds later ones."""
+    fires with the dense gradient: the loss node SAVES the image (round 6; until then it held a weak reference, and a
+    late hook on a dropped image was called with None)."""
     import gc
     scene = _Scene(device)
     spelled = SPELLINGS["reference"]

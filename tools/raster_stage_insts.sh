@@ -1,8 +1,8 @@
 # Instruction counts, wait cycles and written bytes of k_raster per stage-timing probe (probes build), one --pmc pass per
 # counter group (round 6: the wait / store counters DESIGN r5 named for configs[3]'s shape).
 #   gpurun --timeout 1200 -- 'make -C pytorch_mesh_renderer_amd/csrc -j8 probes >/dev/null 2>&1; bash tools/raster_stage_insts.sh [config]'
-# Probes (include/mesh_raster_debug.h): 0 whole kernel, 32 bin only, 8 bin + tile masks, 16 walk without stores,
-# 3 store-only walk, 1 / 2 see the header.  Output: gpurun_out/stage_insts_<config>/summary.txt
+# Probes (include/mesh_raster_debug.h): 0 normal | 32 no stores | 8 no depth loop | 16 no coverage and no depth loop (the empty
+# walk + stores) | 3 bin + tile masks, no walk.  Output: gpurun_out/stage_insts_<config>/summary.txt
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 CFG=${1:-c3}

@@ -1,7 +1,7 @@
 """mr_shade_backward at configs[2] (5k tris, 1024^2, B=32) by what the caller wants: which attribute gradients,
 light gradients or not, dense or sign-coded upstream, rows kernel (1) vs lane-accumulating kernel (2).
     python tools/shade_bwd_variants.py [--iters N]
-(the 36-sum lane kernel exists only in a build with EXTRA=-DMR_SHADE_LANES_ALL=1)"""
+(the 36-sum lane kernel is part of every build)"""
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
