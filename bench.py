@@ -290,6 +290,32 @@ def _chunked_ms(fn, chunks, n, lead=24):
     return out
 
 
+def _slow_leg_evidence(forward, leaf):
+    """Forward and backward of a leg timed separately by HIP events (5 steps), and the GPU's clocks / power as rocm-smi
+    reports them right after -- only gathered when a leg reads far above its recorded time."""
+    import subprocess
+    fwd, bwd = [], []
+    for _ in range(5):
+        leaf.grad = None
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        e[0].record()
+        loss = forward().mean()
+        e[1].record()
+        loss.backward()
+        e[2].record()
+        torch.cuda.synchronize()
+        fwd.append(round(e[0].elapsed_time(e[1]), 4))
+        bwd.append(round(e[1].elapsed_time(e[2]), 4))
+    out = {"forward_ms": fwd, "backward_ms": bwd}
+    try:
+        smi = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showperflevel", "--showtemp", "--json"],
+                             capture_output=True, text=True, timeout=30).stdout
+        out["rocm_smi"] = json.loads(smi) if smi.strip().startswith("{") else smi[-600:]
+    except Exception as exc:   # (diagnostics only)
+        out["rocm_smi"] = "%s: %s" % (type(exc).__name__, exc)
+    return out
+
+
 def extra_legs(job, device, batch, width, height):
     """What used to be builder-run only, AFTER the timed region, one GPU, ~20 s in all: the same
     step through the reference's own loss spelling, with every gradient wanted, replayed as a captured HIP graph, and
@@ -385,6 +411,9 @@ def extra_legs(job, device, batch, width, height):
                              "mean() + backward to the vertices (tools/soft_bench.py's step); ms_per_step = median of the chunks",
                      "ms_per_step": round(ms5, 4), "Mpixels_per_s": round(16 * 512 * 512 / ms5 / 1e3, 1),
                      "chunks_of_20_steps": chunks5}
+    if ms5 > 1.5:   # a slow reading at last (recorded: 0.77): leave behind what tells the GPU from the host and the clocks
+        configs["c5"]["slow_reading"] = _slow_leg_evidence(lambda: soft_mesh_renderer.render(
+            v5, tri5, kd5, eyes5, zero5, up5, lp5, li5, 512, 512), v5)
     out["configs"] = configs
     torch.cuda.empty_cache()
 

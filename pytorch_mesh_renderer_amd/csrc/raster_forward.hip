@@ -821,6 +821,9 @@ __global__ __launch_bounds__(kThreads, SHADE ? (XREC ? MR_RASTER_XREC_WAVES : MR
     if (xcd * regions_per_xcd + pos >= n_regions || pos >= regions_per_xcd) return;  // padding block (whole workgroup)
     const int32_t *counts = order_count + xcd * kWeightClasses;
     int cls = 0;
+    // (Measured in round 6, no effect: half or all of the XCD's EMPTY regions -- store-only -- opening the order instead of
+    //  closing it, so that the launch's first round of workgroups does not bin in lockstep with nothing in the store
+    //  queue: whole call 0.193-0.195 / 0.194 / 0.196 ms, profiles/r06_raster_empty_first.txt.)
 #pragma unroll
     for (int c = 0; c < kWeightClasses - 1; ++c) {
       const int n = counts[c];   // wave-uniform scalar loads

@@ -20,10 +20,19 @@ for group in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH" \
   done
 done
 for v in ${PROBES:-0 32 8 16 3}; do timeout -k 10 100 python3 tools/raster_bench.py --config $CFG --iters 20 --variant $v 2>/dev/null | grep variant; done > "$OUT/times.txt"
+# ... and the kernels' own durations per probe (plain kernel trace, no counters)
+for v in ${PROBES:-0 32 8 16 3}; do
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/t/v$v" -o run -- \
+      python3 tools/raster_bench.py --config $CFG --iters 10 --variant $v > "$OUT/t.v$v.log" 2>&1 || echo "trace of variant $v failed"
+done
 STAGE_OUT=$OUT python3 - <<'PY' | tee "$OUT/summary.txt"
 import csv, glob, collections, os
 out = os.environ["STAGE_OUT"]
 print(open(out + "/times.txt").read().rstrip())
+for v in [int(x) for x in os.environ.get("PROBES", "0 32 8 16 3").split()]:
+    for f in glob.glob(out + "/t/v%d/**/*kernel_stats.csv" % v, recursive=True):
+        rows = [r for r in csv.DictReader(open(f)) if r["Name"].startswith(("void mr::", "mr::"))]
+        print("probe %2d kernels (avg us): " % v + ", ".join("%s %.1f" % (r["Name"].split("(")[0].split("::")[-1][:28], float(r["AverageNs"]) / 1e3) for r in rows[:5]))
 for v in [int(x) for x in os.environ.get("PROBES", "0 32 8 16 3").split()]:
     acc = collections.defaultdict(list)
     for f in glob.glob(out + "/g*/v%d/**/*counter_collection.csv" % v, recursive=True):
