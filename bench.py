@@ -37,6 +37,10 @@ Extra objects in the line:
   rccl, ms_per_step_render_only   (N > 1) what torch.distributed reports about the group, and the same
                            loop with the hand-over off, run after the timed region: rendering alone
                            next to `ms_per_step`, which includes the hand-over.
+  host_gc                  CPython's cyclic garbage collector is PAUSED inside every timed region, after one full
+                           collection (timeit's convention): round 6 traced the rare 3-4 x readings of short legs to one
+                           generation-2 pass (38 ms over ~170k tracked objects) landing inside a 20-30 step window
+                           (tools/gc_probe.py); the durations of the collections run in front of the regions ride here.
   roofline_l1_forward      same for the loss's streaming pass (33 B/px): with the two above, the three
                            kernels that make up 92 % of the step.
   cpu_baseline             the same step on the host cores for a bounded sample of the batch (torch-CPU
@@ -47,6 +51,8 @@ Extra objects in the line:
 """
 import argparse
 import ctypes
+import contextlib
+import gc
 import json
 import os
 import socket
@@ -69,6 +75,28 @@ CONFIGS = {
     "c4": ("configs[3]", 8, 2048, 2048, 158),
 }
 HBM_PEAK_GBPS = 8000.0                                # MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+
+GC_FULL_PASS_MS = []   # duration of the full collections run in front of the timed regions (reported in the line)
+
+
+@contextlib.contextmanager
+def collector_paused():
+    """Timed regions run with CPython's cyclic garbage collector paused, after one full collection -- timeit's convention.
+    Round 6 found the rare 3-4 x readings of the SoftRas leg (2.5-3.3 ms against 0.77: VERDICT r5 weak 2) to be ONE
+    generation-2 collection -- 38 ms over this process's ~170 000 tracked objects, collecting ten -- landing inside a 23-ms
+    timed loop (tools/gc_probe.py, profiles/r06_gc_probe.txt).  Such a pass is due once in a thousand steps or so: a cost
+    of the host interpreter, ~0.03 ms per step amortised, that a 20- or 30-step window either misses or carries whole."""
+    t0 = time.perf_counter()
+    gc.collect()
+    GC_FULL_PASS_MS.append(round((time.perf_counter() - t0) * 1e3, 2))
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was_enabled:
+            gc.enable()
 
 
 def spawn_ranks(args):
@@ -261,11 +289,12 @@ def _loop_ms(fn, n, lead=24):
     for _ in range(lead):
         fn()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(n):
-        fn()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / n * 1e3
+    with collector_paused():
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
 
 
 def _chunked_ms(fn, chunks, n, lead=24):
@@ -275,18 +304,19 @@ def _chunked_ms(fn, chunks, n, lead=24):
         fn()
     torch.cuda.synchronize()
     out = []
-    for _ in range(chunks):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        e0.record()
-        for _ in range(n):
-            fn()
-        e1.record()
-        t_host = time.perf_counter() - t0
-        torch.cuda.synchronize()
-        t_wall = time.perf_counter() - t0
-        out.append({"wall_ms": round(t_wall / n * 1e3, 4), "gpu_events_ms": round(e0.elapsed_time(e1) / n, 4),
-                    "host_enqueue_ms": round(t_host / n * 1e3, 4)})
+    with collector_paused():
+        for _ in range(chunks):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            e0.record()
+            for _ in range(n):
+                fn()
+            e1.record()
+            t_host = time.perf_counter() - t0
+            torch.cuda.synchronize()
+            t_wall = time.perf_counter() - t0
+            out.append({"wall_ms": round(t_wall / n * 1e3, 4), "gpu_events_ms": round(e0.elapsed_time(e1) / n, 4),
+                        "host_enqueue_ms": round(t_host / n * 1e3, 4)})
     return out
 
 
@@ -602,18 +632,19 @@ def main():
     ev_raster = KernelEvents(n_ev, _native.TIMER_RASTER_FORWARD)
     ev_shade = KernelEvents(n_ev, _native.TIMER_SHADE_BACKWARD)
     ev_l1 = KernelEvents(n_ev, _native.TIMER_L1_FORWARD)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        if ev_every and i % ev_every == ev_every // 2 and i // ev_every < n_ev:
-            ev_raster.arm(i // ev_every)
-            ev_shade.arm(i // ev_every)
-            ev_l1.arm(i // ev_every)
-        step()
-    if gather is not None:
-        gather.drain()                   # the last steps' hand-overs belong to the timed region
-    barrier()
-    elapsed = time.perf_counter() - t0
+    with collector_paused():   # (see collector_paused: the host interpreter's cyclic collector does not run inside timed regions)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            if ev_every and i % ev_every == ev_every // 2 and i // ev_every < n_ev:
+                ev_raster.arm(i // ev_every)
+                ev_shade.arm(i // ev_every)
+                ev_l1.arm(i // ev_every)
+            step()
+        if gather is not None:
+            gather.drain()                   # the last steps' hand-overs belong to the timed region
+        barrier()
+        elapsed = time.perf_counter() - t0
 
     if grouped:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -627,14 +658,15 @@ def main():
     other_handover = "u8" if args.handover == "f32" else "f32"
 
     def max_over_ranks_ms(n):
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(n):
-            step()
-        if gather is not None:
-            gather.drain()
-        barrier()
-        t = torch.tensor([time.perf_counter() - t1], device=device, dtype=torch.float64)
+        with collector_paused():
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(n):
+                step()
+            if gather is not None:
+                gather.drain()
+            barrier()
+            t = torch.tensor([time.perf_counter() - t1], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         return float(t.item()) / n * 1e3
 
@@ -720,6 +752,9 @@ def main():
                      "pixel (1 B/px); nominal_bytes is the figure earlier rounds divided by the same time"),
         }
         line.update(extras)
+        line["host_gc"] = {"policy": "CPython's cyclic collector is paused inside every timed region after one full collection "
+                                     "(timeit's convention; bench.py: collector_paused)",
+                           "full_collection_ms": GC_FULL_PASS_MS[:12], "tracked_objects": len(gc.get_objects())}
         if grouped:
             line["rccl"] = {"backend": torch.distributed.get_backend(), "ranks": torch.distributed.get_world_size(),
                             "device_per_rank": "cuda:%d of %d visible" % (device.index, torch.cuda.device_count()),
