@@ -394,10 +394,11 @@ def test_deterministic_mode_at_configs4_and_at_the_specular_c3_shape(device):
 
 def test_config5_soft_step_time_guard(device):
     """the SoftRas step of BASELINE configs[4] (5k triangles, 512 x 512, batch 16, forward + mean() +
-    backward to the vertices) has been recorded at 0.76-0.78 ms on eleven boxes (README) and at
-    2.5-3.3 ms on three with the same kernels, unexplained.  This guard runs bench.py's own c5 leg -- five chunks of 20
-    steps, each timed by the wall clock and by HIP events -- and fails if the MEDIAN chunk exceeds twice the recorded
-    time, printing every chunk so that the failure says whether the GPU (events) or the host (enqueue) was slow."""
+    backward to the vertices) is recorded at 0.76-0.79 ms (README); round 5's 2.5-3.3 ms readings
+    were one generation-2 pass of CPython's garbage collector inside the 30-step loop (tools/gc_probe.py).  This guard
+    runs bench.py's own c5 leg -- five chunks of 20 steps with the collector paused, each timed by the wall clock and by
+    HIP events -- and fails if the MEDIAN chunk exceeds twice the recorded time, printing every chunk so that a failure
+    says whether the GPU (events) or the host (enqueue) was slow."""
     sys.path.insert(0, ROOT)
     import bench
     j5 = synthetic.sphere_job(16, 512, 512, 50)
