@@ -533,6 +533,10 @@ def main():
                     help="N > 1: where a step's frames are assembled -- rotate (default): the global batch of step s on rank "
                          "s mod N, one all_to_all per N steps, every xGMI link used (distributed.RotatingImageGather); "
                          "root: every step's frames on rank 0, one gather per step, bound by rank 0's N - 1 inbound links")
+    ap.add_argument("--transport", choices=("rccl", "peer"), default="rccl",
+                    help="N > 1 with --gather rotate: rccl (default) = one all_to_all per block (RCCL's copy kernels); peer = every "
+                         "rank copies its frames into the root's IPC-mapped receive buffer (copy engines; rehearsed on one GPU only: "
+                         "distributed.RotatingImageGather)")
     ap.add_argument("--extras", type=int, default=1,
                     help="0: skip the legs that run after the timed region (other spellings, gradient sets, configurations)")
     ap.add_argument("--cpu-sample", type=int, default=12, help="images timed for cpu_baseline (0 = skip)")
@@ -577,7 +581,7 @@ def main():
     # all_to_all per block of N steps -- unless --gather root asks for rank 0 every step
     rotating = grouped and args.gather == "rotate"
     if rotating:
-        gather = distributed.RotatingImageGather(batch * world, depth=2, force_collective=forced)
+        gather = distributed.RotatingImageGather(batch * world, depth=2, force_collective=forced, transport=args.transport)
     else:
         gather = distributed.ImageGather(batch * world, mode="root", force_collective=forced, depth=2) if grouped else None
     step, vertices, step_state = make_step(job, device, gather, args.handover)
@@ -788,6 +792,7 @@ def main():
             if rotating:
                 line["rccl"]["gather"] = ("rotating root: the frames of step s (global batch) land on rank s mod N; one "
                                           "all_to_all per block of N steps on a side stream, depth 2")
+                line["rccl"]["transport"] = args.transport
                 # what every rank sends (and receives) per second while the timed loop runs: (N - 1) / N of a shard per step,
                 # spread over its N - 1 links
                 line["handover_GBps_out_of_each_rank"] = round(
@@ -807,6 +812,8 @@ def main():
             line["cpu_baseline"] = cpu_baseline(batch, width, height, sphere_k, args.cpu_sample)
         print(json.dumps(line), flush=True)
 
+    if gather is not None and hasattr(gather, "close"):
+        gather.close()   # (peer transport: the mapped views of the other ranks' buffers go before anybody frees a buffer)
     if grouped:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

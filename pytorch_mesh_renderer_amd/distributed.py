@@ -220,11 +220,23 @@ class RotatingImageGather:
     Latency: a step's frames reach their root up to N steps later than with a per-step gather; a rank holds the
     frames of up to N steps (plus those of the exchanges in flight)."""
 
-    def __init__(self, n_total, group=None, depth=2, force_collective=False):
+    def __init__(self, n_total, group=None, depth=2, force_collective=False, transport="rccl"):
         """force_collective: run the collective even in a 1-rank group (smoke tests of the RCCL / side-stream path on a
-        single GPU)."""
+        single GPU).
+
+        transport (round 6): "rccl" -- one all_to_all per block, RCCL's copy kernels on the compute units (the default, the
+        path that has met RCCL) -- or "peer": every rank maps every root's receive buffers once (CUDA IPC handles exchanged
+        over the group) and then COPIES its frames of the block's step j straight into root j's buffer on its side stream
+        (hipMemcpy between devices: the copy engines, no kernel of ours or RCCL's), between two tiny barriers on the same
+        stream -- "every root's slot is free" in front, "every copy has landed" behind.  Device tensors only.  Rehearsed
+        with two processes on ONE GPU (tests/test_distributed_gpu.py); never run across two GPUs: DESIGN.md section 6."""
         if depth < 1:
             raise ValueError("depth must be at least 1")
+        if transport not in ("rccl", "peer"):
+            raise ValueError("transport must be 'rccl' or 'peer'")
+        self.transport = transport
+        self._peer = {}                       # per (shape, dtype, device): [root][slot] -> that root's receive buffer as seen from here
+        self._flag = None
         self.group, self.depth = group, int(depth)
         self.force = bool(force_collective) and dist.is_initialized()
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -282,8 +294,12 @@ class RotatingImageGather:
         outs = list(out.split(self.counts, 0))                       # from rank r: its counts[r] images
         # a tail block has no frames for steps >= n_steps: their roots are sent the last step's again and ignore them
         inputs = [held[j] if j < n_steps else held[n_steps - 1] for j in range(self.world)]
-        if self.world == 1 and not self.force:
+        if self.transport == "peer" and self.world == 1:
+            out = held[0]     # one rank: its frames ARE the global batch -- nothing is copied, the tensor itself is handed back
+        elif self.world == 1 and not self.force:
             outs[0].copy_(inputs[0])
+        elif self.transport == "peer":
+            self._exchange_by_peer_copies(key, ring, held, n_steps)
         elif dist.get_backend(self.group) == "gloo":
             # (the CPU tests' backend has no all_to_all: the same exchange as non-blocking sends and receives; device
             #  tensors -- a rehearsal of N ranks on fewer GPUs, MR_DIST_BACKEND=gloo -- travel through the host)
@@ -311,6 +327,49 @@ class RotatingImageGather:
         self._pending.append((done, out, self._block * self.world, n_steps, inputs))
         self._block += 1
         self._held = []
+
+    def _group_barrier(self, device):
+        """(on the side stream) a barrier every rank's side stream passes in order: with RCCL a one-element all-reduce --
+        stream-ordered: it completes on a rank only after every rank's earlier work on that stream has --, with gloo the
+        side stream is drained on the host first."""
+        if dist.get_backend(self.group) == "gloo":
+            if device.type == "cuda":
+                torch.cuda.current_stream(device).synchronize()
+            dist.barrier(group=self.group)
+            return
+        if self._flag is None:
+            self._flag = torch.zeros(1, dtype=torch.float32, device=device)
+        dist.all_reduce(self._flag, group=self.group)
+
+    def _exchange_by_peer_copies(self, key, ring, held, n_steps):
+        device = key[2]
+        if device.type != "cuda":
+            raise ValueError("the peer transport copies between device buffers: frames must live on a GPU")
+        views = self._peer.get(key)
+        if views is None:   # once per frame shape: every rank learns how to reach every root's receive buffers
+            from torch.multiprocessing.reductions import reduce_tensor
+            mine = [reduce_tensor(buf) for buf in ring]
+            everyone = [None] * self.world
+            dist.all_gather_object(everyone, mine, group=self.group)
+            views = [ring if r == self.rank else [rebuild(*args) for rebuild, args in everyone[r]] for r in range(self.world)]
+            self._peer[key] = views
+        slot = self._block % len(ring)
+        first_row = sum(self.counts[:self.rank])
+        self._group_barrier(device)          # every root has finished with what this slot held (its consumer ran before its start())
+        for j in range(min(n_steps, self.world)):   # a tail block has no frames for the later roots: nothing is sent to them
+            views[j][slot][first_row:first_row + self.counts[self.rank]].copy_(held[j], non_blocking=True)
+        self._group_barrier(device)          # every rank's copies have landed in every root's buffer
+
+    def close(self):
+        """Drops the mapped views of the other ranks' buffers (peer transport) and lets every rank do so before any of them
+        frees its buffers.  Call after drain(); a no-op for the RCCL transport."""
+        if self._peer:
+            self._peer = {}
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+                torch.cuda.ipc_collect()     # the consumer side of the IPC handles is released NOW, not at interpreter exit
+            if dist.is_initialized() and self.world > 1:
+                dist.barrier(group=self.group)
 
     def wait(self):
         if not self._pending:
