@@ -437,24 +437,28 @@ def test_rccl_image_gather_single_rank(device):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("handover,gather", [("u8", "rotate"), ("f32", "rotate"), ("u8", "root")])
-def test_bench_rank_path_meets_rccl_on_one_gpu(device, handover, gather):
+@pytest.mark.parametrize("handover,gather,transport", [("u8", "rotate", "rccl"), ("f32", "rotate", "rccl"), ("u8", "root", "rccl"),
+                                                       ("f32", "rotate", "peer")])
+def test_bench_rank_path_meets_rccl_on_one_gpu(device, handover, gather, transport):
     """bench.py's N > 1 path -- 8-bit frames written by the forward's epilogue (or the fp32 image), the
     side-stream hand-over, gather.wait() inside the timed loop, the render-only loop after it -- under
     a 1-rank RCCL group (MR_BENCH_FORCE_GROUP=1): the line names the backend and the rank count that
     torch.distributed reports, and carries both per-step figures.  gather = rotate: bench.py's default at N > 1
-    (distributed.RotatingImageGather: the side-stream bookkeeping + all_to_all on RCCL); root: one gather per step."""
+    (distributed.RotatingImageGather: the side-stream bookkeeping + all_to_all on RCCL); root: one gather per step;
+    transport = peer (round 6): at one rank the frames are handed back without a copy."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MR_BENCH_FORCE_GROUP="1", MASTER_ADDR="127.0.0.1",
-               MASTER_PORT={"u8rotate": "29541", "f32rotate": "29542", "u8root": "29543"}[handover + gather])
+               MASTER_PORT={"u8rotaterccl": "29541", "f32rotaterccl": "29542", "u8rootrccl": "29543",
+                            "f32rotatepeer": "29544"}[handover + gather + transport])
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     proc = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "1",
-                           "--cpu-sample", "0", "--handover", handover, "--gather", gather], env=env, capture_output=True,
+                           "--cpu-sample", "0", "--handover", handover, "--gather", gather, "--transport", transport],
+                          env=env, capture_output=True,
                           text=True, timeout=600)
     assert proc.returncode == 0, proc.stderr[-2000:]
     line = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1])
@@ -468,6 +472,10 @@ def test_bench_rank_path_meets_rccl_on_one_gpu(device, handover, gather):
     px = 32 * 1024 * 1024
     assert abs(line["value_render_only"] / (px / line["ms_per_step_render_only"] / 1e3) - 1.0) < 1e-3   # (rounded figures)
     assert line["config"]["handover"] == handover and line["n_gpus"] == 1
+    if gather == "rotate":
+        assert line["rccl"]["transport"] == transport
+    if transport == "peer":   # (a 1-rank group hands the frames tensor back: the hand-over costs the step next to nothing)
+        assert line["ms_per_step_with_handover"] <= line["ms_per_step_render_only"] * 1.10 + 0.03, line
 
 
 def test_external_triangle_matches_reference_png_and_golden(device):
