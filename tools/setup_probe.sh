@@ -1,3 +1,5 @@
+# (Round 6 record: this probe needs a k_setup that honours -DMR_TIMING_SKIP_CORNER_STORE; the hook was removed with the experiment,
+#  profiles/r06_lean_prepared_forward.txt.  Kept for the method: the upper half of k_setup's durations = its launches inside timed steps.)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for flags in "EXTRA=" "EXTRA=-DMR_TIMING_SKIP_CORNER_STORE=1"; do
   make -C pytorch_mesh_renderer_amd/csrc clean >/dev/null; make -j8 -C pytorch_mesh_renderer_amd/csrc "$flags" all >/dev/null 2>&1
